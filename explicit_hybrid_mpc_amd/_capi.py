@@ -1,0 +1,145 @@
+"""
+ctypes binding of libehmpc.so (include/ehmpc.h).  Thin: argument marshalling and error
+translation only.  There is no CPU fallback -- if the library is missing, or there is no
+HIP device, the calls raise.
+"""
+
+import ctypes
+import os
+import numpy as np
+
+from . import build as _build
+
+c_double_p = ctypes.POINTER(ctypes.c_double)
+c_int32_p = ctypes.POINTER(ctypes.c_int32)
+c_uint8_p = ctypes.POINTER(ctypes.c_uint8)
+
+EHM_OK = 0
+EHM_E_INVALID = -1
+EHM_E_NO_DEVICE = -2
+EHM_E_HIP = -3
+EHM_E_CAPACITY = -4
+EHM_E_INFEASIBLE = -5
+EHM_E_NUMERIC = -6
+
+# every symbol include/ehmpc.h declares
+EXPORTED = [
+    'ehm_problem_create', 'ehm_problem_destroy', 'ehm_problem_set_eps', 'ehm_sync',
+    'ehm_stream', 'ehm_solve_ptd_batch', 'ehm_feas_ptd_batch', 'ehm_solve_pt_batch',
+    'ehm_vr_batch', 'ehm_slack_batch', 'ehm_bar_e_batch', 'ehm_min_simplex_batch',
+    'ehm_bar_d_batch', 'ehm_split_batch', 'ehm_volume_batch', 'ehm_partition_run',
+    'ehm_tree_info_get', 'ehm_tree_export', 'ehm_tree_destroy', 'ehm_stats',
+    'ehm_last_error', 'ehm_version',
+]
+
+
+class EhmError(RuntimeError):
+    def __init__(self, code, message):
+        super().__init__('libehmpc error %d: %s' % (code, message))
+        self.code = code
+
+
+class ProblemDesc(ctypes.Structure):
+    _fields_ = [('n', ctypes.c_int32), ('m', ctypes.c_int32), ('p', ctypes.c_int32),
+                ('n_u', ctypes.c_int32), ('n_delta', ctypes.c_int32),
+                ('delta_len', ctypes.c_int32),
+                ('G', c_double_p), ('w', c_double_p), ('S', c_double_p), ('c', c_double_p),
+                ('deltas', c_uint8_p),
+                ('eps_a', ctypes.c_double), ('eps_r', ctypes.c_double)]
+
+
+class RunOpts(ctypes.Structure):
+    _fields_ = [('max_nodes', ctypes.c_int64), ('max_depth', ctypes.c_int32),
+                ('action', ctypes.c_int32), ('engine', ctypes.c_int32),
+                ('reserved', ctypes.c_int32)]
+
+
+class NodeInit(ctypes.Structure):
+    _fields_ = [('delta', c_uint8_p), ('vcost', c_double_p), ('vinput', c_double_p)]
+
+
+class TreeInfo(ctypes.Structure):
+    _fields_ = [('n_nodes', ctypes.c_int64), ('n_leaves', ctypes.c_int64),
+                ('n_roots', ctypes.c_int64), ('n_closed', ctypes.c_int64),
+                ('lp_solves', ctypes.c_int64), ('ref_solves', ctypes.c_int64),
+                ('ipm_iters', ctypes.c_int64), ('sweeps', ctypes.c_int64),
+                ('max_depth', ctypes.c_int32), ('truncated', ctypes.c_int32),
+                ('volume_closed', ctypes.c_double), ('min_margin', ctypes.c_double),
+                ('device_seconds', ctypes.c_double)]
+
+
+class Counters(ctypes.Structure):
+    _fields_ = [('lp_solves', ctypes.c_int64), ('ipm_iters', ctypes.c_int64),
+                ('kernel_launches', ctypes.c_int64), ('stalled', ctypes.c_int64)]
+
+
+_lib = None
+
+
+def library_path():
+    return _build.LIB
+
+
+def load(build_if_missing=True):
+    """Load libehmpc.so (building it first if the sources are newer)."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    path = _build.LIB
+    if build_if_missing and _build.is_stale():
+        _build.build()
+    if not os.path.exists(path):
+        raise EhmError(EHM_E_NO_DEVICE,
+                       'libehmpc.so is not built (run explicit_hybrid_mpc_amd/build.py); '
+                       'there is no CPU fallback')
+    lib = ctypes.CDLL(path)
+    vp = ctypes.c_void_p
+    i64 = ctypes.c_int64
+    i32 = ctypes.c_int32
+    lib.ehm_last_error.restype = ctypes.c_char_p
+    lib.ehm_version.restype = ctypes.c_char_p
+    lib.ehm_stream.restype = vp
+    lib.ehm_stream.argtypes = [vp]
+    lib.ehm_problem_create.argtypes = [ctypes.POINTER(ProblemDesc), i32, ctypes.POINTER(vp)]
+    lib.ehm_problem_destroy.argtypes = [vp]
+    lib.ehm_problem_set_eps.argtypes = [vp, ctypes.c_double, ctypes.c_double]
+    lib.ehm_sync.argtypes = [vp]
+    lib.ehm_solve_ptd_batch.argtypes = [vp, i64, vp, vp, vp, vp, vp, vp]
+    lib.ehm_feas_ptd_batch.argtypes = [vp, i64, vp, vp, vp, vp]
+    lib.ehm_solve_pt_batch.argtypes = [vp, i64, vp, vp, vp, vp]
+    lib.ehm_vr_batch.argtypes = [vp, i64, vp, vp, vp, vp]
+    lib.ehm_slack_batch.argtypes = [vp, i64, vp, vp, vp, vp, vp, vp]
+    lib.ehm_bar_e_batch.argtypes = [vp, i64, vp, vp, vp, vp]
+    lib.ehm_min_simplex_batch.argtypes = [vp, i64, vp, vp, vp, vp]
+    lib.ehm_bar_d_batch.argtypes = [vp, i64, vp, vp, vp, vp, vp, vp, vp, vp]
+    lib.ehm_split_batch.argtypes = [i32, i64, i32, vp, vp, vp, vp]
+    lib.ehm_volume_batch.argtypes = [i32, i64, i32, vp, vp]
+    lib.ehm_partition_run.argtypes = [vp, i64, vp, ctypes.POINTER(NodeInit),
+                                      ctypes.POINTER(RunOpts), ctypes.POINTER(vp)]
+    lib.ehm_tree_info_get.argtypes = [vp, ctypes.POINTER(TreeInfo)]
+    lib.ehm_tree_export.argtypes = [vp, vp, vp, vp, vp, vp, vp, vp, vp]
+    lib.ehm_tree_destroy.argtypes = [vp]
+    lib.ehm_stats.argtypes = [vp, ctypes.POINTER(Counters)]
+    for name in EXPORTED:
+        fn = getattr(lib, name)
+        if name not in ('ehm_last_error', 'ehm_version', 'ehm_stream'):
+            fn.restype = i32
+    _lib = lib
+    return lib
+
+
+def check(rc):
+    if rc != EHM_OK:
+        raise EhmError(rc, load().ehm_last_error().decode('utf-8', 'replace'))
+
+
+def f64(a):
+    return np.ascontiguousarray(a, dtype=np.float64)
+
+
+def u8(a):
+    return np.ascontiguousarray(a, dtype=np.uint8)
+
+
+def ptr(a):
+    return None if a is None else a.ctypes.data

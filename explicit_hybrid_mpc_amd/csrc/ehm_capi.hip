@@ -1,0 +1,1076 @@
+// libehmpc.so -- kernels and C-ABI (include/ehmpc.h) of the MI355X partitioning hot path.
+// gfx950 only; no CPU fallback.
+#include <hip/hip_runtime.h>
+
+#include <algorithm>
+#include <cmath>
+#include <cstdarg>
+#include <cstdio>
+#include <cstring>
+#include <string>
+#include <vector>
+
+#include "../../include/ehmpc.h"
+
+#define EHM_MAX_P_DEV 8
+#include "ehm_kernels.h"
+
+using namespace ehm;
+
+// =========================================================================================
+// kernels: one 64-lane workgroup (= one wavefront) per LP / per node
+// =========================================================================================
+#define NODE_LDS_DOUBLES 160   // >= (p+1)*p + (p+1) + (p+1)*n_u for p <= 8, n_u <= 8 (checked)
+
+extern __shared__ __attribute__((aligned(16))) char ehm_smem[];
+
+__device__ __forceinline__ void count_solve(DevCounters* cnt, const IpmResult& r, int lane) {
+    if (lane == 0 && cnt) {
+        atomicAdd(&cnt->lp_solves, 1ULL);
+        atomicAdd(&cnt->ipm_iters, (unsigned long long)r.iters);
+        if (r.status != 0) atomicAdd(&cnt->stalled, 1ULL);
+    }
+}
+
+// a2: P_theta_delta batch / its feasibility form
+__global__ __launch_bounds__(64) void k_point_batch(DevProblem P, long long n_inst,
+                                                    const double* __restrict__ theta,
+                                                    const int32_t* __restrict__ didx,
+                                                    int feas, double* __restrict__ J,
+                                                    double* __restrict__ u0,
+                                                    int32_t* __restrict__ status,
+                                                    int32_t* __restrict__ iters,
+                                                    DevCounters* cnt) {
+    double* smem = reinterpret_cast<double*>(ehm_smem);
+    double* th = smem;                 // p doubles
+    double* lp_base = smem + 16;
+    const int lane = threadIdx.x;
+    for (long long inst = blockIdx.x; inst < n_inst; inst += gridDim.x) {
+        wave_sync();
+        if (lane < P.p) th[lane] = theta[inst * P.p + lane];
+        wave_sync();
+        const int d = didx ? didx[inst] : 0;
+        LpWork w;
+        double b[EHM_SLOTS];
+        assemble_point(w, lp_base, P, d, th, feas != 0, b, lane);
+        const IpmResult r = ipm_solve(w, b, lane);
+        count_solve(cnt, r, lane);
+        if (lane == 0) {
+            J[inst] = r.obj;
+            if (status) status[inst] = r.status;
+            if (iters) iters[inst] = r.iters;
+        }
+        if (u0 && lane < P.n_u) u0[inst * P.n_u + lane] = w.xb[lane];
+    }
+}
+
+// a5 / a7': slack of the suboptimality test, or min over the simplex, one commutation each
+__global__ __launch_bounds__(64) void k_simplex_batch(DevProblem P, long long n_inst,
+                                                      const double* __restrict__ R,
+                                                      const double* __restrict__ Vbar,
+                                                      const int32_t* __restrict__ didx,
+                                                      int slack, double* __restrict__ obj,
+                                                      double* __restrict__ alpha,
+                                                      int32_t* __restrict__ status,
+                                                      int32_t* __restrict__ iters,
+                                                      DevCounters* cnt) {
+    double* smem = reinterpret_cast<double*>(ehm_smem);
+    double* Rl = smem;                          // (p+1)*p
+    double* Vl = smem + (P.p + 1) * P.p;        // p+1
+    double* lp_base = smem + NODE_LDS_DOUBLES;
+    const int lane = threadIdx.x;
+    const int nR = (P.p + 1) * P.p;
+    for (long long inst = blockIdx.x; inst < n_inst; inst += gridDim.x) {
+        wave_sync();
+        for (int k = lane; k < nR; k += 64) Rl[k] = R[inst * nR + k];
+        if (slack && lane <= P.p) Vl[lane] = Vbar[inst * (P.p + 1) + lane];
+        wave_sync();
+        const int d = didx ? didx[inst] : 0;
+        LpWork w;
+        double b[EHM_SLOTS];
+        assemble_simplex(w, lp_base, P, d, Rl, Vl, slack != 0, b, lane);
+        const IpmResult r = ipm_solve(w, b, lane);
+        count_solve(cnt, r, lane);
+        if (lane == 0) {
+            obj[inst] = slack ? -r.obj : r.obj;     // t* = -(min -t)
+            if (status) status[inst] = r.status;
+            if (iters) iters[inst] = r.iters;
+        }
+        if (alpha) {
+            double beta = (lane < P.p) ? w.xb[P.n + lane] : 0.0;
+            const double sb = wave_sum(beta);
+            if (lane < P.p) alpha[inst * (P.p + 1) + lane + 1] = beta;
+            if (lane == 0) alpha[inst * (P.p + 1)] = 1.0 - sb;
+        }
+    }
+}
+
+// a12: split_along_longest_edge, one simplex per thread
+__global__ void k_split_batch(long long n, int p, const double* __restrict__ R,
+                              double* __restrict__ S1, double* __restrict__ S2,
+                              int32_t* __restrict__ ij) {
+#pragma clang fp contract(off)
+    const long long k = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (k >= n) return;
+    const int nR = (p + 1) * p;
+    const double* r = R + k * nR;
+    int bi, bj;
+    longest_edge(r, p, bi, bj);
+    double* s1 = S1 + k * nR;
+    double* s2 = S2 + k * nR;
+    for (int q = 0; q < nR; ++q) {
+        s1[q] = r[q];
+        s2[q] = r[q];
+    }
+    for (int c = 0; c < p; ++c) {
+        const double mid = (r[bi * p + c] + r[bj * p + c]) / 2.0;
+        s1[bi * p + c] = mid;
+        s2[bj * p + c] = mid;
+    }
+    ij[2 * k] = bi;
+    ij[2 * k + 1] = bj;
+}
+
+// a14: simplex_volume = |det([v_i - v_0])| / p!, one simplex per thread
+__device__ inline double simplex_volume_dev(const double* r, int p) {
+    double M[EHM_MAX_P_DEV * EHM_MAX_P_DEV];
+    for (int i = 0; i < p; ++i)
+        for (int c = 0; c < p; ++c) M[c * p + i] = r[(i + 1) * p + c] - r[c];   // column i
+    double det = 1.0;
+    for (int k = 0; k < p; ++k) {
+        int piv = k;
+        double best = fabs(M[k * p + k]);
+        for (int i = k + 1; i < p; ++i)
+            if (fabs(M[i * p + k]) > best) {
+                best = fabs(M[i * p + k]);
+                piv = i;
+            }
+        if (best == 0.0) return 0.0;
+        if (piv != k) {
+            for (int c = 0; c < p; ++c) {
+                const double t = M[k * p + c];
+                M[k * p + c] = M[piv * p + c];
+                M[piv * p + c] = t;
+            }
+            det = -det;
+        }
+        det *= M[k * p + k];
+        for (int i = k + 1; i < p; ++i) {
+            const double l = M[i * p + k] / M[k * p + k];
+            for (int c = k + 1; c < p; ++c) M[i * p + c] -= l * M[k * p + c];
+        }
+    }
+    double fact = 1.0;
+    for (int k = 2; k <= p; ++k) fact *= k;
+    return fabs(1.0 / fact * det);
+}
+
+__global__ void k_volume_batch(long long n, int p, const double* __restrict__ R,
+                               double* __restrict__ vol) {
+    const long long k = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (k >= n) return;
+    vol[k] = simplex_volume_dev(R + k * (p + 1) * p, p);
+}
+
+// ---- frontier sweep, level-synchronous engine ---------------------------------------------
+// K1: epsilon-suboptimality decision for every frontier node (lib/worker.py:368-375).
+__global__ __launch_bounds__(64) void k_lcss_decide(DevProblem P, DevTree T,
+                                                    const int32_t* __restrict__ frontier,
+                                                    int nf, int32_t* __restrict__ open_flag,
+                                                    DevCounters* cnt) {
+    double* smem = reinterpret_cast<double*>(ehm_smem);
+    double* node = smem;
+    double* lp_base = smem + NODE_LDS_DOUBLES;
+    const int lane = threadIdx.x;
+    const int nrec = rec_doubles(P.p, P.n_u);
+    for (int f = blockIdx.x; f < nf; f += gridDim.x) {
+        wave_sync();
+        const int id = frontier[f];
+        const double* rec = T.rec + (size_t)id * T.rec_stride;
+        for (int k = lane; k < nrec; k += 64) node[k] = rec[k];
+        wave_sync();
+        LpWork w;
+        double b[EHM_SLOTS];
+        assemble_simplex(w, lp_base, P, T.didx[id], node, node + rec_off_vcost(P.p), true, b,
+                         lane);
+        const IpmResult r = ipm_solve(w, b, lane);
+        count_solve(cnt, r, lane);
+        if (lane == 0) {
+            const double t = -r.obj;
+            const bool open = (t >= 0.0);
+            T.tstar[id] = t;
+            open_flag[f] = open ? 1 : 0;
+            if (!open) T.flags[id] |= 1;
+            const double a = fabs(t);
+            atomicMin(&cnt->min_margin_bits, (unsigned long long)__double_as_longlong(a));
+        }
+    }
+}
+
+// K2: exclusive scan of the open flags -> compacted list of open nodes (single workgroup).
+__global__ __launch_bounds__(1024) void k_scan_open(const int32_t* __restrict__ open_flag,
+                                                    const int32_t* __restrict__ frontier,
+                                                    int nf, int32_t* __restrict__ open_list,
+                                                    int32_t* __restrict__ count) {
+    __shared__ int part[1024];
+    const int tid = threadIdx.x;
+    const int chunk = (nf + 1023) / 1024;
+    const int lo = tid * chunk, hi = min(nf, lo + chunk);
+    int s = 0;
+    for (int k = lo; k < hi; ++k) s += open_flag[k];
+    part[tid] = s;
+    __syncthreads();
+    for (int off = 1; off < 1024; off <<= 1) {
+        int v = (tid >= off) ? part[tid - off] : 0;
+        __syncthreads();
+        part[tid] += v;
+        __syncthreads();
+    }
+    int base = part[tid] - s;
+    for (int k = lo; k < hi; ++k)
+        if (open_flag[k]) open_list[base++] = frontier[k];
+    if (tid == 1023) *count = part[1023];
+}
+
+// K3: split every open node along its longest edge, solve P_theta_delta at the midpoint
+// and write the two child records (lib/worker.py:403-414, 354-365).
+__global__ __launch_bounds__(64) void k_lcss_expand(DevProblem P, DevTree T,
+                                                    const int32_t* __restrict__ open_list,
+                                                    int n_open, int child_base,
+                                                    int32_t* __restrict__ next_frontier,
+                                                    DevCounters* cnt) {
+    double* smem = reinterpret_cast<double*>(ehm_smem);
+    double* node = smem;
+    double* mid = smem + NODE_LDS_DOUBLES - 8;    // p doubles
+    double* lp_base = smem + NODE_LDS_DOUBLES;
+    const int lane = threadIdx.x;
+    const int p = P.p, n_u = P.n_u;
+    const int nrec = rec_doubles(p, n_u);
+    for (int f = blockIdx.x; f < n_open; f += gridDim.x) {
+        wave_sync();
+        const int id = open_list[f];
+        const double* rec = T.rec + (size_t)id * T.rec_stride;
+        for (int k = lane; k < nrec; k += 64) node[k] = rec[k];
+        wave_sync();
+        int bi, bj;
+        longest_edge(node, p, bi, bj);
+        if (lane < p) {
+#pragma clang fp contract(off)
+            mid[lane] = (node[bi * p + lane] + node[bj * p + lane]) / 2.0;
+        }
+        wave_sync();
+        const int d = T.didx[id];
+        LpWork w;
+        double b[EHM_SLOTS];
+        assemble_point(w, lp_base, P, d, mid, false, b, lane);
+        const IpmResult r = ipm_solve(w, b, lane);
+        count_solve(cnt, r, lane);
+        if (r.status != 0 && lane == 0) atomicAdd(&cnt->errors, 1ULL);
+        const int c0 = child_base + 2 * f;
+        double* rec0 = T.rec + (size_t)c0 * T.rec_stride;
+        double* rec1 = rec0 + T.rec_stride;
+        const int ov = rec_off_vcost(p), ou = rec_off_vinput(p);
+        for (int k = lane; k < nrec; k += 64) {
+            double v0 = node[k], v1 = node[k];
+            if (k < ov) {                       // vertices
+                const int row = k / p, col = k - row * p;
+                if (row == bi) v0 = mid[col];
+                if (row == bj) v1 = mid[col];
+            } else if (k < ou) {                // vertex costs
+                const int row = k - ov;
+                if (row == bi) v0 = r.obj;
+                if (row == bj) v1 = r.obj;
+            } else {                            // vertex inputs
+                const int row = (k - ou) / n_u, col = (k - ou) - row * n_u;
+                if (row == bi) v0 = w.xb[col];
+                if (row == bj) v1 = w.xb[col];
+            }
+            rec0[k] = v0;
+            rec1[k] = v1;
+        }
+        if (lane == 0) {
+            T.left[id] = c0;
+            const int dep = T.depth[id] + 1;
+            T.left[c0] = -1;
+            T.left[c0 + 1] = -1;
+            T.didx[c0] = d;
+            T.didx[c0 + 1] = d;
+            T.depth[c0] = dep;
+            T.depth[c0 + 1] = dep;
+            T.flags[c0] = 2;
+            T.flags[c0 + 1] = 2;
+            T.tstar[c0] = 0.0;
+            T.tstar[c0 + 1] = 0.0;
+            next_frontier[2 * f] = c0;
+            next_frontier[2 * f + 1] = c0 + 1;
+        }
+    }
+}
+
+// vertex solves that seed a node's costs / inputs (lib/oracle.py:416-443): one LP per
+// (node, vertex) pair, results written straight into the node record.
+__global__ __launch_bounds__(64) void k_vertex_solve(DevProblem P, DevTree T,
+                                                     const int32_t* __restrict__ nodes,
+                                                     int n_nodes, DevCounters* cnt) {
+    double* smem = reinterpret_cast<double*>(ehm_smem);
+    double* th = smem;
+    double* lp_base = smem + 16;
+    const int lane = threadIdx.x;
+    const int p = P.p, n_u = P.n_u;
+    const int total = n_nodes * (p + 1);
+    for (int t = blockIdx.x; t < total; t += gridDim.x) {
+        wave_sync();
+        const int id = nodes[t / (p + 1)];
+        const int v = t % (p + 1);
+        double* rec = T.rec + (size_t)id * T.rec_stride;
+        if (lane < p) th[lane] = rec[v * p + lane];
+        wave_sync();
+        LpWork w;
+        double b[EHM_SLOTS];
+        assemble_point(w, lp_base, P, T.didx[id], th, false, b, lane);
+        const IpmResult r = ipm_solve(w, b, lane);
+        count_solve(cnt, r, lane);
+        if (r.status != 0 && lane == 0) atomicAdd(&cnt->errors, 1ULL);
+        if (lane == 0) rec[rec_off_vcost(p) + v] = r.obj;
+        if (lane < n_u) rec[rec_off_vinput(p) + v * n_u + lane] = w.xb[lane];
+    }
+}
+
+// =========================================================================================
+// host side
+// =========================================================================================
+static thread_local std::string g_err;
+
+static int fail(int code, const char* fmt, ...) {
+    char buf[512];
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(buf, sizeof buf, fmt, ap);
+    va_end(ap);
+    g_err = buf;
+    return code;
+}
+
+#define HIP_TRY(expr, code)                                                              \
+    do {                                                                                 \
+        hipError_t e_ = (expr);                                                          \
+        if (e_ != hipSuccess)                                                            \
+            return fail(code, "%s failed: %s (%s:%d)", #expr, hipGetErrorString(e_),     \
+                        __FILE__, __LINE__);                                             \
+    } while (0)
+
+struct DevBuf {
+    void* ptr = nullptr;
+    size_t cap = 0;
+    int ensure(size_t bytes) {
+        if (bytes <= cap) return EHM_OK;
+        if (ptr) (void)hipFree(ptr);
+        ptr = nullptr;
+        cap = 0;
+        size_t want = std::max(bytes, (size_t)4096);
+        HIP_TRY(hipMalloc(&ptr, want), EHM_E_HIP);
+        cap = want;
+        return EHM_OK;
+    }
+    void release() {
+        if (ptr) (void)hipFree(ptr);
+        ptr = nullptr;
+        cap = 0;
+    }
+    template <typename T>
+    T* as() { return reinterpret_cast<T*>(ptr); }
+};
+
+struct ehm_problem {
+    int device = 0;
+    hipStream_t stream = nullptr;
+    DevProblem dp{};
+    int delta_len = 0;
+    std::vector<uint8_t> deltas;
+    DevBuf consts;           // Gt | St | w | c
+    DevBuf in0, in1, in2, out0, out1, out2, out3;
+    DevCounters* d_cnt = nullptr;
+    long long launches = 0;
+    int num_cu = 256;
+    size_t lds_point = 0, lds_simplex = 0;
+};
+
+struct ehm_tree {
+    ehm_problem* prob = nullptr;
+    DevTree dt{};
+    long long cap = 0;
+    DevBuf rec, left, didx, depth, flags, tstar;
+    ehm_tree_info info{};
+};
+
+static int map_deltas(ehm_problem* P, int64_t n_inst, const uint8_t* delta,
+                      std::vector<int32_t>& out) {
+    out.resize((size_t)n_inst);
+    const int L = P->delta_len;
+    for (int64_t k = 0; k < n_inst; ++k) {
+        int found = -1;
+        if (!delta) {
+            found = 0;
+        } else {
+            for (int d = 0; d < P->dp.n_delta; ++d) {
+                bool eq = true;
+                for (int q = 0; q < L && eq; ++q)
+                    eq = ((delta[k * L + q] != 0) == (P->deltas[(size_t)d * L + q] != 0));
+                if (eq) {
+                    found = d;
+                    break;
+                }
+            }
+        }
+        if (found < 0)
+            return fail(EHM_E_INVALID, "instance %lld: not an admissible commutation",
+                        (long long)k);
+        out[(size_t)k] = found;
+    }
+    return EHM_OK;
+}
+
+static size_t lds_bytes_for(const DevProblem& dp, int kind, size_t prefix_doubles) {
+    return (prefix_doubles + lp_lds_doubles(lp_cols(dp, kind), lp_rows(dp, kind))) * sizeof(double);
+}
+
+static int grid_for(ehm_problem* P, long long n) {
+    long long cap = (long long)P->num_cu * 64;
+    return (int)std::max(1LL, std::min(n, cap));
+}
+
+extern "C" {
+
+const char* ehm_last_error(void) { return g_err.c_str(); }
+const char* ehm_version(void) { return "ehmpc 0.1 (gfx950)"; }
+
+int ehm_problem_create(const ehm_problem_desc* d, int device, ehm_problem** out) {
+    if (!d || !out) return fail(EHM_E_INVALID, "null argument");
+    *out = nullptr;
+    if (d->n < 1 || d->m < 1 || d->p < 1 || d->n_u < 1 || d->n_delta < 1)
+        return fail(EHM_E_INVALID, "non-positive dimension");
+    if (d->p > EHM_MAX_P || d->n + d->p + 1 > EHM_MAX_N || d->m + d->p + 3 > EHM_MAX_M)
+        return fail(EHM_E_INVALID,
+                    "unsupported size: need n+p+1 <= %d, m+p+3 <= %d, p <= %d (got n=%d m=%d p=%d)",
+                    EHM_MAX_N, EHM_MAX_M, EHM_MAX_P, d->n, d->m, d->p);
+    if (d->n_u > d->n || rec_doubles(d->p, d->n_u) > NODE_LDS_DOUBLES - 8)
+        return fail(EHM_E_INVALID, "unsupported n_u=%d", d->n_u);
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0)
+        return fail(EHM_E_NO_DEVICE, "no HIP device available (libehmpc has no CPU fallback)");
+    if (device < 0 || device >= ndev)
+        return fail(EHM_E_NO_DEVICE, "device %d out of range (%d devices)", device, ndev);
+    HIP_TRY(hipSetDevice(device), EHM_E_NO_DEVICE);
+    ehm_problem* P = new ehm_problem();
+    P->device = device;
+    hipDeviceProp_t prop;
+    if (hipGetDeviceProperties(&prop, device) == hipSuccess) P->num_cu = prop.multiProcessorCount;
+    HIP_TRY(hipStreamCreate(&P->stream), EHM_E_NO_DEVICE);
+    const int n = d->n, m = d->m, p = d->p, nd = d->n_delta;
+    // transpose to column-major per commutation
+    const size_t nG = (size_t)nd * n * m, nS = (size_t)nd * p * m, nw = (size_t)nd * m;
+    std::vector<double> host(nG + nS + nw + n);
+    double* Gt = host.data();
+    double* St = Gt + nG;
+    double* w = St + nS;
+    double* c = w + nw;
+    for (int k = 0; k < nd; ++k)
+        for (int i = 0; i < m; ++i) {
+            for (int j = 0; j < n; ++j)
+                Gt[((size_t)k * n + j) * m + i] = d->G[((size_t)k * m + i) * n + j];
+            for (int q = 0; q < p; ++q)
+                St[((size_t)k * p + q) * m + i] = d->S[((size_t)k * m + i) * p + q];
+            w[(size_t)k * m + i] = d->w[(size_t)k * m + i];
+        }
+    for (int j = 0; j < n; ++j) c[j] = d->c[j];
+    int rc = P->consts.ensure(host.size() * sizeof(double));
+    if (rc) { delete P; return rc; }
+    HIP_TRY(hipMemcpy(P->consts.ptr, host.data(), host.size() * sizeof(double),
+                      hipMemcpyHostToDevice), EHM_E_HIP);
+    P->dp.n = n; P->dp.m = m; P->dp.p = p; P->dp.n_u = d->n_u; P->dp.n_delta = nd;
+    P->dp.Gt = P->consts.as<double>();
+    P->dp.St = P->dp.Gt + nG;
+    P->dp.w = P->dp.St + nS;
+    P->dp.c = P->dp.w + nw;
+    P->dp.eps_a = d->eps_a;
+    P->dp.eps_r = d->eps_r;
+    P->delta_len = d->delta_len;
+    if (d->deltas && d->delta_len > 0)
+        P->deltas.assign(d->deltas, d->deltas + (size_t)nd * d->delta_len);
+    else
+        P->deltas.assign((size_t)nd * std::max(1, d->delta_len), 1);
+    HIP_TRY(hipMalloc((void**)&P->d_cnt, sizeof(DevCounters)), EHM_E_HIP);
+    DevCounters zero{};
+    zero.min_margin_bits = 0x7FF0000000000000ULL;   // +inf
+    HIP_TRY(hipMemcpy(P->d_cnt, &zero, sizeof zero, hipMemcpyHostToDevice), EHM_E_HIP);
+    P->lds_point = lds_bytes_for(P->dp, LP_FEAS, 16);
+    P->lds_simplex = lds_bytes_for(P->dp, LP_SLACK, NODE_LDS_DOUBLES);
+    const size_t lds_max = std::max(P->lds_point, P->lds_simplex);
+    if (lds_max > 160 * 1024) {
+        ehm_problem_destroy(P);
+        return fail(EHM_E_INVALID, "LP does not fit in LDS (%zu bytes)", lds_max);
+    }
+    const void* kernels[] = {(const void*)k_point_batch, (const void*)k_simplex_batch,
+                             (const void*)k_lcss_decide, (const void*)k_lcss_expand,
+                             (const void*)k_vertex_solve};
+    for (const void* k : kernels)
+        HIP_TRY(hipFuncSetAttribute(k, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                    (int)lds_max), EHM_E_HIP);
+    *out = P;
+    return EHM_OK;
+}
+
+int ehm_problem_destroy(ehm_problem* P) {
+    if (!P) return EHM_OK;
+    (void)hipSetDevice(P->device);
+    if (P->stream) (void)hipStreamSynchronize(P->stream);
+    P->consts.release();
+    P->in0.release(); P->in1.release(); P->in2.release();
+    P->out0.release(); P->out1.release(); P->out2.release(); P->out3.release();
+    if (P->d_cnt) (void)hipFree(P->d_cnt);
+    if (P->stream) (void)hipStreamDestroy(P->stream);
+    delete P;
+    return EHM_OK;
+}
+
+int ehm_problem_set_eps(ehm_problem* P, double eps_a, double eps_r) {
+    if (!P) return fail(EHM_E_INVALID, "null problem");
+    P->dp.eps_a = eps_a;
+    P->dp.eps_r = eps_r;
+    return EHM_OK;
+}
+
+int ehm_sync(ehm_problem* P) {
+    if (!P) return fail(EHM_E_INVALID, "null problem");
+    HIP_TRY(hipStreamSynchronize(P->stream), EHM_E_HIP);
+    return EHM_OK;
+}
+
+void* ehm_stream(ehm_problem* P) { return P ? (void*)P->stream : nullptr; }
+
+int ehm_stats(ehm_problem* P, ehm_counters* out) {
+    if (!P || !out) return fail(EHM_E_INVALID, "null argument");
+    HIP_TRY(hipSetDevice(P->device), EHM_E_HIP);
+    DevCounters c;
+    HIP_TRY(hipStreamSynchronize(P->stream), EHM_E_HIP);
+    HIP_TRY(hipMemcpy(&c, P->d_cnt, sizeof c, hipMemcpyDeviceToHost), EHM_E_HIP);
+    out->lp_solves = (int64_t)c.lp_solves;
+    out->ipm_iters = (int64_t)c.ipm_iters;
+    out->stalled = (int64_t)c.stalled;
+    out->kernel_launches = P->launches;
+    return EHM_OK;
+}
+
+// ---- batched oracles --------------------------------------------------------------------
+static int point_batch(ehm_problem* P, int64_t n_inst, const double* theta,
+                       const int32_t* didx_host, int feas, double* J, double* u0,
+                       int32_t* status, int32_t* iters) {
+    if (n_inst == 0) return EHM_OK;
+    HIP_TRY(hipSetDevice(P->device), EHM_E_HIP);
+    const int p = P->dp.p, n_u = P->dp.n_u;
+    int rc;
+    if ((rc = P->in0.ensure((size_t)n_inst * p * sizeof(double)))) return rc;
+    if ((rc = P->in1.ensure((size_t)n_inst * sizeof(int32_t)))) return rc;
+    if ((rc = P->out0.ensure((size_t)n_inst * sizeof(double)))) return rc;
+    if ((rc = P->out1.ensure((size_t)n_inst * n_u * sizeof(double)))) return rc;
+    if ((rc = P->out2.ensure((size_t)n_inst * 2 * sizeof(int32_t)))) return rc;
+    HIP_TRY(hipMemcpyAsync(P->in0.ptr, theta, (size_t)n_inst * p * sizeof(double),
+                           hipMemcpyHostToDevice, P->stream), EHM_E_HIP);
+    HIP_TRY(hipMemcpyAsync(P->in1.ptr, didx_host, (size_t)n_inst * sizeof(int32_t),
+                           hipMemcpyHostToDevice, P->stream), EHM_E_HIP);
+    int32_t* d_status = P->out2.as<int32_t>();
+    int32_t* d_iters = d_status + n_inst;
+    hipLaunchKernelGGL(k_point_batch, dim3(grid_for(P, n_inst)), dim3(64), P->lds_point,
+                       P->stream, P->dp, (long long)n_inst, P->in0.as<double>(),
+                       P->in1.as<int32_t>(), feas, P->out0.as<double>(), P->out1.as<double>(),
+                       d_status, d_iters, P->d_cnt);
+    P->launches++;
+    HIP_TRY(hipGetLastError(), EHM_E_HIP);
+    HIP_TRY(hipMemcpyAsync(J, P->out0.ptr, (size_t)n_inst * sizeof(double),
+                           hipMemcpyDeviceToHost, P->stream), EHM_E_HIP);
+    if (u0)
+        HIP_TRY(hipMemcpyAsync(u0, P->out1.ptr, (size_t)n_inst * n_u * sizeof(double),
+                               hipMemcpyDeviceToHost, P->stream), EHM_E_HIP);
+    if (status)
+        HIP_TRY(hipMemcpyAsync(status, d_status, (size_t)n_inst * sizeof(int32_t),
+                               hipMemcpyDeviceToHost, P->stream), EHM_E_HIP);
+    if (iters)
+        HIP_TRY(hipMemcpyAsync(iters, d_iters, (size_t)n_inst * sizeof(int32_t),
+                               hipMemcpyDeviceToHost, P->stream), EHM_E_HIP);
+    HIP_TRY(hipStreamSynchronize(P->stream), EHM_E_HIP);
+    return EHM_OK;
+}
+
+int ehm_solve_ptd_batch(ehm_problem* P, int64_t n_inst, const double* theta,
+                        const uint8_t* delta, double* J, double* u0, int32_t* status,
+                        int32_t* iters) {
+    if (!P || !theta || !J || n_inst < 0) return fail(EHM_E_INVALID, "bad argument");
+    std::vector<int32_t> didx;
+    int rc = map_deltas(P, n_inst, delta, didx);
+    if (rc) return rc;
+    return point_batch(P, n_inst, theta, didx.data(), 0, J, u0, status, iters);
+}
+
+// feasibility margin: the phase-one optimum is compared against a tolerance that is far
+// above the solver accuracy (1e-10 relative) and far below any constraint scale
+#define EHM_FEAS_TOL 1e-8
+
+int ehm_feas_ptd_batch(ehm_problem* P, int64_t n_inst, const double* theta,
+                       const uint8_t* delta, uint8_t* feasible, double* tau) {
+    if (!P || !theta || !feasible || n_inst < 0) return fail(EHM_E_INVALID, "bad argument");
+    std::vector<int32_t> didx;
+    int rc = map_deltas(P, n_inst, delta, didx);
+    if (rc) return rc;
+    std::vector<double> t((size_t)n_inst);
+    rc = point_batch(P, n_inst, theta, didx.data(), 1, t.data(), nullptr, nullptr, nullptr);
+    if (rc) return rc;
+    for (int64_t k = 0; k < n_inst; ++k) {
+        feasible[k] = (t[(size_t)k] <= EHM_FEAS_TOL) ? 1 : 0;
+        if (tau) tau[k] = t[(size_t)k];
+    }
+    return EHM_OK;
+}
+
+static int simplex_batch(ehm_problem* P, int64_t n_inst, const double* R, const double* Vbar,
+                         const int32_t* didx_host, int slack, double* obj, double* alpha,
+                         int32_t* status) {
+    if (n_inst == 0) return EHM_OK;
+    HIP_TRY(hipSetDevice(P->device), EHM_E_HIP);
+    const int p = P->dp.p;
+    const size_t nR = (size_t)(p + 1) * p;
+    int rc;
+    if ((rc = P->in0.ensure((size_t)n_inst * nR * sizeof(double)))) return rc;
+    if ((rc = P->in1.ensure((size_t)n_inst * sizeof(int32_t)))) return rc;
+    if ((rc = P->in2.ensure((size_t)n_inst * (p + 1) * sizeof(double)))) return rc;
+    if ((rc = P->out0.ensure((size_t)n_inst * sizeof(double)))) return rc;
+    if ((rc = P->out1.ensure((size_t)n_inst * (p + 1) * sizeof(double)))) return rc;
+    if ((rc = P->out2.ensure((size_t)n_inst * 2 * sizeof(int32_t)))) return rc;
+    HIP_TRY(hipMemcpyAsync(P->in0.ptr, R, (size_t)n_inst * nR * sizeof(double),
+                           hipMemcpyHostToDevice, P->stream), EHM_E_HIP);
+    HIP_TRY(hipMemcpyAsync(P->in1.ptr, didx_host, (size_t)n_inst * sizeof(int32_t),
+                           hipMemcpyHostToDevice, P->stream), EHM_E_HIP);
+    if (slack)
+        HIP_TRY(hipMemcpyAsync(P->in2.ptr, Vbar, (size_t)n_inst * (p + 1) * sizeof(double),
+                               hipMemcpyHostToDevice, P->stream), EHM_E_HIP);
+    int32_t* d_status = P->out2.as<int32_t>();
+    hipLaunchKernelGGL(k_simplex_batch, dim3(grid_for(P, n_inst)), dim3(64), P->lds_simplex,
+                       P->stream, P->dp, (long long)n_inst, P->in0.as<double>(),
+                       P->in2.as<double>(), P->in1.as<int32_t>(), slack, P->out0.as<double>(),
+                       alpha ? P->out1.as<double>() : (double*)nullptr, d_status,
+                       d_status + n_inst, P->d_cnt);
+    P->launches++;
+    HIP_TRY(hipGetLastError(), EHM_E_HIP);
+    HIP_TRY(hipMemcpyAsync(obj, P->out0.ptr, (size_t)n_inst * sizeof(double),
+                           hipMemcpyDeviceToHost, P->stream), EHM_E_HIP);
+    if (alpha)
+        HIP_TRY(hipMemcpyAsync(alpha, P->out1.ptr, (size_t)n_inst * (p + 1) * sizeof(double),
+                               hipMemcpyDeviceToHost, P->stream), EHM_E_HIP);
+    if (status)
+        HIP_TRY(hipMemcpyAsync(status, d_status, (size_t)n_inst * sizeof(int32_t),
+                               hipMemcpyDeviceToHost, P->stream), EHM_E_HIP);
+    HIP_TRY(hipStreamSynchronize(P->stream), EHM_E_HIP);
+    return EHM_OK;
+}
+
+int ehm_slack_batch(ehm_problem* P, int64_t n_inst, const double* R, const double* Vbar,
+                    const uint8_t* delta, double* tstar, double* alpha, int32_t* status) {
+    if (!P || !R || !Vbar || !tstar || n_inst < 0) return fail(EHM_E_INVALID, "bad argument");
+    std::vector<int32_t> didx;
+    int rc = map_deltas(P, n_inst, delta, didx);
+    if (rc) return rc;
+    return simplex_batch(P, n_inst, R, Vbar, didx.data(), 1, tstar, alpha, status);
+}
+
+int ehm_min_simplex_batch(ehm_problem* P, int64_t n_inst, const double* R,
+                          const uint8_t* delta, double* Jmin, int32_t* status) {
+    if (!P || !R || !Jmin || n_inst < 0) return fail(EHM_E_INVALID, "bad argument");
+    std::vector<int32_t> didx;
+    int rc = map_deltas(P, n_inst, delta, didx);
+    if (rc) return rc;
+    return simplex_batch(P, n_inst, R, nullptr, didx.data(), 0, Jmin, nullptr, status);
+}
+
+// ---- multi-commutation oracles (host-orchestrated over the batched kernels) ---------------
+int ehm_solve_pt_batch(ehm_problem* P, int64_t n_inst, const double* theta, double* J,
+                       double* u0, int32_t* delta_idx) {
+    (void)P; (void)n_inst; (void)theta; (void)J; (void)u0; (void)delta_idx;
+    return fail(EHM_E_INVALID, "ehm_solve_pt_batch: not implemented yet");
+}
+int ehm_vr_batch(ehm_problem* P, int64_t n_inst, const double* R, int32_t* delta_idx,
+                 double* vJ, double* vu0) {
+    (void)P; (void)n_inst; (void)R; (void)delta_idx; (void)vJ; (void)vu0;
+    return fail(EHM_E_INVALID, "ehm_vr_batch: not implemented yet");
+}
+int ehm_bar_e_batch(ehm_problem* P, int64_t n_inst, const double* R, const double* Vbar,
+                    uint8_t* closed, double* tbest) {
+    (void)P; (void)n_inst; (void)R; (void)Vbar; (void)closed; (void)tbest;
+    return fail(EHM_E_INVALID, "ehm_bar_e_batch: not implemented yet");
+}
+int ehm_bar_d_batch(ehm_problem* P, int64_t n_inst, const double* R, const double* Vbar,
+                    const uint8_t* delta_ref, int32_t* delta_idx, double* theta_star,
+                    double* vJ, double* vu0, uint8_t* var_small) {
+    (void)P; (void)n_inst; (void)R; (void)Vbar; (void)delta_ref; (void)delta_idx;
+    (void)theta_star; (void)vJ; (void)vu0; (void)var_small;
+    return fail(EHM_E_INVALID, "ehm_bar_d_batch: not implemented yet");
+}
+
+// ---- geometry -------------------------------------------------------------------------------
+int ehm_split_batch(int device, int64_t n, int32_t p, const double* R, double* S1, double* S2,
+                    int32_t* ij) {
+    if (!R || !S1 || !S2 || !ij || n < 0 || p < 1 || p > EHM_MAX_P)
+        return fail(EHM_E_INVALID, "bad argument");
+    if (n == 0) return EHM_OK;
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || device >= ndev || device < 0)
+        return fail(EHM_E_NO_DEVICE, "no HIP device %d (libehmpc has no CPU fallback)", device);
+    HIP_TRY(hipSetDevice(device), EHM_E_NO_DEVICE);
+    const size_t bytes = (size_t)n * (p + 1) * p * sizeof(double);
+    double *dR = nullptr, *d1 = nullptr, *d2 = nullptr;
+    int32_t* dij = nullptr;
+    HIP_TRY(hipMalloc((void**)&dR, bytes), EHM_E_HIP);
+    HIP_TRY(hipMalloc((void**)&d1, bytes), EHM_E_HIP);
+    HIP_TRY(hipMalloc((void**)&d2, bytes), EHM_E_HIP);
+    HIP_TRY(hipMalloc((void**)&dij, (size_t)n * 2 * sizeof(int32_t)), EHM_E_HIP);
+    HIP_TRY(hipMemcpy(dR, R, bytes, hipMemcpyHostToDevice), EHM_E_HIP);
+    hipLaunchKernelGGL(k_split_batch, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, 0,
+                       (long long)n, (int)p, dR, d1, d2, dij);
+    HIP_TRY(hipGetLastError(), EHM_E_HIP);
+    HIP_TRY(hipMemcpy(S1, d1, bytes, hipMemcpyDeviceToHost), EHM_E_HIP);
+    HIP_TRY(hipMemcpy(S2, d2, bytes, hipMemcpyDeviceToHost), EHM_E_HIP);
+    HIP_TRY(hipMemcpy(ij, dij, (size_t)n * 2 * sizeof(int32_t), hipMemcpyDeviceToHost),
+            EHM_E_HIP);
+    (void)hipFree(dR); (void)hipFree(d1); (void)hipFree(d2); (void)hipFree(dij);
+    return EHM_OK;
+}
+
+int ehm_volume_batch(int device, int64_t n, int32_t p, const double* R, double* vol) {
+    if (!R || !vol || n < 0 || p < 1 || p > EHM_MAX_P) return fail(EHM_E_INVALID, "bad argument");
+    if (n == 0) return EHM_OK;
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || device >= ndev || device < 0)
+        return fail(EHM_E_NO_DEVICE, "no HIP device %d (libehmpc has no CPU fallback)", device);
+    HIP_TRY(hipSetDevice(device), EHM_E_NO_DEVICE);
+    const size_t bytes = (size_t)n * (p + 1) * p * sizeof(double);
+    double *dR = nullptr, *dv = nullptr;
+    HIP_TRY(hipMalloc((void**)&dR, bytes), EHM_E_HIP);
+    HIP_TRY(hipMalloc((void**)&dv, (size_t)n * sizeof(double)), EHM_E_HIP);
+    HIP_TRY(hipMemcpy(dR, R, bytes, hipMemcpyHostToDevice), EHM_E_HIP);
+    hipLaunchKernelGGL(k_volume_batch, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, 0,
+                       (long long)n, (int)p, dR, dv);
+    HIP_TRY(hipGetLastError(), EHM_E_HIP);
+    HIP_TRY(hipMemcpy(vol, dv, (size_t)n * sizeof(double), hipMemcpyDeviceToHost), EHM_E_HIP);
+    (void)hipFree(dR); (void)hipFree(dv);
+    return EHM_OK;
+}
+
+// ---- partition engine -------------------------------------------------------------------------
+int ehm_tree_destroy(ehm_tree* T) {
+    if (!T) return EHM_OK;
+    if (T->prob) (void)hipSetDevice(T->prob->device);
+    T->rec.release(); T->left.release(); T->didx.release(); T->depth.release();
+    T->flags.release(); T->tstar.release();
+    delete T;
+    return EHM_OK;
+}
+
+static int tree_alloc(ehm_tree* T, ehm_problem* P, long long cap) {
+    const int p = P->dp.p, n_u = P->dp.n_u;
+    const int stride = ((rec_doubles(p, n_u) + 7) / 8) * 8;
+    int rc;
+    if ((rc = T->rec.ensure((size_t)cap * stride * sizeof(double)))) return rc;
+    if ((rc = T->left.ensure((size_t)cap * sizeof(int32_t)))) return rc;
+    if ((rc = T->didx.ensure((size_t)cap * sizeof(int32_t)))) return rc;
+    if ((rc = T->depth.ensure((size_t)cap * sizeof(int32_t)))) return rc;
+    if ((rc = T->flags.ensure((size_t)cap))) return rc;
+    if ((rc = T->tstar.ensure((size_t)cap * sizeof(double)))) return rc;
+    T->prob = P;
+    T->cap = cap;
+    T->dt.rec = T->rec.as<double>();
+    T->dt.left = T->left.as<int32_t>();
+    T->dt.didx = T->didx.as<int32_t>();
+    T->dt.depth = T->depth.as<int32_t>();
+    T->dt.flags = T->flags.as<uint8_t>();
+    T->dt.tstar = T->tstar.as<double>();
+    T->dt.rec_stride = stride;
+    T->dt.p = p;
+    T->dt.n_u = n_u;
+    return EHM_OK;
+}
+
+static int read_counters(ehm_problem* P, DevCounters& c) {
+    HIP_TRY(hipMemcpyAsync(&c, P->d_cnt, sizeof c, hipMemcpyDeviceToHost, P->stream), EHM_E_HIP);
+    HIP_TRY(hipStreamSynchronize(P->stream), EHM_E_HIP);
+    return EHM_OK;
+}
+
+int ehm_partition_run(ehm_problem* P, int64_t n_roots, const double* root_vertices,
+                      const ehm_node_init* init, const ehm_run_opts* opts, ehm_tree** out) {
+    if (!P || !root_vertices || !out || n_roots < 1) return fail(EHM_E_INVALID, "bad argument");
+    *out = nullptr;
+    if (P->dp.n_delta != 1)
+        return fail(EHM_E_INVALID,
+                    "ehm_partition_run: multi-commutation problems are handled by the host "
+                    "driver on top of the batched oracles in this build");
+    HIP_TRY(hipSetDevice(P->device), EHM_E_HIP);
+    const int p = P->dp.p, n_u = P->dp.n_u;
+    long long cap = (opts && opts->max_nodes > 0) ? opts->max_nodes : (1LL << 21);
+    cap = std::max<long long>(cap, 2 * n_roots);
+    const int max_depth = (opts && opts->max_depth > 0) ? opts->max_depth : 0;
+    const int action = opts ? opts->action : 0;
+    ehm_tree* T = new ehm_tree();
+    int rc = tree_alloc(T, P, cap);
+    if (rc) { ehm_tree_destroy(T); return rc; }
+    const int stride = T->dt.rec_stride;
+    const int nR = (p + 1) * p;
+    // ---- roots -> node pool
+    {
+        std::vector<double> recs((size_t)n_roots * stride, 0.0);
+        std::vector<int32_t> left((size_t)n_roots, -1), didx((size_t)n_roots, 0),
+            depth((size_t)n_roots, 0);
+        std::vector<uint8_t> flags((size_t)n_roots, 2);
+        std::vector<double> ts((size_t)n_roots, 0.0);
+        for (int64_t k = 0; k < n_roots; ++k) {
+            double* r = recs.data() + (size_t)k * stride;
+            std::memcpy(r, root_vertices + (size_t)k * nR, nR * sizeof(double));
+            if (action == 1 && init && init->vcost && init->vinput) {
+                std::memcpy(r + rec_off_vcost(p), init->vcost + (size_t)k * (p + 1),
+                            (p + 1) * sizeof(double));
+                std::memcpy(r + rec_off_vinput(p), init->vinput + (size_t)k * (p + 1) * n_u,
+                            (size_t)(p + 1) * n_u * sizeof(double));
+            }
+        }
+        HIP_TRY(hipMemcpyAsync(T->dt.rec, recs.data(), recs.size() * sizeof(double),
+                               hipMemcpyHostToDevice, P->stream), EHM_E_HIP);
+        HIP_TRY(hipMemcpyAsync(T->dt.left, left.data(), left.size() * 4, hipMemcpyHostToDevice,
+                               P->stream), EHM_E_HIP);
+        HIP_TRY(hipMemcpyAsync(T->dt.didx, didx.data(), didx.size() * 4, hipMemcpyHostToDevice,
+                               P->stream), EHM_E_HIP);
+        HIP_TRY(hipMemcpyAsync(T->dt.depth, depth.data(), depth.size() * 4,
+                               hipMemcpyHostToDevice, P->stream), EHM_E_HIP);
+        HIP_TRY(hipMemcpyAsync(T->dt.flags, flags.data(), flags.size(), hipMemcpyHostToDevice,
+                               P->stream), EHM_E_HIP);
+        HIP_TRY(hipMemcpyAsync(T->dt.tstar, ts.data(), ts.size() * 8, hipMemcpyHostToDevice,
+                               P->stream), EHM_E_HIP);
+        HIP_TRY(hipStreamSynchronize(P->stream), EHM_E_HIP);
+    }
+    // frontier buffers (ping-pong) + open flags + open list + count
+    DevBuf fr_a, fr_b, open_flag, open_list, d_count;
+    auto cleanup = [&]() {
+        fr_a.release(); fr_b.release(); open_flag.release(); open_list.release();
+        d_count.release();
+    };
+#define RUN_TRY(expr)                          \
+    do {                                       \
+        int rc_ = (expr);                      \
+        if (rc_) {                             \
+            cleanup();                         \
+            ehm_tree_destroy(T);               \
+            return rc_;                        \
+        }                                      \
+    } while (0)
+    long long fr_cap = std::max<long long>(n_roots, 1024);
+    RUN_TRY(fr_a.ensure((size_t)fr_cap * 4));
+    RUN_TRY(fr_b.ensure((size_t)fr_cap * 4));
+    RUN_TRY(open_flag.ensure((size_t)fr_cap * 4));
+    RUN_TRY(open_list.ensure((size_t)fr_cap * 4));
+    RUN_TRY(d_count.ensure(64));
+    {
+        std::vector<int32_t> ids((size_t)n_roots);
+        for (int64_t k = 0; k < n_roots; ++k) ids[(size_t)k] = (int32_t)k;
+        hipError_t e = hipMemcpyAsync(fr_a.ptr, ids.data(), ids.size() * 4,
+                                      hipMemcpyHostToDevice, P->stream);
+        if (e != hipSuccess) RUN_TRY(fail(EHM_E_HIP, "frontier upload failed"));
+        (void)hipStreamSynchronize(P->stream);
+    }
+    DevCounters c0;
+    RUN_TRY(read_counters(P, c0));
+    // reset the margin tracker for this run
+    {
+        unsigned long long inf_bits = 0x7FF0000000000000ULL;
+        (void)hipMemcpyAsync(&P->d_cnt->min_margin_bits, &inf_bits, 8, hipMemcpyHostToDevice,
+                             P->stream);
+        unsigned long long zero = 0;
+        (void)hipMemcpyAsync(&P->d_cnt->errors, &zero, 8, hipMemcpyHostToDevice, P->stream);
+    }
+    hipEvent_t ev0, ev1;
+    (void)hipEventCreate(&ev0);
+    (void)hipEventCreate(&ev1);
+    (void)hipEventRecord(ev0, P->stream);
+    // ---- 'ecc' for a single-commutation problem: the only commutation is feasible at every
+    // vertex of a feasible Theta, so V_R reduces to the vertex solves (lib/worker.py:279-291)
+    long long ref_solves = 0;
+    if (action == 0) {
+        hipLaunchKernelGGL(k_vertex_solve, dim3(grid_for(P, n_roots * (p + 1))), dim3(64),
+                           P->lds_point, P->stream, P->dp, T->dt, fr_a.as<int32_t>(),
+                           (int)n_roots, P->d_cnt);
+        P->launches++;
+        ref_solves += n_roots * (2 + (p + 1));   // P_theta check + V_R MICP + vertex solves
+    }
+    long long n_nodes = n_roots;
+    long long nf = n_roots;
+    long long n_closed = 0;
+    int sweeps = 0, depth = 0;
+    int truncated = 0;
+    int32_t* cur = fr_a.as<int32_t>();
+    int32_t* nxt = fr_b.as<int32_t>();
+    bool cur_is_a = true;
+    while (nf > 0) {
+        if ((long long)open_flag.cap < nf * 4) {
+            RUN_TRY(open_flag.ensure((size_t)nf * 4 * 2));
+            RUN_TRY(open_list.ensure((size_t)nf * 4 * 2));
+        }
+        hipLaunchKernelGGL(k_lcss_decide, dim3(grid_for(P, nf)), dim3(64), P->lds_simplex,
+                           P->stream, P->dp, T->dt, cur, (int)nf, open_flag.as<int32_t>(),
+                           P->d_cnt);
+        hipLaunchKernelGGL(k_scan_open, dim3(1), dim3(1024), 0, P->stream,
+                           open_flag.as<int32_t>(), cur, (int)nf, open_list.as<int32_t>(),
+                           d_count.as<int32_t>());
+        P->launches += 2;
+        int32_t n_open = 0;
+        {
+            hipError_t e = hipMemcpyAsync(&n_open, d_count.ptr, 4, hipMemcpyDeviceToHost,
+                                          P->stream);
+            if (e == hipSuccess) e = hipStreamSynchronize(P->stream);
+            if (e != hipSuccess)
+                RUN_TRY(fail(EHM_E_HIP, "sweep %d failed: %s", sweeps, hipGetErrorString(e)));
+        }
+        ++sweeps;
+        ref_solves += nf;                 // one bar_E MICP per visited node
+        n_closed += nf - n_open;
+        if (n_open == 0) break;
+        if (max_depth > 0 && depth >= max_depth) {
+            truncated = 1;
+            break;
+        }
+        if (n_nodes + 2LL * n_open > cap) {
+            truncated = 1;
+            cleanup();
+            ehm_tree_destroy(T);
+            return fail(EHM_E_CAPACITY, "node pool exhausted at %lld nodes (max_nodes=%lld)",
+                        n_nodes, cap);
+        }
+        // next frontier buffer must hold 2*n_open ids
+        DevBuf& nb = cur_is_a ? fr_b : fr_a;
+        if ((long long)nb.cap < 2LL * n_open * 4) {
+            RUN_TRY(nb.ensure((size_t)n_open * 2 * 4 * 2));
+        }
+        nxt = nb.as<int32_t>();
+        hipLaunchKernelGGL(k_lcss_expand, dim3(grid_for(P, n_open)), dim3(64), P->lds_point,
+                           P->stream, P->dp, T->dt, open_list.as<int32_t>(), (int)n_open,
+                           (int)n_nodes, nxt, P->d_cnt);
+        P->launches++;
+        ref_solves += 2LL * n_open;       // bar_D MICP + midpoint P_theta_delta per split
+        n_nodes += 2LL * n_open;
+        nf = 2LL * n_open;
+        cur = nxt;
+        cur_is_a = !cur_is_a;
+        ++depth;
+    }
+    (void)hipEventRecord(ev1, P->stream);
+    (void)hipEventSynchronize(ev1);
+    float ms = 0.f;
+    (void)hipEventElapsedTime(&ms, ev0, ev1);
+    (void)hipEventDestroy(ev0);
+    (void)hipEventDestroy(ev1);
+    DevCounters c1;
+    RUN_TRY(read_counters(P, c1));
+    cleanup();
+    if (c1.errors != 0) {
+        ehm_tree_destroy(T);
+        return fail(EHM_E_NUMERIC, "%llu vertex/midpoint solves did not converge",
+                    (unsigned long long)c1.errors);
+    }
+    T->info.n_nodes = n_nodes;
+    T->info.n_roots = n_roots;
+    T->info.n_leaves = n_nodes - (n_nodes - n_roots) / 2;
+    T->info.n_closed = n_closed;
+    T->info.lp_solves = (int64_t)(c1.lp_solves - c0.lp_solves);
+    T->info.ipm_iters = (int64_t)(c1.ipm_iters - c0.ipm_iters);
+    T->info.ref_solves = ref_solves;
+    T->info.sweeps = sweeps;
+    T->info.max_depth = depth;
+    T->info.truncated = truncated;
+    T->info.device_seconds = ms * 1e-3;
+    {
+        double mm;
+        std::memcpy(&mm, &c1.min_margin_bits, 8);
+        T->info.min_margin = mm;
+    }
+    T->info.volume_closed = -1.0;   // filled lazily by ehm_tree_info_get
+    *out = T;
+    return EHM_OK;
+#undef RUN_TRY
+}
+
+int ehm_tree_info_get(const ehm_tree* Tc, ehm_tree_info* out) {
+    if (!Tc || !out) return fail(EHM_E_INVALID, "null argument");
+    ehm_tree* T = const_cast<ehm_tree*>(Tc);
+    if (T->info.volume_closed < 0.0) {
+        // sum of closed-leaf volumes (lib/worker.py:374-375), computed from the export
+        ehm_problem* P = T->prob;
+        HIP_TRY(hipSetDevice(P->device), EHM_E_HIP);
+        const long long n = T->info.n_nodes;
+        const int p = P->dp.p, stride = T->dt.rec_stride, nR = (p + 1) * p;
+        std::vector<double> rec((size_t)n * stride);
+        std::vector<uint8_t> flags((size_t)n);
+        HIP_TRY(hipMemcpy(rec.data(), T->dt.rec, rec.size() * 8, hipMemcpyDeviceToHost), EHM_E_HIP);
+        HIP_TRY(hipMemcpy(flags.data(), T->dt.flags, flags.size(), hipMemcpyDeviceToHost),
+                EHM_E_HIP);
+        std::vector<double> verts;
+        for (long long k = 0; k < n; ++k)
+            if (flags[(size_t)k] & 1)
+                verts.insert(verts.end(), rec.begin() + (size_t)k * stride,
+                             rec.begin() + (size_t)k * stride + nR);
+        const long long nc = (long long)(verts.size() / nR);
+        std::vector<double> vol((size_t)nc);
+        if (nc > 0) {
+            int rc = ehm_volume_batch(P->device, nc, p, verts.data(), vol.data());
+            if (rc) return rc;
+        }
+        double s = 0.0;
+        for (double v : vol) s += v;
+        T->info.volume_closed = s;
+    }
+    *out = T->info;
+    return EHM_OK;
+}
+
+int ehm_tree_export(const ehm_tree* Tc, double* vertices, int32_t* left, int32_t* right,
+                    int32_t* delta_idx, double* vcost, double* vinput, uint8_t* flags,
+                    double* tstar) {
+    if (!Tc) return fail(EHM_E_INVALID, "null tree");
+    ehm_tree* T = const_cast<ehm_tree*>(Tc);
+    ehm_problem* P = T->prob;
+    HIP_TRY(hipSetDevice(P->device), EHM_E_HIP);
+    const long long n = T->info.n_nodes;
+    const int p = P->dp.p, n_u = P->dp.n_u, stride = T->dt.rec_stride;
+    const int nR = (p + 1) * p;
+    if (vertices || vcost || vinput) {
+        std::vector<double> rec((size_t)n * stride);
+        HIP_TRY(hipMemcpy(rec.data(), T->dt.rec, rec.size() * 8, hipMemcpyDeviceToHost), EHM_E_HIP);
+        for (long long k = 0; k < n; ++k) {
+            const double* r = rec.data() + (size_t)k * stride;
+            if (vertices) std::memcpy(vertices + (size_t)k * nR, r, nR * 8);
+            if (vcost) std::memcpy(vcost + (size_t)k * (p + 1), r + rec_off_vcost(p), (p + 1) * 8);
+            if (vinput)
+                std::memcpy(vinput + (size_t)k * (p + 1) * n_u, r + rec_off_vinput(p),
+                            (size_t)(p + 1) * n_u * 8);
+        }
+    }
+    if (left || right) {
+        std::vector<int32_t> l((size_t)n);
+        HIP_TRY(hipMemcpy(l.data(), T->dt.left, (size_t)n * 4, hipMemcpyDeviceToHost), EHM_E_HIP);
+        for (long long k = 0; k < n; ++k) {
+            if (left) left[k] = l[(size_t)k];
+            if (right) right[k] = l[(size_t)k] < 0 ? -1 : l[(size_t)k] + 1;
+        }
+    }
+    if (delta_idx)
+        HIP_TRY(hipMemcpy(delta_idx, T->dt.didx, (size_t)n * 4, hipMemcpyDeviceToHost), EHM_E_HIP);
+    if (flags) HIP_TRY(hipMemcpy(flags, T->dt.flags, (size_t)n, hipMemcpyDeviceToHost), EHM_E_HIP);
+    if (tstar)
+        HIP_TRY(hipMemcpy(tstar, T->dt.tstar, (size_t)n * 8, hipMemcpyDeviceToHost), EHM_E_HIP);
+    return EHM_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,215 @@
+// Device-side problem data, LP assembly for every oracle kind, and the kernels.
+// (Included once, by ehm_capi.hip.)
+#pragma once
+
+#include "ehm_ipm.h"
+
+namespace ehm {
+
+// Problem constants, read-only, L2 resident.  Stored column-major per commutation so that
+// the LDS fill of one LP column is one coalesced stream over the rows.
+struct DevProblem {
+    int n, m, p, n_u, n_delta;
+    const double* Gt;   // [n_delta][n][m]
+    const double* St;   // [n_delta][p][m]
+    const double* w;    // [n_delta][m]
+    const double* c;    // [n]
+    double eps_a, eps_r;
+};
+
+// Node pool of the partition tree (structure of arrays of fixed-size records).
+//   rec[k] = [ vertices (p+1)*p | vertex_costs (p+1) | vertex_inputs (p+1)*n_u ]  (doubles)
+// which is the payload of the reference's NodeData (lib/tree.py:31-39).
+struct DevTree {
+    double*  rec;
+    int32_t* left;      // left child index (right = left+1), -1 for a leaf
+    int32_t* didx;      // commutation index, -1 = none yet
+    int32_t* depth;
+    uint8_t* flags;     // bit0 closed (is_epsilon_suboptimal), bit1 has commutation data
+    double*  tstar;     // slack of the last close/split decision
+    int rec_stride;     // doubles per record (multiple of 8)
+    int p, n_u;
+};
+
+struct DevCounters {
+    unsigned long long lp_solves;
+    unsigned long long ipm_iters;
+    unsigned long long stalled;
+    unsigned long long min_margin_bits;   // |t*| as ordered uint64
+    unsigned long long errors;
+};
+
+__host__ __device__ inline int rec_off_vcost(int p) { return (p + 1) * p; }
+__host__ __device__ inline int rec_off_vinput(int p) { return (p + 1) * p + (p + 1); }
+__host__ __device__ inline int rec_doubles(int p, int n_u) {
+    return (p + 1) * p + (p + 1) + (p + 1) * n_u;
+}
+
+// ---------------------------------------------------------------------------------------
+// LP assembly
+// ---------------------------------------------------------------------------------------
+enum { LP_POINT = 0, LP_FEAS = 1, LP_MIN_SIMPLEX = 2, LP_SLACK = 3 };
+
+__host__ __device__ inline int lp_cols(const DevProblem& P, int kind) {
+    switch (kind) {
+        case LP_POINT: return P.n;
+        case LP_FEAS: return P.n + 1;
+        case LP_MIN_SIMPLEX: return P.n + P.p;
+        default: return P.n + P.p + 1;
+    }
+}
+__host__ __device__ inline int lp_rows(const DevProblem& P, int kind) {
+    switch (kind) {
+        case LP_POINT: return P.m;
+        case LP_FEAS: return P.m + 1;
+        case LP_MIN_SIMPLEX: return P.m + P.p + 1;
+        default: return P.m + P.p + 3;
+    }
+}
+
+// P_theta_delta at one parameter value (lib/oracle.py:141-173), or its phase-one form
+//   min tau  s.t.  G z - tau <= h,  tau >= -1      (feasible  <=>  tau* <= 0).
+// theta: p doubles readable by every lane (LDS or global).
+__device__ inline void assemble_point(LpWork& w, double* smem, const DevProblem& P, int d,
+                                      const double* theta, bool feas,
+                                      double (&b)[EHM_SLOTS], int lane) {
+    const int n = P.n, m = P.m;
+    lp_carve(w, smem, n + (feas ? 1 : 0), m + (feas ? 1 : 0));
+    lp_clear(w, lane);
+    wave_sync();
+    const double* Gt = P.Gt + (size_t)d * n * m;
+    for (int j = 0; j < n; ++j) {
+        const double* src = Gt + (size_t)j * m;
+        double* dst = w.A + (size_t)j * w.lda;
+        for (int i = lane; i < m; i += 64) dst[i] = src[i];
+    }
+    if (feas) {
+        double* dst = w.A + (size_t)n * w.lda;
+        for (int i = lane; i <= m; i += 64) dst[i] = -1.0;
+        if (lane == 0) w.c[n] = 1.0;
+    } else if (lane < n) {
+        w.c[lane] = P.c[lane];
+    }
+    const double* wd = P.w + (size_t)d * m;
+    const double* St = P.St + (size_t)d * P.p * m;
+#pragma unroll
+    for (int sl = 0; sl < EHM_SLOTS; ++sl) {
+        const int i = lane + 64 * sl;
+        double v = 0.0;
+        if (i < m) {
+            v = wd[i];
+            for (int q = 0; q < P.p; ++q) v = fma(St[(size_t)q * m + i], theta[q], v);
+        } else if (feas && i == m) {
+            v = 1.0;
+        }
+        b[sl] = v;
+    }
+    wave_sync();
+}
+
+// Problems over a simplex R (rows = vertices, in LDS), variables (z, beta[, t]) with
+// theta = R[0] + sum_q beta_q (R[q+1]-R[0]), beta >= 0, sum beta <= 1:
+//   LP_MIN_SIMPLEX : min V                       (lib/oracle.py:74-79)
+//   LP_SLACK       : max t  s.t.  sum alpha_i Vbar_i - V - eps_a >= t,
+//                                 sum alpha_i Vbar_i - (1+eps_r) V >= t   (lib/oracle.py:89-97)
+__device__ inline void assemble_simplex(LpWork& w, double* smem, const DevProblem& P, int d,
+                                        const double* R, const double* Vbar, bool slack,
+                                        double (&b)[EHM_SLOTS], int lane) {
+    const int n = P.n, m = P.m, p = P.p;
+    const int n_lp = n + p + (slack ? 1 : 0);
+    const int m_lp = m + p + 1 + (slack ? 2 : 0);
+    lp_carve(w, smem, n_lp, m_lp);
+    lp_clear(w, lane);
+    wave_sync();
+    const double* Gt = P.Gt + (size_t)d * n * m;
+    const double* St = P.St + (size_t)d * p * m;
+    for (int j = 0; j < n; ++j) {
+        const double* src = Gt + (size_t)j * m;
+        double* dst = w.A + (size_t)j * w.lda;
+        for (int i = lane; i < m; i += 64) dst[i] = src[i];
+    }
+    // beta columns on the MPC rows: -(S Dv)[i][q]
+    for (int i = lane; i < m; i += 64) {
+        double srow[EHM_MAX_P_DEV];
+        for (int r = 0; r < p; ++r) srow[r] = St[(size_t)r * m + i];
+        for (int q = 0; q < p; ++q) {
+            double acc = 0.0;
+            for (int r = 0; r < p; ++r) acc = fma(srow[r], R[(q + 1) * p + r] - R[r], acc);
+            w.A[(size_t)(n + q) * w.lda + i] = -acc;
+        }
+    }
+    // simplex rows and (for the slack problem) the two suboptimality rows
+    if (lane < p) {
+        double* col = w.A + (size_t)(n + lane) * w.lda;
+        col[m + lane] = -1.0;          // -beta_q <= 0
+        col[m + p] = 1.0;              // sum beta <= 1
+        if (slack) {
+            const double dv = Vbar[lane + 1] - Vbar[0];
+            col[m + p + 1] = -dv;
+            col[m + p + 2] = -dv;
+        }
+    }
+    if (slack) {
+        if (lane < n) {
+            const double cj = P.c[lane];
+            double* col = w.A + (size_t)lane * w.lda;
+            col[m + p + 1] = cj;
+            col[m + p + 2] = (1.0 + P.eps_r) * cj;
+        }
+        if (lane == 0) {
+            double* col = w.A + (size_t)(n + p) * w.lda;
+            col[m + p + 1] = 1.0;
+            col[m + p + 2] = 1.0;
+            w.c[n + p] = -1.0;
+        }
+    } else if (lane < n) {
+        w.c[lane] = P.c[lane];
+    }
+    const double* wd = P.w + (size_t)d * m;
+#pragma unroll
+    for (int sl = 0; sl < EHM_SLOTS; ++sl) {
+        const int i = lane + 64 * sl;
+        double v = 0.0;
+        if (i < m) {
+            v = wd[i];
+            for (int q = 0; q < p; ++q) v = fma(St[(size_t)q * m + i], R[q], v);
+        } else if (i == m + p) {
+            v = 1.0;
+        } else if (slack && i == m + p + 1) {
+            v = Vbar[0] - P.eps_a;
+        } else if (slack && i == m + p + 2) {
+            v = Vbar[0];
+        }
+        b[sl] = v;
+    }
+    wave_sync();
+}
+
+// ---------------------------------------------------------------------------------------
+// geometry (bit-exact restatement of lib/tools.py:224-257 arithmetic)
+// ---------------------------------------------------------------------------------------
+// Edge length = sqrt(fma-chain of squared differences): numpy evaluates la.norm(x) as
+// sqrt(x.dot(x)) and OpenBLAS' ddot tail loop is a fused-multiply-add chain starting from
+// 0 (oracle/csrc/geom_ref.c).  First maximal edge in itertools.combinations order wins.
+__device__ inline void longest_edge(const double* R, int p, int& bi, int& bj) {
+#pragma clang fp contract(off)
+    double best = -1.0;
+    bi = 0;
+    bj = 1;
+    for (int i = 0; i <= p; ++i)
+        for (int j = i + 1; j <= p; ++j) {
+            double s = 0.0;
+            for (int k = 0; k < p; ++k) {
+                const double df = R[i * p + k] - R[j * p + k];
+                s = __fma_rn(df, df, s);
+            }
+            const double len = __dsqrt_rn(s);
+            if (len > best) {
+                best = len;
+                bi = i;
+                bj = j;
+            }
+        }
+}
+
+}  // namespace ehm

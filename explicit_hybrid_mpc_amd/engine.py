@@ -1,0 +1,280 @@
+"""
+Batched device oracles and the partition engine: numpy-in / numpy-out wrappers over the
+C-ABI (include/ehmpc.h).  This is the layer ``oracle.Oracle`` (reference signatures) and
+``partition`` sit on.
+
+Reference counterparts: the oracle problems of lib/oracle.py:23-443 evaluated for whole
+batches of parameters / simplices at a time, and the per-node work of
+lib/worker.py:241-417 executed as frontier sweeps on the GPU.
+"""
+
+import ctypes
+import numpy as np
+
+from . import _capi
+from ._capi import f64, u8, ptr, check
+
+
+class FlatTree:
+    """
+    Flat export of a grown partition (struct of arrays, node k):
+    vertices (K,p+1,p), left/right (K,) child index or -1, delta_idx (K,),
+    vertex_costs (K,p+1), vertex_inputs (K,p+1,n_u), flags (K,) bit0 = epsilon-suboptimal,
+    bit1 = has commutation data, tstar (K,) slack of the node's last decision.
+    Nodes 0..n_roots-1 are the roots in input order.
+    """
+
+    def __init__(self, vertices, left, right, delta_idx, vertex_costs, vertex_inputs, flags,
+                 tstar, info, deltas):
+        self.vertices = vertices
+        self.left = left
+        self.right = right
+        self.delta_idx = delta_idx
+        self.vertex_costs = vertex_costs
+        self.vertex_inputs = vertex_inputs
+        self.flags = flags
+        self.tstar = tstar
+        self.info = info
+        self.deltas = deltas
+
+    @property
+    def n_nodes(self):
+        return self.left.shape[0]
+
+    def is_leaf(self, k):
+        return self.left[k] < 0
+
+    def locations(self, root_locations=None):
+        """Location string of every node ('0' left / '1' right, lib/worker.py:254-258)."""
+        n_roots = self.info['n_roots']
+        loc = [None] * self.n_nodes
+        for r in range(n_roots):
+            loc[r] = '' if root_locations is None else root_locations[r]
+        for k in range(self.n_nodes):         # children always have larger indices
+            if self.left[k] >= 0:
+                loc[self.left[k]] = loc[k] + '0'
+                loc[self.right[k]] = loc[k] + '1'
+        return loc
+
+
+class GpuProblem:
+    """Device-resident canonical MPC instance (one GPU, one HIP stream)."""
+
+    def __init__(self, canonical, eps_a, eps_r, device=0):
+        self.can = canonical
+        self.device = int(device)
+        self._lib = _capi.load()
+        self._handle = ctypes.c_void_p()
+        can = canonical
+        self._keep = (f64(can.G), f64(can.w), f64(can.S), f64(can.c),
+                      u8(can.deltas.astype(int)))
+        G, w, S, c, deltas = self._keep
+        desc = _capi.ProblemDesc(
+            n=can.n, m=can.m, p=can.p, n_u=can.n_u, n_delta=can.n_delta,
+            delta_len=deltas.shape[1],
+            G=G.ctypes.data_as(_capi.c_double_p), w=w.ctypes.data_as(_capi.c_double_p),
+            S=S.ctypes.data_as(_capi.c_double_p), c=c.ctypes.data_as(_capi.c_double_p),
+            deltas=deltas.ctypes.data_as(_capi.c_uint8_p),
+            eps_a=float(eps_a), eps_r=float(eps_r))
+        check(self._lib.ehm_problem_create(ctypes.byref(desc), self.device,
+                                           ctypes.byref(self._handle)))
+        self.eps_a = float(eps_a)
+        self.eps_r = float(eps_r)
+
+    def close(self):
+        if getattr(self, '_handle', None) is not None and self._handle:
+            self._lib.ehm_problem_destroy(self._handle)
+            self._handle = ctypes.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def set_eps(self, eps_a, eps_r):
+        check(self._lib.ehm_problem_set_eps(self._handle, float(eps_a), float(eps_r)))
+        self.eps_a, self.eps_r = float(eps_a), float(eps_r)
+
+    # -- helpers ------------------------------------------------------------------------
+    def _delta_arg(self, delta, n_inst):
+        if delta is None:
+            return None
+        d = u8(np.asarray(delta).astype(int))
+        if d.ndim == 1:
+            d = np.ascontiguousarray(np.broadcast_to(d, (n_inst, d.shape[0])))
+        return d
+
+    # -- batched oracles ------------------------------------------------------------------
+    def solve_ptd(self, theta, delta=None):
+        """P_theta_delta for a batch: returns (J, u0, status, iters)."""
+        theta = f64(np.atleast_2d(theta))
+        n = theta.shape[0]
+        d = self._delta_arg(delta, n)
+        J = np.empty(n)
+        u0 = np.empty((n, self.can.n_u))
+        status = np.empty(n, dtype=np.int32)
+        iters = np.empty(n, dtype=np.int32)
+        check(self._lib.ehm_solve_ptd_batch(self._handle, n, ptr(theta), ptr(d), ptr(J),
+                                            ptr(u0), ptr(status), ptr(iters)))
+        return J, u0, status, iters
+
+    def feasible_ptd(self, theta, delta=None):
+        """check_feasibility form of P_theta_delta: returns (feasible bool array, tau)."""
+        theta = f64(np.atleast_2d(theta))
+        n = theta.shape[0]
+        d = self._delta_arg(delta, n)
+        feas = np.empty(n, dtype=np.uint8)
+        tau = np.empty(n)
+        check(self._lib.ehm_feas_ptd_batch(self._handle, n, ptr(theta), ptr(d), ptr(feas),
+                                           ptr(tau)))
+        return feas.astype(bool), tau
+
+    def solve_pt(self, theta):
+        """P_theta: returns (J, u0, delta_idx)."""
+        theta = f64(np.atleast_2d(theta))
+        n = theta.shape[0]
+        J = np.empty(n)
+        u0 = np.empty((n, self.can.n_u))
+        didx = np.empty(n, dtype=np.int32)
+        check(self._lib.ehm_solve_pt_batch(self._handle, n, ptr(theta), ptr(J), ptr(u0),
+                                           ptr(didx)))
+        return J, u0, didx
+
+    def v_r(self, R):
+        """V_R: returns (delta_idx, vertex J, vertex u0)."""
+        R = f64(R).reshape(-1, self.can.p + 1, self.can.p)
+        n = R.shape[0]
+        didx = np.empty(n, dtype=np.int32)
+        vJ = np.empty((n, self.can.p + 1))
+        vu = np.empty((n, self.can.p + 1, self.can.n_u))
+        check(self._lib.ehm_vr_batch(self._handle, n, ptr(R), ptr(didx), ptr(vJ), ptr(vu)))
+        return didx, vJ, vu
+
+    def slack(self, R, Vbar, delta=None):
+        """t*(delta) of the suboptimality test: returns (tstar, alpha, status)."""
+        R = f64(R).reshape(-1, self.can.p + 1, self.can.p)
+        n = R.shape[0]
+        Vbar = f64(Vbar).reshape(n, self.can.p + 1)
+        d = self._delta_arg(delta, n)
+        t = np.empty(n)
+        alpha = np.empty((n, self.can.p + 1))
+        status = np.empty(n, dtype=np.int32)
+        check(self._lib.ehm_slack_batch(self._handle, n, ptr(R), ptr(Vbar), ptr(d), ptr(t),
+                                        ptr(alpha), ptr(status)))
+        return t, alpha, status
+
+    def bar_e(self, R, Vbar):
+        """bar_E_delta_R: returns (closed bool array, best slack)."""
+        R = f64(R).reshape(-1, self.can.p + 1, self.can.p)
+        n = R.shape[0]
+        Vbar = f64(Vbar).reshape(n, self.can.p + 1)
+        closed = np.empty(n, dtype=np.uint8)
+        tb = np.empty(n)
+        check(self._lib.ehm_bar_e_batch(self._handle, n, ptr(R), ptr(Vbar), ptr(closed),
+                                        ptr(tb)))
+        return closed.astype(bool), tb
+
+    def min_simplex(self, R, delta=None):
+        R = f64(R).reshape(-1, self.can.p + 1, self.can.p)
+        n = R.shape[0]
+        d = self._delta_arg(delta, n)
+        J = np.empty(n)
+        status = np.empty(n, dtype=np.int32)
+        check(self._lib.ehm_min_simplex_batch(self._handle, n, ptr(R), ptr(d), ptr(J),
+                                              ptr(status)))
+        return J, status
+
+    def bar_d(self, R, Vbar, delta_ref):
+        """bar_D_delta_R: returns (delta_idx, theta_star, vJ, vu0, var_small)."""
+        R = f64(R).reshape(-1, self.can.p + 1, self.can.p)
+        n = R.shape[0]
+        Vbar = f64(Vbar).reshape(n, self.can.p + 1)
+        d = self._delta_arg(delta_ref, n)
+        didx = np.empty(n, dtype=np.int32)
+        ths = np.empty((n, self.can.p))
+        vJ = np.empty((n, self.can.p + 1))
+        vu = np.empty((n, self.can.p + 1, self.can.n_u))
+        vs = np.empty(n, dtype=np.uint8)
+        check(self._lib.ehm_bar_d_batch(self._handle, n, ptr(R), ptr(Vbar), ptr(d), ptr(didx),
+                                        ptr(ths), ptr(vJ), ptr(vu), ptr(vs)))
+        return didx, ths, vJ, vu, vs.astype(bool)
+
+    # -- partition ------------------------------------------------------------------------------
+    def partition(self, roots, action='ecc', init=None, max_nodes=0, max_depth=0, engine=0):
+        """
+        Grow every root simplex until all leaves are epsilon-suboptimal.
+        roots: (n_roots, p+1, p).  init: optional dict(delta, vertex_costs, vertex_inputs)
+        for action 'lcss'.  Returns a FlatTree.
+        """
+        roots = f64(roots).reshape(-1, self.can.p + 1, self.can.p)
+        n_roots = roots.shape[0]
+        opts = _capi.RunOpts(max_nodes=int(max_nodes), max_depth=int(max_depth),
+                             action=0 if action == 'ecc' else 1, engine=int(engine),
+                             reserved=0)
+        init_struct = None
+        keep = None
+        if init is not None:
+            dl = u8(np.asarray(init['delta']).astype(int)).reshape(n_roots, -1)
+            vc = f64(init['vertex_costs']).reshape(n_roots, self.can.p + 1)
+            vi = f64(init['vertex_inputs']).reshape(n_roots, self.can.p + 1, self.can.n_u)
+            keep = (dl, vc, vi)
+            init_struct = ctypes.pointer(_capi.NodeInit(
+                delta=dl.ctypes.data_as(_capi.c_uint8_p),
+                vcost=vc.ctypes.data_as(_capi.c_double_p),
+                vinput=vi.ctypes.data_as(_capi.c_double_p)))
+        tree = ctypes.c_void_p()
+        check(self._lib.ehm_partition_run(self._handle, n_roots, ptr(roots), init_struct,
+                                          ctypes.byref(opts), ctypes.byref(tree)))
+        del keep
+        try:
+            info = _capi.TreeInfo()
+            check(self._lib.ehm_tree_info_get(tree, ctypes.byref(info)))
+            K = info.n_nodes
+            p, n_u = self.can.p, self.can.n_u
+            vertices = np.empty((K, p + 1, p))
+            left = np.empty(K, dtype=np.int32)
+            right = np.empty(K, dtype=np.int32)
+            didx = np.empty(K, dtype=np.int32)
+            vcost = np.empty((K, p + 1))
+            vinput = np.empty((K, p + 1, n_u))
+            flags = np.empty(K, dtype=np.uint8)
+            tstar = np.empty(K)
+            check(self._lib.ehm_tree_export(tree, ptr(vertices), ptr(left), ptr(right),
+                                            ptr(didx), ptr(vcost), ptr(vinput), ptr(flags),
+                                            ptr(tstar)))
+            info_d = {name: getattr(info, name) for name, _ in _capi.TreeInfo._fields_}
+        finally:
+            self._lib.ehm_tree_destroy(tree)
+        return FlatTree(vertices, left, right, didx, vcost, vinput, flags, tstar, info_d,
+                        self.can.deltas)
+
+    def stats(self):
+        c = _capi.Counters()
+        check(self._lib.ehm_stats(self._handle, ctypes.byref(c)))
+        return {name: getattr(c, name) for name, _ in _capi.Counters._fields_}
+
+
+# -- geometry (no problem handle needed) -----------------------------------------------------
+def split_batch(R, device=0):
+    """tools.split_along_longest_edge for a batch: returns (S1, S2, ij)."""
+    R = f64(R)
+    p = R.shape[-1]
+    R = R.reshape(-1, p + 1, p)
+    n = R.shape[0]
+    S1 = np.empty_like(R)
+    S2 = np.empty_like(R)
+    ij = np.empty((n, 2), dtype=np.int32)
+    lib = _capi.load()
+    check(lib.ehm_split_batch(int(device), n, p, ptr(R), ptr(S1), ptr(S2), ptr(ij)))
+    return S1, S2, ij
+
+
+def volume_batch(R, device=0):
+    R = f64(R)
+    p = R.shape[-1]
+    R = R.reshape(-1, p + 1, p)
+    vol = np.empty(R.shape[0])
+    lib = _capi.load()
+    check(lib.ehm_volume_batch(int(device), R.shape[0], p, ptr(R), ptr(vol)))
+    return vol

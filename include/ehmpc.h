@@ -1,0 +1,209 @@
+/*
+ * ehmpc.h -- C-ABI of libehmpc.so, the MI355X (gfx950) implementation of the offline
+ * parameter-space partitioning hot path of dmalyuta/explicit_hybrid_mpc.
+ *
+ * The reference is pure Python and has no FFI/plugin interface of its own
+ * (SURVEY.md section 8b): its seam for this path is the Python `Oracle` object
+ * (lib/oracle.py:18-474), the geometry helpers (lib/tools.py:134-257), the node types
+ * (lib/tree.py:12-95) and the partition entry `alg_call(which_alg, branch, location)`
+ * (lib/worker.py:180-185, 241-417).  Every entry point below states which of those it
+ * replaces.  The Python package `explicit_hybrid_mpc_amd` binds this header with ctypes
+ * and re-exposes the reference's Python signatures; INTEGRATION.md shows the binding a
+ * maintainer of the reference would add.
+ *
+ * Conventions: plain C, every function returns 0 on success or a negative EHM_E_* code
+ * (message via ehm_last_error(), thread-local).  All arrays are C-contiguous, caller
+ * owned, float64 / int32 / uint8.  "host" entry points take host pointers and copy;
+ * "_dev" entry points take device pointers valid on the problem's GPU and enqueue on
+ * the problem's HIP stream without synchronising (use ehm_sync()).  A handle is bound to
+ * one GPU and is not thread-safe (the reference's Oracle is not re-entrant either,
+ * lib/oracle.py:271-280).  There is no CPU fallback: without a usable GPU
+ * ehm_problem_create fails with EHM_E_NO_DEVICE.
+ */
+#ifndef EHMPC_H
+#define EHMPC_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define EHM_OK              0
+#define EHM_E_INVALID      -1   /* bad argument / unsupported dimension */
+#define EHM_E_NO_DEVICE    -2   /* no HIP device, or HIP runtime error at setup */
+#define EHM_E_HIP          -3   /* HIP runtime error during execution */
+#define EHM_E_CAPACITY     -4   /* node pool exhausted (raise max_nodes) */
+#define EHM_E_INFEASIBLE   -5   /* Theta contains infeasible regions (lib/worker.py:266) */
+#define EHM_E_NUMERIC      -6   /* a vertex solve failed (lib/oracle.py:440-442) */
+
+/* Limits of this build (one wavefront per LP, KKT row in registers). */
+#define EHM_MAX_N   32          /* LP columns incl. simplex weights and slack */
+#define EHM_MAX_M   256         /* LP rows   incl. simplex / cost rows */
+#define EHM_MAX_P   8           /* parameter dimension */
+
+/* Per-instance solve status (status arrays). */
+#define EHM_ST_OPTIMAL  0       /* all relative optimality criteria met */
+#define EHM_ST_STALLED  1       /* best iterate returned; merit > 1 */
+
+/*
+ * Canonical data of one MPC instance: for commutation index d (0..n_delta-1)
+ *     J*(theta,d) = min_z c^T z   s.t.  G[d] z <= w[d] + S[d] theta ,   u0 = z[0:n_u].
+ * Built on the host by explicit_hybrid_mpc_amd.mpc_library.PWAMPC.compile(); it carries
+ * what the reference's Oracle.__init__ (lib/oracle.py:23-102) extracts from
+ * mpc.make_constraints / mpc.cost.
+ */
+typedef struct ehm_problem_desc {
+    int32_t n;          /* decision variables of P_theta_delta                       */
+    int32_t m;          /* inequality rows                                           */
+    int32_t p;          /* parameter dimension (= n_x; simplices have p+1 vertices)  */
+    int32_t n_u;        /* inputs returned as u0                                     */
+    int32_t n_delta;    /* admissible commutations                                   */
+    int32_t delta_len;  /* length of one commutation vector (delta_size * N)         */
+    const double*  G;       /* [n_delta][m][n] row-major                              */
+    const double*  w;       /* [n_delta][m]                                           */
+    const double*  S;       /* [n_delta][m][p]                                        */
+    const double*  c;       /* [n]                                                    */
+    const uint8_t* deltas;  /* [n_delta][delta_len] 0/1, enumeration order           */
+    double eps_a;       /* absolute suboptimality tolerance (lib/oracle.py:38)       */
+    double eps_r;       /* relative suboptimality tolerance (lib/oracle.py:39)       */
+} ehm_problem_desc;
+
+typedef struct ehm_problem ehm_problem;   /* opaque: device copies + stream + scratch */
+typedef struct ehm_tree    ehm_tree;      /* opaque: grown partition, device resident */
+
+/* Oracle.__init__ (lib/oracle.py:23-102). device = HIP ordinal. */
+int ehm_problem_create(const ehm_problem_desc* desc, int device, ehm_problem** out);
+int ehm_problem_destroy(ehm_problem* prob);
+/* Re-set eps_a / eps_r (examples.create_oracle builds a second Oracle, lib/examples.py:43-46). */
+int ehm_problem_set_eps(ehm_problem* prob, double eps_a, double eps_r);
+int ehm_sync(ehm_problem* prob);
+/* HIP stream the handle enqueues on (a hipStream_t), for event timing by the caller. */
+void* ehm_stream(ehm_problem* prob);
+
+/* ---- batched oracles (host buffers) ------------------------------------------------ */
+
+/* Oracle.P_theta_delta(theta, delta) (lib/oracle.py:141-173) for n_inst instances.
+ * delta: [n_inst][delta_len] 0/1.  Outputs J [n_inst], u0 [n_inst][n_u],
+ * status/iters [n_inst] (may be NULL).  An infeasible instance reports EHM_ST_STALLED. */
+int ehm_solve_ptd_batch(ehm_problem* prob, int64_t n_inst, const double* theta,
+                        const uint8_t* delta, double* J, double* u0,
+                        int32_t* status, int32_t* iters);
+
+/* Oracle.P_theta_delta(theta, delta, check_feasibility=True) (lib/oracle.py:164-167):
+ * feasible[k] = 1 iff the constraint set is non-empty; tau[k] (may be NULL) is the
+ * optimal worst-row violation (<= 0 iff feasible). */
+int ehm_feas_ptd_batch(ehm_problem* prob, int64_t n_inst, const double* theta,
+                       const uint8_t* delta, uint8_t* feasible, double* tau);
+
+/* Oracle.P_theta(theta) (lib/oracle.py:104-139): minimum over all commutations, lowest
+ * index on ties.  delta_idx[k] = -1 and J = +inf when no commutation is feasible. */
+int ehm_solve_pt_batch(ehm_problem* prob, int64_t n_inst, const double* theta,
+                       double* J, double* u0, int32_t* delta_idx);
+
+/* Oracle.V_R(R) (lib/oracle.py:175-218): first commutation feasible at every vertex of
+ * R [n_inst][p+1][p]; delta_idx = -1 if none.  vJ [n_inst][p+1], vu0 [n_inst][p+1][n_u]. */
+int ehm_vr_batch(ehm_problem* prob, int64_t n_inst, const double* R,
+                 int32_t* delta_idx, double* vJ, double* vu0);
+
+/* Slack of the epsilon-suboptimality test for ONE commutation per instance: the decision
+ * form of Oracle.bar_E_delta_R's constraints (lib/oracle.py:89-97)
+ *     t* = max t  s.t. MPC constraints at theta = sum alpha_i v_i,
+ *                      sum alpha_i Vbar_i - V - eps_a >= t,  sum alpha_i Vbar_i - (1+eps_r) V >= t.
+ * alpha [n_inst][p+1] (may be NULL) is the maximiser's simplex weights. */
+int ehm_slack_batch(ehm_problem* prob, int64_t n_inst, const double* R, const double* Vbar,
+                    const uint8_t* delta, double* tstar, double* alpha, int32_t* status);
+
+/* Oracle.bar_E_delta_R(R, V_delta_R) (lib/oracle.py:285-309): closed[k] = 1 iff no
+ * commutation has t* >= 0 (epsilon-suboptimal => close the leaf).  tbest = max_d t*(d). */
+int ehm_bar_e_batch(ehm_problem* prob, int64_t n_inst, const double* R, const double* Vbar,
+                    uint8_t* closed, double* tbest);
+
+/* min over the simplex for a fixed commutation (lib/oracle.py:74-79, used by
+ * in_variability_ball :276). */
+int ehm_min_simplex_batch(ehm_problem* prob, int64_t n_inst, const double* R,
+                          const uint8_t* delta, double* Jmin, int32_t* status);
+
+/* Oracle.bar_D_delta_R(R, V_delta_R, delta_ref) incl. in_variability_ball
+ * (lib/oracle.py:311-414, 220-283).  delta_idx = -1 when there is no better commutation
+ * (the reference's (None,None,None,None)); otherwise theta_star [p], vJ [p+1],
+ * vu0 [p+1][n_u], var_small. */
+int ehm_bar_d_batch(ehm_problem* prob, int64_t n_inst, const double* R, const double* Vbar,
+                    const uint8_t* delta_ref, int32_t* delta_idx, double* theta_star,
+                    double* vJ, double* vu0, uint8_t* var_small);
+
+/* ---- geometry ------------------------------------------------------------------------ */
+
+/* tools.split_along_longest_edge (lib/tools.py:224-257), bit-exact incl. the first-max
+ * tie rule.  R,S1,S2: [n][p+1][p]; ij: [n][2].  device = HIP ordinal. */
+int ehm_split_batch(int device, int64_t n, int32_t p, const double* R,
+                    double* S1, double* S2, int32_t* ij);
+/* tools.simplex_volume (lib/tools.py:134-150). */
+int ehm_volume_batch(int device, int64_t n, int32_t p, const double* R, double* vol);
+
+/* ---- partition engine ---------------------------------------------------------------- */
+
+typedef struct ehm_run_opts {
+    int64_t max_nodes;      /* node pool capacity (0 = default)                          */
+    int32_t max_depth;      /* stop splitting below this depth relative to roots (0 = none) */
+    int32_t action;         /* 0 = 'ecc' then 'lcss' (lib/worker.py:241-291), 1 = 'lcss'   */
+    int32_t engine;         /* 0 = level-synchronous sweeps, 1 = persistent frontier kernel */
+    int32_t reserved;
+} ehm_run_opts;
+
+/* Optional initial node data for action 1 ('lcss' roots already carry a commutation,
+ * lib/scheduler.py:633-639). */
+typedef struct ehm_node_init {
+    const uint8_t* delta;   /* [n_roots][delta_len]   */
+    const double*  vcost;   /* [n_roots][p+1]         */
+    const double*  vinput;  /* [n_roots][p+1][n_u]    */
+} ehm_node_init;
+
+/* alg_call(which_alg, branch, location) (lib/worker.py:180-185) for a batch of root
+ * simplices: grows every root until all leaves are epsilon-suboptimal.
+ * root_vertices: [n_roots][p+1][p] host. */
+int ehm_partition_run(ehm_problem* prob, int64_t n_roots, const double* root_vertices,
+                      const ehm_node_init* init, const ehm_run_opts* opts, ehm_tree** out);
+
+typedef struct ehm_tree_info {
+    int64_t n_nodes;
+    int64_t n_leaves;
+    int64_t n_roots;
+    int64_t n_closed;       /* leaves with is_epsilon_suboptimal                        */
+    int64_t lp_solves;      /* LP sub-problems solved on the device                     */
+    int64_t ref_solves;     /* reference-equivalent oracle calls (one MICP = 1)         */
+    int64_t ipm_iters;      /* interior-point iterations summed over all solves         */
+    int64_t sweeps;         /* frontier sweeps (levels)                                 */
+    int32_t max_depth;
+    int32_t truncated;      /* 1 if max_depth / capacity stopped the growth             */
+    double  volume_closed;  /* sum of closed leaf volumes (lib/worker.py:374-375)       */
+    double  min_margin;     /* min |t*| over all close/split decisions                  */
+    double  device_seconds; /* GPU time of the sweeps (HIP events)                      */
+} ehm_tree_info;
+
+int ehm_tree_info_get(const ehm_tree* tree, ehm_tree_info* out);
+/* Flat export, node k: vertices [k][p+1][p], left[k] / right[k] child index or -1,
+ * delta_idx[k] (-1 = none), vcost [k][p+1], vinput [k][p+1][n_u],
+ * flags[k] bit0 = is_epsilon_suboptimal, bit1 = has commutation data.
+ * Nodes 0..n_roots-1 are the roots in input order.  Any pointer may be NULL. */
+int ehm_tree_export(const ehm_tree* tree, double* vertices, int32_t* left, int32_t* right,
+                    int32_t* delta_idx, double* vcost, double* vinput, uint8_t* flags,
+                    double* tstar);
+int ehm_tree_destroy(ehm_tree* tree);
+
+/* Cumulative counters of a problem handle (SURVEY.md section 5 "tracing"). */
+typedef struct ehm_counters {
+    int64_t lp_solves;
+    int64_t ipm_iters;
+    int64_t kernel_launches;
+    int64_t stalled;
+} ehm_counters;
+int ehm_stats(ehm_problem* prob, ehm_counters* out);
+
+const char* ehm_last_error(void);
+const char* ehm_version(void);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* EHMPC_H */

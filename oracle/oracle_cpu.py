@@ -1,0 +1,166 @@
+"""
+TEST INFRASTRUCTURE (see oracle/__init__.py).
+
+CPU restatement of the reference's ``Oracle`` (lib/oracle.py:18-474): same six methods,
+same argument meaning, same return conventions.  Every mixed-integer problem of the
+reference is solved by enumerating the admissible commutations and solving one LP per
+commutation with SciPy HiGHS -- one solver call per sub-problem, like the reference's
+one ``Problem.solve`` per oracle.
+
+Canonical commutation rule (the reference returns whatever feasible commutation MOSEK
+happens to find, lib/oracle.py:201,347 -- ``Minimize(0)``):
+
+* ``P_theta``      : commutation with the smallest optimal cost, lowest index on ties.
+* ``V_R``          : first commutation (enumeration order) feasible at every vertex.
+* ``bar_E_delta_R``: feasible  <=>  max over commutations of the slack t* is >= 0.
+* ``bar_D_delta_R``: among commutations feasible at every vertex of R, the one with the
+  largest slack t* (lowest index on ties), provided t* >= 0;  theta* is that LP's
+  maximiser.
+"""
+
+import time
+import numpy as np
+from scipy.optimize import linprog
+
+from .lp_models import FixedCommutationModel
+
+
+# HiGHS defaults to 1e-7 feasibility tolerances; the parity bar on optimal costs is 1e-7
+# relative, so the checker itself is run tighter.
+HIGHS_OPTIONS = dict(primal_feasibility_tolerance=1e-10, dual_feasibility_tolerance=1e-10)
+
+
+class SolverError(RuntimeError):
+    """Stands in for cvx.SolverError (lib/oracle.py:442)."""
+
+
+class OracleCPU:
+    def __init__(self, mpc, eps_a, eps_r):
+        """Same signature and attributes as lib/oracle.py:23-39."""
+        self.mpc = mpc
+        self.eps_a = eps_a
+        self.eps_r = eps_r
+        self.sequences = mpc.mode_sequences()
+        self.deltas = [mpc.sequence_to_delta(s) for s in self.sequences]
+        self.models = [FixedCommutationModel(mpc, s) for s in self.sequences]
+        self.n_solves = 0          # LP solver calls (one per commutation sub-problem)
+        self.last_margin = np.inf  # |t*| of the last feasibility decision
+
+    # -- helpers ---------------------------------------------------------------------
+    def delta_index(self, delta):
+        key = np.asarray(delta).astype(int)  # lib/oracle.py:384-385 comparison
+        for d, ref in enumerate(self.deltas):
+            if np.array_equal(ref.astype(int), key):
+                return d
+        raise ValueError('not an admissible commutation')
+
+    def _solve(self, lp):
+        self.n_solves += 1
+        bounds = lp.get('bounds', (None, None))
+        res = linprog(lp['c'], A_ub=lp['A_ub'], b_ub=lp['b_ub'], A_eq=lp['A_eq'],
+                      b_eq=lp['b_eq'], bounds=bounds, method='highs',
+                      options=HIGHS_OPTIONS)
+        return res
+
+    def _point(self, theta, d):
+        """(feasible, u0, J) of P_theta_delta for commutation index d."""
+        res = self._solve(self.models[d].lp_point(theta))
+        if res.status != 0:
+            return False, None, None
+        return True, self.models[d].u0(res.x), float(res.fun)
+
+    # -- lib/oracle.py:104-139 -----------------------------------------------------------
+    def P_theta(self, theta, check_feasibility=False):
+        t0 = time.time()
+        best = None
+        for d in range(len(self.models)):
+            ok, u, J = self._point(theta, d)
+            if not ok:
+                continue
+            if check_feasibility:
+                return True
+            if best is None or J < best[2]:
+                best = (u, self.deltas[d].copy(), J)
+        if check_feasibility:
+            return False
+        if best is None:
+            return None, None, None, time.time() - t0
+        return best[0], best[1], best[2], time.time() - t0
+
+    # -- lib/oracle.py:141-173 -----------------------------------------------------------
+    def P_theta_delta(self, theta, delta, check_feasibility=False):
+        t0 = time.time()
+        ok, u, J = self._point(theta, self.delta_index(delta))
+        if check_feasibility:
+            return ok
+        if not ok:
+            return None, None, time.time() - t0
+        return u, J, time.time() - t0
+
+    # -- lib/oracle.py:416-443 -----------------------------------------------------------
+    def _compute_vx_inputs_and_costs(self, R, delta):
+        out = []
+        for vertex in R:
+            u, J, t = self.P_theta_delta(theta=vertex, delta=delta)
+            if u is None:
+                raise SolverError('problem infeasible')
+            out.append((u, J, t))
+        return out
+
+    def _feasible_on_vertices(self, R, d):
+        return all(self._point(v, d)[0] for v in R)
+
+    # -- lib/oracle.py:175-218 -----------------------------------------------------------
+    def V_R(self, R):
+        for d in range(len(self.models)):
+            if self._feasible_on_vertices(R, d):
+                delta = self.deltas[d].copy()
+                return delta, self._compute_vx_inputs_and_costs(R, delta)
+        return None, None
+
+    # -- lib/oracle.py:285-309 -----------------------------------------------------------
+    def slack(self, R, V_delta_R, d):
+        """t*(d) and its maximiser (alpha) of the bar_E decision LP."""
+        res = self._solve(self.models[d].lp_bar_E(R, V_delta_R, self.eps_a, self.eps_r))
+        if res.status != 0:
+            return -np.inf, None
+        na = np.asarray(R).shape[0]
+        return -float(res.fun), np.array(res.x[-1 - na:-1])
+
+    def bar_E_delta_R(self, R, V_delta_R):
+        t_best = max(self.slack(R, V_delta_R, d)[0] for d in range(len(self.models)))
+        self.last_margin = abs(t_best)
+        return not (t_best >= 0.)
+
+    # -- lib/oracle.py:220-283 -----------------------------------------------------------
+    def in_variability_ball(self, R, V_delta_R, delta_ref, delta_star, theta_star):
+        d_ref = self.delta_index(delta_ref)
+        res = self._solve(self.models[d_ref].lp_min_over_simplex(R))
+        if res.status != 0:
+            raise SolverError('min over simplex failed')
+        min_lhs = float(res.fun)
+        max_lhs = np.max(V_delta_R)
+        V_delta_theta = self.P_theta_delta(theta=theta_star, delta=delta_star)[1]
+        rhs = max(self.eps_a, self.eps_r * V_delta_theta)
+        return bool(max_lhs - min_lhs < rhs)
+
+    # -- lib/oracle.py:311-414 -----------------------------------------------------------
+    def bar_D_delta_R(self, R, V_delta_R, delta_ref):
+        R = np.asarray(R, dtype=np.float64)
+        best = None
+        for d in range(len(self.models)):
+            if not self._feasible_on_vertices(R, d):
+                continue
+            t, alpha = self.slack(R, V_delta_R, d)
+            if t >= 0. and (best is None or t > best[0]):
+                best = (t, d, alpha)
+        if best is None:
+            return None, None, None, None
+        delta_star = self.deltas[best[1]].copy()
+        if np.array_equal(delta_star.astype(int), np.asarray(delta_ref).astype(int)):
+            return None, None, None, None
+        theta_star = best[2] @ R
+        vx = self._compute_vx_inputs_and_costs(R, delta_star)
+        var_small = self.in_variability_ball(R, V_delta_R, delta_ref, delta_star,
+                                             theta_star)
+        return delta_star, theta_star, vx, var_small

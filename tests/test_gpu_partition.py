@@ -1,0 +1,50 @@
+"""
+GPU partition engine vs the CPU restatement of lib/worker.py:241-417: identical region
+tree (same node set, bit-identical vertices, same closed leaves), vertex costs within
+1e-7 relative, volume closure, and no decision closer than 1e-6 to its threshold.
+"""
+
+import numpy as np
+import pytest
+
+from tests import helpers
+
+pytestmark = pytest.mark.gpu
+
+RTOL = 1e-7
+
+
+def compare_trees(flat, nodes_cpu, locs):
+    loc = flat.locations(locs)
+    assert len(loc) == len(nodes_cpu)
+    assert set(loc) == set(nodes_cpu.keys())
+    for k, name in enumerate(loc):
+        ref = nodes_cpu[name]
+        assert np.array_equal(flat.vertices[k], ref['vertices']), name
+        assert flat.is_leaf(k) == ref['leaf'], name
+        assert bool(flat.flags[k] & 1) == ref['is_epsilon_suboptimal'], name
+        assert np.allclose(flat.vertex_costs[k], ref['vertex_costs'],
+                           rtol=RTOL, atol=RTOL), name
+
+
+@pytest.mark.parametrize('kind,seed,abs_frac,eps_r', [('di', 0, 0.25, 0.1),
+                                                      ('lin', 0, 0.5, 1.0),
+                                                      ('lin', 1, 0.5, 0.5)])
+def test_tree_identical_to_cpu_partition(kind, seed, abs_frac, eps_r):
+    from explicit_hybrid_mpc_amd import engine, examples
+    from oracle.oracle_cpu import OracleCPU
+    from oracle.partition_cpu import PartitionCPU
+    mpc = helpers.make_instance(kind, seed)
+    eps_a = helpers.eps_a_rule(mpc, abs_frac)
+    roots, locs = helpers.roots_of(mpc)
+    orc = OracleCPU(mpc, eps_a, eps_r)
+    cpu = PartitionCPU(orc)
+    cpu.run(roots, locs, 'ecc')
+    gp = engine.GpuProblem(mpc.compile(), eps_a, eps_r)
+    flat = gp.partition(np.array(roots), action='ecc')
+    gp.close()
+    compare_trees(flat, cpu.nodes, locs)
+    total = np.prod(2 * examples.theta_box(mpc))
+    assert abs(flat.info['volume_closed'] - total) <= 1e-9 * total
+    assert flat.info['min_margin'] > 1e-6
+    assert min(cpu.min_margin, flat.info['min_margin']) > 1e-6
