@@ -195,6 +195,7 @@ __global__ __launch_bounds__(64) void k_lcss_decide(DevProblem P, DevTree T,
                          lane);
         const IpmResult r = ipm_solve(w, b, lane);
         count_solve(cnt, r, lane);
+        if (r.status != 0 && lane == 0) atomicAdd(&cnt->errors, 1ULL);
         if (lane == 0) {
             const double t = -r.obj;
             const bool open = (t >= 0.0);
@@ -392,7 +393,7 @@ struct ehm_problem {
     DevCounters* d_cnt = nullptr;
     long long launches = 0;
     int num_cu = 256;
-    size_t lds_point = 0, lds_simplex = 0;
+    size_t lds_point = 0, lds_simplex = 0, lds_expand = 0;
 };
 
 struct ehm_tree {
@@ -505,6 +506,7 @@ int ehm_problem_create(const ehm_problem_desc* d, int device, ehm_problem** out)
     HIP_TRY(hipMemcpy(P->d_cnt, &zero, sizeof zero, hipMemcpyHostToDevice), EHM_E_HIP);
     P->lds_point = lds_bytes_for(P->dp, LP_FEAS, 16);
     P->lds_simplex = lds_bytes_for(P->dp, LP_SLACK, NODE_LDS_DOUBLES);
+    P->lds_expand = lds_bytes_for(P->dp, LP_POINT, NODE_LDS_DOUBLES);
     const size_t lds_max = std::max(P->lds_point, P->lds_simplex);
     if (lds_max > 160 * 1024) {
         ehm_problem_destroy(P);
@@ -955,7 +957,7 @@ int ehm_partition_run(ehm_problem* P, int64_t n_roots, const double* root_vertic
             RUN_TRY(nb.ensure((size_t)n_open * 2 * 4 * 2));
         }
         nxt = nb.as<int32_t>();
-        hipLaunchKernelGGL(k_lcss_expand, dim3(grid_for(P, n_open)), dim3(64), P->lds_point,
+        hipLaunchKernelGGL(k_lcss_expand, dim3(grid_for(P, n_open)), dim3(64), P->lds_expand,
                            P->stream, P->dp, T->dt, open_list.as<int32_t>(), (int)n_open,
                            (int)n_nodes, nxt, P->d_cnt);
         P->launches++;
@@ -977,7 +979,7 @@ int ehm_partition_run(ehm_problem* P, int64_t n_roots, const double* root_vertic
     cleanup();
     if (c1.errors != 0) {
         ehm_tree_destroy(T);
-        return fail(EHM_E_NUMERIC, "%llu vertex/midpoint solves did not converge",
+        return fail(EHM_E_NUMERIC, "%llu oracle solves did not converge",
                     (unsigned long long)c1.errors);
     }
     T->info.n_nodes = n_nodes;

@@ -34,6 +34,9 @@
 #define EHM_STEP_FRAC   0.99
 #define EHM_PIVOT_REL   1e-13
 #define EHM_PIVOT_BIG   1e128
+// non-improving iterations only count as a stall once the best iterate is within this factor
+// of the tolerances (the merit of an infeasible-start method is not monotone early on)
+#define EHM_STALL_ZONE  1e4
 
 namespace ehm {
 
@@ -357,7 +360,7 @@ __device__ inline IpmResult ipm_solve(const LpWork& w, const double (&b)[EHM_SLO
             res.obj = pobj;
             stall = 0;
             if (lane < EHM_NP) w.xb[lane] = w.x[lane];
-        } else {
+        } else if (res.merit < EHM_STALL_ZONE) {
             ++stall;
         }
         res.iters = it;

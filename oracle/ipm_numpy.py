@@ -81,6 +81,7 @@ class IPMResult:
 
 PIVOT_REL = 1e-13     # a pivot below PIVOT_REL * (its original diagonal) is a dependent column
 PIVOT_BIG = 1e128     # replacing it by this zeroes the corresponding solution component
+STALL_ZONE = 1e4      # non-improving iterations count as a stall only this close to the tolerances
 
 
 def guarded_cholesky(M):
@@ -145,7 +146,7 @@ def solve_lp(c, A, b, max_iter=40, tol_res=1e-8, tol_gap=1e-9, step_frac=0.99):
         if best is None or merit < best[0]:
             best = (merit, x.copy(), lam.copy(), it)
             stall = 0
-        else:
+        elif best[0] < STALL_ZONE:
             stall += 1
         if merit <= 1.:
             status = 0
