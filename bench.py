@@ -1,0 +1,219 @@
+#!/usr/bin/env python
+"""
+Benchmark of the partitioning hot path on MI355X.
+
+A "step" is one complete partition of the synthetic config-2 instance
+(n_x=4, n_u=2, N=5, p=4 linear MPC, infinity-norm LP cost, eps_r=1e-2; BASELINE.json
+configs[1]): feasible-commutation pass over the 22 Delaunay root simplices, then
+epsilon-suboptimal refinement until every leaf is closed.  Problem constants and the
+root simplices are resident in HBM before the timed region; the timed region contains
+everything else (all frontier sweeps, LP solves, child construction).
+
+    python bench.py --gpus N --steps K --warmup W
+
+prints ONE JSON line on rank 0.  For N > 1 it is launched by torch.distributed.run with
+one rank per GPU; the live frontier is dealt round-robin over the ranks once it is wide
+enough (no data-path collective: subtrees are independent), so the total work is fixed
+("strong" scaling) and `value` is the whole-job LP-solve rate.
+"""
+
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+FP64_PEAK_TFLOPS = 78.6     # MI355X FP64 vector = FP32 vector / 2 (157.3 TF, MI355X_MICROARCH.md)
+HBM_PEAK_GBS = 8000.0
+
+
+def flops_per_iteration(n, m):
+    """dense primal-dual IPM iteration on  min c^T z, G z <= h."""
+    return 2. * m * n * n + n ** 3 / 3. + 8. * m * n + 4. * n * n
+
+
+def node_bytes(p, n_u, delta_len):
+    """node payload + 16 B topology/flags."""
+    return 8 * ((p + 1) * p + (p + 1) + (p + 1) * n_u) + delta_len + 16
+
+
+def cpu_baseline(mpc, eps_a, eps_r, seconds):
+    """Oracle (CPU restatement, HiGHS) timed on a bounded prefix of the same partition."""
+    from oracle.oracle_cpu import OracleCPU
+    from oracle.partition_cpu import PartitionCPU
+    from oracle import geometry
+    from explicit_hybrid_mpc_amd import examples
+    V = examples.box_vertices(examples.theta_box(mpc))
+    roots, locs = geometry.delaunay_simplices(V)
+    orc = OracleCPU(mpc, eps_a, eps_r)
+    part = PartitionCPU(orc, max_nodes=50)
+    t0 = time.perf_counter()
+    visits = 0
+    while time.perf_counter() - t0 < seconds:
+        # extend the bounded prefix in chunks of node visits
+        part.max_nodes = part.visits + 50
+        if part.visits == 0:
+            part.run(roots, locs, 'ecc')
+        else:
+            part.resume()
+        visits = part.visits
+        if not part.truncated:
+            break
+    dt = time.perf_counter() - t0
+    return dict(value=orc.n_solves / dt, unit='LP solves/s', cores=1, kind='port',
+                sample='first %d node visits of the same partition (%d HiGHS LP solves, '
+                       '%.1f s), oracle/partition_cpu.py' % (visits, orc.n_solves, dt))
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument('--gpus', type=int, default=1)
+    ap.add_argument('--steps', type=int, default=3)
+    ap.add_argument('--warmup', type=int, default=1)
+    ap.add_argument('--seed', type=int, default=0)
+    ap.add_argument('--abs-frac', type=float, default=0.1)
+    ap.add_argument('--eps-r', type=float, default=1e-2)
+    ap.add_argument('--max-nodes', type=int, default=1 << 22)
+    ap.add_argument('--shard-min-frontier', type=int, default=2048)
+    ap.add_argument('--cpu-seconds', type=float, default=15.)
+    ap.add_argument('--no-cpu-baseline', action='store_true')
+    args = ap.parse_args()
+
+    rank = int(os.environ.get('RANK', '0'))
+    local_rank = int(os.environ.get('LOCAL_RANK', '0'))
+    world = int(os.environ.get('WORLD_SIZE', '1'))
+    import torch
+    import torch.distributed as dist
+    if world > 1:
+        os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
+        torch.cuda.set_device(local_rank)
+        dist.init_process_group('nccl', rank=rank, world_size=world)
+    if world != args.gpus:
+        if rank == 0:
+            sys.stderr.write('bench.py: --gpus %d but WORLD_SIZE=%d; using WORLD_SIZE\n' %
+                             (args.gpus, world))
+    from explicit_hybrid_mpc_amd import engine, examples
+    from explicit_hybrid_mpc_amd import tools as ehm_tools
+
+    mpc = examples.linear_mpc(seed=args.seed)
+    can = mpc.compile()
+    gp = engine.GpuProblem(can, 1., 1., device=local_rank)
+    half = examples.theta_box(mpc)
+    V = examples.box_vertices(half)
+    # eps_a by the reference's rule (lib/examples.py:42-46), evaluated on the GPU oracle
+    J_abs, _, _ = gp.solve_pt(args.abs_frac * V)
+    eps_a = float(np.max(J_abs))
+    gp.set_eps(eps_a, args.eps_r)
+    roots, _ = ehm_tools.delaunay_roots(V)
+    shard = (rank, world, args.shard_min_frontier) if world > 1 else None
+
+    def step():
+        return gp.partition(roots, action='ecc', max_nodes=args.max_nodes, export=False,
+                            shard=shard, with_volume=False)
+
+    def barrier():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        step()
+    barrier()
+    t0 = time.perf_counter()
+    infos = [step() for _ in range(args.steps)]
+    barrier()
+    elapsed = time.perf_counter() - t0
+    # totals over ranks (max time, summed work)
+    keys = ['lp_solves', 'ipm_iters', 'n_nodes', 'n_closed', 'ref_solves', 'decide_solves',
+            'decide_iters']
+    local = torch.tensor([float(sum(i[k] for i in infos)) for k in keys] +
+                         [elapsed, sum(i['decide_seconds'] for i in infos),
+                          sum(i['expand_seconds'] for i in infos)],
+                         dtype=torch.float64, device='cuda:%d' % local_rank)
+    if world > 1:
+        tot = local.clone()
+        dist.all_reduce(tot, op=dist.ReduceOp.SUM)
+        mx = local.clone()
+        dist.all_reduce(mx, op=dist.ReduceOp.MAX)
+        tot = tot.cpu().numpy()
+        mx = mx.cpu().numpy()
+    else:
+        tot = local.cpu().numpy()
+        mx = tot
+    elapsed_max = float(mx[len(keys)])
+    agg = dict(zip(keys, tot[:len(keys)]))
+    decide_s = float(mx[len(keys) + 1])
+    expand_s = float(mx[len(keys) + 2])
+    if rank == 0:
+        K = args.steps
+        info0 = infos[-1]
+        n_slack, m_slack = can.n + can.p + 1, can.m + can.p + 3
+        n_pt, m_pt = can.n, can.m
+        decide_flops = agg['decide_iters'] * flops_per_iteration(n_slack, m_slack)
+        expand_flops = (agg['ipm_iters'] - agg['decide_iters']) * flops_per_iteration(n_pt, m_pt)
+        # dominant kernel = the suboptimality-test sweep (k_lcss_decide)
+        achieved = decide_flops / decide_s / 1e12
+        B = node_bytes(can.p, can.n_u, can.deltas.shape[1])
+        closed, nodes = agg['n_closed'], agg['n_nodes']
+        splits = (nodes - K * world * len(roots)) / 2. if world == 1 else None
+        hbm_alg = agg['decide_solves'] * (B + 8)          # decide: read record, write verdict
+        out = {
+            'metric': 'oracle LP solves/sec + final regions/sec, 4-state 2-input N=5 hybrid MPC',
+            'value': agg['lp_solves'] / elapsed_max,
+            'unit': 'LP solves/s',
+            'regions_per_s': closed / elapsed_max,
+            'n_gpus': world, 'steps': K, 'warmup': args.warmup,
+            'ms_per_step': 1e3 * elapsed_max / K,
+            'higher_is_better': True,
+            'scaling': 'strong',
+            'vs_baseline': None,
+            'dtype': 'f64',
+            'data': 'synthetic',
+            'config': {
+                'workload': 'configs[1]: n_x=4 n_u=2 N=5 p=4 linear MPC, inf-norm LP oracle '
+                            '(n=%d m=%d), seed %d, eps_r=%g, eps_a=%.6g (abs_frac=%g), '
+                            '%d Delaunay roots' % (can.n, can.m, args.seed, args.eps_r, eps_a,
+                                                   args.abs_frac, len(roots)),
+                'regions_per_step': closed / K,
+                'nodes_per_step': nodes / K,
+                'lp_solves_per_step': agg['lp_solves'] / K,
+                'reference_equivalent_solves_per_step': agg['ref_solves'] / K,
+                'mean_ipm_iterations': agg['ipm_iters'] / max(agg['lp_solves'], 1),
+                'sweeps': info0['sweeps'], 'tree_depth': info0['max_depth'],
+                'min_decision_margin': info0['min_margin'],
+                'parallelism': 'frontier dealt round-robin over %d GPU(s)' % world,
+            },
+            'roofline': {
+                'bound': 'mfma', 'kernel': 'k_lcss_decide',
+                'note': 'FP64 vector FMA bound (no f64 contraction >= 32 wide at n=25); peak = '
+                        'FP64 vector = matrix peak of MI355X',
+                'achieved': achieved, 'peak': FP64_PEAK_TFLOPS, 'unit': 'TFLOP/s',
+                'frac': achieved / FP64_PEAK_TFLOPS, 'traffic': None,
+                'flop_per_ipm_iteration': flops_per_iteration(n_slack, m_slack),
+                'kernel_seconds': decide_s, 'launches': info0['decide_launches'] * K,
+                'expand_kernel': {'achieved': expand_flops / max(expand_s, 1e-12) / 1e12,
+                                  'kernel_seconds': expand_s},
+                'hbm': {'achieved': hbm_alg / decide_s / 1e9, 'peak': HBM_PEAK_GBS,
+                        'unit': 'GB/s', 'frac': hbm_alg / decide_s / 1e9 / HBM_PEAK_GBS,
+                        'bytes_per_node': B + 8},
+            },
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            out['cpu_baseline'] = cpu_baseline(mpc, eps_a, args.eps_r, args.cpu_seconds)
+        else:
+            out['cpu_baseline'] = None
+        print(json.dumps(out))
+    gp.close()
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == '__main__':
+    main()

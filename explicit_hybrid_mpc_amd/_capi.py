@@ -51,7 +51,8 @@ class ProblemDesc(ctypes.Structure):
 class RunOpts(ctypes.Structure):
     _fields_ = [('max_nodes', ctypes.c_int64), ('max_depth', ctypes.c_int32),
                 ('action', ctypes.c_int32), ('engine', ctypes.c_int32),
-                ('reserved', ctypes.c_int32)]
+                ('shard_rank', ctypes.c_int32), ('shard_world', ctypes.c_int32),
+                ('skip_volume', ctypes.c_int32), ('shard_min_frontier', ctypes.c_int64)]
 
 
 class NodeInit(ctypes.Structure):
@@ -65,7 +66,10 @@ class TreeInfo(ctypes.Structure):
                 ('ipm_iters', ctypes.c_int64), ('sweeps', ctypes.c_int64),
                 ('max_depth', ctypes.c_int32), ('truncated', ctypes.c_int32),
                 ('volume_closed', ctypes.c_double), ('min_margin', ctypes.c_double),
-                ('device_seconds', ctypes.c_double)]
+                ('device_seconds', ctypes.c_double), ('decide_seconds', ctypes.c_double),
+                ('expand_seconds', ctypes.c_double), ('decide_launches', ctypes.c_int64),
+                ('expand_launches', ctypes.c_int64), ('decide_solves', ctypes.c_int64),
+                ('decide_iters', ctypes.c_int64)]
 
 
 class Counters(ctypes.Structure):

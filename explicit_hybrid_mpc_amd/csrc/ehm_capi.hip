@@ -6,6 +6,7 @@
 #include <cmath>
 #include <cstdarg>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <string>
 #include <vector>
@@ -83,16 +84,16 @@ __global__ __launch_bounds__(64) void k_simplex_batch(DevProblem P, long long n_
     for (long long inst = blockIdx.x; inst < n_inst; inst += gridDim.x) {
         wave_sync();
         for (int k = lane; k < nR; k += 64) Rl[k] = R[inst * nR + k];
-        if (slack && lane <= P.p) Vl[lane] = Vbar[inst * (P.p + 1) + lane];
+        if (slack == SX_SLACK && lane <= P.p) Vl[lane] = Vbar[inst * (P.p + 1) + lane];
         wave_sync();
         const int d = didx ? didx[inst] : 0;
         LpWork w;
         double b[EHM_SLOTS];
-        assemble_simplex(w, lp_base, P, d, Rl, Vl, slack != 0, b, lane);
+        assemble_simplex(w, lp_base, P, d, Rl, Vl, slack, b, lane);
         const IpmResult r = ipm_solve(w, b, lane);
         count_solve(cnt, r, lane);
         if (lane == 0) {
-            obj[inst] = slack ? -r.obj : r.obj;     // t* = -(min -t)
+            obj[inst] = (slack == SX_SLACK) ? -r.obj : r.obj;     // t* = -(min -t)
             if (status) status[inst] = r.status;
             if (iters) iters[inst] = r.iters;
         }
@@ -191,12 +192,17 @@ __global__ __launch_bounds__(64) void k_lcss_decide(DevProblem P, DevTree T,
         wave_sync();
         LpWork w;
         double b[EHM_SLOTS];
-        assemble_simplex(w, lp_base, P, T.didx[id], node, node + rec_off_vcost(P.p), true, b,
-                         lane);
+        assemble_simplex(w, lp_base, P, T.didx[id], node, node + rec_off_vcost(P.p), SX_SLACK,
+                         b, lane);
         const IpmResult r = ipm_solve(w, b, lane);
         count_solve(cnt, r, lane);
-        if (r.status != 0 && lane == 0) atomicAdd(&cnt->errors, 1ULL);
+        if (r.status != 0 && lane == 0) {
+            atomicAdd(&cnt->errors, 1ULL);
+            T.flags[id] |= 8;
+        }
         if (lane == 0) {
+            atomicAdd(&cnt->slack_solves, 1ULL);
+            atomicAdd(&cnt->slack_iters, (unsigned long long)r.iters);
             const double t = -r.obj;
             const bool open = (t >= 0.0);
             T.tstar[id] = t;
@@ -233,6 +239,18 @@ __global__ __launch_bounds__(1024) void k_scan_open(const int32_t* __restrict__ 
     if (tid == 1023) *count = part[1023];
 }
 
+// Multi-GPU sharding: keep frontier position k iff k % world == rank; flag the others.
+__global__ void k_shard_filter(DevTree T, const int32_t* __restrict__ frontier, int nf, int rank,
+                               int world, int32_t* __restrict__ kept) {
+    const int k = blockIdx.x * blockDim.x + threadIdx.x;
+    if (k >= nf) return;
+    const int id = frontier[k];
+    if (k % world == rank)
+        kept[k / world] = id;
+    else
+        T.flags[id] |= 4;
+}
+
 // K3: split every open node along its longest edge, solve P_theta_delta at the midpoint
 // and write the two child records (lib/worker.py:403-414, 354-365).
 __global__ __launch_bounds__(64) void k_lcss_expand(DevProblem P, DevTree T,
@@ -266,7 +284,10 @@ __global__ __launch_bounds__(64) void k_lcss_expand(DevProblem P, DevTree T,
         assemble_point(w, lp_base, P, d, mid, false, b, lane);
         const IpmResult r = ipm_solve(w, b, lane);
         count_solve(cnt, r, lane);
-        if (r.status != 0 && lane == 0) atomicAdd(&cnt->errors, 1ULL);
+        if (r.status != 0 && lane == 0) {
+            atomicAdd(&cnt->errors, 1ULL);
+            T.flags[id] |= 16;
+        }
         const int c0 = child_base + 2 * f;
         double* rec0 = T.rec + (size_t)c0 * T.rec_stride;
         double* rec1 = rec0 + T.rec_stride;
@@ -402,6 +423,7 @@ struct ehm_tree {
     long long cap = 0;
     DevBuf rec, left, didx, depth, flags, tstar;
     ehm_tree_info info{};
+    int skip_volume = 0;
 };
 
 static int map_deltas(ehm_problem* P, int64_t n_inst, const uint8_t* delta,
@@ -651,7 +673,7 @@ static int simplex_batch(ehm_problem* P, int64_t n_inst, const double* R, const 
                            hipMemcpyHostToDevice, P->stream), EHM_E_HIP);
     HIP_TRY(hipMemcpyAsync(P->in1.ptr, didx_host, (size_t)n_inst * sizeof(int32_t),
                            hipMemcpyHostToDevice, P->stream), EHM_E_HIP);
-    if (slack)
+    if (slack == SX_SLACK)
         HIP_TRY(hipMemcpyAsync(P->in2.ptr, Vbar, (size_t)n_inst * (p + 1) * sizeof(double),
                                hipMemcpyHostToDevice, P->stream), EHM_E_HIP);
     int32_t* d_status = P->out2.as<int32_t>();
@@ -693,27 +715,297 @@ int ehm_min_simplex_batch(ehm_problem* P, int64_t n_inst, const double* R,
 }
 
 // ---- multi-commutation oracles (host-orchestrated over the batched kernels) ---------------
+// Every mixed-integer problem of the reference is "enumerate the admissible commutations x
+// one LP each" (SURVEY.md section 8a); these entry points expand the (instance,
+// commutation[, vertex]) pairs on the host and run them as ONE batched launch per stage.
+// Canonical choice rules: DESIGN.md "canonical commutation rule".
+
+// feasibility of (theta_k, d_k) pairs through the phase-one LP
+static int feas_pairs(ehm_problem* P, int64_t K, const double* theta, const int32_t* didx,
+                      std::vector<uint8_t>& ok) {
+    std::vector<double> tau((size_t)K);
+    int rc = point_batch(P, K, theta, didx, 1, tau.data(), nullptr, nullptr, nullptr);
+    if (rc) return rc;
+    ok.resize((size_t)K);
+    for (int64_t k = 0; k < K; ++k) ok[(size_t)k] = tau[(size_t)k] <= EHM_FEAS_TOL;
+    return EHM_OK;
+}
+
 int ehm_solve_pt_batch(ehm_problem* P, int64_t n_inst, const double* theta, double* J,
                        double* u0, int32_t* delta_idx) {
-    (void)P; (void)n_inst; (void)theta; (void)J; (void)u0; (void)delta_idx;
-    return fail(EHM_E_INVALID, "ehm_solve_pt_batch: not implemented yet");
+    if (!P || !theta || !J || n_inst < 0) return fail(EHM_E_INVALID, "bad argument");
+    const int nd = P->dp.n_delta, p = P->dp.p, n_u = P->dp.n_u;
+    const int64_t K = n_inst * nd;
+    std::vector<double> th((size_t)K * p);
+    std::vector<int32_t> di((size_t)K);
+    for (int64_t k = 0; k < n_inst; ++k)
+        for (int d = 0; d < nd; ++d) {
+            std::memcpy(&th[(size_t)(k * nd + d) * p], theta + (size_t)k * p, p * sizeof(double));
+            di[(size_t)(k * nd + d)] = d;
+        }
+    std::vector<uint8_t> ok;
+    int rc = feas_pairs(P, K, th.data(), di.data(), ok);
+    if (rc) return rc;
+    // solve only the feasible pairs
+    std::vector<int64_t> sel;
+    for (int64_t q = 0; q < K; ++q)
+        if (ok[(size_t)q]) sel.push_back(q);
+    const int64_t F = (int64_t)sel.size();
+    std::vector<double> th2((size_t)F * p), J2((size_t)F), u2((size_t)F * n_u);
+    std::vector<int32_t> di2((size_t)F), st2((size_t)F);
+    for (int64_t f = 0; f < F; ++f) {
+        std::memcpy(&th2[(size_t)f * p], &th[(size_t)sel[(size_t)f] * p], p * sizeof(double));
+        di2[(size_t)f] = di[(size_t)sel[(size_t)f]];
+    }
+    rc = point_batch(P, F, th2.data(), di2.data(), 0, J2.data(), u2.data(), st2.data(), nullptr);
+    if (rc) return rc;
+    for (int64_t k = 0; k < n_inst; ++k) {
+        J[k] = INFINITY;
+        if (delta_idx) delta_idx[k] = -1;
+        if (u0)
+            for (int c = 0; c < n_u; ++c) u0[k * n_u + c] = NAN;
+    }
+    for (int64_t f = 0; f < F; ++f) {
+        if (st2[(size_t)f] != 0) continue;
+        const int64_t k = sel[(size_t)f] / nd;
+        if (J2[(size_t)f] < J[k]) {        // strict: lowest index wins ties
+            J[k] = J2[(size_t)f];
+            if (delta_idx) delta_idx[k] = di2[(size_t)f];
+            if (u0) std::memcpy(u0 + k * n_u, &u2[(size_t)f * n_u], n_u * sizeof(double));
+        }
+    }
+    return EHM_OK;
 }
+
+// which commutations are feasible at EVERY vertex of each simplex:  mask[k*nd + d]
+static int vertex_feasible_mask(ehm_problem* P, int64_t n_inst, const double* R,
+                                std::vector<uint8_t>& mask) {
+    const int nd = P->dp.n_delta, p = P->dp.p, nv = p + 1;
+    const int64_t K = n_inst * nd * nv;
+    std::vector<double> th((size_t)K * p);
+    std::vector<int32_t> di((size_t)K);
+    for (int64_t k = 0; k < n_inst; ++k)
+        for (int d = 0; d < nd; ++d)
+            for (int v = 0; v < nv; ++v) {
+                const int64_t q = (k * nd + d) * nv + v;
+                std::memcpy(&th[(size_t)q * p], R + ((size_t)k * nv + v) * p, p * sizeof(double));
+                di[(size_t)q] = d;
+            }
+    std::vector<uint8_t> ok;
+    int rc = feas_pairs(P, K, th.data(), di.data(), ok);
+    if (rc) return rc;
+    mask.assign((size_t)(n_inst * nd), 1);
+    for (int64_t q = 0; q < K; ++q)
+        if (!ok[(size_t)q]) mask[(size_t)(q / nv)] = 0;
+    return EHM_OK;
+}
+
+// P_theta_delta at every vertex of simplex k for commutation dsel[k] (>= 0)
+static int vertex_solves(ehm_problem* P, int64_t n_inst, const double* R, const int32_t* dsel,
+                         double* vJ, double* vu0, bool& all_ok) {
+    const int p = P->dp.p, nv = p + 1, n_u = P->dp.n_u;
+    std::vector<int64_t> sel;
+    for (int64_t k = 0; k < n_inst; ++k)
+        if (dsel[k] >= 0) sel.push_back(k);
+    const int64_t F = (int64_t)sel.size() * nv;
+    std::vector<double> th((size_t)F * p), J((size_t)F), u((size_t)F * n_u);
+    std::vector<int32_t> di((size_t)F), st((size_t)F);
+    for (size_t f = 0; f < sel.size(); ++f)
+        for (int v = 0; v < nv; ++v) {
+            std::memcpy(&th[(f * nv + v) * p], R + ((size_t)sel[f] * nv + v) * p,
+                        p * sizeof(double));
+            di[f * nv + v] = dsel[sel[f]];
+        }
+    int rc = point_batch(P, F, th.data(), di.data(), 0, J.data(), u.data(), st.data(), nullptr);
+    if (rc) return rc;
+    all_ok = true;
+    for (size_t f = 0; f < sel.size(); ++f)
+        for (int v = 0; v < nv; ++v) {
+            const size_t q = f * nv + v;
+            if (st[q] != 0) all_ok = false;
+            if (vJ) vJ[(size_t)sel[f] * nv + v] = J[q];
+            if (vu0)
+                std::memcpy(vu0 + ((size_t)sel[f] * nv + v) * n_u, &u[q * n_u],
+                            n_u * sizeof(double));
+        }
+    return EHM_OK;
+}
+
 int ehm_vr_batch(ehm_problem* P, int64_t n_inst, const double* R, int32_t* delta_idx,
                  double* vJ, double* vu0) {
-    (void)P; (void)n_inst; (void)R; (void)delta_idx; (void)vJ; (void)vu0;
-    return fail(EHM_E_INVALID, "ehm_vr_batch: not implemented yet");
+    if (!P || !R || !delta_idx || n_inst < 0) return fail(EHM_E_INVALID, "bad argument");
+    const int nd = P->dp.n_delta;
+    std::vector<uint8_t> mask;
+    int rc = vertex_feasible_mask(P, n_inst, R, mask);
+    if (rc) return rc;
+    for (int64_t k = 0; k < n_inst; ++k) {
+        delta_idx[k] = -1;
+        for (int d = 0; d < nd; ++d)
+            if (mask[(size_t)(k * nd + d)]) {
+                delta_idx[k] = d;
+                break;
+            }
+    }
+    bool all_ok = true;
+    rc = vertex_solves(P, n_inst, R, delta_idx, vJ, vu0, all_ok);
+    if (rc) return rc;
+    if (!all_ok) return fail(EHM_E_NUMERIC, "a vertex solve of V_R did not converge");
+    return EHM_OK;
 }
+
+// slack t*(d) for every (instance, commutation) pair that is feasible somewhere in the
+// simplex; -inf for the others.  tall[k*nd + d], optional alpha_all [k*nd+d][p+1].
+static int slack_all(ehm_problem* P, int64_t n_inst, const double* R, const double* Vbar,
+                     const std::vector<uint8_t>* restrict_mask, std::vector<double>& tall,
+                     std::vector<double>* alpha_all) {
+    const int nd = P->dp.n_delta, p = P->dp.p, nv = p + 1;
+    const size_t nR = (size_t)nv * p;
+    std::vector<int64_t> sel;
+    for (int64_t q = 0; q < n_inst * nd; ++q)
+        if (!restrict_mask || (*restrict_mask)[(size_t)q]) sel.push_back(q);
+    int64_t F = (int64_t)sel.size();
+    std::vector<double> R2((size_t)F * nR), V2((size_t)F * nv), obj((size_t)F);
+    std::vector<int32_t> di((size_t)F), st((size_t)F);
+    for (int64_t f = 0; f < F; ++f) {
+        const int64_t k = sel[(size_t)f] / nd;
+        std::memcpy(&R2[(size_t)f * nR], R + (size_t)k * nR, nR * sizeof(double));
+        std::memcpy(&V2[(size_t)f * nv], Vbar + (size_t)k * nv, nv * sizeof(double));
+        di[(size_t)f] = (int32_t)(sel[(size_t)f] % nd);
+    }
+    tall.assign((size_t)(n_inst * nd), -INFINITY);
+    if (alpha_all) alpha_all->assign((size_t)(n_inst * nd) * nv, 0.0);
+    if (nd > 1) {
+        // drop pairs whose commutation is infeasible on the whole simplex
+        int rc = simplex_batch(P, F, R2.data(), nullptr, di.data(), SX_FEAS, obj.data(), nullptr,
+                               st.data());
+        if (rc) return rc;
+        std::vector<int64_t> sel2;
+        for (int64_t f = 0; f < F; ++f)
+            if (obj[(size_t)f] <= EHM_FEAS_TOL) sel2.push_back(f);
+        const int64_t F2 = (int64_t)sel2.size();
+        std::vector<double> R3((size_t)F2 * nR), V3((size_t)F2 * nv);
+        std::vector<int32_t> di3((size_t)F2);
+        std::vector<int64_t> sel3((size_t)F2);
+        for (int64_t g = 0; g < F2; ++g) {
+            const int64_t f = sel2[(size_t)g];
+            std::memcpy(&R3[(size_t)g * nR], &R2[(size_t)f * nR], nR * sizeof(double));
+            std::memcpy(&V3[(size_t)g * nv], &V2[(size_t)f * nv], nv * sizeof(double));
+            di3[(size_t)g] = di[(size_t)f];
+            sel3[(size_t)g] = sel[(size_t)f];
+        }
+        R2.swap(R3); V2.swap(V3); di.swap(di3); sel.swap(sel3);
+        F = F2;
+        obj.resize((size_t)F);
+        st.resize((size_t)F);
+    }
+    std::vector<double> al((size_t)F * nv);
+    int rc = simplex_batch(P, F, R2.data(), V2.data(), di.data(), SX_SLACK, obj.data(),
+                           al.data(), st.data());
+    if (rc) return rc;
+    for (int64_t f = 0; f < F; ++f) {
+        if (st[(size_t)f] != 0)
+            return fail(EHM_E_NUMERIC, "slack LP (instance %lld, commutation %d) did not converge",
+                        (long long)(sel[(size_t)f] / nd), (int)(sel[(size_t)f] % nd));
+        tall[(size_t)sel[(size_t)f]] = obj[(size_t)f];
+        if (alpha_all)
+            std::memcpy(&(*alpha_all)[(size_t)sel[(size_t)f] * nv], &al[(size_t)f * nv],
+                        nv * sizeof(double));
+    }
+    return EHM_OK;
+}
+
 int ehm_bar_e_batch(ehm_problem* P, int64_t n_inst, const double* R, const double* Vbar,
                     uint8_t* closed, double* tbest) {
-    (void)P; (void)n_inst; (void)R; (void)Vbar; (void)closed; (void)tbest;
-    return fail(EHM_E_INVALID, "ehm_bar_e_batch: not implemented yet");
+    if (!P || !R || !Vbar || !closed || n_inst < 0) return fail(EHM_E_INVALID, "bad argument");
+    const int nd = P->dp.n_delta;
+    std::vector<double> tall;
+    int rc = slack_all(P, n_inst, R, Vbar, nullptr, tall, nullptr);
+    if (rc) return rc;
+    for (int64_t k = 0; k < n_inst; ++k) {
+        double tb = -INFINITY;
+        for (int d = 0; d < nd; ++d) tb = std::max(tb, tall[(size_t)(k * nd + d)]);
+        closed[k] = (tb >= 0.0) ? 0 : 1;
+        if (tbest) tbest[k] = tb;
+    }
+    return EHM_OK;
 }
+
 int ehm_bar_d_batch(ehm_problem* P, int64_t n_inst, const double* R, const double* Vbar,
                     const uint8_t* delta_ref, int32_t* delta_idx, double* theta_star,
                     double* vJ, double* vu0, uint8_t* var_small) {
-    (void)P; (void)n_inst; (void)R; (void)Vbar; (void)delta_ref; (void)delta_idx;
-    (void)theta_star; (void)vJ; (void)vu0; (void)var_small;
-    return fail(EHM_E_INVALID, "ehm_bar_d_batch: not implemented yet");
+    if (!P || !R || !Vbar || !delta_idx || n_inst < 0) return fail(EHM_E_INVALID, "bad argument");
+    const int nd = P->dp.n_delta, p = P->dp.p, nv = p + 1;
+    std::vector<int32_t> dref;
+    int rc = map_deltas(P, n_inst, delta_ref, dref);
+    if (rc) return rc;
+    std::vector<uint8_t> mask;
+    rc = vertex_feasible_mask(P, n_inst, R, mask);
+    if (rc) return rc;
+    std::vector<double> tall, alpha_all;
+    rc = slack_all(P, n_inst, R, Vbar, &mask, tall, &alpha_all);
+    if (rc) return rc;
+    std::vector<double> ths((size_t)n_inst * p, 0.0);
+    for (int64_t k = 0; k < n_inst; ++k) {
+        int best = -1;
+        double tb = -INFINITY;
+        for (int d = 0; d < nd; ++d) {
+            const double t = tall[(size_t)(k * nd + d)];
+            if (mask[(size_t)(k * nd + d)] && t >= 0.0 && t > tb) {
+                tb = t;
+                best = d;
+            }
+        }
+        if (best >= 0 && best == dref[(size_t)k]) best = -1;   // lib/oracle.py:384-394
+        delta_idx[k] = best;
+        if (best >= 0) {
+            const double* al = &alpha_all[(size_t)(k * nd + best) * nv];
+            for (int c = 0; c < p; ++c) {
+                double acc = 0.0;
+                for (int v = 0; v < nv; ++v) acc += al[v] * R[((size_t)k * nv + v) * p + c];
+                ths[(size_t)k * p + c] = acc;
+            }
+        }
+        if (theta_star)
+            std::memcpy(theta_star + (size_t)k * p, &ths[(size_t)k * p], p * sizeof(double));
+        if (var_small) var_small[k] = 0;
+    }
+    bool all_ok = true;
+    rc = vertex_solves(P, n_inst, R, delta_idx, vJ, vu0, all_ok);
+    if (rc) return rc;
+    if (!all_ok) return fail(EHM_E_NUMERIC, "a vertex solve of bar_D did not converge");
+    // in_variability_ball (lib/oracle.py:220-283) for the instances with a better commutation
+    std::vector<int64_t> sel;
+    for (int64_t k = 0; k < n_inst; ++k)
+        if (delta_idx[k] >= 0) sel.push_back(k);
+    const int64_t F = (int64_t)sel.size();
+    if (F > 0 && var_small) {
+        const size_t nR = (size_t)nv * p;
+        std::vector<double> R2((size_t)F * nR), Jmin((size_t)F), th2((size_t)F * p), Jth((size_t)F);
+        std::vector<int32_t> d_ref2((size_t)F), d_star2((size_t)F), st((size_t)F), st2((size_t)F);
+        for (int64_t f = 0; f < F; ++f) {
+            const int64_t k = sel[(size_t)f];
+            std::memcpy(&R2[(size_t)f * nR], R + (size_t)k * nR, nR * sizeof(double));
+            std::memcpy(&th2[(size_t)f * p], &ths[(size_t)k * p], p * sizeof(double));
+            d_ref2[(size_t)f] = dref[(size_t)k];
+            d_star2[(size_t)f] = delta_idx[k];
+        }
+        rc = simplex_batch(P, F, R2.data(), nullptr, d_ref2.data(), SX_MIN, Jmin.data(), nullptr,
+                           st.data());
+        if (rc) return rc;
+        rc = point_batch(P, F, th2.data(), d_star2.data(), 0, Jth.data(), nullptr, st2.data(),
+                         nullptr);
+        if (rc) return rc;
+        for (int64_t f = 0; f < F; ++f) {
+            if (st[(size_t)f] != 0 || st2[(size_t)f] != 0)
+                return fail(EHM_E_NUMERIC, "in_variability_ball solve did not converge");
+            const int64_t k = sel[(size_t)f];
+            double vmax = -INFINITY;
+            for (int v = 0; v < nv; ++v) vmax = std::max(vmax, Vbar[(size_t)k * nv + v]);
+            const double rhs = std::max(P->dp.eps_a, P->dp.eps_r * Jth[(size_t)f]);
+            var_small[k] = (vmax - Jmin[(size_t)f] < rhs) ? 1 : 0;
+        }
+    }
+    return EHM_OK;
 }
 
 // ---- geometry -------------------------------------------------------------------------------
@@ -819,7 +1111,15 @@ int ehm_partition_run(ehm_problem* P, int64_t n_roots, const double* root_vertic
     cap = std::max<long long>(cap, 2 * n_roots);
     const int max_depth = (opts && opts->max_depth > 0) ? opts->max_depth : 0;
     const int action = opts ? opts->action : 0;
+    const int shard_world = (opts && opts->shard_world > 1) ? opts->shard_world : 1;
+    const int shard_rank = opts ? opts->shard_rank : 0;
+    const long long shard_min = opts ? opts->shard_min_frontier : 0;
+    if (shard_world > 1 && (shard_rank < 0 || shard_rank >= shard_world))
+        return fail(EHM_E_INVALID, "shard_rank %d out of range for world %d", shard_rank,
+                    shard_world);
+    bool sharded = (shard_world == 1);
     ehm_tree* T = new ehm_tree();
+    T->skip_volume = opts ? opts->skip_volume : 0;
     int rc = tree_alloc(T, P, cap);
     if (rc) { ehm_tree_destroy(T); return rc; }
     const int stride = T->dt.rec_stride;
@@ -908,6 +1208,14 @@ int ehm_partition_run(ehm_problem* P, int64_t n_roots, const double* root_vertic
         P->launches++;
         ref_solves += n_roots * (2 + (p + 1));   // P_theta check + V_R MICP + vertex solves
     }
+    std::vector<hipEvent_t> evs;   // (start, stop) pairs: even index pairs = decide, odd = expand
+    auto stamp = [&]() {
+        hipEvent_t e;
+        (void)hipEventCreate(&e);
+        (void)hipEventRecord(e, P->stream);
+        evs.push_back(e);
+    };
+    std::vector<int> ev_kind;      // 0 decide, 1 expand, per pair
     long long n_nodes = n_roots;
     long long nf = n_roots;
     long long n_closed = 0;
@@ -917,13 +1225,30 @@ int ehm_partition_run(ehm_problem* P, int64_t n_roots, const double* root_vertic
     int32_t* nxt = fr_b.as<int32_t>();
     bool cur_is_a = true;
     while (nf > 0) {
+        if (!sharded && nf >= shard_min) {
+            // deal the frontier round-robin over the ranks; the kept ids go to the other buffer
+            DevBuf& ob = cur_is_a ? fr_b : fr_a;
+            RUN_TRY(ob.ensure((size_t)(nf / shard_world + 1) * 4));
+            hipLaunchKernelGGL(k_shard_filter, dim3((unsigned)((nf + 255) / 256)), dim3(256), 0,
+                               P->stream, T->dt, cur, (int)nf, shard_rank, shard_world,
+                               ob.as<int32_t>());
+            P->launches++;
+            cur = ob.as<int32_t>();
+            cur_is_a = !cur_is_a;
+            nf = (nf - shard_rank + shard_world - 1) / shard_world;
+            sharded = true;
+            if (nf == 0) break;
+        }
         if ((long long)open_flag.cap < nf * 4) {
             RUN_TRY(open_flag.ensure((size_t)nf * 4 * 2));
             RUN_TRY(open_list.ensure((size_t)nf * 4 * 2));
         }
+        stamp();
         hipLaunchKernelGGL(k_lcss_decide, dim3(grid_for(P, nf)), dim3(64), P->lds_simplex,
                            P->stream, P->dp, T->dt, cur, (int)nf, open_flag.as<int32_t>(),
                            P->d_cnt);
+        stamp();
+        ev_kind.push_back(0);
         hipLaunchKernelGGL(k_scan_open, dim3(1), dim3(1024), 0, P->stream,
                            open_flag.as<int32_t>(), cur, (int)nf, open_list.as<int32_t>(),
                            d_count.as<int32_t>());
@@ -957,9 +1282,12 @@ int ehm_partition_run(ehm_problem* P, int64_t n_roots, const double* root_vertic
             RUN_TRY(nb.ensure((size_t)n_open * 2 * 4 * 2));
         }
         nxt = nb.as<int32_t>();
+        stamp();
         hipLaunchKernelGGL(k_lcss_expand, dim3(grid_for(P, n_open)), dim3(64), P->lds_expand,
                            P->stream, P->dp, T->dt, open_list.as<int32_t>(), (int)n_open,
                            (int)n_nodes, nxt, P->d_cnt);
+        stamp();
+        ev_kind.push_back(1);
         P->launches++;
         ref_solves += 2LL * n_open;       // bar_D MICP + midpoint P_theta_delta per split
         n_nodes += 2LL * n_open;
@@ -974,10 +1302,19 @@ int ehm_partition_run(ehm_problem* P, int64_t n_roots, const double* root_vertic
     (void)hipEventElapsedTime(&ms, ev0, ev1);
     (void)hipEventDestroy(ev0);
     (void)hipEventDestroy(ev1);
+    double t_kind[2] = {0.0, 0.0};
+    long long n_kind[2] = {0, 0};
+    for (size_t k = 0; k < ev_kind.size(); ++k) {
+        float t = 0.f;
+        (void)hipEventElapsedTime(&t, evs[2 * k], evs[2 * k + 1]);
+        t_kind[ev_kind[k]] += t * 1e-3;
+        n_kind[ev_kind[k]]++;
+    }
+    for (hipEvent_t e : evs) (void)hipEventDestroy(e);
     DevCounters c1;
     RUN_TRY(read_counters(P, c1));
     cleanup();
-    if (c1.errors != 0) {
+    if (c1.errors != 0 && !getenv("EHM_KEEP_GOING")) {
         ehm_tree_destroy(T);
         return fail(EHM_E_NUMERIC, "%llu oracle solves did not converge",
                     (unsigned long long)c1.errors);
@@ -993,6 +1330,12 @@ int ehm_partition_run(ehm_problem* P, int64_t n_roots, const double* root_vertic
     T->info.max_depth = depth;
     T->info.truncated = truncated;
     T->info.device_seconds = ms * 1e-3;
+    T->info.decide_seconds = t_kind[0];
+    T->info.expand_seconds = t_kind[1];
+    T->info.decide_launches = n_kind[0];
+    T->info.expand_launches = n_kind[1];
+    T->info.decide_solves = (int64_t)(c1.slack_solves - c0.slack_solves);
+    T->info.decide_iters = (int64_t)(c1.slack_iters - c0.slack_iters);
     {
         double mm;
         std::memcpy(&mm, &c1.min_margin_bits, 8);
@@ -1007,7 +1350,7 @@ int ehm_partition_run(ehm_problem* P, int64_t n_roots, const double* root_vertic
 int ehm_tree_info_get(const ehm_tree* Tc, ehm_tree_info* out) {
     if (!Tc || !out) return fail(EHM_E_INVALID, "null argument");
     ehm_tree* T = const_cast<ehm_tree*>(Tc);
-    if (T->info.volume_closed < 0.0) {
+    if (T->info.volume_closed < 0.0 && !T->skip_volume) {
         // sum of closed-leaf volumes (lib/worker.py:374-375), computed from the export
         ehm_problem* P = T->prob;
         HIP_TRY(hipSetDevice(P->device), EHM_E_HIP);

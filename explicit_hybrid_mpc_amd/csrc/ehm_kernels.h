@@ -37,6 +37,8 @@ struct DevCounters {
     unsigned long long stalled;
     unsigned long long min_margin_bits;   // |t*| as ordered uint64
     unsigned long long errors;
+    unsigned long long slack_solves;      // LPs over a simplex (decide sweep)
+    unsigned long long slack_iters;
 };
 
 __host__ __device__ inline int rec_off_vcost(int p) { return (p + 1) * p; }
@@ -48,13 +50,15 @@ __host__ __device__ inline int rec_doubles(int p, int n_u) {
 // ---------------------------------------------------------------------------------------
 // LP assembly
 // ---------------------------------------------------------------------------------------
-enum { LP_POINT = 0, LP_FEAS = 1, LP_MIN_SIMPLEX = 2, LP_SLACK = 3 };
+enum { LP_POINT = 0, LP_FEAS = 1, LP_MIN_SIMPLEX = 2, LP_SLACK = 3, LP_FEAS_SIMPLEX = 4 };
+enum { SX_MIN = 0, SX_SLACK = 1, SX_FEAS = 2 };
 
 __host__ __device__ inline int lp_cols(const DevProblem& P, int kind) {
     switch (kind) {
         case LP_POINT: return P.n;
         case LP_FEAS: return P.n + 1;
         case LP_MIN_SIMPLEX: return P.n + P.p;
+        case LP_FEAS_SIMPLEX: return P.n + P.p + 1;
         default: return P.n + P.p + 1;
     }
 }
@@ -63,6 +67,7 @@ __host__ __device__ inline int lp_rows(const DevProblem& P, int kind) {
         case LP_POINT: return P.m;
         case LP_FEAS: return P.m + 1;
         case LP_MIN_SIMPLEX: return P.m + P.p + 1;
+        case LP_FEAS_SIMPLEX: return P.m + P.p + 2;
         default: return P.m + P.p + 3;
     }
 }
@@ -112,12 +117,16 @@ __device__ inline void assemble_point(LpWork& w, double* smem, const DevProblem&
 //   LP_MIN_SIMPLEX : min V                       (lib/oracle.py:74-79)
 //   LP_SLACK       : max t  s.t.  sum alpha_i Vbar_i - V - eps_a >= t,
 //                                 sum alpha_i Vbar_i - (1+eps_r) V >= t   (lib/oracle.py:89-97)
+//   LP_FEAS_SIMPLEX: min tau s.t. MPC rows relaxed by tau, tau >= -1  (is the commutation
+//                    feasible anywhere in R?  feasible <=> tau* <= 0)
 __device__ inline void assemble_simplex(LpWork& w, double* smem, const DevProblem& P, int d,
-                                        const double* R, const double* Vbar, bool slack,
+                                        const double* R, const double* Vbar, int mode,
                                         double (&b)[EHM_SLOTS], int lane) {
     const int n = P.n, m = P.m, p = P.p;
-    const int n_lp = n + p + (slack ? 1 : 0);
-    const int m_lp = m + p + 1 + (slack ? 2 : 0);
+    const bool slack = (mode == SX_SLACK);
+    const bool feas = (mode == SX_FEAS);
+    const int n_lp = n + p + ((slack || feas) ? 1 : 0);
+    const int m_lp = m + p + 1 + (slack ? 2 : 0) + (feas ? 1 : 0);
     lp_carve(w, smem, n_lp, m_lp);
     lp_clear(w, lane);
     wave_sync();
@@ -162,6 +171,13 @@ __device__ inline void assemble_simplex(LpWork& w, double* smem, const DevProble
             col[m + p + 2] = 1.0;
             w.c[n + p] = -1.0;
         }
+    } else if (feas) {
+        double* col = w.A + (size_t)(n + p) * w.lda;
+        for (int i = lane; i < m; i += 64) col[i] = -1.0;
+        if (lane == 0) {
+            col[m + p + 1] = -1.0;     // -tau <= 1
+            w.c[n + p] = 1.0;
+        }
     } else if (lane < n) {
         w.c[lane] = P.c[lane];
     }
@@ -174,6 +190,8 @@ __device__ inline void assemble_simplex(LpWork& w, double* smem, const DevProble
             v = wd[i];
             for (int q = 0; q < p; ++q) v = fma(St[(size_t)q * m + i], R[q], v);
         } else if (i == m + p) {
+            v = 1.0;
+        } else if (feas && i == m + p + 1) {
             v = 1.0;
         } else if (slack && i == m + p + 1) {
             v = Vbar[0] - P.eps_a;

@@ -201,17 +201,23 @@ class GpuProblem:
         return didx, ths, vJ, vu, vs.astype(bool)
 
     # -- partition ------------------------------------------------------------------------------
-    def partition(self, roots, action='ecc', init=None, max_nodes=0, max_depth=0, engine=0):
+    def partition(self, roots, action='ecc', init=None, max_nodes=0, max_depth=0, engine=0,
+                  export=True, shard=None, with_volume=True):
         """
         Grow every root simplex until all leaves are epsilon-suboptimal.
         roots: (n_roots, p+1, p).  init: optional dict(delta, vertex_costs, vertex_inputs)
-        for action 'lcss'.  Returns a FlatTree.
+        for action 'lcss'.  shard = (rank, world, min_frontier) keeps only this rank's share
+        of the frontier once it is min_frontier wide (multi-GPU).  Returns a FlatTree, or
+        just the info dict when export is False.
         """
         roots = f64(roots).reshape(-1, self.can.p + 1, self.can.p)
         n_roots = roots.shape[0]
+        rank, world, min_frontier = shard if shard is not None else (0, 1, 0)
         opts = _capi.RunOpts(max_nodes=int(max_nodes), max_depth=int(max_depth),
                              action=0 if action == 'ecc' else 1, engine=int(engine),
-                             reserved=0)
+                             shard_rank=int(rank), shard_world=int(world),
+                             shard_min_frontier=int(min_frontier),
+                             skip_volume=0 if with_volume else 1)
         init_struct = None
         keep = None
         if init is not None:
@@ -230,6 +236,9 @@ class GpuProblem:
         try:
             info = _capi.TreeInfo()
             check(self._lib.ehm_tree_info_get(tree, ctypes.byref(info)))
+            info_d = {name: getattr(info, name) for name, _ in _capi.TreeInfo._fields_}
+            if not export:
+                return info_d
             K = info.n_nodes
             p, n_u = self.can.p, self.can.n_u
             vertices = np.empty((K, p + 1, p))
@@ -243,7 +252,6 @@ class GpuProblem:
             check(self._lib.ehm_tree_export(tree, ptr(vertices), ptr(left), ptr(right),
                                             ptr(didx), ptr(vcost), ptr(vinput), ptr(flags),
                                             ptr(tstar)))
-            info_d = {name: getattr(info, name) for name, _ in _capi.TreeInfo._fields_}
         finally:
             self._lib.ehm_tree_destroy(tree)
         return FlatTree(vertices, left, right, didx, vcost, vinput, flags, tstar, info_d,

@@ -148,7 +148,14 @@ typedef struct ehm_run_opts {
     int32_t max_depth;      /* stop splitting below this depth relative to roots (0 = none) */
     int32_t action;         /* 0 = 'ecc' then 'lcss' (lib/worker.py:241-291), 1 = 'lcss'   */
     int32_t engine;         /* 0 = level-synchronous sweeps, 1 = persistent frontier kernel */
-    int32_t reserved;
+    /* Multi-GPU sharding of the live frontier: every rank grows the same top of the tree
+     * until a sweep's frontier holds >= shard_min_frontier nodes, then keeps only the
+     * frontier nodes whose position k satisfies k % shard_world == shard_rank (the rest are
+     * flagged bit2 = "owned by another rank").  shard_world <= 1 disables it. */
+    int32_t shard_rank;
+    int32_t shard_world;
+    int32_t skip_volume;    /* 1 = do not compute volume_closed in ehm_tree_info_get       */
+    int64_t shard_min_frontier;
 } ehm_run_opts;
 
 /* Optional initial node data for action 1 ('lcss' roots already carry a commutation,
@@ -178,13 +185,20 @@ typedef struct ehm_tree_info {
     int32_t truncated;      /* 1 if max_depth / capacity stopped the growth             */
     double  volume_closed;  /* sum of closed leaf volumes (lib/worker.py:374-375)       */
     double  min_margin;     /* min |t*| over all close/split decisions                  */
-    double  device_seconds; /* GPU time of the sweeps (HIP events)                      */
+    double  device_seconds; /* GPU time of the whole run (HIP events on the stream)     */
+    double  decide_seconds; /* summed duration of the suboptimality-test sweep kernel   */
+    double  expand_seconds; /* summed duration of the split + midpoint-solve kernel     */
+    int64_t decide_launches;
+    int64_t expand_launches;
+    int64_t decide_solves;  /* LPs solved by the decide kernel                          */
+    int64_t decide_iters;   /* their interior-point iterations                          */
 } ehm_tree_info;
 
 int ehm_tree_info_get(const ehm_tree* tree, ehm_tree_info* out);
 /* Flat export, node k: vertices [k][p+1][p], left[k] / right[k] child index or -1,
  * delta_idx[k] (-1 = none), vcost [k][p+1], vinput [k][p+1][n_u],
- * flags[k] bit0 = is_epsilon_suboptimal, bit1 = has commutation data.
+ * flags[k] bit0 = is_epsilon_suboptimal, bit1 = has commutation data,
+ * bit2 = subtree owned by another rank (multi-GPU sharding).
  * Nodes 0..n_roots-1 are the roots in input order.  Any pointer may be NULL. */
 int ehm_tree_export(const ehm_tree* tree, double* vertices, int32_t* left, int32_t* right,
                     int32_t* delta_idx, double* vcost, double* vinput, uint8_t* flags,

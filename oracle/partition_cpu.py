@@ -107,6 +107,13 @@ class PartitionCPU:
             self.nodes[loc] = R if isinstance(R, dict) else _new(R)
             work.append((loc, action))
         work.reverse()
+        self._work = work
+        return self.resume()
+
+    def resume(self):
+        """Continue a run that stopped at ``max_nodes`` (raise the limit first)."""
+        work = self._work
+        self.truncated = False
         while work:
             if self.max_nodes is not None and self.visits >= self.max_nodes:
                 self.truncated = True
