@@ -38,10 +38,10 @@
 // of the tolerances (the merit of an infeasible-start method is not monotone early on)
 #define EHM_STALL_ZONE  1e4
 // a stalled solve whose best iterate is within this factor of the tolerances (residuals and
-// gap <= 1e-8 relative) is accepted, like the reference accepts OPTIMAL_INACCURATE
+// gap <= 1e-7 relative) is accepted, like the reference accepts OPTIMAL_INACCURATE
 // (lib/oracle.py:440-442): the floor of the dual residual in double precision sits at
 // ~1e-10 for the worst-conditioned instances
-#define EHM_ACCEPT_MERIT 1e2
+#define EHM_ACCEPT_MERIT 1e3
 
 namespace ehm {
 

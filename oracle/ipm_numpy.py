@@ -79,9 +79,10 @@ class IPMResult:
     __slots__ = ('x', 'obj', 'status', 'iters', 'lam', 'res', 'merit')
 
 
+PROX_REL = 1e-9       # relative proximal term added to the diagonal of the normal matrix
 PIVOT_REL = 1e-13     # a pivot below PIVOT_REL * (its original diagonal) is a dependent column
 PIVOT_BIG = 1e128     # replacing it by this zeroes the corresponding solution component
-ACCEPT_MERIT = 1e2    # stalled but within 100x of the tolerances: accepted (OPTIMAL_INACCURATE)
+ACCEPT_MERIT = 1e3    # stalled but within 1000x of the tolerances: accepted (OPTIMAL_INACCURATE)
 STALL_ZONE = 1e4      # non-improving iterations count as a stall only this close to the tolerances
 
 
@@ -117,7 +118,8 @@ def chol_solve(L, rhs):
     return y
 
 
-def solve_lp(c, A, b, max_iter=40, tol_res=1e-8, tol_gap=1e-9, step_frac=0.99):
+def solve_lp(c, A, b, max_iter=40, tol_res=1e-10, tol_gap=1e-10, step_frac=0.99,
+             prox=PROX_REL):
     """
     min c^T x  s.t.  A x <= b.
     status: 0 optimal (all three relative criteria met), 1 stalled / iteration limit
@@ -156,6 +158,9 @@ def solve_lp(c, A, b, max_iter=40, tol_res=1e-8, tol_gap=1e-9, step_frac=0.99):
             break
         dvec = lam / s
         M = A.T @ (dvec[:, None] * A)
+        # proximal (primal) regularisation relative to each column's own scale: bounds the
+        # condition number of the scaled normal matrix by 1/prox on degenerate LPs
+        M[np.diag_indices(n)] *= (1. + prox)
         L = guarded_cholesky(M)
 
         def solve(rc):
