@@ -638,6 +638,9 @@ int ehm_solve_ptd_batch(ehm_problem* P, int64_t n_inst, const double* theta,
 // feasibility margin: the phase-one optimum is compared against a tolerance that is far
 // above the solver accuracy (1e-10 relative) and far below any constraint scale
 #define EHM_FEAS_TOL 1e-8
+// optimal values of different commutations closer than this (relative to 1+|value|) are
+// ties, broken by enumeration order (DESIGN.md "canonical commutation rule")
+#define EHM_TIE_TOL 1e-6
 
 int ehm_feas_ptd_batch(ehm_problem* P, int64_t n_inst, const double* theta,
                        const uint8_t* delta, uint8_t* feasible, double* tau) {
@@ -765,10 +768,20 @@ int ehm_solve_pt_batch(ehm_problem* P, int64_t n_inst, const double* theta, doub
         if (u0)
             for (int c = 0; c < n_u; ++c) u0[k * n_u + c] = NAN;
     }
+    std::vector<double> Jmin((size_t)n_inst, INFINITY);
     for (int64_t f = 0; f < F; ++f) {
         if (st2[(size_t)f] != 0) continue;
         const int64_t k = sel[(size_t)f] / nd;
-        if (J2[(size_t)f] < J[k]) {        // strict: lowest index wins ties
+        Jmin[(size_t)k] = std::min(Jmin[(size_t)k], J2[(size_t)f]);
+    }
+    std::vector<uint8_t> done((size_t)n_inst, 0);
+    for (int64_t f = 0; f < F; ++f) {      // f ascends with the commutation index
+        if (st2[(size_t)f] != 0) continue;
+        const int64_t k = sel[(size_t)f] / nd;
+        if (done[(size_t)k]) continue;
+        const double jm = Jmin[(size_t)k];
+        if (J2[(size_t)f] <= jm + EHM_TIE_TOL * (1.0 + std::fabs(jm))) {
+            done[(size_t)k] = 1;
             J[k] = J2[(size_t)f];
             if (delta_idx) delta_idx[k] = di2[(size_t)f];
             if (u0) std::memcpy(u0 + k * n_u, &u2[(size_t)f * n_u], n_u * sizeof(double));
@@ -950,10 +963,13 @@ int ehm_bar_d_batch(ehm_problem* P, int64_t n_inst, const double* R, const doubl
         double tb = -INFINITY;
         for (int d = 0; d < nd; ++d) {
             const double t = tall[(size_t)(k * nd + d)];
-            if (mask[(size_t)(k * nd + d)] && t >= 0.0 && t > tb) {
-                tb = t;
+            if (mask[(size_t)(k * nd + d)] && t >= 0.0) tb = std::max(tb, t);
+        }
+        for (int d = 0; d < nd && best < 0; ++d) {
+            const double t = tall[(size_t)(k * nd + d)];
+            if (mask[(size_t)(k * nd + d)] && t >= 0.0 &&
+                t >= tb - EHM_TIE_TOL * (1.0 + std::fabs(tb)))
                 best = d;
-            }
         }
         if (best >= 0 && best == dref[(size_t)k]) best = -1;   // lib/oracle.py:384-394
         delta_idx[k] = best;

@@ -169,3 +169,45 @@ THETA_SCALE.update({
     'pwa_nx4_nu2_N5_seed2': 0.4866,   # max feasible 0.5408
     'chain_nx6_N10': 0.6590,   # max feasible 0.7323
 })
+
+
+# ---------------------------------------------------------------------------------------
+# oracle factory and example dispatcher (lib/examples.py:18-47, 165-180)
+# ---------------------------------------------------------------------------------------
+def create_oracle(mpc, set_vrep, abs_frac, abs_err, rel_err, device=0):
+    """
+    Same contract as lib/examples.py:18-47: if ``abs_err`` is None it becomes the largest
+    optimal cost of P_theta over the ``abs_frac``-scaled vertices of the set (evaluated as
+    one batched GPU call instead of 2^p MOSEK solves).
+    """
+    from .oracle import Oracle
+    oracle = Oracle(mpc, eps_a=1., eps_r=1., device=device)
+    if abs_err is None:
+        J, _, didx = oracle.gpu.solve_pt(abs_frac * np.asarray(set_vrep, dtype=np.float64))
+        if (didx < 0).any():
+            raise RuntimeError('scaled vertex of the set is infeasible')
+        abs_err = float(np.max(J))
+    oracle.eps_a = abs_err
+    oracle.eps_r = rel_err
+    oracle.gpu.set_eps(abs_err, rel_err)
+    return oracle
+
+
+EXAMPLES = {
+    'double_integrator': lambda: double_integrator(3),
+    'linear': lambda: linear_mpc(0),
+    'pwa': lambda: pwa_mpc(0),
+}
+
+
+def example(name, abs_frac=0.5, abs_err=None, rel_err=2.0, device=0):
+    """
+    (full_set, partition, oracle) like lib/examples.py:165-180: the vertices of the set to
+    partition, its Delaunay pre-partition as a right-spine Tree, and the oracle.
+    """
+    from . import tools
+    mpc = EXAMPLES[name]()
+    full_set = box_vertices(theta_box(mpc))
+    partition, _, _ = tools.delaunay(full_set)
+    oracle = create_oracle(mpc, full_set, abs_frac, abs_err, rel_err, device=device)
+    return full_set, partition, oracle

@@ -1,0 +1,267 @@
+"""
+Partition algorithms with the reference's entry points (lib/worker.py:180-185, 241-417):
+
+    alg_call(which_alg, branch, location)   ->  grows ``branch`` (a ``tree.Tree``) in place
+
+``ecc`` builds the feasible-commutation partition and continues with ``lcss``;
+``lcss`` refines until every leaf is epsilon-suboptimal.  The recursion, MPI off-loading
+and per-node Python oracle calls of the reference are replaced by frontier sweeps on the
+GPU: single-commutation problems run entirely inside ``ehm_partition_run``
+(level-synchronous sweeps, one wavefront per node); multi-commutation (hybrid) problems
+are driven from here, one batched kernel launch per oracle kind and sweep.
+
+The per-node semantics are the reference's; the grown tree does
+not depend on the visiting order because a node's fate depends only on its own record.
+"""
+
+import numpy as np
+
+from . import engine
+from .engine import FlatTree
+from .tree import Tree, NodeData
+
+
+# ---------------------------------------------------------------------------------------
+# hybrid (multi-commutation) driver on top of the batched oracles
+# ---------------------------------------------------------------------------------------
+class _Pool:
+    """Growable struct-of-arrays node pool (host side of the hybrid driver)."""
+
+    def __init__(self, p, n_u):
+        self.p, self.n_u = p, n_u
+        self.vertices, self.left, self.right = [], [], []
+        self.didx, self.vcost, self.vinput, self.flags, self.tstar = [], [], [], [], []
+
+    def add(self, R, didx=-1, vcost=None, vinput=None):
+        p, n_u = self.p, self.n_u
+        self.vertices.append(np.array(R, dtype=np.float64))
+        self.left.append(-1)
+        self.right.append(-1)
+        self.didx.append(int(didx))
+        self.vcost.append(np.zeros(p + 1) if vcost is None else np.array(vcost))
+        self.vinput.append(np.zeros((p + 1, n_u)) if vinput is None else np.array(vinput))
+        self.flags.append(2 if didx >= 0 else 0)
+        self.tstar.append(0.)
+        return len(self.left) - 1
+
+    def flat(self, info, deltas):
+        return FlatTree(np.array(self.vertices), np.array(self.left, dtype=np.int32),
+                        np.array(self.right, dtype=np.int32),
+                        np.array(self.didx, dtype=np.int32), np.array(self.vcost),
+                        np.array(self.vinput), np.array(self.flags, dtype=np.uint8),
+                        np.array(self.tstar), info, deltas)
+
+
+def grow_hybrid(gp, roots, action='ecc', init=None, max_nodes=1 << 20):
+    """
+    Level-synchronous ``ecc`` / ``lcss`` for any number of commutations, every oracle
+    evaluated as a batched GPU call.  Returns a FlatTree.
+    """
+    can = gp.can
+    p, n_u = can.p, can.n_u
+    pool = _Pool(p, n_u)
+    roots = np.asarray(roots, dtype=np.float64).reshape(-1, p + 1, p)
+    ecc_front, lcss_front = [], []
+    for k in range(roots.shape[0]):
+        if action == 'ecc':
+            ecc_front.append(pool.add(roots[k]))
+        else:
+            d = can.delta_index(init['delta'][k])
+            lcss_front.append(pool.add(roots[k], d, init['vertex_costs'][k],
+                                       init['vertex_inputs'][k]))
+    stats0 = gp.stats()
+    sweeps = 0
+    min_margin = np.inf
+    ref_solves = 0
+
+    def split(ids):
+        R = np.array([pool.vertices[i] for i in ids])
+        S1, S2, ij = engine.split_batch(R, device=gp.device)
+        return S1, S2, ij
+
+    while ecc_front or lcss_front:
+        sweeps += 1
+        if len(pool.left) > max_nodes:
+            raise RuntimeError('node pool exhausted (max_nodes=%d)' % max_nodes)
+        next_ecc, next_lcss = [], []
+        if ecc_front:                                     # lib/worker.py:262-291
+            R = np.array([pool.vertices[i] for i in ecc_front])
+            _, _, d_c = gp.solve_pt(R.mean(axis=1))
+            if (d_c < 0).any():
+                raise RuntimeError('STOP, Theta contains infeasible regions')
+            didx, vJ, vu = gp.v_r(R)
+            ref_solves += 2 * len(ecc_front)
+            to_split = [k for k in range(len(ecc_front)) if didx[k] < 0]
+            for k, i in enumerate(ecc_front):
+                if didx[k] >= 0:
+                    pool.didx[i] = int(didx[k])
+                    pool.vcost[i] = vJ[k].copy()
+                    pool.vinput[i] = vu[k].copy()
+                    pool.flags[i] |= 2
+                    next_lcss.append(i)
+                    ref_solves += p + 1
+            if to_split:
+                ids = [ecc_front[k] for k in to_split]
+                S1, S2, _ = split(ids)
+                for q, i in enumerate(ids):
+                    a, b = pool.add(S1[q]), pool.add(S2[q])
+                    pool.left[i], pool.right[i] = a, b
+                    next_ecc += [a, b]
+        if lcss_front:                                    # lib/worker.py:367-417
+            ids = lcss_front
+            R = np.array([pool.vertices[i] for i in ids])
+            V = np.array([pool.vcost[i] for i in ids])
+            closed, tbest = gp.bar_e(R, V)
+            ref_solves += len(ids)
+            min_margin = min(min_margin, float(np.min(np.abs(tbest))))
+            for k, i in enumerate(ids):
+                pool.tstar[i] = float(tbest[k])
+                if closed[k]:
+                    pool.flags[i] |= 1
+            open_k = [k for k in range(len(ids)) if not closed[k]]
+            if open_k:
+                oi = [ids[k] for k in open_k]
+                Ro, Vo = R[open_k], V[open_k]
+                dref = can.deltas[[pool.didx[i] for i in oi]]
+                dstar, ths, vJ, vu, vsmall = gp.bar_d(Ro, Vo, dref)
+                ref_solves += len(oi)
+                split_ids, split_d, split_c, split_u = [], [], [], []
+                for q, i in enumerate(oi):
+                    if dstar[q] >= 0:
+                        ref_solves += p + 3
+                        if vsmall[q]:                     # swap in place, revisit the node
+                            pool.didx[i] = int(dstar[q])
+                            pool.vcost[i] = vJ[q].copy()
+                            pool.vinput[i] = vu[q].copy()
+                            next_lcss.append(i)
+                            continue
+                        # split with the better commutation; the parent keeps its own data
+                        split_d.append(int(dstar[q]))
+                        split_c.append(vJ[q].copy())
+                        split_u.append(vu[q].copy())
+                    else:                                 # lib/worker.py:381-386
+                        split_d.append(pool.didx[i])
+                        split_c.append(pool.vcost[i].copy())
+                        split_u.append(pool.vinput[i].copy())
+                    split_ids.append(i)
+                if split_ids:
+                    S1, S2, ij = split(split_ids)
+                    mids = np.array([S1[q][ij[q, 0]] for q in range(len(split_ids))])
+                    Jm, um, st, _ = gp.solve_ptd(mids, can.deltas[split_d])
+                    ref_solves += len(split_ids)
+                    if (st != 0).any():
+                        raise RuntimeError('midpoint solve did not converge')
+                    for q, i in enumerate(split_ids):
+                        c1, c2 = split_c[q].copy(), split_c[q].copy()
+                        u1, u2 = split_u[q].copy(), split_u[q].copy()
+                        c1[ij[q, 0]] = Jm[q]
+                        c2[ij[q, 1]] = Jm[q]
+                        u1[ij[q, 0]] = um[q]
+                        u2[ij[q, 1]] = um[q]
+                        a = pool.add(S1[q], split_d[q], c1, u1)
+                        b = pool.add(S2[q], split_d[q], c2, u2)
+                        pool.left[i], pool.right[i] = a, b
+                        next_lcss += [a, b]
+        ecc_front, lcss_front = next_ecc, next_lcss
+    stats1 = gp.stats()
+    flags = np.array(pool.flags)
+    left = np.array(pool.left)
+    n_closed = int(np.sum(flags & 1 > 0))
+    vol = 0.
+    if n_closed:
+        vol = float(np.sum(engine.volume_batch(
+            np.array(pool.vertices)[(flags & 1) > 0], device=gp.device)))
+    info = dict(n_nodes=len(pool.left), n_leaves=int(np.sum(left < 0)),
+                n_roots=roots.shape[0], n_closed=n_closed,
+                lp_solves=stats1['lp_solves'] - stats0['lp_solves'], ref_solves=ref_solves,
+                ipm_iters=stats1['ipm_iters'] - stats0['ipm_iters'], sweeps=sweeps,
+                max_depth=sweeps, truncated=0, volume_closed=vol, min_margin=min_margin,
+                device_seconds=0.)
+    return pool.flat(info, can.deltas)
+
+
+# ---------------------------------------------------------------------------------------
+# FlatTree <-> reference tree objects
+# ---------------------------------------------------------------------------------------
+def node_data_from_flat(flat, k):
+    """NodeData of flat node k, attribute-absence semantics of lib/tree.py:34-39."""
+    has = bool(flat.flags[k] & 2)
+    nd = NodeData(vertices=flat.vertices[k].copy(),
+                  commutation=flat.deltas[flat.delta_idx[k]].copy() if has else None,
+                  vertex_costs=flat.vertex_costs[k].copy() if has else None,
+                  vertex_inputs=flat.vertex_inputs[k].copy() if has else None)
+    nd.is_epsilon_suboptimal = bool(flat.flags[k] & 1)
+    return nd
+
+
+def graft_flat(flat, targets):
+    """
+    Write the subtree below flat root r into ``targets[r]`` (existing ``Tree`` nodes, grown
+    in place), iteratively.
+    """
+    nodes = [None] * flat.n_nodes
+    for r, t in enumerate(targets):
+        nodes[r] = t
+    for k in range(flat.n_nodes):                  # parents precede children
+        node = nodes[k]
+        node.data = node_data_from_flat(flat, k)
+        if flat.left[k] >= 0:
+            node.grow(None, None)
+            nodes[flat.left[k]] = node.left
+            nodes[flat.right[k]] = node.right
+    return targets
+
+
+def run_engine(oracle, roots, action='ecc', init=None, **kw):
+    """Grow ``roots`` on the GPU and return the FlatTree."""
+    gp = oracle.gpu
+    if gp.can.n_delta == 1:
+        return gp.partition(roots, action=action, init=init, **kw)
+    return grow_hybrid(gp, roots, action=action, init=init,
+                       max_nodes=kw.get('max_nodes') or (1 << 20))
+
+
+def alg_call(oracle, which_alg, branch, location=''):
+    """
+    Drop-in for the reference's ``alg_call(which_alg, branch, location)``
+    (lib/worker.py:180-185): grows ``branch`` in place, returns None.  ``location`` is
+    accepted for signature compatibility (the result does not depend on it).
+    """
+    data = branch.data
+    R = np.asarray(data.vertices, dtype=np.float64)[None]
+    init = None
+    if which_alg != 'ecc':
+        init = dict(delta=np.asarray(data.commutation)[None],
+                    vertex_costs=np.asarray(data.vertex_costs)[None],
+                    vertex_inputs=np.asarray(data.vertex_inputs)[None])
+    flat = run_engine(oracle, R, action='ecc' if which_alg == 'ecc' else 'lcss', init=init)
+    graft_flat(flat, [branch])
+    return None
+
+
+class Partitioner:
+    """Object form with the reference's method names (``Worker.ecc`` / ``Worker.lcss``)."""
+
+    def __init__(self, oracle):
+        self.oracle = oracle
+
+    def ecc(self, node, location=''):
+        return alg_call(self.oracle, 'ecc', node, location)
+
+    def lcss(self, node, location=''):
+        return alg_call(self.oracle, 'lcss', node, location)
+
+
+def partition_set(oracle, set_vertices, **kw):
+    """
+    Whole pipeline of scheduler.setup + workers (lib/scheduler.py:373-391, 620-642): Delaunay
+    roots of the set, every root grown to epsilon-suboptimality in ONE engine run, result
+    grafted into the reference's right-spine tree.  Returns (root Tree, FlatTree).
+    """
+    from . import tools
+    root, Nsx, vol = tools.delaunay(set_vertices)
+    roots, locs = tools.delaunay_roots(set_vertices)
+    flat = run_engine(oracle, roots, action='ecc', **kw)
+    targets = [root.descend(loc) for loc in locs]
+    graft_flat(flat, targets)
+    return root, flat

@@ -79,7 +79,8 @@ class IPMResult:
     __slots__ = ('x', 'obj', 'status', 'iters', 'lam', 'res', 'merit')
 
 
-PROX_REL = 1e-9       # relative proximal term added to the diagonal of the normal matrix
+PROX_REL = 0.         # optional relative proximal term on the normal-matrix diagonal (off: it
+                      # slows the tail convergence on these LPs; kept for experiments)
 PIVOT_REL = 1e-13     # a pivot below PIVOT_REL * (its original diagonal) is a dependent column
 PIVOT_BIG = 1e128     # replacing it by this zeroes the corresponding solution component
 ACCEPT_MERIT = 1e3    # stalled but within 1000x of the tolerances: accepted (OPTIMAL_INACCURATE)

@@ -10,12 +10,12 @@ one ``Problem.solve`` per oracle.
 Canonical commutation rule (the reference returns whatever feasible commutation MOSEK
 happens to find, lib/oracle.py:201,347 -- ``Minimize(0)``):
 
-* ``P_theta``      : commutation with the smallest optimal cost, lowest index on ties.
+* ``P_theta``      : commutation with the smallest optimal cost; costs within
+  ``TIE_TOL*(1+|J|)`` of the minimum count as tied and the lowest index wins.
 * ``V_R``          : first commutation (enumeration order) feasible at every vertex.
 * ``bar_E_delta_R``: feasible  <=>  max over commutations of the slack t* is >= 0.
 * ``bar_D_delta_R``: among commutations feasible at every vertex of R, the one with the
-  largest slack t* (lowest index on ties), provided t* >= 0;  theta* is that LP's
-  maximiser.
+  largest slack t* (same tie rule), provided t* >= 0;  theta* is that LP's maximiser.
 """
 
 import time
@@ -28,6 +28,12 @@ from .lp_models import FixedCommutationModel
 # HiGHS defaults to 1e-7 feasibility tolerances; the parity bar on optimal costs is 1e-7
 # relative, so the checker itself is run tighter.
 HIGHS_OPTIONS = dict(primal_feasibility_tolerance=1e-10, dual_feasibility_tolerance=1e-10)
+
+
+# Two commutations often give mathematically identical optima (e.g. both modes admissible in
+# the guard band); which one a solver reports as "smaller" is then rounding noise.  Values
+# closer than this (relative to 1+|value|) are ties, broken by enumeration order.
+TIE_TOL = 1e-6
 
 
 class SolverError(RuntimeError):
@@ -44,6 +50,8 @@ class OracleCPU:
         self.deltas = [mpc.sequence_to_delta(s) for s in self.sequences]
         self.models = [FixedCommutationModel(mpc, s) for s in self.sequences]
         self.n_solves = 0          # LP solver calls (one per commutation sub-problem)
+        self.memoize = False       # cache point solves by (theta, commutation): children
+        self._memo = {}            # share p of their p+1 vertices with the parent
         self.last_margin = np.inf  # |t*| of the last feasibility decision
 
     # -- helpers ---------------------------------------------------------------------
@@ -64,28 +72,38 @@ class OracleCPU:
 
     def _point(self, theta, d):
         """(feasible, u0, J) of P_theta_delta for commutation index d."""
+        key = None
+        if self.memoize:
+            key = (np.asarray(theta, dtype=np.float64).tobytes(), d)
+            if key in self._memo:
+                return self._memo[key]
         res = self._solve(self.models[d].lp_point(theta))
         if res.status != 0:
-            return False, None, None
-        return True, self.models[d].u0(res.x), float(res.fun)
+            out = (False, None, None)
+        else:
+            out = (True, self.models[d].u0(res.x), float(res.fun))
+        if key is not None:
+            self._memo[key] = out
+        return out
 
     # -- lib/oracle.py:104-139 -----------------------------------------------------------
     def P_theta(self, theta, check_feasibility=False):
         t0 = time.time()
-        best = None
+        cand = []
         for d in range(len(self.models)):
             ok, u, J = self._point(theta, d)
             if not ok:
                 continue
             if check_feasibility:
                 return True
-            if best is None or J < best[2]:
-                best = (u, self.deltas[d].copy(), J)
+            cand.append((d, u, J))
         if check_feasibility:
             return False
-        if best is None:
+        if not cand:
             return None, None, None, time.time() - t0
-        return best[0], best[1], best[2], time.time() - t0
+        J_min = min(c[2] for c in cand)
+        d, u, J = next(c for c in cand if c[2] <= J_min + TIE_TOL * (1. + abs(J_min)))
+        return u, self.deltas[d].copy(), J, time.time() - t0
 
     # -- lib/oracle.py:141-173 -----------------------------------------------------------
     def P_theta_delta(self, theta, delta, check_feasibility=False):
@@ -147,15 +165,17 @@ class OracleCPU:
     # -- lib/oracle.py:311-414 -----------------------------------------------------------
     def bar_D_delta_R(self, R, V_delta_R, delta_ref):
         R = np.asarray(R, dtype=np.float64)
-        best = None
+        cand = []
         for d in range(len(self.models)):
             if not self._feasible_on_vertices(R, d):
                 continue
             t, alpha = self.slack(R, V_delta_R, d)
-            if t >= 0. and (best is None or t > best[0]):
-                best = (t, d, alpha)
-        if best is None:
+            if t >= 0.:
+                cand.append((t, d, alpha))
+        if not cand:
             return None, None, None, None
+        t_max = max(c[0] for c in cand)
+        best = next(c for c in cand if c[0] >= t_max - TIE_TOL * (1. + abs(t_max)))
         delta_star = self.deltas[best[1]].copy()
         if np.array_equal(delta_star.astype(int), np.asarray(delta_ref).astype(int)):
             return None, None, None, None

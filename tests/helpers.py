@@ -7,6 +7,9 @@ from oracle.oracle_cpu import OracleCPU
 from oracle import geometry
 
 
+PWA_SMALL_SCALE = 0.367     # 0.9 x max feasible scale (0.408, tools/calibrate_configs.py)
+
+
 def make_instance(kind, seed=0):
     if kind == 'di':
         return examples.double_integrator(3)
@@ -14,6 +17,12 @@ def make_instance(kind, seed=0):
         return examples.linear_mpc(seed)
     if kind == 'pwa':
         return examples.pwa_mpc(seed)
+    if kind == 'pwa_small':
+        # 2 states, 1 input, N=3: 8 commutations -- a hybrid instance whose whole partition
+        # the CPU oracle finishes in seconds
+        mpc = examples.pwa_mpc(seed=seed, n_x=2, n_u=1, N=3, n_random=4, overlap=0.3)
+        examples.THETA_SCALE.setdefault(mpc.name, PWA_SMALL_SCALE)
+        return mpc
     raise ValueError(kind)
 
 

@@ -1,0 +1,119 @@
+"""
+Host-side logic that needs no GPU: the C-ABI library loads and exports every symbol the
+header declares, the canonical LP compiler, the tree types (against the reference's
+semantics) and the reference-format pickles.
+"""
+
+import os
+import pickle
+import re
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+
+from explicit_hybrid_mpc_amd import _capi, examples, tree, tree_io
+from tests import helpers
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def test_library_exports_every_declared_symbol():
+    header = open(os.path.join(ROOT, 'include', 'ehmpc.h')).read()
+    declared = set(re.findall(r'\b(ehm_[a-z_]+)\s*\(', header))
+    declared -= {'ehm_problem_desc', 'ehm_run_opts'}
+    assert declared == set(_capi.EXPORTED), declared ^ set(_capi.EXPORTED)
+    lib = _capi.load()
+    for name in declared:
+        assert hasattr(lib, name), name
+    assert b'gfx950' in lib.ehm_version()
+    out = subprocess.run(['nm', '-D', '--defined-only', _capi.library_path()],
+                         capture_output=True, text=True).stdout
+    for name in declared:
+        assert re.search(r'\bT %s\b' % name, out), name
+
+
+def test_no_cpu_fallback_without_a_gpu():
+    """On a box without a GPU the product path must fail loudly, not compute on the CPU."""
+    import torch
+    if torch.cuda.is_available():
+        pytest.skip('a GPU is present')
+    from explicit_hybrid_mpc_amd import engine
+    mpc = helpers.make_instance('di')
+    with pytest.raises(_capi.EhmError) as err:
+        engine.GpuProblem(mpc.compile(), 0.1, 0.1)
+    assert err.value.code == _capi.EHM_E_NO_DEVICE
+    with pytest.raises(_capi.EhmError):
+        engine.split_batch(np.zeros((1, 3, 2)))
+
+
+def test_product_never_imports_the_oracle():
+    pkg = os.path.join(ROOT, 'explicit_hybrid_mpc_amd')
+    for dirpath, _, files in os.walk(pkg):
+        for f in files:
+            if f.endswith(('.py', '.h', '.hip')):
+                text = open(os.path.join(dirpath, f)).read()
+                assert not re.search(r'^\s*(from|import)\s+oracle\b', text, re.M), f
+
+
+def test_canonical_sizes_match_survey():
+    can = examples.linear_mpc(0).compile()
+    assert (can.n, can.m, can.p, can.n_u, can.n_delta) == (20, 160, 4, 2, 1)
+    can3 = examples.pwa_mpc(0).compile()
+    assert can3.n_delta == 32 and can3.deltas.shape == (32, 10)
+    assert (can3.deltas.reshape(32, 5, 2).sum(axis=2) == 1).all()
+    assert can3.delta_index(can3.deltas[7]) == 7
+    with pytest.raises(ValueError):
+        can3.delta_index(np.ones(10))
+
+
+def test_theta_box_vertices_are_feasible():
+    from oracle.oracle_cpu import OracleCPU
+    for mpc in (examples.double_integrator(3), examples.linear_mpc(2), examples.pwa_mpc(1)):
+        orc = OracleCPU(mpc, 1., 1.)
+        for v in examples.box_vertices(examples.theta_box(mpc)):
+            assert orc.P_theta(v, check_feasibility=True)
+
+
+def test_tree_semantics_match_reference(golden_geometry):
+    """Same observable behaviour as lib/tree.py (flags recorded from the real classes)."""
+    nd = tree.NodeData(np.zeros((3, 2)))
+    t = tree.Tree(nd)
+    flags = [hasattr(nd, 'commutation'), hasattr(nd, 'vertex_costs'),
+             hasattr(nd, 'vertex_inputs'), nd.is_epsilon_suboptimal, t.top, t.is_leaf()]
+    t.grow(tree.NodeData(np.ones((3, 2))), None)
+    flags += [t.is_leaf(), t.left.top, t.right.data is None, t.left.is_leaf()]
+    assert [int(f) for f in flags] == golden_geometry['tree_flags'].tolist()
+    other = tree.Tree(None)
+    t.copy(other)
+    assert other.left is t.left and other.data is t.data
+
+
+def test_reference_format_pickle_roundtrip(tmp_path):
+    root = tree.Tree(tree.NodeData(np.zeros((3, 2))))
+    cursor = root
+    for k in range(3000):            # deeper than the default recursion limit allows
+        cursor.grow(tree.NodeData(np.full((3, 2), float(k)), commutation=np.ones(3),
+                                  vertex_costs=np.arange(3.), vertex_inputs=np.ones((3, 1))),
+                    None)
+        cursor = cursor.right
+    path = str(tmp_path / 'tree.pkl')
+    tree_io.dump_reference(root, path)
+    raw = open(path, 'rb').read()
+    assert b'explicit_hybrid_mpc_amd' not in raw and b'tree' in raw
+    # a consumer that only knows a module called `tree` (like the reference) can load it
+    code = ("import sys, types, pickle; sys.setrecursionlimit(100000);"
+            "m = types.ModuleType('tree');"
+            "exec('class Tree: pass\\nclass NodeData: pass', m.__dict__);"
+            "sys.modules['tree'] = m;"
+            "t = pickle.load(open(%r, 'rb'));"
+            "n = 0\n"
+            "while hasattr(t, 'left'): t = t.right; n += 1\n"
+            "print(n, type(t).__module__)") % path
+    out = subprocess.run([sys.executable, '-c', code], capture_output=True, text=True)
+    assert out.stdout.split() == ['3000', 'tree'], out.stderr
+    back = tree_io.load_reference(path)
+    assert isinstance(back, tree.Tree) and tree_io.tree_depth(back) == 3000
+    assert sys.getrecursionlimit() < 100000
+    assert tree.Tree.__module__ == 'explicit_hybrid_mpc_amd.tree'
