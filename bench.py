@@ -85,25 +85,24 @@ def main():
     ap.add_argument('--no-cpu-baseline', action='store_true')
     args = ap.parse_args()
 
-    rank = int(os.environ.get('RANK', '0'))
-    local_rank = int(os.environ.get('LOCAL_RANK', '0'))
-    world = int(os.environ.get('WORLD_SIZE', '1'))
     import torch
     import torch.distributed as dist
-    if world > 1:
-        os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
-        torch.cuda.set_device(local_rank)
-        dist.init_process_group('nccl', rank=rank, world_size=world)
-    if world != args.gpus:
-        if rank == 0:
-            sys.stderr.write('bench.py: --gpus %d but WORLD_SIZE=%d; using WORLD_SIZE\n' %
-                             (args.gpus, world))
+    from explicit_hybrid_mpc_amd import distributed
+    # "nccl" is RCCL on ROCm; EHM_BENCH_BACKEND=gloo lets several ranks share one GPU (tests)
+    backend = os.environ.get('EHM_BENCH_BACKEND', 'nccl')
+    rank, local_rank, world = distributed.init_process_group(backend)
+    n_dev = max(torch.cuda.device_count(), 1)
+    device_index = local_rank % n_dev
+    torch.cuda.set_device(device_index)
+    if world != args.gpus and rank == 0:
+        sys.stderr.write('bench.py: --gpus %d but WORLD_SIZE=%d; using WORLD_SIZE\n' %
+                         (args.gpus, world))
     from explicit_hybrid_mpc_amd import engine, examples
     from explicit_hybrid_mpc_amd import tools as ehm_tools
 
     mpc = examples.linear_mpc(seed=args.seed)
     can = mpc.compile()
-    gp = engine.GpuProblem(can, 1., 1., device=local_rank)
+    gp = engine.GpuProblem(can, 1., 1., device=device_index)
     half = examples.theta_box(mpc)
     V = examples.box_vertices(half)
     # eps_a by the reference's rule (lib/examples.py:42-46), evaluated on the GPU oracle
@@ -111,7 +110,7 @@ def main():
     eps_a = float(np.max(J_abs))
     gp.set_eps(eps_a, args.eps_r)
     roots, _ = ehm_tools.delaunay_roots(V)
-    shard = (rank, world, args.shard_min_frontier) if world > 1 else None
+    shard = distributed.shard_spec(rank, world, args.shard_min_frontier)
 
     def step():
         return gp.partition(roots, action='ecc', max_nodes=args.max_nodes, export=False,
@@ -132,20 +131,18 @@ def main():
     # totals over ranks (max time, summed work)
     keys = ['lp_solves', 'ipm_iters', 'n_nodes', 'n_closed', 'ref_solves', 'decide_solves',
             'decide_iters']
-    local = torch.tensor([float(sum(i[k] for i in infos)) for k in keys] +
-                         [elapsed, sum(i['decide_seconds'] for i in infos),
-                          sum(i['expand_seconds'] for i in infos)],
-                         dtype=torch.float64, device='cuda:%d' % local_rank)
-    if world > 1:
-        tot = local.clone()
-        dist.all_reduce(tot, op=dist.ReduceOp.SUM)
-        mx = local.clone()
-        dist.all_reduce(mx, op=dist.ReduceOp.MAX)
-        tot = tot.cpu().numpy()
-        mx = mx.cpu().numpy()
-    else:
-        tot = local.cpu().numpy()
-        mx = tot
+    if rank > 0:
+        # the top of the tree is grown identically on every rank: count it once (rank 0)
+        for i in infos:
+            i['lp_solves'] -= i['replicated_solves']
+            i['n_closed'] -= i['replicated_closed']
+            i['n_nodes'] -= i['replicated_nodes']
+    local = [float(sum(i[k] for i in infos)) for k in keys] + \
+        [elapsed, sum(i['decide_seconds'] for i in infos),
+         sum(i['expand_seconds'] for i in infos)]
+    red_dev = ('cuda:%d' % device_index) if backend == 'nccl' else 'cpu'
+    tot, mx = distributed.allreduce_counters(local, device=red_dev)
+    per_rank = distributed.allgather_counts([int(local[0])], device=red_dev)[:, 0]
     elapsed_max = float(mx[len(keys)])
     agg = dict(zip(keys, tot[:len(keys)]))
     decide_s = float(mx[len(keys) + 1])
@@ -188,6 +185,8 @@ def main():
                 'sweeps': info0['sweeps'], 'tree_depth': info0['max_depth'],
                 'min_decision_margin': info0['min_margin'],
                 'parallelism': 'frontier dealt round-robin over %d GPU(s)' % world,
+                'lp_solves_per_rank': [int(v) for v in per_rank],
+                'load_imbalance_max_over_mean': distributed.imbalance(per_rank),
             },
             'roofline': {
                 'bound': 'mfma', 'kernel': 'k_lcss_decide',

@@ -69,7 +69,8 @@ class TreeInfo(ctypes.Structure):
                 ('device_seconds', ctypes.c_double), ('decide_seconds', ctypes.c_double),
                 ('expand_seconds', ctypes.c_double), ('decide_launches', ctypes.c_int64),
                 ('expand_launches', ctypes.c_int64), ('decide_solves', ctypes.c_int64),
-                ('decide_iters', ctypes.c_int64)]
+                ('decide_iters', ctypes.c_int64), ('replicated_closed', ctypes.c_int64),
+                ('replicated_nodes', ctypes.c_int64), ('replicated_solves', ctypes.c_int64)]
 
 
 class Counters(ctypes.Structure):

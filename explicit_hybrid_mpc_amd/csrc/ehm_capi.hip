@@ -1232,6 +1232,7 @@ int ehm_partition_run(ehm_problem* P, int64_t n_roots, const double* root_vertic
         evs.push_back(e);
     };
     std::vector<int> ev_kind;      // 0 decide, 1 expand, per pair
+    long long pre_closed = 0, pre_nodes = 0, pre_solves = 0;
     long long n_nodes = n_roots;
     long long nf = n_roots;
     long long n_closed = 0;
@@ -1253,6 +1254,12 @@ int ehm_partition_run(ehm_problem* P, int64_t n_roots, const double* root_vertic
             cur_is_a = !cur_is_a;
             nf = (nf - shard_rank + shard_world - 1) / shard_world;
             sharded = true;
+            // work done so far is replicated on every rank
+            DevCounters cs;
+            RUN_TRY(read_counters(P, cs));
+            pre_closed = n_closed;
+            pre_nodes = n_nodes;
+            pre_solves = (long long)(cs.lp_solves - c0.lp_solves);
             if (nf == 0) break;
         }
         if ((long long)open_flag.cap < nf * 4) {
@@ -1352,6 +1359,9 @@ int ehm_partition_run(ehm_problem* P, int64_t n_roots, const double* root_vertic
     T->info.expand_launches = n_kind[1];
     T->info.decide_solves = (int64_t)(c1.slack_solves - c0.slack_solves);
     T->info.decide_iters = (int64_t)(c1.slack_iters - c0.slack_iters);
+    T->info.replicated_closed = pre_closed;
+    T->info.replicated_nodes = pre_nodes;
+    T->info.replicated_solves = pre_solves;
     {
         double mm;
         std::memcpy(&mm, &c1.min_margin_bits, 8);

@@ -192,6 +192,10 @@ typedef struct ehm_tree_info {
     int64_t expand_launches;
     int64_t decide_solves;  /* LPs solved by the decide kernel                          */
     int64_t decide_iters;   /* their interior-point iterations                          */
+    /* multi-GPU sharding: work done before the frontier was dealt is identical on every rank */
+    int64_t replicated_closed;
+    int64_t replicated_nodes;
+    int64_t replicated_solves;
 } ehm_tree_info;
 
 int ehm_tree_info_get(const ehm_tree* tree, ehm_tree_info* out);

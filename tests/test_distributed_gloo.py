@@ -1,0 +1,121 @@
+"""
+The N > 1 path on CPU: two processes under torch.distributed/gloo.  The engine itself needs
+a GPU, so each rank's share of the tree is produced by a CPU emulation of the engine's
+sweep order and dealing rule (frontier position k -> rank k % world, children appended in
+open-list order); what is under test is the product's distributed layer: the dealing rule,
+the counter collectives and the merge of the ranks' trees by location.
+"""
+
+import os
+import socket
+
+import numpy as np
+import pytest
+import torch.multiprocessing as mp
+
+from tests import helpers
+
+
+def sweep_partition_cpu(mpc, eps_a, eps_r, roots, rank, world, min_frontier):
+    """Level-synchronous single-commutation partition with the engine's sharding rule."""
+    from explicit_hybrid_mpc_amd.engine import FlatTree
+    from explicit_hybrid_mpc_amd import distributed
+    from oracle.oracle_cpu import OracleCPU
+    from oracle import geometry
+    orc = OracleCPU(mpc, eps_a, eps_r)
+    orc.memoize = True
+    d0 = orc.deltas[0]
+    V, L, Rr, C, U, F, T = [], [], [], [], [], [], []
+
+    def add(R, c, u):
+        V.append(R); L.append(-1); Rr.append(-1); C.append(c); U.append(u); F.append(2); T.append(0.)
+        return len(L) - 1
+    frontier = []
+    for R in roots:
+        sol = [orc.P_theta_delta(v, d0) for v in R]
+        frontier.append(add(np.array(R), np.array([s[1] for s in sol]),
+                            np.array([s[0] for s in sol])))
+    sharded = world == 1
+    while frontier:
+        if not sharded and len(frontier) >= min_frontier:
+            keep = []
+            for k, i in enumerate(frontier):
+                if distributed.owner_of(k, world) == rank:
+                    keep.append(i)
+                else:
+                    F[i] |= 4
+            frontier, sharded = keep, True
+        nxt = []
+        for i in frontier:
+            t, _ = orc.slack(V[i], C[i], 0)
+            T[i] = t
+            if not (t >= 0.):
+                F[i] |= 1
+                continue
+            S1, S2, (a, b) = geometry.split_along_longest_edge(V[i])
+            u_mid, J_mid, _ = orc.P_theta_delta(S1[a], d0)
+            c1, c2, u1, u2 = C[i].copy(), C[i].copy(), U[i].copy(), U[i].copy()
+            c1[a], c2[b], u1[a], u2[b] = J_mid, J_mid, u_mid, u_mid
+            L[i] = add(S1, c1, u1)
+            Rr[i] = add(S2, c2, u2)
+            nxt += [L[i], Rr[i]]
+        frontier = nxt
+    info = dict(n_roots=len(roots), n_nodes=len(L), lp_solves=orc.n_solves,
+                n_closed=int(np.sum(np.array(F) & 1 > 0)))
+    return FlatTree(np.array(V), np.array(L, dtype=np.int32), np.array(Rr, dtype=np.int32),
+                    np.zeros(len(L), dtype=np.int32), np.array(C), np.array(U),
+                    np.array(F, dtype=np.uint8), np.array(T), info, np.ones((1, mpc.N)))
+
+
+def _worker(rank, world, port, out_dir):
+    os.environ.update(RANK=str(rank), LOCAL_RANK=str(rank), WORLD_SIZE=str(world),
+                      MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port))
+    import pickle
+    import torch.distributed as dist
+    from explicit_hybrid_mpc_amd import distributed
+    r, _, w = distributed.init_process_group('gloo')
+    assert (r, w) == (rank, world)
+    mpc = helpers.make_instance('di', 0)
+    eps_a, eps_r = 0.3, 0.02
+    roots, locs = helpers.roots_of(mpc)
+    spec = distributed.shard_spec(rank, world, min_frontier=8)
+    part = sweep_partition_cpu(mpc, eps_a, eps_r, roots, spec[0], spec[1], spec[2])
+    mine = int(np.sum((part.flags & 1) > 0))
+    tot, mx = distributed.allreduce_counters([mine, part.info['lp_solves']])
+    counts = distributed.allgather_counts([mine, part.n_nodes])
+    assert counts.shape == (world, 2) and counts[rank, 0] == mine
+    assert tot[0] == counts[:, 0].sum() and mx[0] == counts[:, 0].max()
+    with open(os.path.join(out_dir, 'part%d.pkl' % rank), 'wb') as f:
+        pickle.dump(dict(part=part, tot=tot, imb=distributed.imbalance(counts[:, 0])), f)
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_two_ranks_tile_the_tree(tmp_path):
+    import pickle
+    from explicit_hybrid_mpc_amd import distributed
+    s = socket.socket()
+    s.bind(('127.0.0.1', 0))
+    port = s.getsockname()[1]
+    s.close()
+    mp.spawn(_worker, args=(2, port, str(tmp_path)), nprocs=2, join=True)
+    outs = [pickle.load(open(str(tmp_path / ('part%d.pkl' % r)), 'rb')) for r in range(2)]
+    mpc = helpers.make_instance('di', 0)
+    roots, locs = helpers.roots_of(mpc)
+    full = sweep_partition_cpu(mpc, 0.3, 0.02, roots, 0, 1, 0)
+    merged = distributed.merge_flat([o['part'] for o in outs], locs)
+    assert merged.n_nodes == full.n_nodes
+    floc, mloc = full.locations(locs), merged.locations(locs)
+    fidx = {n: k for k, n in enumerate(floc)}
+    assert set(floc) == set(mloc)
+    for k, name in enumerate(mloc):
+        j = fidx[name]
+        assert np.array_equal(merged.vertices[k], full.vertices[j])
+        assert merged.is_leaf(k) == full.is_leaf(j)
+        assert (merged.flags[k] & 1) == (full.flags[j] & 1)
+        assert not (merged.flags[k] & 4)
+        assert np.allclose(merged.vertex_costs[k], full.vertex_costs[j], rtol=1e-9, atol=1e-12)
+    assert outs[0]['tot'][0] == full.info['n_closed']
+    assert 1.0 <= outs[0]['imb'] < 1.6
+    # each rank really did only part of the work
+    assert all(o['part'].info['n_closed'] < full.info['n_closed'] for o in outs)
