@@ -2,18 +2,29 @@
 Builds ``explicit_hybrid_mpc_amd/lib/libehmpc.so`` (HIP kernels + C-ABI, include/ehmpc.h)
 for gfx950 with hipcc.  hipcc cross-compiles without a GPU, so this also runs in the
 CPU-only build container.
+
+Objects: ``ehm_capi.hip`` (C-ABI, host orchestration, generation-1 kernels) and one
+instance of ``ehm_k2.hip`` per (column capacity NP, row slots) pair -- the solver keeps a
+row of the normal matrix and the LP's row vectors in registers, so both are compile-time
+sizes.  The objects are compiled in parallel and cached under ``lib/obj``.
 """
 
 import os
 import shutil
 import subprocess
+from concurrent.futures import ThreadPoolExecutor
 
 HERE = os.path.dirname(os.path.abspath(__file__))
 SRC_DIR = os.path.join(HERE, 'csrc')
 LIB_DIR = os.path.join(HERE, 'lib')
+OBJ_DIR = os.path.join(LIB_DIR, 'obj')
 LIB = os.path.join(LIB_DIR, 'libehmpc.so')
-SOURCES = ['ehm_capi.hip']
-HEADERS = ['ehm_ipm.h', 'ehm_kernels.h', os.path.join('..', '..', 'include', 'ehmpc.h')]
+HEADERS = ['ehm_ipm.h', 'ehm_kernels.h', 'ehm_dev.h', 'ehm_k2.h', 'ehm_ipm2.h',
+           os.path.join('..', '..', 'include', 'ehmpc.h')]
+# must match EHM_K2_ALL in ehm_capi.hip
+K2_NPS = (8, 12, 16, 20, 24, 28, 32)
+K2_SLOTS = (1, 2, 3, 4)
+FLAGS = ['--offload-arch=gfx950', '-O3', '-std=c++17', '-fPIC', '-Wno-unused-result']
 
 
 def _hipcc():
@@ -23,22 +34,55 @@ def _hipcc():
     raise RuntimeError('hipcc not found: libehmpc.so cannot be built')
 
 
+def _dep_mtime():
+    deps = [os.path.join(SRC_DIR, h) for h in HEADERS] + [__file__]
+    return max(os.path.getmtime(os.path.normpath(d)) for d in deps)
+
+
+def _objects():
+    """(object path, source path, extra flags)"""
+    objs = [(os.path.join(OBJ_DIR, 'ehm_capi.o'), os.path.join(SRC_DIR, 'ehm_capi.hip'), [])]
+    for np_ in K2_NPS:
+        for sl in K2_SLOTS:
+            objs.append((os.path.join(OBJ_DIR, 'ehm_k2_%d_%d.o' % (np_, sl)),
+                         os.path.join(SRC_DIR, 'ehm_k2.hip'),
+                         ['-DEHM_NP=%d' % np_, '-DEHM_SLOTS=%d' % sl]))
+    return objs
+
+
+def _stale(obj, src, dep_t):
+    return (not os.path.exists(obj) or
+            os.path.getmtime(obj) < max(dep_t, os.path.getmtime(src)))
+
+
 def is_stale():
     if not os.path.exists(LIB):
         return True
     t = os.path.getmtime(LIB)
-    deps = [os.path.join(SRC_DIR, s) for s in SOURCES + HEADERS] + [__file__]
-    return any(os.path.getmtime(os.path.normpath(d)) > t for d in deps)
+    srcs = [os.path.join(SRC_DIR, 'ehm_capi.hip'), os.path.join(SRC_DIR, 'ehm_k2.hip')]
+    return max([_dep_mtime()] + [os.path.getmtime(s) for s in srcs]) > t
 
 
-def build(force=False, verbose=False):
+def build(force=False, verbose=False, jobs=None):
     """Compile the library if it is missing or older than its sources."""
     if not force and not is_stale():
         return LIB
-    os.makedirs(LIB_DIR, exist_ok=True)
-    cmd = [_hipcc(), '--offload-arch=gfx950', '-O3', '-std=c++17', '-shared', '-fPIC',
-           '-Wno-unused-result']
-    cmd += [os.path.join(SRC_DIR, s) for s in SOURCES]
+    os.makedirs(OBJ_DIR, exist_ok=True)
+    hipcc = _hipcc()
+    dep_t = _dep_mtime()
+    todo = [(o, s, f) for (o, s, f) in _objects() if force or _stale(o, s, dep_t)]
+
+    def compile_one(item):
+        obj, src, extra = item
+        cmd = [hipcc] + FLAGS + extra + ['-c', src, '-o', obj]
+        if verbose:
+            print(' '.join(cmd))
+        subprocess.check_call(cmd)
+
+    jobs = jobs or max(1, (os.cpu_count() or 2))
+    with ThreadPoolExecutor(max_workers=jobs) as pool:
+        list(pool.map(compile_one, todo))
+    cmd = [hipcc, '--offload-arch=gfx950', '-shared', '-fPIC'] + [o for (o, _, _) in _objects()]
     cmd += ['-o', LIB]
     if verbose:
         print(' '.join(cmd))

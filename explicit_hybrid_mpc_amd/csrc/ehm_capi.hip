@@ -8,6 +8,7 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <set>
 #include <string>
 #include <vector>
 
@@ -15,8 +16,18 @@
 
 #define EHM_MAX_P_DEV 8
 #include "ehm_kernels.h"
+#include "ehm_k2.h"
 
 using namespace ehm;
+
+// second-generation kernel instances (ehm_k2.hip compiled per column capacity / row slots)
+#define EHM_K2_NPS(X, S) X(8, S) X(12, S) X(16, S) X(20, S) X(24, S) X(28, S) X(32, S)
+#define EHM_K2_ALL(X) EHM_K2_NPS(X, 1) EHM_K2_NPS(X, 2) EHM_K2_NPS(X, 3) EHM_K2_NPS(X, 4)
+#define EHM_K2_DECL(NPV, SL) extern "C" const ehm::K2Api* ehm_k2_api_##NPV##_##SL();
+EHM_K2_ALL(EHM_K2_DECL)
+#define EHM_K2_ENTRY(NPV, SL) ehm_k2_api_##NPV##_##SL,
+typedef const ehm::K2Api* (*k2_getter)();
+static const k2_getter g_k2_getters[] = {EHM_K2_ALL(EHM_K2_ENTRY)};
 
 // =========================================================================================
 // kernels: one 64-lane workgroup (= one wavefront) per LP / per node
@@ -410,6 +421,11 @@ struct ehm_problem {
     int delta_len = 0;
     std::vector<uint8_t> deltas;
     DevBuf consts;           // Gt | St | w | c
+    DevBuf wc2;              // [n_delta][n+p+2][m|1]  LDS image for the k2 kernels
+    bool v1_ok = false;      // the generation-1 kernels fit this problem
+    int solver_gen = 2;      // 1 = one wavefront per workgroup (ehm_kernels.h), 2 = ehm_k2.hip
+    DevBuf seg;              // commutation segment offsets of a sorted batch
+    std::set<const K2Api*> k2_ready;
     DevBuf in0, in1, in2, out0, out1, out2, out3;
     DevCounters* d_cnt = nullptr;
     long long launches = 0;
@@ -460,6 +476,83 @@ static size_t lds_bytes_for(const DevProblem& dp, int kind, size_t prefix_double
 static int grid_for(ehm_problem* P, long long n) {
     long long cap = (long long)P->num_cu * 64;
     return (int)std::max(1LL, std::min(n, cap));
+}
+
+// ---- second-generation launch configuration --------------------------------------------------
+#define EHM_LDS_BUDGET (160 * 1024 - 256)   // dynamic LDS a workgroup may ask for
+
+static void kind_dims(const DevProblem& dp, int kind, int& n_lp, int& ne) {
+    switch (kind) {
+        case LP_POINT: n_lp = dp.n; ne = 0; break;
+        case LP_FEAS: n_lp = dp.n + 1; ne = 1; break;
+        case LP_MIN_SIMPLEX: n_lp = dp.n + dp.p; ne = dp.p + 1; break;
+        case LP_FEAS_SIMPLEX: n_lp = dp.n + dp.p + 1; ne = dp.p + 2; break;
+        default: n_lp = dp.n + dp.p + 1; ne = dp.p + 3; break;
+    }
+}
+
+// smallest compiled instance that holds n_lp columns and `slots` row slots
+static const K2Api* k2_pick(int n_lp, int slots) {
+    const K2Api* best = nullptr;
+    for (k2_getter g : g_k2_getters) {
+        const K2Api* a = g();
+        if (a->np < n_lp || a->slots < slots) continue;
+        if (!best || a->np < best->np || (a->np == best->np && a->slots < best->slots)) best = a;
+    }
+    return best;
+}
+
+struct K2Cfg {
+    const K2Api* api = nullptr;
+    K2Launch L{};
+};
+
+// kind_a / kind_b: the LP kinds the launch may assemble (workspace sized for the larger)
+static int k2_config(ehm_problem* P, int kind_a, int kind_b, long long n_items, K2Cfg& cfg) {
+    int n_lp, ne, n_lp2, ne2;
+    kind_dims(P->dp, kind_a, n_lp, ne);
+    kind_dims(P->dp, kind_b, n_lp2, ne2);
+    const int slots = std::max(lp_slots(P->dp.m, ne), lp_slots(P->dp.m, ne2));
+    n_lp = std::max(n_lp, n_lp2);
+    ne = std::max(ne, ne2);
+    const K2Api* api = k2_pick(n_lp, slots);
+    if (!api)
+        return fail(EHM_E_INVALID, "no kernel instance for an LP with %d columns, %d row slots",
+                    n_lp, slots);
+    const size_t shared = api->shared_doubles(P->dp);
+    const size_t wave = api->wave_doubles(P->dp.p, P->dp.n_u, n_lp, ne);
+    const size_t budget = EHM_LDS_BUDGET / sizeof(double);
+    if (shared + wave > budget)
+        return fail(EHM_E_INVALID, "LP does not fit in LDS (%zu + %zu doubles)", shared, wave);
+    long long nw = std::min<long long>(api->max_threads / 64, (long long)((budget - shared) / wave));
+    nw = std::max(1LL, std::min(nw, n_items));
+    const size_t lds = (shared + (size_t)nw * wave) * sizeof(double);
+    if (!P->k2_ready.count(api)) {
+        HIP_TRY(api->set_lds(EHM_LDS_BUDGET), EHM_E_HIP);
+        P->k2_ready.insert(api);
+    }
+    // residency: LDS, and 2 wavefronts per SIMD at the instances' register budget
+    long long wg_per_cu = std::max<long long>(1, std::min<long long>(EHM_LDS_BUDGET / lds, 8 / nw));
+    long long grid = std::min<long long>((long long)P->num_cu * wg_per_cu, (n_items + nw - 1) / nw);
+    cfg.api = api;
+    cfg.L.grid = (int)std::max(1LL, grid);
+    cfg.L.threads = (int)(64 * nw);
+    cfg.L.lds_bytes = lds;
+    cfg.L.wave_doubles = (int)wave;
+    cfg.L.stream = P->stream;
+    return EHM_OK;
+}
+
+// stable counting sort of a batch by commutation index: order[k] = original position of the
+// k-th instance of the sorted batch, seg[d] = first sorted position of commutation d
+static void sort_by_commutation(int nd, int64_t n, const int32_t* didx, std::vector<int64_t>& order,
+                                std::vector<int32_t>& seg) {
+    seg.assign((size_t)nd + 1, 0);
+    for (int64_t k = 0; k < n; ++k) seg[(size_t)didx[k] + 1]++;
+    for (int d = 0; d < nd; ++d) seg[(size_t)d + 1] += seg[(size_t)d];
+    std::vector<int32_t> pos(seg.begin(), seg.end() - 1);
+    order.resize((size_t)n);
+    for (int64_t k = 0; k < n; ++k) order[(size_t)pos[(size_t)didx[k]]++] = k;
 }
 
 extern "C" {
@@ -517,6 +610,29 @@ int ehm_problem_create(const ehm_problem_desc* d, int device, ehm_problem** out)
     P->dp.c = P->dp.w + nw;
     P->dp.eps_a = d->eps_a;
     P->dp.eps_r = d->eps_r;
+    {
+        // LDS image of the constant LP block per commutation: [G | -S | -1 | 0], column-major
+        const int lda = m | 1, ncw = n + p + 2;
+        std::vector<double> img((size_t)nd * ncw * lda, 0.0);
+        for (int k = 0; k < nd; ++k) {
+            double* base = img.data() + (size_t)k * ncw * lda;
+            for (int i = 0; i < m; ++i) {
+                for (int j = 0; j < n; ++j)
+                    base[(size_t)j * lda + i] = d->G[((size_t)k * m + i) * n + j];
+                for (int q = 0; q < p; ++q)
+                    base[(size_t)(n + q) * lda + i] = -d->S[((size_t)k * m + i) * p + q];
+                base[(size_t)(n + p) * lda + i] = -1.0;
+            }
+        }
+        rc = P->wc2.ensure(img.size() * sizeof(double));
+        if (rc) { delete P; return rc; }
+        HIP_TRY(hipMemcpy(P->wc2.ptr, img.data(), img.size() * sizeof(double),
+                          hipMemcpyHostToDevice), EHM_E_HIP);
+        P->dp.Wc2 = P->wc2.as<double>();
+        P->dp.lda2 = lda;
+        P->dp.ncw2 = ncw;
+    }
+    if (const char* e = getenv("EHM_SOLVER")) P->solver_gen = (atoi(e) == 1) ? 1 : 2;
     P->delta_len = d->delta_len;
     if (d->deltas && d->delta_len > 0)
         P->deltas.assign(d->deltas, d->deltas + (size_t)nd * d->delta_len);
@@ -531,15 +647,19 @@ int ehm_problem_create(const ehm_problem_desc* d, int device, ehm_problem** out)
     P->lds_expand = lds_bytes_for(P->dp, LP_POINT, NODE_LDS_DOUBLES);
     const size_t lds_max = std::max(P->lds_point, P->lds_simplex);
     if (lds_max > 160 * 1024) {
-        ehm_problem_destroy(P);
-        return fail(EHM_E_INVALID, "LP does not fit in LDS (%zu bytes)", lds_max);
+        if (P->solver_gen == 1) {
+            ehm_problem_destroy(P);
+            return fail(EHM_E_INVALID, "LP does not fit in LDS (%zu bytes)", lds_max);
+        }
+    } else {
+        const void* kernels[] = {(const void*)k_point_batch, (const void*)k_simplex_batch,
+                                 (const void*)k_lcss_decide, (const void*)k_lcss_expand,
+                                 (const void*)k_vertex_solve};
+        for (const void* k : kernels)
+            HIP_TRY(hipFuncSetAttribute(k, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                        (int)lds_max), EHM_E_HIP);
+        P->v1_ok = true;
     }
-    const void* kernels[] = {(const void*)k_point_batch, (const void*)k_simplex_batch,
-                             (const void*)k_lcss_decide, (const void*)k_lcss_expand,
-                             (const void*)k_vertex_solve};
-    for (const void* k : kernels)
-        HIP_TRY(hipFuncSetAttribute(k, hipFuncAttributeMaxDynamicSharedMemorySize,
-                                    (int)lds_max), EHM_E_HIP);
     *out = P;
     return EHM_OK;
 }
@@ -549,6 +669,8 @@ int ehm_problem_destroy(ehm_problem* P) {
     (void)hipSetDevice(P->device);
     if (P->stream) (void)hipStreamSynchronize(P->stream);
     P->consts.release();
+    P->wc2.release();
+    P->seg.release();
     P->in0.release(); P->in1.release(); P->in2.release();
     P->out0.release(); P->out1.release(); P->out2.release(); P->out3.release();
     if (P->d_cnt) (void)hipFree(P->d_cnt);
@@ -561,6 +683,37 @@ int ehm_problem_set_eps(ehm_problem* P, double eps_a, double eps_r) {
     if (!P) return fail(EHM_E_INVALID, "null problem");
     P->dp.eps_a = eps_a;
     P->dp.eps_r = eps_r;
+    return EHM_OK;
+}
+
+int ehm_problem_set_solver(ehm_problem* P, int generation) {
+    if (!P) return fail(EHM_E_INVALID, "null problem");
+    if (generation != 1 && generation != 2) return fail(EHM_E_INVALID, "solver generation 1 or 2");
+    if (generation == 1 && !P->v1_ok)
+        return fail(EHM_E_INVALID, "the generation-1 kernels do not fit this problem in LDS");
+    P->solver_gen = generation;
+    return EHM_OK;
+}
+
+// wave-primitive self test of the k2 instances: out[5] per instance (see k2_selftest)
+int ehm_selftest(int device, double* out, int32_t max_instances, int32_t* n_instances) {
+    if (!out || !n_instances) return fail(EHM_E_INVALID, "null argument");
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || device < 0 || device >= ndev)
+        return fail(EHM_E_NO_DEVICE, "no HIP device %d (libehmpc has no CPU fallback)", device);
+    HIP_TRY(hipSetDevice(device), EHM_E_NO_DEVICE);
+    double* d_out = nullptr;
+    HIP_TRY(hipMalloc((void**)&d_out, 5 * sizeof(double)), EHM_E_HIP);
+    int k = 0;
+    for (k2_getter g : g_k2_getters) {
+        if (k >= max_instances) break;
+        g()->selftest(nullptr, d_out);
+        HIP_TRY(hipDeviceSynchronize(), EHM_E_HIP);
+        HIP_TRY(hipMemcpy(out + 5 * k, d_out, 5 * sizeof(double), hipMemcpyDeviceToHost), EHM_E_HIP);
+        ++k;
+    }
+    *n_instances = k;
+    (void)hipFree(d_out);
     return EHM_OK;
 }
 
@@ -604,6 +757,49 @@ static int point_batch(ehm_problem* P, int64_t n_inst, const double* theta,
                            hipMemcpyHostToDevice, P->stream), EHM_E_HIP);
     int32_t* d_status = P->out2.as<int32_t>();
     int32_t* d_iters = d_status + n_inst;
+    if (P->solver_gen == 2) {
+        // instances travel sorted by commutation (one constant block in LDS per run)
+        const int nd = P->dp.n_delta;
+        std::vector<int64_t> order;
+        std::vector<int32_t> seg;
+        sort_by_commutation(nd, n_inst, didx_host, order, seg);
+        std::vector<double> th((size_t)n_inst * p);
+        for (int64_t k = 0; k < n_inst; ++k)
+            std::memcpy(&th[(size_t)k * p], theta + (size_t)order[(size_t)k] * p, p * sizeof(double));
+        if ((rc = P->seg.ensure(seg.size() * sizeof(int32_t)))) return rc;
+        HIP_TRY(hipMemcpyAsync(P->in0.ptr, th.data(), th.size() * sizeof(double),
+                               hipMemcpyHostToDevice, P->stream), EHM_E_HIP);
+        HIP_TRY(hipMemcpyAsync(P->seg.ptr, seg.data(), seg.size() * sizeof(int32_t),
+                               hipMemcpyHostToDevice, P->stream), EHM_E_HIP);
+        K2Cfg cfg;
+        if ((rc = k2_config(P, feas ? LP_FEAS : LP_POINT, feas ? LP_FEAS : LP_POINT, n_inst, cfg)))
+            return rc;
+        cfg.api->point(cfg.L, P->dp, (long long)n_inst, P->in0.as<double>(),
+                       P->seg.as<int32_t>(), feas, P->out0.as<double>(), P->out1.as<double>(),
+                       d_status, d_iters, P->d_cnt);
+        P->launches++;
+        HIP_TRY(hipGetLastError(), EHM_E_HIP);
+        std::vector<double> Js((size_t)n_inst), us(u0 ? (size_t)n_inst * n_u : 0);
+        std::vector<int32_t> sts((size_t)n_inst), its((size_t)n_inst);
+        HIP_TRY(hipMemcpyAsync(Js.data(), P->out0.ptr, (size_t)n_inst * sizeof(double),
+                               hipMemcpyDeviceToHost, P->stream), EHM_E_HIP);
+        if (u0)
+            HIP_TRY(hipMemcpyAsync(us.data(), P->out1.ptr, (size_t)n_inst * n_u * sizeof(double),
+                                   hipMemcpyDeviceToHost, P->stream), EHM_E_HIP);
+        HIP_TRY(hipMemcpyAsync(sts.data(), d_status, (size_t)n_inst * sizeof(int32_t),
+                               hipMemcpyDeviceToHost, P->stream), EHM_E_HIP);
+        HIP_TRY(hipMemcpyAsync(its.data(), d_iters, (size_t)n_inst * sizeof(int32_t),
+                               hipMemcpyDeviceToHost, P->stream), EHM_E_HIP);
+        HIP_TRY(hipStreamSynchronize(P->stream), EHM_E_HIP);
+        for (int64_t k = 0; k < n_inst; ++k) {
+            const int64_t o = order[(size_t)k];
+            J[o] = Js[(size_t)k];
+            if (u0) std::memcpy(u0 + (size_t)o * n_u, &us[(size_t)k * n_u], n_u * sizeof(double));
+            if (status) status[o] = sts[(size_t)k];
+            if (iters) iters[o] = its[(size_t)k];
+        }
+        return EHM_OK;
+    }
     hipLaunchKernelGGL(k_point_batch, dim3(grid_for(P, n_inst)), dim3(64), P->lds_point,
                        P->stream, P->dp, (long long)n_inst, P->in0.as<double>(),
                        P->in1.as<int32_t>(), feas, P->out0.as<double>(), P->out1.as<double>(),
@@ -680,6 +876,54 @@ static int simplex_batch(ehm_problem* P, int64_t n_inst, const double* R, const 
         HIP_TRY(hipMemcpyAsync(P->in2.ptr, Vbar, (size_t)n_inst * (p + 1) * sizeof(double),
                                hipMemcpyHostToDevice, P->stream), EHM_E_HIP);
     int32_t* d_status = P->out2.as<int32_t>();
+    if (P->solver_gen == 2) {
+        const int nd = P->dp.n_delta, nv = p + 1;
+        std::vector<int64_t> order;
+        std::vector<int32_t> seg;
+        sort_by_commutation(nd, n_inst, didx_host, order, seg);
+        std::vector<double> Rs((size_t)n_inst * nR), Vs(slack == SX_SLACK ? (size_t)n_inst * nv : 0);
+        for (int64_t k = 0; k < n_inst; ++k) {
+            const int64_t o = order[(size_t)k];
+            std::memcpy(&Rs[(size_t)k * nR], R + (size_t)o * nR, nR * sizeof(double));
+            if (slack == SX_SLACK)
+                std::memcpy(&Vs[(size_t)k * nv], Vbar + (size_t)o * nv, nv * sizeof(double));
+        }
+        if ((rc = P->seg.ensure(seg.size() * sizeof(int32_t)))) return rc;
+        HIP_TRY(hipMemcpyAsync(P->in0.ptr, Rs.data(), Rs.size() * sizeof(double),
+                               hipMemcpyHostToDevice, P->stream), EHM_E_HIP);
+        if (slack == SX_SLACK)
+            HIP_TRY(hipMemcpyAsync(P->in2.ptr, Vs.data(), Vs.size() * sizeof(double),
+                                   hipMemcpyHostToDevice, P->stream), EHM_E_HIP);
+        HIP_TRY(hipMemcpyAsync(P->seg.ptr, seg.data(), seg.size() * sizeof(int32_t),
+                               hipMemcpyHostToDevice, P->stream), EHM_E_HIP);
+        const int kind = (slack == SX_SLACK) ? LP_SLACK
+                         : (slack == SX_FEAS) ? LP_FEAS_SIMPLEX : LP_MIN_SIMPLEX;
+        K2Cfg cfg;
+        if ((rc = k2_config(P, kind, kind, n_inst, cfg))) return rc;
+        cfg.api->simplex(cfg.L, P->dp, (long long)n_inst, P->in0.as<double>(),
+                         P->in2.as<double>(), P->seg.as<int32_t>(), slack, P->out0.as<double>(),
+                         alpha ? P->out1.as<double>() : (double*)nullptr, d_status,
+                         d_status + n_inst, P->d_cnt);
+        P->launches++;
+        HIP_TRY(hipGetLastError(), EHM_E_HIP);
+        std::vector<double> objs((size_t)n_inst), als(alpha ? (size_t)n_inst * nv : 0);
+        std::vector<int32_t> sts((size_t)n_inst);
+        HIP_TRY(hipMemcpyAsync(objs.data(), P->out0.ptr, (size_t)n_inst * sizeof(double),
+                               hipMemcpyDeviceToHost, P->stream), EHM_E_HIP);
+        if (alpha)
+            HIP_TRY(hipMemcpyAsync(als.data(), P->out1.ptr, (size_t)n_inst * nv * sizeof(double),
+                                   hipMemcpyDeviceToHost, P->stream), EHM_E_HIP);
+        HIP_TRY(hipMemcpyAsync(sts.data(), d_status, (size_t)n_inst * sizeof(int32_t),
+                               hipMemcpyDeviceToHost, P->stream), EHM_E_HIP);
+        HIP_TRY(hipStreamSynchronize(P->stream), EHM_E_HIP);
+        for (int64_t k = 0; k < n_inst; ++k) {
+            const int64_t o = order[(size_t)k];
+            obj[o] = objs[(size_t)k];
+            if (alpha) std::memcpy(alpha + (size_t)o * nv, &als[(size_t)k * nv], nv * sizeof(double));
+            if (status) status[o] = sts[(size_t)k];
+        }
+        return EHM_OK;
+    }
     hipLaunchKernelGGL(k_simplex_batch, dim3(grid_for(P, n_inst)), dim3(64), P->lds_simplex,
                        P->stream, P->dp, (long long)n_inst, P->in0.as<double>(),
                        P->in2.as<double>(), P->in1.as<int32_t>(), slack, P->out0.as<double>(),
@@ -1218,9 +1462,15 @@ int ehm_partition_run(ehm_problem* P, int64_t n_roots, const double* root_vertic
     // vertex of a feasible Theta, so V_R reduces to the vertex solves (lib/worker.py:279-291)
     long long ref_solves = 0;
     if (action == 0) {
-        hipLaunchKernelGGL(k_vertex_solve, dim3(grid_for(P, n_roots * (p + 1))), dim3(64),
-                           P->lds_point, P->stream, P->dp, T->dt, fr_a.as<int32_t>(),
-                           (int)n_roots, P->d_cnt);
+        if (P->solver_gen == 2) {
+            K2Cfg cfg;
+            RUN_TRY(k2_config(P, LP_POINT, LP_POINT, n_roots * (p + 1), cfg));
+            cfg.api->vertex(cfg.L, P->dp, T->dt, fr_a.as<int32_t>(), (int)n_roots, P->d_cnt);
+        } else {
+            hipLaunchKernelGGL(k_vertex_solve, dim3(grid_for(P, n_roots * (p + 1))), dim3(64),
+                               P->lds_point, P->stream, P->dp, T->dt, fr_a.as<int32_t>(),
+                               (int)n_roots, P->d_cnt);
+        }
         P->launches++;
         ref_solves += n_roots * (2 + (p + 1));   // P_theta check + V_R MICP + vertex solves
     }
@@ -1266,10 +1516,16 @@ int ehm_partition_run(ehm_problem* P, int64_t n_roots, const double* root_vertic
             RUN_TRY(open_flag.ensure((size_t)nf * 4 * 2));
             RUN_TRY(open_list.ensure((size_t)nf * 4 * 2));
         }
+        K2Cfg cfg_d;
+        if (P->solver_gen == 2) RUN_TRY(k2_config(P, LP_SLACK, LP_SLACK, nf, cfg_d));
         stamp();
-        hipLaunchKernelGGL(k_lcss_decide, dim3(grid_for(P, nf)), dim3(64), P->lds_simplex,
-                           P->stream, P->dp, T->dt, cur, (int)nf, open_flag.as<int32_t>(),
-                           P->d_cnt);
+        if (P->solver_gen == 2)
+            cfg_d.api->decide(cfg_d.L, P->dp, T->dt, cur, (int)nf, open_flag.as<int32_t>(),
+                              P->d_cnt);
+        else
+            hipLaunchKernelGGL(k_lcss_decide, dim3(grid_for(P, nf)), dim3(64), P->lds_simplex,
+                               P->stream, P->dp, T->dt, cur, (int)nf, open_flag.as<int32_t>(),
+                               P->d_cnt);
         stamp();
         ev_kind.push_back(0);
         hipLaunchKernelGGL(k_scan_open, dim3(1), dim3(1024), 0, P->stream,
@@ -1305,10 +1561,16 @@ int ehm_partition_run(ehm_problem* P, int64_t n_roots, const double* root_vertic
             RUN_TRY(nb.ensure((size_t)n_open * 2 * 4 * 2));
         }
         nxt = nb.as<int32_t>();
+        K2Cfg cfg_e;
+        if (P->solver_gen == 2) RUN_TRY(k2_config(P, LP_POINT, LP_POINT, n_open, cfg_e));
         stamp();
-        hipLaunchKernelGGL(k_lcss_expand, dim3(grid_for(P, n_open)), dim3(64), P->lds_expand,
-                           P->stream, P->dp, T->dt, open_list.as<int32_t>(), (int)n_open,
-                           (int)n_nodes, nxt, P->d_cnt);
+        if (P->solver_gen == 2)
+            cfg_e.api->expand(cfg_e.L, P->dp, T->dt, open_list.as<int32_t>(), (int)n_open,
+                              (int)n_nodes, nxt, P->d_cnt);
+        else
+            hipLaunchKernelGGL(k_lcss_expand, dim3(grid_for(P, n_open)), dim3(64), P->lds_expand,
+                               P->stream, P->dp, T->dt, open_list.as<int32_t>(), (int)n_open,
+                               (int)n_nodes, nxt, P->d_cnt);
         stamp();
         ev_kind.push_back(1);
         P->launches++;

@@ -1,0 +1,673 @@
+// Second-generation wave-local interior-point LP solver for gfx950 (CDNA4).
+//
+// What changed against ehm_ipm.h (one wavefront per workgroup, whole LP matrix private):
+//   * every LP of one commutation shares the SAME dense block.  With the simplex
+//     parametrised by  psi = theta - R0  instead of barycentric weights, the MPC rows are
+//         G z - S psi <= w + S R0
+//     for every node, so the workgroup keeps ONE copy of  Wc = [G | -S | -1 | 0]  in LDS and
+//     8-16 wavefronts solve their own LPs against it.  What is private to an LP is tiny:
+//     the right-hand side, a handful of "extra" rows X (simplex facets in psi coordinates,
+//     the two suboptimality rows, the phase-one bound) and the n x n normal matrix;
+//   * the normal matrix is eliminated with lane j holding row j in registers, but the pivot
+//     row travels through LDS: by symmetry of the Schur complements row k equals column k,
+//     and column k is "register k of every lane" -- one ds_write per step publishes it and
+//     the lanes read it back as uniform (broadcast) ds_reads.  No v_readlane / SGPR traffic;
+//   * wave reductions use DPP row shifts / row broadcasts instead of ds_bpermute shuffles;
+//   * one reciprocal per row and iteration (v_rcp_f64 + Newton) instead of ~25 divisions.
+// The iteration itself (Mehrotra predictor-corrector, infeasible start, stall acceptance,
+// dependent-pivot guard) is unchanged: the psi-LP is the beta-LP under a linear change of
+// variables, and Newton's method is affine invariant (checked in oracle/ipm_numpy.py terms:
+// identical iteration counts, optimal values equal to 1e-12).
+//
+// Reference arithmetic replaced: the `Problem.solve(solver=MOSEK)` call sites of
+// lib/oracle.py:131,134,166,169,203,276,305,350.
+#pragma once
+
+#include "ehm_dev.h"
+
+#ifndef EHM_NP
+#error "EHM_NP (column capacity, multiple of 4) must be defined"
+#endif
+#ifndef EHM_SLOTS
+#error "EHM_SLOTS (row slots per lane) must be defined"
+#endif
+
+#define EHM2_TOL_RES      1e-10
+#define EHM2_TOL_GAP      1e-10
+#define EHM2_MAX_ITER     40
+#define EHM2_STEP_FRAC    0.99
+#define EHM2_PIVOT_REL    1e-13
+#define EHM2_PIVOT_BIG    1e128
+#define EHM2_STALL_ZONE   1e4
+#define EHM2_ACCEPT_MERIT 1e3
+
+// every compiled instance lives in its own namespace: the sizes below differ per instance,
+// and inline host functions of the same name would otherwise be merged by the linker
+#define EHM2_CAT2(a, b, c) a##b##_##c
+#define EHM2_CAT(a, b, c) EHM2_CAT2(a, b, c)
+#define EHM2_NS EHM2_CAT(ehm2_, EHM_NP, EHM_SLOTS)
+
+namespace EHM2_NS {
+
+using namespace ehm;
+
+constexpr int NP = EHM_NP;
+constexpr int SLOTS = EHM_SLOTS;
+constexpr int MROWS = 64 * SLOTS;
+
+// ---------------------------------------------------------------------------------------
+// wave helpers
+// ---------------------------------------------------------------------------------------
+// LDS hand-off between the lanes of ONE wavefront: DS operations of a wave execute in issue
+// order, so only the compiler has to be kept from reordering.
+__device__ __forceinline__ void wsync() {
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+}
+
+template <int CTRL, int ROW_MASK>
+__device__ __forceinline__ double dpp_move(double identity, double v) {
+    const int lo = __builtin_amdgcn_update_dpp(__double2loint(identity), __double2loint(v), CTRL,
+                                               ROW_MASK, 0xf, false);
+    const int hi = __builtin_amdgcn_update_dpp(__double2hiint(identity), __double2hiint(v), CTRL,
+                                               ROW_MASK, 0xf, false);
+    return __hiloint2double(hi, lo);
+}
+__device__ __forceinline__ double lane63(double v) {
+    const int lo = __builtin_amdgcn_readlane(__double2loint(v), 63);
+    const int hi = __builtin_amdgcn_readlane(__double2hiint(v), 63);
+    return __hiloint2double(hi, lo);
+}
+// row_shr:1,2,4,8 leave each 16-lane row's total in its lane 15; row_bcast:15 / :31 carry
+// it into the following rows, so lane 63 ends with the wave total (the reduction LLVM's
+// atomic optimizer emits on GFX9).
+#define EHM2_DPP_REDUCE(OP, IDENT)                                       \
+    v = OP(v, dpp_move<0x111, 0xf>(IDENT, v));                           \
+    v = OP(v, dpp_move<0x112, 0xf>(IDENT, v));                           \
+    v = OP(v, dpp_move<0x114, 0xf>(IDENT, v));                           \
+    v = OP(v, dpp_move<0x118, 0xf>(IDENT, v));                           \
+    v = OP(v, dpp_move<0x142, 0xa>(IDENT, v));                           \
+    v = OP(v, dpp_move<0x143, 0xc>(IDENT, v));                           \
+    return lane63(v);
+__device__ __forceinline__ double op_add(double a, double b) { return a + b; }
+__device__ __forceinline__ double op_max(double a, double b) { return fmax(a, b); }
+__device__ __forceinline__ double op_min(double a, double b) { return fmin(a, b); }
+#ifdef EHM2_REDUCE_SHFL
+__device__ __forceinline__ double wave_sum(double v) {
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+    return v;
+}
+__device__ __forceinline__ double wave_max(double v) {
+    for (int o = 32; o > 0; o >>= 1) v = fmax(v, __shfl_xor(v, o, 64));
+    return v;
+}
+#else
+__device__ __forceinline__ double wave_sum(double v) { EHM2_DPP_REDUCE(op_add, 0.0) }
+__device__ __forceinline__ double wave_max(double v) {
+    EHM2_DPP_REDUCE(op_max, -__builtin_huge_val())
+}
+#endif
+__device__ __forceinline__ double readlane_d(double v, int src) {
+    const int lo = __builtin_amdgcn_readlane(__double2loint(v), src);
+    const int hi = __builtin_amdgcn_readlane(__double2hiint(v), src);
+    return __hiloint2double(hi, lo);
+}
+// Keeps everything derived from x inside the current loop iteration: without it LLVM hoists
+// dozens of loop-invariant per-lane LDS addresses out of the IPM iteration and spills them.
+__device__ __forceinline__ int pin(int x) {
+    asm volatile("" : "+v"(x));
+    return x;
+}
+// 1/x for positive finite x well inside the normal range: v_rcp_f64 + two Newton steps
+__device__ __forceinline__ double frcp(double x) {
+    double r = __builtin_amdgcn_rcp(x);
+    double e = fma(-x, r, 1.0);
+    r = fma(r, e, r);
+    e = fma(-x, r, 1.0);
+    r = fma(r, e, r);
+    return r;
+}
+
+// ---------------------------------------------------------------------------------------
+// LDS layout
+// ---------------------------------------------------------------------------------------
+// Shared by the workgroup (image of DevProblem::Wc2 + w + c of one commutation).
+struct Shared {
+    const double* Wc;   // [ncw][lda]   G | -S | -1 | 0
+    const double* wv;   // [m]
+    const double* cv;   // [n]
+    int n, m, p, lda, ncw;
+};
+__host__ __device__ inline size_t shared_doubles(const DevProblem& P) {
+    return (((size_t)P.ncw2 * P.lda2 + P.m + P.n) + 1) & ~(size_t)1;
+}
+__device__ inline void carve_shared(Shared& S, double* base, const DevProblem& P) {
+    S.n = P.n; S.m = P.m; S.p = P.p; S.lda = P.lda2; S.ncw = P.ncw2;
+    S.Wc = base;
+    S.wv = base + (size_t)P.ncw2 * P.lda2;
+    S.cv = S.wv + P.m;
+}
+// all threads of the workgroup; caller brackets it with __syncthreads()
+__device__ inline void load_shared(const DevProblem& P, int d, double* base, int tid, int nthr) {
+    const int tot = P.ncw2 * P.lda2;
+    const double* src = P.Wc2 + (size_t)d * tot;
+    for (int k = tid; k < tot; k += nthr) base[k] = src[k];
+    const double* wd = P.w + (size_t)d * P.m;
+    for (int k = tid; k < P.m; k += nthr) base[tot + k] = wd[k];
+    for (int k = tid; k < P.n; k += nthr) base[tot + P.m + k] = P.c[k];
+}
+
+// Private to a wavefront.
+struct Wave {
+    double* M;      // NP x LDM normal matrix / scratch for column products (>= 512 doubles)
+    double* X;      // [n_lp][ldx] extra rows, column-major
+    double* vm0;    // MROWS
+    double* vm1;    // MROWS
+    double* c;      // NP objective
+    double* x;      // NP iterate
+    double* xb;     // NP best iterate
+    double* t;      // NP scratch
+    double* ub;     // NP pivot-row broadcast
+    double* db;     // NP original diagonal, then reciprocal pivots
+    double* sc;     // 256 doubles: partial column products while W.M holds the U factor
+    int n_lp, ne, ldx, ldm, xbase;
+    int n_lin;      // LP columns j < n_lin are Wc columns j
+    int spec_col;   // Wc column of LP column n_lin (when n_lin < n_lp)
+};
+constexpr int LDM = NP + 1;     // odd: row- and column-wise access both conflict free
+constexpr size_t M_DOUBLES = ((size_t)NP * LDM < 512) ? 512 : (size_t)NP * LDM;
+__host__ __device__ inline size_t wave_lp_doubles(int n_lp, int ne) {
+    const size_t Md = M_DOUBLES;
+    const size_t ldx = ne ? ((size_t)ne | 1) : 0;
+    return ((Md + (size_t)n_lp * ldx + 2 * (size_t)MROWS + 6 * (size_t)NP + 256) + 1) &
+           ~(size_t)1;
+}
+__device__ inline void carve_wave(Wave& W, double* base, int n_lp, int ne, int m) {
+    W.n_lp = n_lp;
+    W.ne = ne;
+    W.ldm = LDM;
+    W.ldx = ne ? (ne | 1) : 0;
+    W.xbase = lp_xbase(m, ne);
+    // an instance compiled with more slots than the LP needs keeps the extras in ITS last slot
+    if (ne > 0 && W.xbase < 64 * (SLOTS - 1)) W.xbase = 64 * (SLOTS - 1);
+    W.M = base;   base += M_DOUBLES;
+    W.X = base;   base += (size_t)n_lp * W.ldx;
+    W.vm0 = base; base += MROWS;
+    W.vm1 = base; base += MROWS;
+    W.c = base;   base += NP;
+    W.x = base;   base += NP;
+    W.xb = base;  base += NP;
+    W.t = base;   base += NP;
+    W.ub = base;  base += NP;
+    W.db = base;  base += NP;
+    W.sc = base;
+}
+
+__device__ __forceinline__ int wc_col(const Wave& W, int j) {
+    return (j < W.n_lin) ? j : W.spec_col;
+}
+
+struct IpmResult {
+    double obj;
+    double merit;
+    int iters;
+    int status;   // 0 optimal / accepted, 1 stalled
+};
+
+// Per-lane description of the rows this lane owns.
+struct RowMap {
+    bool valid[SLOTS];
+    const double* last_base;   // last slot: address of column 0 for this lane's row
+    int last_stride;           // its column stride
+    const double* last_spec;   // its address in the special column
+    int lane;
+};
+__device__ __forceinline__ void make_rowmap(RowMap& rm, const Shared& S, const Wave& W, int lane) {
+    rm.lane = lane;
+    const int zero_off = (S.ncw - 1) * S.lda;
+#pragma unroll
+    for (int sl = 0; sl < SLOTS - 1; ++sl) rm.valid[sl] = (lane + 64 * sl) < S.m;
+    const int i = lane + 64 * (SLOTS - 1);
+    const bool spec = W.n_lin < W.n_lp;
+    if (i < S.m) {
+        rm.valid[SLOTS - 1] = true;
+        rm.last_base = S.Wc + i;
+        rm.last_stride = S.lda;
+        rm.last_spec = S.Wc + (spec ? W.spec_col * S.lda : zero_off) + i;
+    } else if (i >= W.xbase && i < W.xbase + W.ne) {
+        rm.valid[SLOTS - 1] = true;
+        rm.last_base = W.X + (i - W.xbase);
+        rm.last_stride = W.ldx;
+        rm.last_spec = W.X + (size_t)W.n_lin * W.ldx + (i - W.xbase);
+    } else {
+        rm.valid[SLOTS - 1] = false;
+        rm.last_base = S.Wc + zero_off;
+        rm.last_stride = 0;
+        rm.last_spec = S.Wc + zero_off;
+    }
+}
+
+// out_i = sum_j A[i][j] v[j] for this lane's rows; v: n_lp doubles in LDS
+__device__ __forceinline__ void rows_times(const Shared& S, const Wave& W, const RowMap& rm,
+                                           const double* v, double (&out)[SLOTS]) {
+#pragma unroll
+    for (int sl = 0; sl < SLOTS; ++sl) out[sl] = 0.0;
+    const double* pa = S.Wc + rm.lane;      // slots < SLOTS-1 : MPC rows, offset 64*sl
+    const double* pb = rm.last_base;
+    const int lda = S.lda;
+    for (int j = 0; j < W.n_lin; ++j) {
+        const double vj = v[j];
+#pragma unroll
+        for (int sl = 0; sl < SLOTS - 1; ++sl) out[sl] = fma(pa[64 * sl], vj, out[sl]);
+        out[SLOTS - 1] = fma(*pb, vj, out[SLOTS - 1]);
+        pa += lda;
+        pb += rm.last_stride;
+    }
+    if (W.n_lin < W.n_lp) {
+        const double vj = v[W.n_lin];
+        const double* ps = S.Wc + (size_t)W.spec_col * lda + rm.lane;
+#pragma unroll
+        for (int sl = 0; sl < SLOTS - 1; ++sl) out[sl] = fma(ps[64 * sl], vj, out[sl]);
+        out[SLOTS - 1] = fma(*rm.last_spec, vj, out[SLOTS - 1]);
+    }
+#pragma unroll
+    for (int sl = 0; sl < SLOTS; ++sl) out[sl] = rm.valid[sl] ? out[sl] : 0.0;
+}
+
+// Column pointers of the 4-column block cb for the MPC rows (pc) and the extra rows (px);
+// columns beyond n_lp point at the zero column.
+__device__ __forceinline__ void block_cols(const Shared& S, const Wave& W, int cb,
+                                           const double* (&pc)[4], const double* (&px)[4]) {
+    const double* zero = S.Wc + (size_t)(S.ncw - 1) * S.lda;
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+        const int j = 4 * cb + q;
+        const bool in = j < W.n_lp;
+        pc[q] = in ? (S.Wc + (size_t)wc_col(W, j) * S.lda) : zero;
+        px[q] = (in && W.ne > 0) ? (W.X + (size_t)j * W.ldx) : zero;
+    }
+}
+
+// (A^T u0)_j and (A^T u1)_j in lane j (j < n_lp); u0/u1: m-vectors in LDS (row-indexed).
+// Lanes = (column block, K-split); partial sums meet in `sc` (4*64 doubles per vector).
+template <bool TWO>
+__device__ __forceinline__ void cols_times(const Shared& S, const Wave& W, const double* u0,
+                                           const double* u1, double* sc, int lane, double& r0,
+                                           double& r1) {
+    constexpr int nb = NP / 4;
+    constexpr int ks = 64 / nb;
+    const int cb = pin(lane % nb);
+    const int h = pin(lane / nb);
+    const bool active = h < ks;
+    double a0[4] = {0.0, 0.0, 0.0, 0.0}, a1[4] = {0.0, 0.0, 0.0, 0.0};
+    if (active) {
+        const double *pc[4], *px[4];
+        block_cols(S, W, cb, pc, px);
+        for (int i = h; i < S.m; i += ks) {
+            const double v0 = u0[i];
+            const double v1 = TWO ? u1[i] : 0.0;
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const double a = pc[q][i];
+                a0[q] = fma(a, v0, a0[q]);
+                if (TWO) a1[q] = fma(a, v1, a1[q]);
+            }
+        }
+        for (int e = h; e < W.ne; e += ks) {
+            const double v0 = u0[W.xbase + e];
+            const double v1 = TWO ? u1[W.xbase + e] : 0.0;
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const double a = px[q][e];
+                a0[q] = fma(a, v0, a0[q]);
+                if (TWO) a1[q] = fma(a, v1, a1[q]);
+            }
+        }
+    }
+    // scratch[vec][q][h][cb]: consecutive lanes write consecutive doubles
+    constexpr int plane = ks * nb;
+    wsync();
+    if (active) {
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            sc[q * plane + lane] = a0[q];
+            if (TWO) sc[(4 + q) * plane + lane] = a1[q];
+        }
+    }
+    wsync();
+    r0 = 0.0;
+    r1 = 0.0;
+    if (lane < NP) {
+        const int q = lane & 3, c = lane >> 2;
+        const double* s0 = sc + q * plane + c;
+#pragma unroll
+        for (int hh = 0; hh < ks; ++hh) {
+            r0 += s0[hh * nb];
+            if (TWO) r1 += s0[4 * plane + hh * nb];
+        }
+    }
+    wsync();
+}
+
+// M = A^T diag(dvec) A into W.M (full symmetric), dvec an m-vector in LDS.
+__device__ inline void form_normal_matrix(const Shared& S, const Wave& W, const double* dvec,
+                                          int lane) {
+    constexpr int nb = NP / 4;
+    constexpr int T = nb * (nb + 1) / 2;
+    constexpr bool split = (T <= 32);
+    const int task = split ? (lane & 31) : lane;
+    const int h = split ? (lane >> 5) : 0;
+    const int stride = split ? 2 : 1;
+    int bj = 0, rem = task;
+    while (rem > bj) { rem -= (bj + 1); ++bj; }
+    const int bk = pin(rem);
+    bj = pin(bj);
+    const bool active = task < T;
+    double acc[4][4];
+#pragma unroll
+    for (int q = 0; q < 4; ++q)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) acc[q][r] = 0.0;
+    if (active) {
+        const double *cj[4], *xj[4], *ck[4], *xk[4];
+        block_cols(S, W, bj, cj, xj);
+        block_cols(S, W, bk, ck, xk);
+        for (int i = h; i < S.m; i += stride) {
+            const double d = dvec[i];
+            double aj[4], ak[4];
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                aj[q] = cj[q][i] * d;
+                ak[q] = ck[q][i];
+            }
+#pragma unroll
+            for (int q = 0; q < 4; ++q)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) acc[q][r] = fma(aj[q], ak[r], acc[q][r]);
+        }
+        for (int e = h; e < W.ne; e += stride) {
+            const double d = dvec[W.xbase + e];
+            double aj[4], ak[4];
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                aj[q] = xj[q][e] * d;
+                ak[q] = xk[q][e];
+            }
+#pragma unroll
+            for (int q = 0; q < 4; ++q)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) acc[q][r] = fma(aj[q], ak[r], acc[q][r]);
+        }
+    }
+    if (split) {
+#pragma unroll
+        for (int q = 0; q < 4; ++q)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) acc[q][r] += __shfl_xor(acc[q][r], 32, 64);
+    }
+    wsync();
+    if (active && h == 0) {
+#pragma unroll
+        for (int q = 0; q < 4; ++q)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int jj = 4 * bj + q, kk = 4 * bk + r;
+                W.M[jj * LDM + kk] = acc[q][r];
+                W.M[kk * LDM + jj] = acc[q][r];
+            }
+    }
+    wsync();
+}
+
+// Row-owned elimination of the n x n normal matrix (lane j holds row j in registers), pivot
+// rows broadcast through LDS and NO per-step lane predicates:
+//   * step k publishes column k of the current Schur complement (register k of every lane;
+//     by symmetry it is row k) into row k of W.M.  After the loop the upper triangle of W.M
+//     therefore holds U, and W.db[k] holds 1/U[k][k] (guarded);
+//   * the elimination always runs over all NP columns: columns n_lp..NP-1 are identically
+//     zero (their pointers aim at the zero column), so their pivots are frozen by the guard
+//     and their solution components are exactly 0 -- no data-dependent control flow at all;
+//   * every lane forms its multiplier and updates its trailing row, also the lanes <= k whose
+//     rows are finished: what they destroy is their copy of U (read from LDS from now on),
+//     never their multipliers L[lane][q], q < lane, which stay in row[q].
+// On entry W.db[j] = original diagonal (dependent-pivot guard, LIPSOL/PCx).
+__device__ __forceinline__ void lu_factor(double (&row)[NP], const Wave& W, int lane) {
+#pragma unroll
+    for (int k = 0; k < NP; ++k) {
+        if (lane < NP) W.M[k * LDM + lane] = row[k];
+        wsync();
+        double piv = W.M[k * LDM + k];
+        const double orig = W.db[k];
+        const bool bad = !(piv > EHM2_PIVOT_REL * orig) || !(piv > 0.0);
+        piv = bad ? EHM2_PIVOT_BIG : piv;
+        const double rinv = frcp(piv);
+        if (lane == 0) W.db[k] = rinv;
+        const double l = row[k] * rinv;
+        row[k] = l;
+#pragma unroll
+        for (int q = k + 1; q < NP; ++q) {
+            const double ukq = W.M[k * LDM + q];
+            row[q] = fma(-l, ukq, row[q]);
+        }
+        // the trailing update of step k stays in step k: left alone, the compiler sinks each
+        // FMA chain to where row[q] is next read (step q) and keeps n^2/2 broadcast values alive
+#pragma unroll
+        for (int q = k + 1; q < NP; ++q) asm volatile("" : "+v"(row[q]));
+    }
+    wsync();
+}
+
+// Solve (LU) x = rhs; lane j passes rhs_j, receives x_j, and W.t[0..n) holds x as well.
+// The running right-hand side of a finished lane may turn into garbage: y_k / x_k are taken
+// from the broadcast and parked in LDS by lane 0.
+__device__ __forceinline__ double lu_solve(const double (&row)[NP], const Wave& W, double rhs,
+                                           int lane) {
+    double bv = rhs;
+#pragma unroll
+    for (int k = 0; k < NP; ++k) {
+        const double yk = readlane_d(bv, k);
+        if (lane == 0) W.ub[k] = yk;
+        bv = fma(-row[k], yk, bv);
+        if ((k & 3) == 3) __builtin_amdgcn_sched_barrier(0);
+    }
+    wsync();
+    const int jl = (lane < NP) ? lane : (NP - 1);
+    bv = W.ub[jl];
+    const double* urow = W.M + jl * LDM;
+#pragma unroll
+    for (int k = NP - 1; k >= 0; --k) {
+        const double xk = readlane_d(bv, k) * W.db[k];
+        if (lane == 0) W.t[k] = xk;
+        bv = fma(-urow[k], xk, bv);
+        if ((k & 3) == 0) __builtin_amdgcn_sched_barrier(0);
+    }
+    wsync();
+    return W.t[jl];
+}
+
+// ---------------------------------------------------------------------------------------
+// The solver.  On entry: W.X, W.c filled, b in registers (row layout of RowMap).
+// On exit: W.xb holds the best primal iterate.
+// ---------------------------------------------------------------------------------------
+__device__ inline IpmResult ipm_solve(const Shared& S, const Wave& W, const double (&b)[SLOTS],
+                                      int lane0) {
+    int lane = lane0;
+    const int n = W.n_lp;
+    const int m_lp = S.m + W.ne;
+    RowMap rm;
+    make_rowmap(rm, S, W, lane);
+    double s[SLOTS], lam[SLOTS];
+    int ridx[SLOTS];
+    double bmax = 0.0;
+#pragma unroll
+    for (int sl = 0; sl < SLOTS; ++sl) {
+        ridx[sl] = lane + 64 * sl;
+        s[sl] = rm.valid[sl] ? fmax(b[sl], 1.0) : 1.0;     // x0 = 0  =>  b - A x0 = b
+        lam[sl] = rm.valid[sl] ? 1.0 : 0.0;
+        bmax = fmax(bmax, rm.valid[sl] ? fabs(b[sl]) : 0.0);
+    }
+    const double bnorm = 1.0 + wave_max(bmax);
+    const double cj = (lane < n) ? W.c[lane] : 0.0;
+    const double cnorm = 1.0 + wave_max(fabs(cj));
+    if (lane < NP) {
+        W.x[lane] = 0.0;
+        W.xb[lane] = 0.0;
+    }
+    // rows nobody owns must read as zero in the column products
+#pragma unroll
+    for (int sl = 0; sl < SLOTS; ++sl) {
+        if (!rm.valid[sl]) {
+            W.vm0[ridx[sl]] = 0.0;
+            W.vm1[ridx[sl]] = 0.0;
+        }
+    }
+    wsync();
+
+    IpmResult res;
+    res.obj = 0.0;
+    res.merit = 1e300;
+    res.iters = 0;
+    res.status = 1;
+    int stall = 0;
+    const double inv_m = 1.0 / (double)m_lp;
+
+    for (int it = 0; it <= EHM2_MAX_ITER; ++it) {
+        lane = pin(lane0);      // per-lane addresses are re-derived every iteration (see pin)
+        // ---- residuals -----------------------------------------------------------------
+        double r_p[SLOTS], rs[SLOTS], dd[SLOTS];
+        rows_times(S, W, rm, W.x, r_p);
+        double rpmax = 0.0, sl_sum = 0.0, bl_sum = 0.0;
+#pragma unroll
+        for (int sl = 0; sl < SLOTS; ++sl) {
+            r_p[sl] = rm.valid[sl] ? (r_p[sl] + s[sl] - b[sl]) : 0.0;
+            rpmax = fmax(rpmax, fabs(r_p[sl]));
+            sl_sum = fma(s[sl], lam[sl], sl_sum);
+            bl_sum = fma(b[sl], lam[sl], bl_sum);
+            rs[sl] = frcp(s[sl]);
+            dd[sl] = lam[sl] * rs[sl];
+        }
+#pragma unroll
+        for (int sl = 0; sl < SLOTS; ++sl) {
+            if (rm.valid[sl]) {
+                W.vm0[ridx[sl]] = lam[sl];
+                W.vm1[ridx[sl]] = dd[sl] * r_p[sl];
+            }
+        }
+        wsync();
+        double atl, atdr;
+        cols_times<true>(S, W, W.vm0, W.vm1, W.M, lane, atl, atdr);   // W.M is free here
+        const double cjj = (lane < n) ? W.c[lane] : 0.0;
+        const double xjj = (lane < n) ? W.x[lane] : 0.0;
+        const double r_d = (lane < n) ? (atl + cjj) : 0.0;
+        const double emax = wave_max(fmax(rpmax / bnorm, fabs(r_d) / cnorm));
+        const double mu = wave_sum(sl_sum) * inv_m;
+        const double dobj = -wave_sum(bl_sum);
+        const double pobj = wave_sum(cjj * xjj);
+        const double e_g = fabs(pobj - dobj) / (1.0 + fabs(pobj));
+        const double merit = fmax(emax / EHM2_TOL_RES, e_g / EHM2_TOL_GAP);
+        if (merit < res.merit) {
+            res.merit = merit;
+            res.obj = pobj;
+            stall = 0;
+            if (lane < NP) W.xb[lane] = W.x[lane];
+        } else if (res.merit < EHM2_STALL_ZONE) {
+            ++stall;
+        }
+        res.iters = it;
+        if (merit <= 1.0) {
+            res.status = 0;
+            break;
+        }
+        if (stall >= 3 || it == EHM2_MAX_ITER || !(merit == merit)) break;
+
+        // ---- normal matrix and its factorisation ----------------------------------------
+#pragma unroll
+        for (int sl = 0; sl < SLOTS; ++sl)
+            if (rm.valid[sl]) W.vm0[ridx[sl]] = dd[sl];
+        wsync();
+        form_normal_matrix(S, W, W.vm0, lane);
+        double row[NP];
+        {
+            // lanes >= NP carry a copy of row NP-1; nothing they compute is ever read
+            const double* mrow = W.M + ((lane < NP) ? lane : (NP - 1)) * LDM;
+#pragma unroll
+            for (int q = 0; q < NP; ++q) row[q] = mrow[q];
+            if (lane < NP) W.db[lane] = mrow[lane];
+        }
+        wsync();
+        lu_factor(row, W, lane);
+
+        // ---- predictor ------------------------------------------------------------------
+        const double rhs_aff = (lane < n) ? (-cjj - atdr) : 0.0;
+        double dxj = lu_solve(row, W, rhs_aff, lane);
+        double adx[SLOTS];
+        rows_times(S, W, rm, W.t, adx);
+        double ds_a[SLOTS], dl_a[SLOTS], rl[SLOTS];
+        double rho_p = 0.0, rho_d = 0.0;
+#pragma unroll
+        for (int sl = 0; sl < SLOTS; ++sl) {
+            rl[sl] = frcp(rm.valid[sl] ? lam[sl] : 1.0);
+            ds_a[sl] = rm.valid[sl] ? (-r_p[sl] - adx[sl]) : 0.0;
+            // dl = -(s lam + lam ds)/s = -lam - (lam/s) ds
+            dl_a[sl] = rm.valid[sl] ? (-lam[sl] - dd[sl] * ds_a[sl]) : 0.0;
+            rho_p = fmax(rho_p, -ds_a[sl] * rs[sl]);
+            rho_d = fmax(rho_d, -dl_a[sl] * rl[sl]);
+        }
+        rho_p = wave_max(rho_p);
+        rho_d = wave_max(rho_d);
+        double ap = (rho_p > 1.0) ? 1.0 / rho_p : 1.0;
+        double ad = (rho_d > 1.0) ? 1.0 / rho_d : 1.0;
+        double mu_aff = 0.0;
+#pragma unroll
+        for (int sl = 0; sl < SLOTS; ++sl)
+            if (rm.valid[sl])
+                mu_aff = fma(s[sl] + ap * ds_a[sl], lam[sl] + ad * dl_a[sl], mu_aff);
+        mu_aff = wave_sum(mu_aff) * inv_m;
+        const double ratio = mu_aff / mu;
+        const double sigma = ratio * ratio * ratio;
+        const double smu = sigma * mu;
+
+        // ---- corrector ------------------------------------------------------------------
+        double corr[SLOTS];
+#pragma unroll
+        for (int sl = 0; sl < SLOTS; ++sl) {
+            corr[sl] = (ds_a[sl] * dl_a[sl] - smu) * rs[sl];   // (ds_a dl_a - sigma mu)/s
+            if (rm.valid[sl]) W.vm1[ridx[sl]] = corr[sl];
+        }
+        wsync();
+        double atc, dummy;
+        cols_times<false>(S, W, W.vm1, W.vm1, W.sc, lane, atc, dummy);
+        const double rhs = (lane < n) ? (rhs_aff + atc) : 0.0;
+        dxj = lu_solve(row, W, rhs, lane);
+        rows_times(S, W, rm, W.t, adx);
+        double ds[SLOTS], dl[SLOTS];
+        rho_p = 0.0;
+        rho_d = 0.0;
+#pragma unroll
+        for (int sl = 0; sl < SLOTS; ++sl) {
+            ds[sl] = rm.valid[sl] ? (-r_p[sl] - adx[sl]) : 0.0;
+            // dl = -(s lam + corr_num + lam ds)/s = -lam - corr - (lam/s) ds
+            dl[sl] = rm.valid[sl] ? (-lam[sl] - corr[sl] - dd[sl] * ds[sl]) : 0.0;
+            rho_p = fmax(rho_p, -ds[sl] * rs[sl]);
+            rho_d = fmax(rho_d, -dl[sl] * rl[sl]);
+        }
+        rho_p = wave_max(rho_p);
+        rho_d = wave_max(rho_d);
+        ap = (rho_p > EHM2_STEP_FRAC) ? EHM2_STEP_FRAC / rho_p : 1.0;
+        ad = (rho_d > EHM2_STEP_FRAC) ? EHM2_STEP_FRAC / rho_d : 1.0;
+        if (lane < n) W.x[lane] = fma(ap, dxj, W.x[lane]);
+#pragma unroll
+        for (int sl = 0; sl < SLOTS; ++sl) {
+            if (rm.valid[sl]) {
+                s[sl] = fma(ap, ds[sl], s[sl]);
+                lam[sl] = fma(ad, dl[sl], lam[sl]);
+            }
+        }
+        wsync();
+    }
+    wsync();
+    if (res.status != 0 && res.merit <= EHM2_ACCEPT_MERIT) res.status = 0;
+    return res;
+}
+
+}  // namespace EHM2_NS

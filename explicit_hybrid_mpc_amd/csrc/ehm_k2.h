@@ -1,0 +1,63 @@
+// Interface between ehm_capi.hip and the per-(NP, SLOTS) instances of ehm_k2.hip.
+#pragma once
+
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "ehm_dev.h"
+
+// wavefronts per workgroup are chosen at launch (<= EHM_K2_THREADS / 64)
+#ifndef EHM_K2_THREADS
+#define EHM_K2_THREADS 512
+#endif
+
+namespace ehm {
+
+// per-wave scratch in front of the LP workspace (doubles): node record, Gauss-Jordan
+// tableau (p x 2p), inverse (p x p), parameter (<= 8)
+__host__ __device__ inline size_t k2_node_doubles(int p, int n_u) {
+    const size_t nrec = ((size_t)rec_doubles(p, n_u) + 7) & ~(size_t)7;
+    return (nrec + 3 * (size_t)p * p + 8 + 1) & ~(size_t)1;
+}
+
+// Row layout of an LP with m MPC rows and ne extra rows: MPC row i sits at (lane i%64,
+// slot i/64); the extras follow at xbase (directly behind the MPC rows when they fit into
+// the same slot, otherwise in a slot of their own).  Only the LAST slot can hold extras.
+__host__ __device__ inline int lp_xbase(int m, int ne) {
+    if (ne == 0) return m;
+    const int r = m & 63;
+    return (r != 0 && r + ne <= 64) ? m : ((m + 63) & ~63);
+}
+__host__ __device__ inline int lp_slots(int m, int ne) {
+    return (lp_xbase(m, ne) + ne + 63) >> 6;
+}
+
+struct K2Launch {
+    int grid;
+    int threads;        // 64 * wavefronts per workgroup
+    size_t lds_bytes;
+    int wave_doubles;   // LDS doubles per wavefront
+    hipStream_t stream;
+};
+
+struct K2Api {
+    int np, slots, max_threads;
+    hipError_t (*set_lds)(int bytes);
+    size_t (*wave_doubles)(int p, int n_u, int n_lp, int ne);
+    size_t (*shared_doubles)(const DevProblem& P);
+    void (*point)(const K2Launch&, DevProblem, long long n_inst, const double* theta,
+                  const int32_t* seg, int feas, double* J, double* u0, int32_t* status,
+                  int32_t* iters, DevCounters*);
+    void (*simplex)(const K2Launch&, DevProblem, long long n_inst, const double* R,
+                    const double* Vbar, const int32_t* seg, int mode, double* obj,
+                    double* alpha, int32_t* status, int32_t* iters, DevCounters*);
+    void (*decide)(const K2Launch&, DevProblem, DevTree, const int32_t* frontier, int nf,
+                   int32_t* open_flag, DevCounters*);
+    void (*expand)(const K2Launch&, DevProblem, DevTree, const int32_t* open_list, int n_open,
+                   int child_base, int32_t* next_frontier, DevCounters*);
+    void (*vertex)(const K2Launch&, DevProblem, DevTree, const int32_t* nodes, int n_nodes,
+                   DevCounters*);
+    void (*selftest)(hipStream_t, double* out);
+};
+
+}  // namespace ehm

@@ -1,0 +1,567 @@
+// Second-generation kernels of libehmpc (gfx950): one copy of the commutation's constant LP
+// block in LDS per workgroup, several wavefronts per workgroup, each solving its own LP.
+// Compiled once per (EHM_NP, EHM_SLOTS) pair; ehm_capi.hip picks the instance that fits
+// the LP of each launch.  See ehm_ipm2.h for the solver and DESIGN.md section 3.
+#include <hip/hip_runtime.h>
+
+#include "ehm_k2.h"
+#include "ehm_ipm2.h"
+
+using namespace ehm;
+
+extern __shared__ __attribute__((aligned(16))) char k2_smem[];
+
+namespace EHM2_NS {
+
+// ---------------------------------------------------------------------------------------
+// per-wave scratch in front of the LP workspace: node record, simplex inverse, parameter
+// ---------------------------------------------------------------------------------------
+struct NodeBuf {
+    double* rec;    // node record / simplex vertices (+ vertex costs)
+    double* aug;    // p x 2p Gauss-Jordan tableau
+    double* F;      // p x p inverse of the edge matrix
+    double* th;     // p doubles (parameter / midpoint)
+    double* lp;     // start of the LP workspace
+};
+__device__ __forceinline__ void carve_node(NodeBuf& nb, double* base, int p, int n_u) {
+    const int nrec = (rec_doubles(p, n_u) + 7) & ~7;
+    nb.rec = base;
+    nb.aug = base + nrec;
+    nb.F = nb.aug + 2 * p * p;
+    nb.th = nb.F + p * p;
+    nb.lp = base + k2_node_doubles(p, n_u);
+}
+
+// F = E^-1 with E[r][q] = R[q+1][r] - R[0][r]  (beta = F psi, psi = theta - R0)
+__device__ inline void simplex_inverse(const double* R, int p, double* aug, double* F, int lane) {
+    const int w = 2 * p;
+    for (int k = lane; k < p * w; k += 64) {
+        const int r = k / w, c = k - r * w;
+        aug[k] = (c < p) ? (R[(c + 1) * p + r] - R[r]) : ((c - p == r) ? 1.0 : 0.0);
+    }
+    wsync();
+    for (int k = 0; k < p; ++k) {
+        int piv = k;
+        double best = fabs(aug[k * w + k]);
+        for (int r = k + 1; r < p; ++r) {
+            const double v = fabs(aug[r * w + k]);
+            if (v > best) {
+                best = v;
+                piv = r;
+            }
+        }
+        double a_k = 0.0, a_p = 0.0;
+        if (lane < w) {
+            a_k = aug[k * w + lane];
+            a_p = aug[piv * w + lane];
+        }
+        wsync();
+        if (lane < w && piv != k) {
+            aug[k * w + lane] = a_p;
+            aug[piv * w + lane] = a_k;
+        }
+        wsync();
+        const double rp = 1.0 / aug[k * w + k];
+        double fac[2], rk[2], cur[2];
+#pragma unroll
+        for (int u = 0; u < 2; ++u) {
+            const int idx = lane + 64 * u;
+            fac[u] = rk[u] = cur[u] = 0.0;
+            if (idx < p * w) {
+                const int r = idx / w, c = idx - r * w;
+                fac[u] = aug[r * w + k];
+                rk[u] = aug[k * w + c] * rp;
+                cur[u] = aug[idx];
+            }
+        }
+        wsync();
+#pragma unroll
+        for (int u = 0; u < 2; ++u) {
+            const int idx = lane + 64 * u;
+            if (idx < p * w) {
+                const int r = idx / w;
+                aug[idx] = (r == k) ? rk[u] : fma(-fac[u], rk[u], cur[u]);
+            }
+        }
+        wsync();
+    }
+    for (int k = lane; k < p * p; k += 64) {
+        const int q = k / p, r = k - q * p;
+        F[k] = aug[q * w + p + r];
+    }
+    wsync();
+}
+
+// P_theta_delta at one parameter value (lib/oracle.py:141-173) or its phase-one form
+//   min tau  s.t.  G z - tau <= w + S theta,  tau >= -1.
+__device__ inline void assemble_point(const Shared& S, Wave& W, double* lp_base,
+                                      const double* theta, bool feas, double (&b)[SLOTS],
+                                      int lane) {
+    const int n = S.n, m = S.m, p = S.p;
+    carve_wave(W, lp_base, n + (feas ? 1 : 0), feas ? 1 : 0, m);
+    W.n_lin = n;
+    W.spec_col = n + p;           // the column of -1
+    if (lane < NP) W.c[lane] = feas ? ((lane == n) ? 1.0 : 0.0) : ((lane < n) ? S.cv[lane] : 0.0);
+    if (feas) {
+        // extra row 0:  -tau <= 1      (ldx = 1)
+        if (lane <= n) W.X[lane] = (lane == n) ? -1.0 : 0.0;
+    }
+#pragma unroll
+    for (int sl = 0; sl < SLOTS; ++sl) {
+        const int i = lane + 64 * sl;
+        double v = 0.0;
+        if (i < m) {
+            v = S.wv[i];
+            for (int r = 0; r < p; ++r) v = fma(-S.Wc[(size_t)(n + r) * S.lda + i], theta[r], v);
+        } else if (feas && i == W.xbase) {
+            v = 1.0;
+        }
+        b[sl] = v;
+    }
+    wsync();
+}
+
+// Problems over a simplex R (rows = vertices, in LDS) in the variables (z, psi[, t]) with
+// psi = theta - R0, beta = F psi >= 0, sum beta <= 1:
+//   SX_MIN   : min V                                              (lib/oracle.py:74-79)
+//   SX_SLACK : max t  s.t.  Vbar0 + dV^T beta - V - eps_a >= t,
+//                           Vbar0 + dV^T beta - (1+eps_r) V >= t   (lib/oracle.py:89-97)
+//   SX_FEAS  : min tau s.t. MPC rows relaxed by tau, tau >= -1
+__device__ inline void assemble_simplex(const Shared& S, Wave& W, const NodeBuf& nb,
+                                        const double* R, const double* Vbar, int mode,
+                                        double eps_a, double eps_r, double (&b)[SLOTS],
+                                        int lane) {
+    const int n = S.n, m = S.m, p = S.p;
+    const bool slack = (mode == SX_SLACK);
+    const bool feas = (mode == SX_FEAS);
+    const int n_lp = n + p + ((slack || feas) ? 1 : 0);
+    const int ne = p + 1 + (slack ? 2 : 0) + (feas ? 1 : 0);
+    carve_wave(W, nb.lp, n_lp, ne, m);
+    W.n_lin = n + p;
+    W.spec_col = slack ? (n + p + 1) : (n + p);   // zeros for t, -1 for tau
+    simplex_inverse(R, p, nb.aug, nb.F, lane);
+    const double* F = nb.F;
+    const int ldx = W.ldx;
+    for (int k = lane; k < n_lp * ldx; k += 64) W.X[k] = 0.0;
+    if (lane < NP) W.c[lane] = 0.0;
+    wsync();
+    // facets  -beta_e <= 0
+    for (int k = lane; k < p * p; k += 64) {
+        const int e = k / p, r = k - e * p;
+        W.X[(n + r) * ldx + e] = -F[e * p + r];
+    }
+    if (lane < p) {
+        double sF = 0.0, dvF = 0.0;
+        for (int q = 0; q < p; ++q) {
+            sF += F[q * p + lane];
+            if (slack) dvF = fma(Vbar[q + 1] - Vbar[0], F[q * p + lane], dvF);
+        }
+        W.X[(n + lane) * ldx + p] = sF;                 // sum beta <= 1
+        if (slack) {
+            W.X[(n + lane) * ldx + p + 1] = -dvF;
+            W.X[(n + lane) * ldx + p + 2] = -dvF;
+        }
+    }
+    if (slack) {
+        if (lane < n) {
+            const double cj = S.cv[lane];
+            W.X[lane * ldx + p + 1] = cj;
+            W.X[lane * ldx + p + 2] = (1.0 + eps_r) * cj;
+        }
+        if (lane == 0) {
+            W.X[(n + p) * ldx + p + 1] = 1.0;
+            W.X[(n + p) * ldx + p + 2] = 1.0;
+            W.c[n + p] = -1.0;
+        }
+    } else if (feas) {
+        if (lane == 0) {
+            W.X[(n + p) * ldx + p + 1] = -1.0;          // -tau <= 1
+            W.c[n + p] = 1.0;
+        }
+    } else if (lane < n) {
+        W.c[lane] = S.cv[lane];
+    }
+#pragma unroll
+    for (int sl = 0; sl < SLOTS; ++sl) {
+        const int i = lane + 64 * sl;
+        double v = 0.0;
+        if (i < m) {
+            v = S.wv[i];
+            for (int r = 0; r < p; ++r) v = fma(-S.Wc[(size_t)(n + r) * S.lda + i], R[r], v);
+        } else {
+            const int e = i - W.xbase;
+            if (e == p) v = 1.0;
+            else if (feas && e == p + 1) v = 1.0;
+            else if (slack && e == p + 1) v = Vbar[0] - eps_a;
+            else if (slack && e == p + 2) v = Vbar[0];
+        }
+        b[sl] = v;
+    }
+    wsync();
+}
+
+__device__ __forceinline__ void count_solve(DevCounters* cnt, const IpmResult& r, int lane) {
+    if (lane == 0 && cnt) {
+        atomicAdd(&cnt->lp_solves, 1ULL);
+        atomicAdd(&cnt->ipm_iters, (unsigned long long)r.iters);
+        if (r.status != 0) atomicAdd(&cnt->stalled, 1ULL);
+    }
+}
+
+// Work distribution inside a launch: the workgroup owns a contiguous range of items and its
+// wavefronts pull the next one from an LDS counter.
+__device__ __forceinline__ int pull(int* ctr, int lane) {
+    int f = 0;
+    if (lane == 0) f = atomicAdd(ctr, 1);
+    return __builtin_amdgcn_readfirstlane(f);
+}
+
+#define K2_PROLOGUE()                                                            \
+    double* sm = reinterpret_cast<double*>(k2_smem);                             \
+    __shared__ int s_ctr;                                                        \
+    const int tid = threadIdx.x;                                                 \
+    const int lane0 = tid & 63;                                                  \
+    const int wave = tid >> 6;                                                   \
+    Shared S;                                                                    \
+    carve_shared(S, sm, P);                                                      \
+    NodeBuf nb;                                                                  \
+    carve_node(nb, sm + shared_doubles(P) + (size_t)wave * wave_doubles, P.p, P.n_u)
+
+// ---- a2: P_theta_delta batch / its feasibility form; instances sorted by commutation -----
+__global__ __launch_bounds__(EHM_K2_THREADS) void k2_point_batch(
+    DevProblem P, long long n_inst, const double* __restrict__ theta,
+    const int32_t* __restrict__ seg, int feas, double* __restrict__ J, double* __restrict__ u0,
+    int32_t* __restrict__ status, int32_t* __restrict__ iters, DevCounters* cnt,
+    int wave_doubles) {
+    K2_PROLOGUE();
+    const long long per = (n_inst + gridDim.x - 1) / gridDim.x;
+    const long long lo = (long long)blockIdx.x * per;
+    const long long hi = (lo + per < n_inst) ? lo + per : n_inst;
+    long long pos = lo;
+    while (pos < hi) {      // workgroup-uniform
+        int d = 0;
+        while (d + 1 < P.n_delta && seg[d + 1] <= pos) ++d;
+        const long long run_end = (seg[d + 1] < hi) ? seg[d + 1] : hi;
+        __syncthreads();
+        load_shared(P, d, sm, tid, blockDim.x);
+        if (tid == 0) s_ctr = (int)(pos - lo);
+        __syncthreads();
+        for (;;) {
+            const long long inst = lo + pull(&s_ctr, lane0);
+            if (inst >= run_end) break;
+            const int lane = pin(lane0);
+            if (lane < P.p) nb.th[lane] = theta[inst * P.p + lane];
+            wsync();
+            Wave W;
+            double b[SLOTS];
+            assemble_point(S, W, nb.lp, nb.th, feas != 0, b, lane);
+            const IpmResult r = ipm_solve(S, W, b, lane);
+            count_solve(cnt, r, lane);
+            if (lane == 0) {
+                J[inst] = r.obj;
+                if (status) status[inst] = r.status;
+                if (iters) iters[inst] = r.iters;
+            }
+            if (u0 && lane < P.n_u) u0[inst * P.n_u + lane] = W.xb[lane];
+            wsync();
+        }
+        pos = run_end;
+    }
+}
+
+// ---- a5 / a7': problems over a simplex, one commutation per instance (sorted) -------------
+__global__ __launch_bounds__(EHM_K2_THREADS) void k2_simplex_batch(
+    DevProblem P, long long n_inst, const double* __restrict__ R,
+    const double* __restrict__ Vbar, const int32_t* __restrict__ seg, int mode,
+    double* __restrict__ obj, double* __restrict__ alpha, int32_t* __restrict__ status,
+    int32_t* __restrict__ iters, DevCounters* cnt, int wave_doubles) {
+    K2_PROLOGUE();
+    const int p = P.p;
+    const int nR = (p + 1) * p;
+    const long long per = (n_inst + gridDim.x - 1) / gridDim.x;
+    const long long lo = (long long)blockIdx.x * per;
+    const long long hi = (lo + per < n_inst) ? lo + per : n_inst;
+    long long pos = lo;
+    while (pos < hi) {
+        int d = 0;
+        while (d + 1 < P.n_delta && seg[d + 1] <= pos) ++d;
+        const long long run_end = (seg[d + 1] < hi) ? seg[d + 1] : hi;
+        __syncthreads();
+        load_shared(P, d, sm, tid, blockDim.x);
+        if (tid == 0) s_ctr = (int)(pos - lo);
+        __syncthreads();
+        for (;;) {
+            const long long inst = lo + pull(&s_ctr, lane0);
+            if (inst >= run_end) break;
+            const int lane = pin(lane0);
+            double* Rl = nb.rec;
+            double* Vl = nb.rec + nR;
+            for (int k = lane; k < nR; k += 64) Rl[k] = R[inst * nR + k];
+            if (mode == SX_SLACK && lane <= p) Vl[lane] = Vbar[inst * (p + 1) + lane];
+            wsync();
+            Wave W;
+            double b[SLOTS];
+            assemble_simplex(S, W, nb, Rl, Vl, mode, P.eps_a, P.eps_r, b, lane);
+            const IpmResult r = ipm_solve(S, W, b, lane);
+            count_solve(cnt, r, lane);
+            if (lane == 0) {
+                obj[inst] = (mode == SX_SLACK) ? -r.obj : r.obj;     // t* = -(min -t)
+                if (status) status[inst] = r.status;
+                if (iters) iters[inst] = r.iters;
+            }
+            if (alpha) {
+                double beta = 0.0;
+                if (lane < p)
+                    for (int q = 0; q < p; ++q) beta = fma(nb.F[lane * p + q], W.xb[P.n + q], beta);
+                const double sb = wave_sum(beta);
+                if (lane < p) alpha[inst * (p + 1) + lane + 1] = beta;
+                if (lane == 0) alpha[inst * (p + 1)] = 1.0 - sb;
+            }
+            wsync();
+        }
+        pos = run_end;
+    }
+}
+
+// ---- frontier sweep (single commutation): epsilon-suboptimality decision per node --------
+// (lib/worker.py:368-375)
+__global__ __launch_bounds__(EHM_K2_THREADS) void k2_lcss_decide(
+    DevProblem P, DevTree T, const int32_t* __restrict__ frontier, int nf,
+    int32_t* __restrict__ open_flag, DevCounters* cnt, int wave_doubles) {
+    K2_PROLOGUE();
+    const int nrec = rec_doubles(P.p, P.n_u);
+    const int per = (nf + gridDim.x - 1) / gridDim.x;
+    const int lo = blockIdx.x * per;
+    const int hi = (lo + per < nf) ? lo + per : nf;
+    if (lo >= hi) return;
+    load_shared(P, 0, sm, tid, blockDim.x);
+    if (tid == 0) s_ctr = lo;
+    __syncthreads();
+    for (;;) {
+        const int f = pull(&s_ctr, lane0);
+        if (f >= hi) break;
+        const int lane = pin(lane0);
+        const int id = frontier[f];
+        const double* rec = T.rec + (size_t)id * T.rec_stride;
+        for (int k = lane; k < nrec; k += 64) nb.rec[k] = rec[k];
+        wsync();
+        Wave W;
+        double b[SLOTS];
+        assemble_simplex(S, W, nb, nb.rec, nb.rec + rec_off_vcost(P.p), SX_SLACK, P.eps_a,
+                         P.eps_r, b, lane);
+        const IpmResult r = ipm_solve(S, W, b, lane);
+        count_solve(cnt, r, lane);
+        if (lane == 0) {
+            if (r.status != 0) {
+                atomicAdd(&cnt->errors, 1ULL);
+                T.flags[id] |= 8;
+            }
+            atomicAdd(&cnt->slack_solves, 1ULL);
+            atomicAdd(&cnt->slack_iters, (unsigned long long)r.iters);
+            const double t = -r.obj;
+            const bool open = (t >= 0.0);
+            T.tstar[id] = t;
+            open_flag[f] = open ? 1 : 0;
+            if (!open) T.flags[id] |= 1;
+            atomicMin(&cnt->min_margin_bits, (unsigned long long)__double_as_longlong(fabs(t)));
+        }
+        wsync();
+    }
+}
+
+// ---- split every open node, solve P_theta_delta at the midpoint, write the children -------
+// (lib/worker.py:403-414, 354-365)
+__global__ __launch_bounds__(EHM_K2_THREADS) void k2_lcss_expand(
+    DevProblem P, DevTree T, const int32_t* __restrict__ open_list, int n_open, int child_base,
+    int32_t* __restrict__ next_frontier, DevCounters* cnt, int wave_doubles) {
+    K2_PROLOGUE();
+    const int p = P.p, n_u = P.n_u;
+    const int nrec = rec_doubles(p, n_u);
+    const int per = (n_open + gridDim.x - 1) / gridDim.x;
+    const int lo = blockIdx.x * per;
+    const int hi = (lo + per < n_open) ? lo + per : n_open;
+    if (lo >= hi) return;
+    load_shared(P, 0, sm, tid, blockDim.x);
+    if (tid == 0) s_ctr = lo;
+    __syncthreads();
+    for (;;) {
+        const int f = pull(&s_ctr, lane0);
+        if (f >= hi) break;
+        const int lane = pin(lane0);
+        const int id = open_list[f];
+        const double* rec = T.rec + (size_t)id * T.rec_stride;
+        double* node = nb.rec;
+        double* mid = nb.th;
+        for (int k = lane; k < nrec; k += 64) node[k] = rec[k];
+        wsync();
+        int bi, bj;
+        longest_edge(node, p, bi, bj);
+        if (lane < p) {
+#pragma clang fp contract(off)
+            mid[lane] = (node[bi * p + lane] + node[bj * p + lane]) / 2.0;
+        }
+        wsync();
+        const int d = T.didx[id];
+        Wave W;
+        double b[SLOTS];
+        assemble_point(S, W, nb.lp, mid, false, b, lane);
+        const IpmResult r = ipm_solve(S, W, b, lane);
+        count_solve(cnt, r, lane);
+        if (r.status != 0 && lane == 0) {
+            atomicAdd(&cnt->errors, 1ULL);
+            T.flags[id] |= 16;
+        }
+        const int c0 = child_base + 2 * f;
+        double* rec0 = T.rec + (size_t)c0 * T.rec_stride;
+        double* rec1 = rec0 + T.rec_stride;
+        const int ov = rec_off_vcost(p), ou = rec_off_vinput(p);
+        for (int k = lane; k < nrec; k += 64) {
+            double v0 = node[k], v1 = node[k];
+            if (k < ov) {                       // vertices
+                const int row = k / p, col = k - row * p;
+                if (row == bi) v0 = mid[col];
+                if (row == bj) v1 = mid[col];
+            } else if (k < ou) {                // vertex costs
+                const int row = k - ov;
+                if (row == bi) v0 = r.obj;
+                if (row == bj) v1 = r.obj;
+            } else {                            // vertex inputs
+                const int row = (k - ou) / n_u, col = (k - ou) - row * n_u;
+                if (row == bi) v0 = W.xb[col];
+                if (row == bj) v1 = W.xb[col];
+            }
+            rec0[k] = v0;
+            rec1[k] = v1;
+        }
+        if (lane == 0) {
+            T.left[id] = c0;
+            const int dep = T.depth[id] + 1;
+            T.left[c0] = -1;
+            T.left[c0 + 1] = -1;
+            T.didx[c0] = d;
+            T.didx[c0 + 1] = d;
+            T.depth[c0] = dep;
+            T.depth[c0 + 1] = dep;
+            T.flags[c0] = 2;
+            T.flags[c0 + 1] = 2;
+            T.tstar[c0] = 0.0;
+            T.tstar[c0 + 1] = 0.0;
+            next_frontier[2 * f] = c0;
+            next_frontier[2 * f + 1] = c0 + 1;
+        }
+        wsync();
+    }
+}
+
+// ---- vertex solves that seed a node's costs / inputs (lib/oracle.py:416-443) ---------------
+__global__ __launch_bounds__(EHM_K2_THREADS) void k2_vertex_solve(
+    DevProblem P, DevTree T, const int32_t* __restrict__ nodes, int n_nodes, DevCounters* cnt,
+    int wave_doubles) {
+    K2_PROLOGUE();
+    const int p = P.p, n_u = P.n_u;
+    const int total = n_nodes * (p + 1);
+    const int per = (total + gridDim.x - 1) / gridDim.x;
+    const int lo = blockIdx.x * per;
+    const int hi = (lo + per < total) ? lo + per : total;
+    if (lo >= hi) return;
+    load_shared(P, 0, sm, tid, blockDim.x);
+    if (tid == 0) s_ctr = lo;
+    __syncthreads();
+    for (;;) {
+        const int t = pull(&s_ctr, lane0);
+        if (t >= hi) break;
+        const int lane = pin(lane0);
+        const int id = nodes[t / (p + 1)];
+        const int v = t % (p + 1);
+        double* rec = T.rec + (size_t)id * T.rec_stride;
+        if (lane < p) nb.th[lane] = rec[v * p + lane];
+        wsync();
+        Wave W;
+        double b[SLOTS];
+        assemble_point(S, W, nb.lp, nb.th, false, b, lane);
+        const IpmResult r = ipm_solve(S, W, b, lane);
+        count_solve(cnt, r, lane);
+        if (r.status != 0 && lane == 0) atomicAdd(&cnt->errors, 1ULL);
+        if (lane == 0) rec[rec_off_vcost(p) + v] = r.obj;
+        if (lane < n_u) rec[rec_off_vinput(p) + v * n_u + lane] = W.xb[lane];
+        wsync();
+    }
+}
+
+// ---- self test of the wave primitives (ehm_selftest) --------------------------------------
+__global__ __launch_bounds__(64) void k2_selftest(double* out) {
+    const int lane = threadIdx.x;
+    const double v = 1.0 + 0.5 * lane;                       // sum = 64 + 0.5*2016 = 1072
+    out[0] = wave_sum(v);
+    out[1] = wave_max((lane == 37) ? 99.0 : -(double)lane);
+    out[2] = wave_sum((lane < 25) ? 1.0 : 0.0);
+    out[3] = frcp(3.0);
+    out[4] = wave_max(-1.0 - lane);
+}
+
+}  // namespace EHM2_NS
+
+// ---------------------------------------------------------------------------------------
+// host-side launchers (one set per compiled instance)
+// ---------------------------------------------------------------------------------------
+namespace {
+
+using namespace EHM2_NS;
+
+hipError_t set_lds(int bytes) {
+    const void* ks[] = {(const void*)k2_point_batch, (const void*)k2_simplex_batch,
+                        (const void*)k2_lcss_decide, (const void*)k2_lcss_expand,
+                        (const void*)k2_vertex_solve};
+    for (const void* k : ks) {
+        hipError_t e = hipFuncSetAttribute(k, hipFuncAttributeMaxDynamicSharedMemorySize, bytes);
+        if (e != hipSuccess) return e;
+    }
+    return hipSuccess;
+}
+
+size_t wave_doubles_for(int p, int n_u, int n_lp, int ne) {
+    return k2_node_doubles(p, n_u) + wave_lp_doubles(n_lp, ne);
+}
+size_t shared_doubles_for(const DevProblem& P) { return shared_doubles(P); }
+
+void l_point(const K2Launch& L, DevProblem P, long long n_inst, const double* theta,
+             const int32_t* seg, int feas, double* J, double* u0, int32_t* status,
+             int32_t* iters, DevCounters* cnt) {
+    hipLaunchKernelGGL(k2_point_batch, dim3(L.grid), dim3(L.threads), L.lds_bytes, L.stream, P,
+                       n_inst, theta, seg, feas, J, u0, status, iters, cnt, L.wave_doubles);
+}
+void l_simplex(const K2Launch& L, DevProblem P, long long n_inst, const double* R,
+               const double* Vbar, const int32_t* seg, int mode, double* obj, double* alpha,
+               int32_t* status, int32_t* iters, DevCounters* cnt) {
+    hipLaunchKernelGGL(k2_simplex_batch, dim3(L.grid), dim3(L.threads), L.lds_bytes, L.stream,
+                       P, n_inst, R, Vbar, seg, mode, obj, alpha, status, iters, cnt,
+                       L.wave_doubles);
+}
+void l_decide(const K2Launch& L, DevProblem P, DevTree T, const int32_t* frontier, int nf,
+              int32_t* open_flag, DevCounters* cnt) {
+    hipLaunchKernelGGL(k2_lcss_decide, dim3(L.grid), dim3(L.threads), L.lds_bytes, L.stream, P,
+                       T, frontier, nf, open_flag, cnt, L.wave_doubles);
+}
+void l_expand(const K2Launch& L, DevProblem P, DevTree T, const int32_t* open_list, int n_open,
+              int child_base, int32_t* next_frontier, DevCounters* cnt) {
+    hipLaunchKernelGGL(k2_lcss_expand, dim3(L.grid), dim3(L.threads), L.lds_bytes, L.stream, P,
+                       T, open_list, n_open, child_base, next_frontier, cnt, L.wave_doubles);
+}
+void l_vertex(const K2Launch& L, DevProblem P, DevTree T, const int32_t* nodes, int n_nodes,
+              DevCounters* cnt) {
+    hipLaunchKernelGGL(k2_vertex_solve, dim3(L.grid), dim3(L.threads), L.lds_bytes, L.stream, P,
+                       T, nodes, n_nodes, cnt, L.wave_doubles);
+}
+void l_selftest(hipStream_t stream, double* out) {
+    hipLaunchKernelGGL(k2_selftest, dim3(1), dim3(64), 0, stream, out);
+}
+
+const K2Api g_api = {EHM_NP,          EHM_SLOTS, EHM_K2_THREADS,    set_lds,  wave_doubles_for,
+                     shared_doubles_for, l_point,   l_simplex,         l_decide, l_expand,
+                     l_vertex,        l_selftest};
+
+}  // namespace
+
+#define K2_CAT2(a, b, c) a##b##_##c
+#define K2_CAT(a, b, c) K2_CAT2(a, b, c)
+extern "C" const ehm::K2Api* K2_CAT(ehm_k2_api_, EHM_NP, EHM_SLOTS)() { return &g_api; }

@@ -2,76 +2,14 @@
 // (Included once, by ehm_capi.hip.)
 #pragma once
 
+#include "ehm_dev.h"
 #include "ehm_ipm.h"
 
 namespace ehm {
 
-// Problem constants, read-only, L2 resident.  Stored column-major per commutation so that
-// the LDS fill of one LP column is one coalesced stream over the rows.
-struct DevProblem {
-    int n, m, p, n_u, n_delta;
-    const double* Gt;   // [n_delta][n][m]
-    const double* St;   // [n_delta][p][m]
-    const double* w;    // [n_delta][m]
-    const double* c;    // [n]
-    double eps_a, eps_r;
-};
-
-// Node pool of the partition tree (structure of arrays of fixed-size records).
-//   rec[k] = [ vertices (p+1)*p | vertex_costs (p+1) | vertex_inputs (p+1)*n_u ]  (doubles)
-// which is the payload of the reference's NodeData (lib/tree.py:31-39).
-struct DevTree {
-    double*  rec;
-    int32_t* left;      // left child index (right = left+1), -1 for a leaf
-    int32_t* didx;      // commutation index, -1 = none yet
-    int32_t* depth;
-    uint8_t* flags;     // bit0 closed (is_epsilon_suboptimal), bit1 has commutation data
-    double*  tstar;     // slack of the last close/split decision
-    int rec_stride;     // doubles per record (multiple of 8)
-    int p, n_u;
-};
-
-struct DevCounters {
-    unsigned long long lp_solves;
-    unsigned long long ipm_iters;
-    unsigned long long stalled;
-    unsigned long long min_margin_bits;   // |t*| as ordered uint64
-    unsigned long long errors;
-    unsigned long long slack_solves;      // LPs over a simplex (decide sweep)
-    unsigned long long slack_iters;
-};
-
-__host__ __device__ inline int rec_off_vcost(int p) { return (p + 1) * p; }
-__host__ __device__ inline int rec_off_vinput(int p) { return (p + 1) * p + (p + 1); }
-__host__ __device__ inline int rec_doubles(int p, int n_u) {
-    return (p + 1) * p + (p + 1) + (p + 1) * n_u;
-}
-
 // ---------------------------------------------------------------------------------------
 // LP assembly
 // ---------------------------------------------------------------------------------------
-enum { LP_POINT = 0, LP_FEAS = 1, LP_MIN_SIMPLEX = 2, LP_SLACK = 3, LP_FEAS_SIMPLEX = 4 };
-enum { SX_MIN = 0, SX_SLACK = 1, SX_FEAS = 2 };
-
-__host__ __device__ inline int lp_cols(const DevProblem& P, int kind) {
-    switch (kind) {
-        case LP_POINT: return P.n;
-        case LP_FEAS: return P.n + 1;
-        case LP_MIN_SIMPLEX: return P.n + P.p;
-        case LP_FEAS_SIMPLEX: return P.n + P.p + 1;
-        default: return P.n + P.p + 1;
-    }
-}
-__host__ __device__ inline int lp_rows(const DevProblem& P, int kind) {
-    switch (kind) {
-        case LP_POINT: return P.m;
-        case LP_FEAS: return P.m + 1;
-        case LP_MIN_SIMPLEX: return P.m + P.p + 1;
-        case LP_FEAS_SIMPLEX: return P.m + P.p + 2;
-        default: return P.m + P.p + 3;
-    }
-}
-
 // P_theta_delta at one parameter value (lib/oracle.py:141-173), or its phase-one form
 //   min tau  s.t.  G z - tau <= h,  tau >= -1      (feasible  <=>  tau* <= 0).
 // theta: p doubles readable by every lane (LDS or global).
@@ -201,33 +139,6 @@ __device__ inline void assemble_simplex(LpWork& w, double* smem, const DevProble
         b[sl] = v;
     }
     wave_sync();
-}
-
-// ---------------------------------------------------------------------------------------
-// geometry (bit-exact restatement of lib/tools.py:224-257 arithmetic)
-// ---------------------------------------------------------------------------------------
-// Edge length = sqrt(fma-chain of squared differences): numpy evaluates la.norm(x) as
-// sqrt(x.dot(x)) and OpenBLAS' ddot tail loop is a fused-multiply-add chain starting from
-// 0 (oracle/csrc/geom_ref.c).  First maximal edge in itertools.combinations order wins.
-__device__ inline void longest_edge(const double* R, int p, int& bi, int& bj) {
-#pragma clang fp contract(off)
-    double best = -1.0;
-    bi = 0;
-    bj = 1;
-    for (int i = 0; i <= p; ++i)
-        for (int j = i + 1; j <= p; ++j) {
-            double s = 0.0;
-            for (int k = 0; k < p; ++k) {
-                const double df = R[i * p + k] - R[j * p + k];
-                s = __fma_rn(df, df, s);
-            }
-            const double len = __dsqrt_rn(s);
-            if (len > best) {
-                best = len;
-                bi = i;
-                bj = j;
-            }
-        }
 }
 
 }  // namespace ehm

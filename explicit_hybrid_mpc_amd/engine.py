@@ -96,6 +96,11 @@ class GpuProblem:
         check(self._lib.ehm_problem_set_eps(self._handle, float(eps_a), float(eps_r)))
         self.eps_a, self.eps_r = float(eps_a), float(eps_r)
 
+    def set_solver(self, generation):
+        """Kernel generation: 2 = shared constant block, several wavefronts per workgroup
+        (default); 1 = one wavefront per workgroup (kept as an on-device cross-check)."""
+        check(self._lib.ehm_problem_set_solver(self._handle, int(generation)))
+
     # -- helpers ------------------------------------------------------------------------
     def _delta_arg(self, delta, n_inst):
         if delta is None:
@@ -261,6 +266,16 @@ class GpuProblem:
         c = _capi.Counters()
         check(self._lib.ehm_stats(self._handle, ctypes.byref(c)))
         return {name: getattr(c, name) for name, _ in _capi.Counters._fields_}
+
+
+def selftest(device=0, max_instances=64):
+    """Wave-primitive self test of every compiled kernel instance: (n, 5) array, each row
+    expected to be (1072, 99, 25, 1/3, -1)."""
+    out = np.zeros((max_instances, 5))
+    n = ctypes.c_int32(0)
+    lib = _capi.load()
+    check(lib.ehm_selftest(int(device), ptr(out), int(max_instances), ctypes.addressof(n)))
+    return out[:n.value]
 
 
 # -- geometry (no problem handle needed) -----------------------------------------------------

@@ -37,7 +37,7 @@ extern "C" {
 #define EHM_E_INFEASIBLE   -5   /* Theta contains infeasible regions (lib/worker.py:266) */
 #define EHM_E_NUMERIC      -6   /* a vertex solve failed (lib/oracle.py:440-442) */
 
-/* Limits of this build (one wavefront per LP, KKT row in registers). */
+/* Limits of this build (one wavefront per LP, row of the normal matrix in registers). */
 #define EHM_MAX_N   32          /* LP columns incl. simplex weights and slack */
 #define EHM_MAX_M   256         /* LP rows   incl. simplex / cost rows */
 #define EHM_MAX_P   8           /* parameter dimension */
@@ -77,6 +77,11 @@ int ehm_problem_create(const ehm_problem_desc* desc, int device, ehm_problem** o
 int ehm_problem_destroy(ehm_problem* prob);
 /* Re-set eps_a / eps_r (examples.create_oracle builds a second Oracle, lib/examples.py:43-46). */
 int ehm_problem_set_eps(ehm_problem* prob, double eps_a, double eps_r);
+/* Kernel generation used by this handle's launches: 2 (default) = one copy of the
+ * commutation's constant LP block in LDS per workgroup, several wavefronts per workgroup;
+ * 1 = one wavefront per workgroup with a private copy of the LP (first build, kept as an
+ * on-device cross-check).  Environment override at create time: EHM_SOLVER=1|2. */
+int ehm_problem_set_solver(ehm_problem* prob, int generation);
 int ehm_sync(ehm_problem* prob);
 /* HIP stream the handle enqueues on (a hipStream_t), for event timing by the caller. */
 void* ehm_stream(ehm_problem* prob);
@@ -217,6 +222,11 @@ typedef struct ehm_counters {
     int64_t stalled;
 } ehm_counters;
 int ehm_stats(ehm_problem* prob, ehm_counters* out);
+
+/* Device self test of the wave-level primitives (DPP reductions, reciprocal) of every
+ * compiled kernel instance: out[5*k .. 5*k+4] for instance k, expected
+ * {1072, 99, 25, 1/3, -1}.  Test hook, not part of the reference's surface. */
+int ehm_selftest(int device, double* out, int32_t max_instances, int32_t* n_instances);
 
 const char* ehm_last_error(void);
 const char* ehm_version(void);
