@@ -118,6 +118,13 @@ __device__ __forceinline__ int pin(int x) {
     asm volatile("" : "+v"(x));
     return x;
 }
+// One ds_read_b64.  hipcc fuses neighbouring 8-byte LDS loads into ds_read2_b64 /
+// ds_read2st64_b64, which the LDS serves at half the bytes per clock of ds_read_b64
+// (MI355X_MICROARCH.md, LDS table); volatile loads are left alone.
+typedef __attribute__((address_space(3))) const volatile double lds_cvdouble;
+__device__ __forceinline__ double lds1(const double* p) {
+    return *(lds_cvdouble*)p;      // explicit LDS pointer: a volatile generic load stays flat
+}
 // 1/x for positive finite x well inside the normal range: v_rcp_f64 + two Newton steps
 __device__ __forceinline__ double frcp(double x) {
     double r = __builtin_amdgcn_rcp(x);
@@ -173,9 +180,13 @@ struct Wave {
     int n_lp, ne, ldx, ldm, xbase;
     int n_lin;      // LP columns j < n_lin are Wc columns j
     int spec_col;   // Wc column of LP column n_lin (when n_lin < n_lp)
+    int n_mpc;      // LP columns j < n_mpc have entries in the MPC rows; the rest only in X
 };
-constexpr int LDM = NP + 1;     // odd: row- and column-wise access both conflict free
-constexpr size_t M_DOUBLES = ((size_t)NP * LDM < 512) ? 512 : (size_t)NP * LDM;
+constexpr int LDM = NP + 2;     // even: rows start 16-byte aligned (ds_read_b128 broadcasts)
+typedef double double2v __attribute__((ext_vector_type(2)));
+// W.M also serves as scratch: 8 x 64 partial column products (cols_times) and the K-slices of
+// the normal-matrix blocks, (KS-1) * 16 * TA <= 768 doubles (form_blocks)
+constexpr size_t M_DOUBLES = ((size_t)NP * LDM < 768) ? 768 : (size_t)NP * LDM;
 __host__ __device__ inline size_t wave_lp_doubles(int n_lp, int ne) {
     const size_t Md = M_DOUBLES;
     const size_t ldx = ne ? ((size_t)ne | 1) : 0;
@@ -258,8 +269,8 @@ __device__ __forceinline__ void rows_times(const Shared& S, const Wave& W, const
     for (int j = 0; j < W.n_lin; ++j) {
         const double vj = v[j];
 #pragma unroll
-        for (int sl = 0; sl < SLOTS - 1; ++sl) out[sl] = fma(pa[64 * sl], vj, out[sl]);
-        out[SLOTS - 1] = fma(*pb, vj, out[SLOTS - 1]);
+        for (int sl = 0; sl < SLOTS - 1; ++sl) out[sl] = fma(lds1(pa + 64 * sl), vj, out[sl]);
+        out[SLOTS - 1] = fma(lds1(pb), vj, out[SLOTS - 1]);
         pa += lda;
         pb += rm.last_stride;
     }
@@ -304,11 +315,11 @@ __device__ __forceinline__ void cols_times(const Shared& S, const Wave& W, const
         const double *pc[4], *px[4];
         block_cols(S, W, cb, pc, px);
         for (int i = h; i < S.m; i += ks) {
-            const double v0 = u0[i];
-            const double v1 = TWO ? u1[i] : 0.0;
+            const double v0 = lds1(u0 + i);
+            const double v1 = TWO ? lds1(u1 + i) : 0.0;
 #pragma unroll
             for (int q = 0; q < 4; ++q) {
-                const double a = pc[q][i];
+                const double a = lds1(pc[q] + i);
                 a0[q] = fma(a, v0, a0[q]);
                 if (TWO) a1[q] = fma(a, v1, a1[q]);
             }
@@ -350,19 +361,21 @@ __device__ __forceinline__ void cols_times(const Shared& S, const Wave& W, const
 }
 
 // M = A^T diag(dvec) A into W.M (full symmetric), dvec an m-vector in LDS.
-__device__ inline void form_normal_matrix(const Shared& S, const Wave& W, const double* dvec,
-                                          int lane) {
-    constexpr int nb = NP / 4;
-    constexpr int T = nb * (nb + 1) / 2;
-    constexpr bool split = (T <= 32);
-    const int task = split ? (lane & 31) : lane;
-    const int h = split ? (lane >> 5) : 0;
-    const int stride = split ? 2 : 1;
+//
+// Work split: the nbA = ceil(n_mpc/4) column blocks that have entries in the MPC rows give
+// TA = nbA(nbA+1)/2 block pairs; lane = (pair, K-slice h), KS = min(4, 64/TA) slices, every
+// lane accumulates a 4x4 block over the rows i = h (mod KS) (MPC rows from the shared Wc,
+// extra rows from the private X).  The slices meet in LDS.  Row loop unrolled by 4 so that
+// the 9 loads of a row step use immediate offsets off 9 address registers.
+template <int KS>
+__device__ __forceinline__ void form_blocks(const Shared& S, const Wave& W, const double* dvec,
+                                            int lane, int nbA, int TA) {
+    const int task = pin(lane % TA);
+    const int h = pin(lane / TA);
+    const bool active = h < KS;
     int bj = 0, rem = task;
     while (rem > bj) { rem -= (bj + 1); ++bj; }
-    const int bk = pin(rem);
-    bj = pin(bj);
-    const bool active = task < T;
+    const int bk = rem;
     double acc[4][4];
 #pragma unroll
     for (int q = 0; q < 4; ++q)
@@ -372,41 +385,53 @@ __device__ inline void form_normal_matrix(const Shared& S, const Wave& W, const 
         const double *cj[4], *xj[4], *ck[4], *xk[4];
         block_cols(S, W, bj, cj, xj);
         block_cols(S, W, bk, ck, xk);
-        for (int i = h; i < S.m; i += stride) {
-            const double d = dvec[i];
-            double aj[4], ak[4];
-#pragma unroll
-            for (int q = 0; q < 4; ++q) {
-                aj[q] = cj[q][i] * d;
-                ak[q] = ck[q][i];
-            }
-#pragma unroll
-            for (int q = 0; q < 4; ++q)
-#pragma unroll
-                for (int r = 0; r < 4; ++r) acc[q][r] = fma(aj[q], ak[r], acc[q][r]);
+        const int m = S.m;
+        int i = h;
+#define EHM2_FORM_ROW(CJ, CK, DV, I)                                                  \
+        {                                                                              \
+            const double d = lds1((DV) + (I));                                         \
+            double aj[4], ak[4];                                                       \
+            _Pragma("unroll") for (int q = 0; q < 4; ++q) {                            \
+                aj[q] = lds1((CJ)[q] + (I)) * d;                                       \
+                ak[q] = lds1((CK)[q] + (I));                                           \
+            }                                                                          \
+            _Pragma("unroll") for (int q = 0; q < 4; ++q)                              \
+                _Pragma("unroll") for (int r = 0; r < 4; ++r)                          \
+                    acc[q][r] = fma(aj[q], ak[r], acc[q][r]);                          \
         }
-        for (int e = h; e < W.ne; e += stride) {
-            const double d = dvec[W.xbase + e];
-            double aj[4], ak[4];
-#pragma unroll
-            for (int q = 0; q < 4; ++q) {
-                aj[q] = xj[q][e] * d;
-                ak[q] = xk[q][e];
-            }
-#pragma unroll
-            for (int q = 0; q < 4; ++q)
-#pragma unroll
-                for (int r = 0; r < 4; ++r) acc[q][r] = fma(aj[q], ak[r], acc[q][r]);
+        for (; i + 3 * KS < m; i += 4 * KS) {
+            EHM2_FORM_ROW(cj, ck, dvec, i)
+            EHM2_FORM_ROW(cj, ck, dvec, i + KS)
+            EHM2_FORM_ROW(cj, ck, dvec, i + 2 * KS)
+            EHM2_FORM_ROW(cj, ck, dvec, i + 3 * KS)
         }
+        for (; i < m; i += KS) EHM2_FORM_ROW(cj, ck, dvec, i)
+        const double* dx = dvec + W.xbase;
+        for (int e = h; e < W.ne; e += KS) EHM2_FORM_ROW(xj, xk, dx, e)
+#undef EHM2_FORM_ROW
     }
-    if (split) {
+    // slices h > 0 park their blocks in W.M ([slice][entry][pair]: lanes write consecutively)
+    wsync();
+    if (active && h > 0) {
+        double* sc = W.M + (size_t)(h - 1) * 16 * TA + task;
 #pragma unroll
         for (int q = 0; q < 4; ++q)
 #pragma unroll
-            for (int r = 0; r < 4; ++r) acc[q][r] += __shfl_xor(acc[q][r], 32, 64);
+            for (int r = 0; r < 4; ++r) sc[(4 * q + r) * TA] = acc[q][r];
     }
     wsync();
-    if (active && h == 0) {
+    if (h == 0) {
+#pragma unroll
+        for (int hh = 1; hh < KS; ++hh) {
+            const double* sc = W.M + (size_t)(hh - 1) * 16 * TA + task;
+#pragma unroll
+            for (int q = 0; q < 4; ++q)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) acc[q][r] += sc[(4 * q + r) * TA];
+        }
+    }
+    wsync();
+    if (h == 0) {
 #pragma unroll
         for (int q = 0; q < 4; ++q)
 #pragma unroll
@@ -415,6 +440,39 @@ __device__ inline void form_normal_matrix(const Shared& S, const Wave& W, const 
                 W.M[jj * LDM + kk] = acc[q][r];
                 W.M[kk * LDM + jj] = acc[q][r];
             }
+    }
+}
+
+__device__ inline void form_normal_matrix(const Shared& S, const Wave& W, const double* dvec,
+                                          int lane) {
+    const int nbA = (W.n_mpc + 3) >> 2;
+    const int TA = nbA * (nbA + 1) / 2;
+    const int ks = 64 / TA;     // TA <= 36
+    if (ks >= 4) form_blocks<4>(S, W, dvec, lane, nbA, TA);
+    else if (ks == 3) form_blocks<3>(S, W, dvec, lane, nbA, TA);
+    else if (ks == 2) form_blocks<2>(S, W, dvec, lane, nbA, TA);
+    else form_blocks<1>(S, W, dvec, lane, nbA, TA);
+    // rows / columns 4*nbA .. NP-1: zero (dummy columns), except the columns that live only
+    // in the extra rows (the slack variable t): M[c][j] = sum_e d_e X[c][e] X[j][e]
+    const int c0 = 4 * nbA;
+    if (c0 < NP) {
+        const int nrest = NP - c0;
+        for (int k = lane; k < nrest * LDM; k += 64) W.M[c0 * LDM + k] = 0.0;
+        for (int k = lane; k < c0 * nrest; k += 64) {
+            const int r = k / nrest, c = k - r * nrest;
+            W.M[r * LDM + c0 + c] = 0.0;
+        }
+        wsync();
+        for (int c = W.n_mpc; c < W.n_lp; ++c) {     // at most one column in practice
+            if (lane < W.n_lp) {
+                double v = 0.0;
+                const double* xc = W.X + (size_t)c * W.ldx;
+                const double* xl = W.X + (size_t)lane * W.ldx;
+                for (int e = 0; e < W.ne; ++e) v = fma(dvec[W.xbase + e] * xc[e], xl[e], v);
+                W.M[c * LDM + lane] = v;
+                W.M[lane * LDM + c] = v;
+            }
+        }
     }
     wsync();
 }
@@ -444,10 +502,16 @@ __device__ __forceinline__ void lu_factor(double (&row)[NP], const Wave& W, int 
         if (lane == 0) W.db[k] = rinv;
         const double l = row[k] * rinv;
         row[k] = l;
+        // pivot row: uniform 16-byte reads (rows of W.M start 16-byte aligned)
+        if (((k + 1) & 1) && k + 1 < NP) {
+            const double ukq = W.M[k * LDM + k + 1];
+            row[k + 1] = fma(-l, ukq, row[k + 1]);
+        }
 #pragma unroll
-        for (int q = k + 1; q < NP; ++q) {
-            const double ukq = W.M[k * LDM + q];
-            row[q] = fma(-l, ukq, row[q]);
+        for (int q = (k + 2) & ~1; q < NP; q += 2) {
+            const double2v u = *reinterpret_cast<const double2v*>(W.M + k * LDM + q);
+            row[q] = fma(-l, u.x, row[q]);
+            row[q + 1] = fma(-l, u.y, row[q + 1]);
         }
         // the trailing update of step k stays in step k: left alone, the compiler sinks each
         // FMA chain to where row[q] is next read (step q) and keeps n^2/2 broadcast values alive
@@ -457,11 +521,11 @@ __device__ __forceinline__ void lu_factor(double (&row)[NP], const Wave& W, int 
     wsync();
 }
 
-// Solve (LU) x = rhs; lane j passes rhs_j, receives x_j, and W.t[0..n) holds x as well.
+// Solve (LU) x = rhs; lane j passes rhs_j and 1/U[j][j], receives x_j; W.t[0..NP) gets x too.
 // The running right-hand side of a finished lane may turn into garbage: y_k / x_k are taken
 // from the broadcast and parked in LDS by lane 0.
-__device__ __forceinline__ double lu_solve(const double (&row)[NP], const Wave& W, double rhs,
-                                           int lane) {
+__device__ __forceinline__ double lu_solve(const double (&row)[NP], const Wave& W, double rinv,
+                                           double rhs, int lane) {
     double bv = rhs;
 #pragma unroll
     for (int k = 0; k < NP; ++k) {
@@ -476,7 +540,7 @@ __device__ __forceinline__ double lu_solve(const double (&row)[NP], const Wave& 
     const double* urow = W.M + jl * LDM;
 #pragma unroll
     for (int k = NP - 1; k >= 0; --k) {
-        const double xk = readlane_d(bv, k) * W.db[k];
+        const double xk = readlane_d(bv * rinv, k);
         if (lane == 0) W.t[k] = xk;
         bv = fma(-urow[k], xk, bv);
         if ((k & 3) == 0) __builtin_amdgcn_sched_barrier(0);
@@ -596,10 +660,11 @@ __device__ inline IpmResult ipm_solve(const Shared& S, const Wave& W, const doub
         }
         wsync();
         lu_factor(row, W, lane);
+        const double rinv_l = W.db[(lane < NP) ? lane : (NP - 1)];
 
         // ---- predictor ------------------------------------------------------------------
         const double rhs_aff = (lane < n) ? (-cjj - atdr) : 0.0;
-        double dxj = lu_solve(row, W, rhs_aff, lane);
+        double dxj = lu_solve(row, W, rinv_l, rhs_aff, lane);
         double adx[SLOTS];
         rows_times(S, W, rm, W.t, adx);
         double ds_a[SLOTS], dl_a[SLOTS], rl[SLOTS];
@@ -638,7 +703,7 @@ __device__ inline IpmResult ipm_solve(const Shared& S, const Wave& W, const doub
         double atc, dummy;
         cols_times<false>(S, W, W.vm1, W.vm1, W.sc, lane, atc, dummy);
         const double rhs = (lane < n) ? (rhs_aff + atc) : 0.0;
-        dxj = lu_solve(row, W, rhs, lane);
+        dxj = lu_solve(row, W, rinv_l, rhs, lane);
         rows_times(S, W, rm, W.t, adx);
         double ds[SLOTS], dl[SLOTS];
         rho_p = 0.0;

@@ -101,6 +101,7 @@ __device__ inline void assemble_point(const Shared& S, Wave& W, double* lp_base,
     carve_wave(W, lp_base, n + (feas ? 1 : 0), feas ? 1 : 0, m);
     W.n_lin = n;
     W.spec_col = n + p;           // the column of -1
+    W.n_mpc = W.n_lp;
     if (lane < NP) W.c[lane] = feas ? ((lane == n) ? 1.0 : 0.0) : ((lane < n) ? S.cv[lane] : 0.0);
     if (feas) {
         // extra row 0:  -tau <= 1      (ldx = 1)
@@ -139,6 +140,7 @@ __device__ inline void assemble_simplex(const Shared& S, Wave& W, const NodeBuf&
     carve_wave(W, nb.lp, n_lp, ne, m);
     W.n_lin = n + p;
     W.spec_col = slack ? (n + p + 1) : (n + p);   // zeros for t, -1 for tau
+    W.n_mpc = slack ? (n + p) : n_lp;
     simplex_inverse(R, p, nb.aug, nb.F, lane);
     const double* F = nb.F;
     const int ldx = W.ldx;
