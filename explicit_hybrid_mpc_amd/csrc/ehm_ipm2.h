@@ -266,13 +266,32 @@ __device__ __forceinline__ void rows_times(const Shared& S, const Wave& W, const
     const double* pa = S.Wc + rm.lane;      // slots < SLOTS-1 : MPC rows, offset 64*sl
     const double* pb = rm.last_base;
     const int lda = S.lda;
-    for (int j = 0; j < W.n_lin; ++j) {
+    // columns in groups of 4: 4*SLOTS matrix loads in flight per s_waitcnt
+    const int str = rm.last_stride;
+    int j = 0;
+    for (; j + 3 < W.n_lin; j += 4) {
+        double a[4][SLOTS], vj[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            vj[u] = v[j + u];
+#pragma unroll
+            for (int sl = 0; sl < SLOTS - 1; ++sl) a[u][sl] = lds1(pa + u * lda + 64 * sl);
+            a[u][SLOTS - 1] = lds1(pb + u * str);
+        }
+#pragma unroll
+        for (int u = 0; u < 4; ++u)
+#pragma unroll
+            for (int sl = 0; sl < SLOTS; ++sl) out[sl] = fma(a[u][sl], vj[u], out[sl]);
+        pa += 4 * lda;
+        pb += 4 * str;
+    }
+    for (; j < W.n_lin; ++j) {
         const double vj = v[j];
 #pragma unroll
         for (int sl = 0; sl < SLOTS - 1; ++sl) out[sl] = fma(lds1(pa + 64 * sl), vj, out[sl]);
         out[SLOTS - 1] = fma(lds1(pb), vj, out[SLOTS - 1]);
         pa += lda;
-        pb += rm.last_stride;
+        pb += str;
     }
     if (W.n_lin < W.n_lp) {
         const double vj = v[W.n_lin];
@@ -314,7 +333,25 @@ __device__ __forceinline__ void cols_times(const Shared& S, const Wave& W, const
     if (active) {
         const double *pc[4], *px[4];
         block_cols(S, W, cb, pc, px);
-        for (int i = h; i < S.m; i += ks) {
+        int i = h;
+        for (; i + 3 * ks < S.m; i += 4 * ks) {
+            double a[4][4], v0[4], v1[4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                v0[u] = lds1(u0 + i + u * ks);
+                v1[u] = TWO ? lds1(u1 + i + u * ks) : 0.0;
+#pragma unroll
+                for (int q = 0; q < 4; ++q) a[u][q] = lds1(pc[q] + i + u * ks);
+            }
+#pragma unroll
+            for (int u = 0; u < 4; ++u)
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    a0[q] = fma(a[u][q], v0[u], a0[q]);
+                    if (TWO) a1[q] = fma(a[u][q], v1[u], a1[q]);
+                }
+        }
+        for (; i < S.m; i += ks) {
             const double v0 = lds1(u0 + i);
             const double v1 = TWO ? lds1(u1 + i) : 0.0;
 #pragma unroll
@@ -532,7 +569,7 @@ __device__ __forceinline__ double lu_solve(const double (&row)[NP], const Wave& 
         const double yk = readlane_d(bv, k);
         if (lane == 0) W.ub[k] = yk;
         bv = fma(-row[k], yk, bv);
-        if ((k & 3) == 3) __builtin_amdgcn_sched_barrier(0);
+        if ((k & 7) == 7) __builtin_amdgcn_sched_barrier(0);
     }
     wsync();
     const int jl = (lane < NP) ? lane : (NP - 1);
@@ -543,7 +580,7 @@ __device__ __forceinline__ double lu_solve(const double (&row)[NP], const Wave& 
         const double xk = readlane_d(bv * rinv, k);
         if (lane == 0) W.t[k] = xk;
         bv = fma(-urow[k], xk, bv);
-        if ((k & 3) == 0) __builtin_amdgcn_sched_barrier(0);
+        if ((k & 7) == 0) __builtin_amdgcn_sched_barrier(0);
     }
     wsync();
     return W.t[jl];
