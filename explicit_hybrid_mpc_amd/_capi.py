@@ -30,6 +30,7 @@ EXPORTED = [
     'ehm_bar_d_batch', 'ehm_split_batch', 'ehm_volume_batch', 'ehm_partition_run',
     'ehm_tree_info_get', 'ehm_tree_export', 'ehm_tree_destroy', 'ehm_stats',
     'ehm_last_error', 'ehm_version', 'ehm_problem_set_solver', 'ehm_selftest',
+    'ehm_problem_set_option',
 ]
 
 
@@ -111,6 +112,7 @@ def load(build_if_missing=True):
     lib.ehm_sync.argtypes = [vp]
     lib.ehm_problem_set_solver.argtypes = [vp, i32]
     lib.ehm_selftest.argtypes = [i32, vp, i32, vp]
+    lib.ehm_problem_set_option.argtypes = [vp, ctypes.c_char_p, ctypes.c_double]
     lib.ehm_solve_ptd_batch.argtypes = [vp, i64, vp, vp, vp, vp, vp, vp]
     lib.ehm_feas_ptd_batch.argtypes = [vp, i64, vp, vp, vp, vp]
     lib.ehm_solve_pt_batch.argtypes = [vp, i64, vp, vp, vp, vp]

@@ -423,6 +423,7 @@ struct ehm_problem {
     DevBuf consts;           // Gt | St | w | c
     DevBuf wc2;              // [n_delta][n+p+2][m|1]  LDS image for the k2 kernels
     bool v1_ok = false;      // the generation-1 kernels fit this problem
+    int decide_full = 0;     // 1 = the suboptimality test solves to full accuracy (no sign-only stop)
     int solver_gen = 2;      // 1 = one wavefront per workgroup (ehm_kernels.h), 2 = ehm_k2.hip
     DevBuf seg;              // commutation segment offsets of a sorted batch
     std::set<const K2Api*> k2_ready;
@@ -633,6 +634,7 @@ int ehm_problem_create(const ehm_problem_desc* d, int device, ehm_problem** out)
         P->dp.ncw2 = ncw;
     }
     if (const char* e = getenv("EHM_SOLVER")) P->solver_gen = (atoi(e) == 1) ? 1 : 2;
+    if (const char* e = getenv("EHM_DECIDE_FULL")) P->decide_full = atoi(e) ? 1 : 0;
     P->delta_len = d->delta_len;
     if (d->deltas && d->delta_len > 0)
         P->deltas.assign(d->deltas, d->deltas + (size_t)nd * d->delta_len);
@@ -715,6 +717,16 @@ int ehm_selftest(int device, double* out, int32_t max_instances, int32_t* n_inst
     *n_instances = k;
     (void)hipFree(d_out);
     return EHM_OK;
+}
+
+int ehm_problem_set_option(ehm_problem* P, const char* name, double value) {
+    if (!P || !name) return fail(EHM_E_INVALID, "null argument");
+    if (!strcmp(name, "solver")) return ehm_problem_set_solver(P, (int)value);
+    if (!strcmp(name, "decide_full")) {
+        P->decide_full = value != 0.0;
+        return EHM_OK;
+    }
+    return fail(EHM_E_INVALID, "unknown option '%s'", name);
 }
 
 int ehm_sync(ehm_problem* P) {
@@ -1521,7 +1533,7 @@ int ehm_partition_run(ehm_problem* P, int64_t n_roots, const double* root_vertic
         stamp();
         if (P->solver_gen == 2)
             cfg_d.api->decide(cfg_d.L, P->dp, T->dt, cur, (int)nf, open_flag.as<int32_t>(),
-                              P->d_cnt);
+                              P->d_cnt, P->decide_full ? 0 : 1);
         else
             hipLaunchKernelGGL(k_lcss_decide, dim3(grid_for(P, nf)), dim3(64), P->lds_simplex,
                                P->stream, P->dp, T->dt, cur, (int)nf, open_flag.as<int32_t>(),

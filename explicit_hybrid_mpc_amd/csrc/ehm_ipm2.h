@@ -221,9 +221,18 @@ __device__ __forceinline__ int wc_col(const Wave& W, int j) {
 struct IpmResult {
     double obj;
     double merit;
+    double margin;   // lower bound of |optimum| when the solve stopped on its sign, else |obj|
     int iters;
     int status;   // 0 optimal / accepted, 1 stalled
 };
+
+// Sign-only termination (the suboptimality test needs sign(t*), not t*; the reference's
+// bar_E is a feasibility problem, lib/oracle.py:285-309): stop as soon as the primal and the
+// dual objective agree in sign, the duality gap is at most half of the smaller one, and the
+// relative residuals are below 1e-7 and three orders below that objective.
+#define EHM2_SIGN_RES      1e-7
+#define EHM2_SIGN_GAP      0.5
+#define EHM2_SIGN_RES_REL  1e-3
 
 // Per-lane description of the rows this lane owns.
 struct RowMap {
@@ -591,7 +600,7 @@ __device__ __forceinline__ double lu_solve(const double (&row)[NP], const Wave& 
 // On exit: W.xb holds the best primal iterate.
 // ---------------------------------------------------------------------------------------
 __device__ inline IpmResult ipm_solve(const Shared& S, const Wave& W, const double (&b)[SLOTS],
-                                      int lane0) {
+                                      int lane0, bool sign_only = false) {
     int lane = lane0;
     const int n = W.n_lp;
     const int m_lp = S.m + W.ne;
@@ -678,6 +687,19 @@ __device__ inline IpmResult ipm_solve(const Shared& S, const Wave& W, const doub
         if (merit <= 1.0) {
             res.status = 0;
             break;
+        }
+        if (sign_only && emax <= EHM2_SIGN_RES && pobj * dobj > 0.0) {
+            const double lo = fmin(fabs(pobj), fabs(dobj));
+            if (fabs(pobj - dobj) <= EHM2_SIGN_GAP * lo &&
+                emax * (1.0 + fabs(pobj)) <= EHM2_SIGN_RES_REL * lo) {
+                res.obj = pobj;
+                res.merit = merit;
+                res.margin = lo;
+                res.status = 0;
+                if (lane < NP) W.xb[lane] = W.x[lane];
+                wsync();
+                return res;
+            }
         }
         if (stall >= 3 || it == EHM2_MAX_ITER || !(merit == merit)) break;
 
@@ -769,6 +791,7 @@ __device__ inline IpmResult ipm_solve(const Shared& S, const Wave& W, const doub
     }
     wsync();
     if (res.status != 0 && res.merit <= EHM2_ACCEPT_MERIT) res.status = 0;
+    res.margin = fabs(res.obj);
     return res;
 }
 

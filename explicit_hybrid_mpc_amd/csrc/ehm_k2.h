@@ -52,7 +52,7 @@ struct K2Api {
                     const double* Vbar, const int32_t* seg, int mode, double* obj,
                     double* alpha, int32_t* status, int32_t* iters, DevCounters*);
     void (*decide)(const K2Launch&, DevProblem, DevTree, const int32_t* frontier, int nf,
-                   int32_t* open_flag, DevCounters*);
+                   int32_t* open_flag, DevCounters*, int sign_only);
     void (*expand)(const K2Launch&, DevProblem, DevTree, const int32_t* open_list, int n_open,
                    int child_base, int32_t* next_frontier, DevCounters*);
     void (*vertex)(const K2Launch&, DevProblem, DevTree, const int32_t* nodes, int n_nodes,

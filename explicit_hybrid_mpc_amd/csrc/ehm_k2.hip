@@ -329,7 +329,7 @@ __global__ __launch_bounds__(EHM_K2_THREADS) void k2_simplex_batch(
 // (lib/worker.py:368-375)
 __global__ __launch_bounds__(EHM_K2_THREADS) void k2_lcss_decide(
     DevProblem P, DevTree T, const int32_t* __restrict__ frontier, int nf,
-    int32_t* __restrict__ open_flag, DevCounters* cnt, int wave_doubles) {
+    int32_t* __restrict__ open_flag, DevCounters* cnt, int wave_doubles, int sign_only) {
     K2_PROLOGUE();
     const int nrec = rec_doubles(P.p, P.n_u);
     const int per = (nf + gridDim.x - 1) / gridDim.x;
@@ -351,7 +351,7 @@ __global__ __launch_bounds__(EHM_K2_THREADS) void k2_lcss_decide(
         double b[SLOTS];
         assemble_simplex(S, W, nb, nb.rec, nb.rec + rec_off_vcost(P.p), SX_SLACK, P.eps_a,
                          P.eps_r, b, lane);
-        const IpmResult r = ipm_solve(S, W, b, lane);
+        const IpmResult r = ipm_solve(S, W, b, lane, sign_only != 0);
         count_solve(cnt, r, lane);
         if (lane == 0) {
             if (r.status != 0) {
@@ -365,7 +365,7 @@ __global__ __launch_bounds__(EHM_K2_THREADS) void k2_lcss_decide(
             T.tstar[id] = t;
             open_flag[f] = open ? 1 : 0;
             if (!open) T.flags[id] |= 1;
-            atomicMin(&cnt->min_margin_bits, (unsigned long long)__double_as_longlong(fabs(t)));
+            atomicMin(&cnt->min_margin_bits, (unsigned long long)__double_as_longlong(r.margin));
         }
         wsync();
     }
@@ -540,9 +540,9 @@ void l_simplex(const K2Launch& L, DevProblem P, long long n_inst, const double* 
                        L.wave_doubles);
 }
 void l_decide(const K2Launch& L, DevProblem P, DevTree T, const int32_t* frontier, int nf,
-              int32_t* open_flag, DevCounters* cnt) {
+              int32_t* open_flag, DevCounters* cnt, int sign_only) {
     hipLaunchKernelGGL(k2_lcss_decide, dim3(L.grid), dim3(L.threads), L.lds_bytes, L.stream, P,
-                       T, frontier, nf, open_flag, cnt, L.wave_doubles);
+                       T, frontier, nf, open_flag, cnt, L.wave_doubles, sign_only);
 }
 void l_expand(const K2Launch& L, DevProblem P, DevTree T, const int32_t* open_list, int n_open,
               int child_base, int32_t* next_frontier, DevCounters* cnt) {

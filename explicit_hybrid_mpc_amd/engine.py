@@ -101,6 +101,10 @@ class GpuProblem:
         (default); 1 = one wavefront per workgroup (kept as an on-device cross-check)."""
         check(self._lib.ehm_problem_set_solver(self._handle, int(generation)))
 
+    def set_option(self, name, value):
+        """Named options of the handle (include/ehmpc.h: "solver", "decide_full")."""
+        check(self._lib.ehm_problem_set_option(self._handle, name.encode(), float(value)))
+
     # -- helpers ------------------------------------------------------------------------
     def _delta_arg(self, delta, n_inst):
         if delta is None:

@@ -82,6 +82,12 @@ int ehm_problem_set_eps(ehm_problem* prob, double eps_a, double eps_r);
  * 1 = one wavefront per workgroup with a private copy of the LP (first build, kept as an
  * on-device cross-check).  Environment override at create time: EHM_SOLVER=1|2. */
 int ehm_problem_set_solver(ehm_problem* prob, int generation);
+/* Named options: "solver" (1|2, as above); "decide_full" (0|1): by default the
+ * suboptimality-test sweep of ehm_partition_run stops each LP as soon as the SIGN of its
+ * optimum t* is certain (the reference's bar_E is a feasibility problem,
+ * lib/oracle.py:285-309) and records a lower bound of |t*|; 1 = solve every test LP to full
+ * accuracy (EHM_DECIDE_FULL=1 at create time does the same). */
+int ehm_problem_set_option(ehm_problem* prob, const char* name, double value);
 int ehm_sync(ehm_problem* prob);
 /* HIP stream the handle enqueues on (a hipStream_t), for event timing by the caller. */
 void* ehm_stream(ehm_problem* prob);

@@ -96,8 +96,18 @@ def main():
         f1 = gp.partition(roots, action='ecc')
         t1 = time.perf_counter()
         gp.set_solver(2)
+        gp.set_option('decide_full', 1)
         f2 = gp.partition(roots, action='ecc')
         t2 = time.perf_counter()
+        gp.set_option('decide_full', 0)
+        f3 = gp.partition(roots, action='ecc')
+        same3 = (f1.n_nodes == f3.n_nodes and np.array_equal(f1.vertices, f3.vertices) and
+                 np.array_equal(f1.left, f3.left) and np.array_equal(f1.flags & 1, f3.flags & 1))
+        report('partition %s sign-only decide' % name, same3,
+               'nodes %d, margin bound %.2e, iters/LP %.2f (full %.2f)' %
+               (f3.n_nodes, f3.info['min_margin'],
+                f3.info['decide_iters'] / max(f3.info['decide_solves'], 1),
+                f2.info['decide_iters'] / max(f2.info['decide_solves'], 1)))
         same = (f1.n_nodes == f2.n_nodes and np.array_equal(f1.vertices, f2.vertices) and
                 np.array_equal(f1.left, f2.left) and np.array_equal(f1.flags & 1, f2.flags & 1))
         dc = relerr(f2.vertex_costs.ravel(), f1.vertex_costs.ravel()) if same else np.nan
@@ -113,8 +123,10 @@ def main():
     # bench-size partition, timing only
     eps_a = float(np.max(gp.solve_pt(0.03 * V)[0]))
     gp.set_eps(eps_a, 1e-2)
-    for g in (2, 1, 2):
+    for g, full in ((2, 1), (1, 1), (2, 1), (2, 0), (2, 0)):
         gp.set_solver(g)
+        gp.set_option('decide_full', full)
+        print('decide_full=%d ' % full, end='')
         t0 = time.perf_counter()
         i = gp.partition(roots, action='ecc', max_nodes=1 << 22, export=False, with_volume=False)
         dt = time.perf_counter() - t0
