@@ -43,6 +43,22 @@ def node_bytes(p, n_u, delta_len):
     return 8 * ((p + 1) * p + (p + 1) + (p + 1) * n_u) + delta_len + 16
 
 
+def pmc_traffic(kernel):
+    """
+    HBM bytes per launch of `kernel` from the committed rocprofv3 --pmc passes of THIS workload
+    (profiles/r1/pmc_summary_bench.json, tools/profile.sh): FETCH_SIZE / WRITE_SIZE are in KiB
+    and come from separate passes; on gfx950 FETCH_SIZE tallies 128-byte read requests at 64
+    bytes, so it is doubled (MI355X_MICROARCH.md, HBM section).  None if no profile is there.
+    """
+    path = os.path.join(ROOT, 'profiles', 'r1', 'pmc_summary_bench.json')
+    try:
+        c = json.load(open(path))['counters'][kernel]
+        n_f, n_w = c['_dispatches_pmc3'], c['_dispatches_pmc4']
+        return (2. * c['FETCH_SIZE'] / n_f + c['WRITE_SIZE'] / n_w) * 1024.
+    except (OSError, KeyError, ValueError, ZeroDivisionError):
+        return None
+
+
 def cpu_baseline(mpc, eps_a, eps_r, seconds):
     """Oracle (CPU restatement, HiGHS) timed on a bounded prefix of the same partition."""
     from oracle.oracle_cpu import OracleCPU
@@ -83,6 +99,9 @@ def main():
     ap.add_argument('--shard-min-frontier', type=int, default=2048)
     ap.add_argument('--cpu-seconds', type=float, default=15.)
     ap.add_argument('--no-cpu-baseline', action='store_true')
+    ap.add_argument('--solver', type=int, default=2, help='kernel generation (1 or 2)')
+    ap.add_argument('--decide-full', action='store_true',
+                    help='solve the suboptimality-test LPs to full accuracy (no sign-only stop)')
     args = ap.parse_args()
 
     import torch
@@ -103,6 +122,9 @@ def main():
     mpc = examples.linear_mpc(seed=args.seed)
     can = mpc.compile()
     gp = engine.GpuProblem(can, 1., 1., device=device_index)
+    gp.set_solver(args.solver)
+    gp.set_option('decide_full', 1 if args.decide_full else 0)
+    kname = 'k2_lcss_decide' if args.solver == 2 else 'k_lcss_decide'
     half = examples.theta_box(mpc)
     V = examples.box_vertices(half)
     # eps_a by the reference's rule (lib/examples.py:42-46), evaluated on the GPU oracle
@@ -184,16 +206,22 @@ def main():
                 'mean_ipm_iterations': agg['ipm_iters'] / max(agg['lp_solves'], 1),
                 'sweeps': info0['sweeps'], 'tree_depth': info0['max_depth'],
                 'min_decision_margin': info0['min_margin'],
+                'kernels': 'generation %d' % args.solver,
+                'suboptimality_test': 'full accuracy' if args.decide_full else
+                                      'sign-only stop (lower bound of |t*| recorded)',
                 'parallelism': 'frontier dealt round-robin over %d GPU(s)' % world,
                 'lp_solves_per_rank': [int(v) for v in per_rank],
                 'load_imbalance_max_over_mean': distributed.imbalance(per_rank),
             },
             'roofline': {
-                'bound': 'mfma', 'kernel': 'k_lcss_decide',
+                'bound': 'mfma', 'kernel': kname,
                 'note': 'FP64 vector FMA bound (no f64 contraction >= 32 wide at n=25); peak = '
                         'FP64 vector = matrix peak of MI355X',
                 'achieved': achieved, 'peak': FP64_PEAK_TFLOPS, 'unit': 'TFLOP/s',
-                'frac': achieved / FP64_PEAK_TFLOPS, 'traffic': None,
+                'frac': achieved / FP64_PEAK_TFLOPS, 'traffic': pmc_traffic(kname),
+                'traffic_unit': 'HBM bytes per launch (rocprofv3 FETCH_SIZE x2 + WRITE_SIZE, '
+                                'profiles/r1/pmc_summary_bench.json)',
+                'algorithmic_bytes_per_launch': hbm_alg / max(info0['decide_launches'] * K, 1),
                 'flop_per_ipm_iteration': flops_per_iteration(n_slack, m_slack),
                 'kernel_seconds': decide_s, 'launches': info0['decide_launches'] * K,
                 'expand_kernel': {'achieved': expand_flops / max(expand_s, 1e-12) / 1e12,

@@ -427,6 +427,13 @@ struct ehm_problem {
     int solver_gen = 2;      // 1 = one wavefront per workgroup (ehm_kernels.h), 2 = ehm_k2.hip
     DevBuf seg;              // commutation segment offsets of a sorted batch
     std::set<const K2Api*> k2_ready;
+    // device memory kept between partition runs (hipMalloc/hipFree of a GB-sized node pool
+    // cost milliseconds): the pool of the last destroyed tree and the frontier scratch
+    struct PoolCache {
+        long long cap = 0;
+        DevBuf rec, left, didx, depth, flags, tstar;
+    } pool_cache;
+    DevBuf fr_a, fr_b, open_flag, open_list, d_count;
     DevBuf in0, in1, in2, out0, out1, out2, out3;
     DevCounters* d_cnt = nullptr;
     long long launches = 0;
@@ -673,6 +680,10 @@ int ehm_problem_destroy(ehm_problem* P) {
     P->consts.release();
     P->wc2.release();
     P->seg.release();
+    P->pool_cache.rec.release(); P->pool_cache.left.release(); P->pool_cache.didx.release();
+    P->pool_cache.depth.release(); P->pool_cache.flags.release(); P->pool_cache.tstar.release();
+    P->fr_a.release(); P->fr_b.release(); P->open_flag.release(); P->open_list.release();
+    P->d_count.release();
     P->in0.release(); P->in1.release(); P->in2.release();
     P->out0.release(); P->out1.release(); P->out2.release(); P->out3.release();
     if (P->d_cnt) (void)hipFree(P->d_cnt);
@@ -1333,6 +1344,13 @@ int ehm_volume_batch(int device, int64_t n, int32_t p, const double* R, double* 
 int ehm_tree_destroy(ehm_tree* T) {
     if (!T) return EHM_OK;
     if (T->prob) (void)hipSetDevice(T->prob->device);
+    if (T->prob && T->cap > T->prob->pool_cache.cap) {
+        // keep the larger pool for the next run of this problem
+        auto& c = T->prob->pool_cache;
+        std::swap(c.rec, T->rec); std::swap(c.left, T->left); std::swap(c.didx, T->didx);
+        std::swap(c.depth, T->depth); std::swap(c.flags, T->flags); std::swap(c.tstar, T->tstar);
+        c.cap = T->cap;
+    }
     T->rec.release(); T->left.release(); T->didx.release(); T->depth.release();
     T->flags.release(); T->tstar.release();
     delete T;
@@ -1343,6 +1361,13 @@ static int tree_alloc(ehm_tree* T, ehm_problem* P, long long cap) {
     const int p = P->dp.p, n_u = P->dp.n_u;
     const int stride = ((rec_doubles(p, n_u) + 7) / 8) * 8;
     int rc;
+    if (P->pool_cache.cap >= cap) {
+        auto& c = P->pool_cache;
+        std::swap(c.rec, T->rec); std::swap(c.left, T->left); std::swap(c.didx, T->didx);
+        std::swap(c.depth, T->depth); std::swap(c.flags, T->flags); std::swap(c.tstar, T->tstar);
+        cap = c.cap;
+        c.cap = 0;
+    }
     if ((rc = T->rec.ensure((size_t)cap * stride * sizeof(double)))) return rc;
     if ((rc = T->left.ensure((size_t)cap * sizeof(int32_t)))) return rc;
     if ((rc = T->didx.ensure((size_t)cap * sizeof(int32_t)))) return rc;
@@ -1428,11 +1453,9 @@ int ehm_partition_run(ehm_problem* P, int64_t n_roots, const double* root_vertic
         HIP_TRY(hipStreamSynchronize(P->stream), EHM_E_HIP);
     }
     // frontier buffers (ping-pong) + open flags + open list + count
-    DevBuf fr_a, fr_b, open_flag, open_list, d_count;
-    auto cleanup = [&]() {
-        fr_a.release(); fr_b.release(); open_flag.release(); open_list.release();
-        d_count.release();
-    };
+    DevBuf &fr_a = P->fr_a, &fr_b = P->fr_b, &open_flag = P->open_flag,
+           &open_list = P->open_list, &d_count = P->d_count;
+    auto cleanup = [&]() {};     // the frontier scratch stays with the problem handle
 #define RUN_TRY(expr)                          \
     do {                                       \
         int rc_ = (expr);                      \

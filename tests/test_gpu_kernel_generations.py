@@ -1,0 +1,103 @@
+"""
+The two kernel generations of libehmpc against each other on the device (same inputs, same
+C-ABI): generation 2 (shared constant LP block in LDS, psi-coordinates, several wavefronts
+per workgroup) must reproduce generation 1 (one wavefront per workgroup, barycentric
+coordinates) for every oracle kind and grow the identical tree -- also with the sign-only
+termination of the suboptimality test.  Both are checked against the CPU oracle elsewhere
+(test_gpu_oracles.py, test_gpu_partition.py); this file pins them to each other at sizes
+the CPU oracle cannot reach in seconds.
+"""
+
+import numpy as np
+import pytest
+
+from tests import helpers
+
+pytestmark = pytest.mark.gpu
+
+RTOL = 1e-8
+
+
+def rel(a, b):
+    return float(np.max(np.abs(a - b) / (1. + np.abs(b))))
+
+
+def both(gp, fn):
+    gp.set_solver(1)
+    a = fn()
+    gp.set_solver(2)
+    b = fn()
+    return a, b
+
+
+def test_wave_primitives_of_every_instance():
+    from explicit_hybrid_mpc_amd import engine
+    out = engine.selftest()
+    assert out.shape[0] == 28
+    assert np.abs(out - np.array([1072., 99., 25., 1. / 3., -1.])).max() < 1e-13
+
+
+@pytest.mark.parametrize('kind', ['di', 'lin', 'pwa'])
+def test_batched_oracles_agree(kind):
+    from explicit_hybrid_mpc_amd import engine, examples
+    mpc = helpers.make_instance(kind, 0)
+    can = mpc.compile()
+    gp = engine.GpuProblem(can, 0.05, 0.05)
+    rng = np.random.default_rng(3)
+    half = examples.theta_box(mpc)
+    n = 700
+    theta = rng.uniform(-1.3, 1.3, (n, can.p)) * half
+    delta = can.deltas[rng.integers(can.n_delta, size=n)]     # unsorted on purpose
+    (f1, t1), (f2, t2) = both(gp, lambda: gp.feasible_ptd(theta, delta))
+    assert (f1 == f2).all() and rel(t2, t1) < 1e-7
+    ok = f1
+    (J1, u1, s1, _), (J2, u2, s2, _) = both(gp, lambda: gp.solve_ptd(theta[ok], delta[ok]))
+    assert (s1 == 0).all() and (s2 == 0).all()
+    assert rel(J2, J1) < RTOL
+    (Ja, _, da), (Jb, _, db) = both(gp, lambda: gp.solve_pt(theta))
+    assert (da == db).all() and rel(Jb[da >= 0], Ja[da >= 0]) < RTOL
+    R = helpers.random_simplices(mpc, rng, 300, -2.5, -0.5)
+    didx, vJ, _ = gp.v_r(R)
+    keep = didx >= 0
+    R, vJ, dl = R[keep], vJ[keep], can.deltas[didx[keep]]
+    (ta, aa, sa), (tb, ab, sb) = both(gp, lambda: gp.slack(R, vJ, dl))
+    assert (sa == 0).all() and (sb == 0).all()
+    assert rel(tb, ta) < 1e-7 and ((ta >= 0) == (tb >= 0)).all()
+    assert np.abs(ab.sum(axis=1) - 1).max() < 1e-9 and ab.min() > -1e-7
+    (ma, _), (mb, _) = both(gp, lambda: gp.min_simplex(R, dl))
+    assert rel(mb, ma) < RTOL
+    (ca, tba), (cb, tbb) = both(gp, lambda: gp.bar_e(R, vJ))
+    assert (ca == cb).all()
+    gp.close()
+
+
+@pytest.mark.parametrize('abs_frac', [0.25, 0.08])
+def test_partition_identical_across_generations_and_decide_modes(abs_frac):
+    from explicit_hybrid_mpc_amd import engine, examples
+    from explicit_hybrid_mpc_amd import tools as ehm_tools
+    mpc = helpers.make_instance('lin', 0)
+    gp = engine.GpuProblem(mpc.compile(), 1., 1.)
+    V = examples.box_vertices(examples.theta_box(mpc))
+    eps_a = float(np.max(gp.solve_pt(abs_frac * V)[0]))
+    gp.set_eps(eps_a, 1e-2)
+    roots, _ = ehm_tools.delaunay_roots(V)
+    trees = []
+    for gen, full in ((1, 1), (2, 1), (2, 0)):
+        gp.set_solver(gen)
+        gp.set_option('decide_full', full)
+        trees.append(gp.partition(roots, action='ecc'))
+    gp.close()
+    ref = trees[0]
+    for t in trees[1:]:
+        assert t.n_nodes == ref.n_nodes
+        assert np.array_equal(t.vertices, ref.vertices)          # bit-identical geometry
+        assert np.array_equal(t.left, ref.left)
+        assert np.array_equal(t.flags & 1, ref.flags & 1)        # same closed leaves
+        assert rel(t.vertex_costs.ravel(), ref.vertex_costs.ravel()) < RTOL
+        assert abs(t.info['volume_closed'] - ref.info['volume_closed']) < 1e-9
+    full, sign = trees[1], trees[2]
+    assert rel(full.tstar, ref.tstar) < 1e-6
+    # the sign-only stop records a lower bound of |t*| and needs fewer iterations
+    assert sign.info['min_margin'] <= full.info['min_margin'] * (1 + 1e-9)
+    assert sign.info['decide_iters'] < 0.8 * full.info['decide_iters']
+    assert ((sign.tstar >= 0) == (full.tstar >= 0)).all()

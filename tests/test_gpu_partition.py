@@ -27,10 +27,11 @@ def compare_trees(flat, nodes_cpu, locs):
                            rtol=RTOL, atol=RTOL), name
 
 
+@pytest.mark.parametrize('decide_full', [0, 1])
 @pytest.mark.parametrize('kind,seed,abs_frac,eps_r', [('di', 0, 0.25, 0.1),
                                                       ('lin', 0, 0.5, 1.0),
                                                       ('lin', 1, 0.5, 0.5)])
-def test_tree_identical_to_cpu_partition(kind, seed, abs_frac, eps_r):
+def test_tree_identical_to_cpu_partition(kind, seed, abs_frac, eps_r, decide_full):
     from explicit_hybrid_mpc_amd import engine, examples
     from oracle.oracle_cpu import OracleCPU
     from oracle.partition_cpu import PartitionCPU
@@ -41,6 +42,7 @@ def test_tree_identical_to_cpu_partition(kind, seed, abs_frac, eps_r):
     cpu = PartitionCPU(orc)
     cpu.run(roots, locs, 'ecc')
     gp = engine.GpuProblem(mpc.compile(), eps_a, eps_r)
+    gp.set_option('decide_full', decide_full)
     flat = gp.partition(np.array(roots), action='ecc')
     gp.close()
     compare_trees(flat, cpu.nodes, locs)

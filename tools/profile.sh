@@ -1,7 +1,7 @@
 #!/bin/bash
 # rocprofv3 passes over bench.py (run on the GPU box: gpurun -- 'bash tools/profile.sh TAG').
 # Kernel-trace statistics of the full bench workload, then separate --pmc passes (SQ issue /
-# wait counters, LDS, HBM bytes) on a smaller tree so each pass stays short.
+# wait counters, LDS, HBM bytes) over one step of the same workload.
 TAG=${1:-run}
 R=${GRAFT_REPO_ROOT:-$(pwd)}
 O=$R/gpurun_out/prof_$TAG
@@ -9,7 +9,7 @@ mkdir -p $O
 cd /tmp; export TMPDIR=/tmp
 B="python $R/bench.py --no-cpu-baseline"
 rocprofv3 --kernel-trace --stats --output-format csv -d $O/stats -- $B --steps 3 --warmup 1 > $O/stats.log 2>&1
-S="--steps 1 --warmup 0 --abs-frac 0.05"
+S="--steps 1 --warmup 0 ${PROFILE_ARGS:-}"
 rocprofv3 --pmc SQ_WAVES SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_INSTS_VALU SQ_INSTS_LDS SQ_INSTS_SALU SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_LDS --output-format csv -d $O/pmc1 -- $B $S > $O/pmc1.log 2>&1
 rocprofv3 --pmc SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_WAIT_INST_LDS SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_ACTIVE_INST_ANY SQ_INSTS_SMEM SQ_INSTS_VMEM --output-format csv -d $O/pmc2 -- $B $S > $O/pmc2.log 2>&1
 rocprofv3 --pmc FETCH_SIZE --output-format csv -d $O/pmc3 -- $B $S > $O/pmc3.log 2>&1
