@@ -91,8 +91,8 @@ def load(build_if_missing=True):
     global _lib
     if _lib is not None:
         return _lib
-    path = _build.LIB
-    if build_if_missing and _build.is_stale():
+    path = os.environ.get('EHM_LIB') or _build.LIB      # EHM_LIB: an experimental build
+    if build_if_missing and path == _build.LIB and _build.is_stale():
         _build.build()
     if not os.path.exists(path):
         raise EhmError(EHM_E_NO_DEVICE,

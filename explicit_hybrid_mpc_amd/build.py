@@ -25,6 +25,13 @@ HEADERS = ['ehm_ipm.h', 'ehm_kernels.h', 'ehm_dev.h', 'ehm_k2.h', 'ehm_ipm2.h',
 K2_NPS = (8, 12, 16, 20, 24, 28, 32)
 K2_SLOTS = (1, 2, 3, 4)
 FLAGS = ['--offload-arch=gfx950', '-O3', '-std=c++17', '-fPIC', '-Wno-unused-result']
+# experiments: extra -D flags and an alternative output name, e.g.
+#   EHM_BUILD_FLAGS="-DEHM2_UNROLL=2" EHM_BUILD_TAG=u2 python -m explicit_hybrid_mpc_amd.build
+FLAGS += os.environ.get('EHM_BUILD_FLAGS', '').split()
+_TAG = os.environ.get('EHM_BUILD_TAG', '')
+if _TAG:
+    OBJ_DIR = os.path.join(LIB_DIR, 'obj_' + _TAG)
+    LIB = os.path.join(LIB_DIR, 'libehmpc_%s.so' % _TAG)
 
 
 def _hipcc():

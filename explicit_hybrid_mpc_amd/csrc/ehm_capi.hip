@@ -539,8 +539,9 @@ static int k2_config(ehm_problem* P, int kind_a, int kind_b, long long n_items, 
         HIP_TRY(api->set_lds(EHM_LDS_BUDGET), EHM_E_HIP);
         P->k2_ready.insert(api);
     }
-    // residency: LDS, and 2 wavefronts per SIMD at the instances' register budget
-    long long wg_per_cu = std::max<long long>(1, std::min<long long>(EHM_LDS_BUDGET / lds, 8 / nw));
+    // residency: LDS, and the wavefronts per CU the instances' register budget admits
+    long long wg_per_cu = std::max<long long>(
+        1, std::min<long long>(EHM_LDS_BUDGET / lds, (api->max_threads / 64) / nw));
     long long grid = std::min<long long>((long long)P->num_cu * wg_per_cu, (n_items + nw - 1) / nw);
     cfg.api = api;
     cfg.L.grid = (int)std::max(1LL, grid);

@@ -32,10 +32,17 @@
 #error "EHM_SLOTS (row slots per lane) must be defined"
 #endif
 
+// rows / columns per software-pipelined group in the matrix loops (loads in flight per wait)
+#ifndef EHM2_UNROLL
+#define EHM2_UNROLL 4
+#endif
 #define EHM2_TOL_RES      1e-10
 #define EHM2_TOL_GAP      1e-10
 #define EHM2_MAX_ITER     40
-#define EHM2_STEP_FRAC    0.99
+// fraction of the step to the boundary: 0.999 saves ~12 % of the iterations over 0.99; the few
+// solves per million it stalls are repeated with the conservative value (ipm_solve_retry)
+#define EHM2_STEP_FRAC    0.999
+#define EHM2_STEP_FRAC_SAFE 0.99
 #define EHM2_PIVOT_REL    1e-13
 #define EHM2_PIVOT_BIG    1e128
 #define EHM2_STALL_ZONE   1e4
@@ -166,7 +173,7 @@ __device__ inline void load_shared(const DevProblem& P, int d, double* base, int
 
 // Private to a wavefront.
 struct Wave {
-    double* M;      // NP x LDM normal matrix / scratch for column products (>= 512 doubles)
+    double* M;      // region A: scratch / NP x LDM normal matrix / packed U (see A_DOUBLES)
     double* X;      // [n_lp][ldx] extra rows, column-major
     double* vm0;    // MROWS
     double* vm1;    // MROWS
@@ -176,7 +183,7 @@ struct Wave {
     double* t;      // NP scratch
     double* ub;     // NP pivot-row broadcast
     double* db;     // NP original diagonal, then reciprocal pivots
-    double* sc;     // 256 doubles: partial column products while W.M holds the U factor
+    double* sc;     // 256 doubles inside A: partial column products while A holds the U factor
     int n_lp, ne, ldx, ldm, xbase;
     int n_lin;      // LP columns j < n_lin are Wc columns j
     int spec_col;   // Wc column of LP column n_lin (when n_lin < n_lp)
@@ -184,14 +191,28 @@ struct Wave {
 };
 constexpr int LDM = NP + 2;     // even: rows start 16-byte aligned (ds_read_b128 broadcasts)
 typedef double double2v __attribute__((ext_vector_type(2)));
-// W.M also serves as scratch: 8 x 64 partial column products (cols_times) and the K-slices of
-// the normal-matrix blocks, (KS-1) * 16 * TA <= 768 doubles (form_blocks)
-constexpr size_t M_DOUBLES = ((size_t)NP * LDM < 768) ? 768 : (size_t)NP * LDM;
+
+// Packed upper-triangular factor: row k keeps its columns (k & ~1) .. NP-1 (an even start keeps
+// every row 16-byte aligned); element (k, q) lives at U[uoff(k) + q].
+__host__ __device__ constexpr int u_row_start(int k) {
+    // sum_{j<k} (NP - (j & ~1)) : k = 2t -> 2t*NP - 2t(t-1) ; k = 2t+1 -> (2t+1)*NP - 2t*t
+    return (k & 1) ? (k * NP - 2 * (k / 2) * (k / 2)) : (k * NP - 2 * (k / 2) * (k / 2 - 1));
+}
+__host__ __device__ constexpr int uoff(int k) { return u_row_start(k) - (k & ~1); }
+constexpr int U_SIZE = NP * (NP + 2) / 2;
+// One phase-shared region per wavefront ("A"):
+//   residuals      : lam / d r_p  at vm0 / vm1,  partial column products at A[0..512)
+//   normal matrix  : d at vm0 (read by the row loops), K-slices at A[0..768), then the square
+//                    NP x LDM matrix at A[0..)
+//   factor + solves: packed U at A[0..U_SIZE), corrector input at vm1, its partials at sc
+// vm0 and sc share [U_SIZE, U_SIZE+256); vm1 follows.  Every overwrite happens after the last
+// read of what it overwrites (same wavefront, program order).
+constexpr size_t A_MIN = (size_t)U_SIZE + 256 + MROWS;
+constexpr size_t A_SQ = ((size_t)NP * LDM < 768) ? 768 : (size_t)NP * LDM;
+constexpr size_t A_DOUBLES = (A_MIN < A_SQ) ? A_SQ : A_MIN;
 __host__ __device__ inline size_t wave_lp_doubles(int n_lp, int ne) {
-    const size_t Md = M_DOUBLES;
     const size_t ldx = ne ? ((size_t)ne | 1) : 0;
-    return ((Md + (size_t)n_lp * ldx + 2 * (size_t)MROWS + 6 * (size_t)NP + 256) + 1) &
-           ~(size_t)1;
+    return ((A_DOUBLES + (size_t)n_lp * ldx + 6 * (size_t)NP) + 1) & ~(size_t)1;
 }
 __device__ inline void carve_wave(Wave& W, double* base, int n_lp, int ne, int m) {
     W.n_lp = n_lp;
@@ -201,17 +222,18 @@ __device__ inline void carve_wave(Wave& W, double* base, int n_lp, int ne, int m
     W.xbase = lp_xbase(m, ne);
     // an instance compiled with more slots than the LP needs keeps the extras in ITS last slot
     if (ne > 0 && W.xbase < 64 * (SLOTS - 1)) W.xbase = 64 * (SLOTS - 1);
-    W.M = base;   base += M_DOUBLES;
+    W.M = base;
+    W.vm0 = base + U_SIZE;
+    W.sc = base + U_SIZE;
+    W.vm1 = base + U_SIZE + 256;
+    base += A_DOUBLES;
     W.X = base;   base += (size_t)n_lp * W.ldx;
-    W.vm0 = base; base += MROWS;
-    W.vm1 = base; base += MROWS;
     W.c = base;   base += NP;
     W.x = base;   base += NP;
     W.xb = base;  base += NP;
     W.t = base;   base += NP;
     W.ub = base;  base += NP;
-    W.db = base;  base += NP;
-    W.sc = base;
+    W.db = base;
 }
 
 __device__ __forceinline__ int wc_col(const Wave& W, int j) {
@@ -278,21 +300,22 @@ __device__ __forceinline__ void rows_times(const Shared& S, const Wave& W, const
     // columns in groups of 4: 4*SLOTS matrix loads in flight per s_waitcnt
     const int str = rm.last_stride;
     int j = 0;
-    for (; j + 3 < W.n_lin; j += 4) {
-        double a[4][SLOTS], vj[4];
+    constexpr int UR = EHM2_UNROLL;
+    for (; j + UR - 1 < W.n_lin; j += UR) {
+        double a[UR][SLOTS], vj[UR];
 #pragma unroll
-        for (int u = 0; u < 4; ++u) {
+        for (int u = 0; u < UR; ++u) {
             vj[u] = v[j + u];
 #pragma unroll
             for (int sl = 0; sl < SLOTS - 1; ++sl) a[u][sl] = lds1(pa + u * lda + 64 * sl);
             a[u][SLOTS - 1] = lds1(pb + u * str);
         }
 #pragma unroll
-        for (int u = 0; u < 4; ++u)
+        for (int u = 0; u < UR; ++u)
 #pragma unroll
             for (int sl = 0; sl < SLOTS; ++sl) out[sl] = fma(a[u][sl], vj[u], out[sl]);
-        pa += 4 * lda;
-        pb += 4 * str;
+        pa += UR * lda;
+        pb += UR * str;
     }
     for (; j < W.n_lin; ++j) {
         const double vj = v[j];
@@ -343,17 +366,18 @@ __device__ __forceinline__ void cols_times(const Shared& S, const Wave& W, const
         const double *pc[4], *px[4];
         block_cols(S, W, cb, pc, px);
         int i = h;
-        for (; i + 3 * ks < S.m; i += 4 * ks) {
-            double a[4][4], v0[4], v1[4];
+        constexpr int UR = EHM2_UNROLL;
+        for (; i + (UR - 1) * ks < S.m; i += UR * ks) {
+            double a[UR][4], v0[UR], v1[UR];
 #pragma unroll
-            for (int u = 0; u < 4; ++u) {
+            for (int u = 0; u < UR; ++u) {
                 v0[u] = lds1(u0 + i + u * ks);
                 v1[u] = TWO ? lds1(u1 + i + u * ks) : 0.0;
 #pragma unroll
                 for (int q = 0; q < 4; ++q) a[u][q] = lds1(pc[q] + i + u * ks);
             }
 #pragma unroll
-            for (int u = 0; u < 4; ++u)
+            for (int u = 0; u < UR; ++u)
 #pragma unroll
                 for (int q = 0; q < 4; ++q) {
                     a0[q] = fma(a[u][q], v0[u], a0[q]);
@@ -445,12 +469,19 @@ __device__ __forceinline__ void form_blocks(const Shared& S, const Wave& W, cons
                 _Pragma("unroll") for (int r = 0; r < 4; ++r)                          \
                     acc[q][r] = fma(aj[q], ak[r], acc[q][r]);                          \
         }
+#if EHM2_UNROLL >= 4
         for (; i + 3 * KS < m; i += 4 * KS) {
             EHM2_FORM_ROW(cj, ck, dvec, i)
             EHM2_FORM_ROW(cj, ck, dvec, i + KS)
             EHM2_FORM_ROW(cj, ck, dvec, i + 2 * KS)
             EHM2_FORM_ROW(cj, ck, dvec, i + 3 * KS)
         }
+#else
+        for (; i + KS < m; i += 2 * KS) {
+            EHM2_FORM_ROW(cj, ck, dvec, i)
+            EHM2_FORM_ROW(cj, ck, dvec, i + KS)
+        }
+#endif
         for (; i < m; i += KS) EHM2_FORM_ROW(cj, ck, dvec, i)
         const double* dx = dvec + W.xbase;
         for (int e = h; e < W.ne; e += KS) EHM2_FORM_ROW(xj, xk, dx, e)
@@ -491,6 +522,13 @@ __device__ __forceinline__ void form_blocks(const Shared& S, const Wave& W, cons
 
 __device__ inline void form_normal_matrix(const Shared& S, const Wave& W, const double* dvec,
                                           int lane) {
+    // the square matrix will overwrite dvec (region A): take what is needed from it first
+    double vspec = 0.0;
+    if (W.n_mpc < W.n_lp && lane < W.n_lp) {
+        const double* xc = W.X + (size_t)W.n_mpc * W.ldx;
+        const double* xl = W.X + (size_t)lane * W.ldx;
+        for (int e = 0; e < W.ne; ++e) vspec = fma(dvec[W.xbase + e] * xc[e], xl[e], vspec);
+    }
     const int nbA = (W.n_mpc + 3) >> 2;
     const int TA = nbA * (nbA + 1) / 2;
     const int ks = 64 / TA;     // TA <= 36
@@ -509,15 +547,10 @@ __device__ inline void form_normal_matrix(const Shared& S, const Wave& W, const 
             W.M[r * LDM + c0 + c] = 0.0;
         }
         wsync();
-        for (int c = W.n_mpc; c < W.n_lp; ++c) {     // at most one column in practice
-            if (lane < W.n_lp) {
-                double v = 0.0;
-                const double* xc = W.X + (size_t)c * W.ldx;
-                const double* xl = W.X + (size_t)lane * W.ldx;
-                for (int e = 0; e < W.ne; ++e) v = fma(dvec[W.xbase + e] * xc[e], xl[e], v);
-                W.M[c * LDM + lane] = v;
-                W.M[lane * LDM + c] = v;
-            }
+        if (W.n_mpc < W.n_lp && lane < W.n_lp) {      // at most one such column
+            const int c = W.n_mpc;
+            W.M[c * LDM + lane] = vspec;
+            W.M[lane * LDM + c] = vspec;
         }
     }
     wsync();
@@ -526,8 +559,9 @@ __device__ inline void form_normal_matrix(const Shared& S, const Wave& W, const 
 // Row-owned elimination of the n x n normal matrix (lane j holds row j in registers), pivot
 // rows broadcast through LDS and NO per-step lane predicates:
 //   * step k publishes column k of the current Schur complement (register k of every lane;
-//     by symmetry it is row k) into row k of W.M.  After the loop the upper triangle of W.M
-//     therefore holds U, and W.db[k] holds 1/U[k][k] (guarded);
+//     by symmetry it is row k) as row k of the packed factor U in region A (the square matrix
+//     is dead by then: every lane holds its row).  After the loop A holds U and W.db[k]
+//     holds 1/U[k][k] (guarded);
 //   * the elimination always runs over all NP columns: columns n_lp..NP-1 are identically
 //     zero (their pointers aim at the zero column), so their pivots are frozen by the guard
 //     and their solution components are exactly 0 -- no data-dependent control flow at all;
@@ -536,11 +570,13 @@ __device__ inline void form_normal_matrix(const Shared& S, const Wave& W, const 
 //     never their multipliers L[lane][q], q < lane, which stay in row[q].
 // On entry W.db[j] = original diagonal (dependent-pivot guard, LIPSOL/PCx).
 __device__ __forceinline__ void lu_factor(double (&row)[NP], const Wave& W, int lane) {
+    double* U = W.M;
 #pragma unroll
     for (int k = 0; k < NP; ++k) {
-        if (lane < NP) W.M[k * LDM + lane] = row[k];
+        const int kk = k & ~1;
+        if (lane >= kk && lane < NP) U[uoff(k) + lane] = row[k];
         wsync();
-        double piv = W.M[k * LDM + k];
+        double piv = U[uoff(k) + k];
         const double orig = W.db[k];
         const bool bad = !(piv > EHM2_PIVOT_REL * orig) || !(piv > 0.0);
         piv = bad ? EHM2_PIVOT_BIG : piv;
@@ -548,14 +584,14 @@ __device__ __forceinline__ void lu_factor(double (&row)[NP], const Wave& W, int 
         if (lane == 0) W.db[k] = rinv;
         const double l = row[k] * rinv;
         row[k] = l;
-        // pivot row: uniform 16-byte reads (rows of W.M start 16-byte aligned)
+        // pivot row: uniform 16-byte reads (packed rows start 16-byte aligned)
         if (((k + 1) & 1) && k + 1 < NP) {
-            const double ukq = W.M[k * LDM + k + 1];
+            const double ukq = U[uoff(k) + k + 1];
             row[k + 1] = fma(-l, ukq, row[k + 1]);
         }
 #pragma unroll
         for (int q = (k + 2) & ~1; q < NP; q += 2) {
-            const double2v u = *reinterpret_cast<const double2v*>(W.M + k * LDM + q);
+            const double2v u = *reinterpret_cast<const double2v*>(U + uoff(k) + q);
             row[q] = fma(-l, u.x, row[q]);
             row[q + 1] = fma(-l, u.y, row[q + 1]);
         }
@@ -583,7 +619,7 @@ __device__ __forceinline__ double lu_solve(const double (&row)[NP], const Wave& 
     wsync();
     const int jl = (lane < NP) ? lane : (NP - 1);
     bv = W.ub[jl];
-    const double* urow = W.M + jl * LDM;
+    const double* urow = W.M + uoff(jl);
 #pragma unroll
     for (int k = NP - 1; k >= 0; --k) {
         const double xk = readlane_d(bv * rinv, k);
@@ -600,7 +636,7 @@ __device__ __forceinline__ double lu_solve(const double (&row)[NP], const Wave& 
 // On exit: W.xb holds the best primal iterate.
 // ---------------------------------------------------------------------------------------
 __device__ inline IpmResult ipm_solve(const Shared& S, const Wave& W, const double (&b)[SLOTS],
-                                      int lane0, bool sign_only = false) {
+                                      int lane0, bool sign_only, double step_frac) {
     int lane = lane0;
     const int n = W.n_lp;
     const int m_lp = S.m + W.ne;
@@ -777,8 +813,8 @@ __device__ inline IpmResult ipm_solve(const Shared& S, const Wave& W, const doub
         }
         rho_p = wave_max(rho_p);
         rho_d = wave_max(rho_d);
-        ap = (rho_p > EHM2_STEP_FRAC) ? EHM2_STEP_FRAC / rho_p : 1.0;
-        ad = (rho_d > EHM2_STEP_FRAC) ? EHM2_STEP_FRAC / rho_d : 1.0;
+        ap = (rho_p > step_frac) ? step_frac / rho_p : 1.0;
+        ad = (rho_d > step_frac) ? step_frac / rho_d : 1.0;
         if (lane < n) W.x[lane] = fma(ap, dxj, W.x[lane]);
 #pragma unroll
         for (int sl = 0; sl < SLOTS; ++sl) {
@@ -793,6 +829,22 @@ __device__ inline IpmResult ipm_solve(const Shared& S, const Wave& W, const doub
     if (res.status != 0 && res.merit <= EHM2_ACCEPT_MERIT) res.status = 0;
     res.margin = fabs(res.obj);
     return res;
+}
+
+// One solve with the aggressive step fraction, repeated once with the conservative one if it
+// stalls (one call site: the solver body is instantiated once per kernel).
+__device__ inline IpmResult ipm_solve_retry(const Shared& S, const Wave& W,
+                                            const double (&b)[SLOTS], int lane,
+                                            bool sign_only = false) {
+    IpmResult r;
+    int total = 0;
+    for (int attempt = 0; attempt < 2; ++attempt) {
+        r = ipm_solve(S, W, b, lane, sign_only, attempt ? EHM2_STEP_FRAC_SAFE : EHM2_STEP_FRAC);
+        total += r.iters;
+        if (r.status == 0) break;
+    }
+    r.iters = total;
+    return r;
 }
 
 }  // namespace EHM2_NS

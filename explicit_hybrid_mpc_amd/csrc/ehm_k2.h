@@ -6,9 +6,10 @@
 
 #include "ehm_dev.h"
 
-// wavefronts per workgroup are chosen at launch (<= EHM_K2_THREADS / 64)
+// wavefronts per workgroup are chosen at launch (<= EHM_K2_THREADS / 64); the launch bound
+// also caps the registers: 768 threads = 3 wavefronts per SIMD = 168 VGPRs
 #ifndef EHM_K2_THREADS
-#define EHM_K2_THREADS 512
+#define EHM_K2_THREADS 768
 #endif
 
 namespace ehm {

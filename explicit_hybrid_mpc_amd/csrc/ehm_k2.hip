@@ -257,7 +257,7 @@ __global__ __launch_bounds__(EHM_K2_THREADS) void k2_point_batch(
             Wave W;
             double b[SLOTS];
             assemble_point(S, W, nb.lp, nb.th, feas != 0, b, lane);
-            const IpmResult r = ipm_solve(S, W, b, lane);
+            const IpmResult r = ipm_solve_retry(S, W, b, lane);
             count_solve(cnt, r, lane);
             if (lane == 0) {
                 J[inst] = r.obj;
@@ -304,7 +304,7 @@ __global__ __launch_bounds__(EHM_K2_THREADS) void k2_simplex_batch(
             Wave W;
             double b[SLOTS];
             assemble_simplex(S, W, nb, Rl, Vl, mode, P.eps_a, P.eps_r, b, lane);
-            const IpmResult r = ipm_solve(S, W, b, lane);
+            const IpmResult r = ipm_solve_retry(S, W, b, lane);
             count_solve(cnt, r, lane);
             if (lane == 0) {
                 obj[inst] = (mode == SX_SLACK) ? -r.obj : r.obj;     // t* = -(min -t)
@@ -351,7 +351,7 @@ __global__ __launch_bounds__(EHM_K2_THREADS) void k2_lcss_decide(
         double b[SLOTS];
         assemble_simplex(S, W, nb, nb.rec, nb.rec + rec_off_vcost(P.p), SX_SLACK, P.eps_a,
                          P.eps_r, b, lane);
-        const IpmResult r = ipm_solve(S, W, b, lane, sign_only != 0);
+        const IpmResult r = ipm_solve_retry(S, W, b, lane, sign_only != 0);
         count_solve(cnt, r, lane);
         if (lane == 0) {
             if (r.status != 0) {
@@ -407,7 +407,7 @@ __global__ __launch_bounds__(EHM_K2_THREADS) void k2_lcss_expand(
         Wave W;
         double b[SLOTS];
         assemble_point(S, W, nb.lp, mid, false, b, lane);
-        const IpmResult r = ipm_solve(S, W, b, lane);
+        const IpmResult r = ipm_solve_retry(S, W, b, lane);
         count_solve(cnt, r, lane);
         if (r.status != 0 && lane == 0) {
             atomicAdd(&cnt->errors, 1ULL);
@@ -481,7 +481,7 @@ __global__ __launch_bounds__(EHM_K2_THREADS) void k2_vertex_solve(
         Wave W;
         double b[SLOTS];
         assemble_point(S, W, nb.lp, nb.th, false, b, lane);
-        const IpmResult r = ipm_solve(S, W, b, lane);
+        const IpmResult r = ipm_solve_retry(S, W, b, lane);
         count_solve(cnt, r, lane);
         if (r.status != 0 && lane == 0) atomicAdd(&cnt->errors, 1ULL);
         if (lane == 0) rec[rec_off_vcost(p) + v] = r.obj;

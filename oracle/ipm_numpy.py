@@ -119,13 +119,25 @@ def chol_solve(L, rhs):
     return y
 
 
-def solve_lp(c, A, b, max_iter=40, tol_res=1e-10, tol_gap=1e-10, step_frac=0.99,
+STEP_FRAC = 0.999       # generation-2 kernels (ehm_ipm2.h); generation 1 uses STEP_FRAC_SAFE
+STEP_FRAC_SAFE = 0.99   # a solve that stalls with STEP_FRAC is repeated with this one
+
+
+def solve_lp(c, A, b, max_iter=40, tol_res=1e-10, tol_gap=1e-10, step_frac=None,
              prox=PROX_REL):
     """
     min c^T x  s.t.  A x <= b.
     status: 0 optimal (all three relative criteria met), 1 stalled / iteration limit
     (best iterate returned, its merit in ``.merit``).
+    step_frac=None: STEP_FRAC first, STEP_FRAC_SAFE if that stalls (ipm_solve_retry).
     """
+    if step_frac is None:
+        out = solve_lp(c, A, b, max_iter, tol_res, tol_gap, STEP_FRAC, prox)
+        if out.status != 0:
+            it = out.iters
+            out = solve_lp(c, A, b, max_iter, tol_res, tol_gap, STEP_FRAC_SAFE, prox)
+            out.iters += it
+        return out
     m, n = A.shape
     x = np.zeros(n)
     s = np.maximum(b - A @ x, 1.)
