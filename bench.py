@@ -93,7 +93,7 @@ def main():
     ap.add_argument('--steps', type=int, default=3)
     ap.add_argument('--warmup', type=int, default=1)
     ap.add_argument('--seed', type=int, default=0)
-    ap.add_argument('--abs-frac', type=float, default=0.03)
+    ap.add_argument('--abs-frac', type=float, default=0.02)
     ap.add_argument('--eps-r', type=float, default=1e-2)
     ap.add_argument('--max-nodes', type=int, default=1 << 22)
     ap.add_argument('--shard-min-frontier', type=int, default=2048)

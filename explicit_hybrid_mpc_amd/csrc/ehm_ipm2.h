@@ -34,7 +34,10 @@
 
 // rows / columns per software-pipelined group in the matrix loops (loads in flight per wait)
 #ifndef EHM2_UNROLL
-#define EHM2_UNROLL 4
+#define EHM2_UNROLL 2
+#endif
+#ifndef EHM2_LU_CHUNK
+#define EHM2_LU_CHUNK 8
 #endif
 #define EHM2_TOL_RES      1e-10
 #define EHM2_TOL_GAP      1e-10
@@ -338,15 +341,22 @@ __device__ __forceinline__ void rows_times(const Shared& S, const Wave& W, const
 
 // Column pointers of the 4-column block cb for the MPC rows (pc) and the extra rows (px);
 // columns beyond n_lp point at the zero column.
-__device__ __forceinline__ void block_cols(const Shared& S, const Wave& W, int cb,
-                                           const double* (&pc)[4], const double* (&px)[4]) {
+__device__ __forceinline__ void block_cols_mpc(const Shared& S, const Wave& W, int cb,
+                                               const double* (&pc)[4]) {
     const double* zero = S.Wc + (size_t)(S.ncw - 1) * S.lda;
 #pragma unroll
     for (int q = 0; q < 4; ++q) {
         const int j = 4 * cb + q;
-        const bool in = j < W.n_lp;
-        pc[q] = in ? (S.Wc + (size_t)wc_col(W, j) * S.lda) : zero;
-        px[q] = (in && W.ne > 0) ? (W.X + (size_t)j * W.ldx) : zero;
+        pc[q] = (j < W.n_lp) ? (S.Wc + (size_t)wc_col(W, j) * S.lda) : zero;
+    }
+}
+__device__ __forceinline__ void block_cols_ext(const Shared& S, const Wave& W, int cb,
+                                               const double* (&px)[4]) {
+    const double* zero = S.Wc + (size_t)(S.ncw - 1) * S.lda;
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+        const int j = 4 * cb + q;
+        px[q] = (j < W.n_lp && W.ne > 0) ? (W.X + (size_t)j * W.ldx) : zero;
     }
 }
 
@@ -363,8 +373,8 @@ __device__ __forceinline__ void cols_times(const Shared& S, const Wave& W, const
     const bool active = h < ks;
     double a0[4] = {0.0, 0.0, 0.0, 0.0}, a1[4] = {0.0, 0.0, 0.0, 0.0};
     if (active) {
-        const double *pc[4], *px[4];
-        block_cols(S, W, cb, pc, px);
+        const double* pc[4];
+        block_cols_mpc(S, W, cb, pc);
         int i = h;
         constexpr int UR = EHM2_UNROLL;
         for (; i + (UR - 1) * ks < S.m; i += UR * ks) {
@@ -394,6 +404,8 @@ __device__ __forceinline__ void cols_times(const Shared& S, const Wave& W, const
                 if (TWO) a1[q] = fma(a, v1, a1[q]);
             }
         }
+        const double* px[4];
+        block_cols_ext(S, W, pin(cb), px);     // derived only now: fewer live registers above
         for (int e = h; e < W.ne; e += ks) {
             const double v0 = u0[W.xbase + e];
             const double v1 = TWO ? u1[W.xbase + e] : 0.0;
@@ -440,8 +452,12 @@ __device__ __forceinline__ void cols_times(const Shared& S, const Wave& W, const
 template <int KS>
 __device__ __forceinline__ void form_blocks(const Shared& S, const Wave& W, const double* dvec,
                                             int lane, int nbA, int TA) {
-    const int task = pin(lane % TA);
-    const int h = pin(lane / TA);
+    // lane = h * TA + task without a division by the run-time TA
+    int hq = 0;
+#pragma unroll
+    for (int u = 1; u <= 4; ++u) hq += (lane >= u * TA) ? 1 : 0;
+    const int task = pin(lane - hq * TA);
+    const int h = pin(hq);
     const bool active = h < KS;
     int bj = 0, rem = task;
     while (rem > bj) { rem -= (bj + 1); ++bj; }
@@ -452,9 +468,9 @@ __device__ __forceinline__ void form_blocks(const Shared& S, const Wave& W, cons
 #pragma unroll
         for (int r = 0; r < 4; ++r) acc[q][r] = 0.0;
     if (active) {
-        const double *cj[4], *xj[4], *ck[4], *xk[4];
-        block_cols(S, W, bj, cj, xj);
-        block_cols(S, W, bk, ck, xk);
+        const double *cj[4], *ck[4];
+        block_cols_mpc(S, W, bj, cj);
+        block_cols_mpc(S, W, bk, ck);
         const int m = S.m;
         int i = h;
 #define EHM2_FORM_ROW(CJ, CK, DV, I)                                                  \
@@ -484,6 +500,9 @@ __device__ __forceinline__ void form_blocks(const Shared& S, const Wave& W, cons
 #endif
         for (; i < m; i += KS) EHM2_FORM_ROW(cj, ck, dvec, i)
         const double* dx = dvec + W.xbase;
+        const double *xj[4], *xk[4];
+        block_cols_ext(S, W, pin(bj), xj);     // derived only now: fewer live registers above
+        block_cols_ext(S, W, pin(bk), xk);
         for (int e = h; e < W.ne; e += KS) EHM2_FORM_ROW(xj, xk, dx, e)
 #undef EHM2_FORM_ROW
     }
@@ -542,9 +561,10 @@ __device__ inline void form_normal_matrix(const Shared& S, const Wave& W, const 
     if (c0 < NP) {
         const int nrest = NP - c0;
         for (int k = lane; k < nrest * LDM; k += 64) W.M[c0 * LDM + k] = 0.0;
-        for (int k = lane; k < c0 * nrest; k += 64) {
-            const int r = k / nrest, c = k - r * nrest;
-            W.M[r * LDM + c0 + c] = 0.0;
+        {   // nrest <= 7 (the smallest instance that holds n_lp columns is picked)
+            const int c = lane & 7;
+            if (c < nrest)
+                for (int r = lane >> 3; r < c0; r += 8) W.M[r * LDM + c0 + c] = 0.0;
         }
         wsync();
         if (W.n_mpc < W.n_lp && lane < W.n_lp) {      // at most one such column
@@ -594,6 +614,9 @@ __device__ __forceinline__ void lu_factor(double (&row)[NP], const Wave& W, int 
             const double2v u = *reinterpret_cast<const double2v*>(U + uoff(k) + q);
             row[q] = fma(-l, u.x, row[q]);
             row[q + 1] = fma(-l, u.y, row[q + 1]);
+            // at most EHM2_LU_CHUNK broadcast values in flight (register budget)
+            if (((q - ((k + 2) & ~1)) / 2) % (EHM2_LU_CHUNK / 2) == EHM2_LU_CHUNK / 2 - 1)
+                __builtin_amdgcn_sched_barrier(0);
         }
         // the trailing update of step k stays in step k: left alone, the compiler sinks each
         // FMA chain to where row[q] is next read (step q) and keeps n^2/2 broadcast values alive
@@ -642,15 +665,16 @@ __device__ inline IpmResult ipm_solve(const Shared& S, const Wave& W, const doub
     const int m_lp = S.m + W.ne;
     RowMap rm;
     make_rowmap(rm, S, W, lane);
-    double s[SLOTS], lam[SLOTS];
-    int ridx[SLOTS];
+    // v = b - A x is carried instead of b (v <- v - alpha_p A dx): one matrix-vector product
+    // per iteration less, and b need not stay in registers
+    double s[SLOTS], lam[SLOTS], v[SLOTS];
     double bmax = 0.0;
 #pragma unroll
     for (int sl = 0; sl < SLOTS; ++sl) {
-        ridx[sl] = lane + 64 * sl;
-        s[sl] = rm.valid[sl] ? fmax(b[sl], 1.0) : 1.0;     // x0 = 0  =>  b - A x0 = b
+        v[sl] = rm.valid[sl] ? b[sl] : 0.0;                // x0 = 0  =>  b - A x0 = b
+        s[sl] = rm.valid[sl] ? fmax(b[sl], 1.0) : 1.0;
         lam[sl] = rm.valid[sl] ? 1.0 : 0.0;
-        bmax = fmax(bmax, rm.valid[sl] ? fabs(b[sl]) : 0.0);
+        bmax = fmax(bmax, fabs(v[sl]));
     }
     const double bnorm = 1.0 + wave_max(bmax);
     const double cj = (lane < n) ? W.c[lane] : 0.0;
@@ -663,8 +687,8 @@ __device__ inline IpmResult ipm_solve(const Shared& S, const Wave& W, const doub
 #pragma unroll
     for (int sl = 0; sl < SLOTS; ++sl) {
         if (!rm.valid[sl]) {
-            W.vm0[ridx[sl]] = 0.0;
-            W.vm1[ridx[sl]] = 0.0;
+            W.vm0[lane + 64 * sl] = 0.0;
+            W.vm1[lane + 64 * sl] = 0.0;
         }
     }
     wsync();
@@ -680,23 +704,21 @@ __device__ inline IpmResult ipm_solve(const Shared& S, const Wave& W, const doub
     for (int it = 0; it <= EHM2_MAX_ITER; ++it) {
         lane = pin(lane0);      // per-lane addresses are re-derived every iteration (see pin)
         // ---- residuals -----------------------------------------------------------------
-        double r_p[SLOTS], rs[SLOTS], dd[SLOTS];
-        rows_times(S, W, rm, W.x, r_p);
-        double rpmax = 0.0, sl_sum = 0.0, bl_sum = 0.0;
+        double r_p[SLOTS], rs[SLOTS];
+        double rpmax = 0.0, sl_sum = 0.0, vl_sum = 0.0;
 #pragma unroll
         for (int sl = 0; sl < SLOTS; ++sl) {
-            r_p[sl] = rm.valid[sl] ? (r_p[sl] + s[sl] - b[sl]) : 0.0;
+            r_p[sl] = rm.valid[sl] ? (s[sl] - v[sl]) : 0.0;       // A x + s - b
             rpmax = fmax(rpmax, fabs(r_p[sl]));
             sl_sum = fma(s[sl], lam[sl], sl_sum);
-            bl_sum = fma(b[sl], lam[sl], bl_sum);
+            vl_sum = fma(v[sl], lam[sl], vl_sum);
             rs[sl] = frcp(s[sl]);
-            dd[sl] = lam[sl] * rs[sl];
         }
 #pragma unroll
         for (int sl = 0; sl < SLOTS; ++sl) {
             if (rm.valid[sl]) {
-                W.vm0[ridx[sl]] = lam[sl];
-                W.vm1[ridx[sl]] = dd[sl] * r_p[sl];
+                W.vm0[lane + 64 * sl] = lam[sl];
+                W.vm1[lane + 64 * sl] = lam[sl] * rs[sl] * r_p[sl];
             }
         }
         wsync();
@@ -707,7 +729,8 @@ __device__ inline IpmResult ipm_solve(const Shared& S, const Wave& W, const doub
         const double r_d = (lane < n) ? (atl + cjj) : 0.0;
         const double emax = wave_max(fmax(rpmax / bnorm, fabs(r_d) / cnorm));
         const double mu = wave_sum(sl_sum) * inv_m;
-        const double dobj = -wave_sum(bl_sum);
+        // b^T lam = v^T lam + x^T (A^T lam)
+        const double dobj = -wave_sum(vl_sum + xjj * atl);
         const double pobj = wave_sum(cjj * xjj);
         const double e_g = fabs(pobj - dobj) / (1.0 + fabs(pobj));
         const double merit = fmax(emax / EHM2_TOL_RES, e_g / EHM2_TOL_GAP);
@@ -740,11 +763,13 @@ __device__ inline IpmResult ipm_solve(const Shared& S, const Wave& W, const doub
         if (stall >= 3 || it == EHM2_MAX_ITER || !(merit == merit)) break;
 
         // ---- normal matrix and its factorisation ----------------------------------------
+        lane = pin(lane0);      // fresh per phase: addresses derived above die here
 #pragma unroll
         for (int sl = 0; sl < SLOTS; ++sl)
-            if (rm.valid[sl]) W.vm0[ridx[sl]] = dd[sl];
+            if (rm.valid[sl]) W.vm0[lane + 64 * sl] = lam[sl] * rs[sl];
         wsync();
         form_normal_matrix(S, W, W.vm0, lane);
+        lane = pin(lane0);
         double row[NP];
         {
             // lanes >= NP carry a copy of row NP-1; nothing they compute is ever read
@@ -758,20 +783,20 @@ __device__ inline IpmResult ipm_solve(const Shared& S, const Wave& W, const doub
         const double rinv_l = W.db[(lane < NP) ? lane : (NP - 1)];
 
         // ---- predictor ------------------------------------------------------------------
+        lane = pin(lane0);
         const double rhs_aff = (lane < n) ? (-cjj - atdr) : 0.0;
         double dxj = lu_solve(row, W, rinv_l, rhs_aff, lane);
         double adx[SLOTS];
         rows_times(S, W, rm, W.t, adx);
-        double ds_a[SLOTS], dl_a[SLOTS], rl[SLOTS];
+        double ds_a[SLOTS], dl_a[SLOTS];
         double rho_p = 0.0, rho_d = 0.0;
 #pragma unroll
         for (int sl = 0; sl < SLOTS; ++sl) {
-            rl[sl] = frcp(rm.valid[sl] ? lam[sl] : 1.0);
             ds_a[sl] = rm.valid[sl] ? (-r_p[sl] - adx[sl]) : 0.0;
-            // dl = -(s lam + lam ds)/s = -lam - (lam/s) ds
-            dl_a[sl] = rm.valid[sl] ? (-lam[sl] - dd[sl] * ds_a[sl]) : 0.0;
+            // dl = -(s lam + lam ds)/s = -lam - (lam/s) ds ;  -dl/lam = 1 + ds/s
+            dl_a[sl] = rm.valid[sl] ? (-lam[sl] - lam[sl] * rs[sl] * ds_a[sl]) : 0.0;
             rho_p = fmax(rho_p, -ds_a[sl] * rs[sl]);
-            rho_d = fmax(rho_d, -dl_a[sl] * rl[sl]);
+            rho_d = fmax(rho_d, rm.valid[sl] ? fma(ds_a[sl], rs[sl], 1.0) : 0.0);
         }
         rho_p = wave_max(rho_p);
         rho_d = wave_max(rho_d);
@@ -788,11 +813,11 @@ __device__ inline IpmResult ipm_solve(const Shared& S, const Wave& W, const doub
         const double smu = sigma * mu;
 
         // ---- corrector ------------------------------------------------------------------
-        double corr[SLOTS];
+        lane = pin(lane0);
 #pragma unroll
         for (int sl = 0; sl < SLOTS; ++sl) {
-            corr[sl] = (ds_a[sl] * dl_a[sl] - smu) * rs[sl];   // (ds_a dl_a - sigma mu)/s
-            if (rm.valid[sl]) W.vm1[ridx[sl]] = corr[sl];
+            // (ds_a dl_a - sigma mu)/s : parked in LDS, read back after the corrector solve
+            if (rm.valid[sl]) W.vm1[lane + 64 * sl] = (ds_a[sl] * dl_a[sl] - smu) * rs[sl];
         }
         wsync();
         double atc, dummy;
@@ -805,11 +830,13 @@ __device__ inline IpmResult ipm_solve(const Shared& S, const Wave& W, const doub
         rho_d = 0.0;
 #pragma unroll
         for (int sl = 0; sl < SLOTS; ++sl) {
+            const double corr = rm.valid[sl] ? W.vm1[lane + 64 * sl] : 0.0;
+            const double rl = frcp(rm.valid[sl] ? lam[sl] : 1.0);
             ds[sl] = rm.valid[sl] ? (-r_p[sl] - adx[sl]) : 0.0;
             // dl = -(s lam + corr_num + lam ds)/s = -lam - corr - (lam/s) ds
-            dl[sl] = rm.valid[sl] ? (-lam[sl] - corr[sl] - dd[sl] * ds[sl]) : 0.0;
+            dl[sl] = rm.valid[sl] ? (-lam[sl] - corr - lam[sl] * rs[sl] * ds[sl]) : 0.0;
             rho_p = fmax(rho_p, -ds[sl] * rs[sl]);
-            rho_d = fmax(rho_d, -dl[sl] * rl[sl]);
+            rho_d = fmax(rho_d, -dl[sl] * rl);
         }
         rho_p = wave_max(rho_p);
         rho_d = wave_max(rho_d);
@@ -821,6 +848,7 @@ __device__ inline IpmResult ipm_solve(const Shared& S, const Wave& W, const doub
             if (rm.valid[sl]) {
                 s[sl] = fma(ap, ds[sl], s[sl]);
                 lam[sl] = fma(ad, dl[sl], lam[sl]);
+                v[sl] = fma(-ap, adx[sl], v[sl]);
             }
         }
         wsync();
@@ -829,22 +857,6 @@ __device__ inline IpmResult ipm_solve(const Shared& S, const Wave& W, const doub
     if (res.status != 0 && res.merit <= EHM2_ACCEPT_MERIT) res.status = 0;
     res.margin = fabs(res.obj);
     return res;
-}
-
-// One solve with the aggressive step fraction, repeated once with the conservative one if it
-// stalls (one call site: the solver body is instantiated once per kernel).
-__device__ inline IpmResult ipm_solve_retry(const Shared& S, const Wave& W,
-                                            const double (&b)[SLOTS], int lane,
-                                            bool sign_only = false) {
-    IpmResult r;
-    int total = 0;
-    for (int attempt = 0; attempt < 2; ++attempt) {
-        r = ipm_solve(S, W, b, lane, sign_only, attempt ? EHM2_STEP_FRAC_SAFE : EHM2_STEP_FRAC);
-        total += r.iters;
-        if (r.status == 0) break;
-    }
-    r.iters = total;
-    return r;
 }
 
 }  // namespace EHM2_NS

@@ -33,11 +33,16 @@ __device__ __forceinline__ void carve_node(NodeBuf& nb, double* base, int p, int
 }
 
 // F = E^-1 with E[r][q] = R[q+1][r] - R[0][r]  (beta = F psi, psi = theta - R0)
+// Gauss-Jordan with partial pivoting on the p x 2p tableau; lanes = (row lane>>4 [+4], column
+// lane&15): no division by run-time sizes anywhere (p <= 8).
 __device__ inline void simplex_inverse(const double* R, int p, double* aug, double* F, int lane) {
     const int w = 2 * p;
-    for (int k = lane; k < p * w; k += 64) {
-        const int r = k / w, c = k - r * w;
-        aug[k] = (c < p) ? (R[(c + 1) * p + r] - R[r]) : ((c - p == r) ? 1.0 : 0.0);
+    const int c = lane & 15, r0 = lane >> 4;
+#pragma unroll
+    for (int u = 0; u < 2; ++u) {
+        const int r = r0 + 4 * u;
+        if (r < p && c < w)
+            aug[r * w + c] = (c < p) ? (R[(c + 1) * p + r] - R[r]) : ((c - p == r) ? 1.0 : 0.0);
     }
     wsync();
     for (int k = 0; k < p; ++k) {
@@ -65,29 +70,25 @@ __device__ inline void simplex_inverse(const double* R, int p, double* aug, doub
         double fac[2], rk[2], cur[2];
 #pragma unroll
         for (int u = 0; u < 2; ++u) {
-            const int idx = lane + 64 * u;
+            const int r = r0 + 4 * u;
             fac[u] = rk[u] = cur[u] = 0.0;
-            if (idx < p * w) {
-                const int r = idx / w, c = idx - r * w;
+            if (r < p && c < w) {
                 fac[u] = aug[r * w + k];
                 rk[u] = aug[k * w + c] * rp;
-                cur[u] = aug[idx];
+                cur[u] = aug[r * w + c];
             }
         }
         wsync();
 #pragma unroll
         for (int u = 0; u < 2; ++u) {
-            const int idx = lane + 64 * u;
-            if (idx < p * w) {
-                const int r = idx / w;
-                aug[idx] = (r == k) ? rk[u] : fma(-fac[u], rk[u], cur[u]);
-            }
+            const int r = r0 + 4 * u;
+            if (r < p && c < w) aug[r * w + c] = (r == k) ? rk[u] : fma(-fac[u], rk[u], cur[u]);
         }
         wsync();
     }
-    for (int k = lane; k < p * p; k += 64) {
-        const int q = k / p, r = k - q * p;
-        F[k] = aug[q * w + p + r];
+    {
+        const int q = lane >> 3, r = lane & 7;
+        if (q < p && r < p) F[q * p + r] = aug[q * w + p + r];
     }
     wsync();
 }
@@ -148,9 +149,9 @@ __device__ inline void assemble_simplex(const Shared& S, Wave& W, const NodeBuf&
     if (lane < NP) W.c[lane] = 0.0;
     wsync();
     // facets  -beta_e <= 0
-    for (int k = lane; k < p * p; k += 64) {
-        const int e = k / p, r = k - e * p;
-        W.X[(n + r) * ldx + e] = -F[e * p + r];
+    {
+        const int e = lane >> 3, r = lane & 7;
+        if (e < p && r < p) W.X[(n + r) * ldx + e] = -F[e * p + r];
     }
     if (lane < p) {
         double sF = 0.0, dvF = 0.0;
@@ -168,7 +169,7 @@ __device__ inline void assemble_simplex(const Shared& S, Wave& W, const NodeBuf&
         if (lane < n) {
             const double cj = S.cv[lane];
             W.X[lane * ldx + p + 1] = cj;
-            W.X[lane * ldx + p + 2] = (1.0 + eps_r) * cj;
+            W.X[lane * ldx + p + 2] = fma(eps_r, cj, cj);     // (1 + eps_r) c_j
         }
         if (lane == 0) {
             W.X[(n + p) * ldx + p + 1] = 1.0;
@@ -223,7 +224,7 @@ __device__ __forceinline__ int pull(int* ctr, int lane) {
     __shared__ int s_ctr;                                                        \
     const int tid = threadIdx.x;                                                 \
     const int lane0 = tid & 63;                                                  \
-    const int wave = tid >> 6;                                                   \
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);   /* uniform: SGPR pointers */ \
     Shared S;                                                                    \
     carve_shared(S, sm, P);                                                      \
     NodeBuf nb;                                                                  \
@@ -255,9 +256,18 @@ __global__ __launch_bounds__(EHM_K2_THREADS) void k2_point_batch(
             if (lane < P.p) nb.th[lane] = theta[inst * P.p + lane];
             wsync();
             Wave W;
-            double b[SLOTS];
-            assemble_point(S, W, nb.lp, nb.th, feas != 0, b, lane);
-            const IpmResult r = ipm_solve_retry(S, W, b, lane);
+            IpmResult r;
+            int its = 0;
+            for (int attempt = 0; attempt < 2; ++attempt) {     // see EHM2_STEP_FRAC
+                double b[SLOTS];
+                const int ln = pin(lane);     // nothing of the assembly outlives the attempt
+                assemble_point(S, W, nb.lp, nb.th, feas != 0, b, ln);
+                r = ipm_solve(S, W, b, ln, false,
+                              attempt ? EHM2_STEP_FRAC_SAFE : EHM2_STEP_FRAC);
+                its += r.iters;
+                if (r.status == 0) break;
+            }
+            r.iters = its;
             count_solve(cnt, r, lane);
             if (lane == 0) {
                 J[inst] = r.obj;
@@ -302,9 +312,18 @@ __global__ __launch_bounds__(EHM_K2_THREADS) void k2_simplex_batch(
             if (mode == SX_SLACK && lane <= p) Vl[lane] = Vbar[inst * (p + 1) + lane];
             wsync();
             Wave W;
-            double b[SLOTS];
-            assemble_simplex(S, W, nb, Rl, Vl, mode, P.eps_a, P.eps_r, b, lane);
-            const IpmResult r = ipm_solve_retry(S, W, b, lane);
+            IpmResult r;
+            int its = 0;
+            for (int attempt = 0; attempt < 2; ++attempt) {
+                double b[SLOTS];
+                const int ln = pin(lane);
+                assemble_simplex(S, W, nb, Rl, Vl, mode, P.eps_a, P.eps_r, b, ln);
+                r = ipm_solve(S, W, b, ln, false,
+                              attempt ? EHM2_STEP_FRAC_SAFE : EHM2_STEP_FRAC);
+                its += r.iters;
+                if (r.status == 0) break;
+            }
+            r.iters = its;
             count_solve(cnt, r, lane);
             if (lane == 0) {
                 obj[inst] = (mode == SX_SLACK) ? -r.obj : r.obj;     // t* = -(min -t)
@@ -348,10 +367,19 @@ __global__ __launch_bounds__(EHM_K2_THREADS) void k2_lcss_decide(
         for (int k = lane; k < nrec; k += 64) nb.rec[k] = rec[k];
         wsync();
         Wave W;
-        double b[SLOTS];
-        assemble_simplex(S, W, nb, nb.rec, nb.rec + rec_off_vcost(P.p), SX_SLACK, P.eps_a,
-                         P.eps_r, b, lane);
-        const IpmResult r = ipm_solve_retry(S, W, b, lane, sign_only != 0);
+        IpmResult r;
+        int its = 0;
+        for (int attempt = 0; attempt < 2; ++attempt) {
+            double b[SLOTS];
+            const int ln = pin(lane);
+            assemble_simplex(S, W, nb, nb.rec, nb.rec + rec_off_vcost(P.p), SX_SLACK, P.eps_a,
+                             P.eps_r, b, ln);
+            r = ipm_solve(S, W, b, ln, sign_only != 0,
+                          attempt ? EHM2_STEP_FRAC_SAFE : EHM2_STEP_FRAC);
+            its += r.iters;
+            if (r.status == 0) break;
+        }
+        r.iters = its;
         count_solve(cnt, r, lane);
         if (lane == 0) {
             if (r.status != 0) {
@@ -405,9 +433,17 @@ __global__ __launch_bounds__(EHM_K2_THREADS) void k2_lcss_expand(
         wsync();
         const int d = T.didx[id];
         Wave W;
-        double b[SLOTS];
-        assemble_point(S, W, nb.lp, mid, false, b, lane);
-        const IpmResult r = ipm_solve_retry(S, W, b, lane);
+        IpmResult r;
+        int its = 0;
+        for (int attempt = 0; attempt < 2; ++attempt) {
+            double b[SLOTS];
+            const int ln = pin(lane);
+            assemble_point(S, W, nb.lp, mid, false, b, ln);
+            r = ipm_solve(S, W, b, ln, false, attempt ? EHM2_STEP_FRAC_SAFE : EHM2_STEP_FRAC);
+            its += r.iters;
+            if (r.status == 0) break;
+        }
+        r.iters = its;
         count_solve(cnt, r, lane);
         if (r.status != 0 && lane == 0) {
             atomicAdd(&cnt->errors, 1ULL);
@@ -419,18 +455,17 @@ __global__ __launch_bounds__(EHM_K2_THREADS) void k2_lcss_expand(
         const int ov = rec_off_vcost(p), ou = rec_off_vinput(p);
         for (int k = lane; k < nrec; k += 64) {
             double v0 = node[k], v1 = node[k];
+            // row bi / bj of each block is replaced (range tests instead of k / p)
             if (k < ov) {                       // vertices
-                const int row = k / p, col = k - row * p;
-                if (row == bi) v0 = mid[col];
-                if (row == bj) v1 = mid[col];
+                if (k >= bi * p && k < bi * p + p) v0 = mid[k - bi * p];
+                if (k >= bj * p && k < bj * p + p) v1 = mid[k - bj * p];
             } else if (k < ou) {                // vertex costs
-                const int row = k - ov;
-                if (row == bi) v0 = r.obj;
-                if (row == bj) v1 = r.obj;
+                if (k - ov == bi) v0 = r.obj;
+                if (k - ov == bj) v1 = r.obj;
             } else {                            // vertex inputs
-                const int row = (k - ou) / n_u, col = (k - ou) - row * n_u;
-                if (row == bi) v0 = W.xb[col];
-                if (row == bj) v1 = W.xb[col];
+                const int q = k - ou;
+                if (q >= bi * n_u && q < bi * n_u + n_u) v0 = W.xb[q - bi * n_u];
+                if (q >= bj * n_u && q < bj * n_u + n_u) v1 = W.xb[q - bj * n_u];
             }
             rec0[k] = v0;
             rec1[k] = v1;
@@ -479,9 +514,17 @@ __global__ __launch_bounds__(EHM_K2_THREADS) void k2_vertex_solve(
         if (lane < p) nb.th[lane] = rec[v * p + lane];
         wsync();
         Wave W;
-        double b[SLOTS];
-        assemble_point(S, W, nb.lp, nb.th, false, b, lane);
-        const IpmResult r = ipm_solve_retry(S, W, b, lane);
+        IpmResult r;
+        int its = 0;
+        for (int attempt = 0; attempt < 2; ++attempt) {
+            double b[SLOTS];
+            const int ln = pin(lane);
+            assemble_point(S, W, nb.lp, nb.th, false, b, ln);
+            r = ipm_solve(S, W, b, ln, false, attempt ? EHM2_STEP_FRAC_SAFE : EHM2_STEP_FRAC);
+            its += r.iters;
+            if (r.status == 0) break;
+        }
+        r.iters = its;
         count_solve(cnt, r, lane);
         if (r.status != 0 && lane == 0) atomicAdd(&cnt->errors, 1ULL);
         if (lane == 0) rec[rec_off_vcost(p) + v] = r.obj;
