@@ -13,8 +13,9 @@ everything else (all frontier sweeps, LP solves, child construction).
 
 prints ONE JSON line on rank 0.  For N > 1 it is launched by torch.distributed.run with
 one rank per GPU; the live frontier is dealt round-robin over the ranks once it is wide
-enough (no data-path collective: subtrees are independent), so the total work is fixed
-("strong" scaling) and `value` is the whole-job LP-solve rate.
+enough, and every few sweeps the ranks all-gather their frontier sizes and move node records
+from the longest frontiers to the shortest (explicit_hybrid_mpc_amd/distributed.py); the total
+work is fixed ("strong" scaling) and `value` is the whole-job LP-solve rate.
 """
 
 import argparse
@@ -96,7 +97,9 @@ def main():
     ap.add_argument('--abs-frac', type=float, default=0.02)
     ap.add_argument('--eps-r', type=float, default=1e-2)
     ap.add_argument('--max-nodes', type=int, default=1 << 22)
-    ap.add_argument('--shard-min-frontier', type=int, default=2048)
+    ap.add_argument('--shard-min-frontier', type=int, default=1024)
+    ap.add_argument('--sweeps-per-round', type=int, default=2,
+                    help='frontier sweeps between two rebalancing rounds (N > 1)')
     ap.add_argument('--cpu-seconds', type=float, default=15.)
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--solver', type=int, default=2, help='kernel generation (1 or 2)')
@@ -134,9 +137,19 @@ def main():
     roots, _ = ehm_tools.delaunay_roots(V)
     shard = distributed.shard_spec(rank, world, args.shard_min_frontier)
 
+    xdev = ('cuda:%d' % device_index) if backend == 'nccl' else None
+
     def step():
-        return gp.partition(roots, action='ecc', max_nodes=args.max_nodes, export=False,
-                            shard=shard, with_volume=False)
+        if world == 1:
+            return gp.partition(roots, action='ecc', max_nodes=args.max_nodes, export=False,
+                                shard=shard, with_volume=False)
+        info, log, rounds = distributed.run_balanced(
+            gp, roots, action='ecc', max_nodes=args.max_nodes,
+            min_frontier=args.shard_min_frontier, sweeps_per_round=args.sweeps_per_round,
+            device=xdev, export=False)
+        info['rounds'] = rounds
+        info['moved'] = sum(len(e['ids']) for e in log if e['kind'] == 'give')
+        return info
 
     def barrier():
         if world > 1:
@@ -161,7 +174,9 @@ def main():
             i['n_nodes'] -= i['replicated_nodes']
     local = [float(sum(i[k] for i in infos)) for k in keys] + \
         [elapsed, sum(i['decide_seconds'] for i in infos),
-         sum(i['expand_seconds'] for i in infos)]
+         sum(i['expand_seconds'] for i in infos),
+         float(sum(i.get('moved', 0) for i in infos)),
+         float(sum(i.get('rounds', 0) for i in infos))]
     red_dev = ('cuda:%d' % device_index) if backend == 'nccl' else 'cpu'
     tot, mx = distributed.allreduce_counters(local, device=red_dev)
     per_rank = distributed.allgather_counts([int(local[0])], device=red_dev)[:, 0]
@@ -209,7 +224,12 @@ def main():
                 'kernels': 'generation %d' % args.solver,
                 'suboptimality_test': 'full accuracy' if args.decide_full else
                                       'sign-only stop (lower bound of |t*| recorded)',
-                'parallelism': 'frontier dealt round-robin over %d GPU(s)' % world,
+                'parallelism': 'frontier dealt round-robin over %d GPU(s)' % world +
+                               ('' if world == 1 else
+                                ', rebalanced every %d sweeps (all-gather of frontier sizes + '
+                                'point-to-point node records)' % args.sweeps_per_round),
+                'rebalance_rounds_per_step': float(mx[len(keys) + 4]) / K,
+                'nodes_moved_per_step': float(tot[len(keys) + 3]) / K,
                 'lp_solves_per_rank': [int(v) for v in per_rank],
                 'load_imbalance_max_over_mean': distributed.imbalance(per_rank),
             },

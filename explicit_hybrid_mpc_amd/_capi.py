@@ -30,7 +30,8 @@ EXPORTED = [
     'ehm_bar_d_batch', 'ehm_split_batch', 'ehm_volume_batch', 'ehm_partition_run',
     'ehm_tree_info_get', 'ehm_tree_export', 'ehm_tree_destroy', 'ehm_stats',
     'ehm_last_error', 'ehm_version', 'ehm_problem_set_solver', 'ehm_selftest',
-    'ehm_problem_set_option',
+    'ehm_problem_set_option', 'ehm_partition_begin', 'ehm_partition_step',
+    'ehm_partition_take', 'ehm_partition_give', 'ehm_partition_finish',
 ]
 
 
@@ -125,6 +126,11 @@ def load(build_if_missing=True):
     lib.ehm_volume_batch.argtypes = [i32, i64, i32, vp, vp]
     lib.ehm_partition_run.argtypes = [vp, i64, vp, ctypes.POINTER(NodeInit),
                                       ctypes.POINTER(RunOpts), ctypes.POINTER(vp)]
+    lib.ehm_partition_begin.argtypes = lib.ehm_partition_run.argtypes
+    lib.ehm_partition_step.argtypes = [vp, i32, vp]
+    lib.ehm_partition_take.argtypes = [vp, i64, vp, vp, vp]
+    lib.ehm_partition_give.argtypes = [vp, i64, vp, vp, vp]
+    lib.ehm_partition_finish.argtypes = [vp]
     lib.ehm_tree_info_get.argtypes = [vp, ctypes.POINTER(TreeInfo)]
     lib.ehm_tree_export.argtypes = [vp, vp, vp, vp, vp, vp, vp, vp, vp]
     lib.ehm_tree_destroy.argtypes = [vp]

@@ -448,6 +448,20 @@ struct ehm_tree {
     DevBuf rec, left, didx, depth, flags, tstar;
     ehm_tree_info info{};
     int skip_volume = 0;
+    // state of a run in progress (ehm_partition_begin .. ehm_partition_finish)
+    struct Run {
+        bool active = false;
+        int max_depth = 0, action = 0, shard_world = 1, shard_rank = 0;
+        long long shard_min = 0;
+        bool sharded = true, cur_is_a = true;
+        long long n_roots = 0, n_nodes = 0, nf = 0, n_closed = 0, ref_solves = 0;
+        long long pre_closed = 0, pre_nodes = 0, pre_solves = 0, given = 0, received = 0;
+        int sweeps = 0, depth = 0, truncated = 0;
+        DevCounters c0{};
+        hipEvent_t ev0 = nullptr;
+        std::vector<hipEvent_t> evs;    // (start, stop) pairs
+        std::vector<int> ev_kind;       // 0 decide, 1 expand, per pair
+    } run;
 };
 
 static int map_deltas(ehm_problem* P, int64_t n_inst, const uint8_t* delta,
@@ -1345,6 +1359,10 @@ int ehm_volume_batch(int device, int64_t n, int32_t p, const double* R, double* 
 int ehm_tree_destroy(ehm_tree* T) {
     if (!T) return EHM_OK;
     if (T->prob) (void)hipSetDevice(T->prob->device);
+    for (hipEvent_t e : T->run.evs) (void)hipEventDestroy(e);
+    T->run.evs.clear();
+    if (T->run.ev0) (void)hipEventDestroy(T->run.ev0);
+    T->run.ev0 = nullptr;
     if (T->prob && T->cap > T->prob->pool_cache.cap) {
         // keep the larger pool for the next run of this problem
         auto& c = T->prob->pool_cache;
@@ -1395,8 +1413,55 @@ static int read_counters(ehm_problem* P, DevCounters& c) {
     return EHM_OK;
 }
 
-int ehm_partition_run(ehm_problem* P, int64_t n_roots, const double* root_vertices,
-                      const ehm_node_init* init, const ehm_run_opts* opts, ehm_tree** out) {
+// ---- resumable engine: begin / step / take / give / finish ---------------------------------
+// ehm_partition_run = begin + step(until the frontier is empty) + finish.  The pieces exist for
+// the multi-GPU driver (explicit_hybrid_mpc_amd/distributed.py): every rank runs a few sweeps,
+// the ranks all-gather their frontier sizes and move node records from the longest frontiers
+// to the shortest.
+
+// gather / scatter of node records for the frontier hand-over
+__global__ void k_take_nodes(DevTree T, const int32_t* __restrict__ ids, int n, int nrec,
+                             double* __restrict__ rec_out, int32_t* __restrict__ meta_out) {
+    const int k = blockIdx.x;
+    if (k >= n) return;
+    const int id = ids[k];
+    const double* r = T.rec + (size_t)id * T.rec_stride;
+    for (int q = threadIdx.x; q < nrec; q += blockDim.x) rec_out[(size_t)k * nrec + q] = r[q];
+    if (threadIdx.x == 0) {
+        meta_out[2 * k] = T.didx[id];
+        meta_out[2 * k + 1] = T.depth[id];
+        T.flags[id] |= 4;                      // subtree now owned by another rank
+    }
+}
+__global__ void k_give_nodes(DevTree T, int first, int n, int nrec,
+                             const double* __restrict__ rec_in,
+                             const int32_t* __restrict__ meta_in, int32_t* __restrict__ frontier,
+                             int frontier_at) {
+    const int k = blockIdx.x;
+    if (k >= n) return;
+    const int id = first + k;
+    double* r = T.rec + (size_t)id * T.rec_stride;
+    for (int q = threadIdx.x; q < nrec; q += blockDim.x) r[q] = rec_in[(size_t)k * nrec + q];
+    if (threadIdx.x == 0) {
+        T.left[id] = -1;
+        T.didx[id] = meta_in[2 * k];
+        T.depth[id] = meta_in[2 * k + 1];
+        T.flags[id] = 2 | 32;                  // has data, received from another rank
+        T.tstar[id] = 0.0;
+        frontier[frontier_at + k] = id;
+    }
+}
+
+static void run_release_events(ehm_tree* T) {
+    for (hipEvent_t e : T->run.evs) (void)hipEventDestroy(e);
+    T->run.evs.clear();
+    T->run.ev_kind.clear();
+    if (T->run.ev0) (void)hipEventDestroy(T->run.ev0);
+    T->run.ev0 = nullptr;
+}
+
+int ehm_partition_begin(ehm_problem* P, int64_t n_roots, const double* root_vertices,
+                        const ehm_node_init* init, const ehm_run_opts* opts, ehm_tree** out) {
     if (!P || !root_vertices || !out || n_roots < 1) return fail(EHM_E_INVALID, "bad argument");
     *out = nullptr;
     if (P->dp.n_delta != 1)
@@ -1407,22 +1472,33 @@ int ehm_partition_run(ehm_problem* P, int64_t n_roots, const double* root_vertic
     const int p = P->dp.p, n_u = P->dp.n_u;
     long long cap = (opts && opts->max_nodes > 0) ? opts->max_nodes : (1LL << 21);
     cap = std::max<long long>(cap, 2 * n_roots);
-    const int max_depth = (opts && opts->max_depth > 0) ? opts->max_depth : 0;
-    const int action = opts ? opts->action : 0;
-    const int shard_world = (opts && opts->shard_world > 1) ? opts->shard_world : 1;
-    const int shard_rank = opts ? opts->shard_rank : 0;
-    const long long shard_min = opts ? opts->shard_min_frontier : 0;
-    if (shard_world > 1 && (shard_rank < 0 || shard_rank >= shard_world))
-        return fail(EHM_E_INVALID, "shard_rank %d out of range for world %d", shard_rank,
-                    shard_world);
-    bool sharded = (shard_world == 1);
     ehm_tree* T = new ehm_tree();
+    auto& R = T->run;
+    R.active = true;
+    R.max_depth = (opts && opts->max_depth > 0) ? opts->max_depth : 0;
+    R.action = opts ? opts->action : 0;
+    R.shard_world = (opts && opts->shard_world > 1) ? opts->shard_world : 1;
+    R.shard_rank = opts ? opts->shard_rank : 0;
+    R.shard_min = opts ? opts->shard_min_frontier : 0;
+    if (R.shard_world > 1 && (R.shard_rank < 0 || R.shard_rank >= R.shard_world)) {
+        delete T;
+        return fail(EHM_E_INVALID, "shard_rank %d out of range for world %d", R.shard_rank,
+                    R.shard_world);
+    }
+    R.sharded = (R.shard_world == 1);
     T->skip_volume = opts ? opts->skip_volume : 0;
     int rc = tree_alloc(T, P, cap);
     if (rc) { ehm_tree_destroy(T); return rc; }
+#define RUN_TRY(expr)                          \
+    do {                                       \
+        int rc_ = (expr);                      \
+        if (rc_) {                             \
+            ehm_tree_destroy(T);               \
+            return rc_;                        \
+        }                                      \
+    } while (0)
     const int stride = T->dt.rec_stride;
     const int nR = (p + 1) * p;
-    // ---- roots -> node pool
     {
         std::vector<double> recs((size_t)n_roots * stride, 0.0);
         std::vector<int32_t> left((size_t)n_roots, -1), didx((size_t)n_roots, 0),
@@ -1432,7 +1508,7 @@ int ehm_partition_run(ehm_problem* P, int64_t n_roots, const double* root_vertic
         for (int64_t k = 0; k < n_roots; ++k) {
             double* r = recs.data() + (size_t)k * stride;
             std::memcpy(r, root_vertices + (size_t)k * nR, nR * sizeof(double));
-            if (action == 1 && init && init->vcost && init->vinput) {
+            if (R.action == 1 && init && init->vcost && init->vinput) {
                 std::memcpy(r + rec_off_vcost(p), init->vcost + (size_t)k * (p + 1),
                             (p + 1) * sizeof(double));
                 std::memcpy(r + rec_off_vinput(p), init->vinput + (size_t)k * (p + 1) * n_u,
@@ -1453,36 +1529,22 @@ int ehm_partition_run(ehm_problem* P, int64_t n_roots, const double* root_vertic
                                P->stream), EHM_E_HIP);
         HIP_TRY(hipStreamSynchronize(P->stream), EHM_E_HIP);
     }
-    // frontier buffers (ping-pong) + open flags + open list + count
-    DevBuf &fr_a = P->fr_a, &fr_b = P->fr_b, &open_flag = P->open_flag,
-           &open_list = P->open_list, &d_count = P->d_count;
-    auto cleanup = [&]() {};     // the frontier scratch stays with the problem handle
-#define RUN_TRY(expr)                          \
-    do {                                       \
-        int rc_ = (expr);                      \
-        if (rc_) {                             \
-            cleanup();                         \
-            ehm_tree_destroy(T);               \
-            return rc_;                        \
-        }                                      \
-    } while (0)
+    // frontier buffers (ping-pong) + open flags + open list + count live in the problem handle
     long long fr_cap = std::max<long long>(n_roots, 1024);
-    RUN_TRY(fr_a.ensure((size_t)fr_cap * 4));
-    RUN_TRY(fr_b.ensure((size_t)fr_cap * 4));
-    RUN_TRY(open_flag.ensure((size_t)fr_cap * 4));
-    RUN_TRY(open_list.ensure((size_t)fr_cap * 4));
-    RUN_TRY(d_count.ensure(64));
+    RUN_TRY(P->fr_a.ensure((size_t)fr_cap * 4));
+    RUN_TRY(P->fr_b.ensure((size_t)fr_cap * 4));
+    RUN_TRY(P->open_flag.ensure((size_t)fr_cap * 4));
+    RUN_TRY(P->open_list.ensure((size_t)fr_cap * 4));
+    RUN_TRY(P->d_count.ensure(64));
     {
         std::vector<int32_t> ids((size_t)n_roots);
         for (int64_t k = 0; k < n_roots; ++k) ids[(size_t)k] = (int32_t)k;
-        hipError_t e = hipMemcpyAsync(fr_a.ptr, ids.data(), ids.size() * 4,
+        hipError_t e = hipMemcpyAsync(P->fr_a.ptr, ids.data(), ids.size() * 4,
                                       hipMemcpyHostToDevice, P->stream);
         if (e != hipSuccess) RUN_TRY(fail(EHM_E_HIP, "frontier upload failed"));
         (void)hipStreamSynchronize(P->stream);
     }
-    DevCounters c0;
-    RUN_TRY(read_counters(P, c0));
-    // reset the margin tracker for this run
+    RUN_TRY(read_counters(P, R.c0));
     {
         unsigned long long inf_bits = 0x7FF0000000000000ULL;
         (void)hipMemcpyAsync(&P->d_cnt->min_margin_bits, &inf_bits, 8, hipMemcpyHostToDevice,
@@ -1490,82 +1552,94 @@ int ehm_partition_run(ehm_problem* P, int64_t n_roots, const double* root_vertic
         unsigned long long zero = 0;
         (void)hipMemcpyAsync(&P->d_cnt->errors, &zero, 8, hipMemcpyHostToDevice, P->stream);
     }
-    hipEvent_t ev0, ev1;
-    (void)hipEventCreate(&ev0);
-    (void)hipEventCreate(&ev1);
-    (void)hipEventRecord(ev0, P->stream);
-    // ---- 'ecc' for a single-commutation problem: the only commutation is feasible at every
+    (void)hipEventCreate(&R.ev0);
+    (void)hipEventRecord(R.ev0, P->stream);
+    R.n_roots = n_roots;
+    R.n_nodes = n_roots;
+    R.nf = n_roots;
+    R.cur_is_a = true;
+    // 'ecc' for a single-commutation problem: the only commutation is feasible at every
     // vertex of a feasible Theta, so V_R reduces to the vertex solves (lib/worker.py:279-291)
-    long long ref_solves = 0;
-    if (action == 0) {
+    if (R.action == 0) {
         if (P->solver_gen == 2) {
             K2Cfg cfg;
             RUN_TRY(k2_config(P, LP_POINT, LP_POINT, n_roots * (p + 1), cfg));
-            cfg.api->vertex(cfg.L, P->dp, T->dt, fr_a.as<int32_t>(), (int)n_roots, P->d_cnt);
+            cfg.api->vertex(cfg.L, P->dp, T->dt, P->fr_a.as<int32_t>(), (int)n_roots, P->d_cnt);
         } else {
             hipLaunchKernelGGL(k_vertex_solve, dim3(grid_for(P, n_roots * (p + 1))), dim3(64),
-                               P->lds_point, P->stream, P->dp, T->dt, fr_a.as<int32_t>(),
+                               P->lds_point, P->stream, P->dp, T->dt, P->fr_a.as<int32_t>(),
                                (int)n_roots, P->d_cnt);
         }
         P->launches++;
-        ref_solves += n_roots * (2 + (p + 1));   // P_theta check + V_R MICP + vertex solves
+        R.ref_solves += n_roots * (2 + (p + 1));   // P_theta check + V_R MICP + vertex solves
     }
-    std::vector<hipEvent_t> evs;   // (start, stop) pairs: even index pairs = decide, odd = expand
+    *out = T;
+    return EHM_OK;
+#undef RUN_TRY
+}
+
+// Runs up to max_sweeps frontier sweeps (<= 0: until the frontier is empty).
+int ehm_partition_step(ehm_tree* T, int32_t max_sweeps, int64_t* frontier_size) {
+    if (!T || !T->run.active) return fail(EHM_E_INVALID, "no partition run in progress");
+    ehm_problem* P = T->prob;
+    auto& R = T->run;
+    HIP_TRY(hipSetDevice(P->device), EHM_E_HIP);
+    DevBuf &fr_a = P->fr_a, &fr_b = P->fr_b, &open_flag = P->open_flag,
+           &open_list = P->open_list, &d_count = P->d_count;
     auto stamp = [&]() {
         hipEvent_t e;
         (void)hipEventCreate(&e);
         (void)hipEventRecord(e, P->stream);
-        evs.push_back(e);
+        R.evs.push_back(e);
     };
-    std::vector<int> ev_kind;      // 0 decide, 1 expand, per pair
-    long long pre_closed = 0, pre_nodes = 0, pre_solves = 0;
-    long long n_nodes = n_roots;
-    long long nf = n_roots;
-    long long n_closed = 0;
-    int sweeps = 0, depth = 0;
-    int truncated = 0;
-    int32_t* cur = fr_a.as<int32_t>();
-    int32_t* nxt = fr_b.as<int32_t>();
-    bool cur_is_a = true;
-    while (nf > 0) {
-        if (!sharded && nf >= shard_min) {
+    int done = 0;
+    while (R.nf > 0 && !R.truncated && (max_sweeps <= 0 || done < max_sweeps)) {
+        int32_t* cur = (R.cur_is_a ? fr_a : fr_b).as<int32_t>();
+        if (!R.sharded && R.nf >= R.shard_min) {
             // deal the frontier round-robin over the ranks; the kept ids go to the other buffer
-            DevBuf& ob = cur_is_a ? fr_b : fr_a;
-            RUN_TRY(ob.ensure((size_t)(nf / shard_world + 1) * 4));
-            hipLaunchKernelGGL(k_shard_filter, dim3((unsigned)((nf + 255) / 256)), dim3(256), 0,
-                               P->stream, T->dt, cur, (int)nf, shard_rank, shard_world,
+            DevBuf& ob = R.cur_is_a ? fr_b : fr_a;
+            int rc = ob.ensure((size_t)(R.nf / R.shard_world + 1) * 4);
+            if (rc) return rc;
+            hipLaunchKernelGGL(k_shard_filter, dim3((unsigned)((R.nf + 255) / 256)), dim3(256), 0,
+                               P->stream, T->dt, cur, (int)R.nf, R.shard_rank, R.shard_world,
                                ob.as<int32_t>());
             P->launches++;
             cur = ob.as<int32_t>();
-            cur_is_a = !cur_is_a;
-            nf = (nf - shard_rank + shard_world - 1) / shard_world;
-            sharded = true;
+            R.cur_is_a = !R.cur_is_a;
+            R.nf = (R.nf - R.shard_rank + R.shard_world - 1) / R.shard_world;
+            R.sharded = true;
             // work done so far is replicated on every rank
             DevCounters cs;
-            RUN_TRY(read_counters(P, cs));
-            pre_closed = n_closed;
-            pre_nodes = n_nodes;
-            pre_solves = (long long)(cs.lp_solves - c0.lp_solves);
-            if (nf == 0) break;
+            int rc2 = read_counters(P, cs);
+            if (rc2) return rc2;
+            R.pre_closed = R.n_closed;
+            R.pre_nodes = R.n_nodes;
+            R.pre_solves = (long long)(cs.lp_solves - R.c0.lp_solves);
+            if (R.nf == 0) break;
         }
-        if ((long long)open_flag.cap < nf * 4) {
-            RUN_TRY(open_flag.ensure((size_t)nf * 4 * 2));
-            RUN_TRY(open_list.ensure((size_t)nf * 4 * 2));
+        if ((long long)open_flag.cap < R.nf * 4) {
+            int rc = open_flag.ensure((size_t)R.nf * 4 * 2);
+            if (rc) return rc;
+            rc = open_list.ensure((size_t)R.nf * 4 * 2);
+            if (rc) return rc;
         }
         K2Cfg cfg_d;
-        if (P->solver_gen == 2) RUN_TRY(k2_config(P, LP_SLACK, LP_SLACK, nf, cfg_d));
+        if (P->solver_gen == 2) {
+            int rc = k2_config(P, LP_SLACK, LP_SLACK, R.nf, cfg_d);
+            if (rc) return rc;
+        }
         stamp();
         if (P->solver_gen == 2)
-            cfg_d.api->decide(cfg_d.L, P->dp, T->dt, cur, (int)nf, open_flag.as<int32_t>(),
+            cfg_d.api->decide(cfg_d.L, P->dp, T->dt, cur, (int)R.nf, open_flag.as<int32_t>(),
                               P->d_cnt, P->decide_full ? 0 : 1);
         else
-            hipLaunchKernelGGL(k_lcss_decide, dim3(grid_for(P, nf)), dim3(64), P->lds_simplex,
-                               P->stream, P->dp, T->dt, cur, (int)nf, open_flag.as<int32_t>(),
+            hipLaunchKernelGGL(k_lcss_decide, dim3(grid_for(P, R.nf)), dim3(64), P->lds_simplex,
+                               P->stream, P->dp, T->dt, cur, (int)R.nf, open_flag.as<int32_t>(),
                                P->d_cnt);
         stamp();
-        ev_kind.push_back(0);
+        R.ev_kind.push_back(0);
         hipLaunchKernelGGL(k_scan_open, dim3(1), dim3(1024), 0, P->stream,
-                           open_flag.as<int32_t>(), cur, (int)nf, open_list.as<int32_t>(),
+                           open_flag.as<int32_t>(), cur, (int)R.nf, open_list.as<int32_t>(),
                            d_count.as<int32_t>());
         P->launches += 2;
         int32_t n_open = 0;
@@ -1574,101 +1648,208 @@ int ehm_partition_run(ehm_problem* P, int64_t n_roots, const double* root_vertic
                                           P->stream);
             if (e == hipSuccess) e = hipStreamSynchronize(P->stream);
             if (e != hipSuccess)
-                RUN_TRY(fail(EHM_E_HIP, "sweep %d failed: %s", sweeps, hipGetErrorString(e)));
+                return fail(EHM_E_HIP, "sweep %d failed: %s", R.sweeps, hipGetErrorString(e));
         }
-        ++sweeps;
-        ref_solves += nf;                 // one bar_E MICP per visited node
-        n_closed += nf - n_open;
-        if (n_open == 0) break;
-        if (max_depth > 0 && depth >= max_depth) {
-            truncated = 1;
+        ++R.sweeps;
+        ++done;
+        R.ref_solves += R.nf;                 // one bar_E MICP per visited node
+        R.n_closed += R.nf - n_open;
+        if (n_open == 0) {
+            R.nf = 0;
             break;
         }
-        if (n_nodes + 2LL * n_open > cap) {
-            truncated = 1;
-            cleanup();
-            ehm_tree_destroy(T);
+        if (R.max_depth > 0 && R.depth >= R.max_depth) {
+            R.truncated = 1;
+            break;
+        }
+        if (R.n_nodes + 2LL * n_open > T->cap)
             return fail(EHM_E_CAPACITY, "node pool exhausted at %lld nodes (max_nodes=%lld)",
-                        n_nodes, cap);
-        }
+                        R.n_nodes, T->cap);
         // next frontier buffer must hold 2*n_open ids
-        DevBuf& nb = cur_is_a ? fr_b : fr_a;
+        DevBuf& nb = R.cur_is_a ? fr_b : fr_a;
         if ((long long)nb.cap < 2LL * n_open * 4) {
-            RUN_TRY(nb.ensure((size_t)n_open * 2 * 4 * 2));
+            int rc = nb.ensure((size_t)n_open * 2 * 4 * 2);
+            if (rc) return rc;
         }
-        nxt = nb.as<int32_t>();
+        int32_t* nxt = nb.as<int32_t>();
         K2Cfg cfg_e;
-        if (P->solver_gen == 2) RUN_TRY(k2_config(P, LP_POINT, LP_POINT, n_open, cfg_e));
+        if (P->solver_gen == 2) {
+            int rc = k2_config(P, LP_POINT, LP_POINT, n_open, cfg_e);
+            if (rc) return rc;
+        }
         stamp();
         if (P->solver_gen == 2)
             cfg_e.api->expand(cfg_e.L, P->dp, T->dt, open_list.as<int32_t>(), (int)n_open,
-                              (int)n_nodes, nxt, P->d_cnt);
+                              (int)R.n_nodes, nxt, P->d_cnt);
         else
             hipLaunchKernelGGL(k_lcss_expand, dim3(grid_for(P, n_open)), dim3(64), P->lds_expand,
                                P->stream, P->dp, T->dt, open_list.as<int32_t>(), (int)n_open,
-                               (int)n_nodes, nxt, P->d_cnt);
+                               (int)R.n_nodes, nxt, P->d_cnt);
         stamp();
-        ev_kind.push_back(1);
+        R.ev_kind.push_back(1);
         P->launches++;
-        ref_solves += 2LL * n_open;       // bar_D MICP + midpoint P_theta_delta per split
-        n_nodes += 2LL * n_open;
-        nf = 2LL * n_open;
-        cur = nxt;
-        cur_is_a = !cur_is_a;
-        ++depth;
+        R.ref_solves += 2LL * n_open;       // bar_D MICP + midpoint P_theta_delta per split
+        R.n_nodes += 2LL * n_open;
+        R.nf = 2LL * n_open;
+        R.cur_is_a = !R.cur_is_a;
+        ++R.depth;
     }
+    if (frontier_size) *frontier_size = R.truncated ? 0 : R.nf;
+    return EHM_OK;
+}
+
+// Removes the LAST `count` nodes from the live frontier: their records [count][rec_doubles]
+// (vertices | vertex costs | vertex inputs), meta [count][2] = (commutation index, depth) and
+// node ids go to the caller; the nodes are flagged bit2 (owned by another rank).
+int ehm_partition_take(ehm_tree* T, int64_t count, int32_t* node_ids, double* records,
+                       int32_t* meta) {
+    if (!T || !T->run.active || !node_ids || !records || !meta || count < 0)
+        return fail(EHM_E_INVALID, "bad argument");
+    ehm_problem* P = T->prob;
+    auto& R = T->run;
+    if (count > R.nf) return fail(EHM_E_INVALID, "cannot take %lld of %lld frontier nodes",
+                                  (long long)count, (long long)R.nf);
+    if (count == 0) return EHM_OK;
+    HIP_TRY(hipSetDevice(P->device), EHM_E_HIP);
+    const int nrec = rec_doubles(P->dp.p, P->dp.n_u);
+    int rc;
+    if ((rc = P->out0.ensure((size_t)count * nrec * sizeof(double)))) return rc;
+    if ((rc = P->out2.ensure((size_t)count * 2 * sizeof(int32_t)))) return rc;
+    const int32_t* cur = (R.cur_is_a ? P->fr_a : P->fr_b).as<int32_t>() + (R.nf - count);
+    hipLaunchKernelGGL(k_take_nodes, dim3((unsigned)count), dim3(64), 0, P->stream, T->dt, cur,
+                       (int)count, nrec, P->out0.as<double>(), P->out2.as<int32_t>());
+    HIP_TRY(hipMemcpyAsync(node_ids, cur, (size_t)count * 4, hipMemcpyDeviceToHost, P->stream),
+            EHM_E_HIP);
+    HIP_TRY(hipMemcpyAsync(records, P->out0.ptr, (size_t)count * nrec * sizeof(double),
+                           hipMemcpyDeviceToHost, P->stream), EHM_E_HIP);
+    HIP_TRY(hipMemcpyAsync(meta, P->out2.ptr, (size_t)count * 2 * sizeof(int32_t),
+                           hipMemcpyDeviceToHost, P->stream), EHM_E_HIP);
+    HIP_TRY(hipStreamSynchronize(P->stream), EHM_E_HIP);
+    R.nf -= count;
+    R.given += count;
+    return EHM_OK;
+}
+
+// Appends `count` nodes received from another rank (records / meta as produced by
+// ehm_partition_take) to the pool and to the live frontier; first_id = id of the first one.
+int ehm_partition_give(ehm_tree* T, int64_t count, const double* records, const int32_t* meta,
+                       int32_t* first_id) {
+    if (!T || !T->run.active || !records || !meta || count < 0)
+        return fail(EHM_E_INVALID, "bad argument");
+    ehm_problem* P = T->prob;
+    auto& R = T->run;
+    if (first_id) *first_id = (int32_t)R.n_nodes;
+    if (count == 0) return EHM_OK;
+    if (R.n_nodes + count > T->cap)
+        return fail(EHM_E_CAPACITY, "node pool exhausted at %lld nodes (max_nodes=%lld)",
+                    R.n_nodes, T->cap);
+    HIP_TRY(hipSetDevice(P->device), EHM_E_HIP);
+    const int nrec = rec_doubles(P->dp.p, P->dp.n_u);
+    int rc;
+    if ((rc = P->in0.ensure((size_t)count * nrec * sizeof(double)))) return rc;
+    if ((rc = P->in1.ensure((size_t)count * 2 * sizeof(int32_t)))) return rc;
+    DevBuf& fb = R.cur_is_a ? P->fr_a : P->fr_b;
+    if ((long long)fb.cap < (R.nf + count) * 4) {
+        // grow the live frontier buffer, keeping its contents
+        DevBuf bigger;
+        if ((rc = bigger.ensure((size_t)(R.nf + count) * 4 * 2))) return rc;
+        HIP_TRY(hipMemcpyAsync(bigger.ptr, fb.ptr, (size_t)R.nf * 4, hipMemcpyDeviceToDevice,
+                               P->stream), EHM_E_HIP);
+        HIP_TRY(hipStreamSynchronize(P->stream), EHM_E_HIP);
+        std::swap(bigger, fb);
+        bigger.release();
+    }
+    HIP_TRY(hipMemcpyAsync(P->in0.ptr, records, (size_t)count * nrec * sizeof(double),
+                           hipMemcpyHostToDevice, P->stream), EHM_E_HIP);
+    HIP_TRY(hipMemcpyAsync(P->in1.ptr, meta, (size_t)count * 2 * sizeof(int32_t),
+                           hipMemcpyHostToDevice, P->stream), EHM_E_HIP);
+    hipLaunchKernelGGL(k_give_nodes, dim3((unsigned)count), dim3(64), 0, P->stream, T->dt,
+                       (int)R.n_nodes, (int)count, nrec, P->in0.as<double>(),
+                       P->in1.as<int32_t>(), fb.as<int32_t>(), (int)R.nf);
+    HIP_TRY(hipStreamSynchronize(P->stream), EHM_E_HIP);
+    R.n_nodes += count;
+    R.nf += count;
+    R.received += count;
+    return EHM_OK;
+}
+
+int ehm_partition_finish(ehm_tree* T) {
+    if (!T || !T->run.active) return fail(EHM_E_INVALID, "no partition run in progress");
+    ehm_problem* P = T->prob;
+    auto& R = T->run;
+    HIP_TRY(hipSetDevice(P->device), EHM_E_HIP);
+    hipEvent_t ev1;
+    (void)hipEventCreate(&ev1);
     (void)hipEventRecord(ev1, P->stream);
     (void)hipEventSynchronize(ev1);
     float ms = 0.f;
-    (void)hipEventElapsedTime(&ms, ev0, ev1);
-    (void)hipEventDestroy(ev0);
+    (void)hipEventElapsedTime(&ms, R.ev0, ev1);
     (void)hipEventDestroy(ev1);
     double t_kind[2] = {0.0, 0.0};
     long long n_kind[2] = {0, 0};
-    for (size_t k = 0; k < ev_kind.size(); ++k) {
+    for (size_t k = 0; k < R.ev_kind.size(); ++k) {
         float t = 0.f;
-        (void)hipEventElapsedTime(&t, evs[2 * k], evs[2 * k + 1]);
-        t_kind[ev_kind[k]] += t * 1e-3;
-        n_kind[ev_kind[k]]++;
+        (void)hipEventElapsedTime(&t, R.evs[2 * k], R.evs[2 * k + 1]);
+        t_kind[R.ev_kind[k]] += t * 1e-3;
+        n_kind[R.ev_kind[k]]++;
     }
-    for (hipEvent_t e : evs) (void)hipEventDestroy(e);
+    run_release_events(T);
     DevCounters c1;
-    RUN_TRY(read_counters(P, c1));
-    cleanup();
-    if (c1.errors != 0 && !getenv("EHM_KEEP_GOING")) {
-        ehm_tree_destroy(T);
+    int rc = read_counters(P, c1);
+    if (rc) return rc;
+    R.active = false;
+    if (c1.errors != 0 && !getenv("EHM_KEEP_GOING"))
         return fail(EHM_E_NUMERIC, "%llu oracle solves did not converge",
                     (unsigned long long)c1.errors);
-    }
-    T->info.n_nodes = n_nodes;
-    T->info.n_roots = n_roots;
-    T->info.n_leaves = n_nodes - (n_nodes - n_roots) / 2;
-    T->info.n_closed = n_closed;
-    T->info.lp_solves = (int64_t)(c1.lp_solves - c0.lp_solves);
-    T->info.ipm_iters = (int64_t)(c1.ipm_iters - c0.ipm_iters);
-    T->info.ref_solves = ref_solves;
-    T->info.sweeps = sweeps;
-    T->info.max_depth = depth;
-    T->info.truncated = truncated;
+    const long long received = R.received;
+    T->info.n_nodes = R.n_nodes;
+    T->info.n_roots = R.n_roots;
+    // every non-root node that was not received is one of two children of a split
+    T->info.n_leaves = R.n_nodes - (R.n_nodes - R.n_roots - received) / 2;
+    T->info.n_closed = R.n_closed;
+    T->info.lp_solves = (int64_t)(c1.lp_solves - R.c0.lp_solves);
+    T->info.ipm_iters = (int64_t)(c1.ipm_iters - R.c0.ipm_iters);
+    T->info.ref_solves = R.ref_solves;
+    T->info.sweeps = R.sweeps;
+    T->info.max_depth = R.depth;
+    T->info.truncated = R.truncated;
     T->info.device_seconds = ms * 1e-3;
     T->info.decide_seconds = t_kind[0];
     T->info.expand_seconds = t_kind[1];
     T->info.decide_launches = n_kind[0];
     T->info.expand_launches = n_kind[1];
-    T->info.decide_solves = (int64_t)(c1.slack_solves - c0.slack_solves);
-    T->info.decide_iters = (int64_t)(c1.slack_iters - c0.slack_iters);
-    T->info.replicated_closed = pre_closed;
-    T->info.replicated_nodes = pre_nodes;
-    T->info.replicated_solves = pre_solves;
+    T->info.decide_solves = (int64_t)(c1.slack_solves - R.c0.slack_solves);
+    T->info.decide_iters = (int64_t)(c1.slack_iters - R.c0.slack_iters);
+    T->info.replicated_closed = R.pre_closed;
+    T->info.replicated_nodes = R.pre_nodes;
+    T->info.replicated_solves = R.pre_solves;
     {
         double mm;
         std::memcpy(&mm, &c1.min_margin_bits, 8);
         T->info.min_margin = mm;
     }
     T->info.volume_closed = -1.0;   // filled lazily by ehm_tree_info_get
+    return EHM_OK;
+}
+
+int ehm_partition_run(ehm_problem* P, int64_t n_roots, const double* root_vertices,
+                      const ehm_node_init* init, const ehm_run_opts* opts, ehm_tree** out) {
+    if (!out) return fail(EHM_E_INVALID, "bad argument");
+    ehm_tree* T = nullptr;
+    int rc = ehm_partition_begin(P, n_roots, root_vertices, init, opts, &T);
+    if (rc) return rc;
+    rc = ehm_partition_step(T, 0, nullptr);
+    if (!rc) rc = ehm_partition_finish(T);
+    if (rc) {
+        std::string keep = g_err;      // the destroy below must not lose the message
+        run_release_events(T);
+        ehm_tree_destroy(T);
+        g_err = keep;
+        *out = nullptr;
+        return rc;
+    }
     *out = T;
     return EHM_OK;
-#undef RUN_TRY
 }
 
 int ehm_tree_info_get(const ehm_tree* Tc, ehm_tree_info* out) {

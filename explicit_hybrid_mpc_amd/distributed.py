@@ -6,9 +6,13 @@ The reference distributes work with an MPI master/worker star and pickled subtre
 (lib/scheduler.py:498-599, lib/worker.py:187-239).  Here the live frontier is sharded instead:
 every rank grows the same top of the tree, and once a sweep's frontier is wide enough each
 rank keeps the positions ``k % world == rank`` (``ehm_run_opts.shard_*``).  Subtrees are
-independent, so the data path needs no collective; the collectives below carry only counters
-(work accounting, load-imbalance report) and, on request, the ranks' finished subtrees to
-rank 0, where they are grafted by location -- the contract of ``build_tree``
+independent, so the data path itself needs no collective.  Because subtree sizes are very
+uneven, ``run_balanced`` rebalances as it goes: every few sweeps the
+ranks all-gather their frontier sizes (one int64 per rank over RCCL), derive the same
+donor -> receiver plan from them, and the donors send node records point to point (a pair talks
+over its own xGMI link; nothing is ringed).  The other collectives carry counters (work
+accounting, load-imbalance report) and, on request, the ranks' finished subtrees to rank 0,
+where they are grafted by location -- the contract of ``build_tree``
 (lib/scheduler.py:644-691).
 """
 
@@ -86,7 +90,135 @@ def imbalance(counts):
     return float(counts.max() / max(counts.mean(), 1e-300))
 
 
-def merge_flat(parts, root_locations=None):
+def balance_plan(counts, tolerance=0.1, min_move=16):
+    """
+    Deterministic rebalancing plan from the all-gathered frontier sizes: a list of
+    (donor, receiver, n) that brings every rank to within `tolerance` of the mean, largest
+    surplus matched with largest deficit first.  Empty when the frontiers are already even,
+    or too short for a transfer to pay (less than min_move nodes).
+    """
+    counts = [int(c) for c in counts]
+    world = len(counts)
+    total = sum(counts)
+    if world < 2 or total == 0:
+        return []
+    mean = total / float(world)
+    if max(counts) <= mean * (1. + tolerance) + min_move:
+        return []
+    target = [total // world + (1 if r < total % world else 0) for r in range(world)]
+    surplus = sorted([[counts[r] - target[r], r] for r in range(world) if counts[r] > target[r]],
+                     key=lambda e: (-e[0], e[1]))
+    deficit = sorted([[target[r] - counts[r], r] for r in range(world) if counts[r] < target[r]],
+                     key=lambda e: (-e[0], e[1]))
+    plan = []
+    i = j = 0
+    while i < len(surplus) and j < len(deficit):
+        n = min(surplus[i][0], deficit[j][0])
+        if n >= min_move:
+            plan.append((surplus[i][1], deficit[j][1], n))
+        surplus[i][0] -= n
+        deficit[j][0] -= n
+        if surplus[i][0] == 0:
+            i += 1
+        if deficit[j][0] == 0:
+            j += 1
+    return plan
+
+
+def _exchange(run, plan, rank, device, rnd, log):
+    """Execute this rank's part of a plan: donors take + send, receivers recv + give."""
+    import torch
+    import torch.distributed as dist
+    nrec = run.nrec
+    for donor, receiver, n in plan:
+        if rank == donor:
+            ids, rec, meta = run.take(n)
+            buf = np.concatenate([rec, meta.astype(np.float64)], axis=1)
+            t = torch.from_numpy(np.ascontiguousarray(buf))
+            if device is not None:
+                t = t.to(device)
+            dist.send(t, dst=receiver)
+            log.append(dict(kind='give', round=rnd, peer=receiver, ids=ids))
+        elif rank == receiver:
+            t = torch.empty((n, nrec + 2), dtype=torch.float64,
+                            device=device if device is not None else 'cpu')
+            dist.recv(t, src=donor)
+            buf = t.cpu().numpy()
+            first = run.give(buf[:, :nrec], np.rint(buf[:, nrec:]).astype(np.int32))
+            log.append(dict(kind='recv', round=rnd, peer=donor, first=first, count=n))
+
+
+def run_balanced(gp, roots, action='ecc', init=None, max_nodes=0, min_frontier=1024,
+                 sweeps_per_round=3, tolerance=0.1, min_move=16, device=None, export=False,
+                 with_volume=False, run_factory=None):
+    """
+    One partition over all ranks with periodic rebalancing of the live frontiers.
+    Returns (FlatTree or info dict of THIS rank's share, transfer log, rounds).
+    run_factory(shard) -> object with step/take/give/finish/nrec replaces the GPU engine
+    (the CPU tests emulate it).
+    """
+    import torch.distributed as dist
+    rank, _, world = env_rank_world()
+    if not (dist.is_available() and dist.is_initialized()):
+        world, rank = 1, 0
+    shard = shard_spec(rank, world, min_frontier)
+    if run_factory is not None:
+        run = run_factory(shard)
+    else:
+        run = gp.begin(roots, action=action, init=init, max_nodes=max_nodes, shard=shard,
+                       with_volume=with_volume)
+    log, rnd = [], 0
+    while True:
+        n = run.step(sweeps_per_round if world > 1 else 0)
+        if world == 1:
+            break
+        counts = allgather_counts([n], device=device)[:, 0]
+        if counts.sum() == 0:
+            break
+        _exchange(run, balance_plan(counts, tolerance, min_move), rank, device, rnd, log)
+        rnd += 1
+    return run.finish(export), log, rnd
+
+
+def resolve_received(parts, logs, root_locations=None):
+    """
+    Locations of the nodes every rank received: a received root sits where its donor's node
+    sat.  parts[r] / logs[r] = FlatTree and transfer log of rank r.  Returns a list of
+    {node id: location} per rank (transfers are matched by round, in plan order).
+    """
+    world = len(parts)
+    received = [dict() for _ in range(world)]
+    gives = {}      # (round, donor, receiver) -> list of id arrays, in order
+    for r in range(world):
+        for e in logs[r]:
+            if e['kind'] == 'give':
+                gives.setdefault((e['round'], r, e['peer']), []).append(e['ids'])
+    pending = []
+    for r in range(world):
+        seen = {}
+        for e in logs[r]:
+            if e['kind'] == 'recv':
+                key = (e['round'], e['peer'], r)
+                k = seen.get(key, 0)
+                seen[key] = k + 1
+                pending.append((r, e['first'], gives[key][k], e['peer']))
+    while pending:
+        locs = [parts[r].locations(root_locations, received[r]) for r in range(world)]
+        rest = []
+        for r, first, ids, donor in pending:
+            names = [locs[donor][i] for i in ids]
+            if any(nm is None for nm in names):
+                rest.append((r, first, ids, donor))
+                continue
+            for k, nm in enumerate(names):
+                received[r][first + k] = nm
+        if len(rest) == len(pending):
+            raise RuntimeError('transfer log cannot be resolved')
+        pending = rest
+    return received
+
+
+def merge_flat(parts, root_locations=None, received=None):
     """
     Graft the ranks' trees into one FlatTree.  Every part holds the replicated top of the
     tree plus its own subtrees; leaves flagged bit2 are placeholders for subtrees another
@@ -94,13 +226,13 @@ def merge_flat(parts, root_locations=None):
     """
     owner = {}
     for pi, part in enumerate(parts):
-        loc = part.locations(root_locations)
+        loc = part.locations(root_locations, received[pi] if received else None)
         for k, name in enumerate(loc):
             remote = bool(part.flags[k] & 4)
             if name not in owner or (owner[name][2] and not remote):
                 owner[name] = (pi, k, remote)
     n_roots = parts[0].info['n_roots']
-    first_loc = parts[0].locations(root_locations)
+    first_loc = parts[0].locations(root_locations, received[0] if received else None)
     order = [first_loc[r] for r in range(n_roots)]
     index = {name: i for i, name in enumerate(order)}
     head = 0

@@ -44,14 +44,20 @@ class FlatTree:
     def is_leaf(self, k):
         return self.left[k] < 0
 
-    def locations(self, root_locations=None):
-        """Location string of every node ('0' left / '1' right, lib/worker.py:254-258)."""
+    def locations(self, root_locations=None, received=None):
+        """
+        Location string of every node ('0' left / '1' right, lib/worker.py:254-258).
+        received: {node id: location} for the nodes another rank handed over (flag bit5);
+        nodes below a received root whose location is not known yet stay None.
+        """
         n_roots = self.info['n_roots']
         loc = [None] * self.n_nodes
         for r in range(n_roots):
             loc[r] = '' if root_locations is None else root_locations[r]
+        for k, name in (received or {}).items():
+            loc[k] = name
         for k in range(self.n_nodes):         # children always have larger indices
-            if self.left[k] >= 0:
+            if self.left[k] >= 0 and loc[k] is not None:
                 loc[self.left[k]] = loc[k] + '0'
                 loc[self.right[k]] = loc[k] + '1'
         return loc
@@ -266,10 +272,107 @@ class GpuProblem:
         return FlatTree(vertices, left, right, didx, vcost, vinput, flags, tstar, info_d,
                         self.can.deltas)
 
+    def begin(self, roots, action='ecc', init=None, max_nodes=0, max_depth=0, shard=None,
+              with_volume=True):
+        """Resumable partition run (see PartitionRun); same arguments as partition()."""
+        return PartitionRun(self, roots, action, init, max_nodes, max_depth, shard, with_volume)
+
     def stats(self):
         c = _capi.Counters()
         check(self._lib.ehm_stats(self._handle, ctypes.byref(c)))
         return {name: getattr(c, name) for name, _ in _capi.Counters._fields_}
+
+
+class PartitionRun:
+    """
+    The partition run in resumable pieces (ehm_partition_begin/step/take/give/finish): what the
+    multi-GPU driver in ``distributed.py`` needs to move frontier nodes between ranks.
+    """
+
+    def __init__(self, gp, roots, action, init, max_nodes, max_depth, shard, with_volume):
+        self.gp = gp
+        self._lib = gp._lib
+        can = gp.can
+        roots = f64(roots).reshape(-1, can.p + 1, can.p)
+        n_roots = roots.shape[0]
+        rank, world, min_frontier = shard if shard is not None else (0, 1, 0)
+        opts = _capi.RunOpts(max_nodes=int(max_nodes), max_depth=int(max_depth),
+                             action=0 if action == 'ecc' else 1, engine=0,
+                             shard_rank=int(rank), shard_world=int(world),
+                             shard_min_frontier=int(min_frontier),
+                             skip_volume=0 if with_volume else 1)
+        init_struct, keep = None, None
+        if init is not None:
+            dl = u8(np.asarray(init['delta']).astype(int)).reshape(n_roots, -1)
+            vc = f64(init['vertex_costs']).reshape(n_roots, can.p + 1)
+            vi = f64(init['vertex_inputs']).reshape(n_roots, can.p + 1, can.n_u)
+            keep = (dl, vc, vi)
+            init_struct = ctypes.pointer(_capi.NodeInit(
+                delta=dl.ctypes.data_as(_capi.c_uint8_p),
+                vcost=vc.ctypes.data_as(_capi.c_double_p),
+                vinput=vi.ctypes.data_as(_capi.c_double_p)))
+        self._tree = ctypes.c_void_p()
+        check(self._lib.ehm_partition_begin(gp._handle, n_roots, ptr(roots), init_struct,
+                                            ctypes.byref(opts), ctypes.byref(self._tree)))
+        del keep
+        self.nrec = (can.p + 1) * can.p + (can.p + 1) + (can.p + 1) * can.n_u
+        self.frontier = n_roots
+
+    def step(self, max_sweeps=0):
+        """Up to max_sweeps frontier sweeps (0 = until done); returns the live frontier size."""
+        n = ctypes.c_int64(0)
+        check(self._lib.ehm_partition_step(self._tree, int(max_sweeps), ctypes.addressof(n)))
+        self.frontier = int(n.value)
+        return self.frontier
+
+    def take(self, count):
+        """Hand over the last `count` frontier nodes: (node ids, records, meta)."""
+        count = int(count)
+        ids = np.empty(count, dtype=np.int32)
+        rec = np.empty((count, self.nrec))
+        meta = np.empty((count, 2), dtype=np.int32)
+        check(self._lib.ehm_partition_take(self._tree, count, ptr(ids), ptr(rec), ptr(meta)))
+        self.frontier -= count
+        return ids, rec, meta
+
+    def give(self, records, meta):
+        """Adopt nodes another rank took from its frontier; returns the id of the first one."""
+        rec = f64(records).reshape(-1, self.nrec)
+        meta = np.ascontiguousarray(meta, dtype=np.int32).reshape(-1, 2)
+        first = ctypes.c_int32(0)
+        check(self._lib.ehm_partition_give(self._tree, rec.shape[0], ptr(rec), ptr(meta),
+                                           ctypes.addressof(first)))
+        self.frontier += rec.shape[0]
+        return int(first.value)
+
+    def finish(self, export=True):
+        """Totals (and the flat export); releases the device tree."""
+        gp = self.gp
+        try:
+            check(self._lib.ehm_partition_finish(self._tree))
+            info = _capi.TreeInfo()
+            check(self._lib.ehm_tree_info_get(self._tree, ctypes.byref(info)))
+            info_d = {name: getattr(info, name) for name, _ in _capi.TreeInfo._fields_}
+            if not export:
+                return info_d
+            K = info.n_nodes
+            p, n_u = gp.can.p, gp.can.n_u
+            vertices = np.empty((K, p + 1, p))
+            left = np.empty(K, dtype=np.int32)
+            right = np.empty(K, dtype=np.int32)
+            didx = np.empty(K, dtype=np.int32)
+            vcost = np.empty((K, p + 1))
+            vinput = np.empty((K, p + 1, n_u))
+            flags = np.empty(K, dtype=np.uint8)
+            tstar = np.empty(K)
+            check(self._lib.ehm_tree_export(self._tree, ptr(vertices), ptr(left), ptr(right),
+                                            ptr(didx), ptr(vcost), ptr(vinput), ptr(flags),
+                                            ptr(tstar)))
+        finally:
+            self._lib.ehm_tree_destroy(self._tree)
+            self._tree = ctypes.c_void_p()
+        return FlatTree(vertices, left, right, didx, vcost, vinput, flags, tstar, info_d,
+                        gp.can.deltas)
 
 
 def selftest(device=0, max_instances=64):

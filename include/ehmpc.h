@@ -183,6 +183,28 @@ typedef struct ehm_node_init {
 int ehm_partition_run(ehm_problem* prob, int64_t n_roots, const double* root_vertices,
                       const ehm_node_init* init, const ehm_run_opts* opts, ehm_tree** out);
 
+/* The same run in resumable pieces, for the multi-GPU driver (one process per GPU): every rank
+ * runs a few sweeps, the ranks all-gather their frontier sizes (RCCL) and move node records
+ * from the longest frontiers to the shortest.  The reference rebalances through its MPI
+ * master/worker star (lib/scheduler.py:498-599); here only counts and the moved records travel.
+ *   begin  : uploads the roots (and runs the 'ecc' vertex solves);
+ *   step   : up to max_sweeps frontier sweeps (<= 0: until the frontier is empty);
+ *            *frontier_size = live frontier nodes afterwards;
+ *   take   : removes the LAST count frontier nodes: node_ids [count], records
+ *            [count][(p+1)p + (p+1) + (p+1)n_u] (vertices | vertex costs | vertex inputs),
+ *            meta [count][2] = (commutation index, depth); the nodes get flag bit2;
+ *   give   : appends count nodes produced by another rank's take to the pool (flag bit5)
+ *            and to the live frontier; *first_id = node id of the first one;
+ *   finish : totals for ehm_tree_info_get / ehm_tree_export (required before either). */
+int ehm_partition_begin(ehm_problem* prob, int64_t n_roots, const double* root_vertices,
+                        const ehm_node_init* init, const ehm_run_opts* opts, ehm_tree** out);
+int ehm_partition_step(ehm_tree* tree, int32_t max_sweeps, int64_t* frontier_size);
+int ehm_partition_take(ehm_tree* tree, int64_t count, int32_t* node_ids, double* records,
+                       int32_t* meta);
+int ehm_partition_give(ehm_tree* tree, int64_t count, const double* records,
+                       const int32_t* meta, int32_t* first_id);
+int ehm_partition_finish(ehm_tree* tree);
+
 typedef struct ehm_tree_info {
     int64_t n_nodes;
     int64_t n_leaves;
@@ -213,7 +235,8 @@ int ehm_tree_info_get(const ehm_tree* tree, ehm_tree_info* out);
 /* Flat export, node k: vertices [k][p+1][p], left[k] / right[k] child index or -1,
  * delta_idx[k] (-1 = none), vcost [k][p+1], vinput [k][p+1][n_u],
  * flags[k] bit0 = is_epsilon_suboptimal, bit1 = has commutation data,
- * bit2 = subtree owned by another rank (multi-GPU sharding).
+ * bit2 = subtree owned by another rank (multi-GPU sharding / ehm_partition_take),
+ * bit5 = node received from another rank (ehm_partition_give; it is a root of this part).
  * Nodes 0..n_roots-1 are the roots in input order.  Any pointer may be NULL. */
 int ehm_tree_export(const ehm_tree* tree, double* vertices, int32_t* left, int32_t* right,
                     int32_t* delta_idx, double* vcost, double* vinput, uint8_t* flags,

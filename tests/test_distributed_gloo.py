@@ -67,6 +67,117 @@ def sweep_partition_cpu(mpc, eps_a, eps_r, roots, rank, world, min_frontier):
                     np.array(F, dtype=np.uint8), np.array(T), info, np.ones((1, mpc.N)))
 
 
+class CpuRun:
+    """
+    CPU emulation of engine.PartitionRun (begin/step/take/give/finish) with the engine's sweep
+    order, dealing rule and hand-over semantics, so that distributed.run_balanced can be driven
+    on a box without a GPU.
+    """
+
+    def __init__(self, mpc, eps_a, eps_r, roots, shard):
+        from oracle.oracle_cpu import OracleCPU
+        self.mpc = mpc
+        self.orc = OracleCPU(mpc, eps_a, eps_r)
+        self.orc.memoize = True
+        self.d0 = self.orc.deltas[0]
+        self.rank, self.world, self.min_frontier = shard if shard is not None else (0, 1, 0)
+        self.sharded = self.world == 1
+        self.V, self.L, self.Rr, self.C, self.U, self.F, self.T = [], [], [], [], [], [], []
+        self.n_roots = len(roots)
+        self.frontier = []
+        for R in roots:
+            sol = [self.orc.P_theta_delta(v, self.d0) for v in R]
+            self.frontier.append(self._add(np.array(R), np.array([s[1] for s in sol]),
+                                           np.array([s[0] for s in sol]), 2))
+        p, n_u = np.array(roots[0]).shape[1], self.U[0].shape[1]
+        self.p, self.n_u = p, n_u
+        self.nrec = (p + 1) * p + (p + 1) + (p + 1) * n_u
+
+    def _add(self, R, c, u, flag):
+        self.V.append(R); self.L.append(-1); self.Rr.append(-1); self.C.append(c)
+        self.U.append(u); self.F.append(flag); self.T.append(0.)
+        return len(self.L) - 1
+
+    def step(self, max_sweeps=0):
+        from explicit_hybrid_mpc_amd import distributed
+        from oracle import geometry
+        done = 0
+        while self.frontier and (max_sweeps <= 0 or done < max_sweeps):
+            if not self.sharded and len(self.frontier) >= self.min_frontier:
+                keep = []
+                for k, i in enumerate(self.frontier):
+                    if distributed.owner_of(k, self.world) == self.rank:
+                        keep.append(i)
+                    else:
+                        self.F[i] |= 4
+                self.frontier, self.sharded = keep, True
+            nxt = []
+            for i in self.frontier:
+                t, _ = self.orc.slack(self.V[i], self.C[i], 0)
+                self.T[i] = t
+                if not (t >= 0.):
+                    self.F[i] |= 1
+                    continue
+                S1, S2, (a, b) = geometry.split_along_longest_edge(self.V[i])
+                u_mid, J_mid, _ = self.orc.P_theta_delta(S1[a], self.d0)
+                c1, c2 = self.C[i].copy(), self.C[i].copy()
+                u1, u2 = self.U[i].copy(), self.U[i].copy()
+                c1[a], c2[b], u1[a], u2[b] = J_mid, J_mid, u_mid, u_mid
+                self.L[i] = self._add(S1, c1, u1, 2)
+                self.Rr[i] = self._add(S2, c2, u2, 2)
+                nxt += [self.L[i], self.Rr[i]]
+            self.frontier = nxt
+            done += 1
+        return len(self.frontier)
+
+    def take(self, count):
+        ids = np.array(self.frontier[len(self.frontier) - count:], dtype=np.int32)
+        self.frontier = self.frontier[:len(self.frontier) - count]
+        rec = np.array([np.concatenate([self.V[i].ravel(), self.C[i], self.U[i].ravel()])
+                        for i in ids]).reshape(count, self.nrec)
+        for i in ids:
+            self.F[i] |= 4
+        return ids, rec, np.zeros((count, 2), dtype=np.int32)
+
+    def give(self, records, meta):
+        p, n_u = self.p, self.n_u
+        first = len(self.L)
+        for r in np.asarray(records).reshape(-1, self.nrec):
+            R = r[:(p + 1) * p].reshape(p + 1, p)
+            c = r[(p + 1) * p:(p + 1) * p + p + 1]
+            u = r[(p + 1) * p + p + 1:].reshape(p + 1, n_u)
+            self.frontier.append(self._add(R.copy(), c.copy(), u.copy(), 2 | 32))
+        return first
+
+    def finish(self, export=True):
+        from explicit_hybrid_mpc_amd.engine import FlatTree
+        F = np.array(self.F, dtype=np.uint8)
+        info = dict(n_roots=self.n_roots, n_nodes=len(self.L), lp_solves=self.orc.n_solves,
+                    n_closed=int(np.sum(F & 1 > 0)))
+        return FlatTree(np.array(self.V), np.array(self.L, dtype=np.int32),
+                        np.array(self.Rr, dtype=np.int32), np.zeros(len(self.L), dtype=np.int32),
+                        np.array(self.C), np.array(self.U), F, np.array(self.T), info,
+                        np.ones((1, self.mpc.N)))
+
+
+def _worker_balanced(rank, world, port, out_dir):
+    os.environ.update(RANK=str(rank), LOCAL_RANK=str(rank), WORLD_SIZE=str(world),
+                      MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port))
+    import pickle
+    import torch.distributed as dist
+    from explicit_hybrid_mpc_amd import distributed
+    distributed.init_process_group('gloo')
+    mpc = helpers.make_instance('di', 0)
+    roots, locs = helpers.roots_of(mpc)
+    part, log, rounds = distributed.run_balanced(
+        None, roots, min_frontier=6, sweeps_per_round=1, tolerance=0., min_move=1, export=True,
+        run_factory=lambda shard: CpuRun(mpc, 0.3, 0.02, roots, shard))
+    with open(os.path.join(out_dir, 'bal%d.pkl' % rank), 'wb') as f:
+        pickle.dump(dict(part=part, log=log, rounds=rounds), f)
+    dist.barrier()
+    dist.destroy_process_group()
+
+
 def _worker(rank, world, port, out_dir):
     os.environ.update(RANK=str(rank), LOCAL_RANK=str(rank), WORLD_SIZE=str(world),
                       MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port))
@@ -119,3 +230,55 @@ def test_two_ranks_tile_the_tree(tmp_path):
     assert 1.0 <= outs[0]['imb'] < 1.6
     # each rank really did only part of the work
     assert all(o['part'].info['n_closed'] < full.info['n_closed'] for o in outs)
+
+
+def test_balance_plan_is_deterministic_and_evens_out():
+    from explicit_hybrid_mpc_amd import distributed
+    assert distributed.balance_plan([100, 100, 100, 100]) == []
+    assert distributed.balance_plan([0, 0]) == []
+    assert distributed.balance_plan([40, 3], min_move=64) == []       # too short to pay
+    counts = [4000, 10, 900, 1200, 0, 3100, 50, 740]
+    plan = distributed.balance_plan(counts, tolerance=0.05)
+    assert plan == distributed.balance_plan(list(counts), tolerance=0.05)
+    after = list(counts)
+    for d, r, n in plan:
+        assert n > 0 and d != r and after[d] >= n
+        after[d] -= n
+        after[r] += n
+    assert sum(after) == sum(counts)
+    assert max(after) <= 1.05 * (sum(counts) / 8.) + 16
+    donors = {d for d, _, _ in plan}
+    assert donors.isdisjoint({r for _, r, _ in plan})                 # nobody relays
+
+
+def test_two_ranks_rebalance_and_merge(tmp_path):
+    """run_balanced over gloo: frontier nodes really move, and the merged tree is the tree."""
+    import pickle
+    from explicit_hybrid_mpc_amd import distributed
+    s = socket.socket()
+    s.bind(('127.0.0.1', 0))
+    port = s.getsockname()[1]
+    s.close()
+    mp.spawn(_worker_balanced, args=(2, port, str(tmp_path)), nprocs=2, join=True)
+    outs = [pickle.load(open(str(tmp_path / ('bal%d.pkl' % r)), 'rb')) for r in range(2)]
+    moved = sum(len(e['ids']) for o in outs for e in o['log'] if e['kind'] == 'give')
+    got = sum(e['count'] for o in outs for e in o['log'] if e['kind'] == 'recv')
+    assert moved == got and moved > 0
+    mpc = helpers.make_instance('di', 0)
+    roots, locs = helpers.roots_of(mpc)
+    full = sweep_partition_cpu(mpc, 0.3, 0.02, roots, 0, 1, 0)
+    parts = [o['part'] for o in outs]
+    received = distributed.resolve_received(parts, [o['log'] for o in outs], locs)
+    assert sum(len(r) for r in received) == moved
+    merged = distributed.merge_flat(parts, locs, received)
+    assert merged.n_nodes == full.n_nodes
+    floc, mloc = full.locations(locs), merged.locations(locs)
+    fidx = {n: k for k, n in enumerate(floc)}
+    assert set(floc) == set(mloc)
+    for k, name in enumerate(mloc):
+        j = fidx[name]
+        assert np.array_equal(merged.vertices[k], full.vertices[j])
+        assert merged.is_leaf(k) == full.is_leaf(j)
+        assert (merged.flags[k] & 1) == (full.flags[j] & 1)
+        assert not (merged.flags[k] & 4)
+        assert np.allclose(merged.vertex_costs[k], full.vertex_costs[j], rtol=1e-9, atol=1e-12)

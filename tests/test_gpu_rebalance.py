@@ -1,0 +1,73 @@
+"""
+The resumable engine (ehm_partition_begin / step / take / give / finish) on the device: two
+handles on one GPU play two ranks, frontier nodes are moved between them with the plan of
+distributed.balance_plan, and the merged shares must be exactly the tree one run grows.
+(The torch.distributed side of the same loop is exercised with gloo in
+test_distributed_gloo.py.)
+"""
+
+import numpy as np
+import pytest
+
+from tests import helpers
+
+pytestmark = pytest.mark.gpu
+
+
+def test_moved_frontier_nodes_give_the_same_tree():
+    from explicit_hybrid_mpc_amd import distributed, engine, examples
+    from explicit_hybrid_mpc_amd import tools as ehm_tools
+    mpc = helpers.make_instance('lin', 0)
+    can = mpc.compile()
+    V = examples.box_vertices(examples.theta_box(mpc))
+    roots, locs = ehm_tools.delaunay_roots(V)
+    gps = [engine.GpuProblem(can, 1., 1.) for _ in range(3)]
+    eps_a = float(np.max(gps[0].solve_pt(0.12 * V)[0]))
+    for g in gps:
+        g.set_eps(eps_a, 1e-2)
+    ref = gps[2].partition(roots, action='ecc')
+    world = 2
+    runs = [gps[r].begin(roots, shard=(r, world, 64)) for r in range(world)]
+    logs = [[] for _ in range(world)]
+    rnd = 0
+    moved = 0
+    while True:
+        counts = [run.step(2) for run in runs]
+        if sum(counts) == 0:
+            break
+        # make the exchange bite: rank 0 works at half speed in this emulation
+        plan = distributed.balance_plan(counts, tolerance=0.02, min_move=4)
+        for donor, receiver, n in plan:
+            ids, rec, meta = runs[donor].take(n)
+            assert rec.shape == (n, runs[donor].nrec) and meta.shape == (n, 2)
+            first = runs[receiver].give(rec, meta)
+            logs[donor].append(dict(kind='give', round=rnd, peer=receiver, ids=ids))
+            logs[receiver].append(dict(kind='recv', round=rnd, peer=donor, first=first, count=n))
+            moved += n
+        rnd += 1
+    parts = [run.finish(export=True) for run in runs]
+    for g in gps:
+        g.close()
+    assert moved > 0
+    for part in parts:
+        assert part.info['n_nodes'] == part.n_nodes
+        assert int(np.sum((part.flags & 32) > 0)) == sum(
+            e['count'] for e in logs[parts.index(part)] if e['kind'] == 'recv')
+    received = distributed.resolve_received(parts, logs, locs)
+    merged = distributed.merge_flat(parts, locs, received)
+    assert merged.n_nodes == ref.n_nodes
+    rloc, mloc = ref.locations(locs), merged.locations(locs)
+    ridx = {n: k for k, n in enumerate(rloc)}
+    assert set(rloc) == set(mloc)
+    for k, name in enumerate(mloc):
+        j = ridx[name]
+        assert np.array_equal(merged.vertices[k], ref.vertices[j])      # bit-identical
+        assert merged.is_leaf(k) == ref.is_leaf(j)
+        assert (merged.flags[k] & 1) == (ref.flags[j] & 1)
+        assert not (merged.flags[k] & 4)
+        assert np.allclose(merged.vertex_costs[k], ref.vertex_costs[j], rtol=1e-9, atol=1e-12)
+    # each closed leaf is closed by exactly one share (the replicated top has none at this size
+    # beyond what rank 0 is credited with)
+    own = [int(p.info['n_closed']) - int(p.info['replicated_closed']) * (r > 0)
+           for r, p in enumerate(parts)]
+    assert sum(own) == int(np.sum((ref.flags & 1) > 0))
