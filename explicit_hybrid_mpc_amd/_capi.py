@@ -32,6 +32,8 @@ EXPORTED = [
     'ehm_last_error', 'ehm_version', 'ehm_problem_set_solver', 'ehm_selftest',
     'ehm_problem_set_option', 'ehm_partition_begin', 'ehm_partition_step',
     'ehm_partition_take', 'ehm_partition_give', 'ehm_partition_finish',
+    'ehm_explicit_create', 'ehm_explicit_eval_batch', 'ehm_explicit_destroy',
+    'ehm_explicit_last_error',
 ]
 
 
@@ -131,13 +133,19 @@ def load(build_if_missing=True):
     lib.ehm_partition_take.argtypes = [vp, i64, vp, vp, vp]
     lib.ehm_partition_give.argtypes = [vp, i64, vp, vp, vp]
     lib.ehm_partition_finish.argtypes = [vp]
+    lib.ehm_explicit_create.argtypes = [i32, i64, i32, i32, i32, vp, vp, vp, vp,
+                                        ctypes.POINTER(vp)]
+    lib.ehm_explicit_eval_batch.argtypes = [vp, i64, vp, vp, vp, vp, vp]
+    lib.ehm_explicit_destroy.argtypes = [vp]
+    lib.ehm_explicit_last_error.restype = ctypes.c_char_p
     lib.ehm_tree_info_get.argtypes = [vp, ctypes.POINTER(TreeInfo)]
     lib.ehm_tree_export.argtypes = [vp, vp, vp, vp, vp, vp, vp, vp, vp]
     lib.ehm_tree_destroy.argtypes = [vp]
     lib.ehm_stats.argtypes = [vp, ctypes.POINTER(Counters)]
     for name in EXPORTED:
         fn = getattr(lib, name)
-        if name not in ('ehm_last_error', 'ehm_version', 'ehm_stream'):
+        if name not in ('ehm_last_error', 'ehm_version', 'ehm_stream',
+                        'ehm_explicit_last_error'):
             fn.restype = i32
     _lib = lib
     return lib

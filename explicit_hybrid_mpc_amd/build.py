@@ -48,7 +48,9 @@ def _dep_mtime():
 
 def _objects():
     """(object path, source path, extra flags)"""
-    objs = [(os.path.join(OBJ_DIR, 'ehm_capi.o'), os.path.join(SRC_DIR, 'ehm_capi.hip'), [])]
+    objs = [(os.path.join(OBJ_DIR, 'ehm_capi.o'), os.path.join(SRC_DIR, 'ehm_capi.hip'), []),
+            (os.path.join(OBJ_DIR, 'ehm_explicit.o'), os.path.join(SRC_DIR, 'ehm_explicit.hip'),
+             [])]
     for np_ in K2_NPS:
         for sl in K2_SLOTS:
             objs.append((os.path.join(OBJ_DIR, 'ehm_k2_%d_%d.o' % (np_, sl)),
@@ -66,7 +68,7 @@ def is_stale():
     if not os.path.exists(LIB):
         return True
     t = os.path.getmtime(LIB)
-    srcs = [os.path.join(SRC_DIR, 'ehm_capi.hip'), os.path.join(SRC_DIR, 'ehm_k2.hip')]
+    srcs = [os.path.join(SRC_DIR, f) for f in ('ehm_capi.hip', 'ehm_k2.hip', 'ehm_explicit.hip')]
     return max([_dep_mtime()] + [os.path.getmtime(s) for s in srcs]) > t
 
 

@@ -243,6 +243,26 @@ int ehm_tree_export(const ehm_tree* tree, double* vertices, int32_t* left, int32
                     double* tstar);
 int ehm_tree_destroy(ehm_tree* tree);
 
+/* ---- batched evaluation of the explicit control law (the partition's consumer) --------- */
+
+/* ExplicitMPC.setup + __call__ (lib/mpc_library.py:677-792) for batches of states.  The
+ * partition comes as the flat export of ehm_tree_export (or any binary forest in that form):
+ * nodes 0..n_roots-1 are the root simplices in tools.delaunay order (they hang off the
+ * reference's right spine, lib/tools.py:152-189), left/right = child index or -1,
+ * vertices [n_nodes][p+1][p], vinput [n_nodes][p+1][n_u].  create computes
+ * inv([v1-v0 .. vp-v0]) for every node on the device (compute_simplex_basis_inverse, :685-712). */
+typedef struct ehm_explicit ehm_explicit;
+int ehm_explicit_create(int device, int64_t n_nodes, int32_t n_roots, int32_t p, int32_t n_u,
+                        const int32_t* left, const int32_t* right, const double* vertices,
+                        const double* vinput, ehm_explicit** out);
+/* x [n][p] -> u [n][n_u] (barycentric interpolation in the containing leaf, :786-789);
+ * leaf [n] = node id of that leaf, visited [n] = containment tests on the way (both may be
+ * NULL); kernel_seconds (may be NULL) = device time of the evaluation kernel. */
+int ehm_explicit_eval_batch(ehm_explicit* ex, int64_t n, const double* x, double* u,
+                            int32_t* leaf, int32_t* visited, double* kernel_seconds);
+int ehm_explicit_destroy(ehm_explicit* ex);
+const char* ehm_explicit_last_error(void);
+
 /* Cumulative counters of a problem handle (SURVEY.md section 5 "tracing"). */
 typedef struct ehm_counters {
     int64_t lp_solves;
