@@ -97,7 +97,8 @@ def main():
     ap.add_argument('--abs-frac', type=float, default=0.02)
     ap.add_argument('--eps-r', type=float, default=1e-2)
     ap.add_argument('--max-nodes', type=int, default=1 << 22)
-    ap.add_argument('--shard-min-frontier', type=int, default=1024)
+    ap.add_argument('--shard-min-frontier', type=int, default=0,
+                    help='frontier size at which it is dealt over the ranks (0 = 64 per rank)')
     ap.add_argument('--sweeps-per-round', type=int, default=2,
                     help='frontier sweeps between two rebalancing rounds (N > 1)')
     ap.add_argument('--cpu-seconds', type=float, default=15.)
@@ -135,6 +136,9 @@ def main():
     eps_a = float(np.max(J_abs))
     gp.set_eps(eps_a, args.eps_r)
     roots, _ = ehm_tools.delaunay_roots(V)
+    if args.shard_min_frontier <= 0:
+        # the top of the tree is latency-bound on any number of GPUs: deal early, rebalance often
+        args.shard_min_frontier = 64 * world
     shard = distributed.shard_spec(rank, world, args.shard_min_frontier)
 
     xdev = ('cuda:%d' % device_index) if backend == 'nccl' else None
