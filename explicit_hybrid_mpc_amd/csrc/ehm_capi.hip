@@ -437,6 +437,7 @@ struct ehm_problem {
     DevBuf in0, in1, in2, out0, out1, out2, out3;
     DevCounters* d_cnt = nullptr;
     long long launches = 0;
+    long long fallbacks = 0;   // LPs handed from the generation-2 to the generation-1 kernels
     int num_cu = 256;
     size_t lds_point = 0, lds_simplex = 0, lds_expand = 0;
 };
@@ -773,6 +774,7 @@ int ehm_stats(ehm_problem* P, ehm_counters* out) {
     out->ipm_iters = (int64_t)c.ipm_iters;
     out->stalled = (int64_t)c.stalled;
     out->kernel_launches = P->launches;
+    out->fallbacks = P->fallbacks;
     return EHM_OK;
 }
 
@@ -829,12 +831,38 @@ static int point_batch(ehm_problem* P, int64_t n_inst, const double* theta,
         HIP_TRY(hipMemcpyAsync(its.data(), d_iters, (size_t)n_inst * sizeof(int32_t),
                                hipMemcpyDeviceToHost, P->stream), EHM_E_HIP);
         HIP_TRY(hipStreamSynchronize(P->stream), EHM_E_HIP);
+        std::vector<int64_t> bad;
         for (int64_t k = 0; k < n_inst; ++k) {
             const int64_t o = order[(size_t)k];
             J[o] = Js[(size_t)k];
             if (u0) std::memcpy(u0 + (size_t)o * n_u, &us[(size_t)k * n_u], n_u * sizeof(double));
             if (status) status[o] = sts[(size_t)k];
             if (iters) iters[o] = its[(size_t)k];
+            if (sts[(size_t)k] != 0) bad.push_back(o);
+        }
+        // same safety net as in simplex_batch (an infeasible instance stays "stalled")
+        if (!bad.empty() && P->v1_ok && (int64_t)bad.size() * 4 <= n_inst) {
+            const int64_t nb = (int64_t)bad.size();
+            std::vector<double> t2((size_t)nb * p), J2((size_t)nb), u2((size_t)nb * n_u);
+            std::vector<int32_t> d2((size_t)nb), s2((size_t)nb), i2((size_t)nb);
+            for (int64_t k = 0; k < nb; ++k) {
+                std::memcpy(&t2[(size_t)k * p], theta + (size_t)bad[(size_t)k] * p, p * sizeof(double));
+                d2[(size_t)k] = didx_host[bad[(size_t)k]];
+            }
+            P->solver_gen = 1;
+            rc = point_batch(P, nb, t2.data(), d2.data(), feas, J2.data(), u2.data(), s2.data(),
+                             i2.data());
+            P->solver_gen = 2;
+            if (rc) return rc;
+            for (int64_t k = 0; k < nb; ++k) {
+                if (s2[(size_t)k] != 0) continue;
+                const int64_t o = bad[(size_t)k];
+                J[o] = J2[(size_t)k];
+                if (u0) std::memcpy(u0 + (size_t)o * n_u, &u2[(size_t)k * n_u], n_u * sizeof(double));
+                if (status) status[o] = 0;
+                if (iters) iters[o] = i2[(size_t)k];
+                P->fallbacks++;
+            }
         }
         return EHM_OK;
     }
@@ -954,11 +982,43 @@ static int simplex_batch(ehm_problem* P, int64_t n_inst, const double* R, const 
         HIP_TRY(hipMemcpyAsync(sts.data(), d_status, (size_t)n_inst * sizeof(int32_t),
                                hipMemcpyDeviceToHost, P->stream), EHM_E_HIP);
         HIP_TRY(hipStreamSynchronize(P->stream), EHM_E_HIP);
+        std::vector<int64_t> bad;
         for (int64_t k = 0; k < n_inst; ++k) {
             const int64_t o = order[(size_t)k];
             obj[o] = objs[(size_t)k];
             if (alpha) std::memcpy(alpha + (size_t)o * nv, &als[(size_t)k * nv], nv * sizeof(double));
             if (status) status[o] = sts[(size_t)k];
+            if (sts[(size_t)k] != 0) bad.push_back(o);
+        }
+        // numerical safety net: an LP the shared-block kernels (psi-coordinates) could not bring
+        // to tolerance is repeated by the generation-1 kernel (barycentric coordinates, private
+        // copy of the LP) -- a few per ten million on hybrid instances
+        if (!bad.empty() && P->v1_ok) {
+            const int64_t nb = (int64_t)bad.size();
+            std::vector<double> R2((size_t)nb * nR), V2((size_t)nb * nv, 0.0), o2((size_t)nb),
+                a2((size_t)nb * nv);
+            std::vector<int32_t> d2((size_t)nb), s2((size_t)nb);
+            for (int64_t k = 0; k < nb; ++k) {
+                std::memcpy(&R2[(size_t)k * nR], R + (size_t)bad[(size_t)k] * nR, nR * sizeof(double));
+                if (slack == SX_SLACK)
+                    std::memcpy(&V2[(size_t)k * nv], Vbar + (size_t)bad[(size_t)k] * nv,
+                                nv * sizeof(double));
+                d2[(size_t)k] = didx_host[bad[(size_t)k]];
+            }
+            P->solver_gen = 1;
+            rc = simplex_batch(P, nb, R2.data(), V2.data(), d2.data(), slack, o2.data(),
+                               a2.data(), s2.data());
+            P->solver_gen = 2;
+            if (rc) return rc;
+            for (int64_t k = 0; k < nb; ++k) {
+                if (s2[(size_t)k] != 0) continue;
+                const int64_t o = bad[(size_t)k];
+                obj[o] = o2[(size_t)k];
+                if (alpha)
+                    std::memcpy(alpha + (size_t)o * nv, &a2[(size_t)k * nv], nv * sizeof(double));
+                if (status) status[o] = 0;
+                P->fallbacks++;
+            }
         }
         return EHM_OK;
     }

@@ -269,6 +269,7 @@ typedef struct ehm_counters {
     int64_t ipm_iters;
     int64_t kernel_launches;
     int64_t stalled;
+    int64_t fallbacks;      /* batch LPs the generation-2 kernels handed to generation 1 */
 } ehm_counters;
 int ehm_stats(ehm_problem* prob, ehm_counters* out);
 
