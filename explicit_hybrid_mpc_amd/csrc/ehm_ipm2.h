@@ -43,9 +43,12 @@
 #define EHM2_TOL_GAP      1e-10
 #define EHM2_MAX_ITER     40
 // fraction of the step to the boundary: 0.999 saves ~12 % of the iterations over 0.99; the few
-// solves per million it stalls are repeated with the conservative value (ipm_solve_retry)
+// solves per million that stall with it are repeated (re-assembled) with 0.99, and -- seen only
+// on hybrid instances, a few per ten million -- with 0.9
 #define EHM2_STEP_FRAC    0.999
 #define EHM2_STEP_FRAC_SAFE 0.99
+#define EHM2_STEP_FRAC_LAST 0.9
+#define EHM2_ATTEMPTS     3
 #define EHM2_PIVOT_REL    1e-13
 #define EHM2_PIVOT_BIG    1e128
 #define EHM2_STALL_ZONE   1e4
@@ -191,6 +194,14 @@ struct Wave {
     int n_lin;      // LP columns j < n_lin are Wc columns j
     int spec_col;   // Wc column of LP column n_lin (when n_lin < n_lp)
     int n_mpc;      // LP columns j < n_mpc have entries in the MPC rows; the rest only in X
+    // simplex problems: LP columns [psi0, psi0 + npsi) are the barycentric weights beta; the
+    // shared block holds -S, so on the MPC rows they act through psi = E beta
+    // (E[r][q] = R[q+1][r] - R[0][r], row-major p x p in LDS).  npsi = 0 for point problems.
+    const double* E;
+    double* yv;     // NP: psi-form copy of a vector / hand-off of psi-form column products
+    int psi0, npsi;
+    int nsx;        // extra rows 0..nsx-1 are the simplex rows (-beta_q <= 0, sum beta <= 1):
+                    // their normal-matrix terms are added analytically, rows >= nsx densely
 };
 constexpr int LDM = NP + 2;     // even: rows start 16-byte aligned (ds_read_b128 broadcasts)
 typedef double double2v __attribute__((ext_vector_type(2)));
@@ -215,7 +226,7 @@ constexpr size_t A_SQ = ((size_t)NP * LDM < 768) ? 768 : (size_t)NP * LDM;
 constexpr size_t A_DOUBLES = (A_MIN < A_SQ) ? A_SQ : A_MIN;
 __host__ __device__ inline size_t wave_lp_doubles(int n_lp, int ne) {
     const size_t ldx = ne ? ((size_t)ne | 1) : 0;
-    return ((A_DOUBLES + (size_t)n_lp * ldx + 6 * (size_t)NP) + 1) & ~(size_t)1;
+    return ((A_DOUBLES + (size_t)n_lp * ldx + 7 * (size_t)NP) + 1) & ~(size_t)1;
 }
 __device__ inline void carve_wave(Wave& W, double* base, int n_lp, int ne, int m) {
     W.n_lp = n_lp;
@@ -236,11 +247,20 @@ __device__ inline void carve_wave(Wave& W, double* base, int n_lp, int ne, int m
     W.xb = base;  base += NP;
     W.t = base;   base += NP;
     W.ub = base;  base += NP;
-    W.db = base;
+    W.db = base;  base += NP;
+    W.yv = base;
+    W.E = nullptr;
+    W.psi0 = n_lp;
+    W.npsi = 0;
+    W.nsx = 0;
 }
 
 __device__ __forceinline__ int wc_col(const Wave& W, int j) {
     return (j < W.n_lin) ? j : W.spec_col;
+}
+
+__device__ __forceinline__ double step_fraction(int attempt) {
+    return attempt == 0 ? EHM2_STEP_FRAC : (attempt == 1 ? EHM2_STEP_FRAC_SAFE : EHM2_STEP_FRAC_LAST);
 }
 
 struct IpmResult {
@@ -265,6 +285,7 @@ struct RowMap {
     const double* last_base;   // last slot: address of column 0 for this lane's row
     int last_stride;           // its column stride
     const double* last_spec;   // its address in the special column
+    bool last_extra;           // last slot: this lane's row is an extra row (beta-form vector)
     int lane;
 };
 __device__ __forceinline__ void make_rowmap(RowMap& rm, const Shared& S, const Wave& W, int lane) {
@@ -274,6 +295,7 @@ __device__ __forceinline__ void make_rowmap(RowMap& rm, const Shared& S, const W
     for (int sl = 0; sl < SLOTS - 1; ++sl) rm.valid[sl] = (lane + 64 * sl) < S.m;
     const int i = lane + 64 * (SLOTS - 1);
     const bool spec = W.n_lin < W.n_lp;
+    rm.last_extra = false;
     if (i < S.m) {
         rm.valid[SLOTS - 1] = true;
         rm.last_base = S.Wc + i;
@@ -281,6 +303,7 @@ __device__ __forceinline__ void make_rowmap(RowMap& rm, const Shared& S, const W
         rm.last_spec = S.Wc + (spec ? W.spec_col * S.lda : zero_off) + i;
     } else if (i >= W.xbase && i < W.xbase + W.ne) {
         rm.valid[SLOTS - 1] = true;
+        rm.last_extra = true;
         rm.last_base = W.X + (i - W.xbase);
         rm.last_stride = W.ldx;
         rm.last_spec = W.X + (size_t)W.n_lin * W.ldx + (i - W.xbase);
@@ -292,44 +315,67 @@ __device__ __forceinline__ void make_rowmap(RowMap& rm, const Shared& S, const W
     }
 }
 
-// out_i = sum_j A[i][j] v[j] for this lane's rows; v: n_lp doubles in LDS
-__device__ __forceinline__ void rows_times(const Shared& S, const Wave& W, const RowMap& rm,
+// psi-form copy of an LP vector: yv = T v with T = blockdiag(I, E, I)
+__device__ __forceinline__ void to_psi(const Wave& W, const double* v, int lane) {
+    if (lane < NP) {
+        double y = (lane < W.n_lp) ? v[lane] : 0.0;
+        const int r = lane - W.psi0;
+        if (r >= 0 && r < W.npsi) {
+            y = 0.0;
+            for (int q = 0; q < W.npsi; ++q) y = fma(W.E[r * W.npsi + q], v[W.psi0 + q], y);
+        }
+        W.yv[lane] = y;
+    }
+    wsync();
+}
+
+// out_i = sum_j A[i][j] v[j] for this lane's rows; v: n_lp doubles in LDS (beta-form).
+// The MPC rows see psi = E beta (shared block), the extra rows see beta itself.
+__device__ __forceinline__ void rows_times(const Shared& S, const Wave& W, int lane,
                                            const double* v, double (&out)[SLOTS]) {
+    RowMap rm;      // rebuilt per call from the pinned lane id: no long-lived address registers
+    make_rowmap(rm, S, W, lane);
+    to_psi(W, v, rm.lane);
+    const double* y = W.yv;
 #pragma unroll
     for (int sl = 0; sl < SLOTS; ++sl) out[sl] = 0.0;
     const double* pa = S.Wc + rm.lane;      // slots < SLOTS-1 : MPC rows, offset 64*sl
     const double* pb = rm.last_base;
+    const double* pv = rm.last_extra ? v : y;       // last slot: per-lane vector
     const int lda = S.lda;
-    // columns in groups of 4: 4*SLOTS matrix loads in flight per s_waitcnt
+    // columns in groups: UR*SLOTS matrix loads in flight per s_waitcnt
     const int str = rm.last_stride;
     int j = 0;
     constexpr int UR = EHM2_UNROLL;
     for (; j + UR - 1 < W.n_lin; j += UR) {
-        double a[UR][SLOTS], vj[UR];
+        double a[UR][SLOTS], yj[UR], vl[UR];
 #pragma unroll
         for (int u = 0; u < UR; ++u) {
-            vj[u] = v[j + u];
+            yj[u] = y[j + u];
+            vl[u] = lds1(pv + j + u);
 #pragma unroll
             for (int sl = 0; sl < SLOTS - 1; ++sl) a[u][sl] = lds1(pa + u * lda + 64 * sl);
             a[u][SLOTS - 1] = lds1(pb + u * str);
         }
 #pragma unroll
-        for (int u = 0; u < UR; ++u)
+        for (int u = 0; u < UR; ++u) {
 #pragma unroll
-            for (int sl = 0; sl < SLOTS; ++sl) out[sl] = fma(a[u][sl], vj[u], out[sl]);
+            for (int sl = 0; sl < SLOTS - 1; ++sl) out[sl] = fma(a[u][sl], yj[u], out[sl]);
+            out[SLOTS - 1] = fma(a[u][SLOTS - 1], vl[u], out[SLOTS - 1]);
+        }
         pa += UR * lda;
         pb += UR * str;
     }
     for (; j < W.n_lin; ++j) {
-        const double vj = v[j];
+        const double yj = y[j];
 #pragma unroll
-        for (int sl = 0; sl < SLOTS - 1; ++sl) out[sl] = fma(lds1(pa + 64 * sl), vj, out[sl]);
-        out[SLOTS - 1] = fma(lds1(pb), vj, out[SLOTS - 1]);
+        for (int sl = 0; sl < SLOTS - 1; ++sl) out[sl] = fma(lds1(pa + 64 * sl), yj, out[sl]);
+        out[SLOTS - 1] = fma(lds1(pb), lds1(pv + j), out[SLOTS - 1]);
         pa += lda;
         pb += str;
     }
     if (W.n_lin < W.n_lp) {
-        const double vj = v[W.n_lin];
+        const double vj = v[W.n_lin];       // the special column is not a beta column
         const double* ps = S.Wc + (size_t)W.spec_col * lda + rm.lane;
 #pragma unroll
         for (int sl = 0; sl < SLOTS - 1; ++sl) out[sl] = fma(ps[64 * sl], vj, out[sl]);
@@ -368,6 +414,16 @@ __device__ __forceinline__ void cols_times(const Shared& S, const Wave& W, const
                                            double& r1) {
     constexpr int nb = NP / 4;
     constexpr int ks = 64 / nb;
+    // the extra rows first (beta-form already): u0 / u1 may be overwritten by the partials
+    double ex0 = 0.0, ex1 = 0.0;
+    if (lane < W.n_lp && W.ne > 0) {
+        const double* xl = W.X + (size_t)lane * W.ldx;
+        for (int e = 0; e < W.ne; ++e) {
+            const double a = xl[e];
+            ex0 = fma(a, u0[W.xbase + e], ex0);
+            if (TWO) ex1 = fma(a, u1[W.xbase + e], ex1);
+        }
+    }
     const int cb = pin(lane % nb);
     const int h = pin(lane / nb);
     const bool active = h < ks;
@@ -404,18 +460,6 @@ __device__ __forceinline__ void cols_times(const Shared& S, const Wave& W, const
                 if (TWO) a1[q] = fma(a, v1, a1[q]);
             }
         }
-        const double* px[4];
-        block_cols_ext(S, W, pin(cb), px);     // derived only now: fewer live registers above
-        for (int e = h; e < W.ne; e += ks) {
-            const double v0 = u0[W.xbase + e];
-            const double v1 = TWO ? u1[W.xbase + e] : 0.0;
-#pragma unroll
-            for (int q = 0; q < 4; ++q) {
-                const double a = px[q][e];
-                a0[q] = fma(a, v0, a0[q]);
-                if (TWO) a1[q] = fma(a, v1, a1[q]);
-            }
-        }
     }
     // scratch[vec][q][h][cb]: consecutive lanes write consecutive doubles
     constexpr int plane = ks * nb;
@@ -440,6 +484,28 @@ __device__ __forceinline__ void cols_times(const Shared& S, const Wave& W, const
         }
     }
     wsync();
+    // psi-form -> beta-form on the weight columns:  g_beta = E^T g_psi
+    if (W.npsi > 0) {
+        const int r = lane - W.psi0;
+        if (r >= 0 && r < W.npsi) {
+            W.yv[r] = r0;
+            if (TWO) W.yv[W.npsi + r] = r1;
+        }
+        wsync();
+        if (r >= 0 && r < W.npsi) {
+            double g0 = 0.0, g1 = 0.0;
+            for (int k = 0; k < W.npsi; ++k) {
+                const double e = W.E[k * W.npsi + r];
+                g0 = fma(e, W.yv[k], g0);
+                if (TWO) g1 = fma(e, W.yv[W.npsi + k], g1);
+            }
+            r0 = g0;
+            r1 = g1;
+        }
+        wsync();
+    }
+    r0 += ex0;
+    r1 += ex1;
 }
 
 // M = A^T diag(dvec) A into W.M (full symmetric), dvec an m-vector in LDS.
@@ -499,11 +565,6 @@ __device__ __forceinline__ void form_blocks(const Shared& S, const Wave& W, cons
         }
 #endif
         for (; i < m; i += KS) EHM2_FORM_ROW(cj, ck, dvec, i)
-        const double* dx = dvec + W.xbase;
-        const double *xj[4], *xk[4];
-        block_cols_ext(S, W, pin(bj), xj);     // derived only now: fewer live registers above
-        block_cols_ext(S, W, pin(bk), xk);
-        for (int e = h; e < W.ne; e += KS) EHM2_FORM_ROW(xj, xk, dx, e)
 #undef EHM2_FORM_ROW
     }
     // slices h > 0 park their blocks in W.M ([slice][entry][pair]: lanes write consecutively)
@@ -539,15 +600,9 @@ __device__ __forceinline__ void form_blocks(const Shared& S, const Wave& W, cons
     }
 }
 
+// dext[e] = d of extra row e (the square matrix overwrites dvec before the extras are added)
 __device__ inline void form_normal_matrix(const Shared& S, const Wave& W, const double* dvec,
-                                          int lane) {
-    // the square matrix will overwrite dvec (region A): take what is needed from it first
-    double vspec = 0.0;
-    if (W.n_mpc < W.n_lp && lane < W.n_lp) {
-        const double* xc = W.X + (size_t)W.n_mpc * W.ldx;
-        const double* xl = W.X + (size_t)lane * W.ldx;
-        for (int e = 0; e < W.ne; ++e) vspec = fma(dvec[W.xbase + e] * xc[e], xl[e], vspec);
-    }
+                                          const double* dext, int lane) {
     const int nbA = (W.n_mpc + 3) >> 2;
     const int TA = nbA * (nbA + 1) / 2;
     const int ks = 64 / TA;     // TA <= 36
@@ -555,8 +610,7 @@ __device__ inline void form_normal_matrix(const Shared& S, const Wave& W, const 
     else if (ks == 3) form_blocks<3>(S, W, dvec, lane, nbA, TA);
     else if (ks == 2) form_blocks<2>(S, W, dvec, lane, nbA, TA);
     else form_blocks<1>(S, W, dvec, lane, nbA, TA);
-    // rows / columns 4*nbA .. NP-1: zero (dummy columns), except the columns that live only
-    // in the extra rows (the slack variable t): M[c][j] = sum_e d_e X[c][e] X[j][e]
+    // rows / columns 4*nbA .. NP-1 (no entries in the MPC rows): zero
     const int c0 = 4 * nbA;
     if (c0 < NP) {
         const int nrest = NP - c0;
@@ -566,14 +620,49 @@ __device__ inline void form_normal_matrix(const Shared& S, const Wave& W, const 
             if (c < nrest)
                 for (int r = lane >> 3; r < c0; r += 8) W.M[r * LDM + c0 + c] = 0.0;
         }
-        wsync();
-        if (W.n_mpc < W.n_lp && lane < W.n_lp) {      // at most one such column
-            const int c = W.n_mpc;
-            W.M[c * LDM + lane] = vspec;
-            W.M[lane * LDM + c] = vspec;
-        }
     }
     wsync();
+    // psi-form -> beta-form of the weight block:  M <- T^T M T,  T = blockdiag(I, E, I)
+    if (W.npsi > 0) {
+        const int np_ = W.npsi, p0 = W.psi0;
+        double tmp[8];
+        if (lane < NP) {            // columns: row `lane` times E
+            double* mr = W.M + lane * LDM + p0;
+#pragma unroll
+            for (int q = 0; q < 8; ++q) {
+                double a = 0.0;
+                if (q < np_)
+                    for (int r = 0; r < np_; ++r) a = fma(mr[r], W.E[r * np_ + q], a);
+                tmp[q] = a;
+            }
+#pragma unroll
+            for (int q = 0; q < 8; ++q)
+                if (q < np_) mr[q] = tmp[q];
+        }
+        wsync();
+        if (lane < NP) {            // rows: E^T times column `lane`
+            double* mc = W.M + p0 * LDM + lane;
+#pragma unroll
+            for (int q = 0; q < 8; ++q) {
+                double a = 0.0;
+                if (q < np_)
+                    for (int r = 0; r < np_; ++r) a = fma(W.E[r * np_ + q], mc[r * LDM], a);
+                tmp[q] = a;
+            }
+#pragma unroll
+            for (int q = 0; q < 8; ++q)
+                if (q < np_) mc[q * LDM] = tmp[q];
+        }
+        wsync();
+        // the simplex rows  -beta_q <= 0,  sum beta <= 1  (extra rows 0..npsi): their term
+        // sum_e d_e a_e a_e^T  is  diag(d_q) + d_sum 1 1^T  on the weight block
+        if (lane < np_) {
+            const double dsum = dext[np_];
+            double* mr = W.M + (p0 + lane) * LDM + p0;
+            for (int q = 0; q < np_; ++q) mr[q] += dsum + ((q == lane) ? dext[lane] : 0.0);
+        }
+        wsync();
+    }
 }
 
 // Row-owned elimination of the n x n normal matrix (lane j holds row j in registers), pivot
@@ -768,7 +857,10 @@ __device__ inline IpmResult ipm_solve(const Shared& S, const Wave& W, const doub
         for (int sl = 0; sl < SLOTS; ++sl)
             if (rm.valid[sl]) W.vm0[lane + 64 * sl] = lam[sl] * rs[sl];
         wsync();
-        form_normal_matrix(S, W, W.vm0, lane);
+        // d of the extra rows, for the terms added after the MPC part (W.ub is free here)
+        if (rm.last_extra) W.ub[lane + 64 * (SLOTS - 1) - W.xbase] = lam[SLOTS - 1] * rs[SLOTS - 1];
+        wsync();
+        form_normal_matrix(S, W, W.vm0, W.ub, lane);
         lane = pin(lane0);
         double row[NP];
         {
@@ -776,7 +868,21 @@ __device__ inline IpmResult ipm_solve(const Shared& S, const Wave& W, const doub
             const double* mrow = W.M + ((lane < NP) ? lane : (NP - 1)) * LDM;
 #pragma unroll
             for (int q = 0; q < NP; ++q) row[q] = mrow[q];
-            if (lane < NP) W.db[lane] = mrow[lane];
+            // dense extra rows (suboptimality rows, phase-one bound): rank-one terms; dg follows
+            // the diagonal (original diagonal for the dependent-pivot guard)
+            double dg = mrow[(lane < NP) ? lane : (NP - 1)];
+            for (int e = W.nsx; e < W.ne; ++e) {
+                const double xl = (lane < W.n_lp) ? W.X[(size_t)lane * W.ldx + e] : 0.0;
+                const double ce = W.ub[e] * xl;
+                dg = fma(ce, xl, dg);
+#pragma unroll
+                for (int q = 0; q < NP; ++q) {
+                    const double xq = (q < W.n_lp) ? W.X[(size_t)q * W.ldx + e] : 0.0;
+                    row[q] = fma(ce, xq, row[q]);
+                    if ((q & 3) == 3) __builtin_amdgcn_sched_barrier(0);   // register budget
+                }
+            }
+            if (lane < NP) W.db[lane] = dg;
         }
         wsync();
         lu_factor(row, W, lane);
@@ -787,7 +893,7 @@ __device__ inline IpmResult ipm_solve(const Shared& S, const Wave& W, const doub
         const double rhs_aff = (lane < n) ? (-cjj - atdr) : 0.0;
         double dxj = lu_solve(row, W, rinv_l, rhs_aff, lane);
         double adx[SLOTS];
-        rows_times(S, W, rm, W.t, adx);
+        rows_times(S, W, lane, W.t, adx);
         double ds_a[SLOTS], dl_a[SLOTS];
         double rho_p = 0.0, rho_d = 0.0;
 #pragma unroll
@@ -824,7 +930,7 @@ __device__ inline IpmResult ipm_solve(const Shared& S, const Wave& W, const doub
         cols_times<false>(S, W, W.vm1, W.vm1, W.sc, lane, atc, dummy);
         const double rhs = (lane < n) ? (rhs_aff + atc) : 0.0;
         dxj = lu_solve(row, W, rinv_l, rhs, lane);
-        rows_times(S, W, rm, W.t, adx);
+        rows_times(S, W, lane, W.t, adx);
         double ds[SLOTS], dl[SLOTS];
         rho_p = 0.0;
         rho_d = 0.0;

@@ -18,8 +18,8 @@ namespace EHM2_NS {
 // ---------------------------------------------------------------------------------------
 struct NodeBuf {
     double* rec;    // node record / simplex vertices (+ vertex costs)
-    double* aug;    // p x 2p Gauss-Jordan tableau
-    double* F;      // p x p inverse of the edge matrix
+    double* aug;    // (unused scratch)
+    double* F;      // p x p edge matrix E[r][q] = R[q+1][r] - R[0][r]
     double* th;     // p doubles (parameter / midpoint)
     double* lp;     // start of the LP workspace
 };
@@ -30,67 +30,6 @@ __device__ __forceinline__ void carve_node(NodeBuf& nb, double* base, int p, int
     nb.F = nb.aug + 2 * p * p;
     nb.th = nb.F + p * p;
     nb.lp = base + k2_node_doubles(p, n_u);
-}
-
-// F = E^-1 with E[r][q] = R[q+1][r] - R[0][r]  (beta = F psi, psi = theta - R0)
-// Gauss-Jordan with partial pivoting on the p x 2p tableau; lanes = (row lane>>4 [+4], column
-// lane&15): no division by run-time sizes anywhere (p <= 8).
-__device__ inline void simplex_inverse(const double* R, int p, double* aug, double* F, int lane) {
-    const int w = 2 * p;
-    const int c = lane & 15, r0 = lane >> 4;
-#pragma unroll
-    for (int u = 0; u < 2; ++u) {
-        const int r = r0 + 4 * u;
-        if (r < p && c < w)
-            aug[r * w + c] = (c < p) ? (R[(c + 1) * p + r] - R[r]) : ((c - p == r) ? 1.0 : 0.0);
-    }
-    wsync();
-    for (int k = 0; k < p; ++k) {
-        int piv = k;
-        double best = fabs(aug[k * w + k]);
-        for (int r = k + 1; r < p; ++r) {
-            const double v = fabs(aug[r * w + k]);
-            if (v > best) {
-                best = v;
-                piv = r;
-            }
-        }
-        double a_k = 0.0, a_p = 0.0;
-        if (lane < w) {
-            a_k = aug[k * w + lane];
-            a_p = aug[piv * w + lane];
-        }
-        wsync();
-        if (lane < w && piv != k) {
-            aug[k * w + lane] = a_p;
-            aug[piv * w + lane] = a_k;
-        }
-        wsync();
-        const double rp = 1.0 / aug[k * w + k];
-        double fac[2], rk[2], cur[2];
-#pragma unroll
-        for (int u = 0; u < 2; ++u) {
-            const int r = r0 + 4 * u;
-            fac[u] = rk[u] = cur[u] = 0.0;
-            if (r < p && c < w) {
-                fac[u] = aug[r * w + k];
-                rk[u] = aug[k * w + c] * rp;
-                cur[u] = aug[r * w + c];
-            }
-        }
-        wsync();
-#pragma unroll
-        for (int u = 0; u < 2; ++u) {
-            const int r = r0 + 4 * u;
-            if (r < p && c < w) aug[r * w + c] = (r == k) ? rk[u] : fma(-fac[u], rk[u], cur[u]);
-        }
-        wsync();
-    }
-    {
-        const int q = lane >> 3, r = lane & 7;
-        if (q < p && r < p) F[q * p + r] = aug[q * w + p + r];
-    }
-    wsync();
 }
 
 // P_theta_delta at one parameter value (lib/oracle.py:141-173) or its phase-one form
@@ -123,12 +62,15 @@ __device__ inline void assemble_point(const Shared& S, Wave& W, double* lp_base,
     wsync();
 }
 
-// Problems over a simplex R (rows = vertices, in LDS) in the variables (z, psi[, t]) with
-// psi = theta - R0, beta = F psi >= 0, sum beta <= 1:
+// Problems over a simplex R (rows = vertices, in LDS) in the variables (z, beta[, t]) with
+// theta = R0 + E beta, beta >= 0, sum beta <= 1 (E[r][q] = R[q+1][r] - R0[r]):
 //   SX_MIN   : min V                                              (lib/oracle.py:74-79)
 //   SX_SLACK : max t  s.t.  Vbar0 + dV^T beta - V - eps_a >= t,
 //                           Vbar0 + dV^T beta - (1+eps_r) V >= t   (lib/oracle.py:89-97)
 //   SX_FEAS  : min tau s.t. MPC rows relaxed by tau, tau >= -1
+// The MPC rows  G z - S E beta <= w + S R0  are not stored: the solver applies the shared
+// block [G | -S] to psi = E beta (ehm_ipm2.h).  Extra rows: e < p facets -beta_e <= 0, e = p
+// sum beta <= 1, then the dense ones.
 __device__ inline void assemble_simplex(const Shared& S, Wave& W, const NodeBuf& nb,
                                         const double* R, const double* Vbar, int mode,
                                         double eps_a, double eps_r, double (&b)[SLOTS],
@@ -142,27 +84,25 @@ __device__ inline void assemble_simplex(const Shared& S, Wave& W, const NodeBuf&
     W.n_lin = n + p;
     W.spec_col = slack ? (n + p + 1) : (n + p);   // zeros for t, -1 for tau
     W.n_mpc = slack ? (n + p) : n_lp;
-    simplex_inverse(R, p, nb.aug, nb.F, lane);
-    const double* F = nb.F;
+    W.E = nb.F;
+    W.psi0 = n;
+    W.npsi = p;
+    W.nsx = p + 1;
     const int ldx = W.ldx;
     for (int k = lane; k < n_lp * ldx; k += 64) W.X[k] = 0.0;
     if (lane < NP) W.c[lane] = 0.0;
-    wsync();
-    // facets  -beta_e <= 0
-    {
-        const int e = lane >> 3, r = lane & 7;
-        if (e < p && r < p) W.X[(n + r) * ldx + e] = -F[e * p + r];
+    {   // edge matrix
+        const int r = lane >> 3, q = lane & 7;
+        if (r < p && q < p) nb.F[r * p + q] = R[(q + 1) * p + r] - R[r];
     }
+    wsync();
     if (lane < p) {
-        double sF = 0.0, dvF = 0.0;
-        for (int q = 0; q < p; ++q) {
-            sF += F[q * p + lane];
-            if (slack) dvF = fma(Vbar[q + 1] - Vbar[0], F[q * p + lane], dvF);
-        }
-        W.X[(n + lane) * ldx + p] = sF;                 // sum beta <= 1
+        W.X[(n + lane) * ldx + lane] = -1.0;            // -beta_q <= 0
+        W.X[(n + lane) * ldx + p] = 1.0;                // sum beta <= 1
         if (slack) {
-            W.X[(n + lane) * ldx + p + 1] = -dvF;
-            W.X[(n + lane) * ldx + p + 2] = -dvF;
+            const double dv = Vbar[lane + 1] - Vbar[0];
+            W.X[(n + lane) * ldx + p + 1] = -dv;
+            W.X[(n + lane) * ldx + p + 2] = -dv;
         }
     }
     if (slack) {
@@ -258,12 +198,12 @@ __global__ __launch_bounds__(EHM_K2_THREADS) void k2_point_batch(
             Wave W;
             IpmResult r;
             int its = 0;
-            for (int attempt = 0; attempt < 2; ++attempt) {     // see EHM2_STEP_FRAC
+            for (int attempt = 0; attempt < EHM2_ATTEMPTS; ++attempt) {     // see EHM2_STEP_FRAC
                 double b[SLOTS];
                 const int ln = pin(lane);     // nothing of the assembly outlives the attempt
                 assemble_point(S, W, nb.lp, nb.th, feas != 0, b, ln);
                 r = ipm_solve(S, W, b, ln, false,
-                              attempt ? EHM2_STEP_FRAC_SAFE : EHM2_STEP_FRAC);
+                              step_fraction(attempt));
                 its += r.iters;
                 if (r.status == 0) break;
             }
@@ -314,12 +254,12 @@ __global__ __launch_bounds__(EHM_K2_THREADS) void k2_simplex_batch(
             Wave W;
             IpmResult r;
             int its = 0;
-            for (int attempt = 0; attempt < 2; ++attempt) {
+            for (int attempt = 0; attempt < EHM2_ATTEMPTS; ++attempt) {
                 double b[SLOTS];
                 const int ln = pin(lane);
                 assemble_simplex(S, W, nb, Rl, Vl, mode, P.eps_a, P.eps_r, b, ln);
                 r = ipm_solve(S, W, b, ln, false,
-                              attempt ? EHM2_STEP_FRAC_SAFE : EHM2_STEP_FRAC);
+                              step_fraction(attempt));
                 its += r.iters;
                 if (r.status == 0) break;
             }
@@ -331,9 +271,7 @@ __global__ __launch_bounds__(EHM_K2_THREADS) void k2_simplex_batch(
                 if (iters) iters[inst] = r.iters;
             }
             if (alpha) {
-                double beta = 0.0;
-                if (lane < p)
-                    for (int q = 0; q < p; ++q) beta = fma(nb.F[lane * p + q], W.xb[P.n + q], beta);
+                const double beta = (lane < p) ? W.xb[P.n + lane] : 0.0;
                 const double sb = wave_sum(beta);
                 if (lane < p) alpha[inst * (p + 1) + lane + 1] = beta;
                 if (lane == 0) alpha[inst * (p + 1)] = 1.0 - sb;
@@ -369,13 +307,13 @@ __global__ __launch_bounds__(EHM_K2_THREADS) void k2_lcss_decide(
         Wave W;
         IpmResult r;
         int its = 0;
-        for (int attempt = 0; attempt < 2; ++attempt) {
+        for (int attempt = 0; attempt < EHM2_ATTEMPTS; ++attempt) {
             double b[SLOTS];
             const int ln = pin(lane);
             assemble_simplex(S, W, nb, nb.rec, nb.rec + rec_off_vcost(P.p), SX_SLACK, P.eps_a,
                              P.eps_r, b, ln);
             r = ipm_solve(S, W, b, ln, sign_only != 0,
-                          attempt ? EHM2_STEP_FRAC_SAFE : EHM2_STEP_FRAC);
+                          step_fraction(attempt));
             its += r.iters;
             if (r.status == 0) break;
         }
@@ -435,11 +373,11 @@ __global__ __launch_bounds__(EHM_K2_THREADS) void k2_lcss_expand(
         Wave W;
         IpmResult r;
         int its = 0;
-        for (int attempt = 0; attempt < 2; ++attempt) {
+        for (int attempt = 0; attempt < EHM2_ATTEMPTS; ++attempt) {
             double b[SLOTS];
             const int ln = pin(lane);
             assemble_point(S, W, nb.lp, mid, false, b, ln);
-            r = ipm_solve(S, W, b, ln, false, attempt ? EHM2_STEP_FRAC_SAFE : EHM2_STEP_FRAC);
+            r = ipm_solve(S, W, b, ln, false, step_fraction(attempt));
             its += r.iters;
             if (r.status == 0) break;
         }
@@ -516,11 +454,11 @@ __global__ __launch_bounds__(EHM_K2_THREADS) void k2_vertex_solve(
         Wave W;
         IpmResult r;
         int its = 0;
-        for (int attempt = 0; attempt < 2; ++attempt) {
+        for (int attempt = 0; attempt < EHM2_ATTEMPTS; ++attempt) {
             double b[SLOTS];
             const int ln = pin(lane);
             assemble_point(S, W, nb.lp, nb.th, false, b, ln);
-            r = ipm_solve(S, W, b, ln, false, attempt ? EHM2_STEP_FRAC_SAFE : EHM2_STEP_FRAC);
+            r = ipm_solve(S, W, b, ln, false, step_fraction(attempt));
             its += r.iters;
             if (r.status == 0) break;
         }

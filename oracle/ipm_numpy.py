@@ -120,7 +120,8 @@ def chol_solve(L, rhs):
 
 
 STEP_FRAC = 0.999       # generation-2 kernels (ehm_ipm2.h); generation 1 uses STEP_FRAC_SAFE
-STEP_FRAC_SAFE = 0.99   # a solve that stalls with STEP_FRAC is repeated with this one
+STEP_FRAC_SAFE = 0.99   # a solve that stalls with STEP_FRAC is repeated with this one,
+STEP_FRAC_LAST = 0.9    # and once more with this one (hybrid instances, a few per 1e7)
 
 
 def solve_lp(c, A, b, max_iter=40, tol_res=1e-10, tol_gap=1e-10, step_frac=None,
@@ -132,11 +133,13 @@ def solve_lp(c, A, b, max_iter=40, tol_res=1e-10, tol_gap=1e-10, step_frac=None,
     step_frac=None: STEP_FRAC first, STEP_FRAC_SAFE if that stalls (ipm_solve_retry).
     """
     if step_frac is None:
-        out = solve_lp(c, A, b, max_iter, tol_res, tol_gap, STEP_FRAC, prox)
-        if out.status != 0:
-            it = out.iters
-            out = solve_lp(c, A, b, max_iter, tol_res, tol_gap, STEP_FRAC_SAFE, prox)
-            out.iters += it
+        it = 0
+        for sf in (STEP_FRAC, STEP_FRAC_SAFE, STEP_FRAC_LAST):
+            out = solve_lp(c, A, b, max_iter, tol_res, tol_gap, sf, prox)
+            it += out.iters
+            if out.status == 0:
+                break
+        out.iters = it
         return out
     m, n = A.shape
     x = np.zeros(n)

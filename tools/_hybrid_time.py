@@ -22,4 +22,5 @@ for af, er in ((0.5, 1.0), (0.25, 0.3)):
     s1 = gp.stats()
     print('abs_frac %.2f eps_r %.2f: nodes %s  LP %d  launches %d  wall %.3fs  %.3g LP/s' % (
         af, er, (flat.n_nodes if flat else '>150000'), s1['lp_solves'] - s0['lp_solves'],
-        s1['kernel_launches'] - s0['kernel_launches'], dt, (s1['lp_solves'] - s0['lp_solves']) / dt))
+        s1['kernel_launches'] - s0['kernel_launches'], dt, (s1['lp_solves'] - s0['lp_solves']) / dt),
+        'stalled', s1['stalled'] - s0['stalled'], 'fallbacks', s1['fallbacks'] - s0['fallbacks'])
