@@ -138,6 +138,26 @@ typedef __attribute__((address_space(3))) const volatile double lds_cvdouble;
 __device__ __forceinline__ double lds1(const double* p) {
     return *(lds_cvdouble*)p;      // explicit LDS pointer: a volatile generic load stays flat
 }
+// A wave-uniform double parked in an SGPR pair: there is no scalar FP unit, so uniform doubles
+// (norms, tolerances, the best merit) otherwise occupy two VGPRs each for the whole solve.
+// (The empty asm pins the register class: hipcc folds readfirstlane of a value it knows to be
+// uniform -- literals included -- and then keeps the f64 in a hoisted VGPR pair again.)
+__device__ __forceinline__ double uniform_d(double v) {
+    int lo, hi;
+    // explicit v_readfirstlane: the builtin is folded away for values hipcc knows to be uniform
+    // (they then stay in VGPRs); nops: VGPR write -> readfirstlane, SGPR write -> VALU read
+    asm("s_nop 0\n\tv_readfirstlane_b32 %0, %2\n\tv_readfirstlane_b32 %1, %3\n\ts_nop 1"
+        : "=s"(lo), "=s"(hi)
+        : "v"(__double2loint(v)), "v"(__double2hiint(v)));
+    return __hiloint2double(hi, lo);
+}
+// An f64 literal materialised with two s_mov right where it is used: as a VALU literal it would
+// be a hoisted v_mov pair that lives (or spills) across the whole kernel.
+__device__ __forceinline__ double const_d(double literal) {
+    int lo = __double2loint(literal), hi = __double2hiint(literal);
+    asm volatile("" : "+s"(lo), "+s"(hi));
+    return __hiloint2double(hi, lo);
+}
 // 1/x for positive finite x well inside the normal range: v_rcp_f64 + two Newton steps
 __device__ __forceinline__ double frcp(double x) {
     double r = __builtin_amdgcn_rcp(x);
@@ -687,8 +707,8 @@ __device__ __forceinline__ void lu_factor(double (&row)[NP], const Wave& W, int 
         wsync();
         double piv = U[uoff(k) + k];
         const double orig = W.db[k];
-        const bool bad = !(piv > EHM2_PIVOT_REL * orig) || !(piv > 0.0);
-        piv = bad ? EHM2_PIVOT_BIG : piv;
+        const bool bad = !(piv > const_d(EHM2_PIVOT_REL) * orig) || !(piv > 0.0);
+        piv = bad ? const_d(EHM2_PIVOT_BIG) : piv;
         const double rinv = frcp(piv);
         if (lane == 0) W.db[k] = rinv;
         const double l = row[k] * rinv;
@@ -765,9 +785,10 @@ __device__ inline IpmResult ipm_solve(const Shared& S, const Wave& W, const doub
         lam[sl] = rm.valid[sl] ? 1.0 : 0.0;
         bmax = fmax(bmax, fabs(v[sl]));
     }
-    const double bnorm = 1.0 + wave_max(bmax);
+    const double bnorm = uniform_d(1.0 + wave_max(bmax));
     const double cj = (lane < n) ? W.c[lane] : 0.0;
-    const double cnorm = 1.0 + wave_max(fabs(cj));
+    const double cnorm = uniform_d(1.0 + wave_max(fabs(cj)));
+    step_frac = uniform_d(step_frac);
     if (lane < NP) {
         W.x[lane] = 0.0;
         W.xb[lane] = 0.0;
@@ -784,11 +805,11 @@ __device__ inline IpmResult ipm_solve(const Shared& S, const Wave& W, const doub
 
     IpmResult res;
     res.obj = 0.0;
-    res.merit = 1e300;
+    res.merit = const_d(1e300);
     res.iters = 0;
     res.status = 1;
     int stall = 0;
-    const double inv_m = 1.0 / (double)m_lp;
+    const double inv_m = uniform_d(1.0 / (double)m_lp);
 
     for (int it = 0; it <= EHM2_MAX_ITER; ++it) {
         lane = pin(lane0);      // per-lane addresses are re-derived every iteration (see pin)
@@ -822,13 +843,13 @@ __device__ inline IpmResult ipm_solve(const Shared& S, const Wave& W, const doub
         const double dobj = -wave_sum(vl_sum + xjj * atl);
         const double pobj = wave_sum(cjj * xjj);
         const double e_g = fabs(pobj - dobj) / (1.0 + fabs(pobj));
-        const double merit = fmax(emax / EHM2_TOL_RES, e_g / EHM2_TOL_GAP);
+        const double merit = fmax(emax / const_d(EHM2_TOL_RES), e_g / const_d(EHM2_TOL_GAP));
         if (merit < res.merit) {
-            res.merit = merit;
-            res.obj = pobj;
+            res.merit = uniform_d(merit);
+            res.obj = uniform_d(pobj);
             stall = 0;
             if (lane < NP) W.xb[lane] = W.x[lane];
-        } else if (res.merit < EHM2_STALL_ZONE) {
+        } else if (res.merit < const_d(EHM2_STALL_ZONE)) {
             ++stall;
         }
         res.iters = it;
@@ -836,10 +857,10 @@ __device__ inline IpmResult ipm_solve(const Shared& S, const Wave& W, const doub
             res.status = 0;
             break;
         }
-        if (sign_only && emax <= EHM2_SIGN_RES && pobj * dobj > 0.0) {
+        if (sign_only && emax <= const_d(EHM2_SIGN_RES) && pobj * dobj > 0.0) {
             const double lo = fmin(fabs(pobj), fabs(dobj));
-            if (fabs(pobj - dobj) <= EHM2_SIGN_GAP * lo &&
-                emax * (1.0 + fabs(pobj)) <= EHM2_SIGN_RES_REL * lo) {
+            if (fabs(pobj - dobj) <= const_d(EHM2_SIGN_GAP) * lo &&
+                emax * (1.0 + fabs(pobj)) <= const_d(EHM2_SIGN_RES_REL) * lo) {
                 res.obj = pobj;
                 res.merit = merit;
                 res.margin = lo;
@@ -960,7 +981,7 @@ __device__ inline IpmResult ipm_solve(const Shared& S, const Wave& W, const doub
         wsync();
     }
     wsync();
-    if (res.status != 0 && res.merit <= EHM2_ACCEPT_MERIT) res.status = 0;
+    if (res.status != 0 && res.merit <= const_d(EHM2_ACCEPT_MERIT)) res.status = 0;
     res.margin = fabs(res.obj);
     return res;
 }

@@ -97,8 +97,8 @@ __device__ inline void assemble_simplex(const Shared& S, Wave& W, const NodeBuf&
     }
     wsync();
     if (lane < p) {
-        W.X[(n + lane) * ldx + lane] = -1.0;            // -beta_q <= 0
-        W.X[(n + lane) * ldx + p] = 1.0;                // sum beta <= 1
+        W.X[(n + lane) * ldx + lane] = const_d(-1.0);   // -beta_q <= 0
+        W.X[(n + lane) * ldx + p] = const_d(1.0);       // sum beta <= 1
         if (slack) {
             const double dv = Vbar[lane + 1] - Vbar[0];
             W.X[(n + lane) * ldx + p + 1] = -dv;
@@ -112,14 +112,14 @@ __device__ inline void assemble_simplex(const Shared& S, Wave& W, const NodeBuf&
             W.X[lane * ldx + p + 2] = fma(eps_r, cj, cj);     // (1 + eps_r) c_j
         }
         if (lane == 0) {
-            W.X[(n + p) * ldx + p + 1] = 1.0;
-            W.X[(n + p) * ldx + p + 2] = 1.0;
-            W.c[n + p] = -1.0;
+            W.X[(n + p) * ldx + p + 1] = const_d(1.0);
+            W.X[(n + p) * ldx + p + 2] = const_d(1.0);
+            W.c[n + p] = const_d(-1.0);
         }
     } else if (feas) {
         if (lane == 0) {
-            W.X[(n + p) * ldx + p + 1] = -1.0;          // -tau <= 1
-            W.c[n + p] = 1.0;
+            W.X[(n + p) * ldx + p + 1] = const_d(-1.0);   // -tau <= 1
+            W.c[n + p] = const_d(1.0);
         }
     } else if (lane < n) {
         W.c[lane] = S.cv[lane];
