@@ -36,6 +36,15 @@
 #ifndef EHM2_UNROLL
 #define EHM2_UNROLL 2
 #endif
+// 1: normal matrix of the MPC rows on the matrix cores (form_mfma), 0: vector FMAs (form_blocks).
+// Measured on the bench tree (MI355X): identical results, decide sweep 59 ms either way, expand
+// sweep 35 ms (MFMA) vs 32 ms (vector) -- v_mfma_f64_16x16x4 issues every 64 cycles, the tiles
+// compute 1024 entries for the 300 (decide) / 210 (expand) distinct ones, and with vector pipe
+// and LDS already shared by three wavefronts the longer per-wavefront chain costs what the
+// off-load frees.  Kept selectable: it is the path for n > 32.
+#ifndef EHM2_FORM_MFMA
+#define EHM2_FORM_MFMA 0
+#endif
 #ifndef EHM2_LU_CHUNK
 #define EHM2_LU_CHUNK 8
 #endif
@@ -620,9 +629,66 @@ __device__ __forceinline__ void form_blocks(const Shared& S, const Wave& W, cons
     }
 }
 
+// The same contraction on the matrix cores: M_mpc = W^T diag(d) W over the columns that have MPC
+// entries, as 16x16 output tiles of v_mfma_f64_16x16x4_f64 (K = 4 rows per instruction).
+// Operand layout (one f64 per lane): A[i = lane%16][k = lane/16] = d_k W[k][16I + i],
+// B[k = lane/16][j = lane%16] = W[k][16J + j]; result D[(lane>>4) + 4r][lane&15], r = 0..3.
+// Two column panels (<= 32 columns) give the tiles (0,0), (1,0), (1,1); the matrix pipe is
+// otherwise idle in this kernel while the vector pipe and the LDS are the bottleneck, and a
+// K-step needs 3 LDS loads and 2 multiplies instead of 9 loads and 20 vector FMAs per row.
+// FP64 MFMA runs at the vector-FMA rate on MI355X and the tiles compute both triangles: this
+// is an off-load, not a flop saving.
+typedef double double4v __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ void form_mfma(const Shared& S, const Wave& W, const double* dvec,
+                                          int lane, int ncols) {
+    const int li = lane & 15, lk = lane >> 4;
+    const bool two = ncols > 16;
+    const double* zero = S.Wc + (size_t)(S.ncw - 1) * S.lda;
+    const int j0 = li, j1 = 16 + li;
+    const double* p0 = (j0 < ncols) ? (S.Wc + (size_t)wc_col(W, j0) * S.lda) : zero;
+    const double* p1 = (j1 < ncols) ? (S.Wc + (size_t)wc_col(W, j1) * S.lda) : zero;
+    double4v c00 = {0.0, 0.0, 0.0, 0.0}, c10 = {0.0, 0.0, 0.0, 0.0}, c11 = {0.0, 0.0, 0.0, 0.0};
+    const int m = S.m;
+    for (int i0 = 0; i0 < m; i0 += 4) {
+        const int i = i0 + lk;
+        const bool in = i < m;
+        const int ic = in ? i : (m - 1);
+        const double d = in ? lds1(dvec + ic) : 0.0;
+        const double w0 = lds1(p0 + ic);
+        const double a0 = w0 * d;
+        c00 = __builtin_amdgcn_mfma_f64_16x16x4f64(a0, w0, c00, 0, 0, 0);
+        if (two) {      // wave-uniform
+            const double w1 = lds1(p1 + ic);
+            const double a1 = w1 * d;
+            c10 = __builtin_amdgcn_mfma_f64_16x16x4f64(a1, w0, c10, 0, 0, 0);
+            c11 = __builtin_amdgcn_mfma_f64_16x16x4f64(a1, w1, c11, 0, 0, 0);
+        }
+    }
+    wsync();
+    // D[(lane>>4) + 4r][lane&15] of every tile; rows / columns >= NP do not exist
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+        const int row = lk + 4 * r, col = li;
+        if (row < NP && col < NP) W.M[row * LDM + col] = c00[r];
+        if (two) {
+            if (16 + row < NP && col < NP) {
+                W.M[(16 + row) * LDM + col] = c10[r];
+                W.M[col * LDM + 16 + row] = c10[r];
+            }
+            if (16 + row < NP && 16 + col < NP) W.M[(16 + row) * LDM + 16 + col] = c11[r];
+        }
+    }
+}
+
 // dext[e] = d of extra row e (the square matrix overwrites dvec before the extras are added)
 __device__ inline void form_normal_matrix(const Shared& S, const Wave& W, const double* dvec,
                                           const double* dext, int lane) {
+#if EHM2_FORM_MFMA
+    // columns >= n_mpc are zero columns for the tiles; what they leave in W.M is zero too.
+    // A single panel (n_mpc <= 16) writes rows / columns 0..15 only.
+    const int nbA = (W.n_mpc > 16 || NP <= 16) ? (NP >> 2) : 4;
+    form_mfma(S, W, dvec, lane, W.n_mpc);
+#else
     const int nbA = (W.n_mpc + 3) >> 2;
     const int TA = nbA * (nbA + 1) / 2;
     const int ks = 64 / TA;     // TA <= 36
@@ -630,6 +696,7 @@ __device__ inline void form_normal_matrix(const Shared& S, const Wave& W, const 
     else if (ks == 3) form_blocks<3>(S, W, dvec, lane, nbA, TA);
     else if (ks == 2) form_blocks<2>(S, W, dvec, lane, nbA, TA);
     else form_blocks<1>(S, W, dvec, lane, nbA, TA);
+#endif
     // rows / columns 4*nbA .. NP-1 (no entries in the MPC rows): zero
     const int c0 = 4 * nbA;
     if (c0 < NP) {
