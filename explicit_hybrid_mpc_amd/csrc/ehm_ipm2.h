@@ -876,7 +876,9 @@ __device__ inline IpmResult ipm_solve(const Shared& S, const Wave& W, const doub
     res.iters = 0;
     res.status = 1;
     int stall = 0;
-    const double inv_m = uniform_d(1.0 / (double)m_lp);
+    int m_op = __builtin_amdgcn_readfirstlane(m_lp);
+    asm volatile("" : "+s"(m_op));      // keeps the reciprocal below out of the kernel prologue
+    const double inv_m = uniform_d(frcp((double)m_op));
 
     for (int it = 0; it <= EHM2_MAX_ITER; ++it) {
         lane = pin(lane0);      // per-lane addresses are re-derived every iteration (see pin)
