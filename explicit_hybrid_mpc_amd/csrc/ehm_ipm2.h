@@ -232,7 +232,8 @@ struct Wave {
     int nsx;        // extra rows 0..nsx-1 are the simplex rows (-beta_q <= 0, sum beta <= 1):
                     // their normal-matrix terms are added analytically, rows >= nsx densely
 };
-constexpr int LDM = NP + 2;     // even: rows start 16-byte aligned (ds_read_b128 broadcasts)
+constexpr int LDM = NP + 1;     // odd: row- and column-wise access of the square matrix are both
+                                // bank-conflict free (the factor U is kept packed, see below)
 typedef double double2v __attribute__((ext_vector_type(2)));
 
 // Packed upper-triangular factor: row k keeps its columns (k & ~1) .. NP-1 (an even start keeps
