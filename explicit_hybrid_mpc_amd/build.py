@@ -3,10 +3,11 @@ Builds ``explicit_hybrid_mpc_amd/lib/libehmpc.so`` (HIP kernels + C-ABI, include
 for gfx950 with hipcc.  hipcc cross-compiles without a GPU, so this also runs in the
 CPU-only build container.
 
-Objects: ``ehm_capi.hip`` (C-ABI, host orchestration, generation-1 kernels) and one
+Objects: ``ehm_capi.hip`` (C-ABI, host orchestration, generation-1 kernels), one
 instance of ``ehm_k2.hip`` per (column capacity NP, row slots) pair -- the solver keeps a
 row of the normal matrix and the LP's row vectors in registers, so both are compile-time
-sizes.  The objects are compiled in parallel and cached under ``lib/obj``.
+sizes -- and the wide kernels ``ehm_k3.hip`` per row capacity.  The objects are compiled
+in parallel and cached under ``lib/obj``.
 """
 
 import os
@@ -19,11 +20,14 @@ SRC_DIR = os.path.join(HERE, 'csrc')
 LIB_DIR = os.path.join(HERE, 'lib')
 OBJ_DIR = os.path.join(LIB_DIR, 'obj')
 LIB = os.path.join(LIB_DIR, 'libehmpc.so')
-HEADERS = ['ehm_ipm.h', 'ehm_kernels.h', 'ehm_dev.h', 'ehm_k2.h', 'ehm_ipm2.h',
+HEADERS = ['ehm_ipm.h', 'ehm_kernels.h', 'ehm_dev.h', 'ehm_k2.h', 'ehm_ipm2.h', 'ehm_ipm3.h',
            os.path.join('..', '..', 'include', 'ehmpc.h')]
 # must match EHM_K2_ALL in ehm_capi.hip
 K2_NPS = (8, 12, 16, 20, 24, 28, 32)
 K2_SLOTS = (1, 2, 3, 4)
+# wide kernels (ehm_k3.hip): row slots per thread, rows <= 256 * slots; must match the
+# ehm_k3_api_* getters in ehm_capi.hip
+K3_RS = (2, 4)
 FLAGS = ['--offload-arch=gfx950', '-O3', '-std=c++17', '-fPIC', '-Wno-unused-result']
 # experiments: extra -D flags and an alternative output name, e.g.
 #   EHM_BUILD_FLAGS="-DEHM2_UNROLL=2" EHM_BUILD_TAG=u2 python -m explicit_hybrid_mpc_amd.build
@@ -56,6 +60,9 @@ def _objects():
             objs.append((os.path.join(OBJ_DIR, 'ehm_k2_%d_%d.o' % (np_, sl)),
                          os.path.join(SRC_DIR, 'ehm_k2.hip'),
                          ['-DEHM_NP=%d' % np_, '-DEHM_SLOTS=%d' % sl]))
+    for rs in K3_RS:
+        objs.append((os.path.join(OBJ_DIR, 'ehm_k3_%d.o' % rs),
+                     os.path.join(SRC_DIR, 'ehm_k3.hip'), ['-DEHM3_RS=%d' % rs]))
     return objs
 
 
@@ -68,7 +75,8 @@ def is_stale():
     if not os.path.exists(LIB):
         return True
     t = os.path.getmtime(LIB)
-    srcs = [os.path.join(SRC_DIR, f) for f in ('ehm_capi.hip', 'ehm_k2.hip', 'ehm_explicit.hip')]
+    srcs = [os.path.join(SRC_DIR, f)
+            for f in ('ehm_capi.hip', 'ehm_k2.hip', 'ehm_k3.hip', 'ehm_explicit.hip')]
     return max([_dep_mtime()] + [os.path.getmtime(s) for s in srcs]) > t
 
 

@@ -26,8 +26,13 @@ using namespace ehm;
 #define EHM_K2_DECL(NPV, SL) extern "C" const ehm::K2Api* ehm_k2_api_##NPV##_##SL();
 EHM_K2_ALL(EHM_K2_DECL)
 #define EHM_K2_ENTRY(NPV, SL) ehm_k2_api_##NPV##_##SL,
+// wide instances (ehm_k3.hip compiled per row capacity): LPs with 33..64 columns or > 256 rows
+extern "C" const ehm::K2Api* ehm_k3_api_2();
+extern "C" const ehm::K2Api* ehm_k3_api_4();
 typedef const ehm::K2Api* (*k2_getter)();
-static const k2_getter g_k2_getters[] = {EHM_K2_ALL(EHM_K2_ENTRY)};
+static const k2_getter g_k2_getters[] = {EHM_K2_ALL(EHM_K2_ENTRY) ehm_k3_api_2, ehm_k3_api_4};
+#define EHM_V1_MAX_N 32     // limits of the generation-1 and wave-local kernels
+#define EHM_V1_MAX_M 256
 
 // =========================================================================================
 // kernels: one 64-lane workgroup (= one wavefront) per LP / per node
@@ -422,6 +427,7 @@ struct ehm_problem {
     std::vector<uint8_t> deltas;
     DevBuf consts;           // Gt | St | w | c
     DevBuf wc2;              // [n_delta][n+p+2][m|1]  LDS image for the k2 kernels
+    DevBuf wr3;              // [n_delta][mpad][64]    row-major image for the wide kernels
     bool v1_ok = false;      // the generation-1 kernels fit this problem
     int decide_full = 0;     // 1 = the suboptimality test solves to full accuracy (no sign-only stop)
     int solver_gen = 2;      // 1 = one wavefront per workgroup (ehm_kernels.h), 2 = ehm_k2.hip
@@ -543,11 +549,15 @@ static int k2_config(ehm_problem* P, int kind_a, int kind_b, long long n_items, 
         return fail(EHM_E_INVALID, "no kernel instance for an LP with %d columns, %d row slots",
                     n_lp, slots);
     const size_t shared = api->shared_doubles(P->dp);
-    const size_t wave = api->wave_doubles(P->dp.p, P->dp.n_u, n_lp, ne);
+    const size_t wave = api->wave_doubles(P->dp, n_lp, ne);
     const size_t budget = EHM_LDS_BUDGET / sizeof(double);
     if (shared + wave > budget)
         return fail(EHM_E_INVALID, "LP does not fit in LDS (%zu + %zu doubles)", shared, wave);
-    long long nw = std::min<long long>(api->max_threads / 64, (long long)((budget - shared) / wave));
+    if (api->threads_per_lp > 64 && !P->dp.Wr3)
+        return fail(EHM_E_INVALID, "wide kernels selected but their constant image is missing");
+    // LPs per workgroup: as many wavefronts as fit (wave-local kernels); exactly one (wide)
+    long long nw = std::min<long long>(api->max_threads / api->threads_per_lp,
+                                       (long long)((budget - shared) / wave));
     nw = std::max(1LL, std::min(nw, n_items));
     const size_t lds = (shared + (size_t)nw * wave) * sizeof(double);
     if (!P->k2_ready.count(api)) {
@@ -555,12 +565,13 @@ static int k2_config(ehm_problem* P, int kind_a, int kind_b, long long n_items, 
         P->k2_ready.insert(api);
     }
     // residency: LDS, and the wavefronts per CU the instances' register budget admits
-    long long wg_per_cu = std::max<long long>(
-        1, std::min<long long>(EHM_LDS_BUDGET / lds, (api->max_threads / 64) / nw));
+    // (wide kernels: 256 threads with up to 256 VGPRs -> two workgroups per CU)
+    const long long reg_wg = (api->threads_per_lp > 64) ? 2 : (api->max_threads / 64) / nw;
+    long long wg_per_cu = std::max<long long>(1, std::min<long long>(EHM_LDS_BUDGET / lds, reg_wg));
     long long grid = std::min<long long>((long long)P->num_cu * wg_per_cu, (n_items + nw - 1) / nw);
     cfg.api = api;
     cfg.L.grid = (int)std::max(1LL, grid);
-    cfg.L.threads = (int)(64 * nw);
+    cfg.L.threads = (int)(api->threads_per_lp * nw);
     cfg.L.lds_bytes = lds;
     cfg.L.wave_doubles = (int)wave;
     cfg.L.stream = P->stream;
@@ -656,6 +667,29 @@ int ehm_problem_create(const ehm_problem_desc* d, int device, ehm_problem** out)
         P->dp.lda2 = lda;
         P->dp.ncw2 = ncw;
     }
+    P->dp.Wr3 = nullptr;
+    P->dp.mpad3 = 0;
+    if (n + p + 1 > EHM_V1_MAX_N || m + p + 3 > EHM_V1_MAX_M) {
+        // row-major image for the wide kernels: [G | -S | -1 | 0 ...], 64 columns, zero rows
+        // up to a multiple of 64
+        const int mpad = (m + 63) & ~63;
+        std::vector<double> img((size_t)nd * mpad * 64, 0.0);
+        for (int k = 0; k < nd; ++k) {
+            double* base = img.data() + (size_t)k * mpad * 64;
+            for (int i = 0; i < m; ++i) {
+                double* rowp = base + (size_t)i * 64;
+                for (int j = 0; j < n; ++j) rowp[j] = d->G[((size_t)k * m + i) * n + j];
+                for (int q = 0; q < p; ++q) rowp[n + q] = -d->S[((size_t)k * m + i) * p + q];
+                rowp[n + p] = -1.0;
+            }
+        }
+        rc = P->wr3.ensure(img.size() * sizeof(double));
+        if (rc) { delete P; return rc; }
+        HIP_TRY(hipMemcpy(P->wr3.ptr, img.data(), img.size() * sizeof(double),
+                          hipMemcpyHostToDevice), EHM_E_HIP);
+        P->dp.Wr3 = P->wr3.as<double>();
+        P->dp.mpad3 = mpad;
+    }
     if (const char* e = getenv("EHM_SOLVER")) P->solver_gen = (atoi(e) == 1) ? 1 : 2;
     if (const char* e = getenv("EHM_DECIDE_FULL")) P->decide_full = atoi(e) ? 1 : 0;
     P->delta_len = d->delta_len;
@@ -671,10 +705,11 @@ int ehm_problem_create(const ehm_problem_desc* d, int device, ehm_problem** out)
     P->lds_simplex = lds_bytes_for(P->dp, LP_SLACK, NODE_LDS_DOUBLES);
     P->lds_expand = lds_bytes_for(P->dp, LP_POINT, NODE_LDS_DOUBLES);
     const size_t lds_max = std::max(P->lds_point, P->lds_simplex);
-    if (lds_max > 160 * 1024) {
+    if (lds_max > 160 * 1024 || n + p + 1 > EHM_V1_MAX_N || m + p + 3 > EHM_V1_MAX_M) {
         if (P->solver_gen == 1) {
             ehm_problem_destroy(P);
-            return fail(EHM_E_INVALID, "LP does not fit in LDS (%zu bytes)", lds_max);
+            return fail(EHM_E_INVALID, "LP too large for the generation-1 kernels (%zu bytes)",
+                        lds_max);
         }
     } else {
         const void* kernels[] = {(const void*)k_point_batch, (const void*)k_simplex_batch,
@@ -695,6 +730,7 @@ int ehm_problem_destroy(ehm_problem* P) {
     if (P->stream) (void)hipStreamSynchronize(P->stream);
     P->consts.release();
     P->wc2.release();
+    P->wr3.release();
     P->seg.release();
     P->pool_cache.rec.release(); P->pool_cache.left.release(); P->pool_cache.didx.release();
     P->pool_cache.depth.release(); P->pool_cache.flags.release(); P->pool_cache.tstar.release();

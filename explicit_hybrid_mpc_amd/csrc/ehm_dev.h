@@ -23,6 +23,12 @@ struct DevProblem {
     // so that  G z - S psi <= w + S R0  with  psi = theta - R0  (ehm_ipm2.h).
     const double* Wc2;  // [n_delta][ncw2][lda2]
     int lda2, ncw2;
+    // wide kernels (ehm_k3.hip, LPs with more than 32 columns): the same block row-major,
+    // padded to 64 columns and to mpad3 rows (multiple of 64) with zeros -- operand layout of
+    // v_mfma_f64_16x16x4_f64 and of the lane-per-column products (ehm_ipm3.h).  Null when
+    // every LP of the problem fits the wave-local kernels.
+    const double* Wr3;  // [n_delta][mpad3][64]
+    int mpad3;
 };
 
 // Node pool of the partition tree (structure of arrays of fixed-size records).

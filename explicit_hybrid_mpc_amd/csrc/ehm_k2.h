@@ -41,10 +41,13 @@ struct K2Launch {
     hipStream_t stream;
 };
 
+// One compiled kernel family: the wave-local instances of ehm_k2.hip (threads_per_lp = 64,
+// several LPs per workgroup around one LDS copy of the constant block) or the wide instances
+// of ehm_k3.hip (threads_per_lp = 256, one LP per workgroup, constant block from L2).
 struct K2Api {
-    int np, slots, max_threads;
+    int np, slots, max_threads, threads_per_lp;
     hipError_t (*set_lds)(int bytes);
-    size_t (*wave_doubles)(int p, int n_u, int n_lp, int ne);
+    size_t (*wave_doubles)(const DevProblem& P, int n_lp, int ne);   // LDS doubles per LP
     size_t (*shared_doubles)(const DevProblem& P);
     void (*point)(const K2Launch&, DevProblem, long long n_inst, const double* theta,
                   const int32_t* seg, int feas, double* J, double* u0, int32_t* status,

@@ -502,8 +502,8 @@ hipError_t set_lds(int bytes) {
     return hipSuccess;
 }
 
-size_t wave_doubles_for(int p, int n_u, int n_lp, int ne) {
-    return k2_node_doubles(p, n_u) + wave_lp_doubles(n_lp, ne);
+size_t wave_doubles_for(const DevProblem& P, int n_lp, int ne) {
+    return k2_node_doubles(P.p, P.n_u) + wave_lp_doubles(n_lp, ne);
 }
 size_t shared_doubles_for(const DevProblem& P) { return shared_doubles(P); }
 
@@ -539,9 +539,9 @@ void l_selftest(hipStream_t stream, double* out) {
     hipLaunchKernelGGL(k2_selftest, dim3(1), dim3(64), 0, stream, out);
 }
 
-const K2Api g_api = {EHM_NP,          EHM_SLOTS, EHM_K2_THREADS,    set_lds,  wave_doubles_for,
-                     shared_doubles_for, l_point,   l_simplex,         l_decide, l_expand,
-                     l_vertex,        l_selftest};
+const K2Api g_api = {EHM_NP,   EHM_SLOTS,        EHM_K2_THREADS,     64,      set_lds,
+                     wave_doubles_for, shared_doubles_for, l_point, l_simplex, l_decide,
+                     l_expand, l_vertex,         l_selftest};
 
 }  // namespace
 

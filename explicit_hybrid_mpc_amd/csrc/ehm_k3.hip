@@ -1,0 +1,492 @@
+// Wide-LP kernels of libehmpc (gfx950): one workgroup of 256 threads per LP, the
+// commutation's constant block read from global memory / L2, the normal matrix formed on the
+// matrix cores (ehm_ipm3.h).  Used when an LP has more than 32 columns (BASELINE.json
+// configs 4 and 5).  Same entry points and node semantics as ehm_k2.hip; compiled once per
+// row capacity (EHM3_RS row slots per thread).
+#include <hip/hip_runtime.h>
+
+#include "ehm_k2.h"
+#include "ehm_ipm3.h"
+
+using namespace ehm;
+
+extern __shared__ __attribute__((aligned(16))) char k3_smem[];
+
+namespace EHM3_NS {
+
+struct NodeBuf {
+    double* rec;    // node record / simplex vertices (+ vertex costs)
+    double* th;     // p doubles (parameter / midpoint)
+};
+__device__ __forceinline__ void carve_node(NodeBuf& nb, double* base, int p, int n_u) {
+    const int nrec = (rec_doubles(p, n_u) + 7) & ~7;
+    nb.rec = base;
+    nb.th = base + nrec;
+}
+__host__ __device__ inline size_t node_doubles(int p, int n_u) {
+    return (size_t)((rec_doubles(p, n_u) + 7) & ~7) + 8 + 64;   // + reduction scratch
+}
+
+// P_theta_delta at one parameter value (lib/oracle.py:141-173) or its phase-one form
+//   min tau  s.t.  G z - tau <= w + S theta,  tau >= -1.
+__device__ inline void assemble_point(Lp& L, const double* theta, bool feas, double (&b)[RS],
+                                      int tid) {
+    const int n = L.n, m = L.m, p = L.p;
+    L.ne = feas ? 1 : 0;
+    L.m_lp = m + L.ne;
+    L.has_beta = 0;
+    L.spec_mpc = feas ? 1 : 0;
+    L.act = ((n < 64) ? ((1ULL << n) - 1ULL) : ~0ULL) | (feas ? (1ULL << (n + p)) : 0ULL);
+    if (tid < NW) {
+        L.c[tid] = feas ? ((tid == n + p) ? 1.0 : 0.0) : ((tid < n) ? L.cv[tid] : 0.0);
+        if (feas) L.X[tid] = (tid == n + p) ? -1.0 : 0.0;      // extra row 0:  -tau <= 1
+    }
+#pragma unroll
+    for (int sl = 0; sl < RS; ++sl) {
+        const int i = tid + NT * sl;
+        double v = 0.0;
+        if (i < m) {
+            v = L.wv[i];
+            for (int r = 0; r < p; ++r) v = fma(-L.Wcm[(size_t)(n + r) * L.ldc + i], theta[r], v);
+        } else if (feas && i == m) {
+            v = 1.0;
+        }
+        b[sl] = v;
+    }
+    __syncthreads();
+}
+
+// Problems over a simplex R (rows = vertices, in LDS) in the variables (z, beta[, t]) with
+// theta = R0 + E beta, beta >= 0, sum beta <= 1 (E[r][q] = R[q+1][r] - R0[r]):
+//   SX_MIN   : min V                                              (lib/oracle.py:74-79)
+//   SX_SLACK : max t  s.t.  Vbar0 + dV^T beta - V - eps_a >= t,
+//                           Vbar0 + dV^T beta - (1+eps_r) V >= t   (lib/oracle.py:89-97)
+//   SX_FEAS  : min tau s.t. MPC rows relaxed by tau, tau >= -1
+// Extra rows: e < p facets -beta_e <= 0, e = p sum beta <= 1, then the dense ones.
+__device__ inline void assemble_simplex(Lp& L, const double* R, const double* Vbar, int mode,
+                                        double eps_a, double eps_r, double (&b)[RS], int tid) {
+    const int n = L.n, m = L.m, p = L.p;
+    const bool slack = (mode == SX_SLACK);
+    const bool feas = (mode == SX_FEAS);
+    L.ne = p + 1 + (slack ? 2 : 0) + (feas ? 1 : 0);
+    L.m_lp = m + L.ne;
+    L.has_beta = 1;
+    L.spec_mpc = feas ? 1 : 0;
+    const int n_lp = n + p + ((slack || feas) ? 1 : 0);
+    L.act = (n_lp < 64) ? ((1ULL << n_lp) - 1ULL) : ~0ULL;
+    for (int k = tid; k < L.ne * NW; k += NT) L.X[k] = 0.0;
+    if (tid < NW) L.c[tid] = 0.0;
+    if (tid < p * p) {
+        const int r = tid / p, q = tid - r * p;
+        L.E[tid] = R[(q + 1) * p + r] - R[r];
+    }
+    __syncthreads();
+    if (tid < p) {
+        L.X[tid * NW + n + tid] = -1.0;     // -beta_q <= 0
+        L.X[p * NW + n + tid] = 1.0;        // sum beta <= 1
+        if (slack) {
+            const double dv = Vbar[tid + 1] - Vbar[0];
+            L.X[(p + 1) * NW + n + tid] = -dv;
+            L.X[(p + 2) * NW + n + tid] = -dv;
+        }
+    }
+    if (slack) {
+        if (tid < n) {
+            const double cj = L.cv[tid];
+            L.X[(p + 1) * NW + tid] = cj;
+            L.X[(p + 2) * NW + tid] = fma(eps_r, cj, cj);     // (1 + eps_r) c_j
+        }
+        if (tid == 0) {
+            L.X[(p + 1) * NW + n + p] = 1.0;
+            L.X[(p + 2) * NW + n + p] = 1.0;
+            L.c[n + p] = -1.0;
+        }
+    } else if (feas) {
+        if (tid == 0) {
+            L.X[(p + 1) * NW + n + p] = -1.0;       // -tau <= 1
+            L.c[n + p] = 1.0;
+        }
+    } else if (tid < n) {
+        L.c[tid] = L.cv[tid];
+    }
+#pragma unroll
+    for (int sl = 0; sl < RS; ++sl) {
+        const int i = tid + NT * sl;
+        double v = 0.0;
+        if (i < m) {
+            v = L.wv[i];
+            for (int r = 0; r < p; ++r) v = fma(-L.Wcm[(size_t)(n + r) * L.ldc + i], R[r], v);
+        } else {
+            const int e = i - m;
+            if (e == p) v = 1.0;
+            else if (feas && e == p + 1) v = 1.0;
+            else if (slack && e == p + 1) v = Vbar[0] - eps_a;
+            else if (slack && e == p + 2) v = Vbar[0];
+        }
+        b[sl] = v;
+    }
+    __syncthreads();
+}
+
+__device__ __forceinline__ void count_solve(DevCounters* cnt, const IpmResult& r, int tid) {
+    if (tid == 0 && cnt) {
+        atomicAdd(&cnt->lp_solves, 1ULL);
+        atomicAdd(&cnt->ipm_iters, (unsigned long long)r.iters);
+        if (r.status != 0) atomicAdd(&cnt->stalled, 1ULL);
+    }
+}
+
+#define K3_PROLOGUE(D)                                                           \
+    double* sm = reinterpret_cast<double*>(k3_smem);                             \
+    const int tid = threadIdx.x;                                                 \
+    Block B;                                                                     \
+    B.tid = tid;                                                                 \
+    B.lane = tid & 63;                                                           \
+    B.wave = __builtin_amdgcn_readfirstlane(tid >> 6);                           \
+    B.flip = 0;                                                                  \
+    NodeBuf nb;                                                                  \
+    carve_node(nb, sm, P.p, P.n_u);                                              \
+    B.red = nb.th + 8;                                                           \
+    Lp L;                                                                        \
+    carve_lp(L, sm + node_doubles(P.p, P.n_u), P, (D))
+
+// ---- a2: P_theta_delta batch / its feasibility form; instances sorted by commutation -----
+__global__ __launch_bounds__(EHM3_THREADS) void k3_point_batch(
+    DevProblem P, long long n_inst, const double* __restrict__ theta,
+    const int32_t* __restrict__ seg, int feas, double* __restrict__ J, double* __restrict__ u0,
+    int32_t* __restrict__ status, int32_t* __restrict__ iters, DevCounters* cnt) {
+    K3_PROLOGUE(0);
+    const long long per = (n_inst + gridDim.x - 1) / gridDim.x;
+    const long long lo = (long long)blockIdx.x * per;
+    const long long hi = (lo + per < n_inst) ? lo + per : n_inst;
+    int d = 0;
+    for (long long inst = lo; inst < hi; ++inst) {
+        while (d + 1 < P.n_delta && seg[d + 1] <= inst) ++d;
+        carve_lp(L, sm + node_doubles(P.p, P.n_u), P, d);
+        if (tid < P.p) nb.th[tid] = theta[inst * P.p + tid];
+        __syncthreads();
+        IpmResult r;
+        int its = 0;
+        for (int attempt = 0; attempt < EHM3_ATTEMPTS; ++attempt) {     // see EHM3_STEP_FRAC
+            double b[RS];
+            assemble_point(L, nb.th, feas != 0, b, tid);
+            r = ipm_solve(L, B, b, false, step_fraction(attempt));
+            its += r.iters;
+            if (r.status == 0) break;
+        }
+        r.iters = its;
+        count_solve(cnt, r, tid);
+        if (tid == 0) {
+            J[inst] = r.obj;
+            if (status) status[inst] = r.status;
+            if (iters) iters[inst] = r.iters;
+        }
+        if (u0 && tid < P.n_u) u0[inst * P.n_u + tid] = L.xb[tid];
+        __syncthreads();
+    }
+}
+
+// ---- a5 / a7': problems over a simplex, one commutation per instance (sorted) -------------
+__global__ __launch_bounds__(EHM3_THREADS) void k3_simplex_batch(
+    DevProblem P, long long n_inst, const double* __restrict__ R,
+    const double* __restrict__ Vbar, const int32_t* __restrict__ seg, int mode,
+    double* __restrict__ obj, double* __restrict__ alpha, int32_t* __restrict__ status,
+    int32_t* __restrict__ iters, DevCounters* cnt) {
+    K3_PROLOGUE(0);
+    const int p = P.p;
+    const int nR = (p + 1) * p;
+    const long long per = (n_inst + gridDim.x - 1) / gridDim.x;
+    const long long lo = (long long)blockIdx.x * per;
+    const long long hi = (lo + per < n_inst) ? lo + per : n_inst;
+    int d = 0;
+    for (long long inst = lo; inst < hi; ++inst) {
+        while (d + 1 < P.n_delta && seg[d + 1] <= inst) ++d;
+        carve_lp(L, sm + node_doubles(P.p, P.n_u), P, d);
+        double* Rl = nb.rec;
+        double* Vl = nb.rec + nR;
+        for (int k = tid; k < nR; k += NT) Rl[k] = R[inst * nR + k];
+        if (mode == SX_SLACK && tid <= p) Vl[tid] = Vbar[inst * (p + 1) + tid];
+        __syncthreads();
+        IpmResult r;
+        int its = 0;
+        for (int attempt = 0; attempt < EHM3_ATTEMPTS; ++attempt) {
+            double b[RS];
+            assemble_simplex(L, Rl, Vl, mode, P.eps_a, P.eps_r, b, tid);
+            r = ipm_solve(L, B, b, false, step_fraction(attempt));
+            its += r.iters;
+            if (r.status == 0) break;
+        }
+        r.iters = its;
+        count_solve(cnt, r, tid);
+        if (tid == 0) {
+            obj[inst] = (mode == SX_SLACK) ? -r.obj : r.obj;     // t* = -(min -t)
+            if (status) status[inst] = r.status;
+            if (iters) iters[inst] = r.iters;
+        }
+        if (alpha && B.wave == 0) {
+            const double beta = (tid < p) ? L.xb[P.n + tid] : 0.0;
+            const double sb = wave_sum(beta);
+            if (tid < p) alpha[inst * (p + 1) + tid + 1] = beta;
+            if (tid == 0) alpha[inst * (p + 1)] = 1.0 - sb;
+        }
+        __syncthreads();
+    }
+}
+
+// ---- frontier sweep (single commutation): epsilon-suboptimality decision per node --------
+// (lib/worker.py:368-375)
+__global__ __launch_bounds__(EHM3_THREADS) void k3_lcss_decide(
+    DevProblem P, DevTree T, const int32_t* __restrict__ frontier, int nf,
+    int32_t* __restrict__ open_flag, DevCounters* cnt, int sign_only) {
+    K3_PROLOGUE(0);
+    const int nrec = rec_doubles(P.p, P.n_u);
+    const int per = (nf + gridDim.x - 1) / gridDim.x;
+    const int lo = blockIdx.x * per;
+    const int hi = (lo + per < nf) ? lo + per : nf;
+    for (int f = lo; f < hi; ++f) {
+        const int id = frontier[f];
+        const double* rec = T.rec + (size_t)id * T.rec_stride;
+        for (int k = tid; k < nrec; k += NT) nb.rec[k] = rec[k];
+        __syncthreads();
+        IpmResult r;
+        int its = 0;
+        for (int attempt = 0; attempt < EHM3_ATTEMPTS; ++attempt) {
+            double b[RS];
+            assemble_simplex(L, nb.rec, nb.rec + rec_off_vcost(P.p), SX_SLACK, P.eps_a, P.eps_r,
+                             b, tid);
+            r = ipm_solve(L, B, b, sign_only != 0, step_fraction(attempt));
+            its += r.iters;
+            if (r.status == 0) break;
+        }
+        r.iters = its;
+        count_solve(cnt, r, tid);
+        if (tid == 0) {
+            if (r.status != 0) {
+                atomicAdd(&cnt->errors, 1ULL);
+                T.flags[id] |= 8;
+            }
+            atomicAdd(&cnt->slack_solves, 1ULL);
+            atomicAdd(&cnt->slack_iters, (unsigned long long)r.iters);
+            const double t = -r.obj;
+            const bool open = (t >= 0.0);
+            T.tstar[id] = t;
+            open_flag[f] = open ? 1 : 0;
+            if (!open) T.flags[id] |= 1;
+            atomicMin(&cnt->min_margin_bits, (unsigned long long)__double_as_longlong(r.margin));
+        }
+        __syncthreads();
+    }
+}
+
+// ---- split every open node, solve P_theta_delta at the midpoint, write the children -------
+// (lib/worker.py:403-414, 354-365)
+__global__ __launch_bounds__(EHM3_THREADS) void k3_lcss_expand(
+    DevProblem P, DevTree T, const int32_t* __restrict__ open_list, int n_open, int child_base,
+    int32_t* __restrict__ next_frontier, DevCounters* cnt) {
+    K3_PROLOGUE(0);
+    const int p = P.p, n_u = P.n_u;
+    const int nrec = rec_doubles(p, n_u);
+    const int per = (n_open + gridDim.x - 1) / gridDim.x;
+    const int lo = blockIdx.x * per;
+    const int hi = (lo + per < n_open) ? lo + per : n_open;
+    for (int f = lo; f < hi; ++f) {
+        const int id = open_list[f];
+        const double* rec = T.rec + (size_t)id * T.rec_stride;
+        double* node = nb.rec;
+        double* mid = nb.th;
+        for (int k = tid; k < nrec; k += NT) node[k] = rec[k];
+        __syncthreads();
+        int bi, bj;
+        longest_edge(node, p, bi, bj);
+        if (tid < p) {
+#pragma clang fp contract(off)
+            mid[tid] = (node[bi * p + tid] + node[bj * p + tid]) / 2.0;
+        }
+        __syncthreads();
+        const int d = T.didx[id];
+        IpmResult r;
+        int its = 0;
+        for (int attempt = 0; attempt < EHM3_ATTEMPTS; ++attempt) {
+            double b[RS];
+            assemble_point(L, mid, false, b, tid);
+            r = ipm_solve(L, B, b, false, step_fraction(attempt));
+            its += r.iters;
+            if (r.status == 0) break;
+        }
+        r.iters = its;
+        count_solve(cnt, r, tid);
+        if (r.status != 0 && tid == 0) {
+            atomicAdd(&cnt->errors, 1ULL);
+            T.flags[id] |= 16;
+        }
+        const int c0 = child_base + 2 * f;
+        double* rec0 = T.rec + (size_t)c0 * T.rec_stride;
+        double* rec1 = rec0 + T.rec_stride;
+        const int ov = rec_off_vcost(p), ou = rec_off_vinput(p);
+        for (int k = tid; k < nrec; k += NT) {
+            double v0 = node[k], v1 = node[k];
+            if (k < ov) {                       // vertices: row bi / bj replaced
+                if (k >= bi * p && k < bi * p + p) v0 = mid[k - bi * p];
+                if (k >= bj * p && k < bj * p + p) v1 = mid[k - bj * p];
+            } else if (k < ou) {                // vertex costs
+                if (k - ov == bi) v0 = r.obj;
+                if (k - ov == bj) v1 = r.obj;
+            } else {                            // vertex inputs
+                const int q = k - ou;
+                if (q >= bi * n_u && q < bi * n_u + n_u) v0 = L.xb[q - bi * n_u];
+                if (q >= bj * n_u && q < bj * n_u + n_u) v1 = L.xb[q - bj * n_u];
+            }
+            rec0[k] = v0;
+            rec1[k] = v1;
+        }
+        if (tid == 0) {
+            T.left[id] = c0;
+            const int dep = T.depth[id] + 1;
+            T.left[c0] = -1;
+            T.left[c0 + 1] = -1;
+            T.didx[c0] = d;
+            T.didx[c0 + 1] = d;
+            T.depth[c0] = dep;
+            T.depth[c0 + 1] = dep;
+            T.flags[c0] = 2;
+            T.flags[c0 + 1] = 2;
+            T.tstar[c0] = 0.0;
+            T.tstar[c0 + 1] = 0.0;
+            next_frontier[2 * f] = c0;
+            next_frontier[2 * f + 1] = c0 + 1;
+        }
+        __syncthreads();
+    }
+}
+
+// ---- vertex solves that seed a node's costs / inputs (lib/oracle.py:416-443) ---------------
+__global__ __launch_bounds__(EHM3_THREADS) void k3_vertex_solve(
+    DevProblem P, DevTree T, const int32_t* __restrict__ nodes, int n_nodes, DevCounters* cnt) {
+    K3_PROLOGUE(0);
+    const int p = P.p, n_u = P.n_u;
+    const int total = n_nodes * (p + 1);
+    const int per = (total + gridDim.x - 1) / gridDim.x;
+    const int lo = blockIdx.x * per;
+    const int hi = (lo + per < total) ? lo + per : total;
+    for (int t = lo; t < hi; ++t) {
+        const int id = nodes[t / (p + 1)];
+        const int v = t % (p + 1);
+        double* rec = T.rec + (size_t)id * T.rec_stride;
+        if (tid < p) nb.th[tid] = rec[v * p + tid];
+        __syncthreads();
+        IpmResult r;
+        int its = 0;
+        for (int attempt = 0; attempt < EHM3_ATTEMPTS; ++attempt) {
+            double b[RS];
+            assemble_point(L, nb.th, false, b, tid);
+            r = ipm_solve(L, B, b, false, step_fraction(attempt));
+            its += r.iters;
+            if (r.status == 0) break;
+        }
+        r.iters = its;
+        count_solve(cnt, r, tid);
+        if (r.status != 0 && tid == 0) atomicAdd(&cnt->errors, 1ULL);
+        if (tid == 0) rec[rec_off_vcost(p) + v] = r.obj;
+        if (tid < n_u) rec[rec_off_vinput(p) + v * n_u + tid] = L.xb[tid];
+        __syncthreads();
+    }
+}
+
+// ---- self test: workgroup reductions and one 16x16x4 tile product --------------------------
+__global__ __launch_bounds__(EHM3_THREADS) void k3_selftest(double* out) {
+    __shared__ double red[64];
+    Block B;
+    B.tid = threadIdx.x;
+    B.lane = threadIdx.x & 63;
+    B.wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    B.flip = 0;
+    B.red = red;
+    const int tid = B.tid;
+    // 256 threads: sum(1 + 0.5 k, k < 64) = 1072 from the first wavefront only
+    double mx[2] = {(tid == 137) ? 99.0 : -(double)tid, -1.0 - tid};
+    double sm[4] = {(tid < 64) ? 1.0 + 0.5 * tid : 0.0, (tid < 25) ? 1.0 : 0.0, 0.0, 0.0};
+    block_reduce(B, mx, sm);
+    // D = A B with A[i][k] = i + 1, B[k][j] = (k == 0): D[i][j] = i + 1; trace / 16 = 8.5
+    const int li = B.lane & 15, lk = B.lane >> 4;
+    double4v C = {0.0, 0.0, 0.0, 0.0};
+    C = __builtin_amdgcn_mfma_f64_16x16x4f64((double)(li + 1), (lk == 0) ? 1.0 : 0.0, C, 0, 0, 0);
+    double tr = 0.0;
+#pragma unroll
+    for (int r = 0; r < 4; ++r)
+        if (lk + 4 * r == li) tr += C[r];
+    tr = wave_sum(tr);
+    if (tid == 0) {
+        out[0] = sm[0];
+        out[1] = mx[0];
+        out[2] = sm[1];
+        out[3] = frcp(3.0) + (tr / 16.0 - 8.5);
+        out[4] = mx[1];
+    }
+}
+
+}  // namespace EHM3_NS
+
+// ---------------------------------------------------------------------------------------
+// host-side launchers
+// ---------------------------------------------------------------------------------------
+namespace {
+
+using namespace EHM3_NS;
+
+hipError_t set_lds(int bytes) {
+    const void* ks[] = {(const void*)k3_point_batch, (const void*)k3_simplex_batch,
+                        (const void*)k3_lcss_decide, (const void*)k3_lcss_expand,
+                        (const void*)k3_vertex_solve};
+    for (const void* k : ks) {
+        hipError_t e = hipFuncSetAttribute(k, hipFuncAttributeMaxDynamicSharedMemorySize, bytes);
+        if (e != hipSuccess) return e;
+    }
+    return hipSuccess;
+}
+
+size_t unit_doubles_for(const DevProblem& P, int /*n_lp*/, int /*ne*/) {
+    return (node_doubles(P.p, P.n_u) + lp_doubles(P.m) + 1) & ~(size_t)1;
+}
+size_t shared_doubles_for(const DevProblem&) { return 0; }
+
+void l_point(const K2Launch& L, DevProblem P, long long n_inst, const double* theta,
+             const int32_t* seg, int feas, double* J, double* u0, int32_t* status,
+             int32_t* iters, DevCounters* cnt) {
+    hipLaunchKernelGGL(k3_point_batch, dim3(L.grid), dim3(L.threads), L.lds_bytes, L.stream, P,
+                       n_inst, theta, seg, feas, J, u0, status, iters, cnt);
+}
+void l_simplex(const K2Launch& L, DevProblem P, long long n_inst, const double* R,
+               const double* Vbar, const int32_t* seg, int mode, double* obj, double* alpha,
+               int32_t* status, int32_t* iters, DevCounters* cnt) {
+    hipLaunchKernelGGL(k3_simplex_batch, dim3(L.grid), dim3(L.threads), L.lds_bytes, L.stream,
+                       P, n_inst, R, Vbar, seg, mode, obj, alpha, status, iters, cnt);
+}
+void l_decide(const K2Launch& L, DevProblem P, DevTree T, const int32_t* frontier, int nf,
+              int32_t* open_flag, DevCounters* cnt, int sign_only) {
+    hipLaunchKernelGGL(k3_lcss_decide, dim3(L.grid), dim3(L.threads), L.lds_bytes, L.stream, P,
+                       T, frontier, nf, open_flag, cnt, sign_only);
+}
+void l_expand(const K2Launch& L, DevProblem P, DevTree T, const int32_t* open_list, int n_open,
+              int child_base, int32_t* next_frontier, DevCounters* cnt) {
+    hipLaunchKernelGGL(k3_lcss_expand, dim3(L.grid), dim3(L.threads), L.lds_bytes, L.stream, P,
+                       T, open_list, n_open, child_base, next_frontier, cnt);
+}
+void l_vertex(const K2Launch& L, DevProblem P, DevTree T, const int32_t* nodes, int n_nodes,
+              DevCounters* cnt) {
+    hipLaunchKernelGGL(k3_vertex_solve, dim3(L.grid), dim3(L.threads), L.lds_bytes, L.stream, P,
+                       T, nodes, n_nodes, cnt);
+}
+void l_selftest(hipStream_t stream, double* out) {
+    hipLaunchKernelGGL(k3_selftest, dim3(1), dim3(EHM3_THREADS), 0, stream, out);
+}
+
+// np = 64 columns; slots in units of 64 rows; one LP per workgroup of 256 threads
+const K2Api g_api = {NW,      4 * EHM3_RS, EHM3_THREADS, EHM3_THREADS, set_lds,  unit_doubles_for,
+                     shared_doubles_for, l_point,   l_simplex,    l_decide,     l_expand,
+                     l_vertex, l_selftest};
+
+}  // namespace
+
+#define K3_CAT2(a, b) a##b
+#define K3_CAT(a, b) K3_CAT2(a, b)
+extern "C" const ehm::K2Api* K3_CAT(ehm_k3_api_, EHM3_RS)() { return &g_api; }

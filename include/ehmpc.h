@@ -37,9 +37,11 @@ extern "C" {
 #define EHM_E_INFEASIBLE   -5   /* Theta contains infeasible regions (lib/worker.py:266) */
 #define EHM_E_NUMERIC      -6   /* a vertex solve failed (lib/oracle.py:440-442) */
 
-/* Limits of this build (one wavefront per LP, row of the normal matrix in registers). */
-#define EHM_MAX_N   32          /* LP columns incl. simplex weights and slack */
-#define EHM_MAX_M   256         /* LP rows   incl. simplex / cost rows */
+/* Limits of this build.  Up to 32 columns / 256 rows an LP is solved by one wavefront
+ * (several LPs per workgroup around one LDS copy of the commutation's constant block);
+ * wider LPs by one workgroup each, with the normal matrix formed on the matrix cores. */
+#define EHM_MAX_N   64          /* LP columns incl. simplex weights and slack */
+#define EHM_MAX_M   1024        /* LP rows   incl. simplex / cost rows */
 #define EHM_MAX_P   8           /* parameter dimension */
 
 /* Per-instance solve status (status arrays). */

@@ -7,6 +7,7 @@ from oracle.oracle_cpu import OracleCPU
 from oracle import geometry
 
 
+CHAIN_SMALL_SCALE = 0.6      # x_max = (1, 1), T = 0.1, N = 8: every vertex feasible (tested)
 PWA_SMALL_SCALE = 0.367     # 0.9 x max feasible scale (0.408, tools/calibrate_configs.py)
 
 
@@ -17,6 +18,15 @@ def make_instance(kind, seed=0):
         return examples.linear_mpc(seed)
     if kind == 'pwa':
         return examples.pwa_mpc(seed)
+    if kind == 'chain':
+        # config 4 (n_x = 6, n_u = 3, N = 10, box constraints): LPs of 50..57 columns, 360..369
+        # rows -- the wide kernels (ehm_k3.hip)
+        return examples.integrator_chain_mpc()
+    if kind == 'chain_small':
+        # same family, n_x = 4, n_u = 2, N = 8: 32 + 4 + 1 = 37 columns, 3-tile normal matrix
+        mpc = examples.integrator_chain_mpc(n_axes=2, N=8)
+        examples.THETA_SCALE.setdefault(mpc.name, CHAIN_SMALL_SCALE)
+        return mpc
     if kind == 'pwa_small':
         # 2 states, 1 input, N=3: 8 commutations -- a hybrid instance whose whole partition
         # the CPU oracle finishes in seconds
