@@ -44,14 +44,14 @@ def node_bytes(p, n_u, delta_len):
     return 8 * ((p + 1) * p + (p + 1) + (p + 1) * n_u) + delta_len + 16
 
 
-def pmc_traffic(kernel):
+def pmc_traffic(kernel, summary='pmc_summary_bench.json'):
     """
     HBM bytes per launch of `kernel` from the committed rocprofv3 --pmc passes of THIS workload
     (profiles/r1/pmc_summary_bench.json, tools/profile.sh): FETCH_SIZE / WRITE_SIZE are in KiB
     and come from separate passes; on gfx950 FETCH_SIZE tallies 128-byte read requests at 64
     bytes, so it is doubled (MI355X_MICROARCH.md, HBM section).  None if no profile is there.
     """
-    path = os.path.join(ROOT, 'profiles', 'r1', 'pmc_summary_bench.json')
+    path = os.path.join(ROOT, 'profiles', 'r1', summary)
     try:
         c = json.load(open(path))['counters'][kernel]
         n_f, n_w = c['_dispatches_pmc3'], c['_dispatches_pmc4']
@@ -94,8 +94,13 @@ def main():
     ap.add_argument('--steps', type=int, default=3)
     ap.add_argument('--warmup', type=int, default=1)
     ap.add_argument('--seed', type=int, default=0)
-    ap.add_argument('--abs-frac', type=float, default=0.02)
-    ap.add_argument('--eps-r', type=float, default=1e-2)
+    ap.add_argument('--workload', choices=['config2', 'config4'], default='config2',
+                    help='config2 = the BASELINE.json metric (default); config4 = n_x=6 n_u=3 N=10 '
+                         'box-constrained instance on the wide kernels (a parity-test '
+                         'configuration, timed for the record)')
+    ap.add_argument('--abs-frac', type=float, default=None,
+                    help='eps_a rule of lib/examples.py:42-46 (default 0.02; config4: 0.4)')
+    ap.add_argument('--eps-r', type=float, default=None, help='default 1e-2; config4: 0.25')
     ap.add_argument('--max-nodes', type=int, default=1 << 22)
     ap.add_argument('--shard-min-frontier', type=int, default=0,
                     help='frontier size at which it is dealt over the ranks (0 = 64 per rank)')
@@ -123,12 +128,20 @@ def main():
     from explicit_hybrid_mpc_amd import engine, examples
     from explicit_hybrid_mpc_amd import tools as ehm_tools
 
-    mpc = examples.linear_mpc(seed=args.seed)
+    wide = args.workload == 'config4'
+    if args.abs_frac is None:
+        args.abs_frac = 0.4 if wide else 0.02
+    if args.eps_r is None:
+        args.eps_r = 0.25 if wide else 1e-2
+    mpc = examples.integrator_chain_mpc() if wide else examples.linear_mpc(seed=args.seed)
     can = mpc.compile()
     gp = engine.GpuProblem(can, 1., 1., device=device_index)
-    gp.set_solver(args.solver)
+    if not wide:
+        gp.set_solver(args.solver)
     gp.set_option('decide_full', 1 if args.decide_full else 0)
-    kname = 'k2_lcss_decide' if args.solver == 2 else 'k_lcss_decide'
+    kname = 'k3_lcss_decide' if wide else ('k2_lcss_decide' if args.solver == 2
+                                           else 'k_lcss_decide')
+    pmc_file = 'pmc_summary_wide.json' if wide else 'pmc_summary_bench.json'
     half = examples.theta_box(mpc)
     V = examples.box_vertices(half)
     # eps_a by the reference's rule (lib/examples.py:42-46), evaluated on the GPU oracle
@@ -214,10 +227,13 @@ def main():
             'dtype': 'f64',
             'data': 'synthetic',
             'config': {
-                'workload': 'configs[1]: n_x=4 n_u=2 N=5 p=4 linear MPC, inf-norm LP oracle '
-                            '(n=%d m=%d), seed %d, eps_r=%g, eps_a=%.6g (abs_frac=%g), '
-                            '%d Delaunay roots' % (can.n, can.m, args.seed, args.eps_r, eps_a,
-                                                   args.abs_frac, len(roots)),
+                'workload': ('configs[3] (NOT the headline configuration): n_x=6 n_u=3 N=10 p=6 '
+                             'box-constrained chain' if wide else
+                             'configs[1]: n_x=4 n_u=2 N=5 p=4 linear MPC') +
+                            ', inf-norm LP oracle (n=%d m=%d), seed %d, eps_r=%g, eps_a=%.6g '
+                            '(abs_frac=%g), %d Delaunay roots' % (
+                                can.n, can.m, args.seed, args.eps_r, eps_a, args.abs_frac,
+                                len(roots)),
                 'regions_per_step': closed / K,
                 'nodes_per_step': nodes / K,
                 'lp_solves_per_step': agg['lp_solves'] / K,
@@ -225,7 +241,8 @@ def main():
                 'mean_ipm_iterations': agg['ipm_iters'] / max(agg['lp_solves'], 1),
                 'sweeps': info0['sweeps'], 'tree_depth': info0['max_depth'],
                 'min_decision_margin': info0['min_margin'],
-                'kernels': 'generation %d' % args.solver,
+                'kernels': 'wide (one workgroup per LP, MFMA normal matrix)' if wide else
+                           'generation %d' % args.solver,
                 'suboptimality_test': 'full accuracy' if args.decide_full else
                                       'sign-only stop (lower bound of |t*| recorded)',
                 'parallelism': 'frontier dealt round-robin over %d GPU(s)' % world +
@@ -239,12 +256,14 @@ def main():
             },
             'roofline': {
                 'bound': 'mfma', 'kernel': kname,
-                'note': 'FP64 vector FMA bound (no f64 contraction >= 32 wide at n=25); peak = '
-                        'FP64 vector = matrix peak of MI355X',
+                'note': ('normal matrix on v_mfma_f64_16x16x4_f64 (57 columns = 4 tiles); peak = '
+                         'FP64 matrix = vector peak of MI355X' if wide else
+                         'FP64 vector FMA bound (no f64 contraction >= 32 wide at n=25); peak = '
+                         'FP64 vector = matrix peak of MI355X'),
                 'achieved': achieved, 'peak': FP64_PEAK_TFLOPS, 'unit': 'TFLOP/s',
-                'frac': achieved / FP64_PEAK_TFLOPS, 'traffic': pmc_traffic(kname),
+                'frac': achieved / FP64_PEAK_TFLOPS, 'traffic': pmc_traffic(kname, pmc_file),
                 'traffic_unit': 'HBM bytes per launch (rocprofv3 FETCH_SIZE x2 + WRITE_SIZE, '
-                                'profiles/r1/pmc_summary_bench.json)',
+                                'profiles/r1/%s)' % pmc_file,
                 'algorithmic_bytes_per_launch': hbm_alg / max(info0['decide_launches'] * K, 1),
                 'flop_per_ipm_iteration': flops_per_iteration(n_slack, m_slack),
                 'kernel_seconds': decide_s, 'launches': info0['decide_launches'] * K,

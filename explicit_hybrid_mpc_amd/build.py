@@ -62,7 +62,9 @@ def _objects():
                          ['-DEHM_NP=%d' % np_, '-DEHM_SLOTS=%d' % sl]))
     for rs in K3_RS:
         objs.append((os.path.join(OBJ_DIR, 'ehm_k3_%d.o' % rs),
-                     os.path.join(SRC_DIR, 'ehm_k3.hip'), ['-DEHM3_RS=%d' % rs]))
+                     os.path.join(SRC_DIR, 'ehm_k3.hip'),
+                     # the 64-step elimination is unrolled completely (rows live in registers)
+                     ['-DEHM3_RS=%d' % rs, '-mllvm', '-pragma-unroll-threshold=200000']))
     return objs
 
 

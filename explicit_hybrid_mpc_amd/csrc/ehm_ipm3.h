@@ -37,6 +37,14 @@
 #define EHM3_RS 2           // row slots per thread: LP rows <= 256 * EHM3_RS
 #endif
 #define EHM3_THREADS 256
+#ifndef EHM3_LU_CHUNK
+#define EHM3_LU_CHUNK 32
+#endif
+#ifndef EHM3_WAVES_PER_EU
+#define EHM3_WAVES_PER_EU 2     // two workgroups per CU: at most 256 registers per lane
+#endif
+#define EHM3_KERNEL __global__ __launch_bounds__(EHM3_THREADS) \
+    __attribute__((amdgpu_waves_per_eu(EHM3_WAVES_PER_EU, EHM3_WAVES_PER_EU)))
 
 #define EHM3_TOL_RES      1e-10
 #define EHM3_TOL_GAP      1e-10
@@ -93,6 +101,13 @@ __device__ __forceinline__ double readlane_d(double v, int src) {
     const int hi = __builtin_amdgcn_readlane(__double2hiint(v), src);
     return __hiloint2double(hi, lo);
 }
+// Keeps everything derived from x inside the current phase: without it LLVM hoists dozens of
+// loop-invariant per-thread addresses and comparison masks out of the IPM iteration (and out
+// of the item loop of the kernels) and spills them.
+__device__ __forceinline__ int pin(int x) {
+    asm volatile("" : "+v"(x));
+    return x;
+}
 // 1/x for positive finite x well inside the normal range: v_rcp_f64 + two Newton steps
 __device__ __forceinline__ double frcp(double x) {
     double r = __builtin_amdgcn_rcp(x);
@@ -103,15 +118,34 @@ __device__ __forceinline__ double frcp(double x) {
     return r;
 }
 
+// Optional phase timing (-DEHM3_PROFILE, experimental builds only): wall-clock ticks of thread 0
+// per solver phase, accumulated in g_prof3[] and read by ehm_debug_profile().
+#ifdef EHM3_PROFILE
+__device__ unsigned long long g_prof3[32];
+#define EHM3_TICK(slot)                                                       \
+    do {                                                                      \
+        const unsigned long long now_ = wall_clock64();                       \
+        if (B.tid == 0) atomicAdd(&g_prof3[slot], now_ - B.pt);               \
+        B.pt = now_;                                                          \
+    } while (0)
+#define EHM3_TICK_INIT() B.pt = wall_clock64()
+#else
+#define EHM3_TICK(slot) do { } while (0)
+#define EHM3_TICK_INIT() do { } while (0)
+#endif
+
 struct Block {
     int tid, lane, wave;
     double* red;    // [2][4][8] reduction scratch, double buffered
     int flip;
+#ifdef EHM3_PROFILE
+    mutable unsigned long long pt;
+#endif
 };
 
 // mx[] -> maxima, sm[] -> sums over the workgroup; every thread receives the same values
 // (wave butterflies, then the four wave results combined in a fixed order).
-__device__ inline void block_reduce(Block& B, double (&mx)[2], double (&sm)[4]) {
+__device__ __forceinline__ void block_reduce(Block& B, double (&mx)[2], double (&sm)[4]) {
 #pragma unroll
     for (int k = 0; k < 2; ++k) mx[k] = wave_max(mx[k]);
 #pragma unroll
@@ -237,28 +271,61 @@ __device__ __forceinline__ void to_block_columns(const Lp& L, int lane) {
     L.xw[lane] = v;
 }
 
-// out[s] = (A t)_i for the rows of this thread; L.t / L.xw hold the vector
-__device__ __forceinline__ void rows_times(const Lp& L, int tid, double (&out)[RS]) {
+// out[s] = (A t)_i for the rows of this thread; L.t / L.xw hold the vector.  The loads of
+// all row slots of a column step are issued together (latency bound: the block comes from L2).
+__device__ __forceinline__ void rows_times(const Lp& L, int tid, int wave, double (&out)[RS]) {
     const int ncw = L.n + L.p + 1;
     const size_t ldc = (size_t)L.ldc;
+    const double* col[RS];
+    bool mpc[RS];
+    double a0[RS], a1[RS];
 #pragma unroll
     for (int sl = 0; sl < RS; ++sl) {
         const int i = tid + NT * sl;
-        double acc = 0.0;
-        if (i < L.m) {
-            const double* col = L.Wcm + i;
-            double a0 = 0.0, a1 = 0.0;
-            int j = 0;
-#pragma unroll 4
-            for (; j + 1 < ncw; j += 2) {
-                a0 = fma(col[(size_t)j * ldc], L.xw[j], a0);
-                a1 = fma(col[(size_t)(j + 1) * ldc], L.xw[j + 1], a1);
+        mpc[sl] = i < L.m;
+        col[sl] = L.Wcm + (mpc[sl] ? i : 0);
+        a0[sl] = 0.0;
+        a1[sl] = 0.0;
+    }
+    // wave-uniform skip of slots without MPC rows (rows are dealt in order)
+    const int nsl = (L.m - 64 * wave + NT - 1) / NT;       // slots with MPC rows in this wave
+    int j = 0;
+    // 8 columns per trip, the loads of every row slot issued before the first product
+    for (; j + 8 <= ncw; j += 8) {
+        double w[RS][8];
+#pragma unroll
+        for (int sl = 0; sl < RS; ++sl)
+            if (sl < nsl) {
+#pragma unroll
+                for (int u = 0; u < 8; ++u) w[sl][u] = col[sl][(size_t)(j + u) * ldc];
             }
-            if (j < ncw) a0 = fma(col[(size_t)j * ldc], L.xw[j], a0);
-            acc = a0 + a1;
-        } else if (i < L.m_lp) {
-            const double* xr = L.X + (i - L.m) * NW;
-            for (int j = 0; j < ncw; ++j) acc = fma(xr[j], L.t[j], acc);
+#pragma unroll
+        for (int u = 0; u < 8; u += 2) {
+            const double x0 = L.xw[j + u], x1 = L.xw[j + u + 1];
+#pragma unroll
+            for (int sl = 0; sl < RS; ++sl)
+                if (sl < nsl) {
+                    a0[sl] = fma(w[sl][u], x0, a0[sl]);
+                    a1[sl] = fma(w[sl][u + 1], x1, a1[sl]);
+                }
+        }
+    }
+    for (; j < ncw; ++j) {
+        const double x0 = L.xw[j];
+#pragma unroll
+        for (int sl = 0; sl < RS; ++sl)
+            if (sl < nsl) a0[sl] = fma(col[sl][(size_t)j * ldc], x0, a0[sl]);
+    }
+#pragma unroll
+    for (int sl = 0; sl < RS; ++sl) {
+        const int i = tid + NT * sl;
+        double acc = a0[sl] + a1[sl];
+        if (!mpc[sl]) {
+            acc = 0.0;
+            if (i < L.m_lp) {
+                const double* xr = L.X + (i - L.m) * NW;
+                for (int jj = 0; jj < ncw; ++jj) acc = fma(xr[jj], L.t[jj], acc);
+            }
         }
         out[sl] = acc;
     }
@@ -268,21 +335,26 @@ __device__ __forceinline__ void rows_times(const Lp& L, int tid, double (&out)[R
 template <bool TWO>
 __device__ __forceinline__ void cols_times(const Lp& L, const Block& B, const double* u0,
                                            const double* u1) {
-    const int lane = B.lane, wave = B.wave;
+    const int lane = pin(B.lane), wave = B.wave;
     {
         const int chunk = L.m_pad >> 2;
         const int r0 = wave * chunk;
         const double* wr = L.Wrm + (size_t)r0 * NW + lane;
         double a0 = 0.0, a1 = 0.0, b0 = 0.0, b1 = 0.0;
-#pragma unroll 4
-        for (int k = 0; k < chunk; k += 2) {
-            const double w0 = wr[(size_t)k * NW];
-            const double w1 = wr[(size_t)(k + 1) * NW];
-            a0 = fma(w0, u0[r0 + k], a0);
-            b0 = fma(w1, u0[r0 + k + 1], b0);
-            if (TWO) {
-                a1 = fma(w0, u1[r0 + k], a1);
-                b1 = fma(w1, u1[r0 + k + 1], b1);
+        // 16 rows per trip: all 16 loads are issued before the first product (latency bound;
+        // the inner loops have constant trip counts so that they really unroll)
+        for (int k = 0; k < chunk; k += 16) {
+            double w[16];
+#pragma unroll
+            for (int u = 0; u < 16; ++u) w[u] = wr[(size_t)(k + u) * NW];
+#pragma unroll
+            for (int u = 0; u < 16; u += 2) {
+                a0 = fma(w[u], u0[r0 + k + u], a0);
+                b0 = fma(w[u + 1], u0[r0 + k + u + 1], b0);
+                if (TWO) {
+                    a1 = fma(w[u], u1[r0 + k + u], a1);
+                    b1 = fma(w[u + 1], u1[r0 + k + u + 1], b1);
+                }
             }
         }
         L.part[(wave * 2 + 0) * NW + lane] = a0 + b0;
@@ -333,64 +405,112 @@ __device__ __forceinline__ void cols_times(const Lp& L, const Block& B, const do
 // Tile (I, J), I >= J, of W^T D W:  A = (W[rows, 16 I ..])^T d,  B = W[rows, 16 J ..]: both
 // operands are "row 4 ks + (l >> 4), column 16 T + (l & 15)" of the row-major image -- four
 // 128-byte segments per load.
+// One wavefront's share of the lower-triangular tiles: up to three tiles (I0,J0) (I1,J1)
+// (I2,J2) (I < 0: none) over ALL rows.  The tiles are split over the four wavefronts, not the
+// rows: no partial sums to combine (bit-reproducible by construction), 24 accumulator
+// registers instead of 80.  Operands of chunk c+1 (4 k-steps = 16 rows) are in flight while
+// chunk c runs on the matrix cores.
+template <int I0, int J0, int I1, int J1, int I2, int J2>
+__device__ __forceinline__ void form_tile_set(const Lp& L, int lane) {
+    constexpr bool use[4] = {I0 == 0 || J0 == 0 || I1 == 0 || J1 == 0 || I2 == 0 || J2 == 0,
+                             I0 == 1 || J0 == 1 || I1 == 1 || J1 == 1 || I2 == 1 || J2 == 1,
+                             I0 == 2 || J0 == 2 || I1 == 2 || J1 == 2 || I2 == 2 || J2 == 2,
+                             I0 == 3 || J0 == 3 || I1 == 3 || J1 == 3 || I2 == 3 || J2 == 3};
+    const int li = lane & 15, lk = lane >> 4;
+    double4v C0 = {0.0, 0.0, 0.0, 0.0}, C1 = C0, C2 = C0;
+    const int chunks = L.m_pad >> 4;                // 16 rows (4 k-steps) per chunk
+    const double* wr = L.Wrm + (size_t)lk * NW + li;
+    const double* dv = L.dvec + lk;
+    double wc[4][4], wn[4][4];
+#pragma unroll
+    for (int u = 0; u < 4; ++u)
+#pragma unroll
+        for (int T = 0; T < 4; ++T) wn[u][T] = use[T] ? wr[(size_t)(4 * u) * NW + 16 * T] : 0.0;
+    for (int c = 0; c < chunks; ++c) {
+        double d[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            d[u] = dv[16 * c + 4 * u];
+#pragma unroll
+            for (int T = 0; T < 4; ++T) wc[u][T] = wn[u][T];
+        }
+        if (c + 1 < chunks) {
+#pragma unroll
+            for (int u = 0; u < 4; ++u)
+#pragma unroll
+                for (int T = 0; T < 4; ++T)
+                    if (use[T]) wn[u][T] = wr[(size_t)(16 * (c + 1) + 4 * u) * NW + 16 * T];
+        }
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            C0 = __builtin_amdgcn_mfma_f64_16x16x4f64(wc[u][I0] * d[u], wc[u][J0], C0, 0, 0, 0);
+            if (I1 >= 0)
+                C1 = __builtin_amdgcn_mfma_f64_16x16x4f64(wc[u][I1 < 0 ? 0 : I1] * d[u],
+                                                          wc[u][J1 < 0 ? 0 : J1], C1, 0, 0, 0);
+            if (I2 >= 0)
+                C2 = __builtin_amdgcn_mfma_f64_16x16x4f64(wc[u][I2 < 0 ? 0 : I2] * d[u],
+                                                          wc[u][J2 < 0 ? 0 : J2], C2, 0, 0, 0);
+        }
+    }
+    // D element r of this lane is (row (lane >> 4) + 4 r, column lane & 15) of the tile
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+        const int rr = lk + 4 * r;
+        {
+            const double val = C0[r];
+            L.M[(16 * I0 + rr) * LDM + 16 * J0 + li] = val;
+            if (I0 != J0) L.M[(16 * J0 + li) * LDM + 16 * I0 + rr] = val;
+        }
+        if (I1 >= 0) {
+            const double val = C1[r];
+            L.M[(16 * I1 + rr) * LDM + 16 * J1 + li] = val;
+            if (I1 != J1) L.M[(16 * J1 + li) * LDM + 16 * I1 + rr] = val;
+        }
+        if (I2 >= 0) {
+            const double val = C2[r];
+            L.M[(16 * I2 + rr) * LDM + 16 * J2 + li] = val;
+            if (I2 != J2) L.M[(16 * J2 + li) * LDM + 16 * I2 + rr] = val;
+        }
+    }
+}
+
+// W^T diag(d) W for the first 16 NTILE columns of the block; ends with a workgroup barrier.
 template <int NTILE>
 __device__ __forceinline__ void form_tiles(const Lp& L, const Block& B) {
-    constexpr int NACC = NTILE * (NTILE + 1) / 2;
-    const int lane = B.lane, wave = B.wave;
-    const int li = lane & 15, lk = lane >> 4;
-    double4v C[NACC];
-#pragma unroll
-    for (int a = 0; a < NACC; ++a) C[a] = double4v{0.0, 0.0, 0.0, 0.0};
-    const int steps = L.m_pad >> 4;                 // 16 rows per step: 4 per wavefront
-    const double* wr = L.Wrm + (size_t)(4 * wave + lk) * NW + li;
-    const double* dv = L.dvec + 4 * wave + lk;
-#pragma unroll 2
-    for (int t = 0; t < steps; ++t) {
-        const double d = dv[16 * t];
-        double w[NTILE], a[NTILE];
-#pragma unroll
-        for (int T = 0; T < NTILE; ++T) {
-            w[T] = wr[(size_t)t * 16 * NW + 16 * T];
-            a[T] = w[T] * d;
-        }
-        int idx = 0;
-#pragma unroll
-        for (int I = 0; I < NTILE; ++I)
-#pragma unroll
-            for (int J = 0; J <= I; ++J) {
-                C[idx] = __builtin_amdgcn_mfma_f64_16x16x4f64(a[I], w[J], C[idx], 0, 0, 0);
-                ++idx;
-            }
+    const int lane = pin(B.lane), wave = B.wave;
+#ifdef EHM3_PROFILE
+    const unsigned long long tw0 = clock64();
+#endif
+    if (NTILE == 4) {           // 10 tiles: 3 + 3 + 2 + 2
+        if (wave == 0) form_tile_set<0, 0, 1, 0, 1, 1>(L, lane);
+        else if (wave == 1) form_tile_set<2, 0, 2, 1, 2, 2>(L, lane);
+        else if (wave == 2) form_tile_set<3, 0, 3, 1, -1, -1>(L, lane);
+        else form_tile_set<3, 2, 3, 3, -1, -1>(L, lane);
+    } else {                    // 6 tiles: 2 + 2 + 1 + 1
+        if (wave == 0) form_tile_set<0, 0, 1, 0, -1, -1>(L, lane);
+        else if (wave == 1) form_tile_set<2, 0, 2, 1, -1, -1>(L, lane);
+        else if (wave == 2) form_tile_set<1, 1, -1, -1, -1, -1>(L, lane);
+        else form_tile_set<2, 2, -1, -1, -1, -1>(L, lane);
     }
-    // the four partial sums meet in LDS, wavefront 0 first (fixed order)
-    for (int wv = 0; wv < 4; ++wv) {
-        if (wave == wv) {
-            int idx = 0;
-#pragma unroll
-            for (int I = 0; I < NTILE; ++I)
-#pragma unroll
-                for (int J = 0; J <= I; ++J) {
-#pragma unroll
-                    for (int r = 0; r < 4; ++r) {
-                        const int row = 16 * I + lk + 4 * r, col = 16 * J + li;
-                        double val = C[idx][r];
-                        if (wv > 0) val += L.M[row * LDM + col];
-                        L.M[row * LDM + col] = val;
-                        if (I != J) L.M[col * LDM + row] = val;
-                    }
-                    ++idx;
-                }
-        }
-        __syncthreads();
+#ifdef EHM3_PROFILE
+    if (lane == 0) {        // per-wavefront cycles of the tile loop, and where the wavefront runs
+        atomicAdd(&g_prof3[20 + wave], (unsigned long long)clock64() - tw0);
+        const unsigned hw = __builtin_amdgcn_s_getreg(4 | (0 << 6) | (31 << 11));   // HW_ID
+        atomicOr(&g_prof3[24 + wave], 1ULL << ((hw >> 4) & 3));
+        atomicAdd(&g_prof3[28], 1ULL);
     }
+#endif
+    EHM3_TICK(13);
+    __syncthreads();
 }
 
 // M = A^T diag(d) A in LP columns, identity on the columns the LP does not have.
 // Entry: L.dvec / L.dext visible.  Exit: workgroup barrier passed.
-__device__ inline void form_normal_matrix(const Lp& L, const Block& B) {
-    const int tid = B.tid;
+__device__ __forceinline__ void form_normal_matrix(const Lp& L, const Block& B) {
+    int tid = pin(B.tid);
     if (L.ntile >= 4) form_tiles<4>(L, B);
     else form_tiles<3>(L, B);
+    EHM3_TICK(14);
     const int n = L.n, p = L.p;
     if (L.has_beta) {
         // psi -> beta on the weight block:  M <- T^T M T,  T = blockdiag(I, E, 1)
@@ -424,8 +544,10 @@ __device__ inline void form_normal_matrix(const Lp& L, const Block& B) {
         }
         __syncthreads();
     }
+    EHM3_TICK(15);
     // mask, extra rows, identity: thread -> row tid >> 2, columns 16 (tid & 3) .. +15
     {
+        tid = pin(B.tid);
         const int r = tid >> 2, c0 = (tid & 3) * 16;
         unsigned long long mact = L.act;                       // columns with MPC entries
         if (!L.spec_mpc) mact &= ~(1ULL << (n + p));
@@ -469,24 +591,42 @@ __host__ __device__ constexpr int uoff(int k) { return u_row_start(k) - (k & ~1)
 
 // Step k publishes column k of the current Schur complement (register k of every lane; by
 // symmetry it is row k) as row k of the packed factor, which overwrites the square matrix
-// (dead: every lane holds its row).  No per-step lane predicates: finished lanes keep
-// computing values nobody reads.  On entry L.db[j] = original diagonal (dependent-pivot
-// guard, LIPSOL/PCx); on exit L.db[k] = 1 / U[k][k].
-__device__ __forceinline__ void lu_factor(double (&row)[NW], const Lp& L, int lane) {
+// (dead: every lane holds its row).  No per-step lane predicates in the arithmetic: finished
+// lanes keep computing values nobody reads.  The multipliers L[j][k], j > k, are parked
+// column-wise behind U (lcol), so the row registers die with this function.
+// Dependent-pivot guard (LIPSOL/PCx) against the original diagonal; rinv_out = 1 / U[lane][lane]
+// (guarded).
+constexpr int U_SIZE = NW * (NW + 2) / 2;
+__host__ __device__ constexpr int lcol(int k) { return U_SIZE + k * (NW - 1) - k * (k - 1) / 2 - k - 1; }
+static_assert(U_SIZE + NW * (NW - 1) / 2 <= NW * LDM + 1, "L and U share the matrix region");
+
+__device__ __forceinline__ void lu_factor(const Lp& L, int lane, double& rinv_out) {
     double* U = L.M;
+    double row[NW];
+    double diag0;
+    {
+        const double* mrow = L.M + lane * LDM;
+#pragma unroll
+        for (int q = 0; q < NW; ++q) row[q] = mrow[q];
+        diag0 = mrow[lane];
+    }
+    wsync();
+    double rinv_own = 0.0;
 #pragma unroll
     for (int k = 0; k < NW; ++k) {
         const int kk = k & ~1;
         if (lane >= kk) U[uoff(k) + lane] = row[k];
-        wsync();
-        double piv = U[uoff(k) + k];
-        const double orig = L.db[k];
+        // pivot and its original value travel through SGPRs: the reciprocal is ready while the
+        // column is still on its way through LDS
+        double piv = readlane_d(row[k], k);
+        const double orig = readlane_d(diag0, k);
         const bool bad = !(piv > EHM3_PIVOT_REL * orig) || !(piv > 0.0);
         piv = bad ? EHM3_PIVOT_BIG : piv;
         const double rinv = frcp(piv);
-        if (lane == 0) L.db[k] = rinv;
+        rinv_own = (lane == k) ? rinv : rinv_own;
         const double l = row[k] * rinv;
-        row[k] = l;
+        if (lane > k) U[lcol(k) + lane] = l;        // element (lane, k) of L
+        wsync();
         if (((k + 1) & 1) && k + 1 < NW) {
             const double ukq = U[uoff(k) + k + 1];
             row[k + 1] = fma(-l, ukq, row[k + 1]);
@@ -496,37 +636,58 @@ __device__ __forceinline__ void lu_factor(double (&row)[NW], const Lp& L, int la
             const double2v u = *reinterpret_cast<const double2v*>(U + uoff(k) + q);
             row[q] = fma(-l, u.x, row[q]);
             row[q + 1] = fma(-l, u.y, row[q + 1]);
+            // at most EHM3_LU_CHUNK broadcast values in flight (register budget)
+            if (((q - ((k + 2) & ~1)) / 2) % (EHM3_LU_CHUNK / 2) == EHM3_LU_CHUNK / 2 - 1)
+                __builtin_amdgcn_sched_barrier(0);
         }
         // keeps the trailing update of step k in step k (otherwise every FMA chain is sunk to
         // where row[q] is next read and n^2/2 broadcast values stay alive)
 #pragma unroll
         for (int q = k + 1; q < NW; ++q) asm volatile("" : "+v"(row[q]));
     }
+    rinv_out = rinv_own;
     wsync();
 }
 
 // Solve (LU) x = rhs; lane j passes rhs_j and 1/U[j][j]; L.t[j] receives x_j.
-__device__ __forceinline__ double lu_solve(const double (&row)[NW], const Lp& L, double rinv,
-                                           double rhs, int lane) {
+// Lanes <= k read the multiplier column k outside its range (in-bounds garbage): their
+// running right-hand side is dead by then, y_k / x_k are taken from the broadcast.
+__device__ __forceinline__ void lu_solve(const Lp& L, double rinv, double rhs, int lane) {
     double bv = rhs;
+    const double* lc = L.M + lane;
+    // no LDS stores inside the chains: lane k keeps y_k / x_k itself, so the multiplier and
+    // pivot-row loads can all be issued ahead of the serial v_readlane / FMA chain
+    double own = 0.0;
 #pragma unroll
-    for (int k = 0; k < NW; ++k) {
-        const double yk = readlane_d(bv, k);
-        if (lane == 0) L.ub[k] = yk;
-        bv = fma(-row[k], yk, bv);
+    for (int k0 = 0; k0 < NW; k0 += 16) {
+        double lv[16];
+#pragma unroll
+        for (int u = 0; u < 16; ++u) lv[u] = lc[lcol(k0 + u)];
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int u = 0; u < 16; ++u) {
+            const double yk = readlane_d(bv, k0 + u);
+            own = (lane == k0 + u) ? yk : own;
+            bv = fma(-lv[u], yk, bv);
+        }
     }
-    wsync();
-    bv = L.ub[lane];
+    bv = own;
     const double* urow = L.M + uoff(lane);
 #pragma unroll
-    for (int k = NW - 1; k >= 0; --k) {
-        const double xk = readlane_d(bv * rinv, k);
-        if (lane == 0) L.t[k] = xk;
-        // lanes > k read below their row start: in-bounds garbage, their bv is dead
-        bv = fma(-urow[k], xk, bv);
+    for (int k0 = NW - 16; k0 >= 0; k0 -= 16) {
+        double uv[16];
+#pragma unroll
+        for (int u = 0; u < 16; ++u) uv[u] = urow[k0 + u];
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int u = 15; u >= 0; --u) {
+            const double xk = readlane_d(bv * rinv, k0 + u);
+            own = (lane == k0 + u) ? xk : own;
+            bv = fma(-uv[u], xk, bv);
+        }
     }
+    L.t[lane] = own;
     wsync();
-    return L.t[lane];
 }
 
 // ---------------------------------------------------------------------------------------
@@ -534,9 +695,10 @@ __device__ __forceinline__ double lu_solve(const double (&row)[NW], const Lp& L,
 // tid + 256 * slot; MPC rows first, extras at m ..).  On exit L.xb holds the best iterate.
 // Every thread returns the same result.
 // ---------------------------------------------------------------------------------------
-__device__ inline IpmResult ipm_solve(const Lp& L, Block& B, const double (&b)[RS],
+__device__ __forceinline__ IpmResult ipm_solve(const Lp& L, Block& B, const double (&b)[RS],
                                       bool sign_only, double step_frac) {
-    const int tid = B.tid, lane = B.lane, wave = B.wave;
+    int tid = pin(B.tid), lane = tid & 63;
+    const int wave = B.wave;
     const int m = L.m, m_lp = L.m_lp;
     bool valid[RS];
     double s[RS], lam[RS], v[RS];
@@ -574,11 +736,16 @@ __device__ inline IpmResult ipm_solve(const Lp& L, Block& B, const double (&b)[R
     res.iters = 0;
     res.status = 1;
     int stall = 0;
-    double row[NW];         // wavefront 0: row `lane` of the factor
-    double rinv_l = 0.0;
+    double rinv_l = 0.0;    // wavefront 0: 1 / U[lane][lane]
 
+    EHM3_TICK_INIT();
+#ifdef EHM3_PROFILE
+    const unsigned long long prof_c0 = clock64(), prof_w0 = wall_clock64();
+#endif
     for (int it = 0; it <= EHM3_MAX_ITER; ++it) {
         // ---- residuals -----------------------------------------------------------------
+        tid = pin(B.tid);       // per-thread addresses are re-derived every phase (see pin)
+        lane = tid & 63;
         double r_p[RS], rs[RS];
         double rpmax = 0.0, sl_sum = 0.0, vl_sum = 0.0;
 #pragma unroll
@@ -595,7 +762,9 @@ __device__ inline IpmResult ipm_solve(const Lp& L, Block& B, const double (&b)[R
             }
         }
         __syncthreads();
+        EHM3_TICK(0);
         cols_times<true>(L, B, L.u0, L.u1);
+        EHM3_TICK(1);
         double atl = 0.0, atdr = 0.0, xj = 0.0;
         if (tid < NW) {
             atl = L.g0[tid];
@@ -645,6 +814,8 @@ __device__ inline IpmResult ipm_solve(const Lp& L, Block& B, const double (&b)[R
         if (stall >= 3 || it == EHM3_MAX_ITER || !(merit == merit)) break;
 
         // ---- normal matrix and its factorisation ----------------------------------------
+        tid = pin(B.tid);
+        lane = tid & 63;
 #pragma unroll
         for (int sl = 0; sl < RS; ++sl) {
             const int i = tid + NT * sl;
@@ -655,23 +826,27 @@ __device__ inline IpmResult ipm_solve(const Lp& L, Block& B, const double (&b)[R
             }
         }
         __syncthreads();
+        EHM3_TICK(2);
         form_normal_matrix(L, B);
+        EHM3_TICK(3);
         const double rhs_aff = -cj - atdr;      // 0 on columns the LP does not have
+        tid = pin(B.tid);
+        lane = tid & 63;
         if (wave == 0) {
-            const double* mrow = L.M + lane * LDM;
-#pragma unroll
-            for (int q = 0; q < NW; ++q) row[q] = mrow[q];
-            L.db[lane] = mrow[lane];
-            wsync();
-            lu_factor(row, L, lane);
-            rinv_l = L.db[lane];
+            lu_factor(L, lane, rinv_l);
+            EHM3_TICK(4);
             // ---- predictor --------------------------------------------------------------
-            lu_solve(row, L, rinv_l, rhs_aff, lane);
+            lu_solve(L, rinv_l, rhs_aff, lane);
             to_block_columns(L, lane);
+            EHM3_TICK(5);
         }
         __syncthreads();
+        EHM3_TICK(6);
+        tid = pin(B.tid);
+        lane = tid & 63;
         double adx[RS];
-        rows_times(L, tid, adx);
+        rows_times(L, tid, wave, adx);
+        EHM3_TICK(7);
         double ds_a[RS], dl_a[RS];
         double rho_p = 0.0, rho_d = 0.0;
 #pragma unroll
@@ -702,6 +877,8 @@ __device__ inline IpmResult ipm_solve(const Lp& L, Block& B, const double (&b)[R
         const double smu = sigma * mu;
 
         // ---- corrector ------------------------------------------------------------------
+        tid = pin(B.tid);
+        lane = tid & 63;
         double corr[RS];
 #pragma unroll
         for (int sl = 0; sl < RS; ++sl) {
@@ -709,14 +886,22 @@ __device__ inline IpmResult ipm_solve(const Lp& L, Block& B, const double (&b)[R
             if (valid[sl]) L.u1[tid + NT * sl] = corr[sl];
         }
         __syncthreads();
+        EHM3_TICK(8);
         cols_times<false>(L, B, L.u1, L.u1);
+        EHM3_TICK(9);
+        tid = pin(B.tid);
+        lane = tid & 63;
         if (wave == 0) {
             const double rhs = rhs_aff + L.g0[lane];
-            lu_solve(row, L, rinv_l, rhs, lane);
+            lu_solve(L, rinv_l, rhs, lane);
             to_block_columns(L, lane);
         }
         __syncthreads();
-        rows_times(L, tid, adx);
+        EHM3_TICK(10);
+        tid = pin(B.tid);
+        lane = tid & 63;
+        rows_times(L, tid, wave, adx);
+        EHM3_TICK(11);
         double ds[RS], dl[RS];
         rho_p = 0.0;
         rho_d = 0.0;
@@ -745,8 +930,15 @@ __device__ inline IpmResult ipm_solve(const Lp& L, Block& B, const double (&b)[R
             }
         }
         __syncthreads();
+        EHM3_TICK(12);
     }
     __syncthreads();
+#ifdef EHM3_PROFILE
+    if (tid == 0) {     // shader clock vs the 100 MHz wall clock
+        atomicAdd(&g_prof3[16], (unsigned long long)clock64() - prof_c0);
+        atomicAdd(&g_prof3[17], (unsigned long long)wall_clock64() - prof_w0);
+    }
+#endif
     if (res.status != 0 && res.merit <= EHM3_ACCEPT_MERIT) res.status = 0;
     res.margin = fabs(res.obj);
     return res;

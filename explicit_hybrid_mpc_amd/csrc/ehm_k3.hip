@@ -29,7 +29,7 @@ __host__ __device__ inline size_t node_doubles(int p, int n_u) {
 
 // P_theta_delta at one parameter value (lib/oracle.py:141-173) or its phase-one form
 //   min tau  s.t.  G z - tau <= w + S theta,  tau >= -1.
-__device__ inline void assemble_point(Lp& L, const double* theta, bool feas, double (&b)[RS],
+__device__ __forceinline__ void assemble_point(Lp& L, const double* theta, bool feas, double (&b)[RS],
                                       int tid) {
     const int n = L.n, m = L.m, p = L.p;
     L.ne = feas ? 1 : 0;
@@ -63,7 +63,7 @@ __device__ inline void assemble_point(Lp& L, const double* theta, bool feas, dou
 //                           Vbar0 + dV^T beta - (1+eps_r) V >= t   (lib/oracle.py:89-97)
 //   SX_FEAS  : min tau s.t. MPC rows relaxed by tau, tau >= -1
 // Extra rows: e < p facets -beta_e <= 0, e = p sum beta <= 1, then the dense ones.
-__device__ inline void assemble_simplex(Lp& L, const double* R, const double* Vbar, int mode,
+__device__ __forceinline__ void assemble_simplex(Lp& L, const double* R, const double* Vbar, int mode,
                                         double eps_a, double eps_r, double (&b)[RS], int tid) {
     const int n = L.n, m = L.m, p = L.p;
     const bool slack = (mode == SX_SLACK);
@@ -138,11 +138,12 @@ __device__ __forceinline__ void count_solve(DevCounters* cnt, const IpmResult& r
 
 #define K3_PROLOGUE(D)                                                           \
     double* sm = reinterpret_cast<double*>(k3_smem);                             \
-    const int tid = threadIdx.x;                                                 \
+    const int tid0 = threadIdx.x;                                                \
+    int tid = tid0;                                                              \
     Block B;                                                                     \
-    B.tid = tid;                                                                 \
-    B.lane = tid & 63;                                                           \
-    B.wave = __builtin_amdgcn_readfirstlane(tid >> 6);                           \
+    B.tid = tid0;                                                                \
+    B.lane = tid0 & 63;                                                          \
+    B.wave = __builtin_amdgcn_readfirstlane(tid0 >> 6);                          \
     B.flip = 0;                                                                  \
     NodeBuf nb;                                                                  \
     carve_node(nb, sm, P.p, P.n_u);                                              \
@@ -151,7 +152,7 @@ __device__ __forceinline__ void count_solve(DevCounters* cnt, const IpmResult& r
     carve_lp(L, sm + node_doubles(P.p, P.n_u), P, (D))
 
 // ---- a2: P_theta_delta batch / its feasibility form; instances sorted by commutation -----
-__global__ __launch_bounds__(EHM3_THREADS) void k3_point_batch(
+EHM3_KERNEL void k3_point_batch(
     DevProblem P, long long n_inst, const double* __restrict__ theta,
     const int32_t* __restrict__ seg, int feas, double* __restrict__ J, double* __restrict__ u0,
     int32_t* __restrict__ status, int32_t* __restrict__ iters, DevCounters* cnt) {
@@ -161,6 +162,7 @@ __global__ __launch_bounds__(EHM3_THREADS) void k3_point_batch(
     const long long hi = (lo + per < n_inst) ? lo + per : n_inst;
     int d = 0;
     for (long long inst = lo; inst < hi; ++inst) {
+        tid = pin(tid0);
         while (d + 1 < P.n_delta && seg[d + 1] <= inst) ++d;
         carve_lp(L, sm + node_doubles(P.p, P.n_u), P, d);
         if (tid < P.p) nb.th[tid] = theta[inst * P.p + tid];
@@ -169,7 +171,7 @@ __global__ __launch_bounds__(EHM3_THREADS) void k3_point_batch(
         int its = 0;
         for (int attempt = 0; attempt < EHM3_ATTEMPTS; ++attempt) {     // see EHM3_STEP_FRAC
             double b[RS];
-            assemble_point(L, nb.th, feas != 0, b, tid);
+            assemble_point(L, nb.th, feas != 0, b, pin(tid));
             r = ipm_solve(L, B, b, false, step_fraction(attempt));
             its += r.iters;
             if (r.status == 0) break;
@@ -187,7 +189,7 @@ __global__ __launch_bounds__(EHM3_THREADS) void k3_point_batch(
 }
 
 // ---- a5 / a7': problems over a simplex, one commutation per instance (sorted) -------------
-__global__ __launch_bounds__(EHM3_THREADS) void k3_simplex_batch(
+EHM3_KERNEL void k3_simplex_batch(
     DevProblem P, long long n_inst, const double* __restrict__ R,
     const double* __restrict__ Vbar, const int32_t* __restrict__ seg, int mode,
     double* __restrict__ obj, double* __restrict__ alpha, int32_t* __restrict__ status,
@@ -200,6 +202,7 @@ __global__ __launch_bounds__(EHM3_THREADS) void k3_simplex_batch(
     const long long hi = (lo + per < n_inst) ? lo + per : n_inst;
     int d = 0;
     for (long long inst = lo; inst < hi; ++inst) {
+        tid = pin(tid0);
         while (d + 1 < P.n_delta && seg[d + 1] <= inst) ++d;
         carve_lp(L, sm + node_doubles(P.p, P.n_u), P, d);
         double* Rl = nb.rec;
@@ -211,7 +214,7 @@ __global__ __launch_bounds__(EHM3_THREADS) void k3_simplex_batch(
         int its = 0;
         for (int attempt = 0; attempt < EHM3_ATTEMPTS; ++attempt) {
             double b[RS];
-            assemble_simplex(L, Rl, Vl, mode, P.eps_a, P.eps_r, b, tid);
+            assemble_simplex(L, Rl, Vl, mode, P.eps_a, P.eps_r, b, pin(tid));
             r = ipm_solve(L, B, b, false, step_fraction(attempt));
             its += r.iters;
             if (r.status == 0) break;
@@ -235,7 +238,7 @@ __global__ __launch_bounds__(EHM3_THREADS) void k3_simplex_batch(
 
 // ---- frontier sweep (single commutation): epsilon-suboptimality decision per node --------
 // (lib/worker.py:368-375)
-__global__ __launch_bounds__(EHM3_THREADS) void k3_lcss_decide(
+EHM3_KERNEL void k3_lcss_decide(
     DevProblem P, DevTree T, const int32_t* __restrict__ frontier, int nf,
     int32_t* __restrict__ open_flag, DevCounters* cnt, int sign_only) {
     K3_PROLOGUE(0);
@@ -244,6 +247,7 @@ __global__ __launch_bounds__(EHM3_THREADS) void k3_lcss_decide(
     const int lo = blockIdx.x * per;
     const int hi = (lo + per < nf) ? lo + per : nf;
     for (int f = lo; f < hi; ++f) {
+        tid = pin(tid0);
         const int id = frontier[f];
         const double* rec = T.rec + (size_t)id * T.rec_stride;
         for (int k = tid; k < nrec; k += NT) nb.rec[k] = rec[k];
@@ -253,7 +257,7 @@ __global__ __launch_bounds__(EHM3_THREADS) void k3_lcss_decide(
         for (int attempt = 0; attempt < EHM3_ATTEMPTS; ++attempt) {
             double b[RS];
             assemble_simplex(L, nb.rec, nb.rec + rec_off_vcost(P.p), SX_SLACK, P.eps_a, P.eps_r,
-                             b, tid);
+                             b, pin(tid));
             r = ipm_solve(L, B, b, sign_only != 0, step_fraction(attempt));
             its += r.iters;
             if (r.status == 0) break;
@@ -280,7 +284,7 @@ __global__ __launch_bounds__(EHM3_THREADS) void k3_lcss_decide(
 
 // ---- split every open node, solve P_theta_delta at the midpoint, write the children -------
 // (lib/worker.py:403-414, 354-365)
-__global__ __launch_bounds__(EHM3_THREADS) void k3_lcss_expand(
+EHM3_KERNEL void k3_lcss_expand(
     DevProblem P, DevTree T, const int32_t* __restrict__ open_list, int n_open, int child_base,
     int32_t* __restrict__ next_frontier, DevCounters* cnt) {
     K3_PROLOGUE(0);
@@ -290,6 +294,7 @@ __global__ __launch_bounds__(EHM3_THREADS) void k3_lcss_expand(
     const int lo = blockIdx.x * per;
     const int hi = (lo + per < n_open) ? lo + per : n_open;
     for (int f = lo; f < hi; ++f) {
+        tid = pin(tid0);
         const int id = open_list[f];
         const double* rec = T.rec + (size_t)id * T.rec_stride;
         double* node = nb.rec;
@@ -308,7 +313,7 @@ __global__ __launch_bounds__(EHM3_THREADS) void k3_lcss_expand(
         int its = 0;
         for (int attempt = 0; attempt < EHM3_ATTEMPTS; ++attempt) {
             double b[RS];
-            assemble_point(L, mid, false, b, tid);
+            assemble_point(L, mid, false, b, pin(tid));
             r = ipm_solve(L, B, b, false, step_fraction(attempt));
             its += r.iters;
             if (r.status == 0) break;
@@ -360,7 +365,7 @@ __global__ __launch_bounds__(EHM3_THREADS) void k3_lcss_expand(
 }
 
 // ---- vertex solves that seed a node's costs / inputs (lib/oracle.py:416-443) ---------------
-__global__ __launch_bounds__(EHM3_THREADS) void k3_vertex_solve(
+EHM3_KERNEL void k3_vertex_solve(
     DevProblem P, DevTree T, const int32_t* __restrict__ nodes, int n_nodes, DevCounters* cnt) {
     K3_PROLOGUE(0);
     const int p = P.p, n_u = P.n_u;
@@ -369,6 +374,7 @@ __global__ __launch_bounds__(EHM3_THREADS) void k3_vertex_solve(
     const int lo = blockIdx.x * per;
     const int hi = (lo + per < total) ? lo + per : total;
     for (int t = lo; t < hi; ++t) {
+        tid = pin(tid0);
         const int id = nodes[t / (p + 1)];
         const int v = t % (p + 1);
         double* rec = T.rec + (size_t)id * T.rec_stride;
@@ -378,7 +384,7 @@ __global__ __launch_bounds__(EHM3_THREADS) void k3_vertex_solve(
         int its = 0;
         for (int attempt = 0; attempt < EHM3_ATTEMPTS; ++attempt) {
             double b[RS];
-            assemble_point(L, nb.th, false, b, tid);
+            assemble_point(L, nb.th, false, b, pin(tid));
             r = ipm_solve(L, B, b, false, step_fraction(attempt));
             its += r.iters;
             if (r.status == 0) break;
@@ -486,6 +492,23 @@ const K2Api g_api = {NW,      4 * EHM3_RS, EHM3_THREADS, EHM3_THREADS, set_lds, 
                      l_vertex, l_selftest};
 
 }  // namespace
+
+// phase timers of an experimental build (-DEHM3_PROFILE); zeros otherwise
+#define K3P_CAT2(a, b) a##b
+#define K3P_CAT(a, b) K3P_CAT2(a, b)
+extern "C" int K3P_CAT(ehm_k3_profile_, EHM3_RS)(unsigned long long* out, int reset) {
+#ifdef EHM3_PROFILE
+    unsigned long long zero[32] = {0};
+    if (hipMemcpyFromSymbol(out, HIP_SYMBOL(EHM3_NS::g_prof3), sizeof zero) != hipSuccess) return -1;
+    if (reset && hipMemcpyToSymbol(HIP_SYMBOL(EHM3_NS::g_prof3), zero, sizeof zero) != hipSuccess)
+        return -1;
+    return 1;
+#else
+    for (int k = 0; k < 32; ++k) out[k] = 0;
+    (void)reset;
+    return 0;
+#endif
+}
 
 #define K3_CAT2(a, b) a##b
 #define K3_CAT(a, b) K3_CAT2(a, b)

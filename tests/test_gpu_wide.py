@@ -112,3 +112,43 @@ def test_sub_forest_identical_to_cpu_partition(wide):
         assert abs(flat.info['volume_closed'] - total) <= 1e-9 * total
         assert flat.info['min_margin'] > 1e-6
     gp.set_option('decide_full', 0)
+
+
+def test_wide_hybrid_batches_match_oracle():
+    """
+    Multi-commutation instance on the wide kernels (2-mode PWA, N = 8: 256 commutations, LPs of
+    32..37 columns x 264..271 rows): instances arrive unsorted, the batch kernels walk the
+    commutation segments.
+    """
+    from explicit_hybrid_mpc_amd import engine, examples
+    from oracle.oracle_cpu import OracleCPU
+    mpc = examples.pwa_mpc(seed=0, n_x=4, n_u=2, N=8)
+    can = mpc.compile()
+    assert can.n_delta == 256 and can.n + can.p + 1 > 32
+    gp = engine.GpuProblem(can, 0.05, 0.1)
+    orc = OracleCPU(mpc, 0.05, 0.1)
+    rng = np.random.default_rng(21)
+    half = examples.theta_box(mpc, scale=0.45)
+    n = 96
+    theta = rng.uniform(-1, 1, (n, can.p)) * half
+    # commutations that stay in one mode for long stretches are the feasible ones
+    pick = rng.integers(can.n_delta, size=n)
+    pick[::3] = 0
+    pick[1::3] = can.n_delta - 1
+    delta = can.deltas[pick]
+    feas, _ = gp.feasible_ptd(theta, delta)
+    ref = np.array([orc.P_theta_delta(theta[k], delta[k], check_feasibility=True)
+                    for k in range(n)])
+    assert np.array_equal(feas, ref)
+    assert feas.any() and (~feas).any()
+    J, _, st, _ = gp.solve_ptd(theta[feas], delta[feas])
+    assert (st == 0).all()
+    for k, kk in enumerate(np.where(feas)[0]):
+        J_ref = orc.P_theta_delta(theta[kk], delta[kk])[1]
+        assert abs(J[k] - J_ref) <= RTOL * (1 + abs(J_ref)), (kk, J[k], J_ref)
+    # P_theta: minimum over all 256 commutations per parameter
+    Jp, _, didx = gp.solve_pt(theta[:6])
+    for k in range(6):
+        _, _, J_ref, _ = orc.P_theta(theta[k])
+        assert didx[k] >= 0 and abs(Jp[k] - J_ref) <= RTOL * (1 + abs(J_ref))
+    gp.close()
