@@ -106,6 +106,10 @@ def main():
                     help='frontier size at which it is dealt over the ranks (0 = 64 per rank)')
     ap.add_argument('--sweeps-per-round', type=int, default=2,
                     help='frontier sweeps between two rebalancing rounds (N > 1)')
+    ap.add_argument('--status-dir', default=None,
+                    help='write status.txt / statistics.pkl (reference formats) there; adds one '
+                         'progress read-back (and, N > 1, one all-gather) per round -- off by '
+                         'default, the headline number is measured without it')
     ap.add_argument('--cpu-seconds', type=float, default=15.)
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--solver', type=int, default=2, help='kernel generation (1 or 2)')
@@ -155,15 +159,23 @@ def main():
     shard = distributed.shard_spec(rank, world, args.shard_min_frontier)
 
     xdev = ('cuda:%d' % device_index) if backend == 'nccl' else None
+    publisher = None
+    if args.status_dir and rank == 0:
+        from explicit_hybrid_mpc_amd import status as ehm_status
+        os.makedirs(args.status_dir, exist_ok=True)
+        publisher = ehm_status.MainStatusPublisher(
+            float(np.prod(2. * half)), os.path.join(args.status_dir, 'status.txt'),
+            os.path.join(args.status_dir, 'statistics.pkl'))
 
     def step():
-        if world == 1:
+        if world == 1 and not args.status_dir:
             return gp.partition(roots, action='ecc', max_nodes=args.max_nodes, export=False,
                                 shard=shard, with_volume=False)
         info, log, rounds = distributed.run_balanced(
             gp, roots, action='ecc', max_nodes=args.max_nodes,
             min_frontier=args.shard_min_frontier, sweeps_per_round=args.sweeps_per_round,
-            device=xdev, export=False)
+            device=xdev, export=False, status=publisher,
+            publish_status=bool(args.status_dir))
         info['rounds'] = rounds
         info['moved'] = sum(len(e['ids']) for e in log if e['kind'] == 'give')
         return info

@@ -33,7 +33,7 @@ EXPORTED = [
     'ehm_problem_set_option', 'ehm_partition_begin', 'ehm_partition_step',
     'ehm_partition_take', 'ehm_partition_give', 'ehm_partition_finish',
     'ehm_explicit_create', 'ehm_explicit_eval_batch', 'ehm_explicit_destroy',
-    'ehm_explicit_last_error',
+    'ehm_explicit_last_error', 'ehm_partition_progress',
 ]
 
 
@@ -75,6 +75,14 @@ class TreeInfo(ctypes.Structure):
                 ('expand_launches', ctypes.c_int64), ('decide_solves', ctypes.c_int64),
                 ('decide_iters', ctypes.c_int64), ('replicated_closed', ctypes.c_int64),
                 ('replicated_nodes', ctypes.c_int64), ('replicated_solves', ctypes.c_int64)]
+
+
+class Progress(ctypes.Structure):
+    _fields_ = [('n_nodes', ctypes.c_int64), ('n_closed', ctypes.c_int64),
+                ('frontier', ctypes.c_int64), ('sweeps', ctypes.c_int64),
+                ('lp_solves', ctypes.c_int64), ('ipm_iters', ctypes.c_int64),
+                ('depth', ctypes.c_int32), ('reserved', ctypes.c_int32),
+                ('volume_closed', ctypes.c_double)]
 
 
 class Counters(ctypes.Structure):
@@ -134,6 +142,7 @@ def load(build_if_missing=True):
     lib.ehm_partition_take.argtypes = [vp, i64, vp, vp, vp]
     lib.ehm_partition_give.argtypes = [vp, i64, vp, vp, vp]
     lib.ehm_partition_finish.argtypes = [vp]
+    lib.ehm_partition_progress.argtypes = [vp, ctypes.POINTER(Progress)]
     lib.ehm_explicit_create.argtypes = [i32, i64, i32, i32, i32, vp, vp, vp, vp,
                                         ctypes.POINTER(vp)]
     lib.ehm_explicit_eval_batch.argtypes = [vp, i64, vp, vp, vp, vp, vp]

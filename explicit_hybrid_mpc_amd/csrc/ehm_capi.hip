@@ -189,6 +189,24 @@ __global__ void k_volume_batch(long long n, int p, const double* __restrict__ R,
     vol[k] = simplex_volume_dev(R + k * (p + 1) * p, p);
 }
 
+// Progress of a run (lib/worker.py:374-375 "volume_filled_increment"): volume of the closed
+// leaves of pool nodes [0, n).  Thread per node, fixed-shape tree reduction per workgroup,
+// one partial sum per workgroup (the host adds them in order: reproducible).
+__global__ __launch_bounds__(256) void k_closed_volume(DevTree T, long long first, long long n,
+                                                       double* __restrict__ partial) {
+    __shared__ double red[256];
+    const long long k = first + (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    double v = 0.0;
+    if (k < n && (T.flags[k] & 1)) v = simplex_volume_dev(T.rec + (size_t)k * T.rec_stride, T.p);
+    red[threadIdx.x] = v;
+    __syncthreads();
+    for (int o = 128; o > 0; o >>= 1) {
+        if ((int)threadIdx.x < o) red[threadIdx.x] += red[threadIdx.x + o];
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) partial[blockIdx.x] = red[0];
+}
+
 // ---- frontier sweep, level-synchronous engine ---------------------------------------------
 // K1: epsilon-suboptimality decision for every frontier node (lib/worker.py:368-375).
 __global__ __launch_bounds__(64) void k_lcss_decide(DevProblem P, DevTree T,
@@ -463,6 +481,7 @@ struct ehm_tree {
         bool sharded = true, cur_is_a = true;
         long long n_roots = 0, n_nodes = 0, nf = 0, n_closed = 0, ref_solves = 0;
         long long pre_closed = 0, pre_nodes = 0, pre_solves = 0, given = 0, received = 0;
+        long long pre_first = 0;    // first node id of the frontier that was dealt
         int sweeps = 0, depth = 0, truncated = 0;
         DevCounters c0{};
         hipEvent_t ev0 = nullptr;
@@ -1702,6 +1721,8 @@ int ehm_partition_step(ehm_tree* T, int32_t max_sweeps, int64_t* frontier_size) 
             P->launches++;
             cur = ob.as<int32_t>();
             R.cur_is_a = !R.cur_is_a;
+            // the frontier that is dealt is the last level grown: ids [n_nodes - nf, n_nodes)
+            R.pre_first = (R.sweeps == 0) ? 0 : R.n_nodes - R.nf;
             R.nf = (R.nf - R.shard_rank + R.shard_world - 1) / R.shard_world;
             R.sharded = true;
             // work done so far is replicated on every rank
@@ -1866,6 +1887,49 @@ int ehm_partition_give(ehm_tree* T, int64_t count, const double* records, const 
     R.n_nodes += count;
     R.nf += count;
     R.received += count;
+    return EHM_OK;
+}
+
+int ehm_partition_progress(ehm_tree* T, ehm_progress* out) {
+    if (!T || !out) return fail(EHM_E_INVALID, "null argument");
+    if (!T->run.active) return fail(EHM_E_INVALID, "no partition run in progress");
+    ehm_problem* P = T->prob;
+    auto& R = T->run;
+    HIP_TRY(hipSetDevice(P->device), EHM_E_HIP);
+    DevCounters c1;
+    int rc = read_counters(P, c1);      // synchronises the stream
+    if (rc) return rc;
+    // multi-GPU: the top of the tree is grown identically on every rank until the frontier is
+    // dealt; rank 0 reports it, the others only what they grew themselves
+    // (its share of the dealt frontier -- still undecided then -- and everything appended since)
+    const long long n = R.n_nodes;
+    long long first = 0, own_nodes = n, own_closed = R.n_closed;
+    if (R.shard_world > 1 && R.shard_rank > 0) {
+        first = R.sharded ? R.pre_first : n;
+        own_nodes = R.sharded ? n - R.pre_nodes : 0;
+        own_closed = R.sharded ? R.n_closed - R.pre_closed : 0;
+    }
+    const int blocks = (int)((n - first + 255) / 256);
+    double vol = 0.0;
+    if (blocks > 0) {
+        rc = P->out3.ensure((size_t)blocks * sizeof(double));
+        if (rc) return rc;
+        hipLaunchKernelGGL(k_closed_volume, dim3(blocks), dim3(256), 0, P->stream, T->dt, first,
+                           n, P->out3.as<double>());
+        std::vector<double> part((size_t)blocks);
+        HIP_TRY(hipMemcpyAsync(part.data(), P->out3.ptr, part.size() * sizeof(double),
+                               hipMemcpyDeviceToHost, P->stream), EHM_E_HIP);
+        HIP_TRY(hipStreamSynchronize(P->stream), EHM_E_HIP);
+        for (double v : part) vol += v;
+    }
+    out->n_nodes = own_nodes;
+    out->n_closed = own_closed;
+    out->frontier = R.nf;
+    out->sweeps = R.sweeps;
+    out->depth = R.depth;
+    out->lp_solves = (int64_t)(c1.lp_solves - R.c0.lp_solves);
+    out->ipm_iters = (int64_t)(c1.ipm_iters - R.c0.ipm_iters);
+    out->volume_closed = vol;
     return EHM_OK;
 }
 

@@ -148,14 +148,51 @@ def _exchange(run, plan, rank, device, rnd, log):
             log.append(dict(kind='recv', round=rnd, peer=donor, first=first, count=n))
 
 
+def allgather_floats(values, device=None):
+    """(world, len(values)) float64 array of every rank's values."""
+    import torch
+    import torch.distributed as dist
+    if not (dist.is_available() and dist.is_initialized()):
+        return np.asarray([values], dtype=np.float64)
+    t = torch.tensor([float(v) for v in values], dtype=torch.float64, device=device or 'cpu')
+    out = [torch.zeros_like(t) for _ in range(dist.get_world_size())]
+    dist.all_gather(out, t)
+    return np.stack([o.cpu().numpy() for o in out])
+
+
+_STATUS_KEYS = ('volume_filled_total', 'simplex_count_total', 'time_active_total', 'time_idle',
+                'time_ecc', 'time_lcss')
+
+
+def _publish(status, worker, run, live, device, rank, force=False):
+    """Every rank's status record to rank 0's MainStatusPublisher (one small all-gather)."""
+    worker.absorb(run.progress())
+    vals = [worker.data[k] for k in _STATUS_KEYS] + [1. if worker.data['status'] == 'active'
+                                                    else 0., float(live)]
+    allv = allgather_floats(vals, device=device)
+    if rank != 0 or status is None:
+        return
+    procs = []
+    for r, row in enumerate(allv):
+        d = dict(worker.data) if r == 0 else dict(worker.data, current_location='')
+        for k, v in zip(_STATUS_KEYS, row):
+            d[k] = int(v) if k == 'simplex_count_total' else float(v)
+        d['simplex_count_current'] = d['simplex_count_total']
+        d['status'] = 'active' if row[len(_STATUS_KEYS)] > 0 else 'idle'
+        procs.append(d)
+    status.update(procs, num_tasks_in_queue=int(allv[:, -1].sum()), force=force)
+
+
 def run_balanced(gp, roots, action='ecc', init=None, max_nodes=0, min_frontier=1024,
                  sweeps_per_round=3, tolerance=0.1, min_move=16, device=None, export=False,
-                 with_volume=False, run_factory=None):
+                 with_volume=False, run_factory=None, status=None, publish_status=False):
     """
     One partition over all ranks with periodic rebalancing of the live frontiers.
     Returns (FlatTree or info dict of THIS rank's share, transfer log, rounds).
     run_factory(shard) -> object with step/take/give/finish/nrec replaces the GPU engine
     (the CPU tests emulate it).
+    publish_status (same value on EVERY rank) adds one all-gather of the ranks' progress
+    counters per round; rank 0 passes them to ``status`` (a status.MainStatusPublisher).
     """
     import torch.distributed as dist
     rank, _, world = env_rank_world()
@@ -168,15 +205,28 @@ def run_balanced(gp, roots, action='ecc', init=None, max_nodes=0, min_frontier=1
         run = gp.begin(roots, action=action, init=init, max_nodes=max_nodes, shard=shard,
                        with_volume=with_volume)
     log, rnd = [], 0
+    worker = None
+    if publish_status:
+        from . import status as _status
+        worker = _status.WorkerStatus(algorithm=action)
+        worker.update(active=True)
     while True:
-        n = run.step(sweeps_per_round if world > 1 else 0)
+        n = run.step(sweeps_per_round if (world > 1 or publish_status) else 0)
+        if publish_status:
+            if n == 0:
+                worker.update(active=False)
+            _publish(status, worker, run, n, device, rank, force=(world == 1 and n == 0))
         if world == 1:
-            break
+            if n == 0:
+                break
+            continue
         counts = allgather_counts([n], device=device)[:, 0]
         if counts.sum() == 0:
             break
         _exchange(run, balance_plan(counts, tolerance, min_move), rank, device, rnd, log)
         rnd += 1
+    if publish_status and world > 1:
+        _publish(status, worker, run, 0, device, rank, force=True)
     return run.finish(export), log, rnd
 
 

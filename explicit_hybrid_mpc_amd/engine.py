@@ -217,14 +217,32 @@ class GpuProblem:
 
     # -- partition ------------------------------------------------------------------------------
     def partition(self, roots, action='ecc', init=None, max_nodes=0, max_depth=0, engine=0,
-                  export=True, shard=None, with_volume=True):
+                  export=True, shard=None, with_volume=True, status=None, status_sweeps=1):
         """
         Grow every root simplex until all leaves are epsilon-suboptimal.
         roots: (n_roots, p+1, p).  init: optional dict(delta, vertex_costs, vertex_inputs)
         for action 'lcss'.  shard = (rank, world, min_frontier) keeps only this rank's share
         of the frontier once it is min_frontier wide (multi-GPU).  Returns a FlatTree, or
         just the info dict when export is False.
+        status: optional ``status.MainStatusPublisher``; the run is then advanced
+        ``status_sweeps`` frontier sweeps at a time and the publisher is fed the device's
+        progress counters in between (status.txt / statistics.pkl of the reference).
         """
+        if status is not None:
+            from . import status as _status
+            run = self.begin(roots, action=action, init=init, max_nodes=max_nodes,
+                             max_depth=max_depth, shard=shard, with_volume=with_volume)
+            worker = _status.WorkerStatus(algorithm=action)
+            worker.update(active=True)
+            while True:
+                live = run.step(max(1, int(status_sweeps)))
+                worker.absorb(run.progress())
+                status.update([worker.data], num_tasks_in_queue=live)
+                if live == 0:
+                    break
+            worker.update(active=False)
+            status.update([worker.data], num_tasks_in_queue=0, force=True)
+            return run.finish(export=export)
         roots = f64(roots).reshape(-1, self.can.p + 1, self.can.p)
         n_roots = roots.shape[0]
         rank, world, min_frontier = shard if shard is not None else (0, 1, 0)
@@ -324,6 +342,13 @@ class PartitionRun:
         check(self._lib.ehm_partition_step(self._tree, int(max_sweeps), ctypes.addressof(n)))
         self.frontier = int(n.value)
         return self.frontier
+
+    def progress(self):
+        """Volume filled / simplex count / LP solves so far (ehm_partition_progress)."""
+        pr = _capi.Progress()
+        check(self._lib.ehm_partition_progress(self._tree, ctypes.byref(pr)))
+        return {name: getattr(pr, name) for name, _ in _capi.Progress._fields_
+                if name != 'reserved'}
 
     def take(self, count):
         """Hand over the last `count` frontier nodes: (node ids, records, meta)."""

@@ -207,6 +207,22 @@ int ehm_partition_give(ehm_tree* tree, int64_t count, const double* records,
                        const int32_t* meta, int32_t* first_id);
 int ehm_partition_finish(ehm_tree* tree);
 
+/* Progress of a run in flight, between two ehm_partition_step calls: what the reference's
+ * WorkerStatusPublisher accumulates per closed leaf (lib/worker.py:19-116, 374-375) -- volume
+ * filled, simplex count -- read from the device node pool (one reduction kernel). */
+typedef struct ehm_progress {
+    int64_t n_nodes;        /* simplices generated so far (multi-GPU: the replicated top */
+    int64_t n_closed;       /* of the tree is reported by rank 0 only); closed leaves    */
+    int64_t frontier;       /* live frontier size                                       */
+    int64_t sweeps;
+    int64_t lp_solves;
+    int64_t ipm_iters;
+    int32_t depth;
+    int32_t reserved;
+    double  volume_closed;  /* sum of the closed leaves' volumes                        */
+} ehm_progress;
+int ehm_partition_progress(ehm_tree* tree, ehm_progress* out);
+
 typedef struct ehm_tree_info {
     int64_t n_nodes;
     int64_t n_leaves;

@@ -50,3 +50,34 @@ def test_tree_identical_to_cpu_partition(kind, seed, abs_frac, eps_r, decide_ful
     assert abs(flat.info['volume_closed'] - total) <= 1e-9 * total
     assert flat.info['min_margin'] > 1e-6
     assert min(cpu.min_margin, flat.info['min_margin']) > 1e-6
+
+
+def test_status_publisher_follows_the_run(tmp_path):
+    """
+    SURVEY section 8 f4: status.txt / statistics.pkl in the reference's formats, fed from the
+    device's progress counters between sweeps; the tree is the one a plain run grows.
+    """
+    from explicit_hybrid_mpc_amd import engine, examples, status
+    from oracle import geometry
+    mpc = helpers.make_instance('lin', 0)
+    eps_a = helpers.eps_a_rule(mpc, 0.25)
+    roots, locs = helpers.roots_of(mpc)
+    roots = np.array(roots)
+    total = sum(geometry.simplex_volume(R) for R in roots)
+    gp = engine.GpuProblem(mpc.compile(), eps_a, 0.5)
+    plain = gp.partition(roots, action='ecc')
+    st, pk = str(tmp_path / 'status.txt'), str(tmp_path / 'statistics.pkl')
+    pub = status.MainStatusPublisher(total, st, pk)
+    flat = gp.partition(roots, action='ecc', status=pub, status_sweeps=2)
+    gp.close()
+    assert np.array_equal(flat.vertices, plain.vertices) and np.array_equal(flat.left, plain.left)
+    assert np.array_equal(flat.flags & 1, plain.flags & 1)
+    stats = status.load_statistics(pk)
+    frac = stats['volume_filled_frac']
+    assert len(frac) >= 3 and all(b >= a for a, b in zip(frac, frac[1:]))
+    assert abs(frac[-1] - 1.) < 1e-9
+    assert stats['simplex_count_total'][-1] == flat.n_nodes
+    assert stats['num_proc_active'][-1] == 0 and max(stats['num_proc_active']) == 1
+    text = open(st).read()
+    assert 'volume filled (total [%]): 1.0000e+02' in text
+    assert 'simplex_count: %d' % flat.n_nodes in text

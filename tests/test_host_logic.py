@@ -117,3 +117,68 @@ def test_reference_format_pickle_roundtrip(tmp_path):
     assert isinstance(back, tree.Tree) and tree_io.tree_depth(back) == 3000
     assert sys.getrecursionlimit() < 100000
     assert tree.Tree.__module__ == 'explicit_hybrid_mpc_amd.tree'
+
+
+def test_status_files_have_the_reference_format(tmp_path):
+    """status.txt / statistics.pkl of lib/scheduler.py:154-362, fed from progress counters."""
+    from explicit_hybrid_mpc_amd import status
+
+    class Clock:
+        t = 100.
+
+        def __call__(self):
+            return self.t
+
+    clock = Clock()
+    # the rate estimator: recursive average with exponential forgetting (lib/scheduler.py:113-152)
+    rls = status.RLS(call_period=10., time_constant=180.)
+    est, sigma = None, 1.
+    for m in (0.02, 0.03, 0.01, 0.05):
+        rls.update(m)
+        if est is None:
+            est = m
+        else:
+            sigma = 1. + np.exp(-10. / 180.) * sigma
+            est = m / sigma + (1. - 1. / sigma) * est
+        assert abs(rls.estimate - est) < 1e-15
+    eta = status.ETACalculator(10., 180.)
+    assert eta.eta(0.3) is None
+    eta.update(0.01)
+    assert abs(eta.eta(0.3) - 70.) < 1e-12
+
+    st, pk = str(tmp_path / 'status.txt'), str(tmp_path / 'statistics.pkl')
+    pub = status.MainStatusPublisher(16., st, pk, clock=clock, eta_window_duration=1.)
+    w = status.WorkerStatus('ecc', clock=clock)
+    w.set_total_volume(16.)
+    w.update(active=True)
+    for k, (vol, nodes) in enumerate([(2., 100), (6., 400), (16., 900)]):
+        clock.t += 2.
+        w.absorb(dict(volume_closed=vol, n_nodes=nodes, n_closed=nodes // 2, frontier=50 - 10 * k,
+                      depth=3 + k, sweeps=k + 1, lp_solves=10 * nodes, ipm_iters=90 * nodes))
+        overall = pub.update([w.data, None], num_tasks_in_queue=50 - 10 * k)
+        assert abs(overall['volume_filled_frac'] - vol / 16.) < 1e-15
+    clock.t += 1.
+    w.update(active=False)
+    pub.update([w.data, None], force=True)
+    assert w.data['time_active_total'] == 7. and w.data['time_ecc'] == 7.
+    text = open(st).read()
+    for line in ('# overall', 'number of processes active: 0', 'volume filled (total [%]): 1.0000e+02',
+                 'simplex_count: 900', 'processes: 0 x ecc, 0 x lcss', '# proc 0', 'status: idle',
+                 'volume filled (current [%]): 1.0000e+02', 'simplex count (total [-]): 900'):
+        assert line in text, line
+    assert re.search(r'^ETA \[s\]: (None|\d+)$', text, re.M)
+    stats = status.load_statistics(pk)          # the reader of lib/post_process.py:57-70
+    assert stats['volume_filled_frac'] == [2. / 16., 6. / 16., 1., 1.]
+    assert stats['simplex_count_total'] == [100, 400, 900, 900]
+    assert stats['num_proc_active'] == [1, 1, 1, 0]
+    assert stats['time_elapsed'] == sorted(stats['time_elapsed'])
+    # volume filled 2/16 -> 6/16 in 2 s, then 6/16 -> 1 in 2 s; ETA after the second window
+    assert stats['eta'][0] is None and stats['eta'][1] is not None
+    with open(pk, 'rb') as f:
+        rec = pickle.load(f)
+    assert set(rec) == {'overall', 'process'} and rec['process'][1] is None
+    assert set(rec['process'][0]) >= {'status', 'current_branch', 'current_location', 'algorithm',
+                                      'volume_filled_total', 'volume_filled_current',
+                                      'simplex_count_total', 'simplex_count_current',
+                                      'time_active_total', 'time_active_current', 'time_idle',
+                                      'time_ecc', 'time_lcss'}
