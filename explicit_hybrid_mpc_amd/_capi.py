@@ -33,7 +33,7 @@ EXPORTED = [
     'ehm_problem_set_option', 'ehm_partition_begin', 'ehm_partition_step',
     'ehm_partition_take', 'ehm_partition_give', 'ehm_partition_finish',
     'ehm_explicit_create', 'ehm_explicit_eval_batch', 'ehm_explicit_destroy',
-    'ehm_explicit_last_error', 'ehm_partition_progress',
+    'ehm_explicit_last_error', 'ehm_partition_progress', 'ehm_problem_set_quadratic',
 ]
 
 
@@ -123,6 +123,7 @@ def load(build_if_missing=True):
     lib.ehm_problem_set_eps.argtypes = [vp, ctypes.c_double, ctypes.c_double]
     lib.ehm_sync.argtypes = [vp]
     lib.ehm_problem_set_solver.argtypes = [vp, i32]
+    lib.ehm_problem_set_quadratic.argtypes = [vp, vp, vp, vp, vp, vp, vp]
     lib.ehm_selftest.argtypes = [i32, vp, i32, vp]
     lib.ehm_problem_set_option.argtypes = [vp, ctypes.c_char_p, ctypes.c_double]
     lib.ehm_solve_ptd_batch.argtypes = [vp, i64, vp, vp, vp, vp, vp, vp]

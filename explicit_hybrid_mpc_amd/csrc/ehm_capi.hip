@@ -446,6 +446,8 @@ struct ehm_problem {
     DevBuf consts;           // Gt | St | w | c
     DevBuf wc2;              // [n_delta][n+p+2][m|1]  LDS image for the k2 kernels
     DevBuf wr3;              // [n_delta][mpad][64]    row-major image for the wide kernels
+    DevBuf quad;             // H | F^T | f0 | C | c1 | c0  (ehm_problem_set_quadratic)
+    bool quadratic = false;
     bool v1_ok = false;      // the generation-1 kernels fit this problem
     int decide_full = 0;     // 1 = the suboptimality test solves to full accuracy (no sign-only stop)
     int solver_gen = 2;      // 1 = one wavefront per workgroup (ehm_kernels.h), 2 = ehm_k2.hip
@@ -750,6 +752,7 @@ int ehm_problem_destroy(ehm_problem* P) {
     P->consts.release();
     P->wc2.release();
     P->wr3.release();
+    P->quad.release();
     P->seg.release();
     P->pool_cache.rec.release(); P->pool_cache.left.release(); P->pool_cache.didx.release();
     P->pool_cache.depth.release(); P->pool_cache.flags.release(); P->pool_cache.tstar.release();
@@ -770,9 +773,63 @@ int ehm_problem_set_eps(ehm_problem* P, double eps_a, double eps_r) {
     return EHM_OK;
 }
 
+int ehm_problem_set_quadratic(ehm_problem* P, const double* H, const double* F, const double* f0,
+                              const double* C, const double* c1, const double* c0) {
+    if (!P || !H || !F || !f0 || !C || !c1 || !c0) return fail(EHM_E_INVALID, "null argument");
+    if (!P->v1_ok)
+        return fail(EHM_E_INVALID,
+                    "quadratic costs need the one-wavefront kernels: n+p+1 <= %d, m+p+3 <= %d",
+                    EHM_V1_MAX_N, EHM_V1_MAX_M);
+    HIP_TRY(hipSetDevice(P->device), EHM_E_HIP);
+    const int n = P->dp.n, p = P->dp.p, nd = P->dp.n_delta;
+    const size_t nH = (size_t)nd * n * n, nF = (size_t)nd * p * n, nf = (size_t)nd * n;
+    const size_t nC = (size_t)nd * p * p, n1 = (size_t)nd * p;
+    std::vector<double> host(nH + nF + nf + nC + n1 + nd);
+    double* h = host.data();
+    // symmetrise H and C (the kernels read one triangle's worth through row j, column k)
+    for (int k = 0; k < nd; ++k)
+        for (int i = 0; i < n; ++i)
+            for (int j = 0; j < n; ++j)
+                h[((size_t)k * n + i) * n + j] =
+                    0.5 * (H[((size_t)k * n + i) * n + j] + H[((size_t)k * n + j) * n + i]);
+    double* Ft = h + nH;
+    for (int k = 0; k < nd; ++k)
+        for (int j = 0; j < n; ++j)
+            for (int q = 0; q < p; ++q)
+                Ft[((size_t)k * p + q) * n + j] = F[((size_t)k * n + j) * p + q];
+    double* f0d = Ft + nF;
+    for (size_t i = 0; i < nf; ++i) f0d[i] = f0[i];
+    double* Cd = f0d + nf;
+    for (int k = 0; k < nd; ++k)
+        for (int i = 0; i < p; ++i)
+            for (int j = 0; j < p; ++j)
+                Cd[((size_t)k * p + i) * p + j] =
+                    0.5 * (C[((size_t)k * p + i) * p + j] + C[((size_t)k * p + j) * p + i]);
+    double* c1d = Cd + nC;
+    for (size_t i = 0; i < n1; ++i) c1d[i] = c1[i];
+    double* c0d = c1d + n1;
+    for (int k = 0; k < nd; ++k) c0d[k] = c0[k];
+    HIP_TRY(hipStreamSynchronize(P->stream), EHM_E_HIP);
+    int rc = P->quad.ensure(host.size() * sizeof(double));
+    if (rc) return rc;
+    HIP_TRY(hipMemcpy(P->quad.ptr, host.data(), host.size() * sizeof(double),
+                      hipMemcpyHostToDevice), EHM_E_HIP);
+    P->dp.Hq = P->quad.as<double>();
+    P->dp.Fq = P->dp.Hq + nH;
+    P->dp.f0q = P->dp.Fq + nF;
+    P->dp.Cq = P->dp.f0q + nf;
+    P->dp.c1q = P->dp.Cq + nC;
+    P->dp.c0q = P->dp.c1q + n1;
+    P->quadratic = true;
+    P->solver_gen = 1;
+    return EHM_OK;
+}
+
 int ehm_problem_set_solver(ehm_problem* P, int generation) {
     if (!P) return fail(EHM_E_INVALID, "null problem");
     if (generation != 1 && generation != 2) return fail(EHM_E_INVALID, "solver generation 1 or 2");
+    if (generation == 2 && P->quadratic)
+        return fail(EHM_E_INVALID, "quadratic costs run on the generation-1 kernels only");
     if (generation == 1 && !P->v1_ok)
         return fail(EHM_E_INVALID, "the generation-1 kernels do not fit this problem in LDS");
     P->solver_gen = generation;

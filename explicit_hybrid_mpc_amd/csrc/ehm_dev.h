@@ -29,6 +29,15 @@ struct DevProblem {
     // every LP of the problem fits the wave-local kernels.
     const double* Wr3;  // [n_delta][mpad3][64]
     int mpad3;
+    // quadratic part of the cost (null Hq: linear cost only), per commutation
+    //   V(z,theta) = c'z + 1/2 z'H z + (f0 + F theta)'z + 1/2 theta'C theta + c1'theta + c0
+    // (ehm_problem_set_quadratic; handled by the generation-1 kernels, ehm_ipm.h)
+    const double* Hq;   // [n_delta][n][n]
+    const double* Fq;   // [n_delta][p][n]   column q of F as an n-vector
+    const double* f0q;  // [n_delta][n]
+    const double* Cq;   // [n_delta][p][p]
+    const double* c1q;  // [n_delta][p]
+    const double* c0q;  // [n_delta]
 };
 
 // Node pool of the partition tree (structure of arrays of fixed-size records).

@@ -16,6 +16,15 @@
 //   * a pivot that collapses relative to its original diagonal is frozen
 //     (LIPSOL/PCx dependent-column guard), which is what keeps degenerate
 //     infinity-norm-cost LPs (non-unique minimisers) well behaved.
+// Quadratic costs (every MPC law of lib/mpc_library.py has a cvx.quad_form cost, :180-183,
+// :515-517): with LpWork::quad set the same solver handles the convex programs
+//        min c^T x + kap0 V(x)   s.t.  A x <= b  and, for the suboptimality test
+//        (lib/oracle.py:89-97), two quadratic rows  kap_i V(x) + a_i^T x <= b_i ,
+//        V(x) = 1/2 x^T Q x + q^T x ,
+// Q (n x n) in LDS: the Newton matrix gains (kap0 + kap1 lam_1 + kap2 lam_2) Q, the two
+// quadratic rows of A hold their CURRENT gradients kap_i (Q x + q) + a_i (rewritten every
+// iteration), their residuals are evaluated exactly, primal and dual step share one length
+// and the gap is measured by s^T lambda (oracle/ipm_numpy.py::solve_cp is the same in numpy).
 // This is the arithmetic of the reference's `Problem.solve(solver=MOSEK)` call sites on
 // the hot path (lib/oracle.py:131,134,166,169,203,276,305,350) for the LP instances of
 // BASELINE.json; it mirrors oracle/ipm_numpy.py step for step.
@@ -84,14 +93,24 @@ struct LpWork {
     double* x;      // EHM_NP
     double* xb;     // EHM_NP   best iterate
     double* t;      // EHM_NP   scratch n-vector
+    // quadratic block (used when quad != 0)
+    double* Q;      // EHM_NP x EHM_LDM   Hessian of V over the LP variables
+    double* qv;     // EHM_NP   linear part of V
+    double* a1;     // EHM_NP   linear part of quadratic row iq
+    double* a2;     // EHM_NP   linear part of quadratic row iq+1
+    double* gv;     // EHM_NP   scratch: grad V at the iterate
     int n, m, lda, slots, nb;
+    int quad;       // 0: linear programme
+    int iq;         // first of the two quadratic rows (iq, iq+1), -1: none
+    double kap0, kap1, kap2;   // weights of V in the objective / the two quadratic rows
+    double v0;      // constant of V (added to the reported objective)
 };
 
 __host__ __device__ inline int lp_lda(int m) { return m | 1; }
 __host__ __device__ inline size_t lp_lds_doubles(int n, int m) {
     int nb = (n + 3) / 4;
-    return (size_t)(4 * nb) * lp_lda(m) + (size_t)EHM_NP * EHM_LDM + 2 * (size_t)lp_lda(m) +
-           4 * EHM_NP;
+    return (size_t)(4 * nb) * lp_lda(m) + 2 * (size_t)EHM_NP * EHM_LDM + 2 * (size_t)lp_lda(m) +
+           8 * EHM_NP;
 }
 
 __device__ inline void lp_carve(LpWork& w, double* base, int n, int m) {
@@ -115,6 +134,19 @@ __device__ inline void lp_carve(LpWork& w, double* base, int n, int m) {
     w.xb = base;
     base += EHM_NP;
     w.t = base;
+    base += EHM_NP;
+    w.Q = base;
+    base += EHM_NP * EHM_LDM;
+    w.qv = base;
+    base += EHM_NP;
+    w.a1 = base;
+    base += EHM_NP;
+    w.a2 = base;
+    base += EHM_NP;
+    w.gv = base;
+    w.quad = 0;
+    w.iq = -1;
+    w.kap0 = w.kap1 = w.kap2 = w.v0 = 0.0;
 }
 
 // zero A (all 4*nb columns) and c
@@ -329,11 +361,34 @@ __device__ inline IpmResult ipm_solve(const LpWork& w, const double (&b)[EHM_SLO
     for (int it = 0; it <= EHM_MAX_ITER; ++it) {
         // ---- residuals -------------------------------------------------------------------
         double ax[EHM_SLOTS], r_p[EHM_SLOTS];
+        double xQx = 0.0, qx = 0.0, gvj = 0.0;     // quadratic block: x'Qx, q'x, (Qx+q)_lane
+        if (w.quad) {
+            const double xj = (lane < n) ? w.x[lane] : 0.0;
+            const double qj = (lane < n) ? w.qv[lane] : 0.0;
+            double g = 0.0;
+            if (lane < n)
+                for (int k = 0; k < n; ++k) g = fma(w.Q[lane * EHM_LDM + k], w.x[k], g);
+            xQx = wave_sum(xj * g);
+            qx = wave_sum(xj * qj);
+            gvj = g + qj;
+            if (lane < EHM_NP) w.gv[lane] = gvj;
+            if (w.iq >= 0 && lane < n) {           // current gradients of the quadratic rows
+                w.A[(size_t)lane * w.lda + w.iq] = fma(w.kap1, gvj, w.a1[lane]);
+                w.A[(size_t)lane * w.lda + w.iq + 1] = fma(w.kap2, gvj, w.a2[lane]);
+            }
+            wave_sync();
+        }
         rows_times(w, w.x, lane, ax);
         double rpmax = 0.0, sl_sum = 0.0, bl_sum = 0.0;
 #pragma unroll
         for (int sl = 0; sl < EHM_SLOTS; ++sl) {
             r_p[sl] = valid[sl] ? (ax[sl] + s[sl] - b[sl]) : 0.0;
+            if (w.quad && w.iq >= 0) {
+                // g_i(x) = J_i x - kap_i/2 x'Qx - b_i  (J_i = the row's current gradient)
+                const int i = lane + 64 * sl;
+                if (i == w.iq) r_p[sl] -= 0.5 * w.kap1 * xQx;
+                if (i == w.iq + 1) r_p[sl] -= 0.5 * w.kap2 * xQx;
+            }
             rpmax = fmax(rpmax, fabs(r_p[sl]));
             sl_sum = fma(s[sl], lam[sl], sl_sum);
             bl_sum = fma(b[sl], lam[sl], bl_sum);
@@ -353,12 +408,17 @@ __device__ inline IpmResult ipm_solve(const LpWork& w, const double (&b)[EHM_SLO
         const int jcol = lane & 31;
         const double cjj = (jcol < n) ? w.c[jcol] : 0.0;
         const double xjj = (jcol < n) ? w.x[jcol] : 0.0;
-        const double r_d = (jcol < n) ? (atl + cjj) : 0.0;
-        const double emax = wave_max(fmax(rpmax / bnorm, fabs(r_d) / cnorm));
-        const double mu = wave_sum(sl_sum) * inv_m;
+        const double gjj = (w.quad && jcol < n) ? w.kap0 * w.gv[jcol] : 0.0;
+        const double r_d = (jcol < n) ? (atl + cjj + gjj) : 0.0;
+        const double cn = w.quad ? (1.0 + wave_max(fmax(fabs(cjj), fabs(gjj)))) : cnorm;
+        const double emax = wave_max(fmax(rpmax / bnorm, fabs(r_d) / cn));
+        const double sl_tot = wave_sum(sl_sum);
+        const double mu = sl_tot * inv_m;
         const double dobj = -wave_sum(bl_sum);
-        const double pobj = wave_sum((lane < 32) ? cjj * xjj : 0.0);
-        const double e_g = fabs(pobj - dobj) / (1.0 + fabs(pobj));
+        double pobj = wave_sum((lane < 32) ? cjj * xjj : 0.0);
+        if (w.quad) pobj += w.kap0 * (0.5 * xQx + qx + w.v0);
+        const double e_g = w.quad ? sl_tot / (1.0 + fabs(pobj))
+                                  : fabs(pobj - dobj) / (1.0 + fabs(pobj));
         const double merit = fmax(emax / EHM_TOL_RES, e_g / EHM_TOL_GAP);
         if (merit < res.merit) {
             res.merit = merit;
@@ -383,17 +443,35 @@ __device__ inline IpmResult ipm_solve(const LpWork& w, const double (&b)[EHM_SLO
         wave_sync();
         form_normal_matrix(w, w.vm0, lane);
         wave_sync();
+        double wq = 0.0;
+        if (w.quad) {
+            double l1 = 0.0, l2 = 0.0;
+            if (w.iq >= 0) {
+#pragma unroll
+                for (int sl = 0; sl < EHM_SLOTS; ++sl) {
+                    const int i = lane + 64 * sl;
+                    l1 += (i == w.iq) ? lam[sl] : 0.0;
+                    l2 += (i == w.iq + 1) ? lam[sl] : 0.0;
+                }
+                l1 = wave_sum(l1);
+                l2 = wave_sum(l2);
+            }
+            wq = w.kap0 + w.kap1 * l1 + w.kap2 * l2;
+        }
         double row[EHM_NP];
 #pragma unroll
-        for (int q = 0; q < EHM_NP; ++q)
+        for (int q = 0; q < EHM_NP; ++q) {
             row[q] = (lane < n && q < n) ? w.M[lane * EHM_LDM + q] : ((q == lane) ? 1.0 : 0.0);
-        const double diag0 = (lane < n) ? w.M[lane * EHM_LDM + lane] : 1.0;
+            if (w.quad && lane < n && q < n) row[q] = fma(wq, w.Q[lane * EHM_LDM + q], row[q]);
+        }
+        double diag0 = (lane < n) ? w.M[lane * EHM_LDM + lane] : 1.0;
+        if (w.quad && lane < n) diag0 = fma(wq, w.Q[lane * EHM_LDM + lane], diag0);
         double rpiv;
         lu_factor(row, diag0, rpiv, n, lane);
 
         // ---- predictor ------------------------------------------------------------------------
         // rhs_aff = -c - A^T (d r_p)
-        const double rhs_aff = (lane < n) ? (-cjj - atdr) : 0.0;
+        const double rhs_aff = (lane < n) ? (-cjj - gjj - atdr) : 0.0;
         double dxj = lu_solve(row, rpiv, (lane < 32) ? rhs_aff : 0.0, n, lane);
         if (lane < EHM_NP) w.t[lane] = (lane < n) ? dxj : 0.0;
         wave_sync();
@@ -411,6 +489,7 @@ __device__ inline IpmResult ipm_solve(const LpWork& w, const double (&b)[EHM_SLO
         }
         ap = fmin(1.0, wave_min(ap));
         ad = fmin(1.0, wave_min(ad));
+        if (w.quad) ap = ad = fmin(ap, ad);     // one step length: r_d couples x and lambda
         double mu_aff = 0.0;
 #pragma unroll
         for (int sl = 0; sl < EHM_SLOTS; ++sl)
@@ -448,6 +527,7 @@ __device__ inline IpmResult ipm_solve(const LpWork& w, const double (&b)[EHM_SLO
         }
         ap = fmin(1.0, EHM_STEP_FRAC * wave_min(ap));
         ad = fmin(1.0, EHM_STEP_FRAC * wave_min(ad));
+        if (w.quad) ap = ad = fmin(ap, ad);
         if (lane < n) w.x[lane] = fma(ap, dxj, w.x[lane]);
 #pragma unroll
         for (int sl = 0; sl < EHM_SLOTS; ++sl) {

@@ -86,6 +86,11 @@ class GpuProblem:
                                            ctypes.byref(self._handle)))
         self.eps_a = float(eps_a)
         self.eps_r = float(eps_r)
+        if getattr(can, 'quadratic', False):
+            # quadratic cost (the reference's cvx.quad_form laws): convex QP / QCQP oracles
+            q = tuple(f64(getattr(can, k)) for k in ('H', 'F', 'f0', 'C', 'c1', 'c0'))
+            self._keep = self._keep + q
+            check(self._lib.ehm_problem_set_quadratic(self._handle, *[ptr(a) for a in q]))
 
     def close(self):
         if getattr(self, '_handle', None) is not None and self._handle:

@@ -35,7 +35,7 @@ def box_vertices(half_widths):
     return signs * half_widths[None, :]
 
 
-def double_integrator(N=3):
+def double_integrator(N=3, cost='inf'):
     """
     Config 1 (plumbing): 2-state double integrator, one input, single mode,
     A=[[1,T],[0,1]], B=[[T^2/2],[T]], T=1, |x|<=(5,5), |u|<=1, infinity-norm cost.
@@ -48,7 +48,7 @@ def double_integrator(N=3):
     Gu = np.array([[1.], [-1.]])
     gu = np.ones(2)
     mpc = PWAMPC([A], [B], [np.zeros(2)], [None], Gx, gx, Gu, gu,
-                 Q=np.eye(2), R=np.eye(1), N=N, name='double_integrator_N%d' % N)
+                 Q=np.eye(2), R=np.eye(1), N=N, name='double_integrator_N%d' % N, cost=cost)
     return mpc
 
 
@@ -67,11 +67,12 @@ def random_polytope(rng, n_x, n_random):
     return G, np.ones(G.shape[0])
 
 
-def linear_mpc(seed=0, n_x=4, n_u=2, N=5, rho=1.05, n_random=8, r_weight=0.1):
+def linear_mpc(seed=0, n_x=4, n_u=2, N=5, rho=1.05, n_random=8, r_weight=0.1, cost='inf'):
     """
     Config 2: n_x=4, n_u=2, N=5, p=4 linear MPC.  A = rho * M / spectral_radius(M),
     M ~ N(0,1); B ~ N(0,1); random-polytope state set; |u| <= 1;
-    cost ||x||_inf + r_weight ||u||_inf.
+    cost ||x||_inf + r_weight ||u||_inf, or with ``cost='quadratic'`` the quadratic cost of
+    the same weights (sum x'x + r_weight u'u, the form of lib/mpc_library.py:515-517).
     """
     rng = np.random.default_rng(seed)
     M = rng.standard_normal((n_x, n_x))
@@ -82,12 +83,12 @@ def linear_mpc(seed=0, n_x=4, n_u=2, N=5, rho=1.05, n_random=8, r_weight=0.1):
     gu = np.ones(2 * n_u)
     mpc = PWAMPC([A], [B], [np.zeros(n_x)], [None], Gx, gx, Gu, gu,
                  Q=np.eye(n_x), R=r_weight * np.eye(n_u), N=N,
-                 name='linear_nx%d_nu%d_N%d_seed%d' % (n_x, n_u, N, seed))
+                 name='linear_nx%d_nu%d_N%d_seed%d' % (n_x, n_u, N, seed), cost=cost)
     return mpc
 
 
 def pwa_mpc(seed=0, n_x=4, n_u=2, N=5, rho=1.05, n_random=8, r_weight=0.1, kink=0.3,
-            overlap=0.05):
+            overlap=0.05, cost='inf'):
     """
     Config 3: two-mode PWA system, mode 0 admissible on x_1 >= -overlap and mode 1 on
     x_1 <= +overlap (pattern of lib/mpc_library.py:530-541 with a fixed commutation
@@ -113,7 +114,7 @@ def pwa_mpc(seed=0, n_x=4, n_u=2, N=5, rho=1.05, n_random=8, r_weight=0.1, kink=
     regions = [(-e1, overlap * np.ones(1)), (e1, overlap * np.ones(1))]
     mpc = PWAMPC([A0, A1], [B, B], [np.zeros(n_x)] * 2, regions, Gx, gx, Gu, gu,
                  Q=np.eye(n_x), R=r_weight * np.eye(n_u), N=N,
-                 name='pwa_nx%d_nu%d_N%d_seed%d' % (n_x, n_u, N, seed))
+                 name='pwa_nx%d_nu%d_N%d_seed%d' % (n_x, n_u, N, seed), cost=cost)
     return mpc
 
 
@@ -193,7 +194,20 @@ def create_oracle(mpc, set_vrep, abs_frac, abs_err, rel_err, device=0):
     return oracle
 
 
+def satellite_z(N=4):
+    """
+    The reference's ``SatelliteZ`` law (lib/mpc_library.py:221-272): robust CWH z-axis
+    control with an off/on-with-minimum-impulse input and quadratic cost; the partitioned
+    set is the full state-error box (lib/examples.py:75-86, ``satellite_z_example``).
+    """
+    from .mpc_library import SatelliteZ
+    mpc = SatelliteZ(N)
+    THETA_SCALE.setdefault(mpc.name, 1.0)
+    return mpc
+
+
 EXAMPLES = {
+    'cwh_z': lambda: satellite_z(4),          # make_jobs.sh:60-61 (EXAMPLE=cwh_z, MPC_N=4)
     'double_integrator': lambda: double_integrator(3),
     'linear': lambda: linear_mpc(0),
     'pwa': lambda: pwa_mpc(0),

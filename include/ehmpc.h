@@ -77,6 +77,18 @@ typedef struct ehm_tree    ehm_tree;      /* opaque: grown partition, device res
 /* Oracle.__init__ (lib/oracle.py:23-102). device = HIP ordinal. */
 int ehm_problem_create(const ehm_problem_desc* desc, int device, ehm_problem** out);
 int ehm_problem_destroy(ehm_problem* prob);
+/* Quadratic part of the cost.  Every MPC law of the reference has a cvx.quad_form cost
+ * (lib/mpc_library.py:180-183, :515-517): per commutation d
+ *     V(z,theta) = c^T z + 1/2 z^T H[d] z + (f0[d] + F[d] theta)^T z
+ *                  + 1/2 theta^T C[d] theta + c1[d]^T theta + c0[d]
+ * H [n_delta][n][n], F [n_delta][n][p], f0 [n_delta][n], C [n_delta][p][p], c1 [n_delta][p],
+ * c0 [n_delta]; H and C symmetric positive semidefinite (symmetrised on entry).  After this
+ * call P_theta_delta is a convex QP, the suboptimality test (lib/oracle.py:89-97) a convex
+ * QCQP with two quadratic rows, and every entry point below works on them; the handle runs
+ * on the one-wavefront-per-problem kernels (n+p+1 <= 32, m+p+3 <= 256). */
+int ehm_problem_set_quadratic(ehm_problem* prob, const double* H, const double* F,
+                              const double* f0, const double* C, const double* c1,
+                              const double* c0);
 /* Re-set eps_a / eps_r (examples.create_oracle builds a second Oracle, lib/examples.py:43-46). */
 int ehm_problem_set_eps(ehm_problem* prob, double eps_a, double eps_r);
 /* Kernel generation used by this handle's launches: 2 (default) = one copy of the

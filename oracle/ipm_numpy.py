@@ -210,3 +210,165 @@ def solve_lp(c, A, b, max_iter=40, tol_res=1e-10, tol_gap=1e-10, step_frac=None,
     out.res = (float(np.max(np.abs(np.minimum(b - A @ x, 0.)))),
                float(np.max(np.abs(A.T @ lam + c))))
     return out
+
+
+# =========================================================================================
+# Quadratic costs: the convex programs the QP-capable HIP kernels (ehm_ipm.h with a
+# quadratic block) solve, in their condensed form, and the kernel's algorithm in numpy.
+#
+#   minimise    c_lin'y + kappa0 V(y)
+#   subject to  A y <= b                                  (rows not in `iq`)
+#               kappa_i V(y) + a_i'y <= b_i               (rows iq[i]; A[iq[i]] holds a_i)
+#   V(y) = 1/2 y'Q y + q'y            (its constant v0 is folded into b_i and reported cost)
+# =========================================================================================
+class QuadProgram:
+    __slots__ = ('c_lin', 'A', 'b', 'Q', 'q', 'v0', 'kappa0', 'iq', 'kap')
+
+
+def _quad_blocks(can, d, v0, E):
+    """Q, q, constant of V over (z, beta) with theta = v0 + E beta (E = None: theta = v0)."""
+    n, p = can.n, can.p
+    H, F, f0, C, c1, c0 = can.H[d], can.F[d], can.f0[d], can.C[d], can.c1[d], can.c0[d]
+    qz = can.c + f0 + F @ v0
+    const = 0.5 * v0 @ C @ v0 + c1 @ v0 + c0
+    if E is None:
+        return H.copy(), qz, const
+    Q = np.zeros((n + p, n + p))
+    Q[:n, :n] = H
+    Q[:n, n:] = F @ E
+    Q[n:, :n] = (F @ E).T
+    Q[n:, n:] = E.T @ C @ E
+    q = np.concatenate([qz, E.T @ (C @ v0 + c1)])
+    return Q, q, const
+
+
+def assemble_point_quad(can, d, theta):
+    theta = np.asarray(theta, dtype=np.float64)
+    pr = QuadProgram()
+    pr.Q, pr.q, pr.v0 = _quad_blocks(can, d, theta, None)
+    pr.c_lin = np.zeros(can.n)
+    pr.A = can.G[d].copy()
+    pr.b = can.w[d] + can.S[d] @ theta
+    pr.kappa0, pr.iq, pr.kap = 1., [], []
+    return pr
+
+
+def assemble_min_simplex_quad(can, d, R):
+    R = np.asarray(R, dtype=np.float64)
+    A, b = _simplex_rows(can, d, R)
+    pr = QuadProgram()
+    pr.Q, pr.q, pr.v0 = _quad_blocks(can, d, R[0], (R[1:] - R[0]).T)
+    pr.c_lin = np.zeros(can.n + can.p)
+    pr.A, pr.b = A, b
+    pr.kappa0, pr.iq, pr.kap = 1., [], []
+    return pr
+
+
+def assemble_bar_E_quad(can, d, R, V_bar, eps_a, eps_r):
+    """Objective -t; rows  kappa_i V - dVbar'beta + t <= Vbar_0 - eps_i  (- kappa_i v0)."""
+    R = np.asarray(R, dtype=np.float64)
+    V_bar = np.asarray(V_bar, dtype=np.float64)
+    A0, b0 = _simplex_rows(can, d, R)
+    n, p = can.n, can.p
+    Q, q, v0 = _quad_blocks(can, d, R[0], (R[1:] - R[0]).T)
+    pr = QuadProgram()
+    pr.Q = np.zeros((n + p + 1, n + p + 1))
+    pr.Q[:n + p, :n + p] = Q
+    pr.q = np.concatenate([q, [0.]])
+    pr.v0 = v0
+    m0 = A0.shape[0]
+    A = np.zeros((m0 + 2, n + p + 1))
+    A[:m0, :n + p] = A0
+    dV = V_bar[1:] - V_bar[0]
+    for r in (m0, m0 + 1):
+        A[r, n:n + p] = -dV
+        A[r, -1] = 1.
+    pr.kap = [1., 1. + eps_r]
+    pr.iq = [m0, m0 + 1]
+    pr.A = A
+    pr.b = np.concatenate([b0, [V_bar[0] - eps_a - pr.kap[0] * v0, V_bar[0] - pr.kap[1] * v0]])
+    pr.c_lin = np.zeros(n + p + 1)
+    pr.c_lin[-1] = -1.
+    pr.kappa0 = 0.
+    return pr
+
+
+def solve_cp(pr, max_iter=60, tol_res=1e-10, tol_gap=1e-10, step_frac=STEP_FRAC_SAFE):
+    """
+    The kernel's algorithm (ehm_ipm.h, quadratic block on) for a QuadProgram: Mehrotra
+    predictor-corrector on the normal equations  (w Q + J'DJ) dy = rhs,  J = the linear rows
+    and the CURRENT gradients of the quadratic rows, w = kappa0 + sum_i kappa_i lambda_i,
+    common primal/dual step, residuals of the quadratic rows re-evaluated every iterate,
+    gap measured by s'lambda.  ``obj`` = c_lin'y + kappa0 (V(y) + v0).
+    """
+    A = pr.A.copy()
+    b, Q, q = pr.b, pr.Q, pr.q
+    m, n = A.shape
+    a_lin = [pr.A[i].copy() for i in pr.iq]
+    y = np.zeros(n)
+    s = np.maximum(b, 1.)
+    lam = np.ones(m)
+    bnorm = 1. + np.max(np.abs(b))
+    out = IPMResult()
+    status = 1
+    best = None
+    stall = 0
+    it = 0
+    for it in range(max_iter + 1):
+        gV = Q @ y + q
+        yQy = y @ (gV - q)
+        for i, r in enumerate(pr.iq):
+            A[r] = pr.kap[i] * gV + a_lin[i]
+        r_p = A @ y + s - b
+        for i, r in enumerate(pr.iq):
+            r_p[r] -= 0.5 * pr.kap[i] * yQy
+        grad = pr.c_lin + pr.kappa0 * gV
+        r_d = grad + A.T @ lam
+        mu = s @ lam / m
+        pobj = pr.c_lin @ y + pr.kappa0 * (0.5 * yQy + q @ y)
+        cnorm = 1. + max(np.max(np.abs(pr.c_lin)), pr.kappa0 * np.max(np.abs(gV)))
+        e_p = np.max(np.abs(r_p)) / bnorm
+        e_d = np.max(np.abs(r_d)) / cnorm
+        e_g = (s @ lam) / (1. + abs(pobj + pr.kappa0 * pr.v0))
+        merit = max(e_p / tol_res, e_d / tol_res, e_g / tol_gap)
+        if best is None or merit < best[0]:
+            best = (merit, y.copy(), lam.copy(), it, pobj)
+            stall = 0
+        elif best[0] < STALL_ZONE:
+            stall += 1
+        if merit <= 1.:
+            status = 0
+            break
+        if stall >= 3 or it == max_iter:
+            break
+        dvec = lam / s
+        wq = pr.kappa0 + sum(pr.kap[i] * lam[r] for i, r in enumerate(pr.iq))
+        M = wq * Q + A.T @ (dvec[:, None] * A)
+        L = guarded_cholesky(M)
+
+        def newton(rc):
+            rhs = -r_d + A.T @ ((rc - lam * r_p) / s)
+            dy = chol_solve(L, rhs)
+            ds = -r_p - A @ dy
+            dl = -(rc + lam * ds) / s
+            return dy, ds, dl
+
+        def max_step(v, dv):
+            neg = dv < 0
+            return np.min(-v[neg] / dv[neg]) if neg.any() else 1e300
+        dy_a, ds_a, dl_a = newton(s * lam)
+        a = min(1., max_step(s, ds_a), max_step(lam, dl_a))
+        mu_aff = (s + a * ds_a) @ (lam + a * dl_a) / m
+        sigma = (mu_aff / mu) ** 3
+        dy, ds, dl = newton(s * lam + ds_a * dl_a - sigma * mu)
+        a = min(1., step_frac * min(max_step(s, ds), max_step(lam, dl)))
+        y = y + a * dy
+        s = s + a * ds
+        lam = lam + a * dl
+    merit, y, lam, _, pobj = best
+    if status != 0 and merit <= ACCEPT_MERIT:
+        status = 0
+    out.x, out.obj, out.status, out.iters, out.lam = y, float(pobj + pr.kappa0 * pr.v0), status, it, lam
+    out.merit = merit
+    out.res = (0., 0.)
+    return out

@@ -25,9 +25,10 @@ class FixedCommutationModel:
         self.n_x, self.n_u, self.N = n_x, n_u, N
         self.ox = 0
         self.ou = n_x * (N + 1)
+        self.quadratic = getattr(mpc, 'cost_type', 'inf') == 'quadratic'
         self.oex = self.ou + n_u * N
-        self.oeu = self.oex + N
-        self.nv = self.oeu + N
+        self.oeu = self.oex + (0 if self.quadratic else N)
+        self.nv = self.oeu + (0 if self.quadratic else N)
         nv = self.nv
         # equalities: dynamics (x_0 = theta is added by the caller)
         Aeq, beq = [], []
@@ -56,14 +57,14 @@ class FixedCommutationModel:
             row[:, self.ou + k * n_u:self.ou + (k + 1) * n_u] = mpc.Gu
             Aub.append(row)
             bub.append(mpc.gu)
-        for k in range(1, N + 1):
+        for k in (() if self.quadratic else range(1, N + 1)):
             for sgn in (1., -1.):
                 row = np.zeros((mpc.Q.shape[0], nv))
                 row[:, self.ox + k * n_x:self.ox + (k + 1) * n_x] = sgn * mpc.Q
                 row[:, self.oex + k - 1] = -1.
                 Aub.append(row)
                 bub.append(np.zeros(mpc.Q.shape[0]))
-        for k in range(N):
+        for k in (() if self.quadratic else range(N)):
             for sgn in (1., -1.):
                 row = np.zeros((mpc.R.shape[0], nv))
                 row[:, self.ou + k * n_u:self.ou + (k + 1) * n_u] = sgn * mpc.R
@@ -79,9 +80,21 @@ class FixedCommutationModel:
                 bub.append(r[1])
         self.A_ub = np.vstack(Aub)
         self.b_ub = np.concatenate(bub)
-        # cost V = sum ex + sum eu
+        # cost V = sum ex + sum eu,  or (cost_type 'quadratic', the form of
+        # lib/mpc_library.py:515-517)  V = 1/2 v'P v = sum u'Ru + sum_{k<N} x'Qx + x_N'P x_N
         self.cost = np.zeros(nv)
-        self.cost[self.oex:] = 1.
+        self.P = None
+        if self.quadratic:
+            Pm = np.zeros((nv, nv))
+            for k in range(N):
+                Pm[self.ou + k * n_u:self.ou + (k + 1) * n_u,
+                   self.ou + k * n_u:self.ou + (k + 1) * n_u] = 2. * mpc.R
+            for k in range(1, N + 1):
+                Pm[self.ox + k * n_x:self.ox + (k + 1) * n_x,
+                   self.ox + k * n_x:self.ox + (k + 1) * n_x] = 2. * (mpc.P if k == N else mpc.Q)
+            self.P = Pm
+        else:
+            self.cost[self.oex:] = 1.
 
     def u0(self, v):
         return np.array(v[self.ou:self.ou + self.n_u])
@@ -90,7 +103,10 @@ class FixedCommutationModel:
     def lp_point(self, theta):
         A_eq = np.vstack([self.A_dyn, self.A_x0])
         b_eq = np.concatenate([self.b_dyn, np.asarray(theta, dtype=np.float64)])
-        return dict(c=self.cost, A_ub=self.A_ub, b_ub=self.b_ub, A_eq=A_eq, b_eq=b_eq)
+        lp = dict(c=self.cost, A_ub=self.A_ub, b_ub=self.b_ub, A_eq=A_eq, b_eq=b_eq)
+        if self.quadratic:
+            lp['P'] = self.P
+        return lp
 
     # -- problems over a simplex (lib/oracle.py:70-79, 89-97) -------------------------
     def _simplex_blocks(self, R, extra_cols):
@@ -115,7 +131,11 @@ class FixedCommutationModel:
         A_eq, b_eq, A_ub, b_ub, bounds, ntot, na = self._simplex_blocks(R, 0)
         c = np.zeros(ntot)
         c[:self.nv] = self.cost
-        return dict(c=c, A_ub=A_ub, b_ub=b_ub, A_eq=A_eq, b_eq=b_eq, bounds=bounds)
+        lp = dict(c=c, A_ub=A_ub, b_ub=b_ub, A_eq=A_eq, b_eq=b_eq, bounds=bounds)
+        if self.quadratic:
+            lp['P'] = np.zeros((ntot, ntot))
+            lp['P'][:self.nv, :self.nv] = self.P
+        return lp
 
     def lp_bar_E(self, R, V_bar, eps_a, eps_r):
         """
@@ -128,6 +148,20 @@ class FixedCommutationModel:
         A_eq, b_eq, A_ub, b_ub, bounds, ntot, na = self._simplex_blocks(R, 1)
         nv = self.nv
         V_bar = np.asarray(V_bar, dtype=np.float64)
+        if self.quadratic:
+            # two convex quadratic rows  kappa V(v) - sum alpha_i V_i + t + eps <= 0
+            Pbig = np.zeros((ntot, ntot))
+            Pbig[:nv, :nv] = self.P
+            quad = []
+            for kappa, r0 in ((1., eps_a), (1. + eps_r, 0.)):
+                q = np.zeros(ntot)
+                q[nv:nv + na] = -V_bar
+                q[-1] = 1.
+                quad.append((kappa * Pbig, q, r0))
+            c = np.zeros(ntot)
+            c[-1] = -1.
+            return dict(c=c, A_ub=A_ub, b_ub=b_ub, A_eq=A_eq, b_eq=b_eq, bounds=bounds,
+                        quad=quad)
         rows = np.zeros((2, ntot))
         rows[0, :nv] = self.cost
         rows[0, nv:nv + na] = -V_bar

@@ -23,6 +23,7 @@ import numpy as np
 from scipy.optimize import linprog
 
 from .lp_models import FixedCommutationModel
+from . import qp_numpy
 
 
 # HiGHS defaults to 1e-7 feasibility tolerances; the parity bar on optimal costs is 1e-7
@@ -48,7 +49,10 @@ class OracleCPU:
         self.eps_r = eps_r
         self.sequences = mpc.mode_sequences()
         self.deltas = [mpc.sequence_to_delta(s) for s in self.sequences]
-        self.models = [FixedCommutationModel(mpc, s) for s in self.sequences]
+        # a model class may bring its own uncondensed restatement (oracle/satellite_cpu.py)
+        make = getattr(mpc, 'fixed_commutation_model', None)
+        self.models = [make(s) if make else FixedCommutationModel(mpc, s)
+                       for s in self.sequences]
         self.n_solves = 0          # LP solver calls (one per commutation sub-problem)
         self.memoize = False       # cache point solves by (theta, commutation): children
         self._memo = {}            # share p of their p+1 vertices with the parent
@@ -65,9 +69,42 @@ class OracleCPU:
     def _solve(self, lp):
         self.n_solves += 1
         bounds = lp.get('bounds', (None, None))
+        if lp.get('P') is not None or lp.get('quad'):
+            return self._solve_quadratic(lp, bounds)
         res = linprog(lp['c'], A_ub=lp['A_ub'], b_ub=lp['b_ub'], A_eq=lp['A_eq'],
                       b_eq=lp['b_eq'], bounds=bounds, method='highs',
                       options=HIGHS_OPTIONS)
+        return res
+
+    def _solve_quadratic(self, lp, bounds):
+        """
+        Quadratic cost (every law of lib/mpc_library.py: ``cvx.quad_form``): feasibility of
+        the linear rows is HiGHS' verdict (the quadratic rows of the suboptimality test can
+        always be met by lowering t), the optimum comes from oracle/qp_numpy.py.
+        """
+        class _Res:
+            pass
+        res = _Res()
+        n = lp['c'].size
+        feas = linprog(np.zeros(n), A_ub=lp['A_ub'], b_ub=lp['b_ub'], A_eq=lp['A_eq'],
+                       b_eq=lp['b_eq'], bounds=bounds, method='highs', options=HIGHS_OPTIONS)
+        if feas.status != 0:
+            res.status, res.x, res.fun = 2, None, None
+            return res
+        A_ub, b_ub = lp['A_ub'], lp['b_ub']
+        if isinstance(bounds, list):         # lower bounds 0 of the simplex weights as rows
+            extra = [j for j, (lo, hi) in enumerate(bounds) if lo is not None]
+            rows = np.zeros((len(extra), n))
+            for r, j in enumerate(extra):
+                rows[r, j] = -1.
+            A_ub = np.vstack([A_ub, rows])
+            b_ub = np.concatenate([b_ub, np.zeros(len(extra))])
+        out = qp_numpy.solve(lp['c'], A_ub, b_ub, lp['A_eq'], lp['b_eq'], P=lp.get('P'),
+                             quad=lp.get('quad', ()))
+        if out.status != 0 and max(out.res_p, out.res_d, out.gap) > 1e-9:
+            raise SolverError('QP oracle did not converge (%g %g %g)' %
+                              (out.res_p, out.res_d, out.gap))
+        res.status, res.x, res.fun = 0, out.x, float(out.fun)
         return res
 
     def _point(self, theta, d):

@@ -1,0 +1,283 @@
+"""
+TEST INFRASTRUCTURE (see oracle/__init__.py).
+
+CPU restatement of the reference's robust satellite MPC law ``SatelliteZ`` ("cwh_z", the
+example ``make_jobs.sh:60`` runs): CWH out-of-plane dynamics, non-convex input set (off,
+or on with a minimum impulse -- two convex pieces, lib/polytope.py:33-69), constraint
+tightening against independent and state-/input-dependent uncertainty, quadratic cost.
+
+Followed line by line (no CVXPY, no cdd, no MOSEK -- for one position dimension every set
+is a box, every norm an absolute value and every setup LP has a closed form):
+
+* parameters            lib/mpc_library.py:794-823  ``satellite_parameters``
+* plant                 lib/mpc_library.py:256-269  (``expm`` discretisation), lib/plant.py:93-115 (``D``)
+* uncertainty set       lib/mpc_library.py:239-254, lib/uncertainty_sets.py:140-233
+* input-set pieces      lib/mpc_library.py:76-79, lib/polytope.py:33-69
+* scalings              lib/mpc_library.py:85-105, lib/polytope.py:386-401 (bounding boxes of boxes)
+* robust terms          lib/mpc_library.py:107-138   (max of a linear function over a box)
+* cost                  lib/mpc_library.py:178-184
+* constraints           lib/mpc_library.py:186-216
+
+The model is kept UNCONDENSED (states, inputs and the epigraph variables of the absolute
+values are all decision variables, the dynamics are equality rows), unlike the condensed
+canonical form the HIP kernels consume (``explicit_hybrid_mpc_amd.mpc_library.SatelliteZ``),
+so that agreement between the two also checks the condensation.
+
+Known answers of the reference (the only numbers of the optimisation half it ships):
+``lib/post_process.py:484-485`` holds the absolute-error tolerances of its cwh_z runs, which
+by ``lib/examples.py:42-45`` are  max_v P_theta(abs_frac * v).J  over the vertices of the
+partitioned box; ``make_jobs.sh:60-66`` fixes N = 4 and (abs_frac, rel_err) = (0.5, 2.0),
+(0.25, 1.0) for the first two.  ``KNOWN_EPS_A`` below; checked in tests/test_oracle_satellite.py.
+"""
+
+import itertools
+import numpy as np
+import scipy.linalg as sla
+from numpy.linalg import matrix_power as mpow
+
+# lib/post_process.py:484-485 with the abs_frac of make_jobs.sh:62 (horizon make_jobs.sh:61)
+KNOWN_EPS_A = {(4, 0.5): 0.048658577500541, (4, 0.25): 0.012183769272642}
+
+
+def satellite_parameters():
+    """lib/mpc_library.py:794-823."""
+    pars = {'mu': 3.986004418e14, 'R_E': 6378137., 'h_E': 415e3, 'T_s': 100,
+            'pos_err_max': 10e-2, 'vel_err_max': 1e-3, 'delta_v_max': 2e-3, 'w_max': 50e-9,
+            'sigma_fix': 1e-6, 'sigma_pos': 2e-2, 'sigma_vel': 1e-3, 'input_ang_err': 2.,
+            'p_max': 0.4e-2, 'v_max': 4e-6}
+    pars.update({'a': pars['h_E'] + pars['R_E']})
+    pars.update({'wo': np.sqrt(pars['mu'] / pars['a'] ** 3)})
+    pars.update({'delta_v_min': pars['delta_v_max'] * 0.01})
+    pars.update({'sigma_rcs': np.tan(np.deg2rad(pars['input_ang_err']) / 2.)})
+    return pars
+
+
+class SatelliteZCPU:
+    """
+    Data of the reference's ``SatelliteZ`` for horizon ``N``: attribute names of the MPC
+    contract (lib/mpc_library.py:26-39) plus what the uncondensed model below needs.
+    """
+
+    def __init__(self, N=4):
+        pars = satellite_parameters()
+        self.pars = pars
+        self.N = int(N)
+        self.n_x, self.n_u = 2, 1
+        self.T_s = pars['T_s']
+        # plant, lib/mpc_library.py:256-269
+        A_c = np.array([[0., 1.], [-pars['wo'] ** 2, 0.]])
+        B_c = np.array([[0.], [1.]])
+        E_c = B_c.copy()
+        self.A = sla.expm(A_c * self.T_s)
+        self.B = self.A.dot(B_c)
+        M = np.block([[A_c, E_c], [np.zeros((1, 3))]])
+        self.E = sla.expm(M * self.T_s)[:2, 2:]
+        # state set X (lib/polytope.py:114-126 row order: +,- per coordinate)
+        self.G = np.array([[1., 0.], [-1., 0.], [0., 1.], [0., -1.]])
+        self.g = np.array([pars['pos_err_max'], pars['pos_err_max'],
+                           pars['vel_err_max'], pars['vel_err_max']])
+        # input set pieces U_ext \ U_int, lib/polytope.py:57-68: axis 0, sign -1 then +1
+        self.delta_size = 2
+        self.u_pieces = [(-pars['delta_v_max'], -pars['delta_v_min']),
+                         (pars['delta_v_min'], pars['delta_v_max'])]
+        # uncertainty set, lib/mpc_library.py:239-254.  Concatenated disturbance
+        # p = (process w | state e | input q0 | state q1 (pos) | state q2 (vel) | input q3)
+        types = ['process', 'state', 'input', 'state', 'state', 'input']
+        Mmap = {'state': -self.A, 'input': self.B, 'process': self.E}     # lib/plant.py:110
+        self.D = np.hstack([Mmap[t] for t in types])                      # 2 x 9
+        # independent part: W maps (w, e_pos, e_vel) into p; box bounds
+        self.W = np.zeros((9, 3))
+        self.W[0, 0] = 1.
+        self.W[1, 1] = 1.
+        self.W[2, 2] = 1.
+        self.w_ub = np.array([pars['w_max'], pars['p_max'], pars['v_max']])
+        # dependent part: L_l maps q_l into p  (lib/uncertainty_sets.py:206-224)
+        I2 = np.eye(2)
+        self.L = []
+        for rows, blk in ((slice(3, 4), np.eye(1)), (slice(4, 6), I2[:, :1]),
+                          (slice(6, 8), I2[:, 1:]), (slice(8, 9), np.eye(1))):
+            L = np.zeros((9, 1))
+            L[rows, :] = blk
+            self.L.append(L)
+        # dual norms qq (lib/mpc_library.py:80-81): pq = 2, inf, inf, 2 -> 2, 1, 1, 2; for
+        # the one-column L_l every one of them is an absolute value
+        # phi_l (lib/mpc_library.py:244-253): sigma_fix, sigma_pos |x_pos|, sigma_vel |x_vel|,
+        # sigma_rcs |u|
+        self.sigma = np.array([pars['sigma_fix'], pars['sigma_pos'], pars['sigma_vel'],
+                               pars['sigma_rcs']])
+        # scalings (lib/polytope.py:386-401 on boxes)
+        self.D_x = np.diag([pars['pos_err_max'], pars['vel_err_max']])
+        self.D_u_box = np.diag([pars['delta_v_max']])
+        self.Q_coeff = 1e-2                                                # :272
+        n_g = self.g.size
+        N = self.N
+        # robust term for the independent noise, lib/mpc_library.py:107-138
+        self.sum_sigma = np.zeros((N + 1, n_g))
+        for k in range(1, N + 1):
+            for j in range(n_g):
+                self.sum_sigma[k, j] = sum(
+                    np.abs(self.G[j].dot(mpow(self.A, k - 1 - i)).dot(self.D).dot(self.W))
+                    .dot(self.w_ub) for i in range(k))
+        # coefficients of the dependent terms, lib/mpc_library.py:197-204
+        # coef[k][i][l] = vector over facets j of |G_j A^(k-1-i) D L_l|
+        self.coef = np.zeros((N + 1, N, 4, n_g))
+        for k in range(1, N + 1):
+            for i in range(k):
+                for l in range(4):
+                    self.coef[k, i, l] = np.abs(
+                        self.G.dot(mpow(self.A, k - 1 - i)).dot(self.D).dot(self.L[l]))[:, 0]
+        self.box_vertices = np.array(list(itertools.product(
+            [-pars['pos_err_max'], pars['pos_err_max']],
+            [-pars['vel_err_max'], pars['vel_err_max']])))
+
+    # -- commutations: per step 0 = off, 1 + i = input piece i ---------------------------
+    def mode_sequences(self):
+        return list(itertools.product(range(self.delta_size + 1), repeat=self.N))
+
+    def sequence_to_delta(self, seq):
+        """lib/mpc_library.py:160 layout: delta[delta_size*k+i]."""
+        d = np.zeros(self.delta_size * self.N)
+        for k, s in enumerate(seq):
+            if s > 0:
+                d[self.delta_size * k + (s - 1)] = 1.
+        return d
+
+    def fixed_commutation_model(self, seq):
+        return SatelliteZModel(self, seq)
+
+
+class SatelliteZModel:
+    """
+    One commutation of ``SatelliteZCPU`` as an uncondensed convex QP.
+    v = [x_0..x_N | u_0..u_{N-1} | apos_0..apos_{N-1} | avel_0.. | au_0..]
+    """
+
+    def __init__(self, sat, seq):
+        self.sat = sat
+        self.seq = tuple(seq)
+        N = sat.N
+        self.N, self.n_x, self.n_u = N, 2, 1
+        self.ox, self.ou = 0, 2 * (N + 1)
+        self.oap, self.oav, self.oau = self.ou + N, self.ou + 2 * N, self.ou + 3 * N
+        self.nv = self.ou + 4 * N
+        nv = self.nv
+        # dynamics, lib/mpc_library.py:190-192
+        self.A_dyn = np.zeros((2 * N, nv))
+        for k in range(N):
+            self.A_dyn[2 * k:2 * k + 2, 2 * (k + 1):2 * (k + 2)] = np.eye(2)
+            self.A_dyn[2 * k:2 * k + 2, 2 * k:2 * k + 2] = -sat.A
+            self.A_dyn[2 * k:2 * k + 2, self.ou + k] = -sat.B[:, 0]
+        self.b_dyn = np.zeros(2 * N)
+        self.A_x0 = np.zeros((2, nv))
+        self.A_x0[:, :2] = np.eye(2)
+        rows, rhs = [], []
+        # tightened state constraints, lib/mpc_library.py:194-205
+        for k in range(1, N + 1):
+            blk = np.zeros((sat.g.size, nv))
+            blk[:, 2 * k:2 * k + 2] = sat.G
+            const = sat.sum_sigma[k].copy()
+            for i in range(k):
+                const += sat.coef[k, i, 0] * sat.sigma[0]
+                blk[:, self.oap + i] += sat.coef[k, i, 1] * sat.sigma[1]
+                blk[:, self.oav + i] += sat.coef[k, i, 2] * sat.sigma[2]
+                blk[:, self.oau + i] += sat.coef[k, i, 3] * sat.sigma[3]
+            rows.append(blk)
+            rhs.append(sat.g - const)
+        # epigraphs of the absolute values (cvx.norm of one-dimensional arguments)
+        for i in range(N):
+            for var, tgt in ((2 * i, self.oap + i), (2 * i + 1, self.oav + i),
+                             (self.ou + i, self.oau + i)):
+                for sgn in (1., -1.):
+                    r = np.zeros((1, nv))
+                    r[0, var] = sgn
+                    r[0, tgt] = -1.
+                    rows.append(r)
+                    rhs.append(np.zeros(1))
+        # input set, lib/mpc_library.py:206-209 with the commutation fixed:
+        # piece i active  ->  lo_i <= u <= hi_i ;  no piece active  ->  u = 0
+        eq_rows, eq_rhs = [], []
+        for k in range(N):
+            s = self.seq[k]
+            if s == 0:
+                r = np.zeros((1, nv))
+                r[0, self.ou + k] = 1.
+                eq_rows.append(r)
+                eq_rhs.append(np.zeros(1))
+            else:
+                lo, hi = sat.u_pieces[s - 1]
+                r = np.zeros((2, nv))
+                r[0, self.ou + k] = 1.
+                r[1, self.ou + k] = -1.
+                rows.append(r)
+                rhs.append(np.array([hi, -lo]))
+        self.A_ub = np.vstack(rows)
+        self.b_ub = np.concatenate(rhs)
+        if eq_rows:
+            self.A_dyn = np.vstack([self.A_dyn] + eq_rows)
+            self.b_dyn = np.concatenate([self.b_dyn] + eq_rhs)
+        # cost, lib/mpc_library.py:178-184:  V = 1/2 v' P v
+        Pm = np.zeros((nv, nv))
+        du = sat.D_u_box[0, 0]
+        for k in range(N):
+            Pm[self.ou + k, self.ou + k] = 2. / du ** 2
+        Dxi = np.linalg.inv(sat.D_x)
+        Qx = sat.Q_coeff * Dxi.T.dot(Dxi)
+        for k in range(1, N + 1):
+            Pm[2 * k:2 * k + 2, 2 * k:2 * k + 2] = 2. * Qx
+        self.P = Pm
+        self.cost = np.zeros(nv)
+
+    def u0(self, v):
+        return np.array(v[self.ou:self.ou + 1])
+
+    # -- P_theta_delta (lib/oracle.py:141-173) ---------------------------------------------
+    def lp_point(self, theta):
+        A_eq = np.vstack([self.A_dyn, self.A_x0])
+        b_eq = np.concatenate([self.b_dyn, np.asarray(theta, dtype=np.float64)])
+        return dict(c=self.cost, P=self.P, A_ub=self.A_ub, b_ub=self.b_ub, A_eq=A_eq, b_eq=b_eq)
+
+    # -- problems over a simplex (lib/oracle.py:70-79, 89-97) -----------------------------
+    def _simplex_blocks(self, R, extra_cols):
+        R = np.asarray(R, dtype=np.float64)
+        na = R.shape[0]
+        nv = self.nv
+        ntot = nv + na + extra_cols
+        nd = self.A_dyn.shape[0]
+        A_eq = np.zeros((nd + 2 + 1, ntot))
+        A_eq[:nd, :nv] = self.A_dyn
+        A_eq[nd:nd + 2, :nv] = self.A_x0
+        A_eq[nd:nd + 2, nv:nv + na] = -R.T
+        A_eq[nd + 2, nv:nv + na] = 1.
+        b_eq = np.concatenate([self.b_dyn, np.zeros(2), [1.]])
+        # alpha >= 0 as rows (the QP solver of this oracle takes no bounds)
+        A_ub = np.zeros((self.A_ub.shape[0] + na, ntot))
+        A_ub[:self.A_ub.shape[0], :nv] = self.A_ub
+        A_ub[self.A_ub.shape[0]:, nv:nv + na] = -np.eye(na)
+        b_ub = np.concatenate([self.b_ub, np.zeros(na)])
+        Pbig = np.zeros((ntot, ntot))
+        Pbig[:nv, :nv] = self.P
+        return A_eq, b_eq, A_ub, b_ub, Pbig, ntot, na
+
+    def lp_min_over_simplex(self, R):
+        A_eq, b_eq, A_ub, b_ub, Pbig, ntot, na = self._simplex_blocks(R, 0)
+        return dict(c=np.zeros(ntot), P=Pbig, A_ub=A_ub, b_ub=b_ub, A_eq=A_eq, b_eq=b_eq)
+
+    def lp_bar_E(self, R, V_bar, eps_a, eps_r):
+        """
+        Decision form of lib/oracle.py:89-97 (see oracle/lp_models.py): maximise t with
+            V(v) - sum alpha_i V_i + eps_a + t <= 0 ,  (1+eps_r) V(v) - sum alpha_i V_i + t <= 0
+        -- two convex quadratic rows, ``quad`` = [(P_i, q_i, r_i)] meaning
+        1/2 v'P_i v + q_i'v + r_i <= 0.
+        """
+        A_eq, b_eq, A_ub, b_ub, Pbig, ntot, na = self._simplex_blocks(R, 1)
+        nv = self.nv
+        V_bar = np.asarray(V_bar, dtype=np.float64)
+        quad = []
+        for kappa, r0 in ((1., eps_a), (1. + eps_r, 0.)):
+            q = np.zeros(ntot)
+            q[nv:nv + na] = -V_bar
+            q[-1] = 1.
+            quad.append((kappa * Pbig, q, r0))
+        c = np.zeros(ntot)
+        c[-1] = -1.
+        return dict(c=c, A_ub=A_ub, b_ub=b_ub, A_eq=A_eq, b_eq=b_eq, quad=quad)
