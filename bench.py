@@ -94,10 +94,12 @@ def main():
     ap.add_argument('--steps', type=int, default=3)
     ap.add_argument('--warmup', type=int, default=1)
     ap.add_argument('--seed', type=int, default=0)
-    ap.add_argument('--workload', choices=['config2', 'config4'], default='config2',
+    ap.add_argument('--workload', choices=['config2', 'config4', 'config2q'], default='config2',
                     help='config2 = the BASELINE.json metric (default); config4 = n_x=6 n_u=3 N=10 '
                          'box-constrained instance on the wide kernels (a parity-test '
-                         'configuration, timed for the record)')
+                         'configuration, timed for the record); config2q = config 2 with the '
+                         'quadratic cost of the same weights (convex QP / QCQP oracles, the '
+                         "reference's cvx.quad_form cost class; not the headline metric)")
     ap.add_argument('--abs-frac', type=float, default=None,
                     help='eps_a rule of lib/examples.py:42-46 (default 0.02; config4: 0.4)')
     ap.add_argument('--eps-r', type=float, default=None, help='default 1e-2; config4: 0.25')
@@ -137,10 +139,14 @@ def main():
         args.abs_frac = 0.4 if wide else 0.02
     if args.eps_r is None:
         args.eps_r = 0.25 if wide else 1e-2
-    mpc = examples.integrator_chain_mpc() if wide else examples.linear_mpc(seed=args.seed)
+    quad = args.workload == 'config2q'
+    if quad:
+        args.solver = 1       # quadratic costs run on the one-wavefront kernels (ehm_ipm.h)
+    mpc = examples.integrator_chain_mpc() if wide else \
+        examples.linear_mpc(seed=args.seed, cost='quadratic' if quad else 'inf')
     can = mpc.compile()
     gp = engine.GpuProblem(can, 1., 1., device=device_index)
-    if not wide:
+    if not wide and not quad:
         gp.set_solver(args.solver)
     gp.set_option('decide_full', 1 if args.decide_full else 0)
     kname = 'k3_lcss_decide' if wide else ('k2_lcss_decide' if args.solver == 2
@@ -242,8 +248,10 @@ def main():
                 'workload': ('configs[3] (NOT the headline configuration): n_x=6 n_u=3 N=10 p=6 '
                              'box-constrained chain' if wide else
                              'configs[1]: n_x=4 n_u=2 N=5 p=4 linear MPC') +
-                            ', inf-norm LP oracle (n=%d m=%d), seed %d, eps_r=%g, eps_a=%.6g '
+                            ', %s (n=%d m=%d), seed %d, eps_r=%g, eps_a=%.6g '
                             '(abs_frac=%g), %d Delaunay roots' % (
+                                'quadratic-cost QP / QCQP oracle (NOT the headline metric)'
+                                if quad else 'inf-norm LP oracle',
                                 can.n, can.m, args.seed, args.eps_r, eps_a, args.abs_frac,
                                 len(roots)),
                 'regions_per_step': closed / K,
@@ -254,8 +262,9 @@ def main():
                 'sweeps': info0['sweeps'], 'tree_depth': info0['max_depth'],
                 'min_decision_margin': info0['min_margin'],
                 'kernels': 'wide (one workgroup per LP, MFMA normal matrix)' if wide else
-                           'generation %d' % args.solver,
-                'suboptimality_test': 'full accuracy' if args.decide_full else
+                           'generation %d%s' % (args.solver, ' with the quadratic block' if quad
+                                                else ''),
+                'suboptimality_test': 'full accuracy' if (args.decide_full or args.solver == 1) else
                                       'sign-only stop (lower bound of |t*| recorded)',
                 'parallelism': 'frontier dealt round-robin over %d GPU(s)' % world +
                                ('' if world == 1 else

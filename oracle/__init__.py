@@ -21,9 +21,17 @@ What is restated and from where (paths into the reference tree):
   vectors for any oracle.  The restatement therefore poses the same
   optimisation problems (same constraint sets, same return conventions) on the
   *uncondensed* state/input variables and solves them with SciPy's HiGHS
-  (``scipy.optimize.linprog``).  PARITY UNPINNED for this half: there is nothing of the
-  reference's to pin it to; it is cross-checked against a second, independent solver
-  path (``oracle/ipm_numpy.py``) instead.
+  (``scipy.optimize.linprog``) for infinity-norm costs and with ``oracle/qp_numpy.py`` for
+  the reference's quadratic costs.  PINNED for the quadratic cost class: the only numbers
+  of this half the reference ships -- the five ``P_theta`` optima hard-coded in
+  ``lib/post_process.py:484-485`` (absolute tolerances of its cwh_z runs, rule
+  ``lib/examples.py:42-45``, job parameters ``make_jobs.sh:60-66``) -- are reproduced by
+  ``oracle/satellite_cpu.py`` (line-by-line restatement of ``SatelliteZ``,
+  ``lib/mpc_library.py:61-272``) + ``OracleCPU.P_theta`` to <= 7e-8 absolute
+  (``tests/test_oracle_satellite.py``, fixture ``tests/golden/known_answers.json`` made by
+  ``tests/golden/make_known_answers.py``).  The synthetic infinity-norm LP instances of
+  BASELINE.json have no counterpart in the reference: for them the oracle is cross-checked
+  against a second, independent solver path (``oracle/ipm_numpy.py``).
 * node semantics of the partition algorithms -- ``lib/worker.py:241-417`` (``ecc``,
   ``lcss``): ``oracle/partition_cpu.py`` (iterative, same per-node oracle sequence).
 

@@ -44,11 +44,12 @@ def cwh():
 
 def test_reference_known_eps_a_on_device():
     from explicit_hybrid_mpc_amd import examples
-    from oracle.satellite_cpu import KNOWN_EPS_A
-    for (N, abs_frac), known in sorted(KNOWN_EPS_A.items()):
+    from oracle.satellite_cpu import KNOWN_EPS_A, KNOWN_EPS_A_INFERRED, KNOWN_EPS_A_ABS_TOL
+    for (N, abs_frac), known in sorted({**KNOWN_EPS_A, **KNOWN_EPS_A_INFERRED}.items()):
         full_set, part, oracle = examples.example('cwh_z', abs_frac=abs_frac, rel_err=2.0)
         assert oracle.mpc.N == N and full_set.shape == (4, 2)
-        assert abs(oracle.eps_a - known) <= 5e-6 * known
+        assert abs(oracle.eps_a - known) <= KNOWN_EPS_A_ABS_TOL
+        assert abs(oracle.eps_a - known) <= 1e-4 * known
         oracle.close()
 
 
