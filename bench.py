@@ -140,13 +140,11 @@ def main():
     if args.eps_r is None:
         args.eps_r = 0.25 if wide else 1e-2
     quad = args.workload == 'config2q'
-    if quad:
-        args.solver = 1       # quadratic costs run on the one-wavefront kernels (ehm_ipm.h)
     mpc = examples.integrator_chain_mpc() if wide else \
         examples.linear_mpc(seed=args.seed, cost='quadratic' if quad else 'inf')
     can = mpc.compile()
     gp = engine.GpuProblem(can, 1., 1., device=device_index)
-    if not wide and not quad:
+    if not wide:
         gp.set_solver(args.solver)
     gp.set_option('decide_full', 1 if args.decide_full else 0)
     kname = 'k3_lcss_decide' if wide else ('k2_lcss_decide' if args.solver == 2

@@ -25,6 +25,8 @@ HEADERS = ['ehm_ipm.h', 'ehm_kernels.h', 'ehm_dev.h', 'ehm_k2.h', 'ehm_ipm2.h', 
 # must match EHM_K2_ALL in ehm_capi.hip
 K2_NPS = (8, 12, 16, 20, 24, 28, 32)
 K2_SLOTS = (1, 2, 3, 4)
+# instances with the quadratic block (-DEHM2_QUAD=1); must match EHM_K2Q_ALL in ehm_capi.hip
+K2Q_NPS = (8, 16, 24, 32)
 # wide kernels (ehm_k3.hip): row slots per thread, rows <= 256 * slots; must match the
 # ehm_k3_api_* getters in ehm_capi.hip
 K3_RS = (2, 4)
@@ -60,6 +62,11 @@ def _objects():
             objs.append((os.path.join(OBJ_DIR, 'ehm_k2_%d_%d.o' % (np_, sl)),
                          os.path.join(SRC_DIR, 'ehm_k2.hip'),
                          ['-DEHM_NP=%d' % np_, '-DEHM_SLOTS=%d' % sl]))
+    for np_ in K2Q_NPS:
+        for sl in K2_SLOTS:
+            objs.append((os.path.join(OBJ_DIR, 'ehm_k2q_%d_%d.o' % (np_, sl)),
+                         os.path.join(SRC_DIR, 'ehm_k2.hip'),
+                         ['-DEHM_NP=%d' % np_, '-DEHM_SLOTS=%d' % sl, '-DEHM2_QUAD=1']))
     for rs in K3_RS:
         objs.append((os.path.join(OBJ_DIR, 'ehm_k3_%d.o' % rs),
                      os.path.join(SRC_DIR, 'ehm_k3.hip'),

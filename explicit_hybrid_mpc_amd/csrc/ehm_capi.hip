@@ -31,6 +31,13 @@ extern "C" const ehm::K2Api* ehm_k3_api_2();
 extern "C" const ehm::K2Api* ehm_k3_api_4();
 typedef const ehm::K2Api* (*k2_getter)();
 static const k2_getter g_k2_getters[] = {EHM_K2_ALL(EHM_K2_ENTRY) ehm_k3_api_2, ehm_k3_api_4};
+// instances of ehm_k2.hip with the quadratic block (-DEHM2_QUAD=1): convex QP / QCQP
+#define EHM_K2Q_NPS(X, S) X(8, S) X(16, S) X(24, S) X(32, S)
+#define EHM_K2Q_ALL(X) EHM_K2Q_NPS(X, 1) EHM_K2Q_NPS(X, 2) EHM_K2Q_NPS(X, 3) EHM_K2Q_NPS(X, 4)
+#define EHM_K2Q_DECL(NPV, SL) extern "C" const ehm::K2Api* ehm_k2q_api_##NPV##_##SL();
+EHM_K2Q_ALL(EHM_K2Q_DECL)
+#define EHM_K2Q_ENTRY(NPV, SL) ehm_k2q_api_##NPV##_##SL,
+static const k2_getter g_k2q_getters[] = {EHM_K2Q_ALL(EHM_K2Q_ENTRY)};
 #define EHM_V1_MAX_N 32     // limits of the generation-1 and wave-local kernels
 #define EHM_V1_MAX_M 256
 
@@ -448,6 +455,7 @@ struct ehm_problem {
     DevBuf wr3;              // [n_delta][mpad][64]    row-major image for the wide kernels
     DevBuf quad;             // H | F^T | f0 | C | c1 | c0  (ehm_problem_set_quadratic)
     bool quadratic = false;
+    bool k2q_ok = false;     // a quadratic shared-block instance fits (ehm_k2.hip, EHM2_QUAD)
     bool v1_ok = false;      // the generation-1 kernels fit this problem
     int decide_full = 0;     // 1 = the suboptimality test solves to full accuracy (no sign-only stop)
     int solver_gen = 2;      // 1 = one wavefront per workgroup (ehm_kernels.h), 2 = ehm_k2.hip
@@ -542,12 +550,16 @@ static void kind_dims(const DevProblem& dp, int kind, int& n_lp, int& ne) {
 }
 
 // smallest compiled instance that holds n_lp columns and `slots` row slots
-static const K2Api* k2_pick(int n_lp, int slots) {
+static const K2Api* k2_pick(int n_lp, int slots, bool quad) {
     const K2Api* best = nullptr;
-    for (k2_getter g : g_k2_getters) {
-        const K2Api* a = g();
-        if (a->np < n_lp || a->slots < slots) continue;
+    auto consider = [&](const K2Api* a) {
+        if (a->np < n_lp || a->slots < slots) return;
         if (!best || a->np < best->np || (a->np == best->np && a->slots < best->slots)) best = a;
+    };
+    if (quad) {
+        for (k2_getter g : g_k2q_getters) consider(g());
+    } else {
+        for (k2_getter g : g_k2_getters) consider(g());
     }
     return best;
 }
@@ -565,7 +577,7 @@ static int k2_config(ehm_problem* P, int kind_a, int kind_b, long long n_items, 
     const int slots = std::max(lp_slots(P->dp.m, ne), lp_slots(P->dp.m, ne2));
     n_lp = std::max(n_lp, n_lp2);
     ne = std::max(ne, ne2);
-    const K2Api* api = k2_pick(n_lp, slots);
+    const K2Api* api = k2_pick(n_lp, slots, P->quadratic);
     if (!api)
         return fail(EHM_E_INVALID, "no kernel instance for an LP with %d columns, %d row slots",
                     n_lp, slots);
@@ -821,15 +833,24 @@ int ehm_problem_set_quadratic(ehm_problem* P, const double* H, const double* F, 
     P->dp.c1q = P->dp.Cq + nC;
     P->dp.c0q = P->dp.c1q + n1;
     P->quadratic = true;
-    P->solver_gen = 1;
+    // shared-block kernels with the quadratic block when an instance holds the largest problem
+    // (the suboptimality test), else the one-wavefront kernels
+    P->k2q_ok = k2_pick(n + p + 1, lp_slots(P->dp.m, p + 3), true) != nullptr;
+    if (!P->k2q_ok || getenv("EHM_SOLVER")) {
+        const char* e = getenv("EHM_SOLVER");
+        P->solver_gen = (P->k2q_ok && e && atoi(e) == 2) ? 2 : 1;
+    } else {
+        P->solver_gen = 2;
+    }
     return EHM_OK;
 }
 
 int ehm_problem_set_solver(ehm_problem* P, int generation) {
     if (!P) return fail(EHM_E_INVALID, "null problem");
     if (generation != 1 && generation != 2) return fail(EHM_E_INVALID, "solver generation 1 or 2");
-    if (generation == 2 && P->quadratic)
-        return fail(EHM_E_INVALID, "quadratic costs run on the generation-1 kernels only");
+    if (generation == 2 && P->quadratic && !P->k2q_ok)
+        return fail(EHM_E_INVALID,
+                    "no shared-block instance with the quadratic block holds this problem");
     if (generation == 1 && !P->v1_ok)
         return fail(EHM_E_INVALID, "the generation-1 kernels do not fit this problem in LDS");
     P->solver_gen = generation;

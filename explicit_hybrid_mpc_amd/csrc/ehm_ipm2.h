@@ -67,7 +67,19 @@
 // and inline host functions of the same name would otherwise be merged by the linker
 #define EHM2_CAT2(a, b, c) a##b##_##c
 #define EHM2_CAT(a, b, c) EHM2_CAT2(a, b, c)
+// EHM2_QUAD = 1 compiles the instance with the quadratic block (convex QP / QCQP, see
+// ehm_ipm.h "Quadratic costs" and DESIGN.md section 3.3b): same solver, plus per wavefront the
+// Hessian Q of the cost over the LP variables, and the two suboptimality rows -- already private
+// "extra rows" here -- rewritten with their current gradients every iteration.  The LP
+// instances (EHM2_QUAD = 0) contain none of it: their register budget is untouched.
+#ifndef EHM2_QUAD
+#define EHM2_QUAD 0
+#endif
+#if EHM2_QUAD
+#define EHM2_NS EHM2_CAT(ehm2q_, EHM_NP, EHM_SLOTS)
+#else
 #define EHM2_NS EHM2_CAT(ehm2_, EHM_NP, EHM_SLOTS)
+#endif
 
 namespace EHM2_NS {
 
@@ -231,6 +243,19 @@ struct Wave {
     int psi0, npsi;
     int nsx;        // extra rows 0..nsx-1 are the simplex rows (-beta_q <= 0, sum beta <= 1):
                     // their normal-matrix terms are added analytically, rows >= nsx densely
+#if EHM2_QUAD
+    // quadratic block: objective c'x + kap0 V(x), extra rows eq / eq+1 are
+    // kap_i V(x) + a_i'x <= bq_i,  V(x) = 1/2 x'Q x + qv'x (+ v0 in the reported objective)
+    double* Q;      // NP x LDM
+    double* qv;     // NP
+    double* a1;     // NP
+    double* a2;     // NP
+    double* gv;     // NP  grad V at the iterate
+    double* lq;     // 2   multipliers of the two quadratic rows
+    int quad;       // 0: linear programme
+    int eq;         // extra-row index of the first quadratic row, -1: none
+    double kap0, kap1, kap2, v0, bq1, bq2;
+#endif
 };
 constexpr int LDM = NP + 1;     // odd: row- and column-wise access of the square matrix are both
                                 // bank-conflict free (the factor U is kept packed, see below)
@@ -256,7 +281,12 @@ constexpr size_t A_SQ = ((size_t)NP * LDM < 768) ? 768 : (size_t)NP * LDM;
 constexpr size_t A_DOUBLES = (A_MIN < A_SQ) ? A_SQ : A_MIN;
 __host__ __device__ inline size_t wave_lp_doubles(int n_lp, int ne) {
     const size_t ldx = ne ? ((size_t)ne | 1) : 0;
+#if EHM2_QUAD
+    return ((A_DOUBLES + (size_t)n_lp * ldx + 12 * (size_t)NP + (size_t)NP * LDM + 2) + 1) &
+           ~(size_t)1;
+#else
     return ((A_DOUBLES + (size_t)n_lp * ldx + 7 * (size_t)NP) + 1) & ~(size_t)1;
+#endif
 }
 __device__ inline void carve_wave(Wave& W, double* base, int n_lp, int ne, int m) {
     W.n_lp = n_lp;
@@ -279,6 +309,18 @@ __device__ inline void carve_wave(Wave& W, double* base, int n_lp, int ne, int m
     W.ub = base;  base += NP;
     W.db = base;  base += NP;
     W.yv = base;
+#if EHM2_QUAD
+    base += NP;
+    W.qv = base;  base += NP;
+    W.a1 = base;  base += NP;
+    W.a2 = base;  base += NP;
+    W.gv = base;  base += NP;
+    W.lq = base;  base += 2;
+    W.Q = base;
+    W.quad = 0;
+    W.eq = -1;
+    W.kap0 = W.kap1 = W.kap2 = W.v0 = W.bq1 = W.bq2 = 0.0;
+#endif
     W.E = nullptr;
     W.psi0 = n_lp;
     W.npsi = 0;
@@ -883,6 +925,39 @@ __device__ inline IpmResult ipm_solve(const Shared& S, const Wave& W, const doub
 
     for (int it = 0; it <= EHM2_MAX_ITER; ++it) {
         lane = pin(lane0);      // per-lane addresses are re-derived every iteration (see pin)
+#if EHM2_QUAD
+        // ---- quadratic block: grad V, V, and the two quadratic rows at this iterate ----------
+        double xQx = 0.0, qx = 0.0, gjj = 0.0;
+        if (W.quad) {
+            const double xj = (lane < n) ? W.x[lane] : 0.0;
+            const double qj = (lane < n) ? W.qv[lane] : 0.0;
+            double g = 0.0;
+            if (lane < n) {
+                const double* qrow = W.Q + lane * LDM;
+                for (int k = 0; k < n; ++k) g = fma(qrow[k], W.x[k], g);
+            }
+            xQx = wave_sum(xj * g);
+            qx = wave_sum(xj * qj);
+            const double gvj = g + qj;
+            gjj = (lane < n) ? W.kap0 * gvj : 0.0;
+            if (W.eq >= 0) {
+                const double a1j = (lane < n) ? W.a1[lane] : 0.0;
+                const double a2j = (lane < n) ? W.a2[lane] : 0.0;
+                if (lane < n) {             // current gradients kap_i (Qx+q) + a_i
+                    W.X[(size_t)lane * W.ldx + W.eq] = fma(W.kap1, gvj, a1j);
+                    W.X[(size_t)lane * W.ldx + W.eq + 1] = fma(W.kap2, gvj, a2j);
+                }
+                const double a1x = wave_sum(a1j * xj);
+                const double a2x = wave_sum(a2j * xj);
+                // exact b_i - g_i(x) replaces the carried value on the two quadratic rows
+                const int e = lane + 64 * (SLOTS - 1) - W.xbase;
+                const double Vx = fma(0.5, xQx, qx);
+                if (rm.last_extra && e == W.eq) v[SLOTS - 1] = W.bq1 - fma(W.kap1, Vx, a1x);
+                if (rm.last_extra && e == W.eq + 1) v[SLOTS - 1] = W.bq2 - fma(W.kap2, Vx, a2x);
+            }
+            wsync();
+        }
+#endif
         // ---- residuals -----------------------------------------------------------------
         double r_p[SLOTS], rs[SLOTS];
         double rpmax = 0.0, sl_sum = 0.0, vl_sum = 0.0;
@@ -906,6 +981,20 @@ __device__ inline IpmResult ipm_solve(const Shared& S, const Wave& W, const doub
         cols_times<true>(S, W, W.vm0, W.vm1, W.M, lane, atl, atdr);   // W.M is free here
         const double cjj = (lane < n) ? W.c[lane] : 0.0;
         const double xjj = (lane < n) ? W.x[lane] : 0.0;
+#if EHM2_QUAD
+        const double r_d = (lane < n) ? (atl + cjj + gjj) : 0.0;
+        const double cn = W.quad ? (1.0 + wave_max(fmax(fabs(cjj), fabs(gjj)))) : cnorm;
+        const double emax = wave_max(fmax(rpmax / bnorm, fabs(r_d) / cn));
+        const double sl_tot = wave_sum(sl_sum);
+        const double mu = sl_tot * inv_m;
+        double pobj = wave_sum(cjj * xjj);
+        double dobj = -wave_sum(vl_sum + xjj * atl);
+        if (W.quad) {       // s'lam measures the gap; pobj - s'lam stands in for the dual value
+            pobj += W.kap0 * (fma(0.5, xQx, qx) + W.v0);
+            dobj = pobj - sl_tot;
+        }
+        const double e_g = fabs(pobj - dobj) / (1.0 + fabs(pobj));
+#else
         const double r_d = (lane < n) ? (atl + cjj) : 0.0;
         const double emax = wave_max(fmax(rpmax / bnorm, fabs(r_d) / cnorm));
         const double mu = wave_sum(sl_sum) * inv_m;
@@ -913,6 +1002,7 @@ __device__ inline IpmResult ipm_solve(const Shared& S, const Wave& W, const doub
         const double dobj = -wave_sum(vl_sum + xjj * atl);
         const double pobj = wave_sum(cjj * xjj);
         const double e_g = fabs(pobj - dobj) / (1.0 + fabs(pobj));
+#endif
         const double merit = fmax(emax / const_d(EHM2_TOL_RES), e_g / const_d(EHM2_TOL_GAP));
         if (merit < res.merit) {
             res.merit = uniform_d(merit);
@@ -950,6 +1040,13 @@ __device__ inline IpmResult ipm_solve(const Shared& S, const Wave& W, const doub
         wsync();
         // d of the extra rows, for the terms added after the MPC part (W.ub is free here)
         if (rm.last_extra) W.ub[lane + 64 * (SLOTS - 1) - W.xbase] = lam[SLOTS - 1] * rs[SLOTS - 1];
+#if EHM2_QUAD
+        if (W.quad && W.eq >= 0 && rm.last_extra) {
+            const int e = lane + 64 * (SLOTS - 1) - W.xbase;
+            if (e == W.eq) W.lq[0] = lam[SLOTS - 1];
+            if (e == W.eq + 1) W.lq[1] = lam[SLOTS - 1];
+        }
+#endif
         wsync();
         form_normal_matrix(S, W, W.vm0, W.ub, lane);
         lane = pin(lane0);
@@ -973,6 +1070,19 @@ __device__ inline IpmResult ipm_solve(const Shared& S, const Wave& W, const doub
                     if ((q & 3) == 3) __builtin_amdgcn_sched_barrier(0);   // register budget
                 }
             }
+#if EHM2_QUAD
+            if (W.quad) {       // + (kap0 + kap1 lam_1 + kap2 lam_2) Q
+                double wq = W.kap0;
+                if (W.eq >= 0) wq = fma(W.kap1, W.lq[0], fma(W.kap2, W.lq[1], wq));
+                const int jl = (lane < NP) ? lane : (NP - 1);
+                const double* qrow = W.Q + jl * LDM;
+                const bool in = jl < W.n_lp;
+#pragma unroll
+                for (int q = 0; q < NP; ++q)
+                    row[q] = fma(wq, (in && q < W.n_lp) ? qrow[q] : 0.0, row[q]);
+                dg = fma(wq, in ? qrow[jl] : 0.0, dg);
+            }
+#endif
             if (lane < NP) W.db[lane] = dg;
         }
         wsync();
@@ -981,7 +1091,11 @@ __device__ inline IpmResult ipm_solve(const Shared& S, const Wave& W, const doub
 
         // ---- predictor ------------------------------------------------------------------
         lane = pin(lane0);
+#if EHM2_QUAD
+        const double rhs_aff = (lane < n) ? (-cjj - gjj - atdr) : 0.0;
+#else
         const double rhs_aff = (lane < n) ? (-cjj - atdr) : 0.0;
+#endif
         double dxj = lu_solve(row, W, rinv_l, rhs_aff, lane);
         double adx[SLOTS];
         rows_times(S, W, lane, W.t, adx);
@@ -999,6 +1113,9 @@ __device__ inline IpmResult ipm_solve(const Shared& S, const Wave& W, const doub
         rho_d = wave_max(rho_d);
         double ap = (rho_p > 1.0) ? 1.0 / rho_p : 1.0;
         double ad = (rho_d > 1.0) ? 1.0 / rho_d : 1.0;
+#if EHM2_QUAD
+        if (W.quad) ap = ad = fmin(ap, ad);     // one step length: r_d couples x and lambda
+#endif
         double mu_aff = 0.0;
 #pragma unroll
         for (int sl = 0; sl < SLOTS; ++sl)
@@ -1039,6 +1156,9 @@ __device__ inline IpmResult ipm_solve(const Shared& S, const Wave& W, const doub
         rho_d = wave_max(rho_d);
         ap = (rho_p > step_frac) ? step_frac / rho_p : 1.0;
         ad = (rho_d > step_frac) ? step_frac / rho_d : 1.0;
+#if EHM2_QUAD
+        if (W.quad) ap = ad = fmin(ap, ad);
+#endif
         if (lane < n) W.x[lane] = fma(ap, dxj, W.x[lane]);
 #pragma unroll
         for (int sl = 0; sl < SLOTS; ++sl) {

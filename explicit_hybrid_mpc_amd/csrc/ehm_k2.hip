@@ -32,11 +32,119 @@ __device__ __forceinline__ void carve_node(NodeBuf& nb, double* base, int p, int
     nb.lp = base + k2_node_doubles(p, n_u);
 }
 
+#if EHM2_QUAD
+// Quadratic block of the cost over the LP variables (DevProblem::Hq set; same construction as
+// quad_point / quad_simplex of ehm_kernels.h, H / F / C read from L2).
+__device__ inline void quad_point(Wave& W, const DevProblem& P, int d, const double* theta,
+                                  int lane) {
+    const int n = P.n, p = P.p;
+    const double* H = P.Hq + (size_t)d * n * n;
+    for (int k = lane; k < n * n; k += 64) W.Q[(k / n) * LDM + (k % n)] = H[k];
+    if (lane < n) {
+        const double* F = P.Fq + (size_t)d * p * n;
+        double v = P.c[lane] + P.f0q[(size_t)d * n + lane];
+        for (int q = 0; q < p; ++q) v = fma(F[(size_t)q * n + lane], theta[q], v);
+        W.qv[lane] = v;
+        W.c[lane] = 0.0;
+    }
+    const double* C = P.Cq + (size_t)d * p * p;
+    double v0 = P.c0q[d];
+    for (int r = 0; r < p; ++r) {
+        double cr = P.c1q[(size_t)d * p + r];
+        for (int q = 0; q < p; ++q) cr = fma(0.5 * C[r * p + q], theta[q], cr);
+        v0 = fma(cr, theta[r], v0);
+    }
+    W.quad = 1;
+    W.eq = -1;
+    W.kap0 = 1.0;
+    W.v0 = v0;
+}
+
+// theta = R0 + E beta (E = the edge matrix already in LDS): Q = [H, F E; E'F', E'C E],
+// q = [c + f0 + F R0; E'(C R0 + c1)]; slack: rows p+1, p+2 of the extras are the quadratic ones.
+__device__ inline void quad_simplex(Wave& W, const DevProblem& P, int d, const double* E,
+                                    const double* R, const double* Vbar, bool slack,
+                                    double eps_a, double eps_r, double (&b)[SLOTS], int lane) {
+    const int n = P.n, p = P.p;
+    const int nl = n + p + (slack ? 1 : 0);
+    const double* H = P.Hq + (size_t)d * n * n;
+    const double* F = P.Fq + (size_t)d * p * n;
+    const double* C = P.Cq + (size_t)d * p * p;
+    for (int k = lane; k < nl * LDM; k += 64) W.Q[k] = 0.0;
+    wsync();
+    for (int k = lane; k < n * n; k += 64) W.Q[(k / n) * LDM + (k % n)] = H[k];
+    if (lane < n) {
+        double v = P.c[lane] + P.f0q[(size_t)d * n + lane];
+        for (int r = 0; r < p; ++r) v = fma(F[(size_t)r * n + lane], R[r], v);
+        W.qv[lane] = v;
+        for (int q = 0; q < p; ++q) {
+            double acc = 0.0;
+            for (int r = 0; r < p; ++r) acc = fma(F[(size_t)r * n + lane], E[r * p + q], acc);
+            W.Q[lane * LDM + n + q] = acc;
+            W.Q[(n + q) * LDM + lane] = acc;
+        }
+    }
+    if (lane < p * p) {                       // E'C E, one entry per lane (p <= 8)
+        const int q = lane / p, q2 = lane % p;
+        double acc = 0.0;
+        for (int r = 0; r < p; ++r) {
+            double ce = 0.0;
+            for (int r2 = 0; r2 < p; ++r2) ce = fma(C[r * p + r2], E[r2 * p + q2], ce);
+            acc = fma(E[r * p + q], ce, acc);
+        }
+        W.Q[(n + q) * LDM + n + q2] = acc;
+    }
+    if (lane < p) {                           // E'(C R0 + c1)
+        double acc = 0.0;
+        for (int r = 0; r < p; ++r) {
+            double cr = P.c1q[(size_t)d * p + r];
+            for (int r2 = 0; r2 < p; ++r2) cr = fma(C[r * p + r2], R[r2], cr);
+            acc = fma(E[r * p + lane], cr, acc);
+        }
+        W.qv[n + lane] = acc;
+    }
+    double v0 = P.c0q[d];
+    for (int r = 0; r < p; ++r) {
+        double cr = P.c1q[(size_t)d * p + r];
+        for (int q = 0; q < p; ++q) cr = fma(0.5 * C[r * p + q], R[q], cr);
+        v0 = fma(cr, R[r], v0);
+    }
+    W.quad = 1;
+    W.v0 = v0;
+    if (slack) {
+        if (lane < NP) {
+            double a = 0.0;
+            if (lane >= n && lane < n + p) a = -(Vbar[lane - n + 1] - Vbar[0]);
+            if (lane == n + p) a = 1.0;
+            W.a1[lane] = a;
+            W.a2[lane] = a;
+        }
+        if (lane == 0) W.qv[n + p] = 0.0;
+        W.eq = p + 1;
+        W.kap0 = 0.0;
+        W.kap1 = 1.0;
+        W.kap2 = 1.0 + eps_r;
+        W.bq1 = Vbar[0] - eps_a - W.kap1 * v0;
+        W.bq2 = Vbar[0] - W.kap2 * v0;
+#pragma unroll
+        for (int sl = 0; sl < SLOTS; ++sl) {
+            const int e = lane + 64 * sl - W.xbase;
+            if (e == p + 1) b[sl] = W.bq1;
+            if (e == p + 2) b[sl] = W.bq2;
+        }
+    } else {
+        if (lane < NP) W.c[lane] = 0.0;
+        W.eq = -1;
+        W.kap0 = 1.0;
+    }
+}
+#endif
+
 // P_theta_delta at one parameter value (lib/oracle.py:141-173) or its phase-one form
 //   min tau  s.t.  G z - tau <= w + S theta,  tau >= -1.
 __device__ inline void assemble_point(const Shared& S, Wave& W, double* lp_base,
                                       const double* theta, bool feas, double (&b)[SLOTS],
-                                      int lane) {
+                                      int lane, const DevProblem& P, int d) {
     const int n = S.n, m = S.m, p = S.p;
     carve_wave(W, lp_base, n + (feas ? 1 : 0), feas ? 1 : 0, m);
     W.n_lin = n;
@@ -59,6 +167,9 @@ __device__ inline void assemble_point(const Shared& S, Wave& W, double* lp_base,
         }
         b[sl] = v;
     }
+#if EHM2_QUAD
+    if (P.Hq && !feas) quad_point(W, P, d, theta, lane);
+#endif
     wsync();
 }
 
@@ -74,7 +185,7 @@ __device__ inline void assemble_point(const Shared& S, Wave& W, double* lp_base,
 __device__ inline void assemble_simplex(const Shared& S, Wave& W, const NodeBuf& nb,
                                         const double* R, const double* Vbar, int mode,
                                         double eps_a, double eps_r, double (&b)[SLOTS],
-                                        int lane) {
+                                        int lane, const DevProblem& P, int d) {
     const int n = S.n, m = S.m, p = S.p;
     const bool slack = (mode == SX_SLACK);
     const bool feas = (mode == SX_FEAS);
@@ -105,7 +216,15 @@ __device__ inline void assemble_simplex(const Shared& S, Wave& W, const NodeBuf&
             W.X[(n + lane) * ldx + p + 2] = -dv;
         }
     }
-    if (slack) {
+#if EHM2_QUAD
+    const bool quadc = (P.Hq != nullptr) && !feas;
+#else
+    const bool quadc = false;
+#endif
+    if (slack && quadc) {
+        // the two suboptimality rows are quadratic: ipm_solve writes their gradients
+        if (lane == 0) W.c[n + p] = const_d(-1.0);
+    } else if (slack) {
         if (lane < n) {
             const double cj = S.cv[lane];
             W.X[lane * ldx + p + 1] = cj;
@@ -140,6 +259,12 @@ __device__ inline void assemble_simplex(const Shared& S, Wave& W, const NodeBuf&
         }
         b[sl] = v;
     }
+#if EHM2_QUAD
+    if (quadc) {
+        wsync();
+        quad_simplex(W, P, d, nb.F, R, Vbar, slack, eps_a, eps_r, b, lane);
+    }
+#endif
     wsync();
 }
 
@@ -201,7 +326,7 @@ __global__ __launch_bounds__(EHM_K2_THREADS) void k2_point_batch(
             for (int attempt = 0; attempt < EHM2_ATTEMPTS; ++attempt) {     // see EHM2_STEP_FRAC
                 double b[SLOTS];
                 const int ln = pin(lane);     // nothing of the assembly outlives the attempt
-                assemble_point(S, W, nb.lp, nb.th, feas != 0, b, ln);
+                assemble_point(S, W, nb.lp, nb.th, feas != 0, b, ln, P, d);
                 r = ipm_solve(S, W, b, ln, false,
                               step_fraction(attempt));
                 its += r.iters;
@@ -257,7 +382,7 @@ __global__ __launch_bounds__(EHM_K2_THREADS) void k2_simplex_batch(
             for (int attempt = 0; attempt < EHM2_ATTEMPTS; ++attempt) {
                 double b[SLOTS];
                 const int ln = pin(lane);
-                assemble_simplex(S, W, nb, Rl, Vl, mode, P.eps_a, P.eps_r, b, ln);
+                assemble_simplex(S, W, nb, Rl, Vl, mode, P.eps_a, P.eps_r, b, ln, P, d);
                 r = ipm_solve(S, W, b, ln, false,
                               step_fraction(attempt));
                 its += r.iters;
@@ -311,7 +436,7 @@ __global__ __launch_bounds__(EHM_K2_THREADS) void k2_lcss_decide(
             double b[SLOTS];
             const int ln = pin(lane);
             assemble_simplex(S, W, nb, nb.rec, nb.rec + rec_off_vcost(P.p), SX_SLACK, P.eps_a,
-                             P.eps_r, b, ln);
+                             P.eps_r, b, ln, P, 0);
             r = ipm_solve(S, W, b, ln, sign_only != 0,
                           step_fraction(attempt));
             its += r.iters;
@@ -376,7 +501,7 @@ __global__ __launch_bounds__(EHM_K2_THREADS) void k2_lcss_expand(
         for (int attempt = 0; attempt < EHM2_ATTEMPTS; ++attempt) {
             double b[SLOTS];
             const int ln = pin(lane);
-            assemble_point(S, W, nb.lp, mid, false, b, ln);
+            assemble_point(S, W, nb.lp, mid, false, b, ln, P, 0);
             r = ipm_solve(S, W, b, ln, false, step_fraction(attempt));
             its += r.iters;
             if (r.status == 0) break;
@@ -457,7 +582,7 @@ __global__ __launch_bounds__(EHM_K2_THREADS) void k2_vertex_solve(
         for (int attempt = 0; attempt < EHM2_ATTEMPTS; ++attempt) {
             double b[SLOTS];
             const int ln = pin(lane);
-            assemble_point(S, W, nb.lp, nb.th, false, b, ln);
+            assemble_point(S, W, nb.lp, nb.th, false, b, ln, P, 0);
             r = ipm_solve(S, W, b, ln, false, step_fraction(attempt));
             its += r.iters;
             if (r.status == 0) break;
@@ -547,4 +672,8 @@ const K2Api g_api = {EHM_NP,   EHM_SLOTS,        EHM_K2_THREADS,     64,      se
 
 #define K2_CAT2(a, b, c) a##b##_##c
 #define K2_CAT(a, b, c) K2_CAT2(a, b, c)
+#if EHM2_QUAD
+extern "C" const ehm::K2Api* K2_CAT(ehm_k2q_api_, EHM_NP, EHM_SLOTS)() { return &g_api; }
+#else
 extern "C" const ehm::K2Api* K2_CAT(ehm_k2_api_, EHM_NP, EHM_SLOTS)() { return &g_api; }
+#endif

@@ -84,8 +84,9 @@ int ehm_problem_destroy(ehm_problem* prob);
  * H [n_delta][n][n], F [n_delta][n][p], f0 [n_delta][n], C [n_delta][p][p], c1 [n_delta][p],
  * c0 [n_delta]; H and C symmetric positive semidefinite (symmetrised on entry).  After this
  * call P_theta_delta is a convex QP, the suboptimality test (lib/oracle.py:89-97) a convex
- * QCQP with two quadratic rows, and every entry point below works on them; the handle runs
- * on the one-wavefront-per-problem kernels (n+p+1 <= 32, m+p+3 <= 256). */
+ * QCQP with two quadratic rows, and every entry point below works on them (n+p+1 <= 32,
+ * m+p+3 <= 256).  Both kernel generations carry the quadratic block; generation 2 is the
+ * default, ehm_problem_set_solver(prob, 1) selects the one-wavefront kernels. */
 int ehm_problem_set_quadratic(ehm_problem* prob, const double* H, const double* F,
                               const double* f0, const double* C, const double* c1,
                               const double* c0);

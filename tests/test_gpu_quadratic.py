@@ -53,11 +53,53 @@ def test_reference_known_eps_a_on_device():
         oracle.close()
 
 
-def test_quadratic_handle_refuses_the_lp_only_kernels(cwh):
-    from explicit_hybrid_mpc_amd._capi import EhmError
+def test_kernel_generations_agree_on_quadratic_problems(cwh):
+    """
+    Two implementations of the quadratic block -- the one-wavefront kernels (ehm_ipm.h) and
+    the shared-block kernels (ehm_ipm2.h, -DEHM2_QUAD instances; the default) -- on the same
+    batches: optima to 1e-9, identical verdicts; and the whole cwh_z example tree identical.
+    """
+    from explicit_hybrid_mpc_amd import examples, partition
+    from oracle import geometry
     mpc, gpu, cpu = cwh
-    with pytest.raises(EhmError):
-        gpu.gpu.set_solver(2)
+    gp = gpu.gpu
+    half = examples.theta_box(mpc)
+    rng = np.random.default_rng(11)
+    n = 400
+    ctr = rng.uniform(-0.7, 0.7, (n, 1, 2)) * half
+    R = ctr + rng.uniform(-1, 1, (n, 3, 2)) * half * 10 ** rng.uniform(-2, -0.5, (n, 1, 1))
+    out = {}
+    for gen in (1, 2):
+        gp.set_solver(gen)
+        didx, vJ, vu = gp.v_r(R)
+        ok = didx >= 0
+        dl = np.array(cpu.deltas)[np.maximum(didx, 0)]
+        t, alpha, st = gp.slack(R[ok], vJ[ok], dl[ok])
+        Jm, st2 = gp.min_simplex(R[ok], dl[ok])
+        closed, tb = gp.bar_e(R[ok][:60], vJ[ok][:60])
+        out[gen] = (didx, vJ[ok], t, st, Jm, st2, closed, tb)
+    gp.set_solver(2)
+    a, b = out[1], out[2]
+    assert np.array_equal(a[0], b[0]) and (a[0] >= 0).sum() > 100
+    rel = lambda x, y: np.max(np.abs(x - y) / (1 + np.abs(y)))
+    assert rel(a[1], b[1]) < 1e-9 and rel(a[2], b[2]) < 1e-9 and rel(a[4], b[4]) < 1e-9
+    assert (a[3] == 0).all() and (b[3] == 0).all() and (a[5] == 0).all() and (b[5] == 0).all()
+    assert np.array_equal(a[6], b[6]) and rel(a[7], b[7]) < 1e-9
+    # the example job's tree under both generations
+    V = examples.box_vertices(half)
+    roots, locs = geometry.delaunay_simplices(V)
+    gpu.gpu.set_eps(0.0486586449, 2.0)
+    trees = []
+    for gen in (1, 2):
+        gp.set_solver(gen)
+        trees.append(partition.run_engine(gpu, np.array(roots), action='ecc'))
+    gp.set_solver(2)
+    gpu.gpu.set_eps(gpu.eps_a, gpu.eps_r)
+    assert trees[0].n_nodes == trees[1].n_nodes == 154
+    assert np.array_equal(trees[0].vertices, trees[1].vertices)
+    assert np.array_equal(trees[0].left, trees[1].left)
+    assert np.array_equal(trees[0].delta_idx, trees[1].delta_idx)
+    assert rel(trees[0].vertex_costs, trees[1].vertex_costs) < 1e-9
 
 
 def test_point_oracles(cwh):
@@ -183,9 +225,15 @@ def test_single_commutation_quadratic_engine(kind, abs_frac, eps_r):
     cpu = PartitionCPU(OracleCPU(mpc, eps_a, eps_r))
     cpu.run(roots, locs, 'ecc')
     gp = engine.GpuProblem(mpc.compile(), eps_a, eps_r)
-    flat = gp.partition(np.array(roots), action='ecc')
-    gp.close()
-    compare_trees(flat, cpu.nodes, locs)
     total = np.prod(2 * examples.theta_box(mpc))
-    assert abs(flat.info['volume_closed'] - total) <= 1e-9 * total
-    assert min(cpu.min_margin, flat.info['min_margin']) > 1e-6
+    flats = []
+    for gen, full in ((2, 0), (2, 1), (1, 1)):     # shared-block (sign-only / full), one-wavefront
+        gp.set_solver(gen)
+        gp.set_option('decide_full', full)
+        flat = gp.partition(np.array(roots), action='ecc')
+        compare_trees(flat, cpu.nodes, locs)
+        assert abs(flat.info['volume_closed'] - total) <= 1e-9 * total
+        assert min(cpu.min_margin, flat.info['min_margin']) > 1e-6
+        flats.append(flat)
+    gp.close()
+    assert flats[0].info['decide_iters'] < flats[1].info['decide_iters']
