@@ -88,7 +88,7 @@ class Progress(ctypes.Structure):
 class Counters(ctypes.Structure):
     _fields_ = [('lp_solves', ctypes.c_int64), ('ipm_iters', ctypes.c_int64),
                 ('kernel_launches', ctypes.c_int64), ('stalled', ctypes.c_int64),
-                ('fallbacks', ctypes.c_int64)]
+                ('fallbacks', ctypes.c_int64), ('slivers', ctypes.c_int64)]
 
 
 _lib = None

@@ -472,6 +472,7 @@ struct ehm_problem {
     DevCounters* d_cnt = nullptr;
     long long launches = 0;
     long long fallbacks = 0;   // LPs handed from the generation-2 to the generation-1 kernels
+    long long slivers = 0;     // (simplex, commutation) pairs dropped as interior-free (slack_all)
     int num_cu = 256;
     size_t lds_point = 0, lds_simplex = 0, lds_expand = 0;
 };
@@ -908,6 +909,7 @@ int ehm_stats(ehm_problem* P, ehm_counters* out) {
     out->stalled = (int64_t)c.stalled;
     out->kernel_launches = P->launches;
     out->fallbacks = P->fallbacks;
+    out->slivers = P->slivers;
     return EHM_OK;
 }
 
@@ -1033,6 +1035,7 @@ int ehm_solve_ptd_batch(ehm_problem* P, int64_t n_inst, const double* theta,
 // feasibility margin: the phase-one optimum is compared against a tolerance that is far
 // above the solver accuracy (1e-10 relative) and far below any constraint scale
 #define EHM_FEAS_TOL 1e-8
+#define EHM_SLIVER_TOL 1e-7
 // optimal values of different commutations closer than this (relative to 1+|value|) are
 // ties, broken by enumeration order (DESIGN.md "canonical commutation rule")
 #define EHM_TIE_TOL 1e-6
@@ -1362,6 +1365,7 @@ static int slack_all(ehm_problem* P, int64_t n_inst, const double* R, const doub
     }
     tall.assign((size_t)(n_inst * nd), -INFINITY);
     if (alpha_all) alpha_all->assign((size_t)(n_inst * nd) * nv, 0.0);
+    std::vector<double> tau_sel;      // phase-one optimum of every pair that stays selected
     if (nd > 1) {
         // drop pairs whose commutation is infeasible on the whole simplex
         int rc = simplex_batch(P, F, R2.data(), nullptr, di.data(), SX_FEAS, obj.data(), nullptr,
@@ -1380,6 +1384,7 @@ static int slack_all(ehm_problem* P, int64_t n_inst, const double* R, const doub
             std::memcpy(&V3[(size_t)g * nv], &V2[(size_t)f * nv], nv * sizeof(double));
             di3[(size_t)g] = di[(size_t)f];
             sel3[(size_t)g] = sel[(size_t)f];
+            tau_sel.push_back(obj[(size_t)f]);
         }
         R2.swap(R3); V2.swap(V3); di.swap(di3); sel.swap(sel3);
         F = F2;
@@ -1391,9 +1396,29 @@ static int slack_all(ehm_problem* P, int64_t n_inst, const double* R, const doub
                            al.data(), st.data());
     if (rc) return rc;
     for (int64_t f = 0; f < F; ++f) {
-        if (st[(size_t)f] != 0)
+        if (st[(size_t)f] != 0 && !tau_sel.empty() && tau_sel[(size_t)f] > -EHM_SLIVER_TOL) {
+            // the commutation is feasible on the simplex only within the accuracy of the
+            // phase-one optimum (|tau*| <= 1e-8 .. 1e-7 in row units): its feasible set has no
+            // interior an interior-point method could work in.  It is treated as infeasible
+            // there, which is also the verdict of a simplex-type solver for tau* > 0
+            // (the CPU oracle: HiGHS at 1e-10); counted in ehm_counters.slivers
+            P->slivers++;
+            continue;
+        }
+        if (st[(size_t)f] != 0) {
+            if (const char* path = getenv("EHM_DUMP_FAIL")) {     // debugging aid: the instance
+                if (FILE* fp = fopen(path, "w")) {
+                    fprintf(fp, "%d %d %.17g\n", (int)(sel[(size_t)f] % nd), p, obj[(size_t)f]);
+                    for (size_t q = 0; q < nR; ++q) fprintf(fp, "%.17g ", R2[(size_t)f * nR + q]);
+                    fprintf(fp, "\n");
+                    for (int q = 0; q < nv; ++q) fprintf(fp, "%.17g ", V2[(size_t)f * nv + q]);
+                    fprintf(fp, "\n%.17g %.17g\n", P->dp.eps_a, P->dp.eps_r);
+                    fclose(fp);
+                }
+            }
             return fail(EHM_E_NUMERIC, "slack LP (instance %lld, commutation %d) did not converge",
                         (long long)(sel[(size_t)f] / nd), (int)(sel[(size_t)f] % nd));
+        }
         tall[(size_t)sel[(size_t)f]] = obj[(size_t)f];
         if (alpha_all)
             std::memcpy(&(*alpha_all)[(size_t)sel[(size_t)f] * nv], &al[(size_t)f * nv],

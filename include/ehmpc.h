@@ -301,6 +301,9 @@ typedef struct ehm_counters {
     int64_t kernel_launches;
     int64_t stalled;
     int64_t fallbacks;      /* batch LPs the generation-2 kernels handed to generation 1 */
+    int64_t slivers;        /* (simplex, commutation) pairs of the mixed-integer oracles whose
+                               phase-one optimum is within 1e-7 of zero AND whose slack problem
+                               found no interior: treated as infeasible on that simplex */
 } ehm_counters;
 int ehm_stats(ehm_problem* prob, ehm_counters* out);
 

@@ -237,3 +237,33 @@ def test_single_commutation_quadratic_engine(kind, abs_frac, eps_r):
         flats.append(flat)
     gp.close()
     assert flats[0].info['decide_iters'] < flats[1].info['decide_iters']
+
+
+def test_interior_free_commutation_is_treated_as_infeasible():
+    """
+    A (simplex, commutation) pair met at depth 20 of the reference's fourth cwh_z job
+    (abs_frac 0.03, rel_err 0.05): the commutation misses the simplex by 2.6e-9 (phase-one
+    optimum +2.6e-9, inside the 1e-8 acceptance band of the interior-point phase one), so its
+    suboptimality-test QCQP has no interior.  HiGHS (the CPU oracle) calls it infeasible; the
+    device must reach the same verdict instead of failing, and count it.
+    """
+    from explicit_hybrid_mpc_amd import examples
+    from explicit_hybrid_mpc_amd.oracle import Oracle
+    from oracle.oracle_cpu import OracleCPU
+    from oracle.satellite_cpu import SatelliteZCPU
+    R = np.array([[-0.086132812500000003, -3.7109375000000019e-05],
+                  [-0.086230468750000011, 4.5898437499999993e-05],
+                  [-0.086328125000000006, -0.00012109375000000003]])
+    Vb = np.array([0.017875426469081447, 0.013115481891411354, 0.024392896780160721])
+    eps_a, eps_r = 0.00021779367304239681, 0.05
+    cpu = OracleCPU(SatelliteZCPU(4), eps_a, eps_r)
+    d = 28
+    assert cpu.sequences[d] == (1, 0, 0, 1)
+    assert cpu.slack(R, Vb, d)[0] == -np.inf               # infeasible on the whole simplex
+    gpu = Oracle(examples.satellite_z(4), eps_a, eps_r)
+    s0 = gpu.gpu.stats()
+    closed_g = gpu.bar_E_delta_R(R, Vb)
+    s1 = gpu.gpu.stats()
+    gpu.close()
+    assert closed_g == cpu.bar_E_delta_R(R, Vb)
+    assert s1['slivers'] - s0['slivers'] >= 1
