@@ -480,7 +480,8 @@ struct ehm_problem {
 struct ehm_tree {
     ehm_problem* prob = nullptr;
     DevTree dt{};
-    long long cap = 0;
+    long long cap = 0;       // allocated node records (a cached pool may be larger than asked for)
+    long long limit = 0;     // max_nodes of this run: the capacity the caller agreed to
     DevBuf rec, left, didx, depth, flags, tstar;
     ehm_tree_info info{};
     int skip_volume = 0;
@@ -1707,6 +1708,7 @@ int ehm_partition_begin(ehm_problem* P, int64_t n_roots, const double* root_vert
     T->skip_volume = opts ? opts->skip_volume : 0;
     int rc = tree_alloc(T, P, cap);
     if (rc) { ehm_tree_destroy(T); return rc; }
+    T->limit = cap;
 #define RUN_TRY(expr)                          \
     do {                                       \
         int rc_ = (expr);                      \
@@ -1790,6 +1792,16 @@ int ehm_partition_begin(ehm_problem* P, int64_t n_roots, const double* root_vert
         }
         P->launches++;
         R.ref_solves += n_roots * (2 + (p + 1));   // P_theta check + V_R MICP + vertex solves
+        // the reference stops a run whose Theta is not feasible everywhere (barycentre check,
+        // lib/worker.py:264-266); with one commutation a root vertex without a feasible point
+        // is that condition -- report it now instead of growing a tree on garbage costs
+        DevCounters cv;
+        RUN_TRY(read_counters(P, cv));
+        if (cv.errors != 0)
+            RUN_TRY(fail(EHM_E_INFEASIBLE,
+                         "STOP, Theta contains infeasible regions (%llu of %lld root-vertex "
+                         "solves found no feasible point)",
+                         (unsigned long long)cv.errors, (long long)(n_roots * (p + 1))));
     }
     *out = T;
     return EHM_OK;
@@ -1882,9 +1894,9 @@ int ehm_partition_step(ehm_tree* T, int32_t max_sweeps, int64_t* frontier_size) 
             R.truncated = 1;
             break;
         }
-        if (R.n_nodes + 2LL * n_open > T->cap)
+        if (R.n_nodes + 2LL * n_open > T->limit)
             return fail(EHM_E_CAPACITY, "node pool exhausted at %lld nodes (max_nodes=%lld)",
-                        R.n_nodes, T->cap);
+                        R.n_nodes, T->limit);
         // next frontier buffer must hold 2*n_open ids
         DevBuf& nb = R.cur_is_a ? fr_b : fr_a;
         if ((long long)nb.cap < 2LL * n_open * 4) {
@@ -1960,9 +1972,9 @@ int ehm_partition_give(ehm_tree* T, int64_t count, const double* records, const 
     auto& R = T->run;
     if (first_id) *first_id = (int32_t)R.n_nodes;
     if (count == 0) return EHM_OK;
-    if (R.n_nodes + count > T->cap)
+    if (R.n_nodes + count > T->limit)
         return fail(EHM_E_CAPACITY, "node pool exhausted at %lld nodes (max_nodes=%lld)",
-                    R.n_nodes, T->cap);
+                    R.n_nodes, T->limit);
     HIP_TRY(hipSetDevice(P->device), EHM_E_HIP);
     const int nrec = rec_doubles(P->dp.p, P->dp.n_u);
     int rc;

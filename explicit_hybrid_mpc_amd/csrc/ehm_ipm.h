@@ -419,7 +419,16 @@ __device__ inline IpmResult ipm_solve(const LpWork& w, const double (&b)[EHM_SLO
         if (w.quad) pobj += w.kap0 * (0.5 * xQx + qx + w.v0);
         const double e_g = w.quad ? sl_tot / (1.0 + fabs(pobj))
                                   : fabs(pobj - dobj) / (1.0 + fabs(pobj));
-        const double merit = fmax(emax / EHM_TOL_RES, e_g / EHM_TOL_GAP);
+        double merit = fmax(emax / EHM_TOL_RES, e_g / EHM_TOL_GAP);
+        // fmax / wave_max drop NaNs: a non-finite input (parameter, vertex, cost) would pass
+        // as "converged".  NaN in x, s or lambda always reaches one of these two sums.
+        if (!(mu == mu) || !(pobj == pobj) || fabs(pobj) > 1e300) {
+            res.merit = 1e300;
+            res.obj = pobj;
+            res.status = 1;
+            res.iters = it;
+            break;
+        }
         if (merit < res.merit) {
             res.merit = merit;
             res.obj = pobj;

@@ -1004,6 +1004,15 @@ __device__ inline IpmResult ipm_solve(const Shared& S, const Wave& W, const doub
         const double e_g = fabs(pobj - dobj) / (1.0 + fabs(pobj));
 #endif
         const double merit = fmax(emax / const_d(EHM2_TOL_RES), e_g / const_d(EHM2_TOL_GAP));
+        // fmax / wave_max drop NaNs: a non-finite input (parameter, vertex, cost) would pass
+        // as "converged".  NaN in x, s or lambda always reaches one of these two sums.
+        if (!(mu == mu) || !(pobj == pobj) || fabs(pobj) > const_d(1e300)) {
+            res.merit = const_d(1e300);
+            res.obj = pobj;
+            res.status = 1;
+            res.iters = it;
+            break;
+        }
         if (merit < res.merit) {
             res.merit = uniform_d(merit);
             res.obj = uniform_d(pobj);

@@ -785,6 +785,14 @@ __device__ __forceinline__ IpmResult ipm_solve(const Lp& L, Block& B, const doub
         const double pobj = sm[2];
         const double e_g = fabs(pobj - dobj) / (1.0 + fabs(pobj));
         const double merit = fmax(emax / EHM3_TOL_RES, e_g / EHM3_TOL_GAP);
+        // fmax drops NaNs: a non-finite input would pass as "converged" (see ehm_ipm2.h)
+        if (!(mu == mu) || !(pobj == pobj) || fabs(pobj) > 1e300) {
+            res.merit = 1e300;
+            res.obj = pobj;
+            res.status = 1;
+            res.iters = it;
+            break;
+        }
         if (merit < res.merit) {
             res.merit = merit;
             res.obj = pobj;
