@@ -72,6 +72,34 @@ def flatten_tree(root):
     return vertices, vinput, np.array(left, dtype=np.int32), np.array(right, dtype=np.int32), nodes
 
 
+class ImplicitMPC:
+    """
+    The implicit law of lib/mpc_library.py:626-660 (same constructor and call signature): one
+    mixed-integer oracle solve ``P_theta(x)`` per call, i.e. on the device one batched launch
+    over the commutations.  ``evaluate`` is the batched form.
+    """
+
+    def __init__(self, oracle):
+        mpc = oracle.mpc
+        self.plant = getattr(mpc, 'plant', None)
+        self.T_s = getattr(mpc, 'T_s', None)
+        if hasattr(mpc, 'specs'):
+            self.specs = mpc.specs
+        self.__oracle = oracle
+
+    def __call__(self, x):
+        """(u, t): epsilon-suboptimal (here: optimal) input and evaluation time."""
+        u, _, _, t = self.__oracle.P_theta(x)
+        return u, t
+
+    def evaluate(self, X):
+        """Inputs for a batch of states (n, p) -> (n, n_u); NaN rows where infeasible."""
+        J, u0, didx = self.__oracle.gpu.solve_pt(np.asarray(X, dtype=np.float64))
+        u0 = u0.copy()
+        u0[didx < 0] = np.nan
+        return u0
+
+
 class ExplicitMPC:
     """GPU counterpart of lib/mpc_library.py:662-792 (same constructor and call signature)."""
 

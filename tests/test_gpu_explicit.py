@@ -60,3 +60,63 @@ def test_explicit_evaluation_matches_reference_walk():
     assert nested.get_containing_cell(X[40]) is nested.nodes[leaf_n[40]].data
     nested.close()
     forest.close()
+
+
+def _interpolated_cost(flat, leaf, X):
+    """sum_i alpha_i V_i at X in the leaves `leaf` of a FlatTree (barycentric weights)."""
+    R = flat.vertices[leaf]                                  # (n, p+1, p)
+    E = np.transpose(R[:, 1:] - R[:, :1], (0, 2, 1))         # columns v_q - v_0
+    beta = np.linalg.solve(E, (X - R[:, 0])[:, :, None])[:, :, 0]
+    alpha = np.concatenate([1. - beta.sum(axis=1, keepdims=True), beta], axis=1)
+    return np.sum(alpha * flat.vertex_costs[leaf], axis=1), alpha
+
+
+@pytest.mark.parametrize('kind', ['lin', 'lin_quadratic', 'cwh_z'])
+def test_partition_delivers_the_epsilon_suboptimality_guarantee(kind):
+    """
+    The property the whole path exists for, checked end to end on the device at sizes no CPU
+    oracle can follow: a leaf is closed iff NO point of it has BOTH  Vbar - V* >= eps_a  and
+    Vbar - V* >= eps_r V*  (lib/oracle.py:89-97), so everywhere in the partitioned set
+        0 <= Vbar(x) - V*(x) < max(eps_a, eps_r V*(x)),
+    Vbar = the leaf's interpolated vertex costs (what ExplicitMPC interpolates the inputs
+    with, lib/mpc_library.py:769-792), V* = the implicit law's optimal cost ``P_theta(x)``
+    (lib/mpc_library.py:643-660).  Partition engine, point location and the mixed-integer
+    oracle all have to be right for this to hold at every sampled state.
+    """
+    from explicit_hybrid_mpc_amd import examples, explicit, partition
+    if kind == 'cwh_z':
+        full_set, _, orc = examples.example('cwh_z', abs_frac=0.1, rel_err=0.1)
+        n_min = 5000
+    else:
+        mpc = examples.linear_mpc(0, cost='quadratic' if kind == 'lin_quadratic' else 'inf')
+        full_set = examples.box_vertices(examples.theta_box(mpc))
+        af, er = (0.1, 0.1) if kind == 'lin_quadratic' else (0.04, 0.01)
+        orc = examples.create_oracle(mpc, full_set, abs_frac=af, abs_err=None, rel_err=er)
+        n_min = 50000
+    from explicit_hybrid_mpc_amd import tools as ehm_tools
+    roots, _ = ehm_tools.delaunay_roots(full_set)
+    flat = partition.run_engine(orc, roots, action='ecc', max_nodes=1 << 22)
+    assert flat.n_nodes > n_min
+    law = explicit.ExplicitMPC(flat, orc)
+    rng = np.random.default_rng(9)
+    half = np.abs(full_set).max(axis=0)
+    X = rng.uniform(-1, 1, (100000, half.size)) * half * (1 - 1e-9)
+    u, leaf, visits, _ = law.evaluate(X, return_info=True)
+    law.close()
+    assert (flat.left[leaf] < 0).all() and (flat.flags[leaf] & 1).all()     # closed leaves
+    Vbar, alpha = _interpolated_cost(flat, leaf, X)
+    assert alpha.min() > -1e-7                                              # x is in its leaf
+    Vstar, _, didx = orc.gpu.solve_pt(X)
+    assert (didx >= 0).all()
+    gap = Vbar - Vstar
+    tol = 1e-7 * (1 + np.abs(Vstar))
+    assert (gap >= -tol).all()
+    bound = np.maximum(orc.eps_a, orc.eps_r * Vstar)
+    assert (gap <= bound + tol).all()
+    # the guarantee is tight somewhere: the partition is not needlessly fine
+    assert (gap > 0.3 * bound).any()
+    # the implicit law through its reference interface agrees with the batch
+    imp = explicit.ImplicitMPC(orc)
+    u1, t1 = imp(X[7])
+    assert np.allclose(u1, imp.evaluate(X[7:8])[0], rtol=1e-9, atol=1e-12) and t1 >= 0
+    orc.close()
