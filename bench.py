@@ -115,6 +115,9 @@ def main():
     ap.add_argument('--cpu-seconds', type=float, default=15.)
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--solver', type=int, default=2, help='kernel generation (1 or 2)')
+    ap.add_argument('--engine', type=int, default=1,
+                    help='1 = persistent frontier kernel (one launch per partition; single rank, '
+                         'shared-block kernels), 0 = level-synchronous sweeps')
     ap.add_argument('--decide-full', action='store_true',
                     help='solve the suboptimality-test LPs to full accuracy (no sign-only stop)')
     args = ap.parse_args()
@@ -147,7 +150,10 @@ def main():
     if not wide:
         gp.set_solver(args.solver)
     gp.set_option('decide_full', 1 if args.decide_full else 0)
-    kname = 'k3_lcss_decide' if wide else ('k2_lcss_decide' if args.solver == 2
+    persistent = (args.engine == 1 and world == 1 and args.solver == 2 and not wide and
+                  not args.status_dir)
+    kname = 'k3_lcss_decide' if wide else ('k2_persist' if persistent else
+                                           'k2_lcss_decide' if args.solver == 2
                                            else 'k_lcss_decide')
     pmc_file = 'pmc_summary_wide.json' if wide else 'pmc_summary_bench.json'
     half = examples.theta_box(mpc)
@@ -174,7 +180,7 @@ def main():
     def step():
         if world == 1 and not args.status_dir:
             return gp.partition(roots, action='ecc', max_nodes=args.max_nodes, export=False,
-                                shard=shard, with_volume=False)
+                                shard=shard, with_volume=False, engine=args.engine)
         info, log, rounds = distributed.run_balanced(
             gp, roots, action='ecc', max_nodes=args.max_nodes,
             min_frontier=args.shard_min_frontier, sweeps_per_round=args.sweeps_per_round,
@@ -224,12 +230,17 @@ def main():
         n_pt, m_pt = can.n, can.m
         decide_flops = agg['decide_iters'] * flops_per_iteration(n_slack, m_slack)
         expand_flops = (agg['ipm_iters'] - agg['decide_iters']) * flops_per_iteration(n_pt, m_pt)
-        # dominant kernel = the suboptimality-test sweep (k_lcss_decide)
-        achieved = decide_flops / decide_s / 1e12
         B = node_bytes(can.p, can.n_u, can.deltas.shape[1])
         closed, nodes = agg['n_closed'], agg['n_nodes']
         splits = (nodes - K * world * len(roots)) / 2. if world == 1 else None
-        hbm_alg = agg['decide_solves'] * (B + 8)          # decide: read record, write verdict
+        if persistent:
+            # ONE kernel per partition: suboptimality tests AND splits / midpoint solves
+            achieved = (decide_flops + expand_flops) / decide_s / 1e12
+            hbm_alg = agg['decide_solves'] * (B + 8) + splits * (B + 2 * B + 16)
+        else:
+            # dominant kernel = the suboptimality-test sweep (k_lcss_decide)
+            achieved = decide_flops / decide_s / 1e12
+            hbm_alg = agg['decide_solves'] * (B + 8)      # decide: read record, write verdict
         out = {
             'metric': 'oracle LP solves/sec + final regions/sec, 4-state 2-input N=5 hybrid MPC',
             'value': agg['lp_solves'] / elapsed_max,
@@ -262,6 +273,8 @@ def main():
                 'kernels': 'wide (one workgroup per LP, MFMA normal matrix)' if wide else
                            'generation %d%s' % (args.solver, ' with the quadratic block' if quad
                                                 else ''),
+                'engine': 'persistent frontier kernel (one launch per partition)' if persistent
+                          else 'level-synchronous sweeps',
                 'suboptimality_test': 'full accuracy' if (args.decide_full or args.solver == 1) else
                                       'sign-only stop (lower bound of |t*| recorded)',
                 'parallelism': 'frontier dealt round-robin over %d GPU(s)' % world +
@@ -277,6 +290,9 @@ def main():
                 'bound': 'mfma', 'kernel': kname,
                 'note': ('normal matrix on v_mfma_f64_16x16x4_f64 (57 columns = 4 tiles); peak = '
                          'FP64 matrix = vector peak of MI355X' if wide else
+                         'one launch holds the slack LPs (n=%d m=%d) and the midpoint LPs (n=%d '
+                         'm=%d); FP64 vector FMA bound; peak = FP64 vector = matrix peak of MI355X'
+                         % (n_slack, m_slack, n_pt, m_pt) if persistent else
                          'FP64 vector FMA bound (no f64 contraction >= 32 wide at n=25); peak = '
                          'FP64 vector = matrix peak of MI355X'),
                 'achieved': achieved, 'peak': FP64_PEAK_TFLOPS, 'unit': 'TFLOP/s',
@@ -286,7 +302,8 @@ def main():
                 'algorithmic_bytes_per_launch': hbm_alg / max(info0['decide_launches'] * K, 1),
                 'flop_per_ipm_iteration': flops_per_iteration(n_slack, m_slack),
                 'kernel_seconds': decide_s, 'launches': info0['decide_launches'] * K,
-                'expand_kernel': {'achieved': expand_flops / max(expand_s, 1e-12) / 1e12,
+                'expand_kernel': None if persistent else
+                                 {'achieved': expand_flops / max(expand_s, 1e-12) / 1e12,
                                   'kernel_seconds': expand_s},
                 'hbm': {'achieved': hbm_alg / decide_s / 1e9, 'peak': HBM_PEAK_GBS,
                         'unit': 'GB/s', 'frac': hbm_alg / decide_s / 1e9 / HBM_PEAK_GBS,

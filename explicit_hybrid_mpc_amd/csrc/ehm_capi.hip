@@ -468,6 +468,7 @@ struct ehm_problem {
         DevBuf rec, left, didx, depth, flags, tstar;
     } pool_cache;
     DevBuf fr_a, fr_b, open_flag, open_list, d_count;
+    DevBuf pq_slots, pq_ctl;   // persistent engine: queue slots, control block
     DevBuf in0, in1, in2, out0, out1, out2, out3;
     DevCounters* d_cnt = nullptr;
     long long launches = 0;
@@ -485,10 +486,14 @@ struct ehm_tree {
     DevBuf rec, left, didx, depth, flags, tstar;
     ehm_tree_info info{};
     int skip_volume = 0;
+    // persistent engine: node ids follow the allocation order; the export relabels them to the
+    // breadth-first order of the level-synchronous engine (perm[new id] = device id)
+    bool unordered = false;
+    std::vector<int32_t> perm;
     // state of a run in progress (ehm_partition_begin .. ehm_partition_finish)
     struct Run {
         bool active = false;
-        int max_depth = 0, action = 0, shard_world = 1, shard_rank = 0;
+        int max_depth = 0, action = 0, shard_world = 1, shard_rank = 0, engine = 0;
         long long shard_min = 0;
         bool sharded = true, cur_is_a = true;
         long long n_roots = 0, n_nodes = 0, nf = 0, n_closed = 0, ref_solves = 0;
@@ -772,6 +777,7 @@ int ehm_problem_destroy(ehm_problem* P) {
     P->pool_cache.depth.release(); P->pool_cache.flags.release(); P->pool_cache.tstar.release();
     P->fr_a.release(); P->fr_b.release(); P->open_flag.release(); P->open_list.release();
     P->d_count.release();
+    P->pq_slots.release(); P->pq_ctl.release();
     P->in0.release(); P->in1.release(); P->in2.release();
     P->out0.release(); P->out1.release(); P->out2.release(); P->out3.release();
     if (P->d_cnt) (void)hipFree(P->d_cnt);
@@ -1696,6 +1702,8 @@ int ehm_partition_begin(ehm_problem* P, int64_t n_roots, const double* root_vert
     R.active = true;
     R.max_depth = (opts && opts->max_depth > 0) ? opts->max_depth : 0;
     R.action = opts ? opts->action : 0;
+    R.engine = opts ? opts->engine : 0;
+    if (const char* e = getenv("EHM_ENGINE")) R.engine = atoi(e);
     R.shard_world = (opts && opts->shard_world > 1) ? opts->shard_world : 1;
     R.shard_rank = opts ? opts->shard_rank : 0;
     R.shard_min = opts ? opts->shard_min_frontier : 0;
@@ -1808,12 +1816,77 @@ int ehm_partition_begin(ehm_problem* P, int64_t n_roots, const double* root_vert
 #undef RUN_TRY
 }
 
+// engine = 1: the whole run in ONE launch of the persistent frontier kernel (ehm_k2.hip,
+// k2_persist).  Single rank, shared-block kernels only; anything else uses the sweeps.
+static int persistent_run(ehm_tree* T) {
+    ehm_problem* P = T->prob;
+    auto& R = T->run;
+    K2Cfg cfg;
+    int rc = k2_config(P, LP_SLACK, LP_POINT, 1LL << 40, cfg);    // the full persistent grid
+    if (rc) return rc;
+    if (!cfg.api->persist) return fail(EHM_E_INVALID, "no persistent kernel for this LP size");
+    const long long waves = (long long)cfg.L.grid * (cfg.L.threads / 64);
+    const long long n_slots = T->limit + waves + 64;
+    if (n_slots > 0x7fffffffLL || T->limit > 0x7fffffffLL)
+        return fail(EHM_E_INVALID, "node pool too large for the persistent engine");
+    if ((rc = P->pq_slots.ensure((size_t)n_slots * 4))) return rc;
+    if ((rc = P->pq_ctl.ensure(sizeof(PersistCtl)))) return rc;
+    int32_t* slots = P->pq_slots.as<int32_t>();
+    HIP_TRY(hipMemsetAsync(slots, 0xFF, (size_t)n_slots * 4, P->stream), EHM_E_HIP);
+    const int32_t* cur = (R.cur_is_a ? P->fr_a : P->fr_b).as<int32_t>();
+    HIP_TRY(hipMemcpyAsync(slots, cur, (size_t)R.nf * 4, hipMemcpyDeviceToDevice, P->stream),
+            EHM_E_HIP);
+    PersistCtl h{};
+    h.head = 0;
+    h.tail = (int)R.nf;
+    h.pending = (int)R.nf;
+    h.n_nodes = (int)R.n_nodes;
+    HIP_TRY(hipMemcpyAsync(P->pq_ctl.ptr, &h, sizeof h, hipMemcpyHostToDevice, P->stream),
+            EHM_E_HIP);
+    hipEvent_t e0, e1;
+    (void)hipEventCreate(&e0);
+    (void)hipEventCreate(&e1);
+    (void)hipEventRecord(e0, P->stream);
+    cfg.api->persist(cfg.L, P->dp, T->dt, slots, (int)n_slots, P->pq_ctl.as<PersistCtl>(),
+                     (int)T->limit, P->d_cnt, P->decide_full ? 0 : 1, R.max_depth);
+    (void)hipEventRecord(e1, P->stream);
+    R.evs.push_back(e0);
+    R.evs.push_back(e1);
+    R.ev_kind.push_back(0);
+    P->launches++;
+    HIP_TRY(hipGetLastError(), EHM_E_HIP);
+    HIP_TRY(hipMemcpyAsync(&h, P->pq_ctl.ptr, sizeof h, hipMemcpyDeviceToHost, P->stream),
+            EHM_E_HIP);
+    HIP_TRY(hipStreamSynchronize(P->stream), EHM_E_HIP);
+    if (h.abort == 1)
+        return fail(EHM_E_CAPACITY, "node pool exhausted at %d nodes (max_nodes=%lld)",
+                    h.n_nodes, T->limit);
+    if (h.abort != 0 || h.pending != 0)
+        return fail(EHM_E_HIP, "persistent frontier kernel stopped early (abort=%d, pending=%d)",
+                    h.abort, h.pending);
+    R.ref_solves += (long long)h.closed + 3LL * (long long)h.splits;
+    R.n_closed += (long long)h.closed;
+    R.n_nodes = h.n_nodes;
+    R.truncated = h.truncated;
+    R.depth = h.max_depth_seen;
+    R.sweeps = h.max_depth_seen + 1;
+    R.nf = 0;
+    T->unordered = true;
+    return EHM_OK;
+}
+
 // Runs up to max_sweeps frontier sweeps (<= 0: until the frontier is empty).
 int ehm_partition_step(ehm_tree* T, int32_t max_sweeps, int64_t* frontier_size) {
     if (!T || !T->run.active) return fail(EHM_E_INVALID, "no partition run in progress");
     ehm_problem* P = T->prob;
     auto& R = T->run;
     HIP_TRY(hipSetDevice(P->device), EHM_E_HIP);
+    if (R.engine == 1 && P->solver_gen == 2 && R.shard_world == 1 && max_sweeps <= 0 &&
+        R.nf > 0 && !P->dp.Wr3) {
+        int rc = persistent_run(T);
+        if (frontier_size) *frontier_size = 0;
+        return rc;
+    }
     DevBuf &fr_a = P->fr_a, &fr_b = P->fr_b, &open_flag = P->open_flag,
            &open_list = P->open_list, &d_count = P->d_count;
     auto stamp = [&]() {
@@ -2170,11 +2243,37 @@ int ehm_tree_export(const ehm_tree* Tc, double* vertices, int32_t* left, int32_t
     const long long n = T->info.n_nodes;
     const int p = P->dp.p, n_u = P->dp.n_u, stride = T->dt.rec_stride;
     const int nR = (p + 1) * p;
+    std::vector<int32_t> inv;
+    if (T->unordered) {
+        // breadth-first relabelling = the numbering of the level-synchronous engine: roots in
+        // order, then per level the two children of every split node in parent order
+        std::vector<int32_t> l((size_t)n);
+        HIP_TRY(hipMemcpy(l.data(), T->dt.left, (size_t)n * 4, hipMemcpyDeviceToHost), EHM_E_HIP);
+        if (T->perm.empty()) {
+            T->perm.reserve((size_t)n);
+            for (int32_t k = 0; k < (int32_t)T->info.n_roots; ++k) T->perm.push_back(k);
+            for (size_t h = 0; h < T->perm.size(); ++h) {
+                const int32_t c = l[(size_t)T->perm[h]];
+                if (c >= 0) {
+                    T->perm.push_back(c);
+                    T->perm.push_back(c + 1);
+                }
+            }
+            if ((long long)T->perm.size() != n)
+                return fail(EHM_E_HIP, "tree structure inconsistent (%zu of %lld nodes reachable)",
+                            T->perm.size(), n);
+        }
+        inv.assign((size_t)n, -1);
+        for (long long k = 0; k < n; ++k) inv[(size_t)T->perm[(size_t)k]] = (int32_t)k;
+    }
+    auto src = [&](long long k) -> size_t {
+        return T->unordered ? (size_t)T->perm[(size_t)k] : (size_t)k;
+    };
     if (vertices || vcost || vinput) {
         std::vector<double> rec((size_t)n * stride);
         HIP_TRY(hipMemcpy(rec.data(), T->dt.rec, rec.size() * 8, hipMemcpyDeviceToHost), EHM_E_HIP);
         for (long long k = 0; k < n; ++k) {
-            const double* r = rec.data() + (size_t)k * stride;
+            const double* r = rec.data() + src(k) * stride;
             if (vertices) std::memcpy(vertices + (size_t)k * nR, r, nR * 8);
             if (vcost) std::memcpy(vcost + (size_t)k * (p + 1), r + rec_off_vcost(p), (p + 1) * 8);
             if (vinput)
@@ -2186,15 +2285,38 @@ int ehm_tree_export(const ehm_tree* Tc, double* vertices, int32_t* left, int32_t
         std::vector<int32_t> l((size_t)n);
         HIP_TRY(hipMemcpy(l.data(), T->dt.left, (size_t)n * 4, hipMemcpyDeviceToHost), EHM_E_HIP);
         for (long long k = 0; k < n; ++k) {
-            if (left) left[k] = l[(size_t)k];
-            if (right) right[k] = l[(size_t)k] < 0 ? -1 : l[(size_t)k] + 1;
+            int32_t c = l[src(k)];
+            if (c >= 0 && T->unordered) c = inv[(size_t)c];
+            if (left) left[k] = c;
+            if (right) right[k] = c < 0 ? -1 : c + 1;
         }
     }
-    if (delta_idx)
-        HIP_TRY(hipMemcpy(delta_idx, T->dt.didx, (size_t)n * 4, hipMemcpyDeviceToHost), EHM_E_HIP);
-    if (flags) HIP_TRY(hipMemcpy(flags, T->dt.flags, (size_t)n, hipMemcpyDeviceToHost), EHM_E_HIP);
-    if (tstar)
-        HIP_TRY(hipMemcpy(tstar, T->dt.tstar, (size_t)n * 8, hipMemcpyDeviceToHost), EHM_E_HIP);
+    if (!T->unordered) {
+        if (delta_idx)
+            HIP_TRY(hipMemcpy(delta_idx, T->dt.didx, (size_t)n * 4, hipMemcpyDeviceToHost),
+                    EHM_E_HIP);
+        if (flags)
+            HIP_TRY(hipMemcpy(flags, T->dt.flags, (size_t)n, hipMemcpyDeviceToHost), EHM_E_HIP);
+        if (tstar)
+            HIP_TRY(hipMemcpy(tstar, T->dt.tstar, (size_t)n * 8, hipMemcpyDeviceToHost),
+                    EHM_E_HIP);
+        return EHM_OK;
+    }
+    if (delta_idx) {
+        std::vector<int32_t> t((size_t)n);
+        HIP_TRY(hipMemcpy(t.data(), T->dt.didx, (size_t)n * 4, hipMemcpyDeviceToHost), EHM_E_HIP);
+        for (long long k = 0; k < n; ++k) delta_idx[k] = t[src(k)];
+    }
+    if (flags) {
+        std::vector<uint8_t> t((size_t)n);
+        HIP_TRY(hipMemcpy(t.data(), T->dt.flags, (size_t)n, hipMemcpyDeviceToHost), EHM_E_HIP);
+        for (long long k = 0; k < n; ++k) flags[k] = t[src(k)];
+    }
+    if (tstar) {
+        std::vector<double> t((size_t)n);
+        HIP_TRY(hipMemcpy(t.data(), T->dt.tstar, (size_t)n * 8, hipMemcpyDeviceToHost), EHM_E_HIP);
+        for (long long k = 0; k < n; ++k) tstar[k] = t[src(k)];
+    }
     return EHM_OK;
 }
 

@@ -33,6 +33,20 @@ __host__ __device__ inline int lp_slots(int m, int ne) {
     return (lp_xbase(m, ne) + ne + 63) >> 6;
 }
 
+// Control block of the persistent frontier kernel (device memory, agent-scope atomics).
+struct PersistCtl {
+    int head;           // next queue slot to pop
+    int tail;           // next queue slot to push
+    int pending;        // nodes pushed and not yet completed; 0 = the partition is finished
+    int n_nodes;        // node pool allocation counter
+    int abort;          // 0 ok, 1 node pool exhausted, 3 watchdog
+    int max_depth_seen;
+    int truncated;      // some open node was left unsplit at max_depth
+    int pad;
+    unsigned long long closed;      // closed leaves
+    unsigned long long splits;      // expanded nodes
+};
+
 struct K2Launch {
     int grid;
     int threads;        // 64 * wavefronts per workgroup
@@ -62,6 +76,9 @@ struct K2Api {
     void (*vertex)(const K2Launch&, DevProblem, DevTree, const int32_t* nodes, int n_nodes,
                    DevCounters*);
     void (*selftest)(hipStream_t, double* out);
+    // persistent frontier kernel (ehm_k2.hip: k2_persist); null where not compiled (wide)
+    void (*persist)(const K2Launch&, DevProblem, DevTree, int32_t* slots, int n_slots,
+                    PersistCtl* ctl, int node_cap, DevCounters*, int sign_only, int max_depth);
 };
 
 }  // namespace ehm

@@ -553,6 +553,194 @@ __global__ __launch_bounds__(EHM_K2_THREADS) void k2_lcss_expand(
     }
 }
 
+
+// ---- persistent frontier kernel ------------------------------------------------------------
+// One launch grows the whole partition: every wavefront pops node ids from a global queue,
+// runs the suboptimality test (lib/worker.py:368-375) and, if the node stays open, at once the
+// split + midpoint solve + child construction (lib/worker.py:403-414, 354-365), allocates the
+// two child records from the node pool and pushes them.  No sweep barriers: subtrees progress
+// independently, the narrow top and bottom levels of the tree overlap with the bulk, and the
+// workgroup's copy of the constant LP block stays in LDS for the whole run.
+//   * queue slot k is written once (-1 = not yet): a consumer that drew a slot ahead of the
+//     tail waits for it (s_sleep) or leaves when `pending` (nodes pushed, not yet completed)
+//     reaches 0.  Producers never wait for consumers, and a waiting wavefront holds nothing
+//     another one needs, so the kernel cannot deadlock whatever the residency of the grid;
+//   * child records are published with a device-scope release (fence, then the slot store);
+//     the consumer fences after reading the slot (MI355X: one L2 per XCD);
+//   * node ids follow the allocation order and differ from run to run; the TREE does not
+//     (a node's fate depends on its own record only).  ehm_tree_export relabels to the
+//     breadth-first order of the level-synchronous engine.
+#define EHM_PERSIST_WATCHDOG_TICKS (60LL * 100000000LL)    // 60 s of the 100 MHz wall clock
+__global__ __launch_bounds__(EHM_K2_THREADS) void k2_persist(
+    DevProblem P, DevTree T, int32_t* slots, int n_slots, PersistCtl* ctl, int node_cap,
+    DevCounters* cnt, int wave_doubles, int sign_only, int max_depth) {
+    K2_PROLOGUE();
+    const int p = P.p, n_u = P.n_u;
+    const int nrec = rec_doubles(p, n_u);
+    load_shared(P, 0, sm, tid, blockDim.x);
+    __syncthreads();
+    const long long t_start = wall_clock64();
+    for (;;) {
+        int id = -1;
+        if (lane0 == 0) {
+            const int idx = atomicAdd(&ctl->head, 1);
+            if (idx < n_slots) {
+                for (;;) {
+                    id = __hip_atomic_load(&slots[idx], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    if (id >= 0) break;
+                    if (__hip_atomic_load(&ctl->pending, __ATOMIC_RELAXED,
+                                          __HIP_MEMORY_SCOPE_AGENT) <= 0 ||
+                        __hip_atomic_load(&ctl->abort, __ATOMIC_RELAXED,
+                                          __HIP_MEMORY_SCOPE_AGENT) != 0)
+                        break;
+                    if (wall_clock64() - t_start > EHM_PERSIST_WATCHDOG_TICKS) {
+                        atomicMax(&ctl->abort, 3);
+                        break;
+                    }
+                    __builtin_amdgcn_s_sleep(64);
+                }
+            }
+        }
+        id = __builtin_amdgcn_readfirstlane(id);
+        if (id < 0) break;
+        __threadfence();        // acquire: the record behind the slot is visible
+        const int lane = pin(lane0);
+        const double* rec = T.rec + (size_t)id * T.rec_stride;
+        double* node = nb.rec;
+        for (int k = lane; k < nrec; k += 64)
+            node[k] = __builtin_nontemporal_load(rec + k);
+        wsync();
+        // ---- suboptimality test --------------------------------------------------------------
+        Wave W;
+        IpmResult r;
+        int its = 0;
+        for (int attempt = 0; attempt < EHM2_ATTEMPTS; ++attempt) {
+            double b[SLOTS];
+            const int ln = pin(lane);
+            assemble_simplex(S, W, nb, node, node + rec_off_vcost(p), SX_SLACK, P.eps_a, P.eps_r,
+                             b, ln, P, 0);
+            r = ipm_solve(S, W, b, ln, sign_only != 0, step_fraction(attempt));
+            its += r.iters;
+            if (r.status == 0) break;
+        }
+        r.iters = its;
+        count_solve(cnt, r, lane);
+        const double tst = -r.obj;
+        const bool open = (tst >= 0.0);
+        const int dep = T.depth[id];
+        if (lane == 0) {
+            if (r.status != 0) {
+                atomicAdd(&cnt->errors, 1ULL);
+                T.flags[id] |= 8;
+            }
+            atomicAdd(&cnt->slack_solves, 1ULL);
+            atomicAdd(&cnt->slack_iters, (unsigned long long)r.iters);
+            T.tstar[id] = tst;
+            if (!open) T.flags[id] |= 1;
+            atomicMin(&cnt->min_margin_bits, (unsigned long long)__double_as_longlong(r.margin));
+            atomicMax(&ctl->max_depth_seen, dep);
+        }
+        if (!open) {
+            if (lane == 0) {
+                atomicAdd(&ctl->closed, 1ULL);
+                atomicSub(&ctl->pending, 1);
+            }
+            wsync();
+            continue;
+        }
+        if (max_depth > 0 && dep >= max_depth) {
+            if (lane == 0) {
+                atomicMax(&ctl->truncated, 1);
+                atomicSub(&ctl->pending, 1);
+            }
+            wsync();
+            continue;
+        }
+        // ---- split, midpoint solve, children -------------------------------------------------
+        int c0 = 0;
+        if (lane == 0) c0 = atomicAdd(&ctl->n_nodes, 2);
+        c0 = __builtin_amdgcn_readfirstlane(c0);
+        if (c0 + 2 > node_cap) {
+            if (lane == 0) {
+                atomicMax(&ctl->abort, 1);
+                atomicSub(&ctl->pending, 1);
+            }
+            break;
+        }
+        double* mid = nb.th;
+        int bi, bj;
+        longest_edge(node, p, bi, bj);
+        if (lane < p) {
+#pragma clang fp contract(off)
+            mid[lane] = (node[bi * p + lane] + node[bj * p + lane]) / 2.0;
+        }
+        wsync();
+        const int d = T.didx[id];
+        its = 0;
+        for (int attempt = 0; attempt < EHM2_ATTEMPTS; ++attempt) {
+            double b[SLOTS];
+            const int ln = pin(lane);
+            assemble_point(S, W, nb.lp, mid, false, b, ln, P, 0);
+            r = ipm_solve(S, W, b, ln, false, step_fraction(attempt));
+            its += r.iters;
+            if (r.status == 0) break;
+        }
+        r.iters = its;
+        count_solve(cnt, r, lane);
+        if (r.status != 0 && lane == 0) {
+            atomicAdd(&cnt->errors, 1ULL);
+            T.flags[id] |= 16;
+        }
+        double* rec0 = T.rec + (size_t)c0 * T.rec_stride;
+        double* rec1 = rec0 + T.rec_stride;
+        const int ov = rec_off_vcost(p), ou = rec_off_vinput(p);
+        for (int k = lane; k < nrec; k += 64) {
+            double v0 = node[k], v1 = node[k];
+            if (k < ov) {
+                if (k >= bi * p && k < bi * p + p) v0 = mid[k - bi * p];
+                if (k >= bj * p && k < bj * p + p) v1 = mid[k - bj * p];
+            } else if (k < ou) {
+                if (k - ov == bi) v0 = r.obj;
+                if (k - ov == bj) v1 = r.obj;
+            } else {
+                const int q = k - ou;
+                if (q >= bi * n_u && q < bi * n_u + n_u) v0 = W.xb[q - bi * n_u];
+                if (q >= bj * n_u && q < bj * n_u + n_u) v1 = W.xb[q - bj * n_u];
+            }
+            rec0[k] = v0;
+            rec1[k] = v1;
+        }
+        if (lane == 0) {
+            T.left[id] = c0;
+            T.left[c0] = -1;
+            T.left[c0 + 1] = -1;
+            T.didx[c0] = d;
+            T.didx[c0 + 1] = d;
+            T.depth[c0] = dep + 1;
+            T.depth[c0 + 1] = dep + 1;
+            T.flags[c0] = 2;
+            T.flags[c0 + 1] = 2;
+            T.tstar[c0] = 0.0;
+            T.tstar[c0 + 1] = 0.0;
+        }
+        __threadfence();        // release: records and structure before the queue slots
+        if (lane == 0) {
+            const int t = atomicAdd(&ctl->tail, 2);
+            if (t + 2 <= n_slots) {
+                __hip_atomic_store(&slots[t], c0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                __hip_atomic_store(&slots[t + 1], c0 + 1, __ATOMIC_RELAXED,
+                                   __HIP_MEMORY_SCOPE_AGENT);
+                atomicAdd(&ctl->splits, 1ULL);
+                atomicAdd(&ctl->pending, 1);       // -1 (this node) + 2 (its children)
+            } else {
+                atomicMax(&ctl->abort, 1);
+                atomicSub(&ctl->pending, 1);
+            }
+        }
+        wsync();
+    }
+}
+
 // ---- vertex solves that seed a node's costs / inputs (lib/oracle.py:416-443) ---------------
 __global__ __launch_bounds__(EHM_K2_THREADS) void k2_vertex_solve(
     DevProblem P, DevTree T, const int32_t* __restrict__ nodes, int n_nodes, DevCounters* cnt,
@@ -619,7 +807,7 @@ using namespace EHM2_NS;
 hipError_t set_lds(int bytes) {
     const void* ks[] = {(const void*)k2_point_batch, (const void*)k2_simplex_batch,
                         (const void*)k2_lcss_decide, (const void*)k2_lcss_expand,
-                        (const void*)k2_vertex_solve};
+                        (const void*)k2_vertex_solve, (const void*)k2_persist};
     for (const void* k : ks) {
         hipError_t e = hipFuncSetAttribute(k, hipFuncAttributeMaxDynamicSharedMemorySize, bytes);
         if (e != hipSuccess) return e;
@@ -660,13 +848,18 @@ void l_vertex(const K2Launch& L, DevProblem P, DevTree T, const int32_t* nodes, 
     hipLaunchKernelGGL(k2_vertex_solve, dim3(L.grid), dim3(L.threads), L.lds_bytes, L.stream, P,
                        T, nodes, n_nodes, cnt, L.wave_doubles);
 }
+void l_persist(const K2Launch& L, DevProblem P, DevTree T, int32_t* slots, int n_slots,
+               PersistCtl* ctl, int node_cap, DevCounters* cnt, int sign_only, int max_depth) {
+    hipLaunchKernelGGL(k2_persist, dim3(L.grid), dim3(L.threads), L.lds_bytes, L.stream, P, T,
+                       slots, n_slots, ctl, node_cap, cnt, L.wave_doubles, sign_only, max_depth);
+}
 void l_selftest(hipStream_t stream, double* out) {
     hipLaunchKernelGGL(k2_selftest, dim3(1), dim3(64), 0, stream, out);
 }
 
 const K2Api g_api = {EHM_NP,   EHM_SLOTS,        EHM_K2_THREADS,     64,      set_lds,
                      wave_doubles_for, shared_doubles_for, l_point, l_simplex, l_decide,
-                     l_expand, l_vertex,         l_selftest};
+                     l_expand, l_vertex,         l_selftest,     l_persist};
 
 }  // namespace
 

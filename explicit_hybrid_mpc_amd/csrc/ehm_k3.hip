@@ -489,7 +489,7 @@ void l_selftest(hipStream_t stream, double* out) {
 // np = 64 columns; slots in units of 64 rows; one LP per workgroup of 256 threads
 const K2Api g_api = {NW,      4 * EHM3_RS, EHM3_THREADS, EHM3_THREADS, set_lds,  unit_doubles_for,
                      shared_doubles_for, l_point,   l_simplex,    l_decide,     l_expand,
-                     l_vertex, l_selftest};
+                     l_vertex, l_selftest, nullptr};
 
 }  // namespace
 

@@ -221,10 +221,15 @@ class GpuProblem:
         return didx, ths, vJ, vu, vs.astype(bool)
 
     # -- partition ------------------------------------------------------------------------------
-    def partition(self, roots, action='ecc', init=None, max_nodes=0, max_depth=0, engine=0,
+    def partition(self, roots, action='ecc', init=None, max_nodes=0, max_depth=0, engine=1,
                   export=True, shard=None, with_volume=True, status=None, status_sweeps=1):
         """
         Grow every root simplex until all leaves are epsilon-suboptimal.
+        engine: 1 (default) = one launch of the persistent frontier kernel where it applies (a
+        single rank running to completion on the shared-block kernels; the export relabels the
+        nodes to the breadth-first numbering), 0 = level-synchronous sweeps.  Sharded runs,
+        runs advanced sweep by sweep (``status``, ``begin``/``step``), the one-wavefront and the
+        wide kernels always sweep.
         roots: (n_roots, p+1, p).  init: optional dict(delta, vertex_costs, vertex_inputs)
         for action 'lcss'.  shard = (rank, world, min_frontier) keeps only this rank's share
         of the frontier once it is min_frontier wide (multi-GPU).  Returns a FlatTree, or

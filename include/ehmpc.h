@@ -173,7 +173,14 @@ typedef struct ehm_run_opts {
     int64_t max_nodes;      /* node pool capacity (0 = default)                          */
     int32_t max_depth;      /* stop splitting below this depth relative to roots (0 = none) */
     int32_t action;         /* 0 = 'ecc' then 'lcss' (lib/worker.py:241-291), 1 = 'lcss'   */
-    int32_t engine;         /* 0 = level-synchronous sweeps, 1 = persistent frontier kernel */
+    int32_t engine;         /* 0 = level-synchronous sweeps (decide / scan / expand launches per
+                             * tree level); 1 = persistent frontier kernel: ONE launch, every
+                             * wavefront pops nodes from a device queue, tests them and pushes
+                             * the children of the ones it splits -- used when the run goes to
+                             * completion on one rank with the shared-block kernels, otherwise
+                             * the sweeps run.  Node ids in device memory then follow the
+                             * allocation order; ehm_tree_export relabels them breadth first,
+                             * i.e. to the numbering of engine 0 (same tree either way). */
     /* Multi-GPU sharding of the live frontier: every rank grows the same top of the tree
      * until a sweep's frontier holds >= shard_min_frontier nodes, then keeps only the
      * frontier nodes whose position k satisfies k % shard_world == shard_rank (the rest are

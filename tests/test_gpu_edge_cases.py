@@ -117,15 +117,16 @@ def test_capacity_and_depth_limits(lin):
     gp.set_eps(eps_a, 0.05)
     full = gp.partition(roots, action='ecc')
     assert full.info['truncated'] == 0 and full.n_nodes > 1500
-    with pytest.raises(EhmError) as e:
-        gp.partition(roots, action='ecc', max_nodes=1000)
-    assert e.value.code == EHM_E_CAPACITY
-    cut = gp.partition(roots, action='ecc', max_depth=3)
-    assert cut.info['truncated'] == 1 and cut.info['max_depth'] <= 3
-    assert cut.n_nodes < full.n_nodes
-    # what was grown is the top of the full tree
-    n = cut.n_nodes
-    assert np.array_equal(cut.vertices, full.vertices[:n])
+    for eng in (1, 0):      # persistent frontier kernel / level-synchronous sweeps
+        with pytest.raises(EhmError) as e:
+            gp.partition(roots, action='ecc', max_nodes=1000, engine=eng)
+        assert e.value.code == EHM_E_CAPACITY
+        cut = gp.partition(roots, action='ecc', max_depth=3, engine=eng)
+        assert cut.info['truncated'] == 1 and cut.info['max_depth'] <= 3
+        assert cut.n_nodes < full.n_nodes
+        # what was grown is the top of the full tree
+        n = cut.n_nodes
+        assert np.array_equal(cut.vertices, full.vertices[:n])
     gp.set_eps(0.05, 0.1)
 
 

@@ -87,10 +87,12 @@ def test_partition_identical_across_generations_and_decide_modes(abs_frac):
     gp.set_eps(eps_a, 1e-2)
     roots, _ = ehm_tools.delaunay_roots(V)
     trees = []
-    for gen, full in ((1, 1), (2, 1), (2, 0)):
+    for gen, full, eng in ((1, 1, 0), (2, 1, 0), (2, 0, 0), (2, 0, 1)):
+        # the last one: everything in ONE launch of the persistent frontier kernel, whose
+        # midpoint LPs run in the wider (suboptimality-test) instance -- a fourth arithmetic
         gp.set_solver(gen)
         gp.set_option('decide_full', full)
-        trees.append(gp.partition(roots, action='ecc', max_nodes=1 << 22))
+        trees.append(gp.partition(roots, action='ecc', max_nodes=1 << 22, engine=eng))
     gp.close()
     ref = trees[0]
     if abs_frac == 0.02:
@@ -104,6 +106,7 @@ def test_partition_identical_across_generations_and_decide_modes(abs_frac):
         assert np.array_equal(t.flags & 1, ref.flags & 1)        # same closed leaves
         assert rel(t.vertex_costs.ravel(), ref.vertex_costs.ravel()) < RTOL
         assert abs(t.info['volume_closed'] - ref.info['volume_closed']) < 1e-9
+    assert trees[3].info['decide_launches'] == 1
     full, sign = trees[1], trees[2]
     assert rel(full.tstar, ref.tstar) < 1e-6
     # the sign-only stop records a lower bound of |t*| and needs fewer iterations

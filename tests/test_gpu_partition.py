@@ -43,13 +43,21 @@ def test_tree_identical_to_cpu_partition(kind, seed, abs_frac, eps_r, decide_ful
     cpu.run(roots, locs, 'ecc')
     gp = engine.GpuProblem(mpc.compile(), eps_a, eps_r)
     gp.set_option('decide_full', decide_full)
-    flat = gp.partition(np.array(roots), action='ecc')
-    gp.close()
-    compare_trees(flat, cpu.nodes, locs)
     total = np.prod(2 * examples.theta_box(mpc))
-    assert abs(flat.info['volume_closed'] - total) <= 1e-9 * total
-    assert flat.info['min_margin'] > 1e-6
-    assert min(cpu.min_margin, flat.info['min_margin']) > 1e-6
+    flats = []
+    for eng in (1, 0):      # persistent frontier kernel / level-synchronous sweeps
+        flat = gp.partition(np.array(roots), action='ecc', engine=eng)
+        compare_trees(flat, cpu.nodes, locs)
+        assert abs(flat.info['volume_closed'] - total) <= 1e-9 * total
+        assert flat.info['min_margin'] > 1e-6
+        assert min(cpu.min_margin, flat.info['min_margin']) > 1e-6
+        flats.append(flat)
+    gp.close()
+    # the export of the persistent engine is relabelled to the sweeps' breadth-first numbering
+    assert np.array_equal(flats[0].left, flats[1].left)
+    assert np.array_equal(flats[0].vertices, flats[1].vertices)
+    assert flats[0].info['sweeps'] == flats[1].info['sweeps']
+    assert flats[0].info['decide_launches'] == 1 < flats[1].info['decide_launches']
 
 
 def test_status_publisher_follows_the_run(tmp_path):
