@@ -12,13 +12,18 @@
 #define EHM_K2_THREADS 768
 #endif
 
+#define K2_AUG_MIN 16
+
 namespace ehm {
 
 // per-wave scratch in front of the LP workspace (doubles): node record, Gauss-Jordan
 // tableau (p x 2p), inverse (p x p), parameter (<= 8)
 __host__ __device__ inline size_t k2_node_doubles(int p, int n_u) {
     const size_t nrec = ((size_t)rec_doubles(p, n_u) + 7) & ~(size_t)7;
-    return (nrec + 3 * (size_t)p * p + 8 + 1) & ~(size_t)1;
+    // the middle block (2 p^2, at least K2_AUG_MIN doubles) also holds the per-wavefront
+    // statistics of the persistent frontier kernel
+    const size_t aug = (2 * (size_t)p * p > K2_AUG_MIN) ? 2 * (size_t)p * p : K2_AUG_MIN;
+    return (nrec + aug + (size_t)p * p + 8 + 1) & ~(size_t)1;
 }
 
 // Row layout of an LP with m MPC rows and ne extra rows: MPC row i sits at (lane i%64,
@@ -33,18 +38,24 @@ __host__ __device__ inline int lp_slots(int m, int ne) {
     return (lp_xbase(m, ne) + ne + 63) >> 6;
 }
 
-// Control block of the persistent frontier kernel (device memory, agent-scope atomics).
+// Control block of the persistent frontier kernel (device memory, agent-scope atomics).  The
+// four words every node touches sit on cache lines of their own: device-scope atomics on one
+// line are serviced one after the other, and at >10 M nodes/s that line is the bottleneck.
 struct PersistCtl {
     int head;           // next queue slot to pop
+    int pad0[31];
     int tail;           // next queue slot to push
+    int pad1[31];
     int pending;        // nodes pushed and not yet completed; 0 = the partition is finished
+    int pad2[31];
     int n_nodes;        // node pool allocation counter
+    int pad3[31];
     int abort;          // 0 ok, 1 node pool exhausted, 3 watchdog
     int max_depth_seen;
     int truncated;      // some open node was left unsplit at max_depth
-    int pad;
-    unsigned long long closed;      // closed leaves
-    unsigned long long splits;      // expanded nodes
+    int pad4;
+    unsigned long long closed;      // closed leaves      } accumulated per wavefront,
+    unsigned long long splits;      // expanded nodes     } added once when it leaves
 };
 
 struct K2Launch {

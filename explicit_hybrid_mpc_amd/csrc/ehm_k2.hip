@@ -27,7 +27,7 @@ __device__ __forceinline__ void carve_node(NodeBuf& nb, double* base, int p, int
     const int nrec = (rec_doubles(p, n_u) + 7) & ~7;
     nb.rec = base;
     nb.aug = base + nrec;
-    nb.F = nb.aug + 2 * p * p;
+    nb.F = nb.aug + ((2 * p * p > K2_AUG_MIN) ? 2 * p * p : K2_AUG_MIN);
     nb.th = nb.F + p * p;
     nb.lp = base + k2_node_doubles(p, n_u);
 }
@@ -565,8 +565,11 @@ __global__ __launch_bounds__(EHM_K2_THREADS) void k2_lcss_expand(
 //     tail waits for it (s_sleep) or leaves when `pending` (nodes pushed, not yet completed)
 //     reaches 0.  Producers never wait for consumers, and a waiting wavefront holds nothing
 //     another one needs, so the kernel cannot deadlock whatever the residency of the grid;
-//   * child records are published with a device-scope release (fence, then the slot store);
-//     the consumer fences after reading the slot (MI355X: one L2 per XCD);
+//   * MI355X has one L2 per XCD: child records and structure words are written through to the
+//     device coherence point (agent-scope atomic stores), the wavefront waits for them to
+//     complete, then stores the queue slots; the consumer reads the slot with an agent-scope
+//     atomic load and invalidates its L1 / non-local L2 lines (acquire fence) before reading
+//     the record.  No L2 write-back anywhere;
 //   * node ids follow the allocation order and differ from run to run; the TREE does not
 //     (a node's fate depends on its own record only).  ehm_tree_export relabels to the
 //     breadth-first order of the level-synchronous engine.
@@ -580,6 +583,16 @@ __global__ __launch_bounds__(EHM_K2_THREADS) void k2_persist(
     load_shared(P, 0, sm, tid, blockDim.x);
     __syncthreads();
     const long long t_start = wall_clock64();
+    // statistics are kept per wavefront (in LDS: registers are what this kernel is short of) and
+    // added to the global counters ONCE, when it leaves -- the level-synchronous kernels pay ~8
+    // device atomics per node for them
+    unsigned long long* wst = reinterpret_cast<unsigned long long*>(nb.aug);
+    double* wmargin = nb.aug + 12;
+    enum { W_SOLVES = 0, W_ITERS, W_STALLED, W_ERRORS, W_SLACK, W_SLACK_ITERS, W_CLOSED, W_SPLITS,
+           W_DEPTH, W_TRUNC };
+    if (lane0 < 12) wst[lane0] = 0ULL;
+    if (lane0 == 0) *wmargin = 1e300;
+    wsync();
     for (;;) {
         int id = -1;
         if (lane0 == 0) {
@@ -603,12 +616,12 @@ __global__ __launch_bounds__(EHM_K2_THREADS) void k2_persist(
         }
         id = __builtin_amdgcn_readfirstlane(id);
         if (id < 0) break;
-        __threadfence();        // acquire: the record behind the slot is visible
+        // acquire (L1 / non-local L2 invalidate): the record behind the slot is visible
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
         const int lane = pin(lane0);
         const double* rec = T.rec + (size_t)id * T.rec_stride;
         double* node = nb.rec;
-        for (int k = lane; k < nrec; k += 64)
-            node[k] = __builtin_nontemporal_load(rec + k);
+        for (int k = lane; k < nrec; k += 64) node[k] = rec[k];
         wsync();
         // ---- suboptimality test --------------------------------------------------------------
         Wave W;
@@ -624,33 +637,35 @@ __global__ __launch_bounds__(EHM_K2_THREADS) void k2_persist(
             if (r.status == 0) break;
         }
         r.iters = its;
-        count_solve(cnt, r, lane);
         const double tst = -r.obj;
         const bool open = (tst >= 0.0);
         const int dep = T.depth[id];
         if (lane == 0) {
+            wst[W_SOLVES] += 1;
+            wst[W_ITERS] += (unsigned long long)r.iters;
+            wst[W_SLACK] += 1;
+            wst[W_SLACK_ITERS] += (unsigned long long)r.iters;
             if (r.status != 0) {
-                atomicAdd(&cnt->errors, 1ULL);
+                wst[W_STALLED] += 1;
+                wst[W_ERRORS] += 1;
                 T.flags[id] |= 8;
             }
-            atomicAdd(&cnt->slack_solves, 1ULL);
-            atomicAdd(&cnt->slack_iters, (unsigned long long)r.iters);
+            *wmargin = fmin(*wmargin, r.margin);
+            if ((unsigned long long)dep > wst[W_DEPTH]) wst[W_DEPTH] = (unsigned long long)dep;
             T.tstar[id] = tst;
-            if (!open) T.flags[id] |= 1;
-            atomicMin(&cnt->min_margin_bits, (unsigned long long)__double_as_longlong(r.margin));
-            atomicMax(&ctl->max_depth_seen, dep);
+            if (!open) {
+                T.flags[id] |= 1;
+                wst[W_CLOSED] += 1;
+            }
         }
         if (!open) {
-            if (lane == 0) {
-                atomicAdd(&ctl->closed, 1ULL);
-                atomicSub(&ctl->pending, 1);
-            }
+            if (lane == 0) atomicSub(&ctl->pending, 1);
             wsync();
             continue;
         }
         if (max_depth > 0 && dep >= max_depth) {
             if (lane == 0) {
-                atomicMax(&ctl->truncated, 1);
+                wst[W_TRUNC] = 1;
                 atomicSub(&ctl->pending, 1);
             }
             wsync();
@@ -686,10 +701,15 @@ __global__ __launch_bounds__(EHM_K2_THREADS) void k2_persist(
             if (r.status == 0) break;
         }
         r.iters = its;
-        count_solve(cnt, r, lane);
-        if (r.status != 0 && lane == 0) {
-            atomicAdd(&cnt->errors, 1ULL);
-            T.flags[id] |= 16;
+        if (lane == 0) {
+            wst[W_SOLVES] += 1;
+            wst[W_ITERS] += (unsigned long long)r.iters;
+            wst[W_SPLITS] += 1;
+            if (r.status != 0) {
+                wst[W_STALLED] += 1;
+                wst[W_ERRORS] += 1;
+                T.flags[id] |= 16;
+            }
         }
         double* rec0 = T.rec + (size_t)c0 * T.rec_stride;
         double* rec1 = rec0 + T.rec_stride;
@@ -707,30 +727,38 @@ __global__ __launch_bounds__(EHM_K2_THREADS) void k2_persist(
                 if (q >= bi * n_u && q < bi * n_u + n_u) v0 = W.xb[q - bi * n_u];
                 if (q >= bj * n_u && q < bj * n_u + n_u) v1 = W.xb[q - bj * n_u];
             }
-            rec0[k] = v0;
-            rec1[k] = v1;
+            // everything a child's consumer reads or later overwrites is written THROUGH to the
+            // device coherence point (agent-scope atomic stores): visible to the other XCDs
+            // without writing this XCD's whole L2 back (a device-scope release fence would --
+            // measured: 47 GB of write-backs per partition, mostly register spills), and no
+            // dirty copy stays behind that could later clobber the consumer's own writes
+            __hip_atomic_store(rec0 + k, v0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            __hip_atomic_store(rec1 + k, v1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         }
         if (lane == 0) {
             T.left[id] = c0;
-            T.left[c0] = -1;
-            T.left[c0 + 1] = -1;
-            T.didx[c0] = d;
-            T.didx[c0 + 1] = d;
-            T.depth[c0] = dep + 1;
-            T.depth[c0 + 1] = dep + 1;
-            T.flags[c0] = 2;
-            T.flags[c0 + 1] = 2;
-            T.tstar[c0] = 0.0;
-            T.tstar[c0 + 1] = 0.0;
+#define EHM_WT(ptr, val) __hip_atomic_store((ptr), (val), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)
+            EHM_WT(&T.left[c0], -1);
+            EHM_WT(&T.left[c0 + 1], -1);
+            EHM_WT(&T.didx[c0], d);
+            EHM_WT(&T.didx[c0 + 1], d);
+            EHM_WT(&T.depth[c0], dep + 1);
+            EHM_WT(&T.depth[c0 + 1], dep + 1);
+            EHM_WT(&T.flags[c0], (uint8_t)2);
+            EHM_WT(&T.flags[c0 + 1], (uint8_t)2);
+            EHM_WT(&T.tstar[c0], 0.0);
+            EHM_WT(&T.tstar[c0 + 1], 0.0);
+#undef EHM_WT
         }
-        __threadfence();        // release: records and structure before the queue slots
+        // the write-through stores above have completed (s_waitcnt) before the slots go out
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+        __builtin_amdgcn_s_waitcnt(0);
         if (lane == 0) {
             const int t = atomicAdd(&ctl->tail, 2);
             if (t + 2 <= n_slots) {
                 __hip_atomic_store(&slots[t], c0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                 __hip_atomic_store(&slots[t + 1], c0 + 1, __ATOMIC_RELAXED,
                                    __HIP_MEMORY_SCOPE_AGENT);
-                atomicAdd(&ctl->splits, 1ULL);
                 atomicAdd(&ctl->pending, 1);       // -1 (this node) + 2 (its children)
             } else {
                 atomicMax(&ctl->abort, 1);
@@ -738,6 +766,20 @@ __global__ __launch_bounds__(EHM_K2_THREADS) void k2_persist(
             }
         }
         wsync();
+    }
+    wsync();
+    if (lane0 == 0) {
+        atomicAdd(&cnt->lp_solves, wst[W_SOLVES]);
+        atomicAdd(&cnt->ipm_iters, wst[W_ITERS]);
+        if (wst[W_STALLED]) atomicAdd(&cnt->stalled, wst[W_STALLED]);
+        if (wst[W_ERRORS]) atomicAdd(&cnt->errors, wst[W_ERRORS]);
+        atomicAdd(&cnt->slack_solves, wst[W_SLACK]);
+        atomicAdd(&cnt->slack_iters, wst[W_SLACK_ITERS]);
+        atomicMin(&cnt->min_margin_bits, (unsigned long long)__double_as_longlong(*wmargin));
+        atomicAdd(&ctl->closed, wst[W_CLOSED]);
+        atomicAdd(&ctl->splits, wst[W_SPLITS]);
+        atomicMax(&ctl->max_depth_seen, (int)wst[W_DEPTH]);
+        if (wst[W_TRUNC]) atomicMax(&ctl->truncated, 1);
     }
 }
 
