@@ -152,7 +152,10 @@ def main():
     gp.set_option('decide_full', 1 if args.decide_full else 0)
     persistent = (args.engine == 1 and world == 1 and args.solver == 2 and not wide and
                   not args.status_dir)
-    kname = 'k3_lcss_decide' if wide else ('k2_persist' if persistent else
+    # (the persistent kernel exists at one solver width, k2_persist, and -- where a pair of
+    # instances is compiled, as for this workload -- at two, kp_persist; the library picks)
+    kname = 'k3_lcss_decide' if wide else (('kp_persist' if not quad else 'k2_persist')
+                                           if persistent else
                                            'k2_lcss_decide' if args.solver == 2
                                            else 'k_lcss_decide')
     pmc_file = 'pmc_summary_wide.json' if wide else 'pmc_summary_bench.json'

@@ -21,12 +21,17 @@ LIB_DIR = os.path.join(HERE, 'lib')
 OBJ_DIR = os.path.join(LIB_DIR, 'obj')
 LIB = os.path.join(LIB_DIR, 'libehmpc.so')
 HEADERS = ['ehm_ipm.h', 'ehm_kernels.h', 'ehm_dev.h', 'ehm_k2.h', 'ehm_ipm2.h', 'ehm_ipm3.h',
+           'ehm_k2_asm.h',
            os.path.join('..', '..', 'include', 'ehmpc.h')]
 # must match EHM_K2_ALL in ehm_capi.hip
 K2_NPS = (8, 12, 16, 20, 24, 28, 32)
 K2_SLOTS = (1, 2, 3, 4)
 # instances with the quadratic block (-DEHM2_QUAD=1); must match EHM_K2Q_ALL in ehm_capi.hip
 K2Q_NPS = (8, 16, 24, 32)
+# persistent frontier kernel at two solver widths (ehm_kp.hip): (decide NP, expand NP, slots);
+# must match EHM_KP_ALL in ehm_capi.hip
+KP_INSTANCES = ((16, 8, 2), (16, 8, 3), (20, 12, 2), (20, 12, 3), (24, 16, 2), (24, 16, 3),
+                (28, 20, 2), (28, 20, 3), (32, 24, 2), (32, 24, 3), (32, 24, 4), (28, 20, 4))
 # wide kernels (ehm_k3.hip): row slots per thread, rows <= 256 * slots; must match the
 # ehm_k3_api_* getters in ehm_capi.hip
 K3_RS = (2, 4)
@@ -67,6 +72,10 @@ def _objects():
             objs.append((os.path.join(OBJ_DIR, 'ehm_k2q_%d_%d.o' % (np_, sl)),
                          os.path.join(SRC_DIR, 'ehm_k2.hip'),
                          ['-DEHM_NP=%d' % np_, '-DEHM_SLOTS=%d' % sl, '-DEHM2_QUAD=1']))
+    for npd, npe, sl in KP_INSTANCES:
+        objs.append((os.path.join(OBJ_DIR, 'ehm_kp_%d_%d_%d.o' % (npd, npe, sl)),
+                     os.path.join(SRC_DIR, 'ehm_kp.hip'),
+                     ['-DEHM_NPD=%d' % npd, '-DEHM_NPE=%d' % npe, '-DEHM_SLOTS=%d' % sl]))
     for rs in K3_RS:
         objs.append((os.path.join(OBJ_DIR, 'ehm_k3_%d.o' % rs),
                      os.path.join(SRC_DIR, 'ehm_k3.hip'),
@@ -85,7 +94,7 @@ def is_stale():
         return True
     t = os.path.getmtime(LIB)
     srcs = [os.path.join(SRC_DIR, f)
-            for f in ('ehm_capi.hip', 'ehm_k2.hip', 'ehm_k3.hip', 'ehm_explicit.hip')]
+            for f in ('ehm_capi.hip', 'ehm_k2.hip', 'ehm_k3.hip', 'ehm_kp.hip', 'ehm_explicit.hip')]
     return max([_dep_mtime()] + [os.path.getmtime(s) for s in srcs]) > t
 
 

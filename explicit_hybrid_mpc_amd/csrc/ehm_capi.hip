@@ -38,6 +38,14 @@ static const k2_getter g_k2_getters[] = {EHM_K2_ALL(EHM_K2_ENTRY) ehm_k3_api_2, 
 EHM_K2Q_ALL(EHM_K2Q_DECL)
 #define EHM_K2Q_ENTRY(NPV, SL) ehm_k2q_api_##NPV##_##SL,
 static const k2_getter g_k2q_getters[] = {EHM_K2Q_ALL(EHM_K2Q_ENTRY)};
+// persistent frontier kernel at two solver widths (ehm_kp.hip): (decide NP, expand NP, slots)
+#define EHM_KP_ALL(X) X(16, 8, 2) X(16, 8, 3) X(20, 12, 2) X(20, 12, 3) X(24, 16, 2) X(24, 16, 3) \
+    X(28, 20, 2) X(28, 20, 3) X(32, 24, 2) X(32, 24, 3) X(32, 24, 4) X(28, 20, 4)
+#define EHM_KP_DECL(D, E, SL) extern "C" const ehm::KpApi* ehm_kp_api_##D##_##E##_##SL();
+EHM_KP_ALL(EHM_KP_DECL)
+#define EHM_KP_ENTRY(D, E, SL) ehm_kp_api_##D##_##E##_##SL,
+typedef const ehm::KpApi* (*kp_getter)();
+static const kp_getter g_kp_getters[] = {EHM_KP_ALL(EHM_KP_ENTRY)};
 #define EHM_V1_MAX_N 32     // limits of the generation-1 and wave-local kernels
 #define EHM_V1_MAX_M 256
 
@@ -461,6 +469,7 @@ struct ehm_problem {
     int solver_gen = 2;      // 1 = one wavefront per workgroup (ehm_kernels.h), 2 = ehm_k2.hip
     DevBuf seg;              // commutation segment offsets of a sorted batch
     std::set<const K2Api*> k2_ready;
+    std::set<const KpApi*> kp_ready;
     // device memory kept between partition runs (hipMalloc/hipFree of a GB-sized node pool
     // cost milliseconds): the pool of the last destroyed tree and the frontier scratch
     struct PoolCache {
@@ -1825,6 +1834,44 @@ static int persistent_run(ehm_tree* T) {
     int rc = k2_config(P, LP_SLACK, LP_POINT, 1LL << 40, cfg);    // the full persistent grid
     if (rc) return rc;
     if (!cfg.api->persist) return fail(EHM_E_INVALID, "no persistent kernel for this LP size");
+    // two solver widths where a pair is compiled: the midpoint LPs have p + 1 columns less
+    const KpApi* kp = nullptr;
+    if (!P->quadratic && !getenv("EHM_NO_KP")) {
+        int n_d, ne_d, n_e, ne_e;
+        kind_dims(P->dp, LP_SLACK, n_d, ne_d);
+        kind_dims(P->dp, LP_POINT, n_e, ne_e);
+        const K2Api* ad = k2_pick(n_d, lp_slots(P->dp.m, ne_d), false);
+        const K2Api* ae = k2_pick(n_e, lp_slots(P->dp.m, ne_e), false);
+        const int slots = std::max(lp_slots(P->dp.m, ne_d), lp_slots(P->dp.m, ne_e));
+        if (ad && ae && ae->np < ad->np)
+            for (kp_getter g : g_kp_getters) {
+                const KpApi* a = g();
+                if (a->np_decide == ad->np && a->np_expand == ae->np && a->slots == slots) kp = a;
+            }
+        if (kp) {
+            const size_t shared = kp->shared_doubles(P->dp);
+            const size_t wave = kp->wave_doubles(P->dp, n_d, ne_d, n_e);
+            const size_t budget = EHM_LDS_BUDGET / sizeof(double);
+            long long nw = std::min<long long>(kp->max_threads / 64,
+                                               (long long)((budget - shared) / wave));
+            if (shared + wave > budget || nw < 1) {
+                kp = nullptr;
+            } else {
+                if (!P->kp_ready.count(kp)) {
+                    HIP_TRY(kp->set_lds(EHM_LDS_BUDGET), EHM_E_HIP);
+                    P->kp_ready.insert(kp);
+                }
+                const size_t lds = (shared + (size_t)nw * wave) * sizeof(double);
+                const long long reg_wg = (kp->max_threads / 64) / nw;
+                const long long wg_per_cu =
+                    std::max<long long>(1, std::min<long long>(EHM_LDS_BUDGET / lds, reg_wg));
+                cfg.L.grid = (int)((long long)P->num_cu * wg_per_cu);
+                cfg.L.threads = (int)(64 * nw);
+                cfg.L.lds_bytes = lds;
+                cfg.L.wave_doubles = (int)wave;
+            }
+        }
+    }
     const long long waves = (long long)cfg.L.grid * (cfg.L.threads / 64);
     const long long n_slots = T->limit + waves + 64;
     if (n_slots > 0x7fffffffLL || T->limit > 0x7fffffffLL)
@@ -1847,8 +1894,9 @@ static int persistent_run(ehm_tree* T) {
     (void)hipEventCreate(&e0);
     (void)hipEventCreate(&e1);
     (void)hipEventRecord(e0, P->stream);
-    cfg.api->persist(cfg.L, P->dp, T->dt, slots, (int)n_slots, P->pq_ctl.as<PersistCtl>(),
-                     (int)T->limit, P->d_cnt, P->decide_full ? 0 : 1, R.max_depth);
+    (kp ? kp->persist : cfg.api->persist)(cfg.L, P->dp, T->dt, slots, (int)n_slots,
+                                          P->pq_ctl.as<PersistCtl>(), (int)T->limit, P->d_cnt,
+                                          P->decide_full ? 0 : 1, R.max_depth);
     (void)hipEventRecord(e1, P->stream);
     R.evs.push_back(e0);
     R.evs.push_back(e1);

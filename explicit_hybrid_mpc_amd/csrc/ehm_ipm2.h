@@ -21,8 +21,7 @@
 //
 // Reference arithmetic replaced: the `Problem.solve(solver=MOSEK)` call sites of
 // lib/oracle.py:131,134,166,169,203,276,305,350.
-#pragma once
-
+// NO include guard: one inclusion per column capacity (see EHM2_NS below; ehm_kp.hip has two).
 #include "ehm_dev.h"
 
 #ifndef EHM_NP

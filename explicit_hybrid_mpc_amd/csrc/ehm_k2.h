@@ -92,4 +92,14 @@ struct K2Api {
                     PersistCtl* ctl, int node_cap, DevCounters*, int sign_only, int max_depth);
 };
 
+// The persistent frontier kernel compiled at two solver widths (ehm_kp.hip).
+struct KpApi {
+    int np_decide, np_expand, slots, max_threads;
+    hipError_t (*set_lds)(int bytes);
+    size_t (*wave_doubles)(const DevProblem& P, int n_lp_decide, int ne_decide, int n_lp_expand);
+    size_t (*shared_doubles)(const DevProblem& P);
+    void (*persist)(const K2Launch&, DevProblem, DevTree, int32_t* slots, int n_slots,
+                    PersistCtl* ctl, int node_cap, DevCounters*, int sign_only, int max_depth);
+};
+
 }  // namespace ehm

@@ -14,7 +14,7 @@ import sys
 
 
 def short(name):
-    m = re.search(r'(k[23]?_[a-z_]+)', name)
+    m = re.search(r'(k[23p]?_[a-z_]+)', name)
     return m.group(1) if m else name.split('(')[0]
 
 
