@@ -12,10 +12,12 @@ everything else (all frontier sweeps, LP solves, child construction).
     python bench.py --gpus N --steps K --warmup W
 
 prints ONE JSON line on rank 0.  For N > 1 it is launched by torch.distributed.run with
-one rank per GPU; the live frontier is dealt round-robin over the ranks once it is wide
-enough, and every few sweeps the ranks all-gather their frontier sizes and move node records
-from the longest frontiers to the shortest (explicit_hybrid_mpc_amd/distributed.py); the total
-work is fixed ("strong" scaling) and `value` is the whole-job LP-solve rate.
+one rank per GPU; every rank grows the same top of the tree until the frontier holds 1024
+nodes per rank, keeps the positions k % N == rank, and grows its share in one launch of the
+persistent frontier kernel -- no collective in the data path (`--balance static`, the default;
+`--balance dynamic` sweeps level by level and rebalances the frontiers with an all-gather of
+their sizes and point-to-point node transfers, explicit_hybrid_mpc_amd/distributed.py).  The
+total work is fixed ("strong" scaling) and `value` is the whole-job LP-solve rate.
 """
 
 import argparse
@@ -106,6 +108,13 @@ def main():
     ap.add_argument('--max-nodes', type=int, default=1 << 22)
     ap.add_argument('--shard-min-frontier', type=int, default=0,
                     help='frontier size at which it is dealt over the ranks (0 = 64 per rank)')
+    ap.add_argument('--balance', choices=['static', 'dynamic'], default='static',
+                    help='N > 1: static = the frontier is dealt round-robin once it holds 1024 '
+                         'nodes per rank and every rank grows its share in ONE launch of the '
+                         'persistent frontier kernel, no collective in the data path (measured '
+                         'load imbalance 1.04 at 8 shards); dynamic = level-synchronous sweeps '
+                         'with an all-gather of the frontier sizes and point-to-point node '
+                         'transfers every --sweeps-per-round sweeps')
     ap.add_argument('--sweeps-per-round', type=int, default=2,
                     help='frontier sweeps between two rebalancing rounds (N > 1)')
     ap.add_argument('--status-dir', default=None,
@@ -150,8 +159,9 @@ def main():
     if not wide:
         gp.set_solver(args.solver)
     gp.set_option('decide_full', 1 if args.decide_full else 0)
-    persistent = (args.engine == 1 and world == 1 and args.solver == 2 and not wide and
-                  not args.status_dir)
+    static = args.balance == 'static' and not args.status_dir
+    persistent = (args.engine == 1 and (world == 1 or static) and args.solver == 2 and
+                  not wide and not args.status_dir)
     # (the persistent kernel exists at one solver width, k2_persist, and -- where a pair of
     # instances is compiled, as for this workload -- at two, kp_persist; the library picks)
     kname = 'k3_lcss_decide' if wide else (('kp_persist' if not quad else 'k2_persist')
@@ -167,8 +177,10 @@ def main():
     gp.set_eps(eps_a, args.eps_r)
     roots, _ = ehm_tools.delaunay_roots(V)
     if args.shard_min_frontier <= 0:
-        # the top of the tree is latency-bound on any number of GPUs: deal early, rebalance often
-        args.shard_min_frontier = 64 * world
+        # static: deal late enough for the shares to even out (tools/shard_balance.py: max/mean
+        # 1.31 at 64 nodes per rank, 1.04 at 1024); dynamic: the top of the tree is latency-bound
+        # on any number of GPUs, deal early and rebalance often
+        args.shard_min_frontier = (1024 if static else 64) * world
     shard = distributed.shard_spec(rank, world, args.shard_min_frontier)
 
     xdev = ('cuda:%d' % device_index) if backend == 'nccl' else None
@@ -181,7 +193,7 @@ def main():
             os.path.join(args.status_dir, 'statistics.pkl'))
 
     def step():
-        if world == 1 and not args.status_dir:
+        if (world == 1 or static) and not args.status_dir:
             return gp.partition(roots, action='ecc', max_nodes=args.max_nodes, export=False,
                                 shard=shard, with_volume=False, engine=args.engine)
         info, log, rounds = distributed.run_balanced(
@@ -235,7 +247,7 @@ def main():
         expand_flops = (agg['ipm_iters'] - agg['decide_iters']) * flops_per_iteration(n_pt, m_pt)
         B = node_bytes(can.p, can.n_u, can.deltas.shape[1])
         closed, nodes = agg['n_closed'], agg['n_nodes']
-        splits = (nodes - K * world * len(roots)) / 2. if world == 1 else None
+        splits = (nodes - K * len(roots)) / 2.
         if persistent:
             # ONE kernel per partition: suboptimality tests AND splits / midpoint solves
             achieved = (decide_flops + expand_flops) / decide_s / 1e12
@@ -282,6 +294,9 @@ def main():
                                       'sign-only stop (lower bound of |t*| recorded)',
                 'parallelism': 'frontier dealt round-robin over %d GPU(s)' % world +
                                ('' if world == 1 else
+                                ' at %d nodes, every rank grows its share in one persistent '
+                                'launch (static; no data-path collective)' %
+                                args.shard_min_frontier if static else
                                 ', rebalanced every %d sweeps (all-gather of frontier sizes + '
                                 'point-to-point node records)' % args.sweeps_per_round),
                 'rebalance_rounds_per_step': float(mx[len(keys) + 4]) / K,

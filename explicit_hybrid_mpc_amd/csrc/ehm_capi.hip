@@ -1929,8 +1929,12 @@ int ehm_partition_step(ehm_tree* T, int32_t max_sweeps, int64_t* frontier_size) 
     ehm_problem* P = T->prob;
     auto& R = T->run;
     HIP_TRY(hipSetDevice(P->device), EHM_E_HIP);
-    if (R.engine == 1 && P->solver_gen == 2 && R.shard_world == 1 && max_sweeps <= 0 &&
-        R.nf > 0 && !P->dp.Wr3) {
+    // persistent frontier kernel: a run that goes to completion in this call.  A sharded run
+    // first sweeps until the frontier has been dealt over the ranks, then grows its share in
+    // one launch (static dealing: no rebalancing rounds, see distributed.py)
+    const bool want_persist = R.engine == 1 && P->solver_gen == 2 && max_sweeps <= 0 &&
+                              !P->dp.Wr3;
+    if (want_persist && R.nf > 0 && (R.shard_world == 1 || R.sharded)) {
         int rc = persistent_run(T);
         if (frontier_size) *frontier_size = 0;
         return rc;
@@ -1969,6 +1973,11 @@ int ehm_partition_step(ehm_tree* T, int32_t max_sweeps, int64_t* frontier_size) 
             R.pre_nodes = R.n_nodes;
             R.pre_solves = (long long)(cs.lp_solves - R.c0.lp_solves);
             if (R.nf == 0) break;
+            if (want_persist) {
+                int rc3 = persistent_run(T);
+                if (frontier_size) *frontier_size = 0;
+                return rc3;
+            }
         }
         if ((long long)open_flag.cap < R.nf * 4) {
             int rc = open_flag.ensure((size_t)R.nf * 4 * 2);
