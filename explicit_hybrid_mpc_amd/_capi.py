@@ -34,6 +34,7 @@ EXPORTED = [
     'ehm_partition_take', 'ehm_partition_give', 'ehm_partition_finish',
     'ehm_explicit_create', 'ehm_explicit_eval_batch', 'ehm_explicit_destroy',
     'ehm_explicit_last_error', 'ehm_partition_progress', 'ehm_problem_set_quadratic',
+    'ehm_feas_all_batch', 'ehm_lcss_batch',
 ]
 
 
@@ -134,6 +135,8 @@ def load(build_if_missing=True):
     lib.ehm_bar_e_batch.argtypes = [vp, i64, vp, vp, vp, vp]
     lib.ehm_min_simplex_batch.argtypes = [vp, i64, vp, vp, vp, vp]
     lib.ehm_bar_d_batch.argtypes = [vp, i64, vp, vp, vp, vp, vp, vp, vp, vp]
+    lib.ehm_feas_all_batch.argtypes = [vp, i64, vp, vp]
+    lib.ehm_lcss_batch.argtypes = [vp, i64] + [vp] * 13
     lib.ehm_split_batch.argtypes = [i32, i64, i32, vp, vp, vp, vp]
     lib.ehm_volume_batch.argtypes = [i32, i64, i32, vp, vp]
     lib.ehm_partition_run.argtypes = [vp, i64, vp, ctypes.POINTER(NodeInit),

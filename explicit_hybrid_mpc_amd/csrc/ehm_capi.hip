@@ -1364,12 +1364,17 @@ int ehm_vr_batch(ehm_problem* P, int64_t n_inst, const double* R, int32_t* delta
 // simplex; -inf for the others.  tall[k*nd + d], optional alpha_all [k*nd+d][p+1].
 static int slack_all(ehm_problem* P, int64_t n_inst, const double* R, const double* Vbar,
                      const std::vector<uint8_t>* restrict_mask, std::vector<double>& tall,
-                     std::vector<double>* alpha_all) {
+                     std::vector<double>* alpha_all, const uint8_t* known = nullptr,
+                     std::vector<uint8_t>* feas_out = nullptr) {
+    // known[k*nd + d] (optional): 0 = run the phase-one problem, 1 = the commutation is known to
+    // be feasible somewhere on the simplex (e.g. at a vertex), 2 = known to be infeasible on it
+    // (e.g. on the parent simplex).  feas_out: the verdicts (1 = feasible with an interior).
     const int nd = P->dp.n_delta, p = P->dp.p, nv = p + 1;
     const size_t nR = (size_t)nv * p;
     std::vector<int64_t> sel;
     for (int64_t q = 0; q < n_inst * nd; ++q)
-        if (!restrict_mask || (*restrict_mask)[(size_t)q]) sel.push_back(q);
+        if ((!restrict_mask || (*restrict_mask)[(size_t)q]) && !(known && known[q] == 2))
+            sel.push_back(q);
     int64_t F = (int64_t)sel.size();
     std::vector<double> R2((size_t)F * nR), V2((size_t)F * nv), obj((size_t)F);
     std::vector<int32_t> di((size_t)F), st((size_t)F);
@@ -1381,12 +1386,30 @@ static int slack_all(ehm_problem* P, int64_t n_inst, const double* R, const doub
     }
     tall.assign((size_t)(n_inst * nd), -INFINITY);
     if (alpha_all) alpha_all->assign((size_t)(n_inst * nd) * nv, 0.0);
+    if (feas_out) feas_out->assign((size_t)(n_inst * nd), 0);
     std::vector<double> tau_sel;      // phase-one optimum of every pair that stays selected
     if (nd > 1) {
-        // drop pairs whose commutation is infeasible on the whole simplex
-        int rc = simplex_batch(P, F, R2.data(), nullptr, di.data(), SX_FEAS, obj.data(), nullptr,
-                               st.data());
-        if (rc) return rc;
+        // drop pairs whose commutation is infeasible on the whole simplex: phase one for the
+        // pairs nothing is known about
+        std::vector<int64_t> ask;
+        for (int64_t f = 0; f < F; ++f)
+            if (!(known && known[sel[(size_t)f]] == 1)) ask.push_back(f);
+        const int64_t A = (int64_t)ask.size();
+        std::vector<double> Ra((size_t)A * nR), tau_a((size_t)A);
+        std::vector<int32_t> da((size_t)A), sa((size_t)A);
+        for (int64_t a = 0; a < A; ++a) {
+            const int64_t f = ask[(size_t)a];
+            std::memcpy(&Ra[(size_t)a * nR], &R2[(size_t)f * nR], nR * sizeof(double));
+            da[(size_t)a] = di[(size_t)f];
+        }
+        if (A > 0) {
+            int rc = simplex_batch(P, A, Ra.data(), nullptr, da.data(), SX_FEAS, tau_a.data(),
+                                   nullptr, sa.data());
+            if (rc) return rc;
+        }
+        // tau of a pair known to be feasible: far from the sliver band
+        std::fill(obj.begin(), obj.end(), -1.0);
+        for (int64_t a = 0; a < A; ++a) obj[(size_t)ask[(size_t)a]] = tau_a[(size_t)a];
         std::vector<int64_t> sel2;
         for (int64_t f = 0; f < F; ++f)
             if (obj[(size_t)f] <= EHM_FEAS_TOL) sel2.push_back(f);
@@ -1411,6 +1434,28 @@ static int slack_all(ehm_problem* P, int64_t n_inst, const double* R, const doub
     int rc = simplex_batch(P, F, R2.data(), V2.data(), di.data(), SX_SLACK, obj.data(),
                            al.data(), st.data());
     if (rc) return rc;
+    if (known && !tau_sel.empty()) {
+        // a pair taken as feasible on the caller's word (feasible at a vertex WITHIN the phase-one
+        // tolerance) whose slack problem stalls: get its phase-one optimum now, so that the
+        // sliver rule below judges it exactly as it would have without the hint
+        std::vector<int64_t> redo;
+        for (int64_t f = 0; f < F; ++f)
+            if (st[(size_t)f] != 0 && known[sel[(size_t)f]] == 1) redo.push_back(f);
+        const int64_t A = (int64_t)redo.size();
+        if (A > 0) {
+            std::vector<double> Ra((size_t)A * nR), tau_a((size_t)A);
+            std::vector<int32_t> da((size_t)A), sa((size_t)A);
+            for (int64_t a = 0; a < A; ++a) {
+                const int64_t f = redo[(size_t)a];
+                std::memcpy(&Ra[(size_t)a * nR], &R2[(size_t)f * nR], nR * sizeof(double));
+                da[(size_t)a] = di[(size_t)f];
+            }
+            rc = simplex_batch(P, A, Ra.data(), nullptr, da.data(), SX_FEAS, tau_a.data(), nullptr,
+                               sa.data());
+            if (rc) return rc;
+            for (int64_t a = 0; a < A; ++a) tau_sel[(size_t)redo[(size_t)a]] = tau_a[(size_t)a];
+        }
+    }
     for (int64_t f = 0; f < F; ++f) {
         if (st[(size_t)f] != 0 && !tau_sel.empty() && tau_sel[(size_t)f] > -EHM_SLIVER_TOL) {
             // the commutation is feasible on the simplex only within the accuracy of the
@@ -1436,6 +1481,7 @@ static int slack_all(ehm_problem* P, int64_t n_inst, const double* R, const doub
                         (long long)(sel[(size_t)f] / nd), (int)(sel[(size_t)f] % nd));
         }
         tall[(size_t)sel[(size_t)f]] = obj[(size_t)f];
+        if (feas_out) (*feas_out)[(size_t)sel[(size_t)f]] = 1;
         if (alpha_all)
             std::memcpy(&(*alpha_all)[(size_t)sel[(size_t)f] * nv], &al[(size_t)f * nv],
                         nv * sizeof(double));
@@ -1459,20 +1505,14 @@ int ehm_bar_e_batch(ehm_problem* P, int64_t n_inst, const double* R, const doubl
     return EHM_OK;
 }
 
-int ehm_bar_d_batch(ehm_problem* P, int64_t n_inst, const double* R, const double* Vbar,
-                    const uint8_t* delta_ref, int32_t* delta_idx, double* theta_star,
-                    double* vJ, double* vu0, uint8_t* var_small) {
-    if (!P || !R || !Vbar || !delta_idx || n_inst < 0) return fail(EHM_E_INVALID, "bad argument");
+// Second half of bar_D_delta_R, given the slacks of the commutations feasible at every vertex
+// (mask) -- shared by ehm_bar_d_batch and ehm_lcss_batch.
+static int bar_d_finish(ehm_problem* P, int64_t n_inst, const double* R, const double* Vbar,
+                        const std::vector<int32_t>& dref, const std::vector<uint8_t>& mask,
+                        const std::vector<double>& tall, const std::vector<double>& alpha_all,
+                        int32_t* delta_idx, double* theta_star, double* vJ, double* vu0,
+                        uint8_t* var_small) {
     const int nd = P->dp.n_delta, p = P->dp.p, nv = p + 1;
-    std::vector<int32_t> dref;
-    int rc = map_deltas(P, n_inst, delta_ref, dref);
-    if (rc) return rc;
-    std::vector<uint8_t> mask;
-    rc = vertex_feasible_mask(P, n_inst, R, mask);
-    if (rc) return rc;
-    std::vector<double> tall, alpha_all;
-    rc = slack_all(P, n_inst, R, Vbar, &mask, tall, &alpha_all);
-    if (rc) return rc;
     std::vector<double> ths((size_t)n_inst * p, 0.0);
     for (int64_t k = 0; k < n_inst; ++k) {
         int best = -1;
@@ -1502,7 +1542,7 @@ int ehm_bar_d_batch(ehm_problem* P, int64_t n_inst, const double* R, const doubl
         if (var_small) var_small[k] = 0;
     }
     bool all_ok = true;
-    rc = vertex_solves(P, n_inst, R, delta_idx, vJ, vu0, all_ok);
+    int rc = vertex_solves(P, n_inst, R, delta_idx, vJ, vu0, all_ok);
     if (rc) return rc;
     if (!all_ok) return fail(EHM_E_NUMERIC, "a vertex solve of bar_D did not converge");
     // in_variability_ball (lib/oracle.py:220-283) for the instances with a better commutation
@@ -1536,6 +1576,131 @@ int ehm_bar_d_batch(ehm_problem* P, int64_t n_inst, const double* R, const doubl
             const double rhs = std::max(P->dp.eps_a, P->dp.eps_r * Jth[(size_t)f]);
             var_small[k] = (vmax - Jmin[(size_t)f] < rhs) ? 1 : 0;
         }
+    }
+    return EHM_OK;
+}
+
+int ehm_bar_d_batch(ehm_problem* P, int64_t n_inst, const double* R, const double* Vbar,
+                    const uint8_t* delta_ref, int32_t* delta_idx, double* theta_star,
+                    double* vJ, double* vu0, uint8_t* var_small) {
+    if (!P || !R || !Vbar || !delta_idx || n_inst < 0) return fail(EHM_E_INVALID, "bad argument");
+    std::vector<int32_t> dref;
+    int rc = map_deltas(P, n_inst, delta_ref, dref);
+    if (rc) return rc;
+    std::vector<uint8_t> mask;
+    rc = vertex_feasible_mask(P, n_inst, R, mask);
+    if (rc) return rc;
+    std::vector<double> tall, alpha_all;
+    rc = slack_all(P, n_inst, R, Vbar, &mask, tall, &alpha_all);
+    if (rc) return rc;
+    return bar_d_finish(P, n_inst, R, Vbar, dref, mask, tall, alpha_all, delta_idx, theta_star,
+                        vJ, vu0, var_small);
+}
+
+// P_theta_delta(theta, d, check_feasibility=True) for EVERY commutation d: feasible[k*nd + d].
+int ehm_feas_all_batch(ehm_problem* P, int64_t n_inst, const double* theta, uint8_t* feasible) {
+    if (!P || !theta || !feasible || n_inst < 0) return fail(EHM_E_INVALID, "bad argument");
+    const int nd = P->dp.n_delta, p = P->dp.p;
+    const int64_t K = n_inst * nd;
+    std::vector<double> th((size_t)K * p);
+    std::vector<int32_t> di((size_t)K);
+    for (int64_t k = 0; k < n_inst; ++k)
+        for (int d = 0; d < nd; ++d) {
+            std::memcpy(&th[(size_t)(k * nd + d) * p], theta + (size_t)k * p, p * sizeof(double));
+            di[(size_t)(k * nd + d)] = d;
+        }
+    std::vector<uint8_t> ok;
+    int rc = feas_pairs(P, K, th.data(), di.data(), ok);
+    if (rc) return rc;
+    for (int64_t q = 0; q < K; ++q) feasible[q] = ok[(size_t)q];
+    return EHM_OK;
+}
+
+// One visit of Worker.lcss for a batch of nodes (lib/worker.py:367-401): bar_E_delta_R, and for
+// the nodes that stay open bar_D_delta_R, sharing what the two oracles have in common and what
+// the caller already knows about the node:
+//   vfeas  [n][p+1][nd]  P_theta_delta feasibility of every commutation at every vertex
+//                        (children inherit p of their p+1 vertices: ehm_feas_all_batch on the
+//                        new midpoints only);
+//   cand   [n][nd] or NULL  commutations that were feasible somewhere on the PARENT simplex.
+// A commutation feasible at a vertex is feasible on the simplex, one infeasible on the parent
+// is infeasible on the child; only the rest needs a phase-one problem, and the slacks bar_E
+// computes are the ones bar_D ranks.  Same verdicts and optima as ehm_bar_e_batch followed by
+// ehm_bar_d_batch, about 2.5 times fewer sub-problems.
+int ehm_lcss_batch(ehm_problem* P, int64_t n_inst, const double* R, const double* Vbar,
+                   const uint8_t* delta_ref, const uint8_t* vfeas, const uint8_t* cand,
+                   uint8_t* closed, double* tbest, uint8_t* cand_out, int32_t* delta_idx,
+                   double* theta_star, double* vJ, double* vu0, uint8_t* var_small) {
+    if (!P || !R || !Vbar || !delta_ref || !vfeas || !closed || !delta_idx || n_inst < 0)
+        return fail(EHM_E_INVALID, "bad argument");
+    const int nd = P->dp.n_delta, p = P->dp.p, nv = p + 1;
+    std::vector<int32_t> dref;
+    int rc = map_deltas(P, n_inst, delta_ref, dref);
+    if (rc) return rc;
+    std::vector<uint8_t> known((size_t)(n_inst * nd), 0), vall((size_t)(n_inst * nd), 1);
+    for (int64_t k = 0; k < n_inst; ++k)
+        for (int d = 0; d < nd; ++d) {
+            bool any = false, all = true;
+            for (int v = 0; v < nv; ++v) {
+                const bool f = vfeas[((size_t)k * nv + v) * nd + d] != 0;
+                any = any || f;
+                all = all && f;
+            }
+            vall[(size_t)(k * nd + d)] = all ? 1 : 0;
+            known[(size_t)(k * nd + d)] =
+                any ? 1 : ((cand && !cand[(size_t)(k * nd + d)]) ? 2 : 0);
+        }
+    std::vector<double> tall, alpha_all;
+    std::vector<uint8_t> feas;
+    rc = slack_all(P, n_inst, R, Vbar, nullptr, tall, &alpha_all, known.data(), &feas);
+    if (rc) return rc;
+    std::vector<int64_t> open;
+    for (int64_t k = 0; k < n_inst; ++k) {
+        double tb = -INFINITY;
+        for (int d = 0; d < nd; ++d) tb = std::max(tb, tall[(size_t)(k * nd + d)]);
+        closed[k] = (tb >= 0.0) ? 0 : 1;
+        if (tbest) tbest[k] = tb;
+        if (cand_out)
+            std::memcpy(cand_out + (size_t)k * nd, &feas[(size_t)k * nd], (size_t)nd);
+        delta_idx[k] = -1;
+        if (var_small) var_small[k] = 0;
+        if (!closed[k]) open.push_back(k);
+    }
+    const int64_t M = (int64_t)open.size();
+    if (M == 0) return EHM_OK;
+    // bar_D for the open nodes, on compacted copies
+    const size_t nR = (size_t)nv * p;
+    const int n_u = P->dp.n_u;
+    std::vector<double> R2((size_t)M * nR), V2((size_t)M * nv), t2((size_t)(M * nd)),
+        a2((size_t)(M * nd) * nv), ths((size_t)M * p), vJ2((size_t)M * nv),
+        vu2((size_t)M * nv * n_u);
+    std::vector<uint8_t> m2((size_t)(M * nd)), vs2((size_t)M);
+    std::vector<int32_t> dr2((size_t)M), di2((size_t)M);
+    for (int64_t q = 0; q < M; ++q) {
+        const int64_t k = open[(size_t)q];
+        std::memcpy(&R2[(size_t)q * nR], R + (size_t)k * nR, nR * sizeof(double));
+        std::memcpy(&V2[(size_t)q * nv], Vbar + (size_t)k * nv, nv * sizeof(double));
+        std::memcpy(&t2[(size_t)q * nd], &tall[(size_t)k * nd], nd * sizeof(double));
+        std::memcpy(&a2[(size_t)q * nd * nv], &alpha_all[(size_t)k * nd * nv],
+                    (size_t)nd * nv * sizeof(double));
+        // commutations feasible at every vertex AND with an interior on the simplex
+        for (int d = 0; d < nd; ++d)
+            m2[(size_t)(q * nd + d)] = vall[(size_t)(k * nd + d)] && feas[(size_t)(k * nd + d)];
+        dr2[(size_t)q] = dref[(size_t)k];
+    }
+    rc = bar_d_finish(P, M, R2.data(), V2.data(), dr2, m2, t2, a2, di2.data(), ths.data(),
+                      vJ2.data(), vu2.data(), vs2.data());
+    if (rc) return rc;
+    for (int64_t q = 0; q < M; ++q) {
+        const int64_t k = open[(size_t)q];
+        delta_idx[k] = di2[(size_t)q];
+        if (theta_star)
+            std::memcpy(theta_star + (size_t)k * p, &ths[(size_t)q * p], p * sizeof(double));
+        if (vJ) std::memcpy(vJ + (size_t)k * nv, &vJ2[(size_t)q * nv], nv * sizeof(double));
+        if (vu0)
+            std::memcpy(vu0 + (size_t)k * nv * n_u, &vu2[(size_t)q * nv * n_u],
+                        (size_t)nv * n_u * sizeof(double));
+        if (var_small) var_small[k] = vs2[(size_t)q];
     }
     return EHM_OK;
 }

@@ -220,6 +220,42 @@ class GpuProblem:
                                         ptr(ths), ptr(vJ), ptr(vu), ptr(vs)))
         return didx, ths, vJ, vu, vs.astype(bool)
 
+    def feas_all(self, theta):
+        """Feasibility of every commutation at every parameter: (n, n_delta) bool."""
+        theta = f64(np.atleast_2d(theta))
+        n = theta.shape[0]
+        out = np.empty((n, self.can.n_delta), dtype=np.uint8)
+        check(self._lib.ehm_feas_all_batch(self._handle, n, ptr(theta), ptr(out)))
+        return out.astype(bool)
+
+    def lcss(self, R, Vbar, delta_ref, vfeas, cand=None):
+        """
+        One ``Worker.lcss`` visit per node (lib/worker.py:367-401): bar_E and, for the open
+        nodes, bar_D, sharing slacks and feasibility knowledge (include/ehmpc.h,
+        ehm_lcss_batch).  vfeas (n, p+1, n_delta) bool, cand (n, n_delta) bool or None.
+        Returns (closed, tbest, cand_out, delta_idx, theta_star, vJ, vu0, var_small).
+        """
+        R = f64(R).reshape(-1, self.can.p + 1, self.can.p)
+        n = R.shape[0]
+        p, n_u, nd = self.can.p, self.can.n_u, self.can.n_delta
+        Vbar = f64(Vbar).reshape(n, p + 1)
+        d = self._delta_arg(delta_ref, n)
+        vf = u8(np.asarray(vfeas).reshape(n, p + 1, nd))
+        cd = None if cand is None else u8(np.asarray(cand).reshape(n, nd))
+        closed = np.empty(n, dtype=np.uint8)
+        tb = np.empty(n)
+        cand_out = np.empty((n, nd), dtype=np.uint8)
+        didx = np.empty(n, dtype=np.int32)
+        ths = np.zeros((n, p))
+        vJ = np.zeros((n, p + 1))
+        vu = np.zeros((n, p + 1, n_u))
+        vs = np.empty(n, dtype=np.uint8)
+        check(self._lib.ehm_lcss_batch(self._handle, n, ptr(R), ptr(Vbar), ptr(d), ptr(vf),
+                                       ptr(cd), ptr(closed), ptr(tb), ptr(cand_out), ptr(didx),
+                                       ptr(ths), ptr(vJ), ptr(vu), ptr(vs)))
+        return (closed.astype(bool), tb, cand_out.astype(bool), didx, ths, vJ, vu,
+                vs.astype(bool))
+
     # -- partition ------------------------------------------------------------------------------
     def partition(self, roots, action='ecc', init=None, max_nodes=0, max_depth=0, engine=1,
                   export=True, shard=None, with_volume=True, status=None, status_sweeps=1):

@@ -73,6 +73,11 @@ def grow_hybrid(gp, roots, action='ecc', init=None, max_nodes=1 << 20):
     sweeps = 0
     min_margin = np.inf
     ref_solves = 0
+    # what is known about the live lcss nodes (dropped when a node is closed or split):
+    # vfeas[i] (p+1, n_delta) feasibility of every commutation at every vertex; cand[i]
+    # (n_delta,) commutations feasible somewhere on the PARENT simplex
+    vfeas, cand = {}, {}
+    all_true = np.ones(can.n_delta, dtype=bool)
 
     def split(ids):
         R = np.array([pool.vertices[i] for i in ids])
@@ -111,57 +116,73 @@ def grow_hybrid(gp, roots, action='ecc', init=None, max_nodes=1 << 20):
             ids = lcss_front
             R = np.array([pool.vertices[i] for i in ids])
             V = np.array([pool.vcost[i] for i in ids])
-            closed, tbest = gp.bar_e(R, V)
+            # per-vertex feasibility of every commutation: inherited with the vertices; a node
+            # that arrives from ecc (or as an lcss root) gets it here, once
+            fresh = [i for i in ids if i not in vfeas]
+            if fresh:
+                Rf = np.array([pool.vertices[i] for i in fresh]).reshape(-1, p)
+                mf = gp.feas_all(Rf).reshape(len(fresh), p + 1, can.n_delta)
+                for q, i in enumerate(fresh):
+                    vfeas[i] = mf[q]
+            vf = np.array([vfeas[i] for i in ids])
+            cd = np.array([cand.get(i, all_true) for i in ids])
+            dref = can.deltas[[pool.didx[i] for i in ids]]
+            closed, tbest, cand_out, dstar, ths, vJ, vu, vsmall = gp.lcss(R, V, dref, vf, cd)
             ref_solves += len(ids)
             min_margin = min(min_margin, float(np.min(np.abs(tbest))))
+            split_ids, split_d, split_c, split_u = [], [], [], []
             for k, i in enumerate(ids):
                 pool.tstar[i] = float(tbest[k])
+                cand[i] = cand_out[k]
                 if closed[k]:
                     pool.flags[i] |= 1
-            open_k = [k for k in range(len(ids)) if not closed[k]]
-            if open_k:
-                oi = [ids[k] for k in open_k]
-                Ro, Vo = R[open_k], V[open_k]
-                dref = can.deltas[[pool.didx[i] for i in oi]]
-                dstar, ths, vJ, vu, vsmall = gp.bar_d(Ro, Vo, dref)
-                ref_solves += len(oi)
-                split_ids, split_d, split_c, split_u = [], [], [], []
-                for q, i in enumerate(oi):
-                    if dstar[q] >= 0:
-                        ref_solves += p + 3
-                        if vsmall[q]:                     # swap in place, revisit the node
-                            pool.didx[i] = int(dstar[q])
-                            pool.vcost[i] = vJ[q].copy()
-                            pool.vinput[i] = vu[q].copy()
-                            next_lcss.append(i)
-                            continue
-                        # split with the better commutation; the parent keeps its own data
-                        split_d.append(int(dstar[q]))
-                        split_c.append(vJ[q].copy())
-                        split_u.append(vu[q].copy())
-                    else:                                 # lib/worker.py:381-386
-                        split_d.append(pool.didx[i])
-                        split_c.append(pool.vcost[i].copy())
-                        split_u.append(pool.vinput[i].copy())
-                    split_ids.append(i)
-                if split_ids:
-                    S1, S2, ij = split(split_ids)
-                    mids = np.array([S1[q][ij[q, 0]] for q in range(len(split_ids))])
-                    Jm, um, st, _ = gp.solve_ptd(mids, can.deltas[split_d])
-                    ref_solves += len(split_ids)
-                    if (st != 0).any():
-                        raise RuntimeError('midpoint solve did not converge')
-                    for q, i in enumerate(split_ids):
-                        c1, c2 = split_c[q].copy(), split_c[q].copy()
-                        u1, u2 = split_u[q].copy(), split_u[q].copy()
-                        c1[ij[q, 0]] = Jm[q]
-                        c2[ij[q, 1]] = Jm[q]
-                        u1[ij[q, 0]] = um[q]
-                        u2[ij[q, 1]] = um[q]
-                        a = pool.add(S1[q], split_d[q], c1, u1)
-                        b = pool.add(S2[q], split_d[q], c2, u2)
-                        pool.left[i], pool.right[i] = a, b
-                        next_lcss += [a, b]
+                    vfeas.pop(i, None)
+                    cand.pop(i, None)
+                    continue
+                ref_solves += 1
+                if dstar[k] >= 0:
+                    ref_solves += p + 3
+                    if vsmall[k]:                     # swap in place, revisit the node
+                        pool.didx[i] = int(dstar[k])
+                        pool.vcost[i] = vJ[k].copy()
+                        pool.vinput[i] = vu[k].copy()
+                        next_lcss.append(i)
+                        continue
+                    # split with the better commutation; the parent keeps its own data
+                    split_d.append(int(dstar[k]))
+                    split_c.append(vJ[k].copy())
+                    split_u.append(vu[k].copy())
+                else:                                 # lib/worker.py:381-386
+                    split_d.append(pool.didx[i])
+                    split_c.append(pool.vcost[i].copy())
+                    split_u.append(pool.vinput[i].copy())
+                split_ids.append(i)
+            if split_ids:
+                S1, S2, ij = split(split_ids)
+                mids = np.array([S1[q][ij[q, 0]] for q in range(len(split_ids))])
+                Jm, um, st, _ = gp.solve_ptd(mids, can.deltas[split_d])
+                ref_solves += len(split_ids)
+                if (st != 0).any():
+                    raise RuntimeError('midpoint solve did not converge')
+                mid_feas = gp.feas_all(mids)          # the one new vertex of the two children
+                for q, i in enumerate(split_ids):
+                    c1, c2 = split_c[q].copy(), split_c[q].copy()
+                    u1, u2 = split_u[q].copy(), split_u[q].copy()
+                    c1[ij[q, 0]] = Jm[q]
+                    c2[ij[q, 1]] = Jm[q]
+                    u1[ij[q, 0]] = um[q]
+                    u2[ij[q, 1]] = um[q]
+                    a = pool.add(S1[q], split_d[q], c1, u1)
+                    b = pool.add(S2[q], split_d[q], c2, u2)
+                    pool.left[i], pool.right[i] = a, b
+                    f1, f2 = vfeas[i].copy(), vfeas[i].copy()
+                    f1[ij[q, 0]] = mid_feas[q]
+                    f2[ij[q, 1]] = mid_feas[q]
+                    vfeas[a], vfeas[b] = f1, f2
+                    cand[a] = cand[b] = cand[i]       # feasible on the parent simplex
+                    vfeas.pop(i, None)
+                    cand.pop(i, None)
+                    next_lcss += [a, b]
         ecc_front, lcss_front = next_ecc, next_lcss
     stats1 = gp.stats()
     flags = np.array(pool.flags)

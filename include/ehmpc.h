@@ -158,6 +158,27 @@ int ehm_bar_d_batch(ehm_problem* prob, int64_t n_inst, const double* R, const do
                     const uint8_t* delta_ref, int32_t* delta_idx, double* theta_star,
                     double* vJ, double* vu0, uint8_t* var_small);
 
+/* Oracle.P_theta_delta(theta, d, check_feasibility=True) for EVERY commutation d:
+ * feasible [n_inst][n_delta]. */
+int ehm_feas_all_batch(ehm_problem* prob, int64_t n_inst, const double* theta, uint8_t* feasible);
+
+/* One visit of Worker.lcss for a batch of nodes (lib/worker.py:367-401): bar_E_delta_R and, for
+ * the nodes that stay open, bar_D_delta_R, sharing the slacks the two oracles have in common and
+ * what the caller already knows:
+ *   vfeas [n_inst][p+1][n_delta]  feasibility of every commutation at every vertex (a child
+ *         inherits p of its p+1 vertices; ehm_feas_all_batch on the new midpoints only),
+ *   cand  [n_inst][n_delta] or NULL  commutations feasible somewhere on the PARENT simplex.
+ * Feasible at a vertex => feasible on the simplex; infeasible on the parent => infeasible on the
+ * child; only the rest gets a phase-one problem.  Outputs: closed / tbest as ehm_bar_e_batch,
+ * cand_out [n_inst][n_delta] (feasible on this simplex: the children's `cand`), and for open
+ * nodes delta_idx / theta_star / vJ / vu0 / var_small as ehm_bar_d_batch (delta_idx = -1 for
+ * closed nodes).  Same verdicts and optima as the two calls, ~2.5x fewer sub-problems. */
+int ehm_lcss_batch(ehm_problem* prob, int64_t n_inst, const double* R, const double* Vbar,
+                   const uint8_t* delta_ref, const uint8_t* vfeas, const uint8_t* cand,
+                   uint8_t* closed, double* tbest, uint8_t* cand_out, int32_t* delta_idx,
+                   double* theta_star, double* vJ, double* vu0, uint8_t* var_small);
+
+
 /* ---- geometry ------------------------------------------------------------------------ */
 
 /* tools.split_along_longest_edge (lib/tools.py:224-257), bit-exact incl. the first-max
