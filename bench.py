@@ -219,7 +219,7 @@ def main():
     elapsed = time.perf_counter() - t0
     # totals over ranks (max time, summed work)
     keys = ['lp_solves', 'ipm_iters', 'n_nodes', 'n_closed', 'ref_solves', 'decide_solves',
-            'decide_iters']
+            'decide_iters', 'cert_closed']
     if rank > 0:
         # the top of the tree is grown identically on every rank: count it once (rank 0)
         for i in infos:
@@ -246,12 +246,16 @@ def main():
         decide_flops = agg['decide_iters'] * flops_per_iteration(n_slack, m_slack)
         expand_flops = (agg['ipm_iters'] - agg['decide_iters']) * flops_per_iteration(n_pt, m_pt)
         B = node_bytes(can.p, can.n_u, can.deltas.shape[1])
+        if agg['cert_closed'] > 0:
+            # the run keeps the vertex gradients of the optimal cost next to every record
+            B += 8 * (can.p + 1) * can.p
         closed, nodes = agg['n_closed'], agg['n_nodes']
         splits = (nodes - K * len(roots)) / 2.
         if persistent:
             # ONE kernel per partition: suboptimality tests AND splits / midpoint solves
             achieved = (decide_flops + expand_flops) / decide_s / 1e12
-            hbm_alg = agg['decide_solves'] * (B + 8) + splits * (B + 2 * B + 16)
+            hbm_alg = (agg['decide_solves'] + agg['cert_closed']) * (B + 8) + \
+                splits * (B + 2 * B + 16)
         else:
             # dominant kernel = the suboptimality-test sweep (k_lcss_decide)
             achieved = decide_flops / decide_s / 1e12
@@ -282,6 +286,8 @@ def main():
                 'nodes_per_step': nodes / K,
                 'lp_solves_per_step': agg['lp_solves'] / K,
                 'reference_equivalent_solves_per_step': agg['ref_solves'] / K,
+                'reference_equivalent_solves_per_s': agg['ref_solves'] / elapsed_max,
+                'leaves_closed_without_lp_per_step': agg['cert_closed'] / K,
                 'mean_ipm_iterations': agg['ipm_iters'] / max(agg['lp_solves'], 1),
                 'sweeps': info0['sweeps'], 'tree_depth': info0['max_depth'],
                 'min_decision_margin': info0['min_margin'],

@@ -75,7 +75,8 @@ class TreeInfo(ctypes.Structure):
                 ('expand_seconds', ctypes.c_double), ('decide_launches', ctypes.c_int64),
                 ('expand_launches', ctypes.c_int64), ('decide_solves', ctypes.c_int64),
                 ('decide_iters', ctypes.c_int64), ('replicated_closed', ctypes.c_int64),
-                ('replicated_nodes', ctypes.c_int64), ('replicated_solves', ctypes.c_int64)]
+                ('replicated_nodes', ctypes.c_int64), ('replicated_solves', ctypes.c_int64),
+                ('cert_closed', ctypes.c_int64)]
 
 
 class Progress(ctypes.Structure):

@@ -474,7 +474,7 @@ struct ehm_problem {
     // cost milliseconds): the pool of the last destroyed tree and the frontier scratch
     struct PoolCache {
         long long cap = 0;
-        DevBuf rec, left, didx, depth, flags, tstar;
+        DevBuf rec, left, didx, depth, flags, tstar, grad;
     } pool_cache;
     DevBuf fr_a, fr_b, open_flag, open_list, d_count;
     DevBuf pq_slots, pq_ctl;   // persistent engine: queue slots, control block
@@ -492,7 +492,7 @@ struct ehm_tree {
     DevTree dt{};
     long long cap = 0;       // allocated node records (a cached pool may be larger than asked for)
     long long limit = 0;     // max_nodes of this run: the capacity the caller agreed to
-    DevBuf rec, left, didx, depth, flags, tstar;
+    DevBuf rec, left, didx, depth, flags, tstar, grad;
     ehm_tree_info info{};
     int skip_volume = 0;
     // persistent engine: node ids follow the allocation order; the export relabels them to the
@@ -784,6 +784,7 @@ int ehm_problem_destroy(ehm_problem* P) {
     P->seg.release();
     P->pool_cache.rec.release(); P->pool_cache.left.release(); P->pool_cache.didx.release();
     P->pool_cache.depth.release(); P->pool_cache.flags.release(); P->pool_cache.tstar.release();
+    P->pool_cache.grad.release();
     P->fr_a.release(); P->fr_b.release(); P->open_flag.release(); P->open_list.release();
     P->d_count.release();
     P->pq_slots.release(); P->pq_ctl.release();
@@ -1767,10 +1768,11 @@ int ehm_tree_destroy(ehm_tree* T) {
         auto& c = T->prob->pool_cache;
         std::swap(c.rec, T->rec); std::swap(c.left, T->left); std::swap(c.didx, T->didx);
         std::swap(c.depth, T->depth); std::swap(c.flags, T->flags); std::swap(c.tstar, T->tstar);
+        std::swap(c.grad, T->grad);
         c.cap = T->cap;
     }
     T->rec.release(); T->left.release(); T->didx.release(); T->depth.release();
-    T->flags.release(); T->tstar.release();
+    T->flags.release(); T->tstar.release(); T->grad.release();
     delete T;
     return EHM_OK;
 }
@@ -1783,6 +1785,7 @@ static int tree_alloc(ehm_tree* T, ehm_problem* P, long long cap) {
         auto& c = P->pool_cache;
         std::swap(c.rec, T->rec); std::swap(c.left, T->left); std::swap(c.didx, T->didx);
         std::swap(c.depth, T->depth); std::swap(c.flags, T->flags); std::swap(c.tstar, T->tstar);
+        std::swap(c.grad, T->grad);
         cap = c.cap;
         c.cap = 0;
     }
@@ -1792,6 +1795,12 @@ static int tree_alloc(ehm_tree* T, ehm_problem* P, long long cap) {
     if ((rc = T->depth.ensure((size_t)cap * sizeof(int32_t)))) return rc;
     if ((rc = T->flags.ensure((size_t)cap))) return rc;
     if ((rc = T->tstar.ensure((size_t)cap * sizeof(double)))) return rc;
+    // vertex gradients of the optimal cost (cutting-plane closure of leaves, ehm_dev.h): kept by
+    // the shared-block kernels of a linear-cost, single-commutation handle
+    const bool grads = P->solver_gen == 2 && !P->quadratic && !P->dp.Wr3 && P->dp.n_delta == 1 &&
+                       !getenv("EHM_NO_CUTS");
+    if (grads && (rc = T->grad.ensure((size_t)cap * (p + 1) * p * sizeof(double)))) return rc;
+    T->dt.grad = grads ? T->grad.as<double>() : nullptr;
     T->prob = P;
     T->cap = cap;
     T->dt.rec = T->rec.as<double>();
@@ -1841,6 +1850,11 @@ __global__ void k_give_nodes(DevTree T, int first, int n, int nrec,
     const int id = first + k;
     double* r = T.rec + (size_t)id * T.rec_stride;
     for (int q = threadIdx.x; q < nrec; q += blockDim.x) r[q] = rec_in[(size_t)k * nrec + q];
+    if (T.grad) {       // the vertex gradients do not travel: unknown (no cutting-plane closure)
+        const int ng = (T.p + 1) * T.p;
+        for (int q = threadIdx.x; q < ng; q += blockDim.x)
+            T.grad[(size_t)id * ng + q] = __builtin_nan("");
+    }
     if (threadIdx.x == 0) {
         T.left[id] = -1;
         T.didx[id] = meta_in[2 * k];
@@ -1947,6 +1961,12 @@ int ehm_partition_begin(ehm_problem* P, int64_t n_roots, const double* root_vert
         (void)hipStreamSynchronize(P->stream);
     }
     RUN_TRY(read_counters(P, R.c0));
+    if (T->dt.grad) {
+        // root gradients start unknown (all-ones = NaN); the vertex solves of 'ecc' fill them
+        hipError_t e = hipMemsetAsync(T->dt.grad, 0xFF, (size_t)n_roots * (p + 1) * p * 8,
+                                      P->stream);
+        if (e != hipSuccess) RUN_TRY(fail(EHM_E_HIP, "gradient buffer init failed"));
+    }
     {
         unsigned long long inf_bits = 0x7FF0000000000000ULL;
         (void)hipMemcpyAsync(&P->d_cnt->min_margin_bits, &inf_bits, 8, hipMemcpyHostToDevice,
@@ -2390,6 +2410,7 @@ int ehm_partition_finish(ehm_tree* T) {
     T->info.expand_launches = n_kind[1];
     T->info.decide_solves = (int64_t)(c1.slack_solves - R.c0.slack_solves);
     T->info.decide_iters = (int64_t)(c1.slack_iters - R.c0.slack_iters);
+    T->info.cert_closed = (int64_t)(c1.cert_closed - R.c0.cert_closed);
     T->info.replicated_closed = R.pre_closed;
     T->info.replicated_nodes = R.pre_nodes;
     T->info.replicated_solves = R.pre_solves;

@@ -52,7 +52,44 @@ struct DevTree {
     double*  tstar;     // slack of the last close/split decision
     int rec_stride;     // doubles per record (multiple of 8)
     int p, n_u;
+    // grad[k][(p+1)*p]: gradient of the optimal cost V*_delta at every vertex of node k (from the
+    // multipliers of the vertex / midpoint solves: dJ/dtheta = -S^T lambda), NaN = unknown.
+    // Null unless the run maintains them (shared-block kernels, linear cost).  They give the
+    // cutting-plane bound that closes most leaves without a suboptimality-test LP (cut_bound).
+    double*  grad;
 };
+
+// Upper bound of the suboptimality-test optimum t* from the tangent planes of the convex optimal
+// cost at the vertices: V*(theta) >= L_i(theta) = V_i + g_i.(theta - v_i), so for every i
+//   t* <= max_alpha min( Vbar - L_i - eps_a, Vbar - (1+eps_r) L_i )
+//      <= min( max_j [V_j - L_i(v_j)] - eps_a,  max_j [V_j - (1+eps_r) L_i(v_j)] )
+// (both are linear in alpha, so their maxima over the simplex sit at vertices), and t* is at most
+// the smallest of these over i.  A negative bound closes the leaf exactly like t* < 0 would.
+// node = [vertices | vertex costs ...] in LDS, g = the node's (p+1)*p gradients in global memory.
+// Every lane returns the bound (+inf when a gradient is unknown).
+__device__ inline double cut_bound(const double* node, const double* g, int p, double eps_a,
+                                   double eps_r, int lane) {
+    const double* V = node + (p + 1) * p;
+    double b = 1e300;
+    if (lane <= p) {
+        const int i = lane;
+        const double* gi = g + i * p;       // read as needed: no private array, no scratch
+        bool ok = true;
+        double m_abs = -1e300, m_rel = -1e300;
+        for (int j = 0; j <= p; ++j) {
+            double d = 0.0;
+            for (int q = 0; q < p; ++q) d = fma(gi[q], node[j * p + q] - node[i * p + q], d);
+            ok = ok && (d == d);            // an unknown (NaN) gradient poisons d
+            const double Li = V[i] + d;
+            m_abs = fmax(m_abs, V[j] - Li);
+            m_rel = fmax(m_rel, V[j] - (1.0 + eps_r) * Li);
+        }
+        b = ok ? fmin(m_abs - eps_a, m_rel) : 1e300;
+    }
+#pragma unroll
+    for (int o = 8; o > 0; o >>= 1) b = fmin(b, __shfl_xor(b, o, 64));   // lanes 0..15 hold i <= 8
+    return __shfl(b, 0, 64);
+}
 
 struct DevCounters {
     unsigned long long lp_solves;
@@ -62,6 +99,7 @@ struct DevCounters {
     unsigned long long errors;
     unsigned long long slack_solves;      // LPs over a simplex (decide sweep)
     unsigned long long slack_iters;
+    unsigned long long cert_closed;       // leaves closed by the cutting-plane bound, no LP
 };
 
 __host__ __device__ inline int rec_off_vcost(int p) { return (p + 1) * p; }

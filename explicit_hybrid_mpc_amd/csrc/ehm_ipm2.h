@@ -885,8 +885,12 @@ __device__ __forceinline__ double lu_solve(const double (&row)[NP], const Wave& 
 // The solver.  On entry: W.X, W.c filled, b in registers (row layout of RowMap).
 // On exit: W.xb holds the best primal iterate.
 // ---------------------------------------------------------------------------------------
+// gout (optional, LDS, S.p doubles; point problems of a linear-cost handle): the gradient of the
+// optimal value with respect to the parameter, -S^T lambda = sum_i lambda_i Wc[n+q][i], NaN
+// unless the solve converged to the tolerances (an accepted-inaccurate solve has no usable dual).
 __device__ inline IpmResult ipm_solve(const Shared& S, const Wave& W, const double (&b)[SLOTS],
-                                      int lane0, bool sign_only, double step_frac) {
+                                      int lane0, bool sign_only, double step_frac,
+                                      double* gout = nullptr) {
     int lane = lane0;
     const int n = W.n_lp;
     const int m_lp = S.m + W.ne;
@@ -1188,6 +1192,21 @@ __device__ inline IpmResult ipm_solve(const Shared& S, const Wave& W, const doub
         wsync();
     }
     wsync();
+    if (gout) {
+        // lam is the multiplier of the LAST iterate = the returned one when the loop left
+        // through the convergence test
+        const bool conv = (res.status == 0) && (res.merit <= 1.0);
+        for (int q = 0; q < S.p; ++q) {
+            const double* col = S.Wc + (size_t)(S.n + q) * S.lda + lane0;
+            double a = 0.0;
+#pragma unroll
+            for (int sl = 0; sl < SLOTS; ++sl)
+                if (lane0 + 64 * sl < S.m) a = fma(col[64 * sl], lam[sl], a);
+            a = wave_sum(a);
+            if (lane0 == 0) gout[q] = conv ? a : __builtin_nan("");
+        }
+        wsync();
+    }
     if (res.status != 0 && res.merit <= const_d(EHM2_ACCEPT_MERIT)) res.status = 0;
     res.margin = fabs(res.obj);
     return res;

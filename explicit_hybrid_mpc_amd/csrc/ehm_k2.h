@@ -13,6 +13,9 @@
 #endif
 
 #define K2_AUG_MIN 16
+// the cutting-plane bound closes a leaf only when it is negative by more than this (relative to
+// 1 + |V_0|): gradients carry the accuracy of the multipliers (~1e-9); closer calls go to the LP
+#define EHM_CUT_TOL 1e-7
 
 namespace ehm {
 

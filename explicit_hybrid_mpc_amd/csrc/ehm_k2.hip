@@ -156,6 +156,24 @@ __global__ __launch_bounds__(EHM_K2_THREADS) void k2_lcss_decide(
         const double* rec = T.rec + (size_t)id * T.rec_stride;
         for (int k = lane; k < nrec; k += 64) nb.rec[k] = rec[k];
         wsync();
+        if (T.grad && sign_only) {
+            // tangent-plane bound of t* (ehm_dev.h, cut_bound): negative => the leaf is closed,
+            // exactly as a negative t* would close it, without solving the LP
+            const double bnd = cut_bound(nb.rec, T.grad + (size_t)id * (P.p + 1) * P.p, P.p,
+                                         P.eps_a, P.eps_r, lane);
+            if (bnd < -EHM_CUT_TOL * (1.0 + fabs(nb.rec[rec_off_vcost(P.p)]))) {
+                if (lane == 0) {
+                    atomicAdd(&cnt->cert_closed, 1ULL);
+                    T.tstar[id] = bnd;
+                    open_flag[f] = 0;
+                    T.flags[id] |= 1;
+                    atomicMin(&cnt->min_margin_bits,
+                              (unsigned long long)__double_as_longlong(-bnd));
+                }
+                wsync();
+                continue;
+            }
+        }
         Wave W;
         IpmResult r;
         int its = 0;
@@ -229,7 +247,7 @@ __global__ __launch_bounds__(EHM_K2_THREADS) void k2_lcss_expand(
             double b[SLOTS];
             const int ln = pin(lane);
             assemble_point(S, W, nb.lp, mid, false, b, ln, P, 0);
-            r = ipm_solve(S, W, b, ln, false, step_fraction(attempt));
+            r = ipm_solve(S, W, b, ln, false, step_fraction(attempt), T.grad ? nb.F : nullptr);
             its += r.iters;
             if (r.status == 0) break;
         }
@@ -240,6 +258,16 @@ __global__ __launch_bounds__(EHM_K2_THREADS) void k2_lcss_expand(
             T.flags[id] |= 16;
         }
         const int c0 = child_base + 2 * f;
+        if (T.grad) {       // the children inherit the vertex gradients, the midpoint's is new
+            const int ng = (p + 1) * p;
+            const double* gp_ = T.grad + (size_t)id * ng;
+            double* g0 = T.grad + (size_t)c0 * ng;
+            for (int k = lane; k < ng; k += 64) {
+                const double gv = gp_[k];
+                g0[k] = (k >= bi * p && k < bi * p + p) ? nb.F[k - bi * p] : gv;
+                g0[ng + k] = (k >= bj * p && k < bj * p + p) ? nb.F[k - bj * p] : gv;
+            }
+        }
         double* rec0 = T.rec + (size_t)c0 * T.rec_stride;
         double* rec1 = rec0 + T.rec_stride;
         const int ov = rec_off_vcost(p), ou = rec_off_vinput(p);
@@ -316,7 +344,7 @@ __global__ __launch_bounds__(EHM_K2_THREADS) void k2_persist(
     unsigned long long* wst = reinterpret_cast<unsigned long long*>(nb.aug);
     double* wmargin = nb.aug + 12;
     enum { W_SOLVES = 0, W_ITERS, W_STALLED, W_ERRORS, W_SLACK, W_SLACK_ITERS, W_CLOSED, W_SPLITS,
-           W_DEPTH, W_TRUNC };
+           W_DEPTH, W_TRUNC, W_CERT };
     if (lane0 < 12) wst[lane0] = 0ULL;
     if (lane0 == 0) *wmargin = 1e300;
     wsync();
@@ -351,6 +379,25 @@ __global__ __launch_bounds__(EHM_K2_THREADS) void k2_persist(
         for (int k = lane; k < nrec; k += 64) node[k] = rec[k];
         wsync();
         // ---- suboptimality test --------------------------------------------------------------
+        if (T.grad && sign_only) {
+            // tangent-plane bound of t* (ehm_dev.h, cut_bound): negative => closed, no LP
+            const double bnd = cut_bound(node, T.grad + (size_t)id * (p + 1) * p, p, P.eps_a,
+                                         P.eps_r, lane);
+            if (bnd < -EHM_CUT_TOL * (1.0 + fabs(node[rec_off_vcost(p)]))) {
+                if (lane == 0) {
+                    const int dep0 = T.depth[id];
+                    wst[W_CERT] += 1;
+                    wst[W_CLOSED] += 1;
+                    *wmargin = fmin(*wmargin, -bnd);
+                    if ((unsigned long long)dep0 > wst[W_DEPTH]) wst[W_DEPTH] = (unsigned long long)dep0;
+                    T.tstar[id] = bnd;
+                    T.flags[id] |= 1;
+                    atomicSub(&ctl->pending, 1);
+                }
+                wsync();
+                continue;
+            }
+        }
         Wave W;
         IpmResult r;
         int its = 0;
@@ -423,11 +470,23 @@ __global__ __launch_bounds__(EHM_K2_THREADS) void k2_persist(
             double b[SLOTS];
             const int ln = pin(lane);
             assemble_point(S, W, nb.lp, mid, false, b, ln, P, 0);
-            r = ipm_solve(S, W, b, ln, false, step_fraction(attempt));
+            r = ipm_solve(S, W, b, ln, false, step_fraction(attempt), T.grad ? nb.F : nullptr);
             its += r.iters;
             if (r.status == 0) break;
         }
         r.iters = its;
+        if (T.grad) {       // children's vertex gradients, written through like the records
+            const int ng = (p + 1) * p;
+            const double* gp_ = T.grad + (size_t)id * ng;
+            double* g0 = T.grad + (size_t)c0 * ng;
+            for (int k = lane; k < ng; k += 64) {
+                const double gv = gp_[k];
+                const double a0 = (k >= bi * p && k < bi * p + p) ? nb.F[k - bi * p] : gv;
+                const double a1 = (k >= bj * p && k < bj * p + p) ? nb.F[k - bj * p] : gv;
+                __hip_atomic_store(g0 + k, a0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                __hip_atomic_store(g0 + ng + k, a1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            }
+        }
         if (lane == 0) {
             wst[W_SOLVES] += 1;
             wst[W_ITERS] += (unsigned long long)r.iters;
@@ -503,6 +562,7 @@ __global__ __launch_bounds__(EHM_K2_THREADS) void k2_persist(
         atomicAdd(&cnt->slack_solves, wst[W_SLACK]);
         atomicAdd(&cnt->slack_iters, wst[W_SLACK_ITERS]);
         atomicMin(&cnt->min_margin_bits, (unsigned long long)__double_as_longlong(*wmargin));
+        if (wst[W_CERT]) atomicAdd(&cnt->cert_closed, wst[W_CERT]);
         atomicAdd(&ctl->closed, wst[W_CLOSED]);
         atomicAdd(&ctl->splits, wst[W_SPLITS]);
         atomicMax(&ctl->max_depth_seen, (int)wst[W_DEPTH]);
@@ -540,13 +600,14 @@ __global__ __launch_bounds__(EHM_K2_THREADS) void k2_vertex_solve(
             double b[SLOTS];
             const int ln = pin(lane);
             assemble_point(S, W, nb.lp, nb.th, false, b, ln, P, 0);
-            r = ipm_solve(S, W, b, ln, false, step_fraction(attempt));
+            r = ipm_solve(S, W, b, ln, false, step_fraction(attempt), T.grad ? nb.F : nullptr);
             its += r.iters;
             if (r.status == 0) break;
         }
         r.iters = its;
         count_solve(cnt, r, lane);
         if (r.status != 0 && lane == 0) atomicAdd(&cnt->errors, 1ULL);
+        if (T.grad && lane < p) T.grad[((size_t)id * (p + 1) + v) * p + lane] = nb.F[lane];
         if (lane == 0) rec[rec_off_vcost(p) + v] = r.obj;
         if (lane < n_u) rec[rec_off_vinput(p) + v * n_u + lane] = W.xb[lane];
         wsync();

@@ -288,6 +288,9 @@ typedef struct ehm_tree_info {
     int64_t replicated_closed;
     int64_t replicated_nodes;
     int64_t replicated_solves;
+    int64_t cert_closed;    /* leaves closed by the tangent-plane bound of t* (gradients of the
+                               optimal cost at the vertices, from the multipliers of the vertex
+                               solves) without solving their suboptimality-test LP            */
 } ehm_tree_info;
 
 int ehm_tree_info_get(const ehm_tree* tree, ehm_tree_info* out);
