@@ -252,6 +252,9 @@ __global__ __launch_bounds__(EHM_K2_THREADS) void k2_lcss_expand(
             if (r.status == 0) break;
         }
         r.iters = its;
+#if EHM2_QUAD
+        if (T.grad) quad_grad_add(W, P, 0, mid, nb.F, lane);
+#endif
         count_solve(cnt, r, lane);
         if (r.status != 0 && lane == 0) {
             atomicAdd(&cnt->errors, 1ULL);
@@ -475,6 +478,9 @@ __global__ __launch_bounds__(EHM_K2_THREADS) void k2_persist(
             if (r.status == 0) break;
         }
         r.iters = its;
+#if EHM2_QUAD
+        if (T.grad) quad_grad_add(W, P, 0, mid, nb.F, lane);
+#endif
         if (T.grad) {       // children's vertex gradients, written through like the records
             const int ng = (p + 1) * p;
             const double* gp_ = T.grad + (size_t)id * ng;
@@ -607,6 +613,9 @@ __global__ __launch_bounds__(EHM_K2_THREADS) void k2_vertex_solve(
         r.iters = its;
         count_solve(cnt, r, lane);
         if (r.status != 0 && lane == 0) atomicAdd(&cnt->errors, 1ULL);
+#if EHM2_QUAD
+        if (T.grad) quad_grad_add(W, P, 0, nb.th, nb.F, lane);
+#endif
         if (T.grad && lane < p) T.grad[((size_t)id * (p + 1) + v) * p + lane] = nb.F[lane];
         if (lane == 0) rec[rec_off_vcost(p) + v] = r.obj;
         if (lane < n_u) rec[rec_off_vinput(p) + v * n_u + lane] = W.xb[lane];

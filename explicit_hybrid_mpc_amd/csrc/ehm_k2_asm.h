@@ -142,6 +142,26 @@ __device__ inline void quad_simplex(Wave& W, const DevProblem& P, int d, const d
 }
 #endif
 
+#if EHM2_QUAD
+// Gradient of the optimal value of a quadratic-cost point problem: the solver delivers the
+// constraint part -S^T lambda (ipm_solve, gout); the envelope theorem adds the explicit
+// dependence of the cost on the parameter at the optimum z*: F^T z* + C theta + c1.
+__device__ inline void quad_grad_add(const Wave& W, const DevProblem& P, int d,
+                                     const double* theta, double* gout, int lane) {
+    if (!P.Hq) return;
+    const int n = P.n, p = P.p;
+    if (lane < p) {
+        const double* Fq = P.Fq + ((size_t)d * p + lane) * n;      // column `lane` of F
+        double a = P.c1q[(size_t)d * p + lane];
+        for (int j = 0; j < n; ++j) a = fma(Fq[j], W.xb[j], a);
+        const double* C = P.Cq + (size_t)d * p * p;
+        for (int r = 0; r < p; ++r) a = fma(C[lane * p + r], theta[r], a);
+        gout[lane] += a;                                            // NaN (unknown) stays NaN
+    }
+    wsync();
+}
+#endif
+
 // P_theta_delta at one parameter value (lib/oracle.py:141-173) or its phase-one form
 //   min tau  s.t.  G z - tau <= w + S theta,  tau >= -1.
 __device__ inline void assemble_point(const Shared& S, Wave& W, double* lp_base,
