@@ -60,35 +60,74 @@ struct DevTree {
 };
 
 // Upper bound of the suboptimality-test optimum t* from the tangent planes of the convex optimal
-// cost at the vertices: V*(theta) >= L_i(theta) = V_i + g_i.(theta - v_i), so for every i
-//   t* <= max_alpha min( Vbar - L_i - eps_a, Vbar - (1+eps_r) L_i )
-//      <= min( max_j [V_j - L_i(v_j)] - eps_a,  max_j [V_j - (1+eps_r) L_i(v_j)] )
-// (both are linear in alpha, so their maxima over the simplex sit at vertices), and t* is at most
-// the smallest of these over i.  A negative bound closes the leaf exactly like t* < 0 would.
-// node = [vertices | vertex costs ...] in LDS, g = the node's (p+1)*p gradients in global memory.
-// Every lane returns the bound (+inf when a gradient is unknown).
+// cost at the vertices: V*(theta) >= L_i(theta) = V_i + g_i.(theta - v_i), so with the 2(p+1)
+// functions, LINEAR in the barycentric weights alpha,
+//     f_{2i}   = Vbar - L_i - eps_a ,      f_{2i+1} = Vbar - (1 + eps_r) L_i ,
+// t* <= max_alpha min_r f_r(alpha).  Two relaxations of that max-min, both in closed form:
+//   * one function at a time: max_alpha f_r sits at a vertex;
+//   * two at a time: max_alpha min(f_a, f_b) sits at a vertex or where an EDGE of the simplex
+//     crosses the plane f_a = f_b (the pieces of a concave piecewise-linear function are
+//     polytopes whose corners are those points),
+// and t* is at most the smallest of all of them.  Measured on closed leaves (CPU oracle, HiGHS
+// duals): the first closes 59 %, the second 93 %, the exact LP over all cuts 95.5 % -- and none
+// ever closes an open node, a negative bound means t* < 0.
+// node = [vertices | vertex costs ...] in LDS, g = the node's (p+1)*p gradients in global memory
+// (NaN = unknown: every function it enters becomes NaN and is skipped), scr = 2(p+1)^2 doubles of
+// LDS scratch.  Every lane returns the bound (+1e300 when nothing is known).
 __device__ inline double cut_bound(const double* node, const double* g, int p, double eps_a,
-                                   double eps_r, int lane) {
-    const double* V = node + (p + 1) * p;
+                                   double eps_r, int lane, double* scr) {
+    const int na = p + 1, nr = 2 * na;
+    const double* V = node + na * p;
+    for (int k = lane; k < na * na; k += 64) {      // f_r at the vertices
+        const int i = k / na, j = k - i * na;
+        double d = 0.0;
+        for (int q = 0; q < p; ++q) d = fma(g[i * p + q], node[j * p + q] - node[i * p + q], d);
+        const double Li = V[i] + d;
+        scr[(2 * i) * na + j] = V[j] - Li - eps_a;
+        scr[(2 * i + 1) * na + j] = V[j] - (1.0 + eps_r) * Li;
+    }
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+    __builtin_amdgcn_wave_barrier();
     double b = 1e300;
-    if (lane <= p) {
-        const int i = lane;
-        const double* gi = g + i * p;       // read as needed: no private array, no scratch
+    if (lane < nr) {                                // one function at a time
+        double m = -1e300;
         bool ok = true;
-        double m_abs = -1e300, m_rel = -1e300;
-        for (int j = 0; j <= p; ++j) {
-            double d = 0.0;
-            for (int q = 0; q < p; ++q) d = fma(gi[q], node[j * p + q] - node[i * p + q], d);
-            ok = ok && (d == d);            // an unknown (NaN) gradient poisons d
-            const double Li = V[i] + d;
-            m_abs = fmax(m_abs, V[j] - Li);
-            m_rel = fmax(m_rel, V[j] - (1.0 + eps_r) * Li);
+        for (int j = 0; j < na; ++j) {
+            const double f = scr[lane * na + j];
+            ok = ok && (f == f);
+            m = fmax(m, f);
         }
-        b = ok ? fmin(m_abs - eps_a, m_rel) : 1e300;
+        if (ok) b = m;
+    }
+    const int npairs = nr * (nr - 1) / 2;
+    for (int t = lane; t < npairs; t += 64) {       // two at a time
+        int a = 0, rem = t;                         // t -> (a < c)
+        while (rem >= nr - 1 - a) {
+            rem -= nr - 1 - a;
+            ++a;
+        }
+        const int c = a + 1 + rem;
+        const double* fa = scr + a * na;
+        const double* fc = scr + c * na;
+        double m = -1e300;
+        bool ok = true;
+        for (int j = 0; j < na; ++j) {
+            ok = ok && (fa[j] == fa[j]) && (fc[j] == fc[j]);
+            m = fmax(m, fmin(fa[j], fc[j]));
+        }
+        for (int u = 0; u < na; ++u)
+            for (int v = u + 1; v < na; ++v) {
+                const double du = fa[u] - fc[u], dv = fa[v] - fc[v];
+                if (du * dv < 0.0) {                // the edge (u, v) crosses f_a = f_c
+                    const double sx = du / (du - dv);
+                    m = fmax(m, fma(sx, fa[v] - fa[u], fa[u]));
+                }
+            }
+        if (ok) b = fmin(b, m);
     }
 #pragma unroll
-    for (int o = 8; o > 0; o >>= 1) b = fmin(b, __shfl_xor(b, o, 64));   // lanes 0..15 hold i <= 8
-    return __shfl(b, 0, 64);
+    for (int o = 32; o > 0; o >>= 1) b = fmin(b, __shfl_xor(b, o, 64));
+    return b;
 }
 
 struct DevCounters {

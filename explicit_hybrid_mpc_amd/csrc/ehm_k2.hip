@@ -160,7 +160,7 @@ __global__ __launch_bounds__(EHM_K2_THREADS) void k2_lcss_decide(
             // tangent-plane bound of t* (ehm_dev.h, cut_bound): negative => the leaf is closed,
             // exactly as a negative t* would close it, without solving the LP
             const double bnd = cut_bound(nb.rec, T.grad + (size_t)id * (P.p + 1) * P.p, P.p,
-                                         P.eps_a, P.eps_r, lane);
+                                         P.eps_a, P.eps_r, lane, nb.lp);
             if (bnd < -EHM_CUT_TOL * (1.0 + fabs(nb.rec[rec_off_vcost(P.p)]))) {
                 if (lane == 0) {
                     atomicAdd(&cnt->cert_closed, 1ULL);
@@ -385,7 +385,7 @@ __global__ __launch_bounds__(EHM_K2_THREADS) void k2_persist(
         if (T.grad && sign_only) {
             // tangent-plane bound of t* (ehm_dev.h, cut_bound): negative => closed, no LP
             const double bnd = cut_bound(node, T.grad + (size_t)id * (p + 1) * p, p, P.eps_a,
-                                         P.eps_r, lane);
+                                         P.eps_r, lane, nb.lp);
             if (bnd < -EHM_CUT_TOL * (1.0 + fabs(node[rec_off_vcost(p)]))) {
                 if (lane == 0) {
                     const int dep0 = T.depth[id];
