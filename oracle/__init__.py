@@ -32,6 +32,9 @@ What is restated and from where (paths into the reference tree):
   ``tests/golden/make_known_answers.py``).  The synthetic infinity-norm LP instances of
   BASELINE.json have no counterpart in the reference: for them the oracle is cross-checked
   against a second, independent solver path (``oracle/ipm_numpy.py``).
+* ``oracle/cut_bound.py`` restates the device's tangent-plane bound of the suboptimality-test
+  optimum with HiGHS duals (not a reference function: a check that the bound never falls below
+  the optimum the reference's ``bar_E_delta_R`` problem has).
 * node semantics of the partition algorithms -- ``lib/worker.py:241-417`` (``ecc``,
   ``lcss``): ``oracle/partition_cpu.py`` (iterative, same per-node oracle sequence).
 
