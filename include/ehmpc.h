@@ -103,6 +103,15 @@ int ehm_problem_set_solver(ehm_problem* prob, int generation);
  * lib/oracle.py:285-309) and records a lower bound of |t*|; 1 = solve every test LP to full
  * accuracy (EHM_DECIDE_FULL=1 at create time does the same). */
 int ehm_problem_set_option(ehm_problem* prob, const char* name, double value);
+/* Environment switches read by the library (experiments and A/B measurements; none is needed):
+ *   EHM_SOLVER=1|2, EHM_DECIDE_FULL=1   at ehm_problem_create, as the options above;
+ *   EHM_ENGINE=0|1     overrides ehm_run_opts.engine (1 = persistent frontier kernel);
+ *   EHM_NO_KP=1        persistent kernel at one solver width even where a two-width instance
+ *                      (ehm_kp.hip) is compiled;
+ *   EHM_NO_CUTS=1      no vertex gradients: every leaf is closed by its suboptimality-test LP
+ *                      (the tangent-plane bound is also off under decide_full = 1);
+ *   EHM_KEEP_GOING=1   a run whose oracle solves failed returns its tree instead of
+ *                      EHM_E_NUMERIC;  EHM_DUMP_FAIL=path  writes the failing instance there. */
 int ehm_sync(ehm_problem* prob);
 /* HIP stream the handle enqueues on (a hipStream_t), for event timing by the caller. */
 void* ehm_stream(ehm_problem* prob);
