@@ -83,3 +83,18 @@ def bound_all_cuts(R, V, g, eps_a, eps_r):
     r = linprog(c, A_ub=np.array(A), b_ub=np.array(b), A_eq=Aeq, b_eq=[1.],
                 bounds=[(0, None)] * na + [(None, None)] * 2, method='highs')
     return float(-r.fun)
+
+
+def vertex_gradient_quadratic(model, theta):
+    """
+    (V*, dV*/dtheta) of a quadratic-cost P_theta_delta (oracle/qp_numpy.py): in the
+    uncondensed model the parameter enters only through the rows x_0 = theta (the last n_x
+    equalities), so dV*/dtheta = -nu of those rows -- the same quantity the device forms from
+    the condensed problem as -S^T lambda + F^T z* + C theta + c1 (envelope theorem).
+    """
+    from . import qp_numpy
+    lp = model.lp_point(theta)
+    r = qp_numpy.solve(lp['c'], lp['A_ub'], lp['b_ub'], lp['A_eq'], lp['b_eq'], P=lp['P'])
+    if r.status != 0 and max(r.res_p, r.res_d, r.gap) > 1e-9:
+        raise RuntimeError('vertex solve failed')
+    return float(r.fun), -np.array(r.nu[-len(theta):])

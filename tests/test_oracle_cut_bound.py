@@ -48,3 +48,37 @@ def test_bound_is_valid_and_closes_most_leaves():
             n_open += 1
     assert n_closed >= 10 and n_open >= 10
     assert n_cert >= 0.7 * n_closed
+
+
+def test_bound_is_valid_for_quadratic_costs():
+    """Convexity is all the bound needs: same check with the quadratic cost (QCQP optimum)."""
+    mpc = examples.linear_mpc(0, cost='quadratic')
+    eps_r = 0.02
+    eps_a = helpers.eps_a_rule(mpc, 0.05)
+    orc = OracleCPU(mpc, eps_a, eps_r)
+    model = orc.models[0]
+    half = examples.theta_box(mpc)
+    rng = np.random.default_rng(3)
+    n_neg = n_pos = 0
+    for trial in range(14):
+        scale = [0.03, 0.1, 0.3][trial % 3]
+        R = rng.uniform(-0.6, 0.6, 4) * half + scale * rng.uniform(-1, 1, (5, 4)) * half
+        VG = [cb.vertex_gradient_quadratic(model, v) for v in R]
+        V = np.array([v for v, _ in VG])
+        g = np.array([gr for _, gr in VG])
+        # the gradient really is the gradient: finite difference along a random direction
+        if trial < 3:
+            d = rng.normal(size=4) * 1e-5 * half
+            Vp = cb.vertex_gradient_quadratic(model, R[0] + d)[0]
+            Vm = cb.vertex_gradient_quadratic(model, R[0] - d)[0]
+            assert abs((Vp - Vm) / 2 - g[0] @ d) <= 1e-6 * (abs(g[0] @ d) + 1e-12) + 1e-12
+        rows = cb.rows_at_vertices(R, V, g, eps_a, eps_r)
+        b1, b2 = cb.bound_single(rows), cb.bound_pairs(rows)
+        t_star, _ = orc.slack(R, V, 0)
+        tol = 1e-7 * (1 + abs(t_star))
+        assert b1 >= b2 - tol and b2 >= t_star - tol
+        n_neg += t_star < 0
+        n_pos += t_star >= 0
+        if t_star >= 0:
+            assert b2 >= -tol
+    assert n_neg >= 2 and n_pos >= 2
