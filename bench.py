@@ -124,6 +124,9 @@ def main():
     ap.add_argument('--cpu-seconds', type=float, default=15.)
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--solver', type=int, default=2, help='kernel generation (1 or 2)')
+    ap.add_argument('--mid-first', action='store_true',
+                    help='EXPERIMENTAL (not validated on the device yet): persistent kernel with '
+                         'the midpoint solve before the suboptimality test')
     ap.add_argument('--engine', type=int, default=1,
                     help='1 = persistent frontier kernel (one launch per partition; single rank, '
                          'shared-block kernels), 0 = level-synchronous sweeps')
@@ -159,6 +162,8 @@ def main():
     if not wide:
         gp.set_solver(args.solver)
     gp.set_option('decide_full', 1 if args.decide_full else 0)
+    if args.mid_first:
+        gp.set_option('mid_first', 1)
     static = args.balance == 'static' and not args.status_dir
     persistent = (args.engine == 1 and (world == 1 or static) and args.solver == 2 and
                   not wide and not args.status_dir)
@@ -219,7 +224,7 @@ def main():
     elapsed = time.perf_counter() - t0
     # totals over ranks (max time, summed work)
     keys = ['lp_solves', 'ipm_iters', 'n_nodes', 'n_closed', 'ref_solves', 'decide_solves',
-            'decide_iters', 'cert_closed']
+            'decide_iters', 'cert_closed', 'witness_open']
     if rank > 0:
         # the top of the tree is grown identically on every rank: count it once (rank 0)
         for i in infos:
@@ -288,6 +293,7 @@ def main():
                 'reference_equivalent_solves_per_step': agg['ref_solves'] / K,
                 'reference_equivalent_solves_per_s': agg['ref_solves'] / elapsed_max,
                 'leaves_closed_without_lp_per_step': agg['cert_closed'] / K,
+                'nodes_proved_open_by_midpoint_per_step': agg['witness_open'] / K,
                 'mean_ipm_iterations': agg['ipm_iters'] / max(agg['lp_solves'], 1),
                 'sweeps': info0['sweeps'], 'tree_depth': info0['max_depth'],
                 'min_decision_margin': info0['min_margin'],

@@ -76,7 +76,7 @@ class TreeInfo(ctypes.Structure):
                 ('expand_launches', ctypes.c_int64), ('decide_solves', ctypes.c_int64),
                 ('decide_iters', ctypes.c_int64), ('replicated_closed', ctypes.c_int64),
                 ('replicated_nodes', ctypes.c_int64), ('replicated_solves', ctypes.c_int64),
-                ('cert_closed', ctypes.c_int64)]
+                ('cert_closed', ctypes.c_int64), ('witness_open', ctypes.c_int64)]
 
 
 class Progress(ctypes.Structure):

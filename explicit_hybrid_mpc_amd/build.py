@@ -32,6 +32,8 @@ K2Q_NPS = (8, 16, 24, 32)
 # must match EHM_KP_ALL in ehm_capi.hip
 KP_INSTANCES = ((16, 8, 2), (16, 8, 3), (20, 12, 2), (20, 12, 3), (24, 16, 2), (24, 16, 3),
                 (28, 20, 2), (28, 20, 3), (32, 24, 2), (32, 24, 3), (32, 24, 4), (28, 20, 4))
+# the same with the midpoint solve first (experimental; must match EHM_KPM_ALL in ehm_capi.hip)
+KPM_INSTANCES = ((28, 20, 3), (24, 16, 3), (20, 12, 2))
 # wide kernels (ehm_k3.hip): row slots per thread, rows <= 256 * slots; must match the
 # ehm_k3_api_* getters in ehm_capi.hip
 K3_RS = (2, 4)
@@ -76,6 +78,11 @@ def _objects():
         objs.append((os.path.join(OBJ_DIR, 'ehm_kp_%d_%d_%d.o' % (npd, npe, sl)),
                      os.path.join(SRC_DIR, 'ehm_kp.hip'),
                      ['-DEHM_NPD=%d' % npd, '-DEHM_NPE=%d' % npe, '-DEHM_SLOTS=%d' % sl]))
+    for npd, npe, sl in KPM_INSTANCES:
+        objs.append((os.path.join(OBJ_DIR, 'ehm_kpm_%d_%d_%d.o' % (npd, npe, sl)),
+                     os.path.join(SRC_DIR, 'ehm_kp.hip'),
+                     ['-DEHM_NPD=%d' % npd, '-DEHM_NPE=%d' % npe, '-DEHM_SLOTS=%d' % sl,
+                      '-DEHM_PERSIST_MIDFIRST=1']))
     for rs in K3_RS:
         objs.append((os.path.join(OBJ_DIR, 'ehm_k3_%d.o' % rs),
                      os.path.join(SRC_DIR, 'ehm_k3.hip'),

@@ -46,6 +46,13 @@ EHM_KP_ALL(EHM_KP_DECL)
 #define EHM_KP_ENTRY(D, E, SL) ehm_kp_api_##D##_##E##_##SL,
 typedef const ehm::KpApi* (*kp_getter)();
 static const kp_getter g_kp_getters[] = {EHM_KP_ALL(EHM_KP_ENTRY)};
+// the same with the midpoint solve BEFORE the suboptimality test (-DEHM_PERSIST_MIDFIRST=1;
+// option "mid_first", off by default: not yet validated on the device)
+#define EHM_KPM_ALL(X) X(28, 20, 3) X(24, 16, 3) X(20, 12, 2)
+#define EHM_KPM_DECL(D, E, SL) extern "C" const ehm::KpApi* ehm_kpm_api_##D##_##E##_##SL();
+EHM_KPM_ALL(EHM_KPM_DECL)
+#define EHM_KPM_ENTRY(D, E, SL) ehm_kpm_api_##D##_##E##_##SL,
+static const kp_getter g_kpm_getters[] = {EHM_KPM_ALL(EHM_KPM_ENTRY)};
 #define EHM_V1_MAX_N 32     // limits of the generation-1 and wave-local kernels
 #define EHM_V1_MAX_M 256
 
@@ -466,6 +473,7 @@ struct ehm_problem {
     bool k2q_ok = false;     // a quadratic shared-block instance fits (ehm_k2.hip, EHM2_QUAD)
     bool v1_ok = false;      // the generation-1 kernels fit this problem
     int decide_full = 0;     // 1 = the suboptimality test solves to full accuracy (no sign-only stop)
+    int mid_first = 0;       // 1 = persistent kernel with the midpoint solve first (experimental)
     int solver_gen = 2;      // 1 = one wavefront per workgroup (ehm_kernels.h), 2 = ehm_k2.hip
     DevBuf seg;              // commutation segment offsets of a sorted batch
     std::set<const K2Api*> k2_ready;
@@ -741,6 +749,7 @@ int ehm_problem_create(const ehm_problem_desc* d, int device, ehm_problem** out)
     }
     if (const char* e = getenv("EHM_SOLVER")) P->solver_gen = (atoi(e) == 1) ? 1 : 2;
     if (const char* e = getenv("EHM_DECIDE_FULL")) P->decide_full = atoi(e) ? 1 : 0;
+    if (const char* e = getenv("EHM_MID_FIRST")) P->mid_first = atoi(e) ? 1 : 0;
     P->delta_len = d->delta_len;
     if (d->deltas && d->delta_len > 0)
         P->deltas.assign(d->deltas, d->deltas + (size_t)nd * d->delta_len);
@@ -902,6 +911,10 @@ int ehm_problem_set_option(ehm_problem* P, const char* name, double value) {
     if (!strcmp(name, "solver")) return ehm_problem_set_solver(P, (int)value);
     if (!strcmp(name, "decide_full")) {
         P->decide_full = value != 0.0;
+        return EHM_OK;
+    }
+    if (!strcmp(name, "mid_first")) {
+        P->mid_first = value != 0.0;
         return EHM_OK;
     }
     return fail(EHM_E_INVALID, "unknown option '%s'", name);
@@ -2028,11 +2041,18 @@ static int persistent_run(ehm_tree* T) {
         const K2Api* ad = k2_pick(n_d, lp_slots(P->dp.m, ne_d), false);
         const K2Api* ae = k2_pick(n_e, lp_slots(P->dp.m, ne_e), false);
         const int slots = std::max(lp_slots(P->dp.m, ne_d), lp_slots(P->dp.m, ne_e));
-        if (ad && ae && ae->np < ad->np)
+        if (ad && ae && ae->np < ad->np) {
             for (kp_getter g : g_kp_getters) {
                 const KpApi* a = g();
                 if (a->np_decide == ad->np && a->np_expand == ae->np && a->slots == slots) kp = a;
             }
+            if (P->mid_first && !P->decide_full)
+                for (kp_getter g : g_kpm_getters) {
+                    const KpApi* a = g();
+                    if (a->np_decide == ad->np && a->np_expand == ae->np && a->slots == slots)
+                        kp = a;
+                }
+        }
         if (kp) {
             const size_t shared = kp->shared_doubles(P->dp);
             const size_t wave = kp->wave_doubles(P->dp, n_d, ne_d, n_e);
@@ -2411,6 +2431,7 @@ int ehm_partition_finish(ehm_tree* T) {
     T->info.decide_solves = (int64_t)(c1.slack_solves - R.c0.slack_solves);
     T->info.decide_iters = (int64_t)(c1.slack_iters - R.c0.slack_iters);
     T->info.cert_closed = (int64_t)(c1.cert_closed - R.c0.cert_closed);
+    T->info.witness_open = (int64_t)(c1.wit_open - R.c0.wit_open);
     T->info.replicated_closed = R.pre_closed;
     T->info.replicated_nodes = R.pre_nodes;
     T->info.replicated_solves = R.pre_solves;

@@ -332,6 +332,9 @@ __global__ __launch_bounds__(EHM_K2_THREADS) void k2_lcss_expand(
 //     (a node's fate depends on its own record only).  ehm_tree_export relabels to the
 //     breadth-first order of the level-synchronous engine.
 #define EHM_PERSIST_WATCHDOG_TICKS (60LL * 100000000LL)    // 60 s of the 100 MHz wall clock
+#ifndef EHM_PERSIST_MIDFIRST
+#define EHM_PERSIST_MIDFIRST 0
+#endif
 __global__ __launch_bounds__(EHM_K2_THREADS) void k2_persist(
     DevProblem P, DevTree T, int32_t* slots, int n_slots, PersistCtl* ctl, int node_cap,
     DevCounters* cnt, int wave_doubles, int sign_only, int max_depth) {
@@ -347,7 +350,7 @@ __global__ __launch_bounds__(EHM_K2_THREADS) void k2_persist(
     unsigned long long* wst = reinterpret_cast<unsigned long long*>(nb.aug);
     double* wmargin = nb.aug + 12;
     enum { W_SOLVES = 0, W_ITERS, W_STALLED, W_ERRORS, W_SLACK, W_SLACK_ITERS, W_CLOSED, W_SPLITS,
-           W_DEPTH, W_TRUNC, W_CERT };
+           W_DEPTH, W_TRUNC, W_CERT, W_WIT };
     if (lane0 < 12) wst[lane0] = 0ULL;
     if (lane0 == 0) *wmargin = 1e300;
     wsync();
@@ -401,6 +404,156 @@ __global__ __launch_bounds__(EHM_K2_THREADS) void k2_persist(
                 continue;
             }
         }
+#if EHM_PERSIST_MIDFIRST
+        // Midpoint first (EHM_PERSIST_MIDFIRST objects; NOT yet validated on the device, off by
+        // default -- DESIGN.md section 7c item 1): after the tangent-plane bound has taken out 97 %
+        // of the closed leaves, almost every node that reaches an LP is open and needs its midpoint
+        // solve anyway.  Doing that solve FIRST gives a witness: at theta = mid the interpolated
+        // cost is (V_bi + V_bj)/2 and the optimal cost is the solve's optimum, so
+        //     t_mid = min( Vbar - J_mid - eps_a , Vbar - (1 + eps_r) J_mid ) <= t* ,
+        // and t_mid > 0 proves the node open without its suboptimality-test LP (42 % of the open
+        // nodes of the bench tree, tools/midpoint_certificate.py).  Otherwise the LP decides as
+        // before; a node it closes has paid for a midpoint solve it did not need (3 % of them).
+        const int dep = T.depth[id];
+        const bool can_split = !(max_depth > 0 && dep >= max_depth);
+        double* mid = nb.th;
+        double* stash = nb.rec - 0 + (size_t)wave_doubles - 16;     // last 16 doubles of the wave's LDS
+        int bi = 0, bj = 1;
+        int its = 0;
+        double Jm = 0.0;
+        int mid_status = 1, mid_iters = 0;
+        bool open = false;
+        double tst = 0.0, margin = 0.0;
+        bool decided = false;
+        if (can_split) {
+            longest_edge(node, p, bi, bj);
+            if (lane < p) {
+#pragma clang fp contract(off)
+                mid[lane] = (node[bi * p + lane] + node[bj * p + lane]) / 2.0;
+            }
+            wsync();
+            {
+            Wave Wm;
+            IpmResult rm;
+            for (int attempt = 0; attempt < EHM2_ATTEMPTS; ++attempt) {
+                double b[SLOTS];
+                const int ln = pin(lane);
+                assemble_point(S, Wm, nb.lp, mid, false, b, ln, P, 0);
+                rm = ipm_solve(S, Wm, b, ln, false, step_fraction(attempt), T.grad ? nb.F : nullptr);
+                its += rm.iters;
+                if (rm.status == 0) break;
+            }
+#if EHM2_QUAD
+            if (T.grad) quad_grad_add(Wm, P, 0, mid, nb.F, lane);
+#endif
+            Jm = rm.obj;
+            mid_status = rm.status;
+            mid_iters = its;
+            if (lane < n_u) stash[lane] = Wm.xb[lane];
+            }
+            if (T.grad && lane < p) stash[8 + lane] = nb.F[lane];
+            wsync();
+            if (sign_only && mid_status == 0) {
+                const double* Vc = node + rec_off_vcost(p);
+                const double vb = 0.5 * (Vc[bi] + Vc[bj]);
+                const double tw = fmin(vb - Jm - P.eps_a, vb - (1.0 + P.eps_r) * Jm);
+                if (tw > EHM_CUT_TOL * (1.0 + fabs(vb))) {
+                    open = true;
+                    decided = true;
+                    tst = tw;
+                    margin = tw;
+                    if (lane == 0) wst[W_WIT] += 1;
+                }
+            }
+        }
+        if (!decided) {
+            Wave W;
+            IpmResult r;
+            its = 0;
+            for (int attempt = 0; attempt < EHM2_ATTEMPTS; ++attempt) {
+                double b[SLOTS];
+                const int ln = pin(lane);
+                assemble_simplex(S, W, nb, node, node + rec_off_vcost(p), SX_SLACK, P.eps_a, P.eps_r,
+                                 b, ln, P, 0);
+                r = ipm_solve(S, W, b, ln, sign_only != 0, step_fraction(attempt));
+                its += r.iters;
+                if (r.status == 0) break;
+            }
+            tst = -r.obj;
+            open = (tst >= 0.0);
+            margin = r.margin;
+            const int slack_status = r.status;
+            if (lane == 0) {
+                wst[W_SOLVES] += 1;
+                wst[W_ITERS] += (unsigned long long)its;
+                wst[W_SLACK] += 1;
+                wst[W_SLACK_ITERS] += (unsigned long long)its;
+                if (slack_status != 0) {
+                    wst[W_STALLED] += 1;
+                    wst[W_ERRORS] += 1;
+                    T.flags[id] |= 8;
+                }
+            }
+        }
+        if (lane == 0) {
+            if (can_split) {        // the midpoint solve was done, whatever became of the node
+                wst[W_SOLVES] += 1;
+                wst[W_ITERS] += (unsigned long long)mid_iters;
+                if (mid_status != 0 && open) {
+                    wst[W_STALLED] += 1;
+                    wst[W_ERRORS] += 1;
+                    T.flags[id] |= 16;
+                }
+            }
+            *wmargin = fmin(*wmargin, margin);
+            if ((unsigned long long)dep > wst[W_DEPTH]) wst[W_DEPTH] = (unsigned long long)dep;
+            T.tstar[id] = tst;
+            if (!open) {
+                T.flags[id] |= 1;
+                wst[W_CLOSED] += 1;
+            }
+        }
+        if (!open) {
+            if (lane == 0) atomicSub(&ctl->pending, 1);
+            wsync();
+            continue;
+        }
+        if (!can_split) {
+            if (lane == 0) {
+                wst[W_TRUNC] = 1;
+                atomicSub(&ctl->pending, 1);
+            }
+            wsync();
+            continue;
+        }
+        // ---- children (the midpoint solve is in Jm / stash) --------------------------------------
+        int c0 = 0;
+        if (lane == 0) c0 = atomicAdd(&ctl->n_nodes, 2);
+        c0 = __builtin_amdgcn_readfirstlane(c0);
+        if (c0 + 2 > node_cap) {
+            if (lane == 0) {
+                atomicMax(&ctl->abort, 1);
+                atomicSub(&ctl->pending, 1);
+            }
+            break;
+        }
+        const int d = T.didx[id];
+        struct { double obj; } r = {Jm};      // the child-record loop below reads r.obj
+        if (T.grad) {       // children's vertex gradients, written through like the records
+            const int ng = (p + 1) * p;
+            const double* gp_ = T.grad + (size_t)id * ng;
+            double* g0 = T.grad + (size_t)c0 * ng;
+            for (int k = lane; k < ng; k += 64) {
+                const double gv = gp_[k];
+                const double a0 = (k >= bi * p && k < bi * p + p) ? stash[8 + k - bi * p] : gv;
+                const double a1 = (k >= bj * p && k < bj * p + p) ? stash[8 + k - bj * p] : gv;
+                __hip_atomic_store(g0 + k, a0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                __hip_atomic_store(g0 + ng + k, a1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            }
+        }
+        if (lane == 0) wst[W_SPLITS] += 1;
+        const double* xmid = stash;
+#else
         Wave W;
         IpmResult r;
         int its = 0;
@@ -503,6 +656,8 @@ __global__ __launch_bounds__(EHM_K2_THREADS) void k2_persist(
                 T.flags[id] |= 16;
             }
         }
+        const double* xmid = W.xb;
+#endif
         double* rec0 = T.rec + (size_t)c0 * T.rec_stride;
         double* rec1 = rec0 + T.rec_stride;
         const int ov = rec_off_vcost(p), ou = rec_off_vinput(p);
@@ -516,8 +671,8 @@ __global__ __launch_bounds__(EHM_K2_THREADS) void k2_persist(
                 if (k - ov == bj) v1 = r.obj;
             } else {
                 const int q = k - ou;
-                if (q >= bi * n_u && q < bi * n_u + n_u) v0 = W.xb[q - bi * n_u];
-                if (q >= bj * n_u && q < bj * n_u + n_u) v1 = W.xb[q - bj * n_u];
+                if (q >= bi * n_u && q < bi * n_u + n_u) v0 = xmid[q - bi * n_u];
+                if (q >= bj * n_u && q < bj * n_u + n_u) v1 = xmid[q - bj * n_u];
             }
             // everything a child's consumer reads or later overwrites is written THROUGH to the
             // device coherence point (agent-scope atomic stores): visible to the other XCDs
@@ -569,6 +724,7 @@ __global__ __launch_bounds__(EHM_K2_THREADS) void k2_persist(
         atomicAdd(&cnt->slack_iters, wst[W_SLACK_ITERS]);
         atomicMin(&cnt->min_margin_bits, (unsigned long long)__double_as_longlong(*wmargin));
         if (wst[W_CERT]) atomicAdd(&cnt->cert_closed, wst[W_CERT]);
+        if (wst[W_WIT]) atomicAdd(&cnt->wit_open, wst[W_WIT]);
         atomicAdd(&ctl->closed, wst[W_CLOSED]);
         atomicAdd(&ctl->splits, wst[W_SPLITS]);
         atomicMax(&ctl->max_depth_seen, (int)wst[W_DEPTH]);

@@ -113,3 +113,28 @@ def test_partition_identical_across_generations_and_decide_modes(abs_frac):
     assert sign.info['min_margin'] <= full.info['min_margin'] * (1 + 1e-9)
     assert sign.info['decide_iters'] < 0.8 * full.info['decide_iters']
     assert ((sign.tstar >= 0) == (full.tstar >= 0)).all()
+
+
+@pytest.mark.skipif(not __import__('os').environ.get('EHM_TEST_EXPERIMENTAL'),
+                    reason='midpoint-first flow: written without device time to validate it; '
+                           'EHM_TEST_EXPERIMENTAL=1 runs the check')
+def test_midpoint_first_flow_grows_the_same_tree():
+    """Option "mid_first" (include/ehmpc.h): identical tree, fewer suboptimality-test LPs."""
+    from explicit_hybrid_mpc_amd import engine, examples
+    from explicit_hybrid_mpc_amd import tools as ehm_tools
+    mpc = helpers.make_instance('lin', 0)
+    gp = engine.GpuProblem(mpc.compile(), 1., 1.)
+    V = examples.box_vertices(examples.theta_box(mpc))
+    gp.set_eps(float(np.max(gp.solve_pt(0.05 * V)[0])), 1e-2)
+    roots, _ = ehm_tools.delaunay_roots(V)
+    ref = gp.partition(roots, action='ecc', max_nodes=1 << 22)
+    gp.set_option('mid_first', 1)
+    new = gp.partition(roots, action='ecc', max_nodes=1 << 22)
+    gp.close()
+    assert new.info['witness_open'] > 0
+    assert new.info['decide_solves'] < ref.info['decide_solves']
+    assert new.n_nodes == ref.n_nodes
+    assert np.array_equal(new.vertices, ref.vertices) and np.array_equal(new.left, ref.left)
+    assert np.array_equal(new.flags & 1, ref.flags & 1)
+    assert rel(new.vertex_costs.ravel(), ref.vertex_costs.ravel()) < RTOL
+    assert ((new.tstar >= 0) == (ref.tstar >= 0)).all()

@@ -87,6 +87,42 @@ sub('''        its = 0;
         r.iters = its;
         r.status = re.status;
         r.obj = re.obj;''')
+sub("        const double* xmid = W.xb;\n#endif", "        const double* xmid = W.xb;\n#endif")
+
+# --- the midpoint-first flow (EHM_PERSIST_MIDFIRST objects) -------------------------------------
+sub('''            Wave Wm;
+            IpmResult rm;
+            for (int attempt = 0; attempt < EHM2_ATTEMPTS; ++attempt) {
+                double b[SLOTS];
+                const int ln = kd::pin(lane);
+                assemble_point(S, Wm, nb.lp, mid, false, b, ln, P, 0);
+                rm = ipm_solve(S, Wm, b, ln, false, step_fraction(attempt), T.grad ? nb.F : nullptr);''',
+    '''            ke::Wave Wm;
+            ke::IpmResult rm;
+            for (int attempt = 0; attempt < EHM2_ATTEMPTS; ++attempt) {
+                double b[ke::SLOTS];
+                const int ln = kd::pin(lane);
+                ke::assemble_point(Se, Wm, nbe.lp, mid, false, b, ln, P, 0);
+                rm = ke::ipm_solve(Se, Wm, b, ln, false, ke::step_fraction(attempt),
+                                   T.grad ? nb.F : nullptr);''')
+sub('''            Wave W;
+            IpmResult r;
+            its = 0;
+            for (int attempt = 0; attempt < EHM2_ATTEMPTS; ++attempt) {
+                double b[SLOTS];
+                const int ln = kd::pin(lane);
+                assemble_simplex(S, W, nb, node, node + rec_off_vcost(p), SX_SLACK, P.eps_a, P.eps_r,
+                                 b, ln, P, 0);
+                r = ipm_solve(S, W, b, ln, sign_only != 0, step_fraction(attempt));''',
+    '''            kd::Wave W;
+            kd::IpmResult r;
+            its = 0;
+            for (int attempt = 0; attempt < EHM2_ATTEMPTS; ++attempt) {
+                double b[kd::SLOTS];
+                const int ln = kd::pin(lane);
+                kd::assemble_simplex(S, W, nb, node, node + rec_off_vcost(p), SX_SLACK, P.eps_a,
+                                     P.eps_r, b, ln, P, 0);
+                r = kd::ipm_solve(S, W, b, ln, sign_only != 0, kd::step_fraction(attempt));''')
 
 HEAD = '''// GENERATED by tools/gen_kp.py from k2_persist in ehm_k2.hip -- edit there, then regenerate.
 //
@@ -116,8 +152,13 @@ using namespace ehm;
 // one named namespace per instance (kernels of different objects must not share a symbol)
 #define KP_CAT2(a, b, c, d) a##b##_##c##_##d
 #define KP_CAT(a, b, c, d) KP_CAT2(a, b, c, d)
+#ifndef EHM_PERSIST_MIDFIRST
+#define EHM_PERSIST_MIDFIRST 0
+#endif
 #if EHM2_QUAD
 #define KP_NS KP_CAT(ehm_kpq_, EHM_NPD, EHM_NPE, EHM_SLOTS)
+#elif EHM_PERSIST_MIDFIRST
+#define KP_NS KP_CAT(ehm_kpm_, EHM_NPD, EHM_NPE, EHM_SLOTS)
 #else
 #define KP_NS KP_CAT(ehm_kp_, EHM_NPD, EHM_NPE, EHM_SLOTS)
 #endif
@@ -135,7 +176,8 @@ hipError_t set_lds(int bytes) {
 }
 size_t wave_doubles_for(const DevProblem& P, int n_lp_d, int ne_d, int n_lp_e) {
     const size_t a = kd::wave_lp_doubles(n_lp_d, ne_d), b = ke::wave_lp_doubles(n_lp_e, 0);
-    return k2_node_doubles(P.p, P.n_u) + (a > b ? a : b);
+    // (+16: the midpoint-first flow parks the midpoint solve's input and gradient there)
+    return k2_node_doubles(P.p, P.n_u) + (a > b ? a : b) + (EHM_PERSIST_MIDFIRST ? 16 : 0);
 }
 size_t shared_doubles_for(const DevProblem& P) { return kd::shared_doubles(P); }
 void l_persist(const K2Launch& L, DevProblem P, DevTree T, int32_t* slots, int n_slots,
@@ -151,6 +193,10 @@ const KpApi g_api = {EHM_NPD, EHM_NPE, EHM_SLOTS, EHM_K2_THREADS, set_lds, wave_
 
 #if EHM2_QUAD
 extern "C" const ehm::KpApi* KP_CAT(ehm_kpq_api_, EHM_NPD, EHM_NPE, EHM_SLOTS)() {
+    return &KP_NS::g_api;
+}
+#elif EHM_PERSIST_MIDFIRST
+extern "C" const ehm::KpApi* KP_CAT(ehm_kpm_api_, EHM_NPD, EHM_NPE, EHM_SLOTS)() {
     return &KP_NS::g_api;
 }
 #else
