@@ -422,6 +422,7 @@ __global__ __launch_bounds__(EHM_K2_THREADS) void k2_persist(
         int its = 0;
         double Jm = 0.0;
         int mid_status = 1, mid_iters = 0;
+        bool mid_conv = false;
         bool open = false;
         double tst = 0.0, margin = 0.0;
         bool decided = false;
@@ -448,12 +449,13 @@ __global__ __launch_bounds__(EHM_K2_THREADS) void k2_persist(
 #endif
             Jm = rm.obj;
             mid_status = rm.status;
+            mid_conv = (rm.status == 0) && (rm.merit <= 1.0);    // not merely "accepted"
             mid_iters = its;
             if (lane < n_u) stash[lane] = Wm.xb[lane];
             }
             if (T.grad && lane < p) stash[8 + lane] = nb.F[lane];
             wsync();
-            if (sign_only && mid_status == 0) {
+            if (sign_only && mid_conv) {
                 const double* Vc = node + rec_off_vcost(p);
                 const double vb = 0.5 * (Vc[bi] + Vc[bj]);
                 const double tw = fmin(vb - Jm - P.eps_a, vb - (1.0 + P.eps_r) * Jm);
