@@ -124,9 +124,9 @@ def main():
     ap.add_argument('--cpu-seconds', type=float, default=15.)
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--solver', type=int, default=2, help='kernel generation (1 or 2)')
-    ap.add_argument('--mid-first', action='store_true',
-                    help='EXPERIMENTAL (not validated on the device yet): persistent kernel with '
-                         'the midpoint solve before the suboptimality test')
+    ap.add_argument('--no-mid-first', action='store_true',
+                    help='persistent kernel WITHOUT the midpoint solve before the suboptimality '
+                         'test (the round-1 flow; A/B measurements)')
     ap.add_argument('--engine', type=int, default=1,
                     help='1 = persistent frontier kernel (one launch per partition; single rank, '
                          'shared-block kernels), 0 = level-synchronous sweeps')
@@ -162,8 +162,8 @@ def main():
     if not wide:
         gp.set_solver(args.solver)
     gp.set_option('decide_full', 1 if args.decide_full else 0)
-    if args.mid_first:
-        gp.set_option('mid_first', 1)
+    if args.no_mid_first:
+        gp.set_option('mid_first', 0)
     static = args.balance == 'static' and not args.status_dir
     persistent = (args.engine == 1 and (world == 1 or static) and args.solver == 2 and
                   not wide and not args.status_dir)

@@ -32,8 +32,8 @@ K2Q_NPS = (8, 16, 24, 32)
 # must match EHM_KP_ALL in ehm_capi.hip
 KP_INSTANCES = ((16, 8, 2), (16, 8, 3), (20, 12, 2), (20, 12, 3), (24, 16, 2), (24, 16, 3),
                 (28, 20, 2), (28, 20, 3), (32, 24, 2), (32, 24, 3), (32, 24, 4), (28, 20, 4))
-# the same with the midpoint solve first (experimental; must match EHM_KPM_ALL in ehm_capi.hip)
-KPM_INSTANCES = ((28, 20, 3), (24, 16, 3), (20, 12, 2))
+# the same with the midpoint solve first (the default flow; EHM_KPM_ALL in ehm_capi.hip)
+KPM_INSTANCES = KP_INSTANCES
 # wide kernels (ehm_k3.hip): row slots per thread, rows <= 256 * slots; must match the
 # ehm_k3_api_* getters in ehm_capi.hip
 K3_RS = (2, 4)

@@ -101,10 +101,10 @@ int ehm_problem_set_solver(ehm_problem* prob, int generation);
  * suboptimality-test sweep of ehm_partition_run stops each LP as soon as the SIGN of its
  * optimum t* is certain (the reference's bar_E is a feasibility problem,
  * lib/oracle.py:285-309) and records a lower bound of |t*|; 1 = solve every test LP to full
- * accuracy (EHM_DECIDE_FULL=1 at create time does the same); "mid_first" (0|1, default 0,
- * EXPERIMENTAL -- written at the end of round 1 with no device time left to validate it): the
+ * accuracy (EHM_DECIDE_FULL=1 at create time does the same); "mid_first" (0|1, default 1): the
  * persistent frontier kernel solves a node's midpoint problem before its suboptimality test and
- * skips the test when the midpoint already proves the node open (EHM_MID_FIRST=1). */
+ * skips the test when the midpoint already proves the node open (42 % of the open nodes of the
+ * bench tree; identical tree, tests/test_gpu_kernel_generations.py; EHM_MID_FIRST=0|1). */
 int ehm_problem_set_option(ehm_problem* prob, const char* name, double value);
 /* Environment switches read by the library (experiments and A/B measurements; none is needed):
  *   EHM_SOLVER=1|2, EHM_DECIDE_FULL=1   at ehm_problem_create, as the options above;

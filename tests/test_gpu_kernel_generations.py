@@ -115,9 +115,6 @@ def test_partition_identical_across_generations_and_decide_modes(abs_frac):
     assert ((sign.tstar >= 0) == (full.tstar >= 0)).all()
 
 
-@pytest.mark.skipif(not __import__('os').environ.get('EHM_TEST_EXPERIMENTAL'),
-                    reason='midpoint-first flow: written without device time to validate it; '
-                           'EHM_TEST_EXPERIMENTAL=1 runs the check')
 def test_midpoint_first_flow_grows_the_same_tree():
     """Option "mid_first" (include/ehmpc.h): identical tree, fewer suboptimality-test LPs."""
     from explicit_hybrid_mpc_amd import engine, examples
@@ -127,6 +124,7 @@ def test_midpoint_first_flow_grows_the_same_tree():
     V = examples.box_vertices(examples.theta_box(mpc))
     gp.set_eps(float(np.max(gp.solve_pt(0.05 * V)[0])), 1e-2)
     roots, _ = ehm_tools.delaunay_roots(V)
+    gp.set_option('mid_first', 0)
     ref = gp.partition(roots, action='ecc', max_nodes=1 << 22)
     gp.set_option('mid_first', 1)
     new = gp.partition(roots, action='ecc', max_nodes=1 << 22)
