@@ -21,7 +21,7 @@ LIB_DIR = os.path.join(HERE, 'lib')
 OBJ_DIR = os.path.join(LIB_DIR, 'obj')
 LIB = os.path.join(LIB_DIR, 'libehmpc.so')
 HEADERS = ['ehm_ipm.h', 'ehm_kernels.h', 'ehm_dev.h', 'ehm_k2.h', 'ehm_ipm2.h', 'ehm_ipm3.h',
-           'ehm_k2_asm.h',
+           'ehm_k2_asm.h', 'ehm_hybrid.h',
            os.path.join('..', '..', 'include', 'ehmpc.h')]
 # must match EHM_K2_ALL in ehm_capi.hip
 K2_NPS = (8, 12, 16, 20, 24, 28, 32)

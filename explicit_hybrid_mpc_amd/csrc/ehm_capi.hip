@@ -488,6 +488,7 @@ struct ehm_problem {
     DevBuf pq_slots, pq_ctl;   // persistent engine: queue slots, control block
     DevBuf in0, in1, in2, out0, out1, out2, out3;
     DevCounters* d_cnt = nullptr;
+    struct ehm_tree* active_run = nullptr;   // the partition run that owns the scratch above
     long long launches = 0;
     long long fallbacks = 0;   // LPs handed from the generation-2 to the generation-1 kernels
     long long slivers = 0;     // (simplex, commutation) pairs dropped as interior-free (slack_all)
@@ -495,8 +496,11 @@ struct ehm_problem {
     size_t lds_point = 0, lds_simplex = 0, lds_expand = 0;
 };
 
+struct HyState;      // multi-commutation engine (ehm_hybrid.h)
+
 struct ehm_tree {
     ehm_problem* prob = nullptr;
+    HyState* hy = nullptr;
     DevTree dt{};
     long long cap = 0;       // allocated node records (a cached pool may be larger than asked for)
     long long limit = 0;     // max_nodes of this run: the capacity the caller agreed to
@@ -981,7 +985,7 @@ static int point_batch(ehm_problem* P, int64_t n_inst, const double* theta,
             return rc;
         cfg.api->point(cfg.L, P->dp, (long long)n_inst, P->in0.as<double>(),
                        P->seg.as<int32_t>(), feas, P->out0.as<double>(), P->out1.as<double>(),
-                       d_status, d_iters, P->d_cnt);
+                       d_status, d_iters, P->d_cnt, K2Gather{});
         P->launches++;
         HIP_TRY(hipGetLastError(), EHM_E_HIP);
         std::vector<double> Js((size_t)n_inst), us(u0 ? (size_t)n_inst * n_u : 0);
@@ -1135,7 +1139,7 @@ static int simplex_batch(ehm_problem* P, int64_t n_inst, const double* R, const 
         cfg.api->simplex(cfg.L, P->dp, (long long)n_inst, P->in0.as<double>(),
                          P->in2.as<double>(), P->seg.as<int32_t>(), slack, P->out0.as<double>(),
                          alpha ? P->out1.as<double>() : (double*)nullptr, d_status,
-                         d_status + n_inst, P->d_cnt);
+                         d_status + n_inst, P->d_cnt, K2Gather{});
         P->launches++;
         HIP_TRY(hipGetLastError(), EHM_E_HIP);
         std::vector<double> objs((size_t)n_inst), als(alpha ? (size_t)n_inst * nv : 0);
@@ -1769,9 +1773,17 @@ int ehm_volume_batch(int device, int64_t n, int32_t p, const double* R, double* 
 }
 
 // ---- partition engine -------------------------------------------------------------------------
+#include "ehm_hybrid.h"
+
 int ehm_tree_destroy(ehm_tree* T) {
     if (!T) return EHM_OK;
     if (T->prob) (void)hipSetDevice(T->prob->device);
+    if (T->prob && T->prob->active_run == T) T->prob->active_run = nullptr;
+    if (T->hy) {
+        T->hy->release();
+        delete T->hy;
+        T->hy = nullptr;
+    }
     for (hipEvent_t e : T->run.evs) (void)hipEventDestroy(e);
     T->run.evs.clear();
     if (T->run.ev0) (void)hipEventDestroy(T->run.ev0);
@@ -1890,10 +1902,10 @@ int ehm_partition_begin(ehm_problem* P, int64_t n_roots, const double* root_vert
                         const ehm_node_init* init, const ehm_run_opts* opts, ehm_tree** out) {
     if (!P || !root_vertices || !out || n_roots < 1) return fail(EHM_E_INVALID, "bad argument");
     *out = nullptr;
-    if (P->dp.n_delta != 1)
-        return fail(EHM_E_INVALID,
-                    "ehm_partition_run: multi-commutation problems are handled by the host "
-                    "driver on top of the batched oracles in this build");
+    // frontier buffers, queue and counters of a run live in the problem handle: one run at a time
+    if (P->active_run)
+        return fail(EHM_E_INVALID, "another partition run is active on this problem handle "
+                                   "(finish or destroy it first)");
     HIP_TRY(hipSetDevice(P->device), EHM_E_HIP);
     const int p = P->dp.p, n_u = P->dp.n_u;
     long long cap = (opts && opts->max_nodes > 0) ? opts->max_nodes : (1LL << 21);
@@ -1993,6 +2005,16 @@ int ehm_partition_begin(ehm_problem* P, int64_t n_roots, const double* root_vert
     R.n_nodes = n_roots;
     R.nf = n_roots;
     R.cur_is_a = true;
+    if (P->dp.n_delta > 1) {
+        // multi-commutation problems: the device engine of ehm_hybrid.h
+        if (R.shard_world > 1)
+            RUN_TRY(fail(EHM_E_INVALID, "sharded runs of multi-commutation problems are not "
+                                        "available in this build"));
+        RUN_TRY(hy_begin(T, n_roots, init));
+        P->active_run = T;
+        *out = T;
+        return EHM_OK;
+    }
     // 'ecc' for a single-commutation problem: the only commutation is feasible at every
     // vertex of a feasible Theta, so V_R reduces to the vertex solves (lib/worker.py:279-291)
     if (R.action == 0) {
@@ -2018,6 +2040,7 @@ int ehm_partition_begin(ehm_problem* P, int64_t n_roots, const double* root_vert
                          "solves found no feasible point)",
                          (unsigned long long)cv.errors, (long long)(n_roots * (p + 1))));
     }
+    P->active_run = T;
     *out = T;
     return EHM_OK;
 #undef RUN_TRY
@@ -2134,6 +2157,16 @@ int ehm_partition_step(ehm_tree* T, int32_t max_sweeps, int64_t* frontier_size) 
     ehm_problem* P = T->prob;
     auto& R = T->run;
     HIP_TRY(hipSetDevice(P->device), EHM_E_HIP);
+    if (T->hy) {
+        int done_h = 0;
+        while (R.nf > 0 && (max_sweeps <= 0 || done_h < max_sweeps)) {
+            int rc = hy_sweep(T);
+            if (rc) return rc;
+            ++done_h;
+        }
+        if (frontier_size) *frontier_size = R.nf;
+        return EHM_OK;
+    }
     // persistent frontier kernel: a run that goes to completion in this call.  A sharded run
     // first sweeps until the frontier has been dealt over the ranks, then grows its share in
     // one launch (static dealing: no rebalancing rounds, see distributed.py)
@@ -2274,6 +2307,7 @@ int ehm_partition_take(ehm_tree* T, int64_t count, int32_t* node_ids, double* re
         return fail(EHM_E_INVALID, "bad argument");
     ehm_problem* P = T->prob;
     auto& R = T->run;
+    if (T->hy) return fail(EHM_E_INVALID, "take/give: not available for multi-commutation runs");
     if (count > R.nf) return fail(EHM_E_INVALID, "cannot take %lld of %lld frontier nodes",
                                   (long long)count, (long long)R.nf);
     if (count == 0) return EHM_OK;
@@ -2305,6 +2339,7 @@ int ehm_partition_give(ehm_tree* T, int64_t count, const double* records, const 
         return fail(EHM_E_INVALID, "bad argument");
     ehm_problem* P = T->prob;
     auto& R = T->run;
+    if (T->hy) return fail(EHM_E_INVALID, "take/give: not available for multi-commutation runs");
     if (first_id) *first_id = (int32_t)R.n_nodes;
     if (count == 0) return EHM_OK;
     if (R.n_nodes + count > T->limit)
@@ -2408,6 +2443,7 @@ int ehm_partition_finish(ehm_tree* T) {
     int rc = read_counters(P, c1);
     if (rc) return rc;
     R.active = false;
+    if (P->active_run == T) P->active_run = nullptr;
     if (c1.errors != 0 && !getenv("EHM_KEEP_GOING"))
         return fail(EHM_E_NUMERIC, "%llu oracle solves did not converge",
                     (unsigned long long)c1.errors);
@@ -2439,6 +2475,15 @@ int ehm_partition_finish(ehm_tree* T) {
         double mm;
         std::memcpy(&mm, &c1.min_margin_bits, 8);
         T->info.min_margin = mm;
+    }
+    if (T->hy) {
+        const HyCtr& h = T->hy->h;
+        double mm;
+        std::memcpy(&mm, &h.min_margin_bits, 8);
+        T->info.min_margin = mm;
+        T->info.swaps = (int64_t)h.swaps;
+        T->info.blacklisted = (int64_t)h.blacklisted;
+        P->slivers += (long long)h.slivers;
     }
     T->info.volume_closed = -1.0;   // filled lazily by ehm_tree_info_get
     return EHM_OK;

@@ -1,0 +1,972 @@
+// Partition engine for multi-commutation (hybrid) problems: Worker.ecc / Worker.lcss of the
+// reference (lib/worker.py:241-417) with its mixed-integer oracles V_R / bar_E_delta_R /
+// bar_D_delta_R / in_variability_ball (lib/oracle.py:175-414) evaluated for a whole frontier at
+// a time, entirely on the device.  Included by ehm_capi.hip (one translation unit).
+//
+// A sweep is a fixed sequence of launches with no host round trip in between: small list
+// kernels turn per-node bit masks ("which commutations still need which LP") into work lists
+// sorted by commutation, the batched oracle kernels of ehm_k2.hip / ehm_k3.hip read their
+// instances straight from the node records through those lists (K2Gather) and write their
+// results at (node, commutation) addresses, decision kernels consume them.  The host reads one
+// control block per sweep (sizes of the next frontiers, node count, error word).
+//
+// What a node carries besides its record (DevTree):
+//   vf   [node][p+1][nw]  bit d of row v: commutation d is feasible at vertex v (phase-one LP,
+//                         lib/oracle.py:141-173 with check_feasibility) -- children inherit p of
+//                         their p+1 rows, the midpoint's row is inferred where convexity decides
+//                         it (feasible at both ends of the split edge => feasible; infeasible on
+//                         the whole parent simplex => infeasible) and solved for the rest;
+//   cand [node][nw]       commutations that were feasible somewhere on the PARENT simplex;
+//   black[node][nw]       commutations blacklisted for this node's bar_D after a failed vertex
+//                         solve (the reference's __delta_neq_constraint retry, lib/oracle.py:406-414).
+// Canonical commutation rule and tolerances: DESIGN.md section 3 ("canonical commutation rule");
+// per-node semantics are exactly those of ehm_lcss_batch + partition.grow_hybrid of round 1.
+
+typedef unsigned long long hy_u64;
+
+struct HyCtr {
+    int n_nodes;            // node pool allocation counter
+    int next_ecc;           // next-frontier cursors
+    int next_lcss;
+    int n_split;            // split list of the current chunk
+    int n_items;            // length of the work list being built
+    int error;              // 0 ok, 1 node pool exhausted, 2 numeric, 3 infeasible Theta
+    int err_node;
+    int truncated;
+    int max_depth_seen;
+    int pad;
+    unsigned long long closed, splits, swaps, slivers, blacklisted, ref_solves;
+    unsigned long long min_margin_bits;
+};
+
+#define HY_BLOCK 256
+
+__device__ __forceinline__ bool hy_bit(const hy_u64* row, int d) {
+    return (row[d >> 6] >> (d & 63)) & 1ULL;
+}
+__device__ __forceinline__ hy_u64 hy_valid_word(int nd, int w) {
+    const int lo = w * 64;
+    if (nd >= lo + 64) return ~0ULL;
+    if (nd <= lo) return 0ULL;
+    return (1ULL << (nd - lo)) - 1ULL;
+}
+
+// ---- work lists sorted by commutation ----------------------------------------------------------
+// bits[k][nw]: row k wants an instance for every set commutation bit.  Threads are laid out
+// commutation-major (t = d * ns_pad + k), so a wavefront works on ONE commutation and adds to its
+// counter once.
+__global__ void hy_list_count(const hy_u64* __restrict__ bits, int ns, int nd, int nw,
+                              int* __restrict__ count) {
+    const long long t = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    const int ns_pad = (ns + 63) & ~63;
+    const int d = (int)(t / ns_pad), k = (int)(t % ns_pad);
+    if (d >= nd) return;
+    const bool has = (k < ns) && hy_bit(bits + (size_t)k * nw, d);
+    const hy_u64 b = __ballot(has);
+    if ((threadIdx.x & 63) == 0 && b) atomicAdd(&count[d], __popcll(b));
+}
+// seg[0..nd] = exclusive prefix of count, cursor = seg, n_items = total; count is cleared
+__global__ void hy_list_scan(int* count, int nd, int* seg, int* cursor, int* n_items) {
+    if (threadIdx.x != 0 || blockIdx.x != 0) return;
+    int acc = 0;
+    for (int d = 0; d < nd; ++d) {
+        seg[d] = acc;
+        cursor[d] = acc;
+        acc += count[d];
+        count[d] = 0;
+    }
+    seg[nd] = acc;
+    *n_items = acc;
+}
+// instance of (row k, commutation d): input at koff[k], results at k * nd + d
+__global__ void hy_list_scatter(const hy_u64* __restrict__ bits, int ns, int nd, int nw,
+                                const long long* __restrict__ koff, int* __restrict__ cursor,
+                                long long* __restrict__ src, int32_t* __restrict__ dst) {
+    const long long t = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    const int ns_pad = (ns + 63) & ~63;
+    const int d = (int)(t / ns_pad), k = (int)(t % ns_pad);
+    if (d >= nd) return;
+    const bool has = (k < ns) && hy_bit(bits + (size_t)k * nw, d);
+    const hy_u64 b = __ballot(has);
+    if (!b) return;
+    const int lane = threadIdx.x & 63;
+    int base = 0;
+    if (lane == 0) base = atomicAdd(&cursor[d], __popcll(b));
+    base = __shfl(base, 0, 64);
+    if (has) {
+        const int idx = base + __popcll(b & ((1ULL << lane) - 1ULL));
+        src[idx] = koff[k];
+        dst[idx] = k * nd + d;
+    }
+}
+// entries with one commutation each: dsel[e] (-1 = no instance), input at eoff[e], results at e
+__global__ void hy_sel_count(const int32_t* __restrict__ dsel, int ne, int* __restrict__ count) {
+    const int e = blockIdx.x * blockDim.x + threadIdx.x;
+    if (e >= ne) return;
+    const int d = dsel[e];
+    if (d >= 0) atomicAdd(&count[d], 1);
+}
+__global__ void hy_sel_scatter(const int32_t* __restrict__ dsel, int ne,
+                               const long long* __restrict__ eoff, int* __restrict__ cursor,
+                               long long* __restrict__ src, int32_t* __restrict__ dst) {
+    const int e = blockIdx.x * blockDim.x + threadIdx.x;
+    if (e >= ne) return;
+    const int d = dsel[e];
+    if (d < 0) return;
+    const int idx = atomicAdd(&cursor[d], 1);
+    src[idx] = eoff[e];
+    dst[idx] = e;
+}
+
+// out[k] = forced[k] | (ask[k] & {tau[k][d] <= tol})
+__global__ void hy_bits_finish(int ns, int nd, int nw, const hy_u64* __restrict__ forced,
+                               const hy_u64* __restrict__ ask, const double* __restrict__ tau,
+                               double tol, hy_u64* __restrict__ out) {
+    const int t = blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= ns * nw) return;
+    const int k = t / nw, w = t - k * nw;
+    hy_u64 f = forced ? forced[t] : 0ULL;
+    hy_u64 a = ask[t];
+    while (a) {
+        const int b = __ffsll((long long)a) - 1;
+        a &= a - 1;
+        if (tau[(size_t)k * nd + w * 64 + b] <= tol) f |= 1ULL << b;
+    }
+    out[t] = f;
+}
+
+// ---- roots: every vertex row asks for every commutation ---------------------------------------
+__global__ void hy_root_rows(int row0, int nrows, int nd, int nw, int nv, int p, int stride,
+                             hy_u64* __restrict__ ask, long long* __restrict__ koff) {
+    const int t = blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= nrows * nw) return;
+    const int k = t / nw, w = t - k * nw;
+    ask[t] = hy_valid_word(nd, w);
+    if (w == 0) {
+        const int row = row0 + k;
+        koff[k] = (long long)(row / nv) * stride + (long long)(row % nv) * p;
+    }
+}
+__global__ void hy_node_init(int first, int n, int nd, int nw, hy_u64* __restrict__ cand,
+                             hy_u64* __restrict__ black) {
+    const int t = blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= n * nw) return;
+    const int k = t / nw, w = t - k * nw;
+    cand[(size_t)(first + k) * nw + w] = hy_valid_word(nd, w);
+    black[(size_t)(first + k) * nw + w] = 0ULL;
+}
+
+// ---- lcss: which (node, commutation) pairs need which problem ---------------------------------
+// known feasible somewhere (feasible at a vertex) -> slack problem directly; infeasible on the
+// parent simplex -> nothing; the rest -> phase one over the simplex first.
+__global__ void hy_lcss_classify(DevTree T, const int32_t* __restrict__ frontier, int ns, int nd,
+                                 int nw, const hy_u64* __restrict__ vf,
+                                 const hy_u64* __restrict__ cand, hy_u64* __restrict__ known1,
+                                 hy_u64* __restrict__ ask, hy_u64* __restrict__ vall,
+                                 long long* __restrict__ koff) {
+    const int t = blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= ns * nw) return;
+    const int k = t / nw, w = t - k * nw;
+    const int id = frontier[k];
+    const int nv = T.p + 1;
+    hy_u64 any = 0ULL, all = ~0ULL;
+    for (int v = 0; v < nv; ++v) {
+        const hy_u64 x = vf[((size_t)id * nv + v) * nw + w];
+        any |= x;
+        all &= x;
+    }
+    const hy_u64 valid = hy_valid_word(nd, w);
+    known1[t] = any & valid;
+    ask[t] = ~any & cand[(size_t)id * nw + w] & valid;
+    vall[t] = all & valid;
+    if (w == 0) koff[k] = (long long)id * T.rec_stride;
+}
+// after phase one: pairs that go to the slack problem; tau of the known-feasible ones := -1
+__global__ void hy_after_phase1(int ns, int nd, int nw, const hy_u64* __restrict__ known1,
+                                const hy_u64* __restrict__ ask, double* __restrict__ tau,
+                                double tol, hy_u64* __restrict__ slk) {
+    const int t = blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= ns * nw) return;
+    const int k = t / nw, w = t - k * nw;
+    hy_u64 f = known1[t], a = ask[t];
+    hy_u64 q = f;
+    while (q) {
+        const int b = __ffsll((long long)q) - 1;
+        q &= q - 1;
+        tau[(size_t)k * nd + w * 64 + b] = -1.0;
+    }
+    while (a) {
+        const int b = __ffsll((long long)a) - 1;
+        a &= a - 1;
+        if (tau[(size_t)k * nd + w * 64 + b] <= tol) f |= 1ULL << b;
+    }
+    slk[t] = f;
+}
+// pairs taken as feasible on a vertex's word whose slack problem stalled: phase one after all
+__global__ void hy_redo_bits(int ns, int nd, int nw, const hy_u64* __restrict__ known1,
+                             const int32_t* __restrict__ st, hy_u64* __restrict__ redo) {
+    const int t = blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= ns * nw) return;
+    const int k = t / nw, w = t - k * nw;
+    hy_u64 q = known1[t], r = 0ULL;
+    while (q) {
+        const int b = __ffsll((long long)q) - 1;
+        q &= q - 1;
+        if (st[(size_t)k * nd + w * 64 + b] != 0) r |= 1ULL << b;
+    }
+    redo[t] = r;
+}
+
+// One Worker.lcss decision per node (lib/worker.py:368-401 with the oracles of
+// lib/oracle.py:285-394): bar_E from the slacks of every commutation, then bar_D's choice.
+//   act: 0 closed, 1 split with the node's own commutation, 2 better commutation found (its
+//        vertex solves / in_variability_ball follow), 3 open but left at max_depth
+__global__ void hy_lcss_decide(DevTree T, const int32_t* __restrict__ frontier, int ns, int nd,
+                               int nw, const hy_u64* __restrict__ slk,
+                               const hy_u64* __restrict__ vall, const hy_u64* __restrict__ black,
+                               const double* __restrict__ tau, const double* __restrict__ tval,
+                               const int32_t* __restrict__ st, const double* __restrict__ alpha,
+                               double sliver_tol, double tie_tol, int max_depth,
+                               hy_u64* __restrict__ cand, int32_t* __restrict__ act,
+                               int32_t* __restrict__ best_out, double* __restrict__ ths,
+                               HyCtr* ctr) {
+    const int k = blockIdx.x * blockDim.x + threadIdx.x;
+    if (k >= ns) return;
+    const int id = frontier[k];
+    const int p = T.p, nv = p + 1;
+    double tb = -INFINITY, tbm = -INFINITY;
+    hy_u64 feas[4] = {0ULL, 0ULL, 0ULL, 0ULL};
+    for (int d = 0; d < nd; ++d) {
+        if (!hy_bit(slk + (size_t)k * nw, d)) continue;
+        const size_t q = (size_t)k * nd + d;
+        if (st[q] != 0) {
+            if (tau[q] > -sliver_tol) {      // feasible only within the phase-one accuracy:
+                atomicAdd(&ctr->slivers, 1ULL);                   // no interior, dropped
+            } else {
+                atomicMax(&ctr->error, 2);
+                ctr->err_node = id;
+                T.flags[id] |= 8;
+            }
+            continue;
+        }
+        feas[d >> 6] |= 1ULL << (d & 63);
+        const double t = tval[q];
+        tb = fmax(tb, t);
+        if (t >= 0.0 && hy_bit(vall + (size_t)k * nw, d) && !hy_bit(black + (size_t)id * nw, d))
+            tbm = fmax(tbm, t);
+    }
+    for (int w = 0; w < nw; ++w) cand[(size_t)id * nw + w] = feas[w];
+    T.tstar[id] = tb;
+    atomicMin(&ctr->min_margin_bits, (unsigned long long)__double_as_longlong(fabs(tb)));
+    atomicAdd(&ctr->ref_solves, 1ULL);
+    const int dep = T.depth[id];
+    atomicMax(&ctr->max_depth_seen, dep);
+    if (!(tb >= 0.0)) {
+        T.flags[id] |= 1;
+        atomicAdd(&ctr->closed, 1ULL);
+        act[k] = 0;
+        return;
+    }
+    if (max_depth > 0 && dep >= max_depth) {
+        ctr->truncated = 1;
+        act[k] = 3;
+        return;
+    }
+    atomicAdd(&ctr->ref_solves, 1ULL);
+    int best = -1;
+    if (tbm >= 0.0) {
+        const double thr = tbm - tie_tol * (1.0 + fabs(tbm));
+        for (int d = 0; d < nd && best < 0; ++d) {
+            if (!((feas[d >> 6] >> (d & 63)) & 1ULL)) continue;
+            if (!hy_bit(vall + (size_t)k * nw, d) || hy_bit(black + (size_t)id * nw, d)) continue;
+            const double t = tval[(size_t)k * nd + d];
+            if (t >= 0.0 && t >= thr) best = d;
+        }
+    }
+    if (best >= 0 && best == T.didx[id]) best = -1;          // lib/oracle.py:384-394
+    best_out[k] = best;
+    if (best < 0) {
+        act[k] = 1;
+        return;
+    }
+    act[k] = 2;
+    atomicAdd(&ctr->ref_solves, (unsigned long long)(p + 3));
+    const double* al = alpha + ((size_t)k * nd + best) * nv;
+    const double* R = T.rec + (size_t)id * T.rec_stride;
+    for (int c = 0; c < p; ++c) {
+        double acc = 0.0;
+        for (int v = 0; v < nv; ++v) acc += al[v] * R[v * p + c];
+        ths[(size_t)k * p + c] = acc;
+    }
+}
+
+// entries of the follow-up solves of the nodes with act == 2 (or, ecc: a commutation to adopt)
+//   V: P_theta_delta at every vertex with the new commutation   (lib/oracle.py:399-401)
+//   T: P_theta_delta at theta* with the new commutation           (lib/oracle.py:281)
+//   M: min over the simplex with the node's own commutation       (lib/oracle.py:276)
+__global__ void hy_delta_entries(DevTree T, const int32_t* __restrict__ frontier, int ns,
+                                 const int32_t* __restrict__ act, const int32_t* __restrict__ best,
+                                 int32_t* __restrict__ dselV, long long* __restrict__ eoffV,
+                                 int32_t* __restrict__ dselT, long long* __restrict__ eoffT,
+                                 int32_t* __restrict__ dselM, long long* __restrict__ eoffM) {
+    const int k = blockIdx.x * blockDim.x + threadIdx.x;
+    if (k >= ns) return;
+    const int id = frontier[k];
+    const int p = T.p, nv = p + 1;
+    const bool on = act[k] == 2;
+    for (int v = 0; v < nv; ++v) {
+        dselV[k * nv + v] = on ? best[k] : -1;
+        eoffV[k * nv + v] = (long long)id * T.rec_stride + (long long)v * p;
+    }
+    if (dselT) {
+        dselT[k] = on ? best[k] : -1;
+        eoffT[k] = (long long)k * p;
+        dselM[k] = on ? T.didx[id] : -1;
+        eoffM[k] = (long long)id * T.rec_stride;
+    }
+}
+
+// in_variability_ball (lib/oracle.py:220-283) and what follows from it (lib/worker.py:396-401):
+//   act 4 = the node takes the better commutation in place and is visited again,
+//   act 5 = split with the better commutation's data;
+// a failed solve blacklists the commutation for this node and the node is visited again
+// (lib/oracle.py:406-414).
+__global__ void hy_varsmall(DevTree T, const int32_t* __restrict__ frontier, int ns, int nw,
+                            int32_t* __restrict__ act, const int32_t* __restrict__ best,
+                            const double* __restrict__ vJ, const double* __restrict__ vu,
+                            const int32_t* __restrict__ vst, const double* __restrict__ Jth,
+                            const int32_t* __restrict__ Jth_st, const double* __restrict__ Jmin,
+                            const int32_t* __restrict__ Jmin_st, double eps_a, double eps_r,
+                            int fail_delta, hy_u64* __restrict__ black, HyCtr* ctr) {
+    const int k = blockIdx.x * blockDim.x + threadIdx.x;
+    if (k >= ns || act[k] != 2) return;
+    const int id = frontier[k];
+    const int p = T.p, nv = p + 1, n_u = T.n_u;
+    bool ok = (Jth_st[k] == 0) && (best[k] != fail_delta);
+    for (int v = 0; v < nv; ++v) ok = ok && (vst[k * nv + v] == 0);
+    if (!ok) {
+        black[(size_t)id * nw + (best[k] >> 6)] |= 1ULL << (best[k] & 63);
+        atomicAdd(&ctr->blacklisted, 1ULL);
+        act[k] = 6;                                   // visit again, nothing changed
+        return;
+    }
+    if (Jmin_st[k] != 0) {                            // the node's OWN commutation failed
+        atomicMax(&ctr->error, 2);
+        ctr->err_node = id;
+        return;
+    }
+    double* rec = T.rec + (size_t)id * T.rec_stride;
+    const double* V = rec + rec_off_vcost(p);
+    double vmax = -INFINITY;
+    for (int v = 0; v < nv; ++v) vmax = fmax(vmax, V[v]);
+    const double rhs = fmax(eps_a, eps_r * Jth[k]);
+    if (vmax - Jmin[k] < rhs) {
+        for (int v = 0; v < nv; ++v) rec[rec_off_vcost(p) + v] = vJ[k * nv + v];
+        for (int q = 0; q < nv * n_u; ++q) rec[rec_off_vinput(p) + q] = vu[(size_t)k * nv * n_u + q];
+        T.didx[id] = best[k];
+        atomicAdd(&ctr->swaps, 1ULL);
+        act[k] = 4;
+    } else {
+        act[k] = 5;
+    }
+}
+
+// nodes that stay in the frontier (act 4 / 6)
+__global__ void hy_revisit(const int32_t* __restrict__ frontier, int ns,
+                           const int32_t* __restrict__ act, int32_t* __restrict__ next_lcss,
+                           HyCtr* ctr) {
+    const int k = blockIdx.x * blockDim.x + threadIdx.x;
+    if (k >= ns) return;
+    if (act[k] == 4 || act[k] == 6) next_lcss[atomicAdd(&ctr->next_lcss, 1)] = frontier[k];
+}
+
+// ---- splits (lib/worker.py:403-414, 269-278; tools.split_along_longest_edge) -------------------
+// has_data = 1: lcss nodes with act 1 / 5; 0: ecc nodes with act 1.
+__global__ void hy_split_collect(DevTree T, const int32_t* __restrict__ frontier, int ns, int nd,
+                                 int nw, int has_data, int node_cap,
+                                 const int32_t* __restrict__ act, const int32_t* __restrict__ best,
+                                 const hy_u64* __restrict__ vf, const hy_u64* __restrict__ cand,
+                                 int32_t* __restrict__ sp_k, int32_t* __restrict__ sp_c0,
+                                 int32_t* __restrict__ sp_ij, int32_t* __restrict__ sp_d,
+                                 double* __restrict__ mids, hy_u64* __restrict__ midforced,
+                                 hy_u64* __restrict__ midask, long long* __restrict__ moff,
+                                 HyCtr* ctr) {
+    const int k = blockIdx.x * blockDim.x + threadIdx.x;
+    if (k >= ns) return;
+    const int a = act[k];
+    if (!(a == 1 || (has_data && a == 5))) return;
+    const int id = frontier[k];
+    const int p = T.p, nv = p + 1;
+    const int c0 = atomicAdd(&ctr->n_nodes, 2);
+    if (c0 + 2 > node_cap) {
+        atomicMax(&ctr->error, 1);
+        return;
+    }
+    const int s = atomicAdd(&ctr->n_split, 1);
+    const double* R = T.rec + (size_t)id * T.rec_stride;
+    int bi, bj;
+    longest_edge(R, p, bi, bj);
+    {
+#pragma clang fp contract(off)
+        for (int c = 0; c < p; ++c) mids[(size_t)s * p + c] = (R[bi * p + c] + R[bj * p + c]) / 2.0;
+    }
+    sp_k[s] = k;
+    sp_c0[s] = c0;
+    sp_ij[2 * s] = bi;
+    sp_ij[2 * s + 1] = bj;
+    sp_d[s] = has_data ? ((a == 5) ? best[k] : T.didx[id]) : -1;
+    moff[s] = (long long)s * p;
+    for (int w = 0; w < nw; ++w) {
+        const hy_u64 f = vf[((size_t)id * nv + bi) * nw + w] & vf[((size_t)id * nv + bj) * nw + w];
+        // ecc nodes have not been through the suboptimality test: nothing known about the simplex
+        const hy_u64 c = has_data ? cand[(size_t)id * nw + w] : ~0ULL;
+        midforced[(size_t)s * nw + w] = f;
+        midask[(size_t)s * nw + w] = ~f & c & hy_valid_word(nd, w);
+    }
+    atomicAdd(&ctr->splits, 1ULL);
+    if (has_data) atomicAdd(&ctr->ref_solves, 1ULL);
+}
+
+// one wavefront per split: the two child records, their feasibility rows, structure words
+__global__ void hy_children(DevTree T, const int32_t* __restrict__ frontier, int nd, int nw,
+                            int has_data, const int32_t* __restrict__ act,
+                            const int32_t* __restrict__ sp_k, const int32_t* __restrict__ sp_c0,
+                            const int32_t* __restrict__ sp_ij, const int32_t* __restrict__ sp_d,
+                            const double* __restrict__ mids, const double* __restrict__ Jm,
+                            const double* __restrict__ um, const int32_t* __restrict__ mst,
+                            const double* __restrict__ vJ, const double* __restrict__ vu,
+                            const hy_u64* __restrict__ midbits, hy_u64* __restrict__ vf,
+                            hy_u64* __restrict__ cand, hy_u64* __restrict__ black,
+                            int32_t* __restrict__ next, HyCtr* ctr) {
+    const int s = blockIdx.x;
+    if (s >= ctr->n_split) return;
+    const int lane = threadIdx.x;
+    const int k = sp_k[s];
+    const int id = frontier[k];
+    const int p = T.p, nv = p + 1, n_u = T.n_u;
+    const int c0 = sp_c0[s], bi = sp_ij[2 * s], bj = sp_ij[2 * s + 1];
+    if (has_data && mst[s] != 0) {
+        if (lane == 0) {
+            atomicMax(&ctr->error, 2);
+            ctr->err_node = id;
+            T.flags[id] |= 16;
+        }
+        return;
+    }
+    const double* rec = T.rec + (size_t)id * T.rec_stride;
+    double* rec0 = T.rec + (size_t)c0 * T.rec_stride;
+    double* rec1 = rec0 + T.rec_stride;
+    const int ov = rec_off_vcost(p), ou = rec_off_vinput(p), nrec = rec_doubles(p, n_u);
+    // the children carry the data of the commutation the split was made with: the node's own, or
+    // the better one's vertex solves (the parent keeps its own record, lib/worker.py:356-365)
+    const bool fresh = has_data && act[k] == 5;
+    const double* mid = mids + (size_t)s * p;
+    for (int q = lane; q < nrec; q += 64) {
+        double v0, v1;
+        if (q < ov) {
+            v0 = v1 = rec[q];
+            if (q >= bi * p && q < bi * p + p) v0 = mid[q - bi * p];
+            if (q >= bj * p && q < bj * p + p) v1 = mid[q - bj * p];
+        } else if (!has_data) {
+            v0 = v1 = 0.0;
+        } else if (q < ou) {
+            v0 = v1 = fresh ? vJ[(size_t)k * nv + (q - ov)] : rec[q];
+            if (q - ov == bi) v0 = Jm[s];
+            if (q - ov == bj) v1 = Jm[s];
+        } else {
+            const int r = q - ou;
+            v0 = v1 = fresh ? vu[(size_t)k * nv * n_u + r] : rec[q];
+            if (r >= bi * n_u && r < bi * n_u + n_u) v0 = um[(size_t)s * n_u + r - bi * n_u];
+            if (r >= bj * n_u && r < bj * n_u + n_u) v1 = um[(size_t)s * n_u + r - bj * n_u];
+        }
+        rec0[q] = v0;
+        rec1[q] = v1;
+    }
+    for (int q = lane; q < nv * nw; q += 64) {
+        const int v = q / nw, w = q - v * nw;
+        const hy_u64 x = vf[((size_t)id * nv + v) * nw + w];
+        const hy_u64 m = midbits[(size_t)s * nw + w];
+        vf[((size_t)c0 * nv + v) * nw + w] = (v == bi) ? m : x;
+        vf[((size_t)(c0 + 1) * nv + v) * nw + w] = (v == bj) ? m : x;
+    }
+    for (int w = lane; w < nw; w += 64) {
+        const hy_u64 c = has_data ? cand[(size_t)id * nw + w] : hy_valid_word(nd, w);
+        cand[(size_t)c0 * nw + w] = c;
+        cand[(size_t)(c0 + 1) * nw + w] = c;
+        black[(size_t)c0 * nw + w] = 0ULL;
+        black[(size_t)(c0 + 1) * nw + w] = 0ULL;
+    }
+    if (lane == 0) {
+        const int dep = T.depth[id] + 1;
+        T.left[id] = c0;
+        for (int c = c0; c < c0 + 2; ++c) {
+            T.left[c] = -1;
+            T.didx[c] = sp_d[s];
+            T.depth[c] = dep;
+            T.flags[c] = has_data ? 2 : 0;
+            T.tstar[c] = 0.0;
+        }
+        const int at = atomicAdd(has_data ? &ctr->next_lcss : &ctr->next_ecc, 2);
+        next[at] = c0;
+        next[at + 1] = c0 + 1;
+    }
+}
+
+// ---- ecc (lib/worker.py:262-291) ----------------------------------------------------------------
+// V_R's choice: first commutation feasible at every vertex (act 2: adopt it after its vertex
+// solves), otherwise split (act 1) -- those nodes get the barycentre check of lib/worker.py:264-266
+// (a commutation feasible at every vertex is feasible at the barycentre, nothing to check there).
+__global__ void hy_ecc_classify(DevTree T, const int32_t* __restrict__ frontier, int ns, int nd,
+                                int nw, const hy_u64* __restrict__ vf,
+                                const hy_u64* __restrict__ black, int32_t* __restrict__ act,
+                                int32_t* __restrict__ best, double* __restrict__ ctrs,
+                                hy_u64* __restrict__ cask, long long* __restrict__ coff,
+                                HyCtr* ctr) {
+    const int k = blockIdx.x * blockDim.x + threadIdx.x;
+    if (k >= ns) return;
+    const int id = frontier[k];
+    const int p = T.p, nv = p + 1;
+    int found = -1;
+    for (int w = 0; w < nw && found < 0; ++w) {
+        hy_u64 all = hy_valid_word(nd, w) & ~black[(size_t)id * nw + w];
+        for (int v = 0; v < nv; ++v) all &= vf[((size_t)id * nv + v) * nw + w];
+        if (all) found = w * 64 + __ffsll((long long)all) - 1;
+    }
+    best[k] = found;
+    act[k] = (found >= 0) ? 2 : 1;
+    atomicAdd(&ctr->ref_solves, (unsigned long long)(2 + (found >= 0 ? nv : 0)));
+    atomicMax(&ctr->max_depth_seen, T.depth[id]);
+    const double* R = T.rec + (size_t)id * T.rec_stride;
+    for (int c = 0; c < p; ++c) {
+        double acc = 0.0;
+        for (int v = 0; v < nv; ++v) acc += R[v * p + c];
+        ctrs[(size_t)k * p + c] = acc / nv;
+    }
+    coff[k] = (long long)k * p;
+    for (int w = 0; w < nw; ++w) cask[(size_t)k * nw + w] = (found >= 0) ? 0ULL : hy_valid_word(nd, w);
+}
+__global__ void hy_ecc_centre_check(const int32_t* __restrict__ frontier, int ns, int nw,
+                                    const int32_t* __restrict__ act,
+                                    const hy_u64* __restrict__ cbits, HyCtr* ctr) {
+    const int k = blockIdx.x * blockDim.x + threadIdx.x;
+    if (k >= ns || act[k] != 1) return;
+    hy_u64 any = 0ULL;
+    for (int w = 0; w < nw; ++w) any |= cbits[(size_t)k * nw + w];
+    if (!any) {
+        atomicMax(&ctr->error, 3);
+        ctr->err_node = frontier[k];
+    }
+}
+__global__ void hy_ecc_adopt(DevTree T, const int32_t* __restrict__ frontier, int ns,
+                             const int32_t* __restrict__ act, const int32_t* __restrict__ best,
+                             const double* __restrict__ vJ, const double* __restrict__ vu,
+                             const int32_t* __restrict__ vst, int nw, int fail_delta,
+                             hy_u64* __restrict__ black, int32_t* __restrict__ next_ecc,
+                             int32_t* __restrict__ next_lcss, HyCtr* ctr) {
+    const int k = blockIdx.x * blockDim.x + threadIdx.x;
+    if (k >= ns || act[k] != 2) return;
+    const int id = frontier[k];
+    const int p = T.p, nv = p + 1, n_u = T.n_u;
+    bool ok = best[k] != fail_delta;
+    for (int v = 0; v < nv; ++v) ok = ok && (vst[k * nv + v] == 0);
+    if (!ok) {
+        // V_R's retry (lib/oracle.py:198-218): blacklist the commutation, visit the node again
+        black[(size_t)id * nw + (best[k] >> 6)] |= 1ULL << (best[k] & 63);
+        atomicAdd(&ctr->blacklisted, 1ULL);
+        next_ecc[atomicAdd(&ctr->next_ecc, 1)] = id;
+        return;
+    }
+    for (int w = 0; w < nw; ++w) black[(size_t)id * nw + w] = 0ULL;   // local to the V_R call
+    double* rec = T.rec + (size_t)id * T.rec_stride;
+    for (int v = 0; v < nv; ++v) rec[rec_off_vcost(p) + v] = vJ[k * nv + v];
+    for (int q = 0; q < nv * n_u; ++q) rec[rec_off_vinput(p) + q] = vu[(size_t)k * nv * n_u + q];
+    T.didx[id] = best[k];
+    T.flags[id] |= 2;
+    next_lcss[atomicAdd(&ctr->next_lcss, 1)] = id;
+}
+
+// =============================================================================================
+// host side
+// =============================================================================================
+struct HyState {
+    bool on = false;
+    int nw = 0;
+    long long ch = 0;                    // frontier nodes per chunk
+    DevBuf vf, cand, black;              // per node
+    DevBuf fr_ecc[2], fr_lcss[2];        // frontiers, ping-pong
+    long long n_ecc = 0, n_lcss = 0;
+    int cur = 0;
+    DevBuf known1, ask, slk, vall, redo, koff, src, dst, cnt, tau, tval, st, alpha;
+    DevBuf act, best, ths, vJ, vu, vst, Jth, Jth_st, Jmin, Jmin_st;
+    DevBuf dselV, eoffV, dselT, eoffT, dselM, eoffM;
+    DevBuf sp_k, sp_c0, sp_ij, sp_d, mids, Jm, um, mst, midforced, midask, midbits, moff;
+    DevBuf ctr;
+    HyCtr h{};
+    int fail_delta = -1;                 // test hook: vertex solves of this commutation "fail"
+    void release() {
+        DevBuf* all[] = {&vf, &cand, &black, &fr_ecc[0], &fr_ecc[1], &fr_lcss[0], &fr_lcss[1],
+                         &known1, &ask, &slk, &vall, &redo, &koff, &src, &dst, &cnt, &tau, &tval,
+                         &st, &alpha, &act, &best, &ths, &vJ, &vu, &vst, &Jth, &Jth_st, &Jmin,
+                         &Jmin_st, &dselV, &eoffV, &dselT, &eoffT, &dselM, &eoffM, &sp_k, &sp_c0,
+                         &sp_ij, &sp_d, &mids, &Jm, &um, &mst, &midforced, &midask, &midbits,
+                         &moff, &ctr};
+        for (DevBuf* b : all) b->release();
+    }
+};
+
+#define HY_GRID(n) dim3((unsigned)(((long long)(n) + HY_BLOCK - 1) / HY_BLOCK)), dim3(HY_BLOCK)
+
+static int hy_alloc(ehm_tree* T) {
+    ehm_problem* P = T->prob;
+    HyState& H = *T->hy;
+    const int nd = P->dp.n_delta, p = P->dp.p, nv = p + 1, n_u = P->dp.n_u;
+    H.nw = (nd + 63) / 64;
+    if (H.nw > 4)
+        return fail(EHM_E_INVALID, "hybrid engine: at most 256 commutations (got %d)", nd);
+    const int nw = H.nw;
+    H.ch = std::max<long long>(1024, std::min<long long>(1LL << 17, (1LL << 22) / nd));
+    if (const char* e = getenv("EHM_HY_CHUNK")) H.ch = std::max(64, atoi(e));
+    const size_t ch = (size_t)H.ch, cap = (size_t)T->cap;
+    int rc;
+#define HY_ENSURE(buf, bytes) if ((rc = H.buf.ensure(bytes))) return rc
+    HY_ENSURE(vf, cap * nv * nw * 8);
+    HY_ENSURE(cand, cap * nw * 8);
+    HY_ENSURE(black, cap * nw * 8);
+    HY_ENSURE(known1, ch * nw * 8); HY_ENSURE(ask, ch * nw * 8); HY_ENSURE(slk, ch * nw * 8);
+    HY_ENSURE(vall, ch * nw * 8);   HY_ENSURE(redo, ch * nw * 8);
+    HY_ENSURE(koff, ch * 8);
+    const size_t nlist = ch * (size_t)std::max(nd, nv);
+    HY_ENSURE(src, nlist * 8);      HY_ENSURE(dst, nlist * 4);
+    HY_ENSURE(cnt, (size_t)(3 * nd + 8) * 4);
+    HY_ENSURE(tau, ch * nd * 8);    HY_ENSURE(tval, ch * nd * 8);  HY_ENSURE(st, ch * nd * 4);
+    HY_ENSURE(alpha, ch * nd * nv * 8);
+    HY_ENSURE(act, ch * 4);         HY_ENSURE(best, ch * 4);       HY_ENSURE(ths, ch * p * 8);
+    HY_ENSURE(vJ, ch * nv * 8);     HY_ENSURE(vu, ch * nv * n_u * 8); HY_ENSURE(vst, ch * nv * 4);
+    HY_ENSURE(Jth, ch * 8);         HY_ENSURE(Jth_st, ch * 4);
+    HY_ENSURE(Jmin, ch * 8);        HY_ENSURE(Jmin_st, ch * 4);
+    HY_ENSURE(dselV, ch * nv * 4);  HY_ENSURE(eoffV, ch * nv * 8);
+    HY_ENSURE(dselT, ch * 4);       HY_ENSURE(eoffT, ch * 8);
+    HY_ENSURE(dselM, ch * 4);       HY_ENSURE(eoffM, ch * 8);
+    HY_ENSURE(sp_k, ch * 4);        HY_ENSURE(sp_c0, ch * 4);      HY_ENSURE(sp_ij, ch * 8);
+    HY_ENSURE(sp_d, ch * 4);        HY_ENSURE(mids, ch * p * 8);   HY_ENSURE(Jm, ch * 8);
+    HY_ENSURE(um, ch * n_u * 8);    HY_ENSURE(mst, ch * 4);
+    HY_ENSURE(midforced, ch * nw * 8); HY_ENSURE(midask, ch * nw * 8);
+    HY_ENSURE(midbits, ch * nw * 8);   HY_ENSURE(moff, ch * 8);
+    HY_ENSURE(ctr, sizeof(HyCtr));
+#undef HY_ENSURE
+    HIP_TRY(hipMemsetAsync(H.cnt.ptr, 0, (size_t)(3 * nd + 8) * 4, P->stream), EHM_E_HIP);
+    return EHM_OK;
+}
+
+struct HyList {      // the work list sitting in H.src / H.dst / seg
+    const long long* src;
+    const int32_t* dst;
+    const int32_t* seg;
+    const int32_t* n_dev;
+};
+
+static HyList hy_list_of(ehm_tree* T) {
+    HyState& H = *T->hy;
+    const int nd = T->prob->dp.n_delta;
+    return HyList{H.src.as<long long>(), H.dst.as<int32_t>(), H.cnt.as<int32_t>() + nd,
+                  &H.ctr.as<HyCtr>()->n_items};
+}
+
+static void hy_build_bits(ehm_tree* T, const hy_u64* bits, int ns, const long long* koff) {
+    ehm_problem* P = T->prob;
+    HyState& H = *T->hy;
+    const int nd = P->dp.n_delta, nw = H.nw;
+    int32_t* count = H.cnt.as<int32_t>();
+    int32_t* seg = count + nd;
+    int32_t* cursor = seg + nd + 1;
+    const long long threads = (long long)nd * ((ns + 63) & ~63);
+    hipLaunchKernelGGL(hy_list_count, HY_GRID(threads), 0, P->stream, bits, ns, nd, nw, count);
+    hipLaunchKernelGGL(hy_list_scan, dim3(1), dim3(64), 0, P->stream, count, nd, seg, cursor,
+                       &H.ctr.as<HyCtr>()->n_items);
+    hipLaunchKernelGGL(hy_list_scatter, HY_GRID(threads), 0, P->stream, bits, ns, nd, nw, koff,
+                       cursor, H.src.as<long long>(), H.dst.as<int32_t>());
+    P->launches += 3;
+}
+
+static void hy_build_sel(ehm_tree* T, const int32_t* dsel, int ne, const long long* eoff) {
+    ehm_problem* P = T->prob;
+    HyState& H = *T->hy;
+    const int nd = P->dp.n_delta;
+    int32_t* count = H.cnt.as<int32_t>();
+    int32_t* seg = count + nd;
+    int32_t* cursor = seg + nd + 1;
+    hipLaunchKernelGGL(hy_sel_count, HY_GRID(ne), 0, P->stream, dsel, ne, count);
+    hipLaunchKernelGGL(hy_list_scan, dim3(1), dim3(64), 0, P->stream, count, nd, seg, cursor,
+                       &H.ctr.as<HyCtr>()->n_items);
+    hipLaunchKernelGGL(hy_sel_scatter, HY_GRID(ne), 0, P->stream, dsel, ne, eoff, cursor,
+                       H.src.as<long long>(), H.dst.as<int32_t>());
+    P->launches += 3;
+}
+
+// batched problems over the simplices the current list points at (records of the node pool)
+static int hy_run_simplex(ehm_tree* T, int mode, double* obj, double* alpha, int32_t* status) {
+    ehm_problem* P = T->prob;
+    const int kind = (mode == SX_SLACK) ? LP_SLACK : (mode == SX_FEAS) ? LP_FEAS_SIMPLEX
+                                                                        : LP_MIN_SIMPLEX;
+    K2Cfg cfg;
+    int rc = k2_config(P, kind, kind, 1LL << 40, cfg);
+    if (rc) return rc;
+    const HyList L = hy_list_of(T);
+    K2Gather G{L.src, L.dst, L.n_dev, rec_off_vcost(P->dp.p), nullptr};
+    cfg.api->simplex(cfg.L, P->dp, 0, T->dt.rec, nullptr, L.seg, mode, obj, alpha, status, nullptr,
+                     P->d_cnt, G);
+    P->launches++;
+    return EHM_OK;
+}
+
+// batched P_theta_delta (or its phase-one form) at the parameters the current list points at
+static int hy_run_point(ehm_tree* T, const double* base, int feas, double* J, double* u0,
+                        int32_t* status) {
+    ehm_problem* P = T->prob;
+    K2Cfg cfg;
+    int rc = k2_config(P, feas ? LP_FEAS : LP_POINT, feas ? LP_FEAS : LP_POINT, 1LL << 40, cfg);
+    if (rc) return rc;
+    const HyList L = hy_list_of(T);
+    K2Gather G{L.src, L.dst, L.n_dev, 0, nullptr};
+    cfg.api->point(cfg.L, P->dp, 0, base, L.seg, feas, J, u0, status, nullptr, P->d_cnt, G);
+    P->launches++;
+    return EHM_OK;
+}
+
+#define HY_TRY(expr) do { int rc_ = (expr); if (rc_) return rc_; } while (0)
+
+// the split of the collected nodes: midpoint solve (lcss), the midpoint's feasibility row,
+// children
+static int hy_split_stage(ehm_tree* T, const int32_t* fr, int ns, int has_data, int32_t* next) {
+    ehm_problem* P = T->prob;
+    HyState& H = *T->hy;
+    const int nd = P->dp.n_delta, nw = H.nw;
+    HyCtr* ctr = H.ctr.as<HyCtr>();
+    HIP_TRY(hipMemsetAsync(&ctr->n_split, 0, 4, P->stream), EHM_E_HIP);
+    HIP_TRY(hipMemsetAsync(H.sp_d.ptr, 0xFF, (size_t)ns * 4, P->stream), EHM_E_HIP);
+    HIP_TRY(hipMemsetAsync(H.midask.ptr, 0, (size_t)ns * nw * 8, P->stream), EHM_E_HIP);
+    hipLaunchKernelGGL(hy_split_collect, HY_GRID(ns), 0, P->stream, T->dt, fr, ns, nd, nw, has_data,
+                       (int)T->limit, H.act.as<int32_t>(), H.best.as<int32_t>(),
+                       H.vf.as<hy_u64>(), H.cand.as<hy_u64>(), H.sp_k.as<int32_t>(),
+                       H.sp_c0.as<int32_t>(), H.sp_ij.as<int32_t>(), H.sp_d.as<int32_t>(),
+                       H.mids.as<double>(), H.midforced.as<hy_u64>(), H.midask.as<hy_u64>(),
+                       H.moff.as<long long>(), ctr);
+    if (has_data) {
+        hy_build_sel(T, H.sp_d.as<int32_t>(), ns, H.moff.as<long long>());
+        HY_TRY(hy_run_point(T, H.mids.as<double>(), 0, H.Jm.as<double>(), H.um.as<double>(),
+                            H.mst.as<int32_t>()));
+    }
+    hy_build_bits(T, H.midask.as<hy_u64>(), ns, H.moff.as<long long>());
+    HY_TRY(hy_run_point(T, H.mids.as<double>(), 1, H.tau.as<double>(), nullptr, nullptr));
+    hipLaunchKernelGGL(hy_bits_finish, HY_GRID((long long)ns * nw), 0, P->stream, ns, nd, nw,
+                       H.midforced.as<hy_u64>(), H.midask.as<hy_u64>(), H.tau.as<double>(),
+                       EHM_FEAS_TOL, H.midbits.as<hy_u64>());
+    hipLaunchKernelGGL(hy_children, dim3((unsigned)ns), dim3(64), 0, P->stream, T->dt, fr, nd, nw,
+                       has_data, H.act.as<int32_t>(), H.sp_k.as<int32_t>(), H.sp_c0.as<int32_t>(),
+                       H.sp_ij.as<int32_t>(), H.sp_d.as<int32_t>(), H.mids.as<double>(),
+                       H.Jm.as<double>(), H.um.as<double>(), H.mst.as<int32_t>(),
+                       H.vJ.as<double>(), H.vu.as<double>(), H.midbits.as<hy_u64>(),
+                       H.vf.as<hy_u64>(), H.cand.as<hy_u64>(), H.black.as<hy_u64>(), next, ctr);
+    P->launches += 3;
+    return EHM_OK;
+}
+
+static int hy_lcss_chunk(ehm_tree* T, const int32_t* fr, int ns, int32_t* next_lcss) {
+    ehm_problem* P = T->prob;
+    HyState& H = *T->hy;
+    const int nd = P->dp.n_delta, nw = H.nw, nv = P->dp.p + 1;
+    HyCtr* ctr = H.ctr.as<HyCtr>();
+    const long long nbw = (long long)ns * nw;
+    hipLaunchKernelGGL(hy_lcss_classify, HY_GRID(nbw), 0, P->stream, T->dt, fr, ns, nd, nw,
+                       H.vf.as<hy_u64>(), H.cand.as<hy_u64>(), H.known1.as<hy_u64>(),
+                       H.ask.as<hy_u64>(), H.vall.as<hy_u64>(), H.koff.as<long long>());
+    // phase one over the simplex for the commutations nothing is known about
+    hy_build_bits(T, H.ask.as<hy_u64>(), ns, H.koff.as<long long>());
+    HY_TRY(hy_run_simplex(T, SX_FEAS, H.tau.as<double>(), nullptr, nullptr));
+    hipLaunchKernelGGL(hy_after_phase1, HY_GRID(nbw), 0, P->stream, ns, nd, nw,
+                       H.known1.as<hy_u64>(), H.ask.as<hy_u64>(), H.tau.as<double>(),
+                       EHM_FEAS_TOL, H.slk.as<hy_u64>());
+    // suboptimality-test problem of every commutation feasible somewhere on the simplex
+    hy_build_bits(T, H.slk.as<hy_u64>(), ns, H.koff.as<long long>());
+    HY_TRY(hy_run_simplex(T, SX_SLACK, H.tval.as<double>(), H.alpha.as<double>(),
+                          H.st.as<int32_t>()));
+    hipLaunchKernelGGL(hy_redo_bits, HY_GRID(nbw), 0, P->stream, ns, nd, nw,
+                       H.known1.as<hy_u64>(), H.st.as<int32_t>(), H.redo.as<hy_u64>());
+    hy_build_bits(T, H.redo.as<hy_u64>(), ns, H.koff.as<long long>());
+    HY_TRY(hy_run_simplex(T, SX_FEAS, H.tau.as<double>(), nullptr, nullptr));
+    hipLaunchKernelGGL(hy_lcss_decide, HY_GRID(ns), 0, P->stream, T->dt, fr, ns, nd, nw,
+                       H.slk.as<hy_u64>(), H.vall.as<hy_u64>(), H.black.as<hy_u64>(),
+                       H.tau.as<double>(), H.tval.as<double>(), H.st.as<int32_t>(),
+                       H.alpha.as<double>(), EHM_SLIVER_TOL, EHM_TIE_TOL, T->run.max_depth,
+                       H.cand.as<hy_u64>(), H.act.as<int32_t>(), H.best.as<int32_t>(),
+                       H.ths.as<double>(), ctr);
+    // the nodes with a better commutation: its vertex solves and in_variability_ball
+    hipLaunchKernelGGL(hy_delta_entries, HY_GRID(ns), 0, P->stream, T->dt, fr, ns,
+                       H.act.as<int32_t>(), H.best.as<int32_t>(), H.dselV.as<int32_t>(),
+                       H.eoffV.as<long long>(), H.dselT.as<int32_t>(), H.eoffT.as<long long>(),
+                       H.dselM.as<int32_t>(), H.eoffM.as<long long>());
+    P->launches += 5;
+    hy_build_sel(T, H.dselV.as<int32_t>(), ns * nv, H.eoffV.as<long long>());
+    HY_TRY(hy_run_point(T, T->dt.rec, 0, H.vJ.as<double>(), H.vu.as<double>(), H.vst.as<int32_t>()));
+    hy_build_sel(T, H.dselT.as<int32_t>(), ns, H.eoffT.as<long long>());
+    HY_TRY(hy_run_point(T, H.ths.as<double>(), 0, H.Jth.as<double>(), nullptr,
+                        H.Jth_st.as<int32_t>()));
+    hy_build_sel(T, H.dselM.as<int32_t>(), ns, H.eoffM.as<long long>());
+    HY_TRY(hy_run_simplex(T, SX_MIN, H.Jmin.as<double>(), nullptr, H.Jmin_st.as<int32_t>()));
+    hipLaunchKernelGGL(hy_varsmall, HY_GRID(ns), 0, P->stream, T->dt, fr, ns, nw,
+                       H.act.as<int32_t>(), H.best.as<int32_t>(), H.vJ.as<double>(),
+                       H.vu.as<double>(), H.vst.as<int32_t>(), H.Jth.as<double>(),
+                       H.Jth_st.as<int32_t>(), H.Jmin.as<double>(), H.Jmin_st.as<int32_t>(),
+                       P->dp.eps_a, P->dp.eps_r, H.fail_delta, H.black.as<hy_u64>(), ctr);
+    hipLaunchKernelGGL(hy_revisit, HY_GRID(ns), 0, P->stream, fr, ns, H.act.as<int32_t>(),
+                       next_lcss, ctr);
+    P->launches += 2;
+    return hy_split_stage(T, fr, ns, 1, next_lcss);
+}
+
+static int hy_ecc_chunk(ehm_tree* T, const int32_t* fr, int ns, int32_t* next_ecc,
+                        int32_t* next_lcss) {
+    ehm_problem* P = T->prob;
+    HyState& H = *T->hy;
+    const int nd = P->dp.n_delta, nw = H.nw, nv = P->dp.p + 1;
+    HyCtr* ctr = H.ctr.as<HyCtr>();
+    hipLaunchKernelGGL(hy_ecc_classify, HY_GRID(ns), 0, P->stream, T->dt, fr, ns, nd, nw,
+                       H.vf.as<hy_u64>(), H.black.as<hy_u64>(), H.act.as<int32_t>(),
+                       H.best.as<int32_t>(),
+                       H.ths.as<double>(), H.ask.as<hy_u64>(), H.koff.as<long long>(), ctr);
+    // barycentre check of the nodes without a commutation feasible at every vertex
+    hy_build_bits(T, H.ask.as<hy_u64>(), ns, H.koff.as<long long>());
+    HY_TRY(hy_run_point(T, H.ths.as<double>(), 1, H.tau.as<double>(), nullptr, nullptr));
+    hipLaunchKernelGGL(hy_bits_finish, HY_GRID((long long)ns * nw), 0, P->stream, ns, nd, nw,
+                       (const hy_u64*)nullptr, H.ask.as<hy_u64>(), H.tau.as<double>(),
+                       EHM_FEAS_TOL, H.slk.as<hy_u64>());
+    hipLaunchKernelGGL(hy_ecc_centre_check, HY_GRID(ns), 0, P->stream, fr, ns, nw,
+                       H.act.as<int32_t>(), H.slk.as<hy_u64>(), ctr);
+    // vertex solves of the commutations V_R picked
+    hipLaunchKernelGGL(hy_delta_entries, HY_GRID(ns), 0, P->stream, T->dt, fr, ns,
+                       H.act.as<int32_t>(), H.best.as<int32_t>(), H.dselV.as<int32_t>(),
+                       H.eoffV.as<long long>(), (int32_t*)nullptr, (long long*)nullptr,
+                       (int32_t*)nullptr, (long long*)nullptr);
+    hy_build_sel(T, H.dselV.as<int32_t>(), ns * nv, H.eoffV.as<long long>());
+    HY_TRY(hy_run_point(T, T->dt.rec, 0, H.vJ.as<double>(), H.vu.as<double>(), H.vst.as<int32_t>()));
+    hipLaunchKernelGGL(hy_ecc_adopt, HY_GRID(ns), 0, P->stream, T->dt, fr, ns, H.act.as<int32_t>(),
+                       H.best.as<int32_t>(), H.vJ.as<double>(), H.vu.as<double>(),
+                       H.vst.as<int32_t>(), nw, H.fail_delta, H.black.as<hy_u64>(), next_ecc,
+                       next_lcss, ctr);
+    P->launches += 5;
+    return hy_split_stage(T, fr, ns, 0, next_ecc);
+}
+
+static int hy_read_ctr(ehm_tree* T) {
+    ehm_problem* P = T->prob;
+    HyState& H = *T->hy;
+    HIP_TRY(hipMemcpyAsync(&H.h, H.ctr.ptr, sizeof(HyCtr), hipMemcpyDeviceToHost, P->stream),
+            EHM_E_HIP);
+    HIP_TRY(hipStreamSynchronize(P->stream), EHM_E_HIP);
+    if (H.h.error == 1)
+        return fail(EHM_E_CAPACITY, "node pool exhausted at %d nodes (max_nodes=%lld)",
+                    H.h.n_nodes, T->limit);
+    if (H.h.error == 3)
+        return fail(EHM_E_INFEASIBLE, "STOP, Theta contains infeasible regions (node %d)",
+                    H.h.err_node);
+    if (H.h.error != 0)
+        return fail(EHM_E_NUMERIC, "an oracle solve of node %d did not converge", H.h.err_node);
+    return EHM_OK;
+}
+
+// one frontier sweep: every ecc node and every lcss node of the live frontiers is visited once
+static int hy_sweep(ehm_tree* T) {
+    ehm_problem* P = T->prob;
+    HyState& H = *T->hy;
+    auto& R = T->run;
+    const int cur = H.cur, nxt = 1 - cur;
+    int rc;
+    if ((rc = H.fr_ecc[nxt].ensure((size_t)(3 * H.n_ecc + 64) * 4))) return rc;
+    if ((rc = H.fr_lcss[nxt].ensure((size_t)(2 * H.n_lcss + H.n_ecc + 64) * 4))) return rc;
+    int32_t* next_ecc = H.fr_ecc[nxt].as<int32_t>();
+    int32_t* next_lcss = H.fr_lcss[nxt].as<int32_t>();
+    for (long long f0 = 0; f0 < H.n_ecc; f0 += H.ch) {
+        const int ns = (int)std::min<long long>(H.ch, H.n_ecc - f0);
+        HY_TRY(hy_ecc_chunk(T, H.fr_ecc[cur].as<int32_t>() + f0, ns, next_ecc, next_lcss));
+    }
+    for (long long f0 = 0; f0 < H.n_lcss; f0 += H.ch) {
+        const int ns = (int)std::min<long long>(H.ch, H.n_lcss - f0);
+        HY_TRY(hy_lcss_chunk(T, H.fr_lcss[cur].as<int32_t>() + f0, ns, next_lcss));
+    }
+    HIP_TRY(hipGetLastError(), EHM_E_HIP);
+    HY_TRY(hy_read_ctr(T));
+    H.n_ecc = H.h.next_ecc;
+    H.n_lcss = H.h.next_lcss;
+    H.cur = nxt;
+    HyCtr* ctr = H.ctr.as<HyCtr>();
+    HIP_TRY(hipMemsetAsync(&ctr->next_ecc, 0, 8, P->stream), EHM_E_HIP);   // next_ecc, next_lcss
+    R.n_nodes = H.h.n_nodes;
+    R.n_closed = (long long)H.h.closed;
+    R.ref_solves = (long long)H.h.ref_solves;
+    R.truncated = H.h.truncated;
+    R.depth = H.h.max_depth_seen;
+    R.nf = H.n_ecc + H.n_lcss;
+    ++R.sweeps;
+    return EHM_OK;
+}
+
+// roots of a hybrid run: structure words, feasibility rows of every root vertex, frontiers
+static int hy_begin(ehm_tree* T, int64_t n_roots, const ehm_node_init* init) {
+    ehm_problem* P = T->prob;
+    auto& R = T->run;
+    if (P->solver_gen != 2)
+        return fail(EHM_E_INVALID, "hybrid partitions need the generation-2 kernels");
+    T->hy = new HyState();
+    HyState& H = *T->hy;
+    H.on = true;
+    int rc = hy_alloc(T);
+    if (rc) return rc;
+    const int nd = P->dp.n_delta, nw = H.nw, p = P->dp.p, nv = p + 1;
+    if (const char* e = getenv("EHM_HY_FAIL_DELTA")) H.fail_delta = atoi(e);
+    std::vector<int32_t> didx((size_t)n_roots, -1);
+    std::vector<uint8_t> flags((size_t)n_roots, 0);
+    if (R.action == 1) {
+        if (!init || !init->delta || !init->vcost || !init->vinput)
+            return fail(EHM_E_INVALID, "action 'lcss' needs delta / vertex costs / vertex inputs");
+        if ((rc = map_deltas(P, n_roots, init->delta, didx))) return rc;
+        std::fill(flags.begin(), flags.end(), (uint8_t)2);
+    }
+    HIP_TRY(hipMemcpyAsync(T->dt.didx, didx.data(), didx.size() * 4, hipMemcpyHostToDevice,
+                           P->stream), EHM_E_HIP);
+    HIP_TRY(hipMemcpyAsync(T->dt.flags, flags.data(), flags.size(), hipMemcpyHostToDevice,
+                           P->stream), EHM_E_HIP);
+    HyCtr h{};
+    h.n_nodes = (int)n_roots;
+    h.min_margin_bits = 0x7FF0000000000000ULL;
+    HIP_TRY(hipMemcpyAsync(H.ctr.ptr, &h, sizeof h, hipMemcpyHostToDevice, P->stream), EHM_E_HIP);
+    HIP_TRY(hipStreamSynchronize(P->stream), EHM_E_HIP);      // didx / flags / h leave scope
+    hipLaunchKernelGGL(hy_node_init, HY_GRID(n_roots * nw), 0, P->stream, 0, (int)n_roots, nd, nw,
+                       H.cand.as<hy_u64>(), H.black.as<hy_u64>());
+    // feasibility of every commutation at every root vertex
+    const long long rows = n_roots * nv;
+    for (long long r0 = 0; r0 < rows; r0 += H.ch) {
+        const int nr = (int)std::min<long long>(H.ch, rows - r0);
+        hipLaunchKernelGGL(hy_root_rows, HY_GRID((long long)nr * nw), 0, P->stream, (int)r0, nr, nd,
+                           nw, nv, p, T->dt.rec_stride, H.ask.as<hy_u64>(),
+                           H.koff.as<long long>());
+        hy_build_bits(T, H.ask.as<hy_u64>(), nr, H.koff.as<long long>());
+        HY_TRY(hy_run_point(T, T->dt.rec, 1, H.tau.as<double>(), nullptr, nullptr));
+        hipLaunchKernelGGL(hy_bits_finish, HY_GRID((long long)nr * nw), 0, P->stream, nr, nd, nw,
+                           (const hy_u64*)nullptr, H.ask.as<hy_u64>(), H.tau.as<double>(),
+                           EHM_FEAS_TOL, H.vf.as<hy_u64>() + (size_t)r0 * nw);
+        P->launches += 2;
+    }
+    DevBuf& f0 = (R.action == 1) ? H.fr_lcss[0] : H.fr_ecc[0];
+    if ((rc = f0.ensure((size_t)n_roots * 4))) return rc;
+    std::vector<int32_t> ids((size_t)n_roots);
+    for (int64_t k = 0; k < n_roots; ++k) ids[(size_t)k] = (int32_t)k;
+    HIP_TRY(hipMemcpyAsync(f0.ptr, ids.data(), ids.size() * 4, hipMemcpyHostToDevice, P->stream),
+            EHM_E_HIP);
+    HIP_TRY(hipStreamSynchronize(P->stream), EHM_E_HIP);
+    HIP_TRY(hipGetLastError(), EHM_E_HIP);
+    H.cur = 0;
+    H.n_ecc = (R.action == 1) ? 0 : n_roots;
+    H.n_lcss = (R.action == 1) ? n_roots : 0;
+    T->unordered = true;      // node ids follow the allocation order; the export relabels
+    return EHM_OK;
+}

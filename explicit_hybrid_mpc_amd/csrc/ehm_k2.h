@@ -61,6 +61,18 @@ struct PersistCtl {
     unsigned long long splits;      // expanded nodes     } added once when it leaves
 };
 
+// Optional indirection of the batched oracle kernels: the hybrid partition engine
+// (ehm_hybrid.h) builds its work lists on the device and reads / writes through them, so a
+// sweep needs no host round trip between its stages.  All-null = dense batches.
+struct K2Gather {
+    const long long* src;   // per instance: offset (doubles) of its input from the base pointer
+                            // (theta / R); null = dense (inst * p, inst * (p+1)p)
+    const int32_t* dst;     // per instance: index its results are written at; null = inst
+    const int32_t* n_dev;   // device-side instance count overriding n_inst (null = n_inst)
+    int v_off;              // simplex kinds with src: Vbar = R + v_off (tree records)
+    double* grad;           // point solves: dJ/dtheta out, [dst][p]; null = not wanted
+};
+
 struct K2Launch {
     int grid;
     int threads;        // 64 * wavefronts per workgroup
@@ -79,10 +91,10 @@ struct K2Api {
     size_t (*shared_doubles)(const DevProblem& P);
     void (*point)(const K2Launch&, DevProblem, long long n_inst, const double* theta,
                   const int32_t* seg, int feas, double* J, double* u0, int32_t* status,
-                  int32_t* iters, DevCounters*);
+                  int32_t* iters, DevCounters*, K2Gather);
     void (*simplex)(const K2Launch&, DevProblem, long long n_inst, const double* R,
                     const double* Vbar, const int32_t* seg, int mode, double* obj,
-                    double* alpha, int32_t* status, int32_t* iters, DevCounters*);
+                    double* alpha, int32_t* status, int32_t* iters, DevCounters*, K2Gather);
     void (*decide)(const K2Launch&, DevProblem, DevTree, const int32_t* frontier, int nf,
                    int32_t* open_flag, DevCounters*, int sign_only);
     void (*expand)(const K2Launch&, DevProblem, DevTree, const int32_t* open_list, int n_open,

@@ -27,8 +27,9 @@ __global__ __launch_bounds__(EHM_K2_THREADS) void k2_point_batch(
     DevProblem P, long long n_inst, const double* __restrict__ theta,
     const int32_t* __restrict__ seg, int feas, double* __restrict__ J, double* __restrict__ u0,
     int32_t* __restrict__ status, int32_t* __restrict__ iters, DevCounters* cnt,
-    int wave_doubles) {
+    int wave_doubles, K2Gather G) {
     K2_PROLOGUE();
+    if (G.n_dev) n_inst = *G.n_dev;
     const long long per = (n_inst + gridDim.x - 1) / gridDim.x;
     const long long lo = (long long)blockIdx.x * per;
     const long long hi = (lo + per < n_inst) ? lo + per : n_inst;
@@ -45,7 +46,9 @@ __global__ __launch_bounds__(EHM_K2_THREADS) void k2_point_batch(
             const long long inst = lo + pull(&s_ctr, lane0);
             if (inst >= run_end) break;
             const int lane = pin(lane0);
-            if (lane < P.p) nb.th[lane] = theta[inst * P.p + lane];
+            const double* tsrc = G.src ? theta + G.src[inst] : theta + inst * P.p;
+            const long long o = G.dst ? (long long)G.dst[inst] : inst;
+            if (lane < P.p) nb.th[lane] = tsrc[lane];
             wsync();
             Wave W;
             IpmResult r;
@@ -55,18 +58,24 @@ __global__ __launch_bounds__(EHM_K2_THREADS) void k2_point_batch(
                 const int ln = pin(lane);     // nothing of the assembly outlives the attempt
                 assemble_point(S, W, nb.lp, nb.th, feas != 0, b, ln, P, d);
                 r = ipm_solve(S, W, b, ln, false,
-                              step_fraction(attempt));
+                              step_fraction(attempt), (G.grad && !feas) ? nb.F : nullptr);
                 its += r.iters;
                 if (r.status == 0) break;
             }
             r.iters = its;
             count_solve(cnt, r, lane);
-            if (lane == 0) {
-                J[inst] = r.obj;
-                if (status) status[inst] = r.status;
-                if (iters) iters[inst] = r.iters;
+            if (G.grad && !feas) {
+#if EHM2_QUAD
+                quad_grad_add(W, P, d, nb.th, nb.F, lane);
+#endif
+                if (lane < P.p) G.grad[o * P.p + lane] = nb.F[lane];
             }
-            if (u0 && lane < P.n_u) u0[inst * P.n_u + lane] = W.xb[lane];
+            if (lane == 0) {
+                J[o] = r.obj;
+                if (status) status[o] = r.status;
+                if (iters) iters[o] = r.iters;
+            }
+            if (u0 && lane < P.n_u) u0[o * P.n_u + lane] = W.xb[lane];
             wsync();
         }
         pos = run_end;
@@ -78,10 +87,11 @@ __global__ __launch_bounds__(EHM_K2_THREADS) void k2_simplex_batch(
     DevProblem P, long long n_inst, const double* __restrict__ R,
     const double* __restrict__ Vbar, const int32_t* __restrict__ seg, int mode,
     double* __restrict__ obj, double* __restrict__ alpha, int32_t* __restrict__ status,
-    int32_t* __restrict__ iters, DevCounters* cnt, int wave_doubles) {
+    int32_t* __restrict__ iters, DevCounters* cnt, int wave_doubles, K2Gather G) {
     K2_PROLOGUE();
     const int p = P.p;
     const int nR = (p + 1) * p;
+    if (G.n_dev) n_inst = *G.n_dev;
     const long long per = (n_inst + gridDim.x - 1) / gridDim.x;
     const long long lo = (long long)blockIdx.x * per;
     const long long hi = (lo + per < n_inst) ? lo + per : n_inst;
@@ -100,8 +110,11 @@ __global__ __launch_bounds__(EHM_K2_THREADS) void k2_simplex_batch(
             const int lane = pin(lane0);
             double* Rl = nb.rec;
             double* Vl = nb.rec + nR;
-            for (int k = lane; k < nR; k += 64) Rl[k] = R[inst * nR + k];
-            if (mode == SX_SLACK && lane <= p) Vl[lane] = Vbar[inst * (p + 1) + lane];
+            const double* Rsrc = G.src ? R + G.src[inst] : R + inst * nR;
+            const double* Vsrc = G.src ? Rsrc + G.v_off : Vbar + inst * (p + 1);
+            const long long o = G.dst ? (long long)G.dst[inst] : inst;
+            for (int k = lane; k < nR; k += 64) Rl[k] = Rsrc[k];
+            if (mode == SX_SLACK && lane <= p) Vl[lane] = Vsrc[lane];
             wsync();
             Wave W;
             IpmResult r;
@@ -118,15 +131,15 @@ __global__ __launch_bounds__(EHM_K2_THREADS) void k2_simplex_batch(
             r.iters = its;
             count_solve(cnt, r, lane);
             if (lane == 0) {
-                obj[inst] = (mode == SX_SLACK) ? -r.obj : r.obj;     // t* = -(min -t)
-                if (status) status[inst] = r.status;
-                if (iters) iters[inst] = r.iters;
+                obj[o] = (mode == SX_SLACK) ? -r.obj : r.obj;     // t* = -(min -t)
+                if (status) status[o] = r.status;
+                if (iters) iters[o] = r.iters;
             }
             if (alpha) {
                 const double beta = (lane < p) ? W.xb[P.n + lane] : 0.0;
                 const double sb = wave_sum(beta);
-                if (lane < p) alpha[inst * (p + 1) + lane + 1] = beta;
-                if (lane == 0) alpha[inst * (p + 1)] = 1.0 - sb;
+                if (lane < p) alpha[o * (p + 1) + lane + 1] = beta;
+                if (lane == 0) alpha[o * (p + 1)] = 1.0 - sb;
             }
             wsync();
         }
@@ -819,16 +832,16 @@ size_t shared_doubles_for(const DevProblem& P) { return shared_doubles(P); }
 
 void l_point(const K2Launch& L, DevProblem P, long long n_inst, const double* theta,
              const int32_t* seg, int feas, double* J, double* u0, int32_t* status,
-             int32_t* iters, DevCounters* cnt) {
+             int32_t* iters, DevCounters* cnt, K2Gather G) {
     hipLaunchKernelGGL(k2_point_batch, dim3(L.grid), dim3(L.threads), L.lds_bytes, L.stream, P,
-                       n_inst, theta, seg, feas, J, u0, status, iters, cnt, L.wave_doubles);
+                       n_inst, theta, seg, feas, J, u0, status, iters, cnt, L.wave_doubles, G);
 }
 void l_simplex(const K2Launch& L, DevProblem P, long long n_inst, const double* R,
                const double* Vbar, const int32_t* seg, int mode, double* obj, double* alpha,
-               int32_t* status, int32_t* iters, DevCounters* cnt) {
+               int32_t* status, int32_t* iters, DevCounters* cnt, K2Gather G) {
     hipLaunchKernelGGL(k2_simplex_batch, dim3(L.grid), dim3(L.threads), L.lds_bytes, L.stream,
                        P, n_inst, R, Vbar, seg, mode, obj, alpha, status, iters, cnt,
-                       L.wave_doubles);
+                       L.wave_doubles, G);
 }
 void l_decide(const K2Launch& L, DevProblem P, DevTree T, const int32_t* frontier, int nf,
               int32_t* open_flag, DevCounters* cnt, int sign_only) {

@@ -155,8 +155,9 @@ __device__ __forceinline__ void count_solve(DevCounters* cnt, const IpmResult& r
 EHM3_KERNEL void k3_point_batch(
     DevProblem P, long long n_inst, const double* __restrict__ theta,
     const int32_t* __restrict__ seg, int feas, double* __restrict__ J, double* __restrict__ u0,
-    int32_t* __restrict__ status, int32_t* __restrict__ iters, DevCounters* cnt) {
+    int32_t* __restrict__ status, int32_t* __restrict__ iters, DevCounters* cnt, K2Gather G) {
     K3_PROLOGUE(0);
+    if (G.n_dev) n_inst = *G.n_dev;
     const long long per = (n_inst + gridDim.x - 1) / gridDim.x;
     const long long lo = (long long)blockIdx.x * per;
     const long long hi = (lo + per < n_inst) ? lo + per : n_inst;
@@ -165,7 +166,9 @@ EHM3_KERNEL void k3_point_batch(
         tid = pin(tid0);
         while (d + 1 < P.n_delta && seg[d + 1] <= inst) ++d;
         carve_lp(L, sm + node_doubles(P.p, P.n_u), P, d);
-        if (tid < P.p) nb.th[tid] = theta[inst * P.p + tid];
+        const double* tsrc = G.src ? theta + G.src[inst] : theta + inst * P.p;
+        const long long o = G.dst ? (long long)G.dst[inst] : inst;
+        if (tid < P.p) nb.th[tid] = tsrc[tid];
         __syncthreads();
         IpmResult r;
         int its = 0;
@@ -179,11 +182,11 @@ EHM3_KERNEL void k3_point_batch(
         r.iters = its;
         count_solve(cnt, r, tid);
         if (tid == 0) {
-            J[inst] = r.obj;
-            if (status) status[inst] = r.status;
-            if (iters) iters[inst] = r.iters;
+            J[o] = r.obj;
+            if (status) status[o] = r.status;
+            if (iters) iters[o] = r.iters;
         }
-        if (u0 && tid < P.n_u) u0[inst * P.n_u + tid] = L.xb[tid];
+        if (u0 && tid < P.n_u) u0[o * P.n_u + tid] = L.xb[tid];
         __syncthreads();
     }
 }
@@ -193,10 +196,11 @@ EHM3_KERNEL void k3_simplex_batch(
     DevProblem P, long long n_inst, const double* __restrict__ R,
     const double* __restrict__ Vbar, const int32_t* __restrict__ seg, int mode,
     double* __restrict__ obj, double* __restrict__ alpha, int32_t* __restrict__ status,
-    int32_t* __restrict__ iters, DevCounters* cnt) {
+    int32_t* __restrict__ iters, DevCounters* cnt, K2Gather G) {
     K3_PROLOGUE(0);
     const int p = P.p;
     const int nR = (p + 1) * p;
+    if (G.n_dev) n_inst = *G.n_dev;
     const long long per = (n_inst + gridDim.x - 1) / gridDim.x;
     const long long lo = (long long)blockIdx.x * per;
     const long long hi = (lo + per < n_inst) ? lo + per : n_inst;
@@ -207,8 +211,11 @@ EHM3_KERNEL void k3_simplex_batch(
         carve_lp(L, sm + node_doubles(P.p, P.n_u), P, d);
         double* Rl = nb.rec;
         double* Vl = nb.rec + nR;
-        for (int k = tid; k < nR; k += NT) Rl[k] = R[inst * nR + k];
-        if (mode == SX_SLACK && tid <= p) Vl[tid] = Vbar[inst * (p + 1) + tid];
+        const double* Rsrc = G.src ? R + G.src[inst] : R + inst * nR;
+        const double* Vsrc = G.src ? Rsrc + G.v_off : Vbar + inst * (p + 1);
+        const long long o = G.dst ? (long long)G.dst[inst] : inst;
+        for (int k = tid; k < nR; k += NT) Rl[k] = Rsrc[k];
+        if (mode == SX_SLACK && tid <= p) Vl[tid] = Vsrc[tid];
         __syncthreads();
         IpmResult r;
         int its = 0;
@@ -222,15 +229,15 @@ EHM3_KERNEL void k3_simplex_batch(
         r.iters = its;
         count_solve(cnt, r, tid);
         if (tid == 0) {
-            obj[inst] = (mode == SX_SLACK) ? -r.obj : r.obj;     // t* = -(min -t)
-            if (status) status[inst] = r.status;
-            if (iters) iters[inst] = r.iters;
+            obj[o] = (mode == SX_SLACK) ? -r.obj : r.obj;     // t* = -(min -t)
+            if (status) status[o] = r.status;
+            if (iters) iters[o] = r.iters;
         }
         if (alpha && B.wave == 0) {
             const double beta = (tid < p) ? L.xb[P.n + tid] : 0.0;
             const double sb = wave_sum(beta);
-            if (tid < p) alpha[inst * (p + 1) + tid + 1] = beta;
-            if (tid == 0) alpha[inst * (p + 1)] = 1.0 - sb;
+            if (tid < p) alpha[o * (p + 1) + tid + 1] = beta;
+            if (tid == 0) alpha[o * (p + 1)] = 1.0 - sb;
         }
         __syncthreads();
     }
@@ -457,15 +464,15 @@ size_t shared_doubles_for(const DevProblem&) { return 0; }
 
 void l_point(const K2Launch& L, DevProblem P, long long n_inst, const double* theta,
              const int32_t* seg, int feas, double* J, double* u0, int32_t* status,
-             int32_t* iters, DevCounters* cnt) {
+             int32_t* iters, DevCounters* cnt, K2Gather G) {
     hipLaunchKernelGGL(k3_point_batch, dim3(L.grid), dim3(L.threads), L.lds_bytes, L.stream, P,
-                       n_inst, theta, seg, feas, J, u0, status, iters, cnt);
+                       n_inst, theta, seg, feas, J, u0, status, iters, cnt, G);
 }
 void l_simplex(const K2Launch& L, DevProblem P, long long n_inst, const double* R,
                const double* Vbar, const int32_t* seg, int mode, double* obj, double* alpha,
-               int32_t* status, int32_t* iters, DevCounters* cnt) {
+               int32_t* status, int32_t* iters, DevCounters* cnt, K2Gather G) {
     hipLaunchKernelGGL(k3_simplex_batch, dim3(L.grid), dim3(L.threads), L.lds_bytes, L.stream,
-                       P, n_inst, R, Vbar, seg, mode, obj, alpha, status, iters, cnt);
+                       P, n_inst, R, Vbar, seg, mode, obj, alpha, status, iters, cnt, G);
 }
 void l_decide(const K2Launch& L, DevProblem P, DevTree T, const int32_t* frontier, int nf,
               int32_t* open_flag, DevCounters* cnt, int sign_only) {

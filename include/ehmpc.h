@@ -304,6 +304,10 @@ typedef struct ehm_tree_info {
                                optimal cost at the vertices, from the multipliers of the vertex
                                solves) without solving their suboptimality-test LP            */
     int64_t witness_open;   /* nodes proved open by their midpoint solve (option "mid_first") */
+    /* multi-commutation runs */
+    int64_t swaps;          /* nodes that took a better commutation in place (lib/worker.py:396-401) */
+    int64_t blacklisted;    /* commutations blacklisted after a failed vertex solve
+                               (lib/oracle.py:198-218, 406-414) */
 } ehm_tree_info;
 
 int ehm_tree_info_get(const ehm_tree* tree, ehm_tree_info* out);

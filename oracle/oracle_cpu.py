@@ -57,6 +57,10 @@ class OracleCPU:
         self.memoize = False       # cache point solves by (theta, commutation): children
         self._memo = {}            # share p of their p+1 vertices with the parent
         self.last_margin = np.inf  # |t*| of the last feasibility decision
+        # test hook for the numerical-failure retry loops (lib/oracle.py:198-218, 406-414):
+        # vertex solves of this commutation index raise like a failed MOSEK call would
+        self.fail_vertex_solves_of = None
+        self.n_blacklisted = 0
 
     # -- helpers ---------------------------------------------------------------------
     def delta_index(self, delta):
@@ -155,6 +159,9 @@ class OracleCPU:
     # -- lib/oracle.py:416-443 -----------------------------------------------------------
     def _compute_vx_inputs_and_costs(self, R, delta):
         out = []
+        if (self.fail_vertex_solves_of is not None and
+                self.delta_index(delta) == self.fail_vertex_solves_of):
+            raise SolverError('forced failure (test hook)')
         for vertex in R:
             u, J, t = self.P_theta_delta(theta=vertex, delta=delta)
             if u is None:
@@ -167,11 +174,21 @@ class OracleCPU:
 
     # -- lib/oracle.py:175-218 -----------------------------------------------------------
     def V_R(self, R):
-        for d in range(len(self.models)):
-            if self._feasible_on_vertices(R, d):
-                delta = self.deltas[d].copy()
+        blacklist = set()                      # lib/oracle.py:198 delta_neq_other_deltas
+        while True:
+            found = None
+            for d in range(len(self.models)):
+                if d not in blacklist and self._feasible_on_vertices(R, d):
+                    found = d
+                    break
+            if found is None:
+                return None, None
+            delta = self.deltas[found].copy()
+            try:
                 return delta, self._compute_vx_inputs_and_costs(R, delta)
-        return None, None
+            except SolverError:                # lib/oracle.py:214-218
+                blacklist.add(found)
+                self.n_blacklisted += 1
 
     # -- lib/oracle.py:285-309 -----------------------------------------------------------
     def slack(self, R, V_delta_R, d):
@@ -209,15 +226,22 @@ class OracleCPU:
             t, alpha = self.slack(R, V_delta_R, d)
             if t >= 0.:
                 cand.append((t, d, alpha))
-        if not cand:
-            return None, None, None, None
-        t_max = max(c[0] for c in cand)
-        best = next(c for c in cand if c[0] >= t_max - TIE_TOL * (1. + abs(t_max)))
-        delta_star = self.deltas[best[1]].copy()
-        if np.array_equal(delta_star.astype(int), np.asarray(delta_ref).astype(int)):
-            return None, None, None, None
-        theta_star = best[2] @ R
-        vx = self._compute_vx_inputs_and_costs(R, delta_star)
-        var_small = self.in_variability_ball(R, V_delta_R, delta_ref, delta_star,
-                                             theta_star)
-        return delta_star, theta_star, vx, var_small
+        blacklist = set()                      # lib/oracle.py:345 delta_blacklist
+        while True:
+            live = [c for c in cand if c[1] not in blacklist]
+            if not live:
+                return None, None, None, None
+            t_max = max(c[0] for c in live)
+            best = next(c for c in live if c[0] >= t_max - TIE_TOL * (1. + abs(t_max)))
+            delta_star = self.deltas[best[1]].copy()
+            if np.array_equal(delta_star.astype(int), np.asarray(delta_ref).astype(int)):
+                return None, None, None, None
+            theta_star = best[2] @ R
+            try:
+                vx = self._compute_vx_inputs_and_costs(R, delta_star)
+                var_small = self.in_variability_ball(R, V_delta_R, delta_ref, delta_star,
+                                                     theta_star)
+                return delta_star, theta_star, vx, var_small
+            except SolverError:                # lib/oracle.py:406-414
+                blacklist.add(best[1])
+                self.n_blacklisted += 1

@@ -1,0 +1,198 @@
+"""
+Multi-commutation (hybrid) partitions on the device engine (csrc/ehm_hybrid.h behind
+ehm_partition_run) against
+
+* the CPU restatement of lib/worker.py:241-417 / lib/oracle.py:175-414 (``oracle/``): identical
+  tree, commutations and closed leaves on a whole small partition, and -- at the dimensions of
+  BASELINE.json's configs[2] (n_x = 4, n_u = 2, N = 5, 32 commutations) -- identical SUB-FORESTS
+  below nodes sampled from the device tree;
+* the round-1 host loop over the batched Level-2 oracles (tests/hybrid_host_loop.py), an
+  independent route through ehm_lcss_batch / ehm_vr_batch / ehm_feas_all_batch.
+
+Tolerances: vertices bit-identical, costs 1e-7 relative, decisions identical.
+"""
+
+import numpy as np
+import pytest
+
+from tests import helpers
+
+pytestmark = pytest.mark.gpu
+
+RTOL = 1e-7
+CONFIG3_PICKS, CONFIG3_VISITS = 8, 8
+CONFIG3_ABS_FRAC, CONFIG3_EPS_R = 0.5, 0.5
+
+
+def by_location(flat, locs):
+    loc = flat.locations(locs)
+    return {name: k for k, name in enumerate(loc)}
+
+
+def assert_same_flat(a, b, locs):
+    """Two FlatTrees with possibly different node numbering describe the same tree."""
+    la, lb = by_location(a, locs), by_location(b, locs)
+    assert set(la) == set(lb)
+    for name, ka in la.items():
+        kb = lb[name]
+        assert np.array_equal(a.vertices[ka], b.vertices[kb]), name
+        assert a.is_leaf(ka) == b.is_leaf(kb), name
+        assert (a.flags[ka] & 3) == (b.flags[kb] & 3), name
+        assert a.delta_idx[ka] == b.delta_idx[kb], name
+        assert np.allclose(a.vertex_costs[ka], b.vertex_costs[kb], rtol=RTOL, atol=RTOL), name
+        assert np.allclose(a.vertex_inputs[ka], b.vertex_inputs[kb], rtol=1e-5, atol=1e-6), name
+
+
+def test_device_engine_equals_host_loop_over_batched_oracles():
+    from explicit_hybrid_mpc_amd import engine
+    from tests.hybrid_host_loop import grow_hybrid_host
+    mpc = helpers.make_instance('pwa_small', 0)
+    eps_a = helpers.eps_a_rule(mpc, 0.25)
+    roots, locs = helpers.roots_of(mpc)
+    gp = engine.GpuProblem(mpc.compile(), eps_a, 0.2)
+    dev = gp.partition(np.array(roots), action='ecc')
+    host = grow_hybrid_host(gp, np.array(roots), action='ecc')
+    # the same with tiny chunks: every chunk boundary of the sweep is exercised
+    import os
+    os.environ['EHM_HY_CHUNK'] = '64'
+    try:
+        dev2 = gp.partition(np.array(roots), action='ecc')
+    finally:
+        del os.environ['EHM_HY_CHUNK']
+    gp.close()
+    assert dev.n_nodes == host.n_nodes and dev.info['n_closed'] == host.info['n_closed']
+    assert_same_flat(dev, host, locs)
+    assert_same_flat(dev2, host, locs)
+    assert dev.info['swaps'] >= 0 and dev.info['blacklisted'] == 0
+    assert dev.info['max_depth'] == max(len(s) for s in dev.locations([''] * len(locs)))
+    assert abs(dev.info['min_margin'] - host.info['min_margin']) <= 1e-6 * (
+        1 + host.info['min_margin'])
+
+
+def test_lcss_resume_on_hybrid_leaf():
+    """action='lcss' with initial data (lib/scheduler.py:633-639) on the device engine."""
+    from explicit_hybrid_mpc_amd import engine
+    mpc = helpers.make_instance('pwa_small', 0)
+    eps_a = helpers.eps_a_rule(mpc, 0.25)
+    roots, locs = helpers.roots_of(mpc)
+    gp = engine.GpuProblem(mpc.compile(), eps_a, 0.2)
+    coarse = gp.partition(np.array(roots), action='ecc', max_depth=3)
+    assert coarse.info['truncated'] == 1
+    open_leaves = [k for k in range(coarse.n_nodes)
+                   if coarse.is_leaf(k) and not (coarse.flags[k] & 1) and (coarse.flags[k] & 2)]
+    assert open_leaves
+    init = dict(delta=coarse.deltas[coarse.delta_idx[open_leaves]],
+                vertex_costs=coarse.vertex_costs[open_leaves],
+                vertex_inputs=coarse.vertex_inputs[open_leaves])
+    sub = gp.partition(coarse.vertices[open_leaves], action='lcss', init=init)
+    full = gp.partition(np.array(roots), action='ecc')
+    gp.close()
+    # the resumed sub-forests are the subtrees of the full run below the same nodes
+    loc_c = coarse.locations(locs)
+    lf = by_location(full, locs)
+    sub_loc = sub.locations([loc_c[k] for k in open_leaves])
+    for k, name in enumerate(sub_loc):
+        kf = lf[name]
+        assert np.array_equal(sub.vertices[k], full.vertices[kf]), name
+        assert sub.is_leaf(k) == full.is_leaf(kf), name
+        assert (sub.flags[k] & 1) == (full.flags[kf] & 1), name
+        assert sub.delta_idx[k] == full.delta_idx[kf], name
+
+
+def test_blacklist_and_retry_after_a_failed_vertex_solve(monkeypatch):
+    """
+    a9 (lib/oracle.py:198-218, 406-414): a commutation whose vertex solves fail is blacklisted
+    for the node and the oracle is asked again.  The failure is forced for one commutation
+    (EHM_HY_FAIL_DELTA); the CPU oracle is given the same failure.
+    """
+    from explicit_hybrid_mpc_amd import engine
+    from oracle.oracle_cpu import OracleCPU
+    from oracle.partition_cpu import PartitionCPU
+    from tests.test_gpu_partition import compare_trees
+    mpc = helpers.make_instance('pwa_small', 0)
+    eps_a = helpers.eps_a_rule(mpc, 0.25)
+    roots, locs = helpers.roots_of(mpc)
+    gp = engine.GpuProblem(mpc.compile(), eps_a, 0.2)
+    plain = gp.partition(np.array(roots), action='ecc')
+    used = [d for d in np.unique(plain.delta_idx) if d >= 0]
+    # a commutation the plain run adopts somewhere but not everywhere
+    counts = {d: int(np.sum(plain.delta_idx == d)) for d in used}
+    fail = min(counts, key=counts.get)
+    monkeypatch.setenv('EHM_HY_FAIL_DELTA', str(fail))
+    forced = gp.partition(np.array(roots), action='ecc')
+    gp.close()
+    assert forced.info['blacklisted'] > 0
+    assert not np.any(forced.delta_idx == fail)
+    orc = OracleCPU(mpc, eps_a, 0.2)
+    orc.memoize = True
+    orc.fail_vertex_solves_of = int(fail)
+    cpu = PartitionCPU(orc)
+    cpu.run(roots, locs, 'ecc')
+    for nd in cpu.nodes.values():
+        if nd['vertex_costs'] is None:
+            nd['vertex_costs'] = np.zeros(nd['vertices'].shape[0])
+    compare_trees(forced, cpu.nodes, locs)
+    assert orc.n_blacklisted > 0
+
+
+def test_config3_subforests_identical_to_cpu_oracle():
+    """
+    BASELINE.json configs[2] dimensions (n_x = 4, n_u = 2, N = 5: 32 commutations, LPs of
+    20..25 columns): nodes sampled from the device tree are grown again by the CPU oracle
+    (HiGHS, action 'lcss' from the exported record, a bounded number of visits each) and the
+    visited part of every sub-forest must equal the device's subtree below that node.
+    """
+    from explicit_hybrid_mpc_amd import engine, examples
+    from oracle.oracle_cpu import OracleCPU
+    from oracle.partition_cpu import PartitionCPU
+    mpc = helpers.make_instance('pwa', 0)
+    can = mpc.compile()
+    assert can.n_delta == 32 and can.p == 4
+    gp = engine.GpuProblem(can, 1., 1.)
+    V = examples.box_vertices(examples.theta_box(mpc))
+    eps_a = float(np.max(gp.solve_pt(CONFIG3_ABS_FRAC * V)[0]))
+    eps_r = CONFIG3_EPS_R
+    gp.set_eps(eps_a, eps_r)
+    roots, locs = helpers.roots_of(mpc)
+    flat = gp.partition(np.array(roots), action='ecc', max_nodes=1 << 21)
+    gp.close()
+    total = np.prod(2 * examples.theta_box(mpc))
+    assert abs(flat.info['volume_closed'] - total) <= 1e-9 * total
+    assert flat.info['min_margin'] > 1e-6
+    assert len(set(int(d) for d in flat.delta_idx if d >= 0)) >= 2
+    loc = flat.locations(locs)
+    pos = {name: k for k, name in enumerate(loc)}
+    # sample internal lcss nodes (they carry data) spread over the tree, deterministic
+    cand = [k for k in range(flat.n_nodes) if (flat.flags[k] & 2) and not flat.is_leaf(k)]
+    rng = np.random.default_rng(0)
+    picks = rng.choice(cand, size=min(CONFIG3_PICKS, len(cand)), replace=False)
+    orc = OracleCPU(mpc, eps_a, eps_r)
+    orc.memoize = True
+    decided, costs = 0, 0
+    for k in picks:
+        # the exported record is the node's FINAL one (after a possible swap in place); the CPU
+        # oracle continues from it and has to make the device's split
+        root = dict(vertices=flat.vertices[k].copy(),
+                    commutation=flat.deltas[flat.delta_idx[k]].copy(),
+                    vertex_costs=flat.vertex_costs[k].copy(),
+                    vertex_inputs=flat.vertex_inputs[k].copy(),
+                    is_epsilon_suboptimal=False, leaf=True)
+        cpu = PartitionCPU(orc, max_nodes=CONFIG3_VISITS)
+        cpu.run([root], [loc[k]], 'lcss')
+        assert cpu.min_margin > 1e-6
+        for name, ref in cpu.nodes.items():
+            kd = pos[name]          # KeyError = the CPU split a node the device did not
+            assert np.array_equal(flat.vertices[kd], ref['vertices']), name
+            same_delta = np.array_equal(flat.deltas[flat.delta_idx[kd]].astype(int),
+                                        ref['commutation'].astype(int))
+            if (not ref['leaf']) or ref['is_epsilon_suboptimal']:
+                # the CPU run finished with this node: same fate, same final commutation
+                assert flat.is_leaf(kd) == ref['leaf'], name
+                assert bool(flat.flags[kd] & 1) == ref['is_epsilon_suboptimal'], name
+                assert same_delta, name
+                decided += 1
+            if same_delta:
+                assert np.allclose(flat.vertex_costs[kd], ref['vertex_costs'],
+                                   rtol=RTOL, atol=RTOL), name
+                costs += 1
+    assert decided >= 3 * CONFIG3_PICKS and costs >= decided
