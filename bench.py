@@ -32,6 +32,7 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 
+CONFIG3 = (0.5, 1.0, 24)     # abs_frac, eps_r, max_depth of --workload config3
 FP64_PEAK_TFLOPS = 78.6     # MI355X FP64 vector = FP32 vector / 2 (157.3 TF, MI355X_MICROARCH.md)
 HBM_PEAK_GBS = 8000.0
 
@@ -46,48 +47,138 @@ def node_bytes(p, n_u, delta_len):
     return 8 * ((p + 1) * p + (p + 1) + (p + 1) * n_u) + delta_len + 16
 
 
-def pmc_traffic(kernel, summary='pmc_summary_bench.json'):
+def flops_executed_per_iteration(n_lp, n_mpc, m, np_cap):
+    """
+    What the shared-block solver (csrc/ehm_ipm2.h) really executes per iteration, as opposed to
+    the SURVEY formula above: the normal matrix is formed on the lower-triangular 4x4 block pairs
+    of the n_mpc columns that have MPC entries (nb (nb + 1) / 2 pairs x 16 entries x m rows), the
+    elimination runs unsymmetric at the compiled column capacity np_cap and updates both
+    triangles (2 np_cap^3 / 3), matrix-vector products and triangular solves as in the formula.
+    """
+    nb = (n_mpc + 3) // 4
+    return nb * (nb + 1) / 2. * 32. * m + 2. * np_cap ** 3 / 3. + 8. * m * n_lp + 4. * n_lp * n_lp
+
+
+def np_capacity(n_lp):
+    """Column capacity of the compiled instance that holds n_lp columns (build.K2_NPS)."""
+    return next(c for c in (8, 12, 16, 20, 24, 28, 32, 64) if c >= n_lp)
+
+
+def kernel_source_hash():
+    """sha256 over the kernel sources: a profile is only quoted for the code it was taken from."""
+    import hashlib
+    h = hashlib.sha256()
+    src = os.path.join(ROOT, 'explicit_hybrid_mpc_amd', 'csrc')
+    for name in sorted(os.listdir(src)):
+        if name.endswith(('.hip', '.h')):
+            h.update(open(os.path.join(src, name), 'rb').read())
+    return h.hexdigest()[:16]
+
+
+def pmc_traffic(kernel, summary):
     """
     HBM bytes per launch of `kernel` from the committed rocprofv3 --pmc passes of THIS workload
-    (profiles/r1/pmc_summary_bench.json, tools/profile.sh): FETCH_SIZE / WRITE_SIZE are in KiB
+    (profiles/<round>/pmc_summary_*.json, tools/profile.sh): FETCH_SIZE / WRITE_SIZE are in KiB
     and come from separate passes; on gfx950 FETCH_SIZE tallies 128-byte read requests at 64
-    bytes, so it is doubled (MI355X_MICROARCH.md, HBM section).  None if no profile is there.
+    bytes, so it is doubled (MI355X_MICROARCH.md, HBM section).  The summary carries the hash of
+    the kernel sources it was measured on (tools/pmc_summary.py); a profile of OTHER code is not
+    quoted: returns (None, reason).
     """
-    path = os.path.join(ROOT, 'profiles', 'r1', summary)
+    for rnd in ('r2', 'r1'):
+        path = os.path.join(ROOT, 'profiles', rnd, summary)
+        if os.path.exists(path):
+            break
+    else:
+        return None, 'no PMC profile committed for this workload'
     try:
-        c = json.load(open(path))['counters'][kernel]
+        doc = json.load(open(path))
+        c = doc['counters'][kernel]
         n_f, n_w = c['_dispatches_pmc3'], c['_dispatches_pmc4']
-        return (2. * c['FETCH_SIZE'] / n_f + c['WRITE_SIZE'] / n_w) * 1024.
+        traffic = (2. * c['FETCH_SIZE'] / n_f + c['WRITE_SIZE'] / n_w) * 1024.
     except (OSError, KeyError, ValueError, ZeroDivisionError):
-        return None
+        return None, 'profile %s holds no counters for %s' % (os.path.relpath(path, ROOT), kernel)
+    if doc.get('kernel_source_sha') != kernel_source_hash():
+        return None, ('stale: %s was measured on kernel sources %s, this tree is %s' %
+                      (os.path.relpath(path, ROOT), doc.get('kernel_source_sha'),
+                       kernel_source_hash()))
+    return traffic, os.path.relpath(path, ROOT)
 
 
-def cpu_baseline(mpc, eps_a, eps_r, seconds):
-    """Oracle (CPU restatement, HiGHS) timed on a bounded prefix of the same partition."""
+def make_mpc(workload, seed):
+    from explicit_hybrid_mpc_amd import examples
+    if workload == 'config4':
+        return examples.integrator_chain_mpc()
+    if workload == 'config3':
+        return examples.pwa_mpc(seed=seed)
+    return examples.linear_mpc(seed=seed, cost='quadratic' if workload == 'config2q' else 'inf')
+
+
+def _cpu_worker(job):
+    """One host core: its share of the oracle's work list, grown for a bounded wall time."""
+    workload, seed, eps_a, eps_r, nodes, work, seconds = job
+    from oracle.oracle_cpu import OracleCPU
+    from oracle.partition_cpu import PartitionCPU
+    orc = OracleCPU(make_mpc(workload, seed), eps_a, eps_r)
+    part = PartitionCPU(orc, max_nodes=0)
+    part.nodes = nodes
+    part._work = work
+    t0 = time.perf_counter()
+    while part._work and time.perf_counter() - t0 < seconds:
+        part.max_nodes = part.visits + 5
+        part.resume()
+    return orc.n_solves, part.visits, time.perf_counter() - t0
+
+
+def cpu_baseline(workload, seed, eps_a, eps_r, seconds):
+    """
+    The oracle (CPU restatement of lib/worker.py + lib/oracle.py, HiGHS) on ALL host cores, laid
+    out like the reference's run (lib/prepare.py:161, lib/scheduler.py:620-642): one process per
+    core; the main process grows the top of the SAME partition until its work list (the
+    reference's task queue: one task per open leaf) holds a task per core, deals it round-robin,
+    and every process grows its tasks for `seconds`.
+    """
+    import multiprocessing as mp
     from oracle.oracle_cpu import OracleCPU
     from oracle.partition_cpu import PartitionCPU
     from oracle import geometry
     from explicit_hybrid_mpc_amd import examples
+    cores = os.cpu_count() or 1
+    mpc = make_mpc(workload, seed)
     V = examples.box_vertices(examples.theta_box(mpc))
     roots, locs = geometry.delaunay_simplices(V)
     orc = OracleCPU(mpc, eps_a, eps_r)
-    part = PartitionCPU(orc, max_nodes=50)
+    top = PartitionCPU(orc, max_nodes=0)
     t0 = time.perf_counter()
-    visits = 0
-    while time.perf_counter() - t0 < seconds:
-        # extend the bounded prefix in chunks of node visits
-        part.max_nodes = part.visits + 50
-        if part.visits == 0:
-            part.run(roots, locs, 'ecc')
-        else:
-            part.resume()
-        visits = part.visits
-        if not part.truncated:
-            break
-    dt = time.perf_counter() - t0
-    return dict(value=orc.n_solves / dt, unit='LP solves/s', cores=1, kind='port',
-                sample='first %d node visits of the same partition (%d HiGHS LP solves, '
-                       '%.1f s), oracle/partition_cpu.py' % (visits, orc.n_solves, dt))
+    top.run(roots, locs, 'ecc')
+    # breadth first (oldest task first) so the queue widens instead of diving
+    while top._work and len(top._work) < cores and time.perf_counter() - t0 < 0.5 * seconds:
+        top._work.insert(0, top._work.pop())      # rotate: next visit takes the OLDEST entry
+        top.max_nodes = top.visits + 1
+        top.resume()
+    t_top = time.perf_counter() - t0
+    work = list(top._work)
+    n_proc = max(1, min(cores, len(work)))
+    jobs = []
+    for r in range(n_proc):
+        mine = work[r::n_proc]
+        jobs.append((workload, seed, eps_a, eps_r, {loc: top.nodes[loc] for loc, _ in mine},
+                     mine, seconds))
+    t1 = time.perf_counter()
+    with mp.get_context('spawn').Pool(n_proc) as pool:
+        # bounded: a worker that dies at start-up must not hang the bench
+        res = pool.map_async(_cpu_worker, jobs).get(timeout=3 * seconds + 120)
+    wall = time.perf_counter() - t1
+    solves = sum(r[0] for r in res)
+    visits = sum(r[1] for r in res)
+    busy = max(r[2] for r in res)
+    return dict(value=solves / busy, unit='LP solves/s', cores=n_proc, host_cores=cores,
+                kind='port',
+                sample='%d processes (one per core; the top of the partition, %d node visits / '
+                       '%d LP solves in %.1f s on one core, produced %d tasks, dealt round-robin), '
+                       '%.1f s each on the same partition: %d node visits, %d HiGHS LP solves '
+                       '(oracle/partition_cpu.py; %.1f s wall incl. process start)' %
+                       (n_proc, top.visits, orc.n_solves, t_top, len(work), busy, visits, solves,
+                        wall))
 
 
 def main():
@@ -96,9 +187,12 @@ def main():
     ap.add_argument('--steps', type=int, default=3)
     ap.add_argument('--warmup', type=int, default=1)
     ap.add_argument('--seed', type=int, default=0)
-    ap.add_argument('--workload', choices=['config2', 'config4', 'config2q'], default='config2',
-                    help='config2 = the BASELINE.json metric (default); config4 = n_x=6 n_u=3 N=10 '
-                         'box-constrained instance on the wide kernels (a parity-test '
+    ap.add_argument('--workload', choices=['config2', 'config3', 'config4', 'config2q'],
+                    default='config2',
+                    help='config2 = the BASELINE.json metric (default); config3 = the 2-mode PWA '
+                         'hybrid instance (32 commutations, mixed-integer oracles on the device '
+                         'engine of csrc/ehm_hybrid.h; BASELINE.json configs[2]); config4 = n_x=6 '
+                         'n_u=3 N=10 box-constrained instance on the wide kernels (a parity-test '
                          'configuration, timed for the record); config2q = config 2 with the '
                          'quadratic cost of the same weights (convex QP / QCQP oracles, the '
                          "reference's cvx.quad_form cost class; not the headline metric)")
@@ -106,6 +200,11 @@ def main():
                     help='eps_a rule of lib/examples.py:42-46 (default 0.02; config4: 0.4)')
     ap.add_argument('--eps-r', type=float, default=None, help='default 1e-2; config4: 0.25')
     ap.add_argument('--max-nodes', type=int, default=1 << 22)
+    ap.add_argument('--max-depth', type=int, default=None,
+                    help='leave nodes open at this tree depth (config3 default: 24 -- its optimal '
+                         'cost jumps where a mode stops being admissible, and no simplicial '
+                         'partition is epsilon-suboptimal ACROSS a jump: the refinement along that '
+                         'surface never ends, in the reference as here)')
     ap.add_argument('--shard-min-frontier', type=int, default=0,
                     help='frontier size at which it is dealt over the ranks (0 = 64 per rank)')
     ap.add_argument('--balance', choices=['static', 'dynamic'], default='static',
@@ -150,13 +249,15 @@ def main():
     from explicit_hybrid_mpc_amd import tools as ehm_tools
 
     wide = args.workload == 'config4'
+    hybrid = args.workload == 'config3'
     if args.abs_frac is None:
-        args.abs_frac = 0.4 if wide else 0.02
+        args.abs_frac = {'config4': 0.4, 'config3': CONFIG3[0]}.get(args.workload, 0.02)
     if args.eps_r is None:
-        args.eps_r = 0.25 if wide else 1e-2
+        args.eps_r = {'config4': 0.25, 'config3': CONFIG3[1]}.get(args.workload, 1e-2)
+    if args.max_depth is None:
+        args.max_depth = CONFIG3[2] if hybrid else 0
     quad = args.workload == 'config2q'
-    mpc = examples.integrator_chain_mpc() if wide else \
-        examples.linear_mpc(seed=args.seed, cost='quadratic' if quad else 'inf')
+    mpc = make_mpc(args.workload, args.seed)
     can = mpc.compile()
     gp = engine.GpuProblem(can, 1., 1., device=device_index)
     if not wide:
@@ -166,14 +267,16 @@ def main():
         gp.set_option('mid_first', 0)
     static = args.balance == 'static' and not args.status_dir
     persistent = (args.engine == 1 and (world == 1 or static) and args.solver == 2 and
-                  not wide and not args.status_dir)
+                  not wide and not hybrid and not args.status_dir)
+    if hybrid and world > 1:
+        raise SystemExit('bench.py: --workload config3 runs on one GPU in this build')
     # (the persistent kernel exists at one solver width, k2_persist, and -- where a pair of
     # instances is compiled, as for this workload -- at two, kp_persist; the library picks)
-    kname = 'k3_lcss_decide' if wide else (('kp_persist' if not quad else 'k2_persist')
-                                           if persistent else
-                                           'k2_lcss_decide' if args.solver == 2
-                                           else 'k_lcss_decide')
-    pmc_file = 'pmc_summary_wide.json' if wide else 'pmc_summary_bench.json'
+    kname = 'k3_lcss_decide' if wide else 'k2_simplex_batch' if hybrid else (
+        ('kp_persist' if not quad else 'k2_persist') if persistent else
+        'k2_lcss_decide' if args.solver == 2 else 'k_lcss_decide')
+    pmc_file = {'config4': 'pmc_summary_wide.json', 'config3': 'pmc_summary_config3.json',
+                'config2q': 'pmc_summary_quad.json'}.get(args.workload, 'pmc_summary_bench.json')
     half = examples.theta_box(mpc)
     V = examples.box_vertices(half)
     # eps_a by the reference's rule (lib/examples.py:42-46), evaluated on the GPU oracle
@@ -200,7 +303,8 @@ def main():
     def step():
         if (world == 1 or static) and not args.status_dir:
             return gp.partition(roots, action='ecc', max_nodes=args.max_nodes, export=False,
-                                shard=shard, with_volume=False, engine=args.engine)
+                                shard=None if hybrid else shard, with_volume=False,
+                                engine=args.engine, max_depth=args.max_depth)
         info, log, rounds = distributed.run_balanced(
             gp, roots, action='ecc', max_nodes=args.max_nodes,
             min_frontier=args.shard_min_frontier, sweeps_per_round=args.sweeps_per_round,
@@ -222,6 +326,15 @@ def main():
     infos = [step() for _ in range(args.steps)]
     barrier()
     elapsed = time.perf_counter() - t0
+    # what the caller gets back: one more partition WITH the flat export (device -> host copy of
+    # every record + breadth-first relabelling), outside the timed region, reported next to it
+    ms_export = None
+    if world == 1:
+        t1 = time.perf_counter()
+        flat = gp.partition(roots, action='ecc', max_nodes=args.max_nodes, export=True,
+                            with_volume=False, engine=args.engine, max_depth=args.max_depth)
+        ms_export = 1e3 * (time.perf_counter() - t1) - 1e3 * elapsed / args.steps
+        del flat
     # totals over ranks (max time, summed work)
     keys = ['lp_solves', 'ipm_iters', 'n_nodes', 'n_closed', 'ref_solves', 'decide_solves',
             'decide_iters', 'cert_closed', 'witness_open']
@@ -231,11 +344,13 @@ def main():
             i['lp_solves'] -= i['replicated_solves']
             i['n_closed'] -= i['replicated_closed']
             i['n_nodes'] -= i['replicated_nodes']
+    kinds = [float(sum(i['kind_solves'][q] for i in infos)) for q in range(5)] + \
+        [float(sum(i['kind_iters'][q] for i in infos)) for q in range(5)]
     local = [float(sum(i[k] for i in infos)) for k in keys] + \
         [elapsed, sum(i['decide_seconds'] for i in infos),
          sum(i['expand_seconds'] for i in infos),
          float(sum(i.get('moved', 0) for i in infos)),
-         float(sum(i.get('rounds', 0) for i in infos))]
+         float(sum(i.get('rounds', 0) for i in infos))] + kinds
     red_dev = ('cuda:%d' % device_index) if backend == 'nccl' else 'cpu'
     tot, mx = distributed.allreduce_counters(local, device=red_dev)
     per_rank = distributed.allgather_counts([int(local[0])], device=red_dev)[:, 0]
@@ -243,28 +358,57 @@ def main():
     agg = dict(zip(keys, tot[:len(keys)]))
     decide_s = float(mx[len(keys) + 1])
     expand_s = float(mx[len(keys) + 2])
+    kind_solves = [float(v) for v in tot[len(keys) + 5:len(keys) + 10]]
+    kind_iters = [float(v) for v in tot[len(keys) + 10:len(keys) + 15]]
     if rank == 0:
         K = args.steps
         info0 = infos[-1]
-        n_slack, m_slack = can.n + can.p + 1, can.m + can.p + 3
-        n_pt, m_pt = can.n, can.m
-        decide_flops = agg['decide_iters'] * flops_per_iteration(n_slack, m_slack)
-        expand_flops = (agg['ipm_iters'] - agg['decide_iters']) * flops_per_iteration(n_pt, m_pt)
-        B = node_bytes(can.p, can.n_u, can.deltas.shape[1])
-        if agg['cert_closed'] > 0:
-            # the run keeps the vertex gradients of the optimal cost next to every record
-            B += 8 * (can.p + 1) * can.p
+        n, m, p = can.n, can.m, can.p
+        # (columns, columns with MPC entries, rows) of the five problem kinds (ehm_dev.h: LP_*)
+        dims = [(n, n, m), (n + 1, n + 1, m + 1), (n + p, n + p, m + p + 1),
+                (n + p + 1, n + p, m + p + 3), (n + p + 1, n + p + 1, m + p + 2)]
+        if not hybrid and not persistent:
+            # sweeps of a single-commutation handle: the decide kernel alone is timed
+            kind_iters = [agg['ipm_iters'] - agg['decide_iters'], 0., 0., agg['decide_iters'], 0.]
+        f_survey = [kind_iters[q] * flops_per_iteration(dims[q][0], dims[q][2]) for q in range(5)]
+        f_exec = [kind_iters[q] * flops_executed_per_iteration(
+            dims[q][0], dims[q][1], dims[q][2], np_capacity(dims[q][0])) for q in range(5)]
+        simplex_kinds, point_kinds = (2, 3, 4), (0, 1)
+        B_node = node_bytes(p, can.n_u, can.deltas.shape[1])      # 301 B at config 2
+        grad_bytes = 8 * (p + 1) * p if agg['cert_closed'] > 0 else 0
         closed, nodes = agg['n_closed'], agg['n_nodes']
         splits = (nodes - K * len(roots)) / 2.
+        visits = agg['decide_solves'] + agg['cert_closed'] + agg['witness_open']
         if persistent:
             # ONE kernel per partition: suboptimality tests AND splits / midpoint solves
-            achieved = (decide_flops + expand_flops) / decide_s / 1e12
-            hbm_alg = (agg['decide_solves'] + agg['cert_closed']) * (B + 8) + \
-                splits * (B + 2 * B + 16)
+            flops, flops_x = sum(f_survey), sum(f_exec)
+            hbm_alg = visits * (B_node + 8) + splits * (3 * B_node + 16)
+            hbm_grad = (visits + 3 * splits) * grad_bytes
+        elif hybrid:
+            # dominant kernel = the batched problems over a simplex (slack / phase one / min);
+            # per instance: a work-list entry, the record's vertices + vertex costs in, the
+            # optimum, the maximiser's weights and the status out
+            flops = sum(f_survey[q] for q in simplex_kinds)
+            flops_x = sum(f_exec[q] for q in simplex_kinds)
+            n_sx = sum(kind_solves[q] for q in simplex_kinds)
+            hbm_alg = n_sx * (12 + 8 * ((p + 1) * p + (p + 1)) + 8 + 8 * (p + 1) + 4)
+            hbm_grad = 0.
         else:
-            # dominant kernel = the suboptimality-test sweep (k_lcss_decide)
-            achieved = decide_flops / decide_s / 1e12
-            hbm_alg = agg['decide_solves'] * (B + 8)      # decide: read record, write verdict
+            flops, flops_x = f_survey[3], f_exec[3]
+            hbm_alg = agg['decide_solves'] * (B_node + 8)
+            hbm_grad = agg['decide_solves'] * grad_bytes
+        achieved = flops / decide_s / 1e12
+        launches = max(info0['decide_launches'] * K, 1)
+        traffic, traffic_src = pmc_traffic(kname, pmc_file)
+        n_slack, m_slack = dims[3][0], dims[3][2]
+        n_pt, m_pt = dims[0][0], dims[0][2]
+        names = {'config2': 'configs[1]: n_x=4 n_u=2 N=5 p=4 linear MPC',
+                 'config2q': 'configs[1]: n_x=4 n_u=2 N=5 p=4 linear MPC',
+                 'config3': 'configs[2] (NOT the headline configuration): 2-mode PWA hybrid '
+                            'system, n_x=4 n_u=2 N=5 p=4, %d commutations, mixed-integer oracles'
+                            % can.n_delta,
+                 'config4': 'configs[3] (NOT the headline configuration): n_x=6 n_u=3 N=10 p=6 '
+                            'box-constrained chain'}
         out = {
             'metric': 'oracle LP solves/sec + final regions/sec, 4-state 2-input N=5 hybrid MPC',
             'value': agg['lp_solves'] / elapsed_max,
@@ -272,24 +416,29 @@ def main():
             'regions_per_s': closed / elapsed_max,
             'n_gpus': world, 'steps': K, 'warmup': args.warmup,
             'ms_per_step': 1e3 * elapsed_max / K,
+            'ms_export': ms_export,
             'higher_is_better': True,
             'scaling': 'strong',
             'vs_baseline': None,
             'dtype': 'f64',
             'data': 'synthetic',
             'config': {
-                'workload': ('configs[3] (NOT the headline configuration): n_x=6 n_u=3 N=10 p=6 '
-                             'box-constrained chain' if wide else
-                             'configs[1]: n_x=4 n_u=2 N=5 p=4 linear MPC') +
+                'workload': names[args.workload] +
                             ', %s (n=%d m=%d), seed %d, eps_r=%g, eps_a=%.6g '
-                            '(abs_frac=%g), %d Delaunay roots' % (
+                            '(abs_frac=%g), %d Delaunay roots%s' % (
                                 'quadratic-cost QP / QCQP oracle (NOT the headline metric)'
                                 if quad else 'inf-norm LP oracle',
                                 can.n, can.m, args.seed, args.eps_r, eps_a, args.abs_frac,
-                                len(roots)),
+                                len(roots),
+                                ', nodes left open at depth %d' % args.max_depth
+                                if args.max_depth else ''),
                 'regions_per_step': closed / K,
                 'nodes_per_step': nodes / K,
+                'open_leaves_at_max_depth_per_step': (nodes - splits - closed) / K,
                 'lp_solves_per_step': agg['lp_solves'] / K,
+                'lp_solves_by_kind_per_step': dict(zip(
+                    ('point', 'point_phase_one', 'min_over_simplex', 'slack', 'simplex_phase_one'),
+                    [v / K for v in kind_solves])),
                 'reference_equivalent_solves_per_step': agg['ref_solves'] / K,
                 'reference_equivalent_solves_per_s': agg['ref_solves'] / elapsed_max,
                 'leaves_closed_without_lp_per_step': agg['cert_closed'] / K,
@@ -301,8 +450,11 @@ def main():
                            'generation %d%s' % (args.solver, ' with the quadratic block' if quad
                                                 else ''),
                 'engine': 'persistent frontier kernel (one launch per partition)' if persistent
+                          else 'multi-commutation device engine (frontier sweeps, work lists and '
+                               'decisions on the device)' if hybrid
                           else 'level-synchronous sweeps',
-                'suboptimality_test': 'full accuracy' if (args.decide_full or args.solver == 1) else
+                'suboptimality_test': 'full accuracy' if (args.decide_full or args.solver == 1
+                                                          or hybrid) else
                                       'sign-only stop (lower bound of |t*| recorded)',
                 'parallelism': 'frontier dealt round-robin over %d GPU(s)' % world +
                                ('' if world == 1 else
@@ -317,31 +469,52 @@ def main():
                 'load_imbalance_max_over_mean': distributed.imbalance(per_rank),
             },
             'roofline': {
-                'bound': 'mfma', 'kernel': kname,
+                # the path is compute-bound on FP64; the contract's two values are
+                # "hbm" | "mfma": the wide kernels form their normal matrix on the matrix cores,
+                # the shared-block kernels execute no MFMA at all -- FP64 vector FMA issue
+                'bound': 'mfma' if wide else 'valu-fp64', 'kernel': kname,
                 'note': ('normal matrix on v_mfma_f64_16x16x4_f64 (57 columns = 4 tiles); peak = '
                          'FP64 matrix = vector peak of MI355X' if wide else
                          'one launch holds the slack LPs (n=%d m=%d) and the midpoint LPs (n=%d '
-                         'm=%d); FP64 vector FMA bound; peak = FP64 vector = matrix peak of MI355X'
-                         % (n_slack, m_slack, n_pt, m_pt) if persistent else
+                         'm=%d); FP64 vector FMA bound; peak = FP64 vector (= matrix) peak of '
+                         'MI355X' % (n_slack, m_slack, n_pt, m_pt) if persistent else
                          'FP64 vector FMA bound (no f64 contraction >= 32 wide at n=25); peak = '
-                         'FP64 vector = matrix peak of MI355X'),
+                         'FP64 vector (= matrix) peak of MI355X'),
                 'achieved': achieved, 'peak': FP64_PEAK_TFLOPS, 'unit': 'TFLOP/s',
-                'frac': achieved / FP64_PEAK_TFLOPS, 'traffic': pmc_traffic(kname, pmc_file),
-                'traffic_unit': 'HBM bytes per launch (rocprofv3 FETCH_SIZE x2 + WRITE_SIZE, '
-                                'profiles/r1/%s)' % pmc_file,
-                'algorithmic_bytes_per_launch': hbm_alg / max(info0['decide_launches'] * K, 1),
+                'frac': achieved / FP64_PEAK_TFLOPS,
+                # the same launches priced with what the solver really executes (lower-triangular
+                # block pairs of the normal matrix, unsymmetric elimination at the compiled width)
+                'achieved_executed': flops_x / decide_s / 1e12,
+                'frac_executed': flops_x / decide_s / 1e12 / FP64_PEAK_TFLOPS,
                 'flop_per_ipm_iteration': flops_per_iteration(n_slack, m_slack),
+                'flop_executed_per_ipm_iteration': flops_executed_per_iteration(
+                    n_slack, dims[3][1], m_slack, np_capacity(n_slack)),
+                'traffic': traffic,
+                'traffic_unit': 'HBM bytes per launch (rocprofv3 FETCH_SIZE x2 + WRITE_SIZE)',
+                'traffic_source': traffic_src,
+                'algorithmic_bytes_per_launch': hbm_alg / launches,
+                'algorithmic_bytes_note': 'SURVEY 8(d): B_node = %d B; node visit = B_node + 8, '
+                                          'split = 3 B_node + 16' % B_node if not hybrid else
+                                          'per instance of the batch: list entry + vertices + '
+                                          'vertex costs in, optimum + weights + status out',
+                'gradient_bytes_per_launch': hbm_grad / launches,
                 'kernel_seconds': decide_s, 'launches': info0['decide_launches'] * K,
                 'expand_kernel': None if persistent else
-                                 {'achieved': expand_flops / max(expand_s, 1e-12) / 1e12,
+                                 {'kernel': 'k2_point_batch' if hybrid else 'k2_lcss_expand',
+                                  'achieved': sum(f_survey[q] for q in point_kinds) /
+                                  max(expand_s, 1e-12) / 1e12,
                                   'kernel_seconds': expand_s},
                 'hbm': {'achieved': hbm_alg / decide_s / 1e9, 'peak': HBM_PEAK_GBS,
                         'unit': 'GB/s', 'frac': hbm_alg / decide_s / 1e9 / HBM_PEAK_GBS,
-                        'bytes_per_node': B + 8},
+                        'bytes_per_node': B_node + 8,
+                        'note': 'not the binding resource: a node is ~0.3-0.9 KB of traffic against '
+                                '~2 Mflop of FP64 work, so north_star\'s ">= 40 % of the HBM '
+                                'roofline" is structurally out of reach (SURVEY 8(d))'},
             },
         }
         if world == 1 and not args.no_cpu_baseline:
-            out['cpu_baseline'] = cpu_baseline(mpc, eps_a, args.eps_r, args.cpu_seconds)
+            out['cpu_baseline'] = cpu_baseline(args.workload, args.seed, eps_a, args.eps_r,
+                                               args.cpu_seconds)
         else:
             out['cpu_baseline'] = None
         print(json.dumps(out))

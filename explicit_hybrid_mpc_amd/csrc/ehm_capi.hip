@@ -79,16 +79,19 @@ __global__ __launch_bounds__(64) void k_point_batch(DevProblem P, long long n_in
                                                     double* __restrict__ u0,
                                                     int32_t* __restrict__ status,
                                                     int32_t* __restrict__ iters,
-                                                    DevCounters* cnt) {
+                                                    DevCounters* cnt, K2Gather G) {
     double* smem = reinterpret_cast<double*>(ehm_smem);
     double* th = smem;                 // p doubles
     double* lp_base = smem + 16;
     const int lane = threadIdx.x;
-    for (long long inst = blockIdx.x; inst < n_inst; inst += gridDim.x) {
+    if (G.n_dev) n_inst = *G.n_dev;
+    for (long long inst0 = blockIdx.x; inst0 < n_inst; inst0 += gridDim.x) {
         wave_sync();
-        if (lane < P.p) th[lane] = theta[inst * P.p + lane];
+        const double* tsrc = G.src ? theta + G.src[inst0] : theta + inst0 * P.p;
+        if (lane < P.p) th[lane] = tsrc[lane];
         wave_sync();
-        const int d = didx ? didx[inst] : 0;
+        const int d = didx ? didx[inst0] : 0;
+        const long long inst = G.dst ? (long long)G.dst[inst0] : inst0;   // results go here
         LpWork w;
         double b[EHM_SLOTS];
         assemble_point(w, lp_base, P, d, th, feas != 0, b, lane);
@@ -112,19 +115,23 @@ __global__ __launch_bounds__(64) void k_simplex_batch(DevProblem P, long long n_
                                                       double* __restrict__ alpha,
                                                       int32_t* __restrict__ status,
                                                       int32_t* __restrict__ iters,
-                                                      DevCounters* cnt) {
+                                                      DevCounters* cnt, K2Gather G) {
     double* smem = reinterpret_cast<double*>(ehm_smem);
     double* Rl = smem;                          // (p+1)*p
     double* Vl = smem + (P.p + 1) * P.p;        // p+1
     double* lp_base = smem + NODE_LDS_DOUBLES;
     const int lane = threadIdx.x;
     const int nR = (P.p + 1) * P.p;
-    for (long long inst = blockIdx.x; inst < n_inst; inst += gridDim.x) {
+    if (G.n_dev) n_inst = *G.n_dev;
+    for (long long inst0 = blockIdx.x; inst0 < n_inst; inst0 += gridDim.x) {
         wave_sync();
-        for (int k = lane; k < nR; k += 64) Rl[k] = R[inst * nR + k];
-        if (slack == SX_SLACK && lane <= P.p) Vl[lane] = Vbar[inst * (P.p + 1) + lane];
+        const double* Rsrc = G.src ? R + G.src[inst0] : R + inst0 * nR;
+        const double* Vsrc = G.src ? Rsrc + G.v_off : Vbar + inst0 * (P.p + 1);
+        for (int k = lane; k < nR; k += 64) Rl[k] = Rsrc[k];
+        if (slack == SX_SLACK && lane <= P.p) Vl[lane] = Vsrc[lane];
         wave_sync();
-        const int d = didx ? didx[inst] : 0;
+        const int d = didx ? didx[inst0] : 0;
+        const long long inst = G.dst ? (long long)G.dst[inst0] : inst0;   // results go here
         LpWork w;
         double b[EHM_SLOTS];
         assemble_simplex(w, lp_base, P, d, Rl, Vl, slack, b, lane);
@@ -1038,7 +1045,7 @@ static int point_batch(ehm_problem* P, int64_t n_inst, const double* theta,
     hipLaunchKernelGGL(k_point_batch, dim3(grid_for(P, n_inst)), dim3(64), P->lds_point,
                        P->stream, P->dp, (long long)n_inst, P->in0.as<double>(),
                        P->in1.as<int32_t>(), feas, P->out0.as<double>(), P->out1.as<double>(),
-                       d_status, d_iters, P->d_cnt);
+                       d_status, d_iters, P->d_cnt, K2Gather{});
     P->launches++;
     HIP_TRY(hipGetLastError(), EHM_E_HIP);
     HIP_TRY(hipMemcpyAsync(J, P->out0.ptr, (size_t)n_inst * sizeof(double),
@@ -1196,7 +1203,7 @@ static int simplex_batch(ehm_problem* P, int64_t n_inst, const double* R, const 
                        P->stream, P->dp, (long long)n_inst, P->in0.as<double>(),
                        P->in2.as<double>(), P->in1.as<int32_t>(), slack, P->out0.as<double>(),
                        alpha ? P->out1.as<double>() : (double*)nullptr, d_status,
-                       d_status + n_inst, P->d_cnt);
+                       d_status + n_inst, P->d_cnt, K2Gather{});
     P->launches++;
     HIP_TRY(hipGetLastError(), EHM_E_HIP);
     HIP_TRY(hipMemcpyAsync(obj, P->out0.ptr, (size_t)n_inst * sizeof(double),
@@ -2476,7 +2483,20 @@ int ehm_partition_finish(ehm_tree* T) {
         std::memcpy(&mm, &c1.min_margin_bits, 8);
         T->info.min_margin = mm;
     }
+    for (int k = 0; k < 5; ++k) T->info.kind_solves[k] = T->info.kind_iters[k] = 0;
+    T->info.kind_solves[LP_SLACK] = T->info.decide_solves;
+    T->info.kind_iters[LP_SLACK] = T->info.decide_iters;
+    T->info.kind_solves[LP_POINT] = T->info.lp_solves - T->info.decide_solves;
+    T->info.kind_iters[LP_POINT] = T->info.ipm_iters - T->info.decide_iters;
+    T->info.swaps = 0;
+    T->info.blacklisted = 0;
     if (T->hy) {
+        rc = hy_kind_totals(T, T->info.kind_solves, T->info.kind_iters);
+        if (rc) return rc;
+        T->info.decide_solves = T->info.kind_solves[LP_MIN_SIMPLEX] + T->info.kind_solves[LP_SLACK] +
+                                T->info.kind_solves[LP_FEAS_SIMPLEX];
+        T->info.decide_iters = T->info.kind_iters[LP_MIN_SIMPLEX] + T->info.kind_iters[LP_SLACK] +
+                               T->info.kind_iters[LP_FEAS_SIMPLEX];
         const HyCtr& h = T->hy->h;
         double mm;
         std::memcpy(&mm, &h.min_margin_bits, 8);
@@ -2484,6 +2504,7 @@ int ehm_partition_finish(ehm_tree* T) {
         T->info.swaps = (int64_t)h.swaps;
         T->info.blacklisted = (int64_t)h.blacklisted;
         P->slivers += (long long)h.slivers;
+        P->fallbacks += (long long)h.fallbacks;
     }
     T->info.volume_closed = -1.0;   // filled lazily by ehm_tree_info_get
     return EHM_OK;

@@ -17,6 +17,14 @@
 //                         it (feasible at both ends of the split edge => feasible; infeasible on
 //                         the whole parent simplex => infeasible) and solved for the rest;
 //   cand [node][nw]       commutations that were feasible somewhere on the PARENT simplex;
+//   neg  [node][nw]       commutations whose suboptimality-test optimum t* is known to be negative
+//                         on this simplex WITHOUT solving anything: t*_d can only go down from a
+//                         node to a child that was split with the node's own commutation (the
+//                         child's interpolated cost lies below the parent's on the smaller simplex
+//                         -- the optimal cost is convex -- and the maximisation runs over a
+//                         subset), so a commutation found negative stays negative until the
+//                         node's commutation changes.  tneg[node] = the largest (closest to 0) of
+//                         those inherited values, so that the recorded margin stays a lower bound;
 //   black[node][nw]       commutations blacklisted for this node's bar_D after a failed vertex
 //                         solve (the reference's __delta_neq_constraint retry, lib/oracle.py:406-414).
 // Canonical commutation rule and tolerances: DESIGN.md section 3 ("canonical commutation rule");
@@ -34,8 +42,8 @@ struct HyCtr {
     int err_node;
     int truncated;
     int max_depth_seen;
-    int pad;
-    unsigned long long closed, splits, swaps, slivers, blacklisted, ref_solves;
+    int err_kind;           // numeric errors: 1 slack problem, 2 min over the simplex, 3 midpoint
+    unsigned long long closed, splits, swaps, slivers, blacklisted, ref_solves, fallbacks;
     unsigned long long min_margin_bits;
 };
 
@@ -81,7 +89,8 @@ __global__ void hy_list_scan(int* count, int nd, int* seg, int* cursor, int* n_i
 // instance of (row k, commutation d): input at koff[k], results at k * nd + d
 __global__ void hy_list_scatter(const hy_u64* __restrict__ bits, int ns, int nd, int nw,
                                 const long long* __restrict__ koff, int* __restrict__ cursor,
-                                long long* __restrict__ src, int32_t* __restrict__ dst) {
+                                long long* __restrict__ src, int32_t* __restrict__ dst,
+                                int32_t* __restrict__ dcomm) {
     const long long t = (long long)blockIdx.x * blockDim.x + threadIdx.x;
     const int ns_pad = (ns + 63) & ~63;
     const int d = (int)(t / ns_pad), k = (int)(t % ns_pad);
@@ -97,6 +106,7 @@ __global__ void hy_list_scatter(const hy_u64* __restrict__ bits, int ns, int nd,
         const int idx = base + __popcll(b & ((1ULL << lane) - 1ULL));
         src[idx] = koff[k];
         dst[idx] = k * nd + d;
+        dcomm[idx] = d;
     }
 }
 // entries with one commutation each: dsel[e] (-1 = no instance), input at eoff[e], results at e
@@ -108,7 +118,8 @@ __global__ void hy_sel_count(const int32_t* __restrict__ dsel, int ne, int* __re
 }
 __global__ void hy_sel_scatter(const int32_t* __restrict__ dsel, int ne,
                                const long long* __restrict__ eoff, int* __restrict__ cursor,
-                               long long* __restrict__ src, int32_t* __restrict__ dst) {
+                               long long* __restrict__ src, int32_t* __restrict__ dst,
+                               int32_t* __restrict__ dcomm) {
     const int e = blockIdx.x * blockDim.x + threadIdx.x;
     if (e >= ne) return;
     const int d = dsel[e];
@@ -116,6 +127,17 @@ __global__ void hy_sel_scatter(const int32_t* __restrict__ dsel, int ne,
     const int idx = atomicAdd(&cursor[d], 1);
     src[idx] = eoff[e];
     dst[idx] = e;
+    dcomm[idx] = d;
+}
+// entries whose solve stalled: again, for the one-wavefront kernels
+__global__ void hy_sel_stalled(const int32_t* __restrict__ dsel, int ne,
+                               const int32_t* __restrict__ st, int32_t* __restrict__ dsel2) {
+    const int e = blockIdx.x * blockDim.x + threadIdx.x;
+    if (e >= ne) return;
+    dsel2[e] = (dsel[e] >= 0 && st[e] != 0) ? dsel[e] : -1;
+}
+__global__ void hy_add_items(HyCtr* ctr) {
+    if (threadIdx.x == 0 && blockIdx.x == 0) ctr->fallbacks += (unsigned long long)ctr->n_items;
 }
 
 // out[k] = forced[k] | (ask[k] & {tau[k][d] <= tol})
@@ -148,12 +170,15 @@ __global__ void hy_root_rows(int row0, int nrows, int nd, int nw, int nv, int p,
     }
 }
 __global__ void hy_node_init(int first, int n, int nd, int nw, hy_u64* __restrict__ cand,
-                             hy_u64* __restrict__ black) {
+                             hy_u64* __restrict__ black, hy_u64* __restrict__ neg,
+                             double* __restrict__ tneg) {
     const int t = blockIdx.x * blockDim.x + threadIdx.x;
     if (t >= n * nw) return;
     const int k = t / nw, w = t - k * nw;
     cand[(size_t)(first + k) * nw + w] = hy_valid_word(nd, w);
     black[(size_t)(first + k) * nw + w] = 0ULL;
+    neg[(size_t)(first + k) * nw + w] = 0ULL;
+    if (w == 0) tneg[first + k] = -INFINITY;
 }
 
 // ---- lcss: which (node, commutation) pairs need which problem ---------------------------------
@@ -161,9 +186,9 @@ __global__ void hy_node_init(int first, int n, int nd, int nw, hy_u64* __restric
 // parent simplex -> nothing; the rest -> phase one over the simplex first.
 __global__ void hy_lcss_classify(DevTree T, const int32_t* __restrict__ frontier, int ns, int nd,
                                  int nw, const hy_u64* __restrict__ vf,
-                                 const hy_u64* __restrict__ cand, hy_u64* __restrict__ known1,
-                                 hy_u64* __restrict__ ask, hy_u64* __restrict__ vall,
-                                 long long* __restrict__ koff) {
+                                 const hy_u64* __restrict__ cand, const hy_u64* __restrict__ neg,
+                                 hy_u64* __restrict__ known1, hy_u64* __restrict__ ask,
+                                 hy_u64* __restrict__ vall, long long* __restrict__ koff) {
     const int t = blockIdx.x * blockDim.x + threadIdx.x;
     if (t >= ns * nw) return;
     const int k = t / nw, w = t - k * nw;
@@ -175,7 +200,7 @@ __global__ void hy_lcss_classify(DevTree T, const int32_t* __restrict__ frontier
         any |= x;
         all &= x;
     }
-    const hy_u64 valid = hy_valid_word(nd, w);
+    const hy_u64 valid = hy_valid_word(nd, w) & ~neg[(size_t)id * nw + w];
     known1[t] = any & valid;
     ask[t] = ~any & cand[(size_t)id * nw + w] & valid;
     vall[t] = all & valid;
@@ -217,6 +242,24 @@ __global__ void hy_redo_bits(int ns, int nd, int nw, const hy_u64* __restrict__ 
     redo[t] = r;
 }
 
+// stalled slack problems of commutations that ARE feasible with an interior (not slivers): once
+// more on the one-wavefront kernels (private copy of the LP, barycentric coordinates)
+__global__ void hy_retry_bits(int ns, int nd, int nw, const hy_u64* __restrict__ slk,
+                              const int32_t* __restrict__ st, const double* __restrict__ tau,
+                              double sliver_tol, hy_u64* __restrict__ retry) {
+    const int t = blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= ns * nw) return;
+    const int k = t / nw, w = t - k * nw;
+    hy_u64 q = slk[t], r = 0ULL;
+    while (q) {
+        const int b = __ffsll((long long)q) - 1;
+        q &= q - 1;
+        const size_t i = (size_t)k * nd + w * 64 + b;
+        if (st[i] != 0 && !(tau[i] > -sliver_tol)) r |= 1ULL << b;
+    }
+    retry[t] = r;
+}
+
 // One Worker.lcss decision per node (lib/worker.py:368-401 with the oracles of
 // lib/oracle.py:285-394): bar_E from the slacks of every commutation, then bar_D's choice.
 //   act: 0 closed, 1 split with the node's own commutation, 2 better commutation found (its
@@ -226,7 +269,8 @@ __global__ void hy_lcss_decide(DevTree T, const int32_t* __restrict__ frontier, 
                                const hy_u64* __restrict__ vall, const hy_u64* __restrict__ black,
                                const double* __restrict__ tau, const double* __restrict__ tval,
                                const int32_t* __restrict__ st, const double* __restrict__ alpha,
-                               double sliver_tol, double tie_tol, int max_depth,
+                               double sliver_tol, double tie_tol, int max_depth, int prune,
+                               hy_u64* __restrict__ neg, double* __restrict__ tneg,
                                hy_u64* __restrict__ cand, int32_t* __restrict__ act,
                                int32_t* __restrict__ best_out, double* __restrict__ ths,
                                HyCtr* ctr) {
@@ -234,8 +278,16 @@ __global__ void hy_lcss_decide(DevTree T, const int32_t* __restrict__ frontier, 
     if (k >= ns) return;
     const int id = frontier[k];
     const int p = T.p, nv = p + 1;
-    double tb = -INFINITY, tbm = -INFINITY;
+    // commutations inherited as negative keep their last value (a bound of the child's)
+    double tb = tneg[id], tbm = -INFINITY, tn = tneg[id];
     hy_u64 feas[4] = {0ULL, 0ULL, 0ULL, 0ULL};
+    hy_u64 ng[4] = {0ULL, 0ULL, 0ULL, 0ULL};
+    const double neg_tol = EHM_CUT_TOL * (1.0 + fabs(T.rec[(size_t)id * T.rec_stride +
+                                                           rec_off_vcost(p)]));
+    for (int w = 0; w < nw; ++w) {
+        ng[w] = neg[(size_t)id * nw + w];
+        feas[w] = ng[w] & cand[(size_t)id * nw + w];     // still "feasible somewhere" as far as known
+    }
     for (int d = 0; d < nd; ++d) {
         if (!hy_bit(slk + (size_t)k * nw, d)) continue;
         const size_t q = (size_t)k * nd + d;
@@ -245,6 +297,7 @@ __global__ void hy_lcss_decide(DevTree T, const int32_t* __restrict__ frontier, 
             } else {
                 atomicMax(&ctr->error, 2);
                 ctr->err_node = id;
+                ctr->err_kind = 1 + 16 * d;
                 T.flags[id] |= 8;
             }
             continue;
@@ -252,10 +305,18 @@ __global__ void hy_lcss_decide(DevTree T, const int32_t* __restrict__ frontier, 
         feas[d >> 6] |= 1ULL << (d & 63);
         const double t = tval[q];
         tb = fmax(tb, t);
+        if (prune && t < -neg_tol) {
+            ng[d >> 6] |= 1ULL << (d & 63);
+            tn = fmax(tn, t);
+        }
         if (t >= 0.0 && hy_bit(vall + (size_t)k * nw, d) && !hy_bit(black + (size_t)id * nw, d))
             tbm = fmax(tbm, t);
     }
-    for (int w = 0; w < nw; ++w) cand[(size_t)id * nw + w] = feas[w];
+    for (int w = 0; w < nw; ++w) {
+        cand[(size_t)id * nw + w] = feas[w];
+        neg[(size_t)id * nw + w] = ng[w];
+    }
+    tneg[id] = tn;
     T.tstar[id] = tb;
     atomicMin(&ctr->min_margin_bits, (unsigned long long)__double_as_longlong(fabs(tb)));
     atomicAdd(&ctr->ref_solves, 1ULL);
@@ -337,7 +398,8 @@ __global__ void hy_varsmall(DevTree T, const int32_t* __restrict__ frontier, int
                             const int32_t* __restrict__ vst, const double* __restrict__ Jth,
                             const int32_t* __restrict__ Jth_st, const double* __restrict__ Jmin,
                             const int32_t* __restrict__ Jmin_st, double eps_a, double eps_r,
-                            int fail_delta, hy_u64* __restrict__ black, HyCtr* ctr) {
+                            int fail_delta, hy_u64* __restrict__ black, hy_u64* __restrict__ neg,
+                            double* __restrict__ tneg, HyCtr* ctr) {
     const int k = blockIdx.x * blockDim.x + threadIdx.x;
     if (k >= ns || act[k] != 2) return;
     const int id = frontier[k];
@@ -353,6 +415,7 @@ __global__ void hy_varsmall(DevTree T, const int32_t* __restrict__ frontier, int
     if (Jmin_st[k] != 0) {                            // the node's OWN commutation failed
         atomicMax(&ctr->error, 2);
         ctr->err_node = id;
+        ctr->err_kind = 2 + 16 * T.didx[id];
         return;
     }
     double* rec = T.rec + (size_t)id * T.rec_stride;
@@ -364,6 +427,9 @@ __global__ void hy_varsmall(DevTree T, const int32_t* __restrict__ frontier, int
         for (int v = 0; v < nv; ++v) rec[rec_off_vcost(p) + v] = vJ[k * nv + v];
         for (int q = 0; q < nv * n_u; ++q) rec[rec_off_vinput(p) + q] = vu[(size_t)k * nv * n_u + q];
         T.didx[id] = best[k];
+        // a new interpolated cost: nothing is known about the other commutations any more
+        for (int w = 0; w < nw; ++w) neg[(size_t)id * nw + w] = 0ULL;
+        tneg[id] = -INFINITY;
         atomicAdd(&ctr->swaps, 1ULL);
         act[k] = 4;
     } else {
@@ -437,6 +503,7 @@ __global__ void hy_children(DevTree T, const int32_t* __restrict__ frontier, int
                             const double* __restrict__ vJ, const double* __restrict__ vu,
                             const hy_u64* __restrict__ midbits, hy_u64* __restrict__ vf,
                             hy_u64* __restrict__ cand, hy_u64* __restrict__ black,
+                            hy_u64* __restrict__ neg, double* __restrict__ tneg,
                             int32_t* __restrict__ next, HyCtr* ctr) {
     const int s = blockIdx.x;
     if (s >= ctr->n_split) return;
@@ -449,6 +516,7 @@ __global__ void hy_children(DevTree T, const int32_t* __restrict__ frontier, int
         if (lane == 0) {
             atomicMax(&ctr->error, 2);
             ctr->err_node = id;
+            ctr->err_kind = 3 + 16 * sp_d[s];
             T.flags[id] |= 16;
         }
         return;
@@ -495,6 +563,15 @@ __global__ void hy_children(DevTree T, const int32_t* __restrict__ frontier, int
         cand[(size_t)(c0 + 1) * nw + w] = c;
         black[(size_t)c0 * nw + w] = 0ULL;
         black[(size_t)(c0 + 1) * nw + w] = 0ULL;
+        // split with the node's OWN commutation: what was negative stays negative
+        const hy_u64 g = (has_data && !fresh) ? neg[(size_t)id * nw + w] : 0ULL;
+        neg[(size_t)c0 * nw + w] = g;
+        neg[(size_t)(c0 + 1) * nw + w] = g;
+    }
+    if (lane == 0) {
+        const double tn = (has_data && !fresh) ? tneg[id] : -INFINITY;
+        tneg[c0] = tn;
+        tneg[c0 + 1] = tn;
     }
     if (lane == 0) {
         const int dep = T.depth[id] + 1;
@@ -592,28 +669,33 @@ struct HyState {
     bool on = false;
     int nw = 0;
     long long ch = 0;                    // frontier nodes per chunk
-    DevBuf vf, cand, black;              // per node
+    DevBuf vf, cand, black, neg, tneg;   // per node
+    int prune = 1;                       // inherit negative suboptimality-test verdicts
     DevBuf fr_ecc[2], fr_lcss[2];        // frontiers, ping-pong
     long long n_ecc = 0, n_lcss = 0;
     int cur = 0;
-    DevBuf known1, ask, slk, vall, redo, koff, src, dst, cnt, tau, tval, st, alpha;
+    DevBuf known1, ask, slk, vall, redo, koff, src, dst, dcomm, dsel2, cnt, tau, tval, st, alpha;
     DevBuf act, best, ths, vJ, vu, vst, Jth, Jth_st, Jmin, Jmin_st;
     DevBuf dselV, eoffV, dselT, eoffT, dselM, eoffM;
     DevBuf sp_k, sp_c0, sp_ij, sp_d, mids, Jm, um, mst, midforced, midask, midbits, moff;
     DevBuf ctr;
+    DevBuf snaps;                        // DevCounters after every batched launch
+    std::vector<int> snap_kind;          // LP kind of that launch
     HyCtr h{};
     int fail_delta = -1;                 // test hook: vertex solves of this commutation "fail"
     void release() {
-        DevBuf* all[] = {&vf, &cand, &black, &fr_ecc[0], &fr_ecc[1], &fr_lcss[0], &fr_lcss[1],
-                         &known1, &ask, &slk, &vall, &redo, &koff, &src, &dst, &cnt, &tau, &tval,
+        DevBuf* all[] = {&vf, &cand, &black, &neg, &tneg, &fr_ecc[0], &fr_ecc[1], &fr_lcss[0], &fr_lcss[1],
+                         &known1, &ask, &slk, &vall, &redo, &koff, &src, &dst, &dcomm, &dsel2, &cnt,
+                         &tau, &tval,
                          &st, &alpha, &act, &best, &ths, &vJ, &vu, &vst, &Jth, &Jth_st, &Jmin,
                          &Jmin_st, &dselV, &eoffV, &dselT, &eoffT, &dselM, &eoffM, &sp_k, &sp_c0,
                          &sp_ij, &sp_d, &mids, &Jm, &um, &mst, &midforced, &midask, &midbits,
-                         &moff, &ctr};
+                         &moff, &ctr, &snaps};
         for (DevBuf* b : all) b->release();
     }
 };
 
+#define HY_MAX_SNAPS 8192
 #define HY_GRID(n) dim3((unsigned)(((long long)(n) + HY_BLOCK - 1) / HY_BLOCK)), dim3(HY_BLOCK)
 
 static int hy_alloc(ehm_tree* T) {
@@ -632,11 +714,14 @@ static int hy_alloc(ehm_tree* T) {
     HY_ENSURE(vf, cap * nv * nw * 8);
     HY_ENSURE(cand, cap * nw * 8);
     HY_ENSURE(black, cap * nw * 8);
+    HY_ENSURE(neg, cap * nw * 8);
+    HY_ENSURE(tneg, cap * 8);
     HY_ENSURE(known1, ch * nw * 8); HY_ENSURE(ask, ch * nw * 8); HY_ENSURE(slk, ch * nw * 8);
     HY_ENSURE(vall, ch * nw * 8);   HY_ENSURE(redo, ch * nw * 8);
     HY_ENSURE(koff, ch * 8);
     const size_t nlist = ch * (size_t)std::max(nd, nv);
-    HY_ENSURE(src, nlist * 8);      HY_ENSURE(dst, nlist * 4);
+    HY_ENSURE(src, nlist * 8);      HY_ENSURE(dst, nlist * 4);     HY_ENSURE(dcomm, nlist * 4);
+    HY_ENSURE(dsel2, ch * nv * 4);
     HY_ENSURE(cnt, (size_t)(3 * nd + 8) * 4);
     HY_ENSURE(tau, ch * nd * 8);    HY_ENSURE(tval, ch * nd * 8);  HY_ENSURE(st, ch * nd * 4);
     HY_ENSURE(alpha, ch * nd * nv * 8);
@@ -653,6 +738,7 @@ static int hy_alloc(ehm_tree* T) {
     HY_ENSURE(midforced, ch * nw * 8); HY_ENSURE(midask, ch * nw * 8);
     HY_ENSURE(midbits, ch * nw * 8);   HY_ENSURE(moff, ch * 8);
     HY_ENSURE(ctr, sizeof(HyCtr));
+    HY_ENSURE(snaps, (size_t)HY_MAX_SNAPS * sizeof(DevCounters));
 #undef HY_ENSURE
     HIP_TRY(hipMemsetAsync(H.cnt.ptr, 0, (size_t)(3 * nd + 8) * 4, P->stream), EHM_E_HIP);
     return EHM_OK;
@@ -664,6 +750,24 @@ struct HyList {      // the work list sitting in H.src / H.dst / seg
     const int32_t* seg;
     const int32_t* n_dev;
 };
+
+// event pair + counter snapshot around a batched launch: kernel seconds and iterations by LP kind
+static void hy_stamp(ehm_tree* T) {
+    hipEvent_t e;
+    (void)hipEventCreate(&e);
+    (void)hipEventRecord(e, T->prob->stream);
+    T->run.evs.push_back(e);
+}
+static void hy_after_batch(ehm_tree* T, int lp_kind, int family) {
+    HyState& H = *T->hy;
+    hy_stamp(T);
+    T->run.ev_kind.push_back(family);
+    if (H.snap_kind.size() < HY_MAX_SNAPS) {
+        (void)hipMemcpyAsync(H.snaps.as<DevCounters>() + H.snap_kind.size(), T->prob->d_cnt,
+                             sizeof(DevCounters), hipMemcpyDeviceToDevice, T->prob->stream);
+        H.snap_kind.push_back(lp_kind);
+    }
+}
 
 static HyList hy_list_of(ehm_tree* T) {
     HyState& H = *T->hy;
@@ -684,7 +788,7 @@ static void hy_build_bits(ehm_tree* T, const hy_u64* bits, int ns, const long lo
     hipLaunchKernelGGL(hy_list_scan, dim3(1), dim3(64), 0, P->stream, count, nd, seg, cursor,
                        &H.ctr.as<HyCtr>()->n_items);
     hipLaunchKernelGGL(hy_list_scatter, HY_GRID(threads), 0, P->stream, bits, ns, nd, nw, koff,
-                       cursor, H.src.as<long long>(), H.dst.as<int32_t>());
+                       cursor, H.src.as<long long>(), H.dst.as<int32_t>(), H.dcomm.as<int32_t>());
     P->launches += 3;
 }
 
@@ -699,22 +803,38 @@ static void hy_build_sel(ehm_tree* T, const int32_t* dsel, int ne, const long lo
     hipLaunchKernelGGL(hy_list_scan, dim3(1), dim3(64), 0, P->stream, count, nd, seg, cursor,
                        &H.ctr.as<HyCtr>()->n_items);
     hipLaunchKernelGGL(hy_sel_scatter, HY_GRID(ne), 0, P->stream, dsel, ne, eoff, cursor,
-                       H.src.as<long long>(), H.dst.as<int32_t>());
+                       H.src.as<long long>(), H.dst.as<int32_t>(), H.dcomm.as<int32_t>());
     P->launches += 3;
 }
+
+static void hy_run_simplex_v1(ehm_tree* T, int mode, double* obj, double* alpha, int32_t* status);
+static void hy_run_point_v1(ehm_tree* T, const double* base, int feas, double* J, double* u0,
+                            int32_t* status);
 
 // batched problems over the simplices the current list points at (records of the node pool)
 static int hy_run_simplex(ehm_tree* T, int mode, double* obj, double* alpha, int32_t* status) {
     ehm_problem* P = T->prob;
+    if (P->solver_gen == 1) {      // cross-check mode: everything on the one-wavefront kernels
+        hy_stamp(T);
+        hy_run_simplex_v1(T, mode, obj, alpha, status);
+        hy_after_batch(T, (mode == SX_SLACK) ? LP_SLACK : (mode == SX_FEAS) ? LP_FEAS_SIMPLEX
+                                                                             : LP_MIN_SIMPLEX, 0);
+        return EHM_OK;
+    }
     const int kind = (mode == SX_SLACK) ? LP_SLACK : (mode == SX_FEAS) ? LP_FEAS_SIMPLEX
                                                                         : LP_MIN_SIMPLEX;
     K2Cfg cfg;
     int rc = k2_config(P, kind, kind, 1LL << 40, cfg);
     if (rc) return rc;
     const HyList L = hy_list_of(T);
-    K2Gather G{L.src, L.dst, L.n_dev, rec_off_vcost(P->dp.p), nullptr};
+    // sign-only stops: a phase-one optimum is only compared with ~0; a slack below zero only has
+    // to be known as negative (bar_E), one above is ranked by its value (bar_D)
+    const int sign_mode = P->decide_full ? 0 : (mode == SX_FEAS) ? 1 : (mode == SX_SLACK) ? 2 : 0;
+    K2Gather G{L.src, L.dst, L.n_dev, rec_off_vcost(P->dp.p), nullptr, sign_mode};
+    hy_stamp(T);
     cfg.api->simplex(cfg.L, P->dp, 0, T->dt.rec, nullptr, L.seg, mode, obj, alpha, status, nullptr,
                      P->d_cnt, G);
+    hy_after_batch(T, kind, 0);
     P->launches++;
     return EHM_OK;
 }
@@ -723,17 +843,63 @@ static int hy_run_simplex(ehm_tree* T, int mode, double* obj, double* alpha, int
 static int hy_run_point(ehm_tree* T, const double* base, int feas, double* J, double* u0,
                         int32_t* status) {
     ehm_problem* P = T->prob;
+    if (P->solver_gen == 1) {
+        hy_stamp(T);
+        hy_run_point_v1(T, base, feas, J, u0, status);
+        hy_after_batch(T, feas ? LP_FEAS : LP_POINT, 1);
+        return EHM_OK;
+    }
     K2Cfg cfg;
     int rc = k2_config(P, feas ? LP_FEAS : LP_POINT, feas ? LP_FEAS : LP_POINT, 1LL << 40, cfg);
     if (rc) return rc;
     const HyList L = hy_list_of(T);
-    K2Gather G{L.src, L.dst, L.n_dev, 0, nullptr};
+    K2Gather G{L.src, L.dst, L.n_dev, 0, nullptr, (feas && !P->decide_full) ? 1 : 0};
+    hy_stamp(T);
     cfg.api->point(cfg.L, P->dp, 0, base, L.seg, feas, J, u0, status, nullptr, P->d_cnt, G);
+    hy_after_batch(T, feas ? LP_FEAS : LP_POINT, 1);
     P->launches++;
     return EHM_OK;
 }
 
 #define HY_TRY(expr) do { int rc_ = (expr); if (rc_) return rc_; } while (0)
+
+// The same lists on the one-wavefront kernels (ehm_kernels.h): the numerical safety net of the
+// batched oracles (simplex_batch / point_batch above), here for the few problems per ten million
+// the shared-block solver leaves stalled.  Results overwrite the stalled ones.
+static void hy_run_simplex_v1(ehm_tree* T, int mode, double* obj, double* alpha, int32_t* status) {
+    ehm_problem* P = T->prob;
+    const HyList L = hy_list_of(T);
+    K2Gather G{L.src, L.dst, L.n_dev, rec_off_vcost(P->dp.p), nullptr, 0};
+    hipLaunchKernelGGL(k_simplex_batch, dim3(P->num_cu * 8), dim3(64), P->lds_simplex, P->stream,
+                       P->dp, 0LL, T->dt.rec, (const double*)nullptr, T->hy->dcomm.as<int32_t>(),
+                       mode, obj, alpha, status, (int32_t*)nullptr, P->d_cnt, G);
+    if (P->solver_gen == 2)
+        hipLaunchKernelGGL(hy_add_items, dim3(1), dim3(64), 0, P->stream, T->hy->ctr.as<HyCtr>());
+    P->launches += 2;
+}
+static void hy_run_point_v1(ehm_tree* T, const double* base, int feas, double* J, double* u0,
+                            int32_t* status) {
+    ehm_problem* P = T->prob;
+    const HyList L = hy_list_of(T);
+    K2Gather G{L.src, L.dst, L.n_dev, 0, nullptr, 0};
+    hipLaunchKernelGGL(k_point_batch, dim3(P->num_cu * 8), dim3(64), P->lds_point, P->stream,
+                       P->dp, 0LL, base, T->hy->dcomm.as<int32_t>(), feas, J, u0, status,
+                       (int32_t*)nullptr, P->d_cnt, G);
+    if (P->solver_gen == 2)
+        hipLaunchKernelGGL(hy_add_items, dim3(1), dim3(64), 0, P->stream, T->hy->ctr.as<HyCtr>());
+    P->launches += 2;
+}
+// stalled entries of a one-commutation-per-entry batch, again
+static void hy_retry_sel_point(ehm_tree* T, const int32_t* dsel, int ne, const long long* eoff,
+                               const double* base, double* J, double* u0, int32_t* status) {
+    ehm_problem* P = T->prob;
+    if (!P->v1_ok || P->solver_gen == 1) return;
+    HyState& H = *T->hy;
+    hipLaunchKernelGGL(hy_sel_stalled, HY_GRID(ne), 0, P->stream, dsel, ne, status,
+                       H.dsel2.as<int32_t>());
+    hy_build_sel(T, H.dsel2.as<int32_t>(), ne, eoff);
+    hy_run_point_v1(T, base, 0, J, u0, status);
+}
 
 // the split of the collected nodes: midpoint solve (lcss), the midpoint's feasibility row,
 // children
@@ -755,6 +921,9 @@ static int hy_split_stage(ehm_tree* T, const int32_t* fr, int ns, int has_data, 
         hy_build_sel(T, H.sp_d.as<int32_t>(), ns, H.moff.as<long long>());
         HY_TRY(hy_run_point(T, H.mids.as<double>(), 0, H.Jm.as<double>(), H.um.as<double>(),
                             H.mst.as<int32_t>()));
+        hy_retry_sel_point(T, H.sp_d.as<int32_t>(), ns, H.moff.as<long long>(),
+                           H.mids.as<double>(), H.Jm.as<double>(), H.um.as<double>(),
+                           H.mst.as<int32_t>());
     }
     hy_build_bits(T, H.midask.as<hy_u64>(), ns, H.moff.as<long long>());
     HY_TRY(hy_run_point(T, H.mids.as<double>(), 1, H.tau.as<double>(), nullptr, nullptr));
@@ -766,7 +935,8 @@ static int hy_split_stage(ehm_tree* T, const int32_t* fr, int ns, int has_data, 
                        H.sp_ij.as<int32_t>(), H.sp_d.as<int32_t>(), H.mids.as<double>(),
                        H.Jm.as<double>(), H.um.as<double>(), H.mst.as<int32_t>(),
                        H.vJ.as<double>(), H.vu.as<double>(), H.midbits.as<hy_u64>(),
-                       H.vf.as<hy_u64>(), H.cand.as<hy_u64>(), H.black.as<hy_u64>(), next, ctr);
+                       H.vf.as<hy_u64>(), H.cand.as<hy_u64>(), H.black.as<hy_u64>(),
+                       H.neg.as<hy_u64>(), H.tneg.as<double>(), next, ctr);
     P->launches += 3;
     return EHM_OK;
 }
@@ -778,8 +948,9 @@ static int hy_lcss_chunk(ehm_tree* T, const int32_t* fr, int ns, int32_t* next_l
     HyCtr* ctr = H.ctr.as<HyCtr>();
     const long long nbw = (long long)ns * nw;
     hipLaunchKernelGGL(hy_lcss_classify, HY_GRID(nbw), 0, P->stream, T->dt, fr, ns, nd, nw,
-                       H.vf.as<hy_u64>(), H.cand.as<hy_u64>(), H.known1.as<hy_u64>(),
-                       H.ask.as<hy_u64>(), H.vall.as<hy_u64>(), H.koff.as<long long>());
+                       H.vf.as<hy_u64>(), H.cand.as<hy_u64>(), H.neg.as<hy_u64>(),
+                       H.known1.as<hy_u64>(), H.ask.as<hy_u64>(), H.vall.as<hy_u64>(),
+                       H.koff.as<long long>());
     // phase one over the simplex for the commutations nothing is known about
     hy_build_bits(T, H.ask.as<hy_u64>(), ns, H.koff.as<long long>());
     HY_TRY(hy_run_simplex(T, SX_FEAS, H.tau.as<double>(), nullptr, nullptr));
@@ -794,11 +965,19 @@ static int hy_lcss_chunk(ehm_tree* T, const int32_t* fr, int ns, int32_t* next_l
                        H.known1.as<hy_u64>(), H.st.as<int32_t>(), H.redo.as<hy_u64>());
     hy_build_bits(T, H.redo.as<hy_u64>(), ns, H.koff.as<long long>());
     HY_TRY(hy_run_simplex(T, SX_FEAS, H.tau.as<double>(), nullptr, nullptr));
+    if (P->v1_ok && P->solver_gen == 2) {
+        hipLaunchKernelGGL(hy_retry_bits, HY_GRID(nbw), 0, P->stream, ns, nd, nw,
+                           H.slk.as<hy_u64>(), H.st.as<int32_t>(), H.tau.as<double>(),
+                           EHM_SLIVER_TOL, H.redo.as<hy_u64>());
+        hy_build_bits(T, H.redo.as<hy_u64>(), ns, H.koff.as<long long>());
+        hy_run_simplex_v1(T, SX_SLACK, H.tval.as<double>(), H.alpha.as<double>(),
+                          H.st.as<int32_t>());
+    }
     hipLaunchKernelGGL(hy_lcss_decide, HY_GRID(ns), 0, P->stream, T->dt, fr, ns, nd, nw,
                        H.slk.as<hy_u64>(), H.vall.as<hy_u64>(), H.black.as<hy_u64>(),
                        H.tau.as<double>(), H.tval.as<double>(), H.st.as<int32_t>(),
                        H.alpha.as<double>(), EHM_SLIVER_TOL, EHM_TIE_TOL, T->run.max_depth,
-                       H.cand.as<hy_u64>(), H.act.as<int32_t>(), H.best.as<int32_t>(),
+                       H.prune, H.neg.as<hy_u64>(), H.tneg.as<double>(), H.cand.as<hy_u64>(), H.act.as<int32_t>(), H.best.as<int32_t>(),
                        H.ths.as<double>(), ctr);
     // the nodes with a better commutation: its vertex solves and in_variability_ball
     hipLaunchKernelGGL(hy_delta_entries, HY_GRID(ns), 0, P->stream, T->dt, fr, ns,
@@ -808,16 +987,27 @@ static int hy_lcss_chunk(ehm_tree* T, const int32_t* fr, int ns, int32_t* next_l
     P->launches += 5;
     hy_build_sel(T, H.dselV.as<int32_t>(), ns * nv, H.eoffV.as<long long>());
     HY_TRY(hy_run_point(T, T->dt.rec, 0, H.vJ.as<double>(), H.vu.as<double>(), H.vst.as<int32_t>()));
+    hy_retry_sel_point(T, H.dselV.as<int32_t>(), ns * nv, H.eoffV.as<long long>(), T->dt.rec,
+                       H.vJ.as<double>(), H.vu.as<double>(), H.vst.as<int32_t>());
     hy_build_sel(T, H.dselT.as<int32_t>(), ns, H.eoffT.as<long long>());
     HY_TRY(hy_run_point(T, H.ths.as<double>(), 0, H.Jth.as<double>(), nullptr,
                         H.Jth_st.as<int32_t>()));
+    hy_retry_sel_point(T, H.dselT.as<int32_t>(), ns, H.eoffT.as<long long>(), H.ths.as<double>(),
+                       H.Jth.as<double>(), nullptr, H.Jth_st.as<int32_t>());
     hy_build_sel(T, H.dselM.as<int32_t>(), ns, H.eoffM.as<long long>());
     HY_TRY(hy_run_simplex(T, SX_MIN, H.Jmin.as<double>(), nullptr, H.Jmin_st.as<int32_t>()));
+    if (P->v1_ok && P->solver_gen == 2) {
+        hipLaunchKernelGGL(hy_sel_stalled, HY_GRID(ns), 0, P->stream, H.dselM.as<int32_t>(), ns,
+                           H.Jmin_st.as<int32_t>(), H.dsel2.as<int32_t>());
+        hy_build_sel(T, H.dsel2.as<int32_t>(), ns, H.eoffM.as<long long>());
+        hy_run_simplex_v1(T, SX_MIN, H.Jmin.as<double>(), nullptr, H.Jmin_st.as<int32_t>());
+    }
     hipLaunchKernelGGL(hy_varsmall, HY_GRID(ns), 0, P->stream, T->dt, fr, ns, nw,
                        H.act.as<int32_t>(), H.best.as<int32_t>(), H.vJ.as<double>(),
                        H.vu.as<double>(), H.vst.as<int32_t>(), H.Jth.as<double>(),
                        H.Jth_st.as<int32_t>(), H.Jmin.as<double>(), H.Jmin_st.as<int32_t>(),
-                       P->dp.eps_a, P->dp.eps_r, H.fail_delta, H.black.as<hy_u64>(), ctr);
+                       P->dp.eps_a, P->dp.eps_r, H.fail_delta, H.black.as<hy_u64>(),
+                       H.neg.as<hy_u64>(), H.tneg.as<double>(), ctr);
     hipLaunchKernelGGL(hy_revisit, HY_GRID(ns), 0, P->stream, fr, ns, H.act.as<int32_t>(),
                        next_lcss, ctr);
     P->launches += 2;
@@ -849,6 +1039,8 @@ static int hy_ecc_chunk(ehm_tree* T, const int32_t* fr, int ns, int32_t* next_ec
                        (int32_t*)nullptr, (long long*)nullptr);
     hy_build_sel(T, H.dselV.as<int32_t>(), ns * nv, H.eoffV.as<long long>());
     HY_TRY(hy_run_point(T, T->dt.rec, 0, H.vJ.as<double>(), H.vu.as<double>(), H.vst.as<int32_t>()));
+    hy_retry_sel_point(T, H.dselV.as<int32_t>(), ns * nv, H.eoffV.as<long long>(), T->dt.rec,
+                       H.vJ.as<double>(), H.vu.as<double>(), H.vst.as<int32_t>());
     hipLaunchKernelGGL(hy_ecc_adopt, HY_GRID(ns), 0, P->stream, T->dt, fr, ns, H.act.as<int32_t>(),
                        H.best.as<int32_t>(), H.vJ.as<double>(), H.vu.as<double>(),
                        H.vst.as<int32_t>(), nw, H.fail_delta, H.black.as<hy_u64>(), next_ecc,
@@ -869,8 +1061,26 @@ static int hy_read_ctr(ehm_tree* T) {
     if (H.h.error == 3)
         return fail(EHM_E_INFEASIBLE, "STOP, Theta contains infeasible regions (node %d)",
                     H.h.err_node);
-    if (H.h.error != 0)
-        return fail(EHM_E_NUMERIC, "an oracle solve of node %d did not converge", H.h.err_node);
+    if (H.h.error != 0) {
+        static const char* what[] = {"?", "suboptimality-test problem", "min over the simplex",
+                                     "midpoint solve"};
+        if (const char* path = getenv("EHM_DUMP_FAIL")) {      // debugging aid: the instance
+            const int p = P->dp.p, nv = p + 1, stride = T->dt.rec_stride;
+            std::vector<double> rec((size_t)stride);
+            (void)hipMemcpy(rec.data(), T->dt.rec + (size_t)H.h.err_node * stride, stride * 8,
+                            hipMemcpyDeviceToHost);
+            if (FILE* fp = fopen(path, "w")) {
+                fprintf(fp, "%d %d %d\n", H.h.err_kind >> 4, p, H.h.err_kind & 3);
+                for (int q = 0; q < nv * p; ++q) fprintf(fp, "%.17g ", rec[(size_t)q]);
+                fprintf(fp, "\n");
+                for (int q = 0; q < nv; ++q) fprintf(fp, "%.17g ", rec[(size_t)(nv * p + q)]);
+                fprintf(fp, "\n%.17g %.17g\n", P->dp.eps_a, P->dp.eps_r);
+                fclose(fp);
+            }
+        }
+        return fail(EHM_E_NUMERIC, "node %d: %s with commutation %d did not converge",
+                    H.h.err_node, what[H.h.err_kind & 3], H.h.err_kind >> 4);
+    }
     return EHM_OK;
 }
 
@@ -907,6 +1117,10 @@ static int hy_sweep(ehm_tree* T) {
     R.depth = H.h.max_depth_seen;
     R.nf = H.n_ecc + H.n_lcss;
     ++R.sweeps;
+    if (getenv("EHM_HY_TRACE"))
+        fprintf(stderr, "[hybrid] sweep %d: nodes %d closed %llu splits %llu swaps %llu -> next ecc "
+                        "%lld lcss %lld\n", R.sweeps, H.h.n_nodes, H.h.closed, H.h.splits,
+                H.h.swaps, H.n_ecc, H.n_lcss);
     return EHM_OK;
 }
 
@@ -914,8 +1128,8 @@ static int hy_sweep(ehm_tree* T) {
 static int hy_begin(ehm_tree* T, int64_t n_roots, const ehm_node_init* init) {
     ehm_problem* P = T->prob;
     auto& R = T->run;
-    if (P->solver_gen != 2)
-        return fail(EHM_E_INVALID, "hybrid partitions need the generation-2 kernels");
+    if (P->solver_gen != 2 && !P->v1_ok)
+        return fail(EHM_E_INVALID, "this problem does not fit the generation-1 kernels");
     T->hy = new HyState();
     HyState& H = *T->hy;
     H.on = true;
@@ -923,6 +1137,7 @@ static int hy_begin(ehm_tree* T, int64_t n_roots, const ehm_node_init* init) {
     if (rc) return rc;
     const int nd = P->dp.n_delta, nw = H.nw, p = P->dp.p, nv = p + 1;
     if (const char* e = getenv("EHM_HY_FAIL_DELTA")) H.fail_delta = atoi(e);
+    if (getenv("EHM_HY_NO_PRUNE")) H.prune = 0;
     std::vector<int32_t> didx((size_t)n_roots, -1);
     std::vector<uint8_t> flags((size_t)n_roots, 0);
     if (R.action == 1) {
@@ -941,7 +1156,8 @@ static int hy_begin(ehm_tree* T, int64_t n_roots, const ehm_node_init* init) {
     HIP_TRY(hipMemcpyAsync(H.ctr.ptr, &h, sizeof h, hipMemcpyHostToDevice, P->stream), EHM_E_HIP);
     HIP_TRY(hipStreamSynchronize(P->stream), EHM_E_HIP);      // didx / flags / h leave scope
     hipLaunchKernelGGL(hy_node_init, HY_GRID(n_roots * nw), 0, P->stream, 0, (int)n_roots, nd, nw,
-                       H.cand.as<hy_u64>(), H.black.as<hy_u64>());
+                       H.cand.as<hy_u64>(), H.black.as<hy_u64>(), H.neg.as<hy_u64>(),
+                       H.tneg.as<double>());
     // feasibility of every commutation at every root vertex
     const long long rows = n_roots * nv;
     for (long long r0 = 0; r0 < rows; r0 += H.ch) {
@@ -968,5 +1184,25 @@ static int hy_begin(ehm_tree* T, int64_t n_roots, const ehm_node_init* init) {
     H.n_ecc = (R.action == 1) ? 0 : n_roots;
     H.n_lcss = (R.action == 1) ? n_roots : 0;
     T->unordered = true;      // node ids follow the allocation order; the export relabels
+    return EHM_OK;
+}
+
+// iterations / solves by LP kind from the counter snapshots (ehm_partition_finish)
+static int hy_kind_totals(ehm_tree* T, int64_t (&solves)[5], int64_t (&iters)[5]) {
+    ehm_problem* P = T->prob;
+    HyState& H = *T->hy;
+    for (int k = 0; k < 5; ++k) solves[k] = iters[k] = 0;
+    const size_t n = H.snap_kind.size();
+    if (n == 0) return EHM_OK;
+    std::vector<DevCounters> c(n);
+    HIP_TRY(hipMemcpyAsync(c.data(), H.snaps.ptr, n * sizeof(DevCounters), hipMemcpyDeviceToHost,
+                           P->stream), EHM_E_HIP);
+    HIP_TRY(hipStreamSynchronize(P->stream), EHM_E_HIP);
+    DevCounters prev = T->run.c0;
+    for (size_t i = 0; i < n; ++i) {
+        solves[H.snap_kind[i]] += (int64_t)(c[i].lp_solves - prev.lp_solves);
+        iters[H.snap_kind[i]] += (int64_t)(c[i].ipm_iters - prev.ipm_iters);
+        prev = c[i];
+    }
     return EHM_OK;
 }

@@ -409,7 +409,13 @@ __device__ inline IpmResult ipm_solve(const LpWork& w, const double (&b)[EHM_SLO
         const double cjj = (jcol < n) ? w.c[jcol] : 0.0;
         const double xjj = (jcol < n) ? w.x[jcol] : 0.0;
         const double gjj = (w.quad && jcol < n) ? w.kap0 * w.gv[jcol] : 0.0;
-        const double r_d = (jcol < n) ? (atl + cjj + gjj) : 0.0;
+        // quadratic costs: the dual residual is measured in the metric of the Hessian's diagonal
+        // (r_d_j / sqrt(1 + Q_jj)) -- a residual along a direction the cost bends by Q_jj moves the
+        // optimum by r_d_j / Q_jj only, and with Q_jj ~ 1e6 (the reference's scaled input
+        // weights) the unscaled measure stalls at 1e-6 on solves that are converged to 1e-11 in
+        // the primal residual, the gap and the optimal value
+        const double r_d = (jcol < n) ? (atl + cjj + gjj) *
+            (w.quad ? rsqrt(1.0 + w.Q[jcol * EHM_LDM + jcol]) : 1.0) : 0.0;
         const double cn = w.quad ? (1.0 + wave_max(fmax(fabs(cjj), fabs(gjj)))) : cnorm;
         const double emax = wave_max(fmax(rpmax / bnorm, fabs(r_d) / cn));
         const double sl_tot = wave_sum(sl_sum);

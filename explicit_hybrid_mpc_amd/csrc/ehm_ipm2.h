@@ -889,7 +889,7 @@ __device__ __forceinline__ double lu_solve(const double (&row)[NP], const Wave& 
 // optimal value with respect to the parameter, -S^T lambda = sum_i lambda_i Wc[n+q][i], NaN
 // unless the solve converged to the tolerances (an accepted-inaccurate solve has no usable dual).
 __device__ inline IpmResult ipm_solve(const Shared& S, const Wave& W, const double (&b)[SLOTS],
-                                      int lane0, bool sign_only, double step_frac,
+                                      int lane0, int sign_only, double step_frac,
                                       double* gout = nullptr) {
     int lane = lane0;
     const int n = W.n_lp;
@@ -994,7 +994,9 @@ __device__ inline IpmResult ipm_solve(const Shared& S, const Wave& W, const doub
         const double cjj = (lane < n) ? W.c[lane] : 0.0;
         const double xjj = (lane < n) ? W.x[lane] : 0.0;
 #if EHM2_QUAD
-        const double r_d = (lane < n) ? (atl + cjj + gjj) : 0.0;
+        // the dual residual in the metric of the Hessian's diagonal (see ehm_ipm.h)
+        const double r_d = (lane < n) ? (atl + cjj + gjj) *
+            (W.quad ? rsqrt(1.0 + W.Q[lane * LDM + lane]) : 1.0) : 0.0;
         const double cn = W.quad ? (1.0 + wave_max(fmax(fabs(cjj), fabs(gjj)))) : cnorm;
         const double emax = wave_max(fmax(rpmax / bnorm, fabs(r_d) / cn));
         const double sl_tot = wave_sum(sl_sum);
@@ -1038,7 +1040,11 @@ __device__ inline IpmResult ipm_solve(const Shared& S, const Wave& W, const doub
             res.status = 0;
             break;
         }
-        if (sign_only && emax <= const_d(EHM2_SIGN_RES) && pobj * dobj > 0.0) {
+        // sign_only: 1 = stop as soon as the sign of the optimum is certain; 2 = only when it is
+        // positive (hybrid suboptimality tests: a commutation with t* = -optimum < 0 only has
+        // to be known as such, one with t* >= 0 is ranked by its value)
+        if (sign_only && emax <= const_d(EHM2_SIGN_RES) && pobj * dobj > 0.0 &&
+            (sign_only == 1 || pobj > 0.0)) {
             const double lo = fmin(fabs(pobj), fabs(dobj));
             if (fabs(pobj - dobj) <= const_d(EHM2_SIGN_GAP) * lo &&
                 emax * (1.0 + fabs(pobj)) <= const_d(EHM2_SIGN_RES_REL) * lo) {

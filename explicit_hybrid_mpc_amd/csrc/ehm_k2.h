@@ -71,6 +71,8 @@ struct K2Gather {
     const int32_t* n_dev;   // device-side instance count overriding n_inst (null = n_inst)
     int v_off;              // simplex kinds with src: Vbar = R + v_off (tree records)
     double* grad;           // point solves: dJ/dtheta out, [dst][p]; null = not wanted
+    int sign_mode;          // 0 = full accuracy; 1 / 2 = sign-only stop (ehm_ipm2.h), the value
+                            // written is then the bound min(|primal|, |dual|) with the sign
 };
 
 struct K2Launch {

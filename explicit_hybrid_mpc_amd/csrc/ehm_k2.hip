@@ -57,7 +57,7 @@ __global__ __launch_bounds__(EHM_K2_THREADS) void k2_point_batch(
                 double b[SLOTS];
                 const int ln = pin(lane);     // nothing of the assembly outlives the attempt
                 assemble_point(S, W, nb.lp, nb.th, feas != 0, b, ln, P, d);
-                r = ipm_solve(S, W, b, ln, false,
+                r = ipm_solve(S, W, b, ln, feas ? G.sign_mode : 0,
                               step_fraction(attempt), (G.grad && !feas) ? nb.F : nullptr);
                 its += r.iters;
                 if (r.status == 0) break;
@@ -71,7 +71,7 @@ __global__ __launch_bounds__(EHM_K2_THREADS) void k2_point_batch(
                 if (lane < P.p) G.grad[o * P.p + lane] = nb.F[lane];
             }
             if (lane == 0) {
-                J[o] = r.obj;
+                J[o] = (feas && G.sign_mode) ? copysign(r.margin, r.obj) : r.obj;
                 if (status) status[o] = r.status;
                 if (iters) iters[o] = r.iters;
             }
@@ -123,7 +123,7 @@ __global__ __launch_bounds__(EHM_K2_THREADS) void k2_simplex_batch(
                 double b[SLOTS];
                 const int ln = pin(lane);
                 assemble_simplex(S, W, nb, Rl, Vl, mode, P.eps_a, P.eps_r, b, ln, P, d);
-                r = ipm_solve(S, W, b, ln, false,
+                r = ipm_solve(S, W, b, ln, (mode == SX_MIN) ? 0 : G.sign_mode,
                               step_fraction(attempt));
                 its += r.iters;
                 if (r.status == 0) break;
@@ -131,7 +131,8 @@ __global__ __launch_bounds__(EHM_K2_THREADS) void k2_simplex_batch(
             r.iters = its;
             count_solve(cnt, r, lane);
             if (lane == 0) {
-                obj[o] = (mode == SX_SLACK) ? -r.obj : r.obj;     // t* = -(min -t)
+                const double val = (G.sign_mode && mode != SX_MIN) ? copysign(r.margin, r.obj) : r.obj;
+                obj[o] = (mode == SX_SLACK) ? -val : val;         // t* = -(min -t)
                 if (status) status[o] = r.status;
                 if (iters) iters[o] = r.iters;
             }

@@ -15,6 +15,15 @@ from . import _capi
 from ._capi import f64, u8, ptr, check
 
 
+def _info_dict(info):
+    """ehm_tree_info as a dict (array members as lists)."""
+    out = {}
+    for name, _ in _capi.TreeInfo._fields_:
+        v = getattr(info, name)
+        out[name] = list(v) if hasattr(v, '__len__') else v
+    return out
+
+
 class FlatTree:
     """
     Flat export of a grown partition (struct of arrays, node k):
@@ -315,7 +324,7 @@ class GpuProblem:
         try:
             info = _capi.TreeInfo()
             check(self._lib.ehm_tree_info_get(tree, ctypes.byref(info)))
-            info_d = {name: getattr(info, name) for name, _ in _capi.TreeInfo._fields_}
+            info_d = _info_dict(info)
             if not export:
                 return info_d
             K = info.n_nodes
@@ -423,7 +432,7 @@ class PartitionRun:
             check(self._lib.ehm_partition_finish(self._tree))
             info = _capi.TreeInfo()
             check(self._lib.ehm_tree_info_get(self._tree, ctypes.byref(info)))
-            info_d = {name: getattr(info, name) for name, _ in _capi.TreeInfo._fields_}
+            info_d = _info_dict(info)
             if not export:
                 return info_d
             K = info.n_nodes

@@ -308,6 +308,12 @@ typedef struct ehm_tree_info {
     int64_t swaps;          /* nodes that took a better commutation in place (lib/worker.py:396-401) */
     int64_t blacklisted;    /* commutations blacklisted after a failed vertex solve
                                (lib/oracle.py:198-218, 406-414) */
+    /* solves / interior-point iterations by problem kind: [0] P_theta_delta, [1] its phase-one
+     * form, [2] min over a simplex, [3] suboptimality test (slack), [4] phase one over a simplex.
+     * Multi-commutation runs: decide_* / decide_seconds cover the simplex kinds (2-4),
+     * expand_seconds the point kinds (0-1). */
+    int64_t kind_solves[5];
+    int64_t kind_iters[5];
 } ehm_tree_info;
 
 int ehm_tree_info_get(const ehm_tree* tree, ehm_tree_info* out);

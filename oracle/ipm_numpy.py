@@ -328,7 +328,8 @@ def solve_cp(pr, max_iter=60, tol_res=1e-10, tol_gap=1e-10, step_frac=STEP_FRAC_
         pobj = pr.c_lin @ y + pr.kappa0 * (0.5 * yQy + q @ y)
         cnorm = 1. + max(np.max(np.abs(pr.c_lin)), pr.kappa0 * np.max(np.abs(gV)))
         e_p = np.max(np.abs(r_p)) / bnorm
-        e_d = np.max(np.abs(r_d)) / cnorm
+        # dual residual in the metric of the Hessian's diagonal, as in the kernels (ehm_ipm.h)
+        e_d = np.max(np.abs(r_d) / np.sqrt(1. + np.diag(Q))) / cnorm
         e_g = (s @ lam) / (1. + abs(pobj + pr.kappa0 * pr.v0))
         merit = max(e_p / tol_res, e_d / tol_res, e_g / tol_gap)
         if best is None or merit < best[0]:

@@ -14,7 +14,7 @@ import sys
 
 
 def short(name):
-    m = re.search(r'(k[23p]?_[a-z_]+)', name)
+    m = re.search(r'(k[23p]?_[a-z_]+|hy_[a-z_0-9]+)', name)
     return m.group(1) if m else name.split('(')[0]
 
 
@@ -48,9 +48,15 @@ def main():
                             row = dict(row)
                             row['Name'] = short(row.get('Name', ''))
                             stats.append(row)
+    # hash of the kernel sources the counters were measured on: bench.py quotes the HBM traffic
+    # of this summary only for the same code (kernel_source_hash there)
+    sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    import bench
+    doc = {'counters': counters, 'kernel_stats': stats,
+           'kernel_source_sha': bench.kernel_source_hash()}
     with open(out_path, 'w') as fh:
-        json.dump({'counters': counters, 'kernel_stats': stats}, fh, indent=1, sort_keys=True)
-    print(json.dumps({'counters': counters, 'kernel_stats': stats}, indent=1, sort_keys=True))
+        json.dump(doc, fh, indent=1, sort_keys=True)
+    print(json.dumps(doc, indent=1, sort_keys=True))
 
 
 if __name__ == '__main__':
