@@ -78,7 +78,8 @@ class TreeInfo(ctypes.Structure):
                 ('replicated_nodes', ctypes.c_int64), ('replicated_solves', ctypes.c_int64),
                 ('cert_closed', ctypes.c_int64), ('witness_open', ctypes.c_int64),
                 ('swaps', ctypes.c_int64), ('blacklisted', ctypes.c_int64),
-                ('kind_solves', ctypes.c_int64 * 5), ('kind_iters', ctypes.c_int64 * 5)]
+                ('kind_solves', ctypes.c_int64 * 5), ('kind_iters', ctypes.c_int64 * 5),
+                ('near_threshold', ctypes.c_int64)]
 
 
 class Progress(ctypes.Structure):

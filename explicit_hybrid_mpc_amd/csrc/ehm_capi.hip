@@ -2475,6 +2475,7 @@ int ehm_partition_finish(ehm_tree* T) {
     T->info.decide_iters = (int64_t)(c1.slack_iters - R.c0.slack_iters);
     T->info.cert_closed = (int64_t)(c1.cert_closed - R.c0.cert_closed);
     T->info.witness_open = (int64_t)(c1.wit_open - R.c0.wit_open);
+    T->info.near_threshold = (int64_t)(c1.routed - R.c0.routed);
     T->info.replicated_closed = R.pre_closed;
     T->info.replicated_nodes = R.pre_nodes;
     T->info.replicated_solves = R.pre_solves;
@@ -2503,6 +2504,7 @@ int ehm_partition_finish(ehm_tree* T) {
         T->info.min_margin = mm;
         T->info.swaps = (int64_t)h.swaps;
         T->info.blacklisted = (int64_t)h.blacklisted;
+        T->info.near_threshold = (int64_t)h.routed;
         P->slivers += (long long)h.slivers;
         P->fallbacks += (long long)h.fallbacks;
     }

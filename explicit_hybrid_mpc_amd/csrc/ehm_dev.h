@@ -140,6 +140,7 @@ struct DevCounters {
     unsigned long long slack_iters;
     unsigned long long cert_closed;       // leaves closed by the cutting-plane bound, no LP
     unsigned long long wit_open;          // nodes proved open by their midpoint solve, no LP
+    unsigned long long routed;            // decisions with |t*| < EHM_ROUTE_TOL (full-accuracy LP)
 };
 
 __host__ __device__ inline int rec_off_vcost(int p) { return (p + 1) * p; }

@@ -43,7 +43,7 @@ struct HyCtr {
     int truncated;
     int max_depth_seen;
     int err_kind;           // numeric errors: 1 slack problem, 2 min over the simplex, 3 midpoint
-    unsigned long long closed, splits, swaps, slivers, blacklisted, ref_solves, fallbacks;
+    unsigned long long closed, splits, swaps, slivers, blacklisted, ref_solves, fallbacks, routed;
     unsigned long long min_margin_bits;
 };
 
@@ -282,7 +282,7 @@ __global__ void hy_lcss_decide(DevTree T, const int32_t* __restrict__ frontier, 
     double tb = tneg[id], tbm = -INFINITY, tn = tneg[id];
     hy_u64 feas[4] = {0ULL, 0ULL, 0ULL, 0ULL};
     hy_u64 ng[4] = {0ULL, 0ULL, 0ULL, 0ULL};
-    const double neg_tol = EHM_CUT_TOL * (1.0 + fabs(T.rec[(size_t)id * T.rec_stride +
+    const double neg_tol = EHM_ROUTE_TOL * (1.0 + fabs(T.rec[(size_t)id * T.rec_stride +
                                                            rec_off_vcost(p)]));
     for (int w = 0; w < nw; ++w) {
         ng[w] = neg[(size_t)id * nw + w];
@@ -317,6 +317,7 @@ __global__ void hy_lcss_decide(DevTree T, const int32_t* __restrict__ frontier, 
         neg[(size_t)id * nw + w] = ng[w];
     }
     tneg[id] = tn;
+    if (fabs(tb) < neg_tol) atomicAdd(&ctr->routed, 1ULL);
     T.tstar[id] = tb;
     atomicMin(&ctr->min_margin_bits, (unsigned long long)__double_as_longlong(fabs(tb)));
     atomicAdd(&ctr->ref_solves, 1ULL);

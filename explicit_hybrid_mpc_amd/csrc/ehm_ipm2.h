@@ -242,6 +242,8 @@ struct Wave {
     int psi0, npsi;
     int nsx;        // extra rows 0..nsx-1 are the simplex rows (-beta_q <= 0, sum beta <= 1):
                     // their normal-matrix terms are added analytically, rows >= nsx densely
+    double sign_floor;  // a sign-only stop must establish |optimum| >= this (near-threshold
+                        // routing, EHM_ROUTE_TOL): closer calls run to full accuracy
 #if EHM2_QUAD
     // quadratic block: objective c'x + kap0 V(x), extra rows eq / eq+1 are
     // kap_i V(x) + a_i'x <= bq_i,  V(x) = 1/2 x'Q x + qv'x (+ v0 in the reported objective)
@@ -1046,7 +1048,7 @@ __device__ inline IpmResult ipm_solve(const Shared& S, const Wave& W, const doub
         if (sign_only && emax <= const_d(EHM2_SIGN_RES) && pobj * dobj > 0.0 &&
             (sign_only == 1 || pobj > 0.0)) {
             const double lo = fmin(fabs(pobj), fabs(dobj));
-            if (fabs(pobj - dobj) <= const_d(EHM2_SIGN_GAP) * lo &&
+            if (lo >= W.sign_floor && fabs(pobj - dobj) <= const_d(EHM2_SIGN_GAP) * lo &&
                 emax * (1.0 + fabs(pobj)) <= const_d(EHM2_SIGN_RES_REL) * lo) {
                 res.obj = pobj;
                 res.merit = merit;

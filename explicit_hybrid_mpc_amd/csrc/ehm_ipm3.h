@@ -175,6 +175,7 @@ struct Lp {
     const double* wv;   // [m]
     const double* cv;   // [n]
     int n, m, p, ldc, m_pad, ntile;
+    double sign_floor;  // a sign-only stop must establish |optimum| >= this (EHM_ROUTE_TOL)
     // LDS
     double* M;      // NW x LDM normal matrix, then the packed factor U
     double* dvec;   // nvec   d = lam / s
@@ -808,7 +809,7 @@ __device__ __forceinline__ IpmResult ipm_solve(const Lp& L, Block& B, const doub
         }
         if (sign_only && emax <= EHM3_SIGN_RES && pobj * dobj > 0.0) {
             const double lo = fmin(fabs(pobj), fabs(dobj));
-            if (fabs(pobj - dobj) <= EHM3_SIGN_GAP * lo &&
+            if (lo >= L.sign_floor && fabs(pobj - dobj) <= EHM3_SIGN_GAP * lo &&
                 emax * (1.0 + fabs(pobj)) <= EHM3_SIGN_RES_REL * lo) {
                 res.obj = pobj;
                 res.merit = merit;

@@ -13,9 +13,12 @@
 #endif
 
 #define K2_AUG_MIN 16
-// the cutting-plane bound closes a leaf only when it is negative by more than this (relative to
-// 1 + |V_0|): gradients carry the accuracy of the multipliers (~1e-9); closer calls go to the LP
-#define EHM_CUT_TOL 1e-7
+// Near-threshold routing (hard part 1): a node's close / split decision may be
+// taken by a shortcut -- sign-only stop of the suboptimality-test LP, tangent-plane bound,
+// midpoint witness, inherited negative verdict -- only when it establishes |t*| >= this
+// (relative to 1 + |V_0|); every closer call is decided by the LP solved to FULL accuracy
+// (tolerances 1e-10), like the CPU oracle's.  ehm_tree_info.near_threshold counts those.
+#define EHM_ROUTE_TOL 1e-6
 
 namespace ehm {
 

@@ -175,7 +175,7 @@ __global__ __launch_bounds__(EHM_K2_THREADS) void k2_lcss_decide(
             // exactly as a negative t* would close it, without solving the LP
             const double bnd = cut_bound(nb.rec, T.grad + (size_t)id * (P.p + 1) * P.p, P.p,
                                          P.eps_a, P.eps_r, lane, nb.lp);
-            if (bnd < -EHM_CUT_TOL * (1.0 + fabs(nb.rec[rec_off_vcost(P.p)]))) {
+            if (bnd < -EHM_ROUTE_TOL * (1.0 + fabs(nb.rec[rec_off_vcost(P.p)]))) {
                 if (lane == 0) {
                     atomicAdd(&cnt->cert_closed, 1ULL);
                     T.tstar[id] = bnd;
@@ -216,6 +216,8 @@ __global__ __launch_bounds__(EHM_K2_THREADS) void k2_lcss_decide(
             open_flag[f] = open ? 1 : 0;
             if (!open) T.flags[id] |= 1;
             atomicMin(&cnt->min_margin_bits, (unsigned long long)__double_as_longlong(r.margin));
+            if (r.margin < EHM_ROUTE_TOL * (1.0 + fabs(nb.rec[rec_off_vcost(P.p)])))
+                atomicAdd(&cnt->routed, 1ULL);
         }
         wsync();
     }
@@ -362,10 +364,10 @@ __global__ __launch_bounds__(EHM_K2_THREADS) void k2_persist(
     // added to the global counters ONCE, when it leaves -- the level-synchronous kernels pay ~8
     // device atomics per node for them
     unsigned long long* wst = reinterpret_cast<unsigned long long*>(nb.aug);
-    double* wmargin = nb.aug + 12;
+    double* wmargin = nb.aug + 13;
     enum { W_SOLVES = 0, W_ITERS, W_STALLED, W_ERRORS, W_SLACK, W_SLACK_ITERS, W_CLOSED, W_SPLITS,
-           W_DEPTH, W_TRUNC, W_CERT, W_WIT };
-    if (lane0 < 12) wst[lane0] = 0ULL;
+           W_DEPTH, W_TRUNC, W_CERT, W_WIT, W_ROUTED };
+    if (lane0 < 13) wst[lane0] = 0ULL;
     if (lane0 == 0) *wmargin = 1e300;
     wsync();
     for (;;) {
@@ -403,7 +405,7 @@ __global__ __launch_bounds__(EHM_K2_THREADS) void k2_persist(
             // tangent-plane bound of t* (ehm_dev.h, cut_bound): negative => closed, no LP
             const double bnd = cut_bound(node, T.grad + (size_t)id * (p + 1) * p, p, P.eps_a,
                                          P.eps_r, lane, nb.lp);
-            if (bnd < -EHM_CUT_TOL * (1.0 + fabs(node[rec_off_vcost(p)]))) {
+            if (bnd < -EHM_ROUTE_TOL * (1.0 + fabs(node[rec_off_vcost(p)]))) {
                 if (lane == 0) {
                     const int dep0 = T.depth[id];
                     wst[W_CERT] += 1;
@@ -473,7 +475,7 @@ __global__ __launch_bounds__(EHM_K2_THREADS) void k2_persist(
                 const double* Vc = node + rec_off_vcost(p);
                 const double vb = 0.5 * (Vc[bi] + Vc[bj]);
                 const double tw = fmin(vb - Jm - P.eps_a, vb - (1.0 + P.eps_r) * Jm);
-                if (tw > EHM_CUT_TOL * (1.0 + fabs(vb))) {
+                if (tw > EHM_ROUTE_TOL * (1.0 + fabs(vb))) {
                     open = true;
                     decided = true;
                     tst = tw;
@@ -522,6 +524,7 @@ __global__ __launch_bounds__(EHM_K2_THREADS) void k2_persist(
                 }
             }
             *wmargin = fmin(*wmargin, margin);
+            if (margin < EHM_ROUTE_TOL * (1.0 + fabs(node[rec_off_vcost(p)]))) wst[W_ROUTED] += 1;
             if ((unsigned long long)dep > wst[W_DEPTH]) wst[W_DEPTH] = (unsigned long long)dep;
             T.tstar[id] = tst;
             if (!open) {
@@ -597,6 +600,7 @@ __global__ __launch_bounds__(EHM_K2_THREADS) void k2_persist(
                 T.flags[id] |= 8;
             }
             *wmargin = fmin(*wmargin, r.margin);
+            if (r.margin < EHM_ROUTE_TOL * (1.0 + fabs(node[rec_off_vcost(p)]))) wst[W_ROUTED] += 1;
             if ((unsigned long long)dep > wst[W_DEPTH]) wst[W_DEPTH] = (unsigned long long)dep;
             T.tstar[id] = tst;
             if (!open) {
@@ -741,6 +745,7 @@ __global__ __launch_bounds__(EHM_K2_THREADS) void k2_persist(
         atomicMin(&cnt->min_margin_bits, (unsigned long long)__double_as_longlong(*wmargin));
         if (wst[W_CERT]) atomicAdd(&cnt->cert_closed, wst[W_CERT]);
         if (wst[W_WIT]) atomicAdd(&cnt->wit_open, wst[W_WIT]);
+        if (wst[W_ROUTED]) atomicAdd(&cnt->routed, wst[W_ROUTED]);
         atomicAdd(&ctl->closed, wst[W_CLOSED]);
         atomicAdd(&ctl->splits, wst[W_SPLITS]);
         atomicMax(&ctl->max_depth_seen, (int)wst[W_DEPTH]);

@@ -172,6 +172,7 @@ __device__ inline void assemble_point(const Shared& S, Wave& W, double* lp_base,
     W.n_lin = n;
     W.spec_col = n + p;           // the column of -1
     W.n_mpc = W.n_lp;
+    W.sign_floor = EHM_ROUTE_TOL;     // phase one: the optimum is compared with ~0
     if (lane < NP) W.c[lane] = feas ? ((lane == n) ? 1.0 : 0.0) : ((lane < n) ? S.cv[lane] : 0.0);
     if (feas) {
         // extra row 0:  -tau <= 1      (ldx = 1)
@@ -221,6 +222,7 @@ __device__ inline void assemble_simplex(const Shared& S, Wave& W, const NodeBuf&
     W.psi0 = n;
     W.npsi = p;
     W.nsx = p + 1;
+    W.sign_floor = EHM_ROUTE_TOL * (1.0 + (slack ? fabs(Vbar[0]) : 0.0));
     const int ldx = W.ldx;
     for (int k = lane; k < n_lp * ldx; k += 64) W.X[k] = 0.0;
     if (lane < NP) W.c[lane] = 0.0;

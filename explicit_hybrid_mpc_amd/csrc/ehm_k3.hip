@@ -35,6 +35,7 @@ __device__ __forceinline__ void assemble_point(Lp& L, const double* theta, bool 
     L.ne = feas ? 1 : 0;
     L.m_lp = m + L.ne;
     L.has_beta = 0;
+    L.sign_floor = EHM_ROUTE_TOL;
     L.spec_mpc = feas ? 1 : 0;
     L.act = ((n < 64) ? ((1ULL << n) - 1ULL) : ~0ULL) | (feas ? (1ULL << (n + p)) : 0ULL);
     if (tid < NW) {
@@ -71,6 +72,7 @@ __device__ __forceinline__ void assemble_simplex(Lp& L, const double* R, const d
     L.ne = p + 1 + (slack ? 2 : 0) + (feas ? 1 : 0);
     L.m_lp = m + L.ne;
     L.has_beta = 1;
+    L.sign_floor = EHM_ROUTE_TOL * (1.0 + ((mode == SX_SLACK) ? fabs(Vbar[0]) : 0.0));
     L.spec_mpc = feas ? 1 : 0;
     const int n_lp = n + p + ((slack || feas) ? 1 : 0);
     L.act = (n_lp < 64) ? ((1ULL << n_lp) - 1ULL) : ~0ULL;
@@ -284,6 +286,8 @@ EHM3_KERNEL void k3_lcss_decide(
             open_flag[f] = open ? 1 : 0;
             if (!open) T.flags[id] |= 1;
             atomicMin(&cnt->min_margin_bits, (unsigned long long)__double_as_longlong(r.margin));
+            if (r.margin < EHM_ROUTE_TOL * (1.0 + fabs(nb.rec[rec_off_vcost(P.p)])))
+                atomicAdd(&cnt->routed, 1ULL);
         }
         __syncthreads();
     }

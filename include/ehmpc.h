@@ -314,6 +314,10 @@ typedef struct ehm_tree_info {
      * expand_seconds the point kinds (0-1). */
     int64_t kind_solves[5];
     int64_t kind_iters[5];
+    /* near-threshold routing: decisions whose |t*| is below 1e-6 (1 + |V_0|); each of them was
+     * taken by the suboptimality-test problem solved to full accuracy, never by a shortcut
+     * (sign-only stop, tangent-plane bound, midpoint witness, inherited verdict) */
+    int64_t near_threshold;
 } ehm_tree_info;
 
 int ehm_tree_info_get(const ehm_tree* tree, ehm_tree_info* out);

@@ -61,6 +61,10 @@ class OracleCPU:
         # vertex solves of this commutation index raise like a failed MOSEK call would
         self.fail_vertex_solves_of = None
         self.n_blacklisted = 0
+        # 'best' = the canonical rule above; 'first' = what a feasibility MICP solved by a
+        # depth-first branch-and-bound tends to return: the FIRST commutation (enumeration
+        # order) that satisfies the constraints (bar_D: feasible at every vertex and t* >= 0)
+        self.bar_d_rule = 'best'
 
     # -- helpers ---------------------------------------------------------------------
     def delta_index(self, delta):
@@ -232,7 +236,10 @@ class OracleCPU:
             if not live:
                 return None, None, None, None
             t_max = max(c[0] for c in live)
-            best = next(c for c in live if c[0] >= t_max - TIE_TOL * (1. + abs(t_max)))
+            if self.bar_d_rule == 'first':
+                best = live[0]
+            else:
+                best = next(c for c in live if c[0] >= t_max - TIE_TOL * (1. + abs(t_max)))
             delta_star = self.deltas[best[1]].copy()
             if np.array_equal(delta_star.astype(int), np.asarray(delta_ref).astype(int)):
                 return None, None, None, None
