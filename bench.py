@@ -12,9 +12,11 @@ everything else (all frontier sweeps, LP solves, child construction).
     python bench.py --gpus N --steps K --warmup W
 
 prints ONE JSON line on rank 0.  For N > 1 it is launched by torch.distributed.run with
-one rank per GPU; every rank grows the same top of the tree until the frontier holds 1024
-nodes per rank, keeps the positions k % N == rank, and grows its share in one launch of the
-persistent frontier kernel -- no collective in the data path (`--balance static`, the default;
+one rank per GPU; every rank runs ONE launch of the persistent frontier kernel from the roots:
+the tree above a deal depth (about 2048 nodes per rank) is grown identically everywhere, a node
+created at that depth is pursued only by the rank a hash of its path names -- no collective in the
+data path (`--balance static`, the default; measured by running the shards one after the other:
+1.93x / 3.52x / 5.98x at 2 / 4 / 8 on the 1.6 M-node bench tree, 7.3x at 8 on a 6.9 M-node tree;
 `--balance dynamic` sweeps level by level and rebalances the frontiers with an all-gather of
 their sizes and point-to-point node transfers, explicit_hybrid_mpc_amd/distributed.py).  The
 total work is fixed ("strong" scaling) and `value` is the whole-job LP-solve rate.
@@ -208,10 +210,10 @@ def main():
     ap.add_argument('--shard-min-frontier', type=int, default=0,
                     help='frontier size at which it is dealt over the ranks (0 = 64 per rank)')
     ap.add_argument('--balance', choices=['static', 'dynamic'], default='static',
-                    help='N > 1: static = the frontier is dealt round-robin once it holds 1024 '
-                         'nodes per rank and every rank grows its share in ONE launch of the '
-                         'persistent frontier kernel, no collective in the data path (measured '
-                         'load imbalance 1.04 at 8 shards); dynamic = level-synchronous sweeps '
+                    help='N > 1: static = ONE launch of the persistent frontier kernel per rank '
+                         'from the roots, dealt at a tree depth by a hash of the node path, no '
+                         'collective in the data path (measured load imbalance 1.024 at 8 '
+                         'shards); dynamic = level-synchronous sweeps '
                          'with an all-gather of the frontier sizes and point-to-point node '
                          'transfers every --sweeps-per-round sweeps')
     ap.add_argument('--sweeps-per-round', type=int, default=2,
@@ -290,6 +292,8 @@ def main():
         # on any number of GPUs, deal early and rebalance often
         args.shard_min_frontier = (1024 if static else 64) * world
     shard = distributed.shard_spec(rank, world, args.shard_min_frontier)
+    # static: ONE persistent launch per rank from the roots, dealt at a tree depth by path code
+    deal_depth = distributed.deal_depth_for(len(roots), world) if (static and world > 1) else 0
 
     xdev = ('cuda:%d' % device_index) if backend == 'nccl' else None
     publisher = None
@@ -304,7 +308,8 @@ def main():
         if (world == 1 or static) and not args.status_dir:
             return gp.partition(roots, action='ecc', max_nodes=args.max_nodes, export=False,
                                 shard=None if hybrid else shard, with_volume=False,
-                                engine=args.engine, max_depth=args.max_depth)
+                                engine=args.engine, max_depth=args.max_depth,
+                                deal_depth=deal_depth)
         info, log, rounds = distributed.run_balanced(
             gp, roots, action='ecc', max_nodes=args.max_nodes,
             min_frontier=args.shard_min_frontier, sweeps_per_round=args.sweeps_per_round,
@@ -397,7 +402,11 @@ def main():
             flops, flops_x = f_survey[3], f_exec[3]
             hbm_alg = agg['decide_solves'] * (B_node + 8)
             hbm_grad = agg['decide_solves'] * grad_bytes
-        achieved = flops / decide_s / 1e12
+        # per GPU: the ranks' launches run side by side, each against its own peak
+        achieved = flops / world / decide_s / 1e12
+        flops_x /= world
+        hbm_alg /= world
+        hbm_grad /= world
         launches = max(info0['decide_launches'] * K, 1)
         traffic, traffic_src = pmc_traffic(kname, pmc_file)
         n_slack, m_slack = dims[3][0], dims[3][2]
@@ -458,9 +467,10 @@ def main():
                                       'sign-only stop (lower bound of |t*| recorded)',
                 'parallelism': 'frontier dealt round-robin over %d GPU(s)' % world +
                                ('' if world == 1 else
-                                ' at %d nodes, every rank grows its share in one persistent '
-                                'launch (static; no data-path collective)' %
-                                args.shard_min_frontier if static else
+                                ': one persistent launch per rank from the roots, the tree above '
+                                'depth %d replicated, the nodes of that depth dealt by a hash of '
+                                'their path (static; no data-path collective)' % deal_depth
+                                if static else
                                 ', rebalanced every %d sweeps (all-gather of frontier sizes + '
                                 'point-to-point node records)' % args.sweeps_per_round),
                 'rebalance_rounds_per_step': float(mx[len(keys) + 4]) / K,

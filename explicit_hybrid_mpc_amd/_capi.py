@@ -57,7 +57,8 @@ class RunOpts(ctypes.Structure):
     _fields_ = [('max_nodes', ctypes.c_int64), ('max_depth', ctypes.c_int32),
                 ('action', ctypes.c_int32), ('engine', ctypes.c_int32),
                 ('shard_rank', ctypes.c_int32), ('shard_world', ctypes.c_int32),
-                ('skip_volume', ctypes.c_int32), ('shard_min_frontier', ctypes.c_int64)]
+                ('skip_volume', ctypes.c_int32), ('shard_min_frontier', ctypes.c_int64),
+                ('deal_depth', ctypes.c_int32), ('reserved0', ctypes.c_int32)]
 
 
 class NodeInit(ctypes.Structure):

@@ -511,7 +511,7 @@ struct ehm_tree {
     DevTree dt{};
     long long cap = 0;       // allocated node records (a cached pool may be larger than asked for)
     long long limit = 0;     // max_nodes of this run: the capacity the caller agreed to
-    DevBuf rec, left, didx, depth, flags, tstar, grad;
+    DevBuf rec, left, didx, depth, flags, tstar, grad, code;
     ehm_tree_info info{};
     int skip_volume = 0;
     // persistent engine: node ids follow the allocation order; the export relabels them to the
@@ -522,6 +522,7 @@ struct ehm_tree {
     struct Run {
         bool active = false;
         int max_depth = 0, action = 0, shard_world = 1, shard_rank = 0, engine = 0;
+        int deal_depth = 0;     // > 0: sharded persistent launch dealt at this tree depth
         long long shard_min = 0;
         bool sharded = true, cur_is_a = true;
         long long n_roots = 0, n_nodes = 0, nf = 0, n_closed = 0, ref_solves = 0;
@@ -1804,7 +1805,7 @@ int ehm_tree_destroy(ehm_tree* T) {
         c.cap = T->cap;
     }
     T->rec.release(); T->left.release(); T->didx.release(); T->depth.release();
-    T->flags.release(); T->tstar.release(); T->grad.release();
+    T->flags.release(); T->tstar.release(); T->grad.release(); T->code.release();
     delete T;
     return EHM_OK;
 }
@@ -1927,6 +1928,7 @@ int ehm_partition_begin(ehm_problem* P, int64_t n_roots, const double* root_vert
     R.shard_world = (opts && opts->shard_world > 1) ? opts->shard_world : 1;
     R.shard_rank = opts ? opts->shard_rank : 0;
     R.shard_min = opts ? opts->shard_min_frontier : 0;
+    R.deal_depth = (opts && opts->shard_world > 1 && opts->deal_depth > 0) ? opts->deal_depth : 0;
     if (R.shard_world > 1 && (R.shard_rank < 0 || R.shard_rank >= R.shard_world)) {
         delete T;
         return fail(EHM_E_INVALID, "shard_rank %d out of range for world %d", R.shard_rank,
@@ -2118,6 +2120,20 @@ static int persistent_run(ehm_tree* T) {
     const int32_t* cur = (R.cur_is_a ? P->fr_a : P->fr_b).as<int32_t>();
     HIP_TRY(hipMemcpyAsync(slots, cur, (size_t)R.nf * 4, hipMemcpyDeviceToDevice, P->stream),
             EHM_E_HIP);
+    PersistDeal deal{0, 0, 1, 0};
+    T->dt.code = nullptr;
+    if (R.deal_depth > 0 && R.shard_world > 1 && R.sweeps == 0) {
+        // one launch from the roots, dealt over the ranks at a tree depth (PersistDeal)
+        deal = PersistDeal{R.deal_depth, R.shard_rank, R.shard_world,
+                           getenv("EHM_DEAL_LOW_BITS") ? 0 : 1};
+        if ((rc = T->code.ensure((size_t)T->cap * 4))) return rc;
+        T->dt.code = T->code.as<uint32_t>();
+        std::vector<uint32_t> codes((size_t)R.n_roots);
+        for (long long k = 0; k < R.n_roots; ++k) codes[(size_t)k] = (uint32_t)k;
+        HIP_TRY(hipMemcpyAsync(T->dt.code, codes.data(), codes.size() * 4, hipMemcpyHostToDevice,
+                               P->stream), EHM_E_HIP);
+        HIP_TRY(hipStreamSynchronize(P->stream), EHM_E_HIP);
+    }
     PersistCtl h{};
     h.head = 0;
     h.tail = (int)R.nf;
@@ -2131,7 +2147,7 @@ static int persistent_run(ehm_tree* T) {
     (void)hipEventRecord(e0, P->stream);
     (kp ? kp->persist : cfg.api->persist)(cfg.L, P->dp, T->dt, slots, (int)n_slots,
                                           P->pq_ctl.as<PersistCtl>(), (int)T->limit, P->d_cnt,
-                                          P->decide_full ? 0 : 1, R.max_depth);
+                                          P->decide_full ? 0 : 1, R.max_depth, deal);
     (void)hipEventRecord(e1, P->stream);
     R.evs.push_back(e0);
     R.evs.push_back(e1);
@@ -2148,6 +2164,14 @@ static int persistent_run(ehm_tree* T) {
         return fail(EHM_E_HIP, "persistent frontier kernel stopped early (abort=%d, pending=%d)",
                     h.abort, h.pending);
     R.ref_solves += (long long)h.closed + 3LL * (long long)h.splits;
+    if (deal.world > 1) {
+        // replicated on every rank: everything above the deal depth (and the nodes AT it, which
+        // replicated parents created -- own ones and the other ranks' placeholders alike)
+        R.pre_closed = (long long)h.repl_closed;
+        R.pre_nodes = R.n_roots + 2LL * (long long)h.repl_splits;
+        R.pre_solves = (long long)h.repl_solves;
+        R.sharded = true;
+    }
     R.n_closed += (long long)h.closed;
     R.n_nodes = h.n_nodes;
     R.truncated = h.truncated;
@@ -2179,7 +2203,7 @@ int ehm_partition_step(ehm_tree* T, int32_t max_sweeps, int64_t* frontier_size) 
     // one launch (static dealing: no rebalancing rounds, see distributed.py)
     const bool want_persist = R.engine == 1 && P->solver_gen == 2 && max_sweeps <= 0 &&
                               !P->dp.Wr3;
-    if (want_persist && R.nf > 0 && (R.shard_world == 1 || R.sharded)) {
+    if (want_persist && R.nf > 0 && (R.shard_world == 1 || R.sharded || R.deal_depth > 0)) {
         int rc = persistent_run(T);
         if (frontier_size) *frontier_size = 0;
         return rc;

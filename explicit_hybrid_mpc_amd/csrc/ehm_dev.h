@@ -57,6 +57,11 @@ struct DevTree {
     // Null unless the run maintains them (shared-block kernels, linear cost).  They give the
     // cutting-plane bound that closes most leaves without a suboptimality-test LP (cut_bound).
     double*  grad;
+    // path code of every node (root r: r; children: 2 code, 2 code + 1; modulo 2^32) -- kept by
+    // sharded runs of the persistent frontier kernel, which deal the nodes of one tree depth over
+    // the ranks by it (code % world: the last turns of the path, so the descendants of one
+    // ancestor spread over all ranks).  Null otherwise.
+    uint32_t* code;
 };
 
 // Upper bound of the suboptimality-test optimum t* from the tangent planes of the convex optimal

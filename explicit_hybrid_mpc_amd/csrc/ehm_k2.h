@@ -12,7 +12,7 @@
 #define EHM_K2_THREADS 768
 #endif
 
-#define K2_AUG_MIN 16
+#define K2_AUG_MIN 24
 // Near-threshold routing (hard part 1): a node's close / split decision may be
 // taken by a shortcut -- sign-only stop of the suboptimality-test LP, tangent-plane bound,
 // midpoint witness, inherited negative verdict -- only when it establishes |t*| >= this
@@ -62,6 +62,18 @@ struct PersistCtl {
     int pad4;
     unsigned long long closed;      // closed leaves      } accumulated per wavefront,
     unsigned long long splits;      // expanded nodes     } added once when it leaves
+    // sharded launches: the part above the deal depth, grown identically on every rank
+    unsigned long long repl_closed, repl_splits, repl_solves;
+};
+
+// Sharding of ONE persistent launch over the ranks of a multi-GPU run: every rank starts from
+// the roots and grows the tree above `depth` identically (replicated, a few thousand nodes);
+// a node created AT that depth is pursued by rank (path code % world) only -- the others flag
+// it "owned by another rank" (bit2) and do not queue it.  world <= 1: no dealing.
+struct PersistDeal {
+    int depth, rank, world;
+    int mix;        // 1 (default) = multiplicative hash of the path code; 0 = its low bits, i.e.
+                    // the last turns of the path (measured: 12 % imbalance at 8 ranks against 5 %)
 };
 
 // Optional indirection of the batched oracle kernels: the hybrid partition engine
@@ -109,7 +121,8 @@ struct K2Api {
     void (*selftest)(hipStream_t, double* out);
     // persistent frontier kernel (ehm_k2.hip: k2_persist); null where not compiled (wide)
     void (*persist)(const K2Launch&, DevProblem, DevTree, int32_t* slots, int n_slots,
-                    PersistCtl* ctl, int node_cap, DevCounters*, int sign_only, int max_depth);
+                    PersistCtl* ctl, int node_cap, DevCounters*, int sign_only, int max_depth,
+                    PersistDeal);
 };
 
 // The persistent frontier kernel compiled at two solver widths (ehm_kp.hip).
@@ -119,7 +132,8 @@ struct KpApi {
     size_t (*wave_doubles)(const DevProblem& P, int n_lp_decide, int ne_decide, int n_lp_expand);
     size_t (*shared_doubles)(const DevProblem& P);
     void (*persist)(const K2Launch&, DevProblem, DevTree, int32_t* slots, int n_slots,
-                    PersistCtl* ctl, int node_cap, DevCounters*, int sign_only, int max_depth);
+                    PersistCtl* ctl, int node_cap, DevCounters*, int sign_only, int max_depth,
+                    PersistDeal);
 };
 
 }  // namespace ehm

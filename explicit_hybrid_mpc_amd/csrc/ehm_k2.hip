@@ -353,7 +353,7 @@ __global__ __launch_bounds__(EHM_K2_THREADS) void k2_lcss_expand(
 #endif
 __global__ __launch_bounds__(EHM_K2_THREADS) void k2_persist(
     DevProblem P, DevTree T, int32_t* slots, int n_slots, PersistCtl* ctl, int node_cap,
-    DevCounters* cnt, int wave_doubles, int sign_only, int max_depth) {
+    DevCounters* cnt, int wave_doubles, int sign_only, int max_depth, PersistDeal deal) {
     K2_PROLOGUE();
     const int p = P.p, n_u = P.n_u;
     const int nrec = rec_doubles(p, n_u);
@@ -364,10 +364,10 @@ __global__ __launch_bounds__(EHM_K2_THREADS) void k2_persist(
     // added to the global counters ONCE, when it leaves -- the level-synchronous kernels pay ~8
     // device atomics per node for them
     unsigned long long* wst = reinterpret_cast<unsigned long long*>(nb.aug);
-    double* wmargin = nb.aug + 13;
+    double* wmargin = nb.aug + 16;
     enum { W_SOLVES = 0, W_ITERS, W_STALLED, W_ERRORS, W_SLACK, W_SLACK_ITERS, W_CLOSED, W_SPLITS,
-           W_DEPTH, W_TRUNC, W_CERT, W_WIT, W_ROUTED };
-    if (lane0 < 13) wst[lane0] = 0ULL;
+           W_DEPTH, W_TRUNC, W_CERT, W_WIT, W_ROUTED, W_RCLOSED, W_RSPLITS, W_RSOLVES };
+    if (lane0 < 16) wst[lane0] = 0ULL;
     if (lane0 == 0) *wmargin = 1e300;
     wsync();
     for (;;) {
@@ -410,6 +410,7 @@ __global__ __launch_bounds__(EHM_K2_THREADS) void k2_persist(
                     const int dep0 = T.depth[id];
                     wst[W_CERT] += 1;
                     wst[W_CLOSED] += 1;
+                    if (dep0 < deal.depth) wst[W_RCLOSED] += 1;
                     *wmargin = fmin(*wmargin, -bnd);
                     if ((unsigned long long)dep0 > wst[W_DEPTH]) wst[W_DEPTH] = (unsigned long long)dep0;
                     T.tstar[id] = bnd;
@@ -503,6 +504,7 @@ __global__ __launch_bounds__(EHM_K2_THREADS) void k2_persist(
             const int slack_status = r.status;
             if (lane == 0) {
                 wst[W_SOLVES] += 1;
+                if (dep < deal.depth) wst[W_RSOLVES] += 1;
                 wst[W_ITERS] += (unsigned long long)its;
                 wst[W_SLACK] += 1;
                 wst[W_SLACK_ITERS] += (unsigned long long)its;
@@ -516,6 +518,7 @@ __global__ __launch_bounds__(EHM_K2_THREADS) void k2_persist(
         if (lane == 0) {
             if (can_split) {        // the midpoint solve was done, whatever became of the node
                 wst[W_SOLVES] += 1;
+                if (dep < deal.depth) wst[W_RSOLVES] += 1;
                 wst[W_ITERS] += (unsigned long long)mid_iters;
                 if (mid_status != 0 && open) {
                     wst[W_STALLED] += 1;
@@ -530,6 +533,7 @@ __global__ __launch_bounds__(EHM_K2_THREADS) void k2_persist(
             if (!open) {
                 T.flags[id] |= 1;
                 wst[W_CLOSED] += 1;
+                if (dep < deal.depth) wst[W_RCLOSED] += 1;
             }
         }
         if (!open) {
@@ -570,7 +574,10 @@ __global__ __launch_bounds__(EHM_K2_THREADS) void k2_persist(
                 __hip_atomic_store(g0 + ng + k, a1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             }
         }
-        if (lane == 0) wst[W_SPLITS] += 1;
+        if (lane == 0) {
+            wst[W_SPLITS] += 1;
+            if (dep < deal.depth) wst[W_RSPLITS] += 1;
+        }
         const double* xmid = stash;
 #else
         Wave W;
@@ -591,6 +598,7 @@ __global__ __launch_bounds__(EHM_K2_THREADS) void k2_persist(
         const int dep = T.depth[id];
         if (lane == 0) {
             wst[W_SOLVES] += 1;
+            if (dep < deal.depth) wst[W_RSOLVES] += 1;
             wst[W_ITERS] += (unsigned long long)r.iters;
             wst[W_SLACK] += 1;
             wst[W_SLACK_ITERS] += (unsigned long long)r.iters;
@@ -606,6 +614,7 @@ __global__ __launch_bounds__(EHM_K2_THREADS) void k2_persist(
             if (!open) {
                 T.flags[id] |= 1;
                 wst[W_CLOSED] += 1;
+                if (dep < deal.depth) wst[W_RCLOSED] += 1;
             }
         }
         if (!open) {
@@ -670,6 +679,10 @@ __global__ __launch_bounds__(EHM_K2_THREADS) void k2_persist(
             wst[W_SOLVES] += 1;
             wst[W_ITERS] += (unsigned long long)r.iters;
             wst[W_SPLITS] += 1;
+            if (dep < deal.depth) {
+                wst[W_RSOLVES] += 1;
+                wst[W_RSPLITS] += 1;
+            }
             if (r.status != 0) {
                 wst[W_STALLED] += 1;
                 wst[W_ERRORS] += 1;
@@ -702,17 +715,31 @@ __global__ __launch_bounds__(EHM_K2_THREADS) void k2_persist(
             __hip_atomic_store(rec0 + k, v0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             __hip_atomic_store(rec1 + k, v1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         }
+        // sharded launch: the children created at the deal depth go to rank (path code % world)
+        int own0 = 1, own1 = 1;
         if (lane == 0) {
             T.left[id] = c0;
 #define EHM_WT(ptr, val) __hip_atomic_store((ptr), (val), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)
+            if (T.code) {
+                const uint32_t pc = T.code[id];
+                const uint32_t code0 = 2u * pc, code1 = 2u * pc + 1u;
+                EHM_WT(&T.code[c0], code0);
+                EHM_WT(&T.code[c0 + 1], code1);
+                if (deal.world > 1 && dep + 1 == deal.depth) {
+                    const uint32_t h0 = deal.mix ? ((code0 * 2654435761u) >> 12) : code0;
+                    const uint32_t h1 = deal.mix ? ((code1 * 2654435761u) >> 12) : code1;
+                    own0 = (int)(h0 % (uint32_t)deal.world) == deal.rank;
+                    own1 = (int)(h1 % (uint32_t)deal.world) == deal.rank;
+                }
+            }
             EHM_WT(&T.left[c0], -1);
             EHM_WT(&T.left[c0 + 1], -1);
             EHM_WT(&T.didx[c0], d);
             EHM_WT(&T.didx[c0 + 1], d);
             EHM_WT(&T.depth[c0], dep + 1);
             EHM_WT(&T.depth[c0 + 1], dep + 1);
-            EHM_WT(&T.flags[c0], (uint8_t)2);
-            EHM_WT(&T.flags[c0 + 1], (uint8_t)2);
+            EHM_WT(&T.flags[c0], (uint8_t)(own0 ? 2 : 6));
+            EHM_WT(&T.flags[c0 + 1], (uint8_t)(own1 ? 2 : 6));
             EHM_WT(&T.tstar[c0], 0.0);
             EHM_WT(&T.tstar[c0 + 1], 0.0);
 #undef EHM_WT
@@ -721,12 +748,16 @@ __global__ __launch_bounds__(EHM_K2_THREADS) void k2_persist(
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
         __builtin_amdgcn_s_waitcnt(0);
         if (lane == 0) {
-            const int t = atomicAdd(&ctl->tail, 2);
-            if (t + 2 <= n_slots) {
-                __hip_atomic_store(&slots[t], c0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                __hip_atomic_store(&slots[t + 1], c0 + 1, __ATOMIC_RELAXED,
-                                   __HIP_MEMORY_SCOPE_AGENT);
-                atomicAdd(&ctl->pending, 1);       // -1 (this node) + 2 (its children)
+            const int nown = own0 + own1;
+            const int t = nown ? atomicAdd(&ctl->tail, nown) : 0;
+            if (t + nown <= n_slots) {
+                int at = t;
+                if (own0)
+                    __hip_atomic_store(&slots[at++], c0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                if (own1)
+                    __hip_atomic_store(&slots[at], c0 + 1, __ATOMIC_RELAXED,
+                                       __HIP_MEMORY_SCOPE_AGENT);
+                atomicAdd(&ctl->pending, nown - 1);    // -1 (this node) + its queued children
             } else {
                 atomicMax(&ctl->abort, 1);
                 atomicSub(&ctl->pending, 1);
@@ -748,6 +779,9 @@ __global__ __launch_bounds__(EHM_K2_THREADS) void k2_persist(
         if (wst[W_ROUTED]) atomicAdd(&cnt->routed, wst[W_ROUTED]);
         atomicAdd(&ctl->closed, wst[W_CLOSED]);
         atomicAdd(&ctl->splits, wst[W_SPLITS]);
+        if (wst[W_RCLOSED]) atomicAdd(&ctl->repl_closed, wst[W_RCLOSED]);
+        if (wst[W_RSPLITS]) atomicAdd(&ctl->repl_splits, wst[W_RSPLITS]);
+        if (wst[W_RSOLVES]) atomicAdd(&ctl->repl_solves, wst[W_RSOLVES]);
         atomicMax(&ctl->max_depth_seen, (int)wst[W_DEPTH]);
         if (wst[W_TRUNC]) atomicMax(&ctl->truncated, 1);
     }
@@ -865,9 +899,11 @@ void l_vertex(const K2Launch& L, DevProblem P, DevTree T, const int32_t* nodes, 
                        T, nodes, n_nodes, cnt, L.wave_doubles);
 }
 void l_persist(const K2Launch& L, DevProblem P, DevTree T, int32_t* slots, int n_slots,
-               PersistCtl* ctl, int node_cap, DevCounters* cnt, int sign_only, int max_depth) {
+               PersistCtl* ctl, int node_cap, DevCounters* cnt, int sign_only, int max_depth,
+               PersistDeal deal) {
     hipLaunchKernelGGL(k2_persist, dim3(L.grid), dim3(L.threads), L.lds_bytes, L.stream, P, T,
-                       slots, n_slots, ctl, node_cap, cnt, L.wave_doubles, sign_only, max_depth);
+                       slots, n_slots, ctl, node_cap, cnt, L.wave_doubles, sign_only, max_depth,
+                       deal);
 }
 void l_selftest(hipStream_t stream, double* out) {
     hipLaunchKernelGGL(k2_selftest, dim3(1), dim3(64), 0, stream, out);

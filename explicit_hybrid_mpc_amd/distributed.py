@@ -46,6 +46,19 @@ def shard_spec(rank, world, min_frontier=2048):
     return None if world <= 1 else (int(rank), int(world), int(min_frontier))
 
 
+def deal_depth_for(n_roots, world, per_rank=2048):
+    """
+    Tree depth at which a sharded persistent launch deals its nodes (ehm_run_opts.deal_depth):
+    the first depth that can hold ``per_rank`` nodes per rank (n_roots * 2^depth >= per_rank *
+    world) -- at 2048 per rank the shares of the bench tree balance to 2.4 % at 8 ranks
+    (profiles/r2/shard_balance_deal_*.txt).
+    """
+    import math
+    if world <= 1:
+        return 0
+    return max(1, int(math.ceil(math.log2(max(1., per_rank * world / float(n_roots))))))
+
+
 def owner_of(position, world):
     """Rank that keeps frontier position ``position`` (the rule of k_shard_filter)."""
     return position % world

@@ -267,7 +267,8 @@ class GpuProblem:
 
     # -- partition ------------------------------------------------------------------------------
     def partition(self, roots, action='ecc', init=None, max_nodes=0, max_depth=0, engine=1,
-                  export=True, shard=None, with_volume=True, status=None, status_sweeps=1):
+                  export=True, shard=None, with_volume=True, status=None, status_sweeps=1,
+                  deal_depth=0):
         """
         Grow every root simplex until all leaves are epsilon-suboptimal.
         engine: 1 (default) = one launch of the persistent frontier kernel where it applies (a
@@ -277,8 +278,10 @@ class GpuProblem:
         wide kernels always sweep.
         roots: (n_roots, p+1, p).  init: optional dict(delta, vertex_costs, vertex_inputs)
         for action 'lcss'.  shard = (rank, world, min_frontier) keeps only this rank's share
-        of the frontier once it is min_frontier wide (multi-GPU).  Returns a FlatTree, or
-        just the info dict when export is False.
+        of the frontier once it is min_frontier wide (multi-GPU); with deal_depth > 0 the
+        whole run is instead ONE persistent launch per rank from the roots, dealt at that tree
+        depth by the nodes' path codes (include/ehmpc.h, ehm_run_opts.deal_depth).  Returns a
+        FlatTree, or just the info dict when export is False.
         status: optional ``status.MainStatusPublisher``; the run is then advanced
         ``status_sweeps`` frontier sweeps at a time and the publisher is fed the device's
         progress counters in between (status.txt / statistics.pkl of the reference).
@@ -305,7 +308,7 @@ class GpuProblem:
                              action=0 if action == 'ecc' else 1, engine=int(engine),
                              shard_rank=int(rank), shard_world=int(world),
                              shard_min_frontier=int(min_frontier),
-                             skip_volume=0 if with_volume else 1)
+                             skip_volume=0 if with_volume else 1, deal_depth=int(deal_depth))
         init_struct = None
         keep = None
         if init is not None:

@@ -222,6 +222,13 @@ typedef struct ehm_run_opts {
     int32_t shard_world;
     int32_t skip_volume;    /* 1 = do not compute volume_closed in ehm_tree_info_get       */
     int64_t shard_min_frontier;
+    /* > 0 (with shard_world > 1, engine 1): the whole run is ONE launch of the persistent
+     * frontier kernel on every rank, from the roots; the tree above this depth is grown
+     * identically everywhere (replicated), a node created AT this depth is pursued by rank
+     * (path code % shard_world) only -- no sweeps, no host round trip, no collective.
+     * 0 = deal the frontier of a sweep (shard_min_frontier), then one launch per share. */
+    int32_t deal_depth;
+    int32_t reserved0;
 } ehm_run_opts;
 
 /* Optional initial node data for action 1 ('lcss' roots already carry a commutation,

@@ -169,6 +169,45 @@ def test_alg_call_grows_tree_in_place_and_pickles(tmp_path):
     oracle.close()
 
 
+def test_dealt_persistent_launches_cover_the_unsharded_tree():
+    """
+    ehm_run_opts.deal_depth: one persistent launch per rank from the roots, dealt at a tree depth
+    by the nodes' path codes.  The shares of 3 ranks (run one after the other here) tile the tree.
+    """
+    from explicit_hybrid_mpc_amd import engine, distributed
+    mpc = helpers.make_instance('lin', 0)
+    eps_a = helpers.eps_a_rule(mpc, 0.25)
+    roots, locs = helpers.roots_of(mpc)
+    gp = engine.GpuProblem(mpc.compile(), eps_a, 0.05)
+    full = gp.partition(np.array(roots))
+    world = 3
+    depth = distributed.deal_depth_for(len(roots), world, per_rank=32)
+    parts = [gp.partition(np.array(roots), shard=(r, world, 0), deal_depth=depth)
+             for r in range(world)]
+    gp.close()
+    full_loc = full.locations(locs)
+    full_leaves = {full_loc[k] for k in range(full.n_nodes) if full.is_leaf(k)}
+    got = set()
+    for part in parts:
+        assert part.info['decide_launches'] == 1            # no sweeps at all
+        loc = part.locations(locs)
+        mine = {loc[k] for k in range(part.n_nodes)
+                if part.is_leaf(k) and not (part.flags[k] & 4)}
+        # the replicated top's closed leaves appear in every share; everything else once
+        shared = {name for name in mine & got}
+        assert all(len(name) - len(locs[0]) <= depth + 40 for name in shared)
+        got |= mine
+        remote = [k for k in range(part.n_nodes) if part.flags[k] & 4]
+        assert remote and all(part.is_leaf(k) for k in remote)
+    assert got == full_leaves
+    own_closed = [p_.info['n_closed'] - (p_.info['replicated_closed'] if r else 0)
+                  for r, p_ in enumerate(parts)]
+    assert sum(own_closed) == full.info['n_closed']
+    own_nodes = [p_.info['n_nodes'] - (p_.info['replicated_nodes'] if r else 0)
+                 for r, p_ in enumerate(parts)]
+    assert sum(own_nodes) == full.n_nodes
+
+
 def test_sharded_runs_cover_the_unsharded_tree():
     """Two ranks' shares (run one after the other on this GPU) tile the full tree."""
     from explicit_hybrid_mpc_amd import engine

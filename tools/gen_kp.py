@@ -181,9 +181,11 @@ size_t wave_doubles_for(const DevProblem& P, int n_lp_d, int ne_d, int n_lp_e) {
 }
 size_t shared_doubles_for(const DevProblem& P) { return kd::shared_doubles(P); }
 void l_persist(const K2Launch& L, DevProblem P, DevTree T, int32_t* slots, int n_slots,
-               PersistCtl* ctl, int node_cap, DevCounters* cnt, int sign_only, int max_depth) {
+               PersistCtl* ctl, int node_cap, DevCounters* cnt, int sign_only, int max_depth,
+               PersistDeal deal) {
     hipLaunchKernelGGL(kp_persist, dim3(L.grid), dim3(L.threads), L.lds_bytes, L.stream, P, T,
-                       slots, n_slots, ctl, node_cap, cnt, L.wave_doubles, sign_only, max_depth);
+                       slots, n_slots, ctl, node_cap, cnt, L.wave_doubles, sign_only, max_depth,
+                       deal);
 }
 
 const KpApi g_api = {EHM_NPD, EHM_NPE, EHM_SLOTS, EHM_K2_THREADS, set_lds, wave_doubles_for,

@@ -1,28 +1,43 @@
-"""Static dealing of the frontier over `world` ranks: per-rank work, measured on ONE GPU by running
-the shards one after the other (engine 0 so that the deal happens inside the sweeps)."""
+"""Static dealing over `world` ranks, measured on ONE GPU by running the shards one after the
+other: per-rank work and time, speed-up = full run / slowest shard.
+  mode "deal": one persistent launch per rank from the roots, dealt at a tree depth by path code
+  (ehm_run_opts.deal_depth -- what bench.py --gpus N runs);
+  mode "sweeps": the round-1 scheme (sweeps until the frontier holds min_frontier nodes, deal by
+  position, then one persistent launch per share).
+usage: shard_balance.py [deal|sweeps] [abs_frac]"""
 import sys, time
 import numpy as np
-from explicit_hybrid_mpc_amd import engine, examples
+from explicit_hybrid_mpc_amd import engine, examples, distributed
 from explicit_hybrid_mpc_amd import tools as ehm_tools
 
+mode = sys.argv[1] if len(sys.argv) > 1 else 'deal'
+abs_frac = float(sys.argv[2]) if len(sys.argv) > 2 else 0.02
 mpc = examples.linear_mpc(0)
 gp = engine.GpuProblem(mpc.compile(), 1., 1.)
 V = examples.box_vertices(examples.theta_box(mpc))
-gp.set_eps(float(np.max(gp.solve_pt(0.02 * V)[0])), 0.01)
+gp.set_eps(float(np.max(gp.solve_pt(abs_frac * V)[0])), 0.01)
 roots, _ = ehm_tools.delaunay_roots(V)
-full = gp.partition(roots, export=False, with_volume=False, max_nodes=1 << 22)
-print('full', full['lp_solves'], 'ms', 1e3 * full['device_seconds'], flush=True)
+cap = 1 << 24
+gp.partition(roots, export=False, with_volume=False, max_nodes=cap)
+full = gp.partition(roots, export=False, with_volume=False, max_nodes=cap)
+print('full: nodes', full['n_nodes'], 'LPs', full['lp_solves'], 'ms', 1e3 * full['device_seconds'], flush=True)
 for world in (2, 4, 8):
-    for mf in (64 * world, 1024 * world, 8192 * world):
-        lp, ms, rep = [], [], 0
+    variants = ([('depth %d' % (distributed.deal_depth_for(len(roots), world, pr)),
+                  dict(deal_depth=distributed.deal_depth_for(len(roots), world, pr),
+                       shard=(None, world, 0))) for pr in (128, 1024, 2048, 4096)]
+                if mode == 'deal' else
+                [('min_frontier %d' % mf, dict(shard=(None, world, mf))) for mf in (64 * world, 1024 * world)])
+    for label, kw in variants:
+        lp, ms, rep, nodes = [], [], 0, 0
         for r in range(world):
-            t0 = time.perf_counter()
-            info = gp.partition(roots, export=False, with_volume=False, max_nodes=1 << 22,
-                                shard=(r, world, mf), engine=int(sys.argv[1]) if len(sys.argv) > 1 else 0)
-            ms.append(1e3 * (time.perf_counter() - t0))
+            kw2 = dict(kw)
+            kw2['shard'] = (r, world, kw['shard'][2])
+            info = gp.partition(roots, export=False, with_volume=False, max_nodes=cap, engine=1, **kw2)
+            ms.append(1e3 * info['device_seconds'])
             lp.append(info['lp_solves'] - info['replicated_solves'])
             rep = info['replicated_solves']
+            nodes += info['n_nodes'] - (info['replicated_nodes'] if r else 0)
         lp = np.array(lp, dtype=float)
-        print('world %d min_frontier %6d: replicated %7d  per-rank LPs max/mean %.3f  time max %.1f ms mean %.1f ms  speedup vs full %.2f'
-              % (world, mf, rep, lp.max() / lp.mean(), max(ms), np.mean(ms), 1e3 * full['device_seconds'] / max(ms)), flush=True)
+        print('world %d %-18s: nodes %d replicated LPs %7d  per-rank LPs max/mean %.3f  time max %.1f ms mean %.1f ms  speedup vs full %.2f'
+              % (world, label, nodes, rep, lp.max() / lp.mean(), max(ms), np.mean(ms), 1e3 * full['device_seconds'] / max(ms)), flush=True)
 gp.close()
