@@ -324,13 +324,34 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
-    for _ in range(args.warmup):
-        step()
+    # a rank whose engine raises (pool exhausted, numeric error) still reaches every barrier; the
+    # ranks then agree on the failure and leave together instead of hanging in a collective
+    failure = None
+    try:
+        for _ in range(args.warmup):
+            step()
+    except Exception as e:
+        failure = e
     barrier()
     t0 = time.perf_counter()
-    infos = [step() for _ in range(args.steps)]
+    infos = []
+    try:
+        if failure is None:
+            infos = [step() for _ in range(args.steps)]
+    except Exception as e:
+        failure = e
     barrier()
     elapsed = time.perf_counter() - t0
+    _, any_failed = distributed.allreduce_counters(
+        [0. if failure is None else 1.],
+        device=('cuda:%d' % device_index) if backend == 'nccl' else 'cpu')
+    if any_failed[0] > 0:
+        sys.stderr.write('bench.py rank %d: %s\n' % (
+            rank, failure if failure is not None else 'another rank failed'))
+        gp.close()
+        if world > 1:
+            dist.destroy_process_group()
+        raise SystemExit(1)
     # what the caller gets back: one more partition WITH the flat export (device -> host copy of
     # every record + breadth-first relabelling), outside the timed region, reported next to it
     ms_export = None

@@ -2406,6 +2406,14 @@ int ehm_partition_give(ehm_tree* T, int64_t count, const double* records, const 
     return EHM_OK;
 }
 
+// Pool occupancy of a run in progress (no device work): nodes allocated, nodes the caller allowed.
+int ehm_partition_counts(const ehm_tree* T, int64_t* n_nodes, int64_t* max_nodes) {
+    if (!T || !T->run.active) return fail(EHM_E_INVALID, "no partition run in progress");
+    if (n_nodes) *n_nodes = T->run.n_nodes;
+    if (max_nodes) *max_nodes = T->limit;
+    return EHM_OK;
+}
+
 int ehm_partition_progress(ehm_tree* T, ehm_progress* out) {
     if (!T || !out) return fail(EHM_E_INVALID, "null argument");
     if (!T->run.active) return fail(EHM_E_INVALID, "no partition run in progress");
@@ -2439,6 +2447,10 @@ int ehm_partition_progress(ehm_tree* T, ehm_progress* out) {
         for (double v : part) vol += v;
     }
     out->n_nodes = own_nodes;
+    // every node that is neither a root nor received from another rank is one of two children
+    out->n_splits = (R.shard_world > 1 && R.shard_rank > 0)
+                        ? (R.sharded ? (n - R.pre_nodes - R.received) / 2 : 0)
+                        : (n - R.n_roots - R.received) / 2;
     out->n_closed = own_closed;
     out->frontier = R.nf;
     out->sweeps = R.sweeps;

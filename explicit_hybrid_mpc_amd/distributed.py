@@ -223,20 +223,60 @@ def run_balanced(gp, roots, action='ecc', init=None, max_nodes=0, min_frontier=1
         from . import status as _status
         worker = _status.WorkerStatus(algorithm=action)
         worker.update(active=True)
+
+    def fail_everywhere(err, who):
+        """Every rank leaves the loop together: nobody is left waiting in a collective."""
+        if worker is not None:
+            worker.update(active=False, failed=True)
+            if status is not None and rank == 0:
+                status.update([worker.data], num_tasks_in_queue=0, force=True)
+        if err is not None:
+            raise err
+        raise RuntimeError('partition run failed on rank(s) %s' % who)
+
     while True:
-        n = run.step(sweeps_per_round if (world > 1 or publish_status) else 0)
-        if publish_status:
-            if n == 0:
-                worker.update(active=False)
-            _publish(status, worker, run, n, device, rank, force=(world == 1 and n == 0))
+        err = None
+        try:
+            n = run.step(sweeps_per_round if (world > 1 or publish_status) else 0)
+        except Exception as e:      # reported to the other ranks below, then re-raised
+            err, n = e, -1
         if world == 1:
+            if err is not None:
+                fail_everywhere(err, [0])
+            if publish_status:
+                if n == 0:
+                    worker.update(active=False)
+                _publish(status, worker, run, n, device, rank, force=(n == 0))
             if n == 0:
                 break
             continue
-        counts = allgather_counts([n], device=device)[:, 0]
+        # frontier size (-1 = this rank failed) and free pool of every rank: ONE small all-gather
+        free = run.free_nodes() if (err is None and hasattr(run, 'free_nodes')) else (1 << 62)
+        info = allgather_counts([n, free], device=device)
+        if (info[:, 0] < 0).any():
+            fail_everywhere(err, [int(r) for r in np.nonzero(info[:, 0] < 0)[0]])
+        if publish_status:
+            if n == 0:
+                worker.update(active=False)
+            _publish(status, worker, run, n, device, rank)
+        counts = info[:, 0]
         if counts.sum() == 0:
             break
-        _exchange(run, balance_plan(counts, tolerance, min_move), rank, device, rnd, log)
+        # a receiver is never sent more than its pool can take (every rank derives the same plan)
+        room = [int(v) for v in info[:, 1]]
+        plan = []
+        for donor, receiver, k in balance_plan(counts, tolerance, min_move):
+            k = min(k, max(0, room[receiver] - 2 * int(counts[receiver]) - 64))
+            if k >= min_move:
+                plan.append((donor, receiver, k))
+                room[receiver] -= k
+        try:
+            _exchange(run, plan, rank, device, rnd, log)
+        except Exception as e:
+            err = e
+        bad = allgather_counts([0 if err is None else 1], device=device)[:, 0]
+        if bad.any():
+            fail_everywhere(err, [int(r) for r in np.nonzero(bad)[0]])
         rnd += 1
     if publish_status and world > 1:
         _publish(status, worker, run, 0, device, rank, force=True)

@@ -408,6 +408,13 @@ class PartitionRun:
         return {name: getattr(pr, name) for name, _ in _capi.Progress._fields_
                 if name != 'reserved'}
 
+    def free_nodes(self):
+        """Node records this run may still allocate (ehm_partition_counts)."""
+        n, cap = ctypes.c_int64(0), ctypes.c_int64(0)
+        check(self._lib.ehm_partition_counts(self._tree, ctypes.addressof(n),
+                                             ctypes.addressof(cap)))
+        return int(cap.value - n.value)
+
     def take(self, count):
         """Hand over the last `count` frontier nodes: (node ids, records, meta)."""
         count = int(count)

@@ -110,8 +110,10 @@ class WorkerStatus:
         if self.volume_current:
             self.data['volume_filled_current'] = \
                 float(progress['volume_closed']) / self.volume_current
-        self.data['simplex_count_total'] = int(progress['n_nodes'])
-        self.data['simplex_count_current'] = int(progress['n_nodes'])
+        # the reference counts +1 per SPLIT (lib/worker.py:274,327,107-109), not per node
+        splits = int(progress.get('n_splits', 0))
+        self.data['simplex_count_total'] = splits
+        self.data['simplex_count_current'] = splits
         self.data['current_location'] = 'depth %d, frontier %d' % (progress['depth'],
                                                                    progress['frontier'])
         self.extra = dict(lp_solves=int(progress['lp_solves']),

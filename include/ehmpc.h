@@ -280,7 +280,14 @@ typedef struct ehm_progress {
     int32_t depth;
     int32_t reserved;
     double  volume_closed;  /* sum of the closed leaves' volumes                        */
+    int64_t n_splits;       /* splits performed by this rank: what the reference's status
+                               publisher counts (simplex_count += 1 per split,
+                               lib/worker.py:274,327,107-109)                           */
 } ehm_progress;
+/* Pool occupancy of a run in progress, without touching the device: nodes allocated so far and
+ * the capacity of this run (max_nodes).  The multi-GPU driver checks a receiver's free pool
+ * before it plans a transfer (explicit_hybrid_mpc_amd/distributed.py). */
+int ehm_partition_counts(const ehm_tree* tree, int64_t* n_nodes, int64_t* max_nodes);
 int ehm_partition_progress(ehm_tree* tree, ehm_progress* out);
 
 typedef struct ehm_tree_info {

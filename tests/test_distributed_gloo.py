@@ -282,3 +282,52 @@ def test_two_ranks_rebalance_and_merge(tmp_path):
         assert (merged.flags[k] & 1) == (full.flags[j] & 1)
         assert not (merged.flags[k] & 4)
         assert np.allclose(merged.vertex_costs[k], full.vertex_costs[j], rtol=1e-9, atol=1e-12)
+
+
+class _FailingRun(CpuRun):
+    """Rank 1's engine fails in its third round (the pool-exhausted / numeric error of a device)."""
+
+    def step(self, max_sweeps=0):
+        self.calls = getattr(self, 'calls', 0) + 1
+        if self.rank == 1 and self.calls == 3:
+            raise RuntimeError('libehmpc error -4: node pool exhausted (emulated)')
+        return super().step(max_sweeps)
+
+    def free_nodes(self):
+        return 1 << 20
+
+
+def _worker_failing(rank, world, port, out_dir):
+    os.environ.update(RANK=str(rank), LOCAL_RANK=str(rank), WORLD_SIZE=str(world),
+                      MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port))
+    import torch.distributed as dist
+    from explicit_hybrid_mpc_amd import distributed
+    distributed.init_process_group('gloo')
+    mpc = helpers.make_instance('di', 0)
+    roots, locs = helpers.roots_of(mpc)
+    try:
+        distributed.run_balanced(
+            None, roots, min_frontier=6, sweeps_per_round=1, tolerance=0., min_move=1,
+            run_factory=lambda shard: _FailingRun(mpc, 0.3, 0.02, roots, shard))
+        outcome = 'finished'
+    except RuntimeError as e:
+        outcome = 'raised: %s' % e
+    with open(os.path.join(out_dir, 'fail%d.txt' % rank), 'w') as f:
+        f.write(outcome)
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_a_failing_rank_stops_every_rank(tmp_path):
+    """
+    run_balanced all-gathers a status word next to the frontier size: when one rank's engine
+    raises, every rank leaves the loop with an error instead of waiting in a collective for ever.
+    """
+    s = socket.socket()
+    s.bind(('127.0.0.1', 0))
+    port = s.getsockname()[1]
+    s.close()
+    mp.spawn(_worker_failing, args=(2, port, str(tmp_path)), nprocs=2, join=True)
+    outs = [open(str(tmp_path / ('fail%d.txt' % r))).read() for r in range(2)]
+    assert outs[1].startswith('raised: libehmpc error -4')
+    assert outs[0].startswith('raised: partition run failed on rank(s) [1]')

@@ -84,8 +84,9 @@ def test_status_publisher_follows_the_run(tmp_path):
     frac = stats['volume_filled_frac']
     assert len(frac) >= 3 and all(b >= a for a, b in zip(frac, frac[1:]))
     assert abs(frac[-1] - 1.) < 1e-9
-    assert stats['simplex_count_total'][-1] == flat.n_nodes
+    n_splits = (flat.n_nodes - len(roots)) // 2     # the reference counts +1 per split
+    assert stats['simplex_count_total'][-1] == n_splits
     assert stats['num_proc_active'][-1] == 0 and max(stats['num_proc_active']) == 1
     text = open(st).read()
     assert 'volume filled (total [%]): 1.0000e+02' in text
-    assert 'simplex_count: %d' % flat.n_nodes in text
+    assert 'simplex_count: %d' % n_splits in text

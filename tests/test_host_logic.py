@@ -153,7 +153,9 @@ def test_status_files_have_the_reference_format(tmp_path):
     w.update(active=True)
     for k, (vol, nodes) in enumerate([(2., 100), (6., 400), (16., 900)]):
         clock.t += 2.
-        w.absorb(dict(volume_closed=vol, n_nodes=nodes, n_closed=nodes // 2, frontier=50 - 10 * k,
+        # n_splits is what the reference's publisher counts (+1 per split, lib/worker.py:274,327)
+        w.absorb(dict(volume_closed=vol, n_nodes=2 * nodes + 22, n_splits=nodes,
+                      n_closed=nodes // 2, frontier=50 - 10 * k,
                       depth=3 + k, sweeps=k + 1, lp_solves=10 * nodes, ipm_iters=90 * nodes))
         overall = pub.update([w.data, None], num_tasks_in_queue=50 - 10 * k)
         assert abs(overall['volume_filled_frac'] - vol / 16.) < 1e-15
