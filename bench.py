@@ -166,9 +166,21 @@ def cpu_baseline(workload, seed, eps_a, eps_r, seconds):
         jobs.append((workload, seed, eps_a, eps_r, {loc: top.nodes[loc] for loc, _ in mine},
                      mine, seconds))
     t1 = time.perf_counter()
-    with mp.get_context('spawn').Pool(n_proc) as pool:
-        # bounded: a worker that dies at start-up must not hang the bench
-        res = pool.map_async(_cpu_worker, jobs).get(timeout=3 * seconds + 120)
+    # one process per core means ONE thread per process: without this every numpy / SciPy import
+    # starts a BLAS pool as wide as the machine (256 x 256 threads on the GPU box)
+    saved = {k: os.environ.get(k) for k in ('OMP_NUM_THREADS', 'OPENBLAS_NUM_THREADS',
+                                            'MKL_NUM_THREADS')}
+    os.environ.update({k: '1' for k in saved})
+    try:
+        with mp.get_context('spawn').Pool(n_proc) as pool:
+            # bounded: a worker that dies at start-up must not hang the bench
+            res = pool.map_async(_cpu_worker, jobs).get(timeout=3 * seconds + 120)
+    finally:
+        for k, v in saved.items():
+            if v is None:
+                os.environ.pop(k, None)
+            else:
+                os.environ[k] = v
     wall = time.perf_counter() - t1
     solves = sum(r[0] for r in res)
     visits = sum(r[1] for r in res)
@@ -476,6 +488,7 @@ def main():
                 'mean_ipm_iterations': agg['ipm_iters'] / max(agg['lp_solves'], 1),
                 'sweeps': info0['sweeps'], 'tree_depth': info0['max_depth'],
                 'min_decision_margin': info0['min_margin'],
+                'near_threshold_decisions_per_step': info0['near_threshold'],
                 'kernels': 'wide (one workgroup per LP, MFMA normal matrix)' if wide else
                            'generation %d%s' % (args.solver, ' with the quadratic block' if quad
                                                 else ''),
