@@ -279,11 +279,10 @@ def main():
     gp.set_option('decide_full', 1 if args.decide_full else 0)
     if args.no_mid_first:
         gp.set_option('mid_first', 0)
-    static = args.balance == 'static' and not args.status_dir
+    hybrid = args.workload == 'config3'
+    static = (args.balance == 'static' or hybrid) and not args.status_dir
     persistent = (args.engine == 1 and (world == 1 or static) and args.solver == 2 and
                   not wide and not hybrid and not args.status_dir)
-    if hybrid and world > 1:
-        raise SystemExit('bench.py: --workload config3 runs on one GPU in this build')
     # (the persistent kernel exists at one solver width, k2_persist, and -- where a pair of
     # instances is compiled, as for this workload -- at two, kp_persist; the library picks)
     kname = 'k3_lcss_decide' if wide else 'k2_simplex_batch' if hybrid else (
@@ -305,7 +304,8 @@ def main():
         args.shard_min_frontier = (1024 if static else 64) * world
     shard = distributed.shard_spec(rank, world, args.shard_min_frontier)
     # static: ONE persistent launch per rank from the roots, dealt at a tree depth by path code
-    deal_depth = distributed.deal_depth_for(len(roots), world) if (static and world > 1) else 0
+    deal_depth = distributed.deal_depth_for(len(roots), world, 64 if hybrid else 2048) \
+        if ((static or hybrid) and world > 1) else 0
 
     xdev = ('cuda:%d' % device_index) if backend == 'nccl' else None
     publisher = None
@@ -319,7 +319,7 @@ def main():
     def step():
         if (world == 1 or static) and not args.status_dir:
             return gp.partition(roots, action='ecc', max_nodes=args.max_nodes, export=False,
-                                shard=None if hybrid else shard, with_volume=False,
+                                shard=shard, with_volume=False,
                                 engine=args.engine, max_depth=args.max_depth,
                                 deal_depth=deal_depth)
         info, log, rounds = distributed.run_balanced(

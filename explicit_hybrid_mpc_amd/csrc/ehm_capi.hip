@@ -1781,6 +1781,7 @@ int ehm_volume_batch(int device, int64_t n, int32_t p, const double* R, double* 
 }
 
 // ---- partition engine -------------------------------------------------------------------------
+static int read_counters(ehm_problem* P, DevCounters& c);
 #include "ehm_hybrid.h"
 
 int ehm_tree_destroy(ehm_tree* T) {
@@ -2016,9 +2017,6 @@ int ehm_partition_begin(ehm_problem* P, int64_t n_roots, const double* root_vert
     R.cur_is_a = true;
     if (P->dp.n_delta > 1) {
         // multi-commutation problems: the device engine of ehm_hybrid.h
-        if (R.shard_world > 1)
-            RUN_TRY(fail(EHM_E_INVALID, "sharded runs of multi-commutation problems are not "
-                                        "available in this build"));
         RUN_TRY(hy_begin(T, n_roots, init));
         P->active_run = T;
         *out = T;

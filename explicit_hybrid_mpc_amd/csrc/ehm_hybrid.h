@@ -43,6 +43,8 @@ struct HyCtr {
     int truncated;
     int max_depth_seen;
     int err_kind;           // numeric errors: 1 slack problem, 2 min over the simplex, 3 midpoint
+    int dealt;              // sharded runs: the deal depth has been reached (children dealt)
+    int pad2;
     unsigned long long closed, splits, swaps, slivers, blacklisted, ref_solves, fallbacks, routed;
     unsigned long long min_margin_bits;
 };
@@ -505,7 +507,7 @@ __global__ void hy_children(DevTree T, const int32_t* __restrict__ frontier, int
                             const hy_u64* __restrict__ midbits, hy_u64* __restrict__ vf,
                             hy_u64* __restrict__ cand, hy_u64* __restrict__ black,
                             hy_u64* __restrict__ neg, double* __restrict__ tneg,
-                            int32_t* __restrict__ next, HyCtr* ctr) {
+                            int32_t* __restrict__ next, HyCtr* ctr, PersistDeal deal) {
     const int s = blockIdx.x;
     if (s >= ctr->n_split) return;
     const int lane = threadIdx.x;
@@ -577,16 +579,35 @@ __global__ void hy_children(DevTree T, const int32_t* __restrict__ frontier, int
     if (lane == 0) {
         const int dep = T.depth[id] + 1;
         T.left[id] = c0;
-        for (int c = c0; c < c0 + 2; ++c) {
+        // sharded runs (PersistDeal, ehm_k2.h): the children created at the deal depth are kept by
+        // the rank a hash of their path code names, flagged "another rank's" (bit2) elsewhere
+        int own[2] = {1, 1};
+        if (T.code) {
+            const uint32_t pc = T.code[id];
+            for (int b = 0; b < 2; ++b) {
+                const uint32_t code = 2u * pc + (uint32_t)b;
+                T.code[c0 + b] = code;
+                if (deal.world > 1 && dep == deal.depth) {
+                    const uint32_t h = deal.mix ? ((code * 2654435761u) >> 12) : code;
+                    own[b] = (int)(h % (uint32_t)deal.world) == deal.rank;
+                    ctr->dealt = 1;
+                }
+            }
+        }
+        for (int b = 0; b < 2; ++b) {
+            const int c = c0 + b;
             T.left[c] = -1;
             T.didx[c] = sp_d[s];
             T.depth[c] = dep;
-            T.flags[c] = has_data ? 2 : 0;
+            T.flags[c] = (uint8_t)((has_data ? 2 : 0) | (own[b] ? 0 : 4));
             T.tstar[c] = 0.0;
         }
-        const int at = atomicAdd(has_data ? &ctr->next_lcss : &ctr->next_ecc, 2);
-        next[at] = c0;
-        next[at + 1] = c0 + 1;
+        const int nown = own[0] + own[1];
+        if (nown) {
+            int at = atomicAdd(has_data ? &ctr->next_lcss : &ctr->next_ecc, nown);
+            if (own[0]) next[at++] = c0;
+            if (own[1]) next[at] = c0 + 1;
+        }
     }
 }
 
@@ -684,6 +705,7 @@ struct HyState {
     std::vector<int> snap_kind;          // LP kind of that launch
     HyCtr h{};
     int fail_delta = -1;                 // test hook: vertex solves of this commutation "fail"
+    PersistDeal deal{0, 0, 1, 1};        // sharded runs: deal depth / rank / world
     void release() {
         DevBuf* all[] = {&vf, &cand, &black, &neg, &tneg, &fr_ecc[0], &fr_ecc[1], &fr_lcss[0], &fr_lcss[1],
                          &known1, &ask, &slk, &vall, &redo, &koff, &src, &dst, &dcomm, &dsel2, &cnt,
@@ -937,7 +959,7 @@ static int hy_split_stage(ehm_tree* T, const int32_t* fr, int ns, int has_data, 
                        H.Jm.as<double>(), H.um.as<double>(), H.mst.as<int32_t>(),
                        H.vJ.as<double>(), H.vu.as<double>(), H.midbits.as<hy_u64>(),
                        H.vf.as<hy_u64>(), H.cand.as<hy_u64>(), H.black.as<hy_u64>(),
-                       H.neg.as<hy_u64>(), H.tneg.as<double>(), next, ctr);
+                       H.neg.as<hy_u64>(), H.tneg.as<double>(), next, ctr, H.deal);
     P->launches += 3;
     return EHM_OK;
 }
@@ -1118,6 +1140,15 @@ static int hy_sweep(ehm_tree* T) {
     R.depth = H.h.max_depth_seen;
     R.nf = H.n_ecc + H.n_lcss;
     ++R.sweeps;
+    if (H.h.dealt && !R.sharded) {
+        // everything up to here was grown identically on every rank (level-synchronous sweeps)
+        DevCounters cs;
+        HY_TRY(read_counters(P, cs));
+        R.pre_closed = R.n_closed;
+        R.pre_nodes = R.n_nodes;
+        R.pre_solves = (long long)(cs.lp_solves - R.c0.lp_solves);
+        R.sharded = true;
+    }
     if (getenv("EHM_HY_TRACE"))
         fprintf(stderr, "[hybrid] sweep %d: nodes %d closed %llu splits %llu swaps %llu -> next ecc "
                         "%lld lcss %lld\n", R.sweeps, H.h.n_nodes, H.h.closed, H.h.splits,
@@ -1156,6 +1187,19 @@ static int hy_begin(ehm_tree* T, int64_t n_roots, const ehm_node_init* init) {
     h.min_margin_bits = 0x7FF0000000000000ULL;
     HIP_TRY(hipMemcpyAsync(H.ctr.ptr, &h, sizeof h, hipMemcpyHostToDevice, P->stream), EHM_E_HIP);
     HIP_TRY(hipStreamSynchronize(P->stream), EHM_E_HIP);      // didx / flags / h leave scope
+    T->dt.code = nullptr;
+    if (R.shard_world > 1) {
+        if (R.deal_depth <= 0)
+            return fail(EHM_E_INVALID, "sharded multi-commutation runs need ehm_run_opts.deal_depth");
+        H.deal = PersistDeal{R.deal_depth, R.shard_rank, R.shard_world, 1};
+        if ((rc = T->code.ensure((size_t)T->cap * 4))) return rc;
+        T->dt.code = T->code.as<uint32_t>();
+        std::vector<uint32_t> codes((size_t)n_roots);
+        for (int64_t k = 0; k < n_roots; ++k) codes[(size_t)k] = (uint32_t)k;
+        HIP_TRY(hipMemcpyAsync(T->dt.code, codes.data(), codes.size() * 4, hipMemcpyHostToDevice,
+                               P->stream), EHM_E_HIP);
+        HIP_TRY(hipStreamSynchronize(P->stream), EHM_E_HIP);
+    }
     hipLaunchKernelGGL(hy_node_init, HY_GRID(n_roots * nw), 0, P->stream, 0, (int)n_roots, nd, nw,
                        H.cand.as<hy_u64>(), H.black.as<hy_u64>(), H.neg.as<hy_u64>(),
                        H.tneg.as<double>());

@@ -209,3 +209,97 @@ def test_config3_subforests_identical_to_cpu_oracle():
                                    rtol=RTOL, atol=RTOL), name
                 costs += 1
     assert decided >= 3 * CONFIG3_PICKS and costs >= decided
+
+
+def test_sharded_hybrid_runs_tile_the_tree():
+    """ehm_run_opts.deal_depth on the multi-commutation engine: the shares of 2 ranks (run one
+    after the other) tile the unsharded tree."""
+    from explicit_hybrid_mpc_amd import engine
+    mpc = helpers.make_instance('pwa_small', 0)
+    eps_a = helpers.eps_a_rule(mpc, 0.25)
+    roots, locs = helpers.roots_of(mpc)
+    gp = engine.GpuProblem(mpc.compile(), eps_a, 0.2)
+    full = gp.partition(np.array(roots), action='ecc')
+    parts = [gp.partition(np.array(roots), action='ecc', shard=(r, 2, 0), deal_depth=3)
+             for r in range(2)]
+    gp.close()
+    lf = by_location(full, locs)
+    leaves = {name for name, k in lf.items() if full.is_leaf(k)}
+    got = set()
+    for part in parts:
+        lp = by_location(part, locs)
+        remote = [k for k in lp.values() if part.flags[k] & 4]
+        assert remote and all(part.is_leaf(k) for k in remote)
+        for name, k in lp.items():
+            kf = lf[name]
+            assert np.array_equal(part.vertices[k], full.vertices[kf]), name
+            if part.flags[k] & 4:
+                continue
+            assert part.is_leaf(k) == full.is_leaf(kf), name
+            assert (part.flags[k] & 3) == (full.flags[kf] & 3), name
+            assert part.delta_idx[k] == full.delta_idx[kf], name
+            if part.is_leaf(k):
+                got.add(name)
+    assert got == leaves
+    own = [p_.info['n_closed'] - (p_.info['replicated_closed'] if r else 0)
+           for r, p_ in enumerate(parts)]
+    assert sum(own) == full.info['n_closed']
+
+
+def test_hybrid_engine_on_the_wide_kernels():
+    """
+    256 commutations on LPs of 33..37 columns: the multi-commutation engine through the wide
+    (one workgroup per LP, MFMA normal matrix) kernels of ehm_k3.hip -- the kernel family of
+    BASELINE.json's configs[3] / configs[4].  Batched oracles and a sub-forest of a truncated
+    partition against the CPU oracle.
+    """
+    from explicit_hybrid_mpc_amd import engine, examples
+    from oracle.oracle_cpu import OracleCPU
+    from oracle.partition_cpu import PartitionCPU
+    mpc = examples.pwa_mpc(seed=0, N=8)
+    examples.THETA_SCALE.setdefault(mpc.name, 0.25)
+    can = mpc.compile()
+    assert can.n_delta == 256 and can.n + can.p + 1 > 32
+    gp = engine.GpuProblem(can, 1., 1.)
+    V = examples.box_vertices(examples.theta_box(mpc))
+    J = gp.solve_pt(0.5 * V)[0]
+    assert np.isfinite(J).all()
+    eps_a, eps_r = float(np.max(J)), 1.0
+    gp.set_eps(eps_a, eps_r)
+    orc = OracleCPU(mpc, eps_a, eps_r)
+    orc.memoize = True
+    # P_theta on the device = the CPU oracle's
+    th = 0.5 * V[[0, 5, 10]]
+    Jd, ud, dd = gp.solve_pt(th)
+    for k in range(3):
+        u, delta, Jc, _ = orc.P_theta(th[k])
+        assert abs(Jd[k] - Jc) <= RTOL * (1 + abs(Jc))
+        assert np.array_equal(can.deltas[dd[k]].astype(int), delta.astype(int))
+    roots, locs = helpers.roots_of(mpc)
+    flat = gp.partition(np.array(roots[:3]), action='ecc', max_depth=7, max_nodes=1 << 18)
+    gp.close()
+    assert flat.info['n_nodes'] > 3
+    loc = flat.locations(locs[:3])
+    pos = {name: k for k, name in enumerate(loc)}
+    cand = [k for k in range(flat.n_nodes) if (flat.flags[k] & 2) and not flat.is_leaf(k)]
+    assert cand
+    k = cand[len(cand) // 2]
+    root = dict(vertices=flat.vertices[k].copy(),
+                commutation=flat.deltas[flat.delta_idx[k]].copy(),
+                vertex_costs=flat.vertex_costs[k].copy(),
+                vertex_inputs=flat.vertex_inputs[k].copy(),
+                is_epsilon_suboptimal=False, leaf=True)
+    cpu = PartitionCPU(orc, max_nodes=2)
+    cpu.run([root], [loc[k]], 'lcss')
+    decided = 0
+    for name, ref in cpu.nodes.items():
+        kd = pos[name]
+        assert np.array_equal(flat.vertices[kd], ref['vertices']), name
+        if (not ref['leaf']) or ref['is_epsilon_suboptimal']:
+            assert flat.is_leaf(kd) == ref['leaf'], name
+            assert bool(flat.flags[kd] & 1) == ref['is_epsilon_suboptimal'], name
+            decided += 1
+        if np.array_equal(flat.deltas[flat.delta_idx[kd]].astype(int),
+                          ref['commutation'].astype(int)):
+            assert np.allclose(flat.vertex_costs[kd], ref['vertex_costs'], rtol=RTOL, atol=RTOL)
+    assert decided >= 1
