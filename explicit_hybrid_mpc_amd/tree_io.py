@@ -13,6 +13,7 @@ classes.  Deep Delaunay spines need a raised recursion limit for the pickle itse
 import contextlib
 import pickle
 import sys
+import threading
 
 from . import tree as _tree
 
@@ -34,14 +35,40 @@ def _as_reference_module():
             sys.modules['tree'] = saved_mod
 
 
-@contextlib.contextmanager
-def _deep_recursion(depth_hint):
-    old = sys.getrecursionlimit()
-    sys.setrecursionlimit(max(old, 10 * depth_hint + 1000))
-    try:
-        yield
-    finally:
-        sys.setrecursionlimit(old)
+# The pickle of a nested tree recurses once per level, and so does the Delaunay right spine
+# (34 573 levels for the 8-dimensional box).  A raised recursion limit alone lets the C stack
+# overflow (a segfault instead of RecursionError), so the (un)pickling runs in a thread whose
+# stack is sized for the depth; beyond MAX_DEPTH the call fails with a clear error.
+MAX_DEPTH = 200000
+_STACK_BYTES_PER_LEVEL = 2048      # measured: ~0.5 KB of C stack per pickled level, 4x margin
+_lock = threading.Lock()           # sys.modules['tree'] / the recursion limit are process-global
+
+
+def _run_deep(fn, depth_hint):
+    if depth_hint > MAX_DEPTH:
+        raise ValueError('tree depth %d exceeds the supported %d levels' % (depth_hint, MAX_DEPTH))
+    out = {}
+
+    def work():
+        try:
+            out['value'] = fn()
+        except BaseException as e:       # re-raised in the caller's thread
+            out['error'] = e
+    with _lock:
+        old_limit, old_stack = sys.getrecursionlimit(), threading.stack_size()
+        sys.setrecursionlimit(max(old_limit, 10 * depth_hint + 1000))
+        threading.stack_size(max(64 << 20, (10 * depth_hint + 1000) * _STACK_BYTES_PER_LEVEL))
+        try:
+            with _as_reference_module():
+                t = threading.Thread(target=work)
+                t.start()
+                t.join()
+        finally:
+            threading.stack_size(old_stack)
+            sys.setrecursionlimit(old_limit)
+    if 'error' in out:
+        raise out['error']
+    return out.get('value')
 
 
 def tree_depth(root):
@@ -56,14 +83,21 @@ def dump_reference(obj, path, depth_hint=None):
     if depth_hint is None:
         root = obj['branch_root'] if isinstance(obj, dict) else obj
         depth_hint = tree_depth(root)
-    with _as_reference_module(), _deep_recursion(depth_hint), open(path, 'wb') as f:
-        pickle.dump(obj, f)
+    def write():
+        with open(path, 'wb') as f:
+            pickle.dump(obj, f)
+    _run_deep(write, depth_hint)
 
 
-def load_reference(path, depth_hint=100000):
-    """Unpickle a file written by the reference (or by ``dump_reference``)."""
-    with _as_reference_module(), _deep_recursion(depth_hint), open(path, 'rb') as f:
-        return pickle.load(f)
+def load_reference(path, depth_hint=40000):
+    """
+    Unpickle a file written by the reference (or by ``dump_reference``).  ``depth_hint``: an
+    upper bound of the nesting depth (default: enough for the 8-dimensional Delaunay spine).
+    """
+    def read():
+        with open(path, 'rb') as f:
+            return pickle.load(f)
+    return _run_deep(read, depth_hint)
 
 
 def branch_task(branch_root, location, action):

@@ -184,3 +184,31 @@ def test_status_files_have_the_reference_format(tmp_path):
                                       'simplex_count_total', 'simplex_count_current',
                                       'time_active_total', 'time_active_current', 'time_idle',
                                       'time_ecc', 'time_lcss'}
+
+
+def test_deep_pickles_do_not_overflow_the_c_stack(tmp_path):
+    """
+    tree_io (un)pickles nested trees in a thread whose stack is sized for the depth: the
+    8-dimensional Delaunay spine is 34 573 levels deep, far beyond what a
+    raised recursion limit alone survives; a tree deeper than the hint raises RecursionError
+    instead of crashing the interpreter.
+    """
+    from explicit_hybrid_mpc_amd import tree_io
+    from explicit_hybrid_mpc_amd.tree import Tree, NodeData
+    depth = 35000
+    root = Tree(None)
+    node = root
+    for _ in range(depth):
+        node.grow(NodeData(vertices=np.zeros((3, 2))), None)
+        node = node.right
+    path = str(tmp_path / 'spine.pkl')
+    tree_io.dump_reference(root, path, depth_hint=depth + 1)
+    back = tree_io.load_reference(path)
+    n, node = 0, back
+    while not node.is_leaf():
+        node, n = node.right, n + 1
+    assert n == depth
+    with pytest.raises(RecursionError):      # a hint that is too small fails cleanly
+        tree_io.dump_reference(root, str(tmp_path / 'x.pkl'), depth_hint=50)
+    with pytest.raises(ValueError):
+        tree_io.load_reference(path, depth_hint=10 ** 7)
