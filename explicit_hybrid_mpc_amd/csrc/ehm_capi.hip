@@ -1831,8 +1831,7 @@ static int tree_alloc(ehm_tree* T, ehm_problem* P, long long cap) {
     if ((rc = T->tstar.ensure((size_t)cap * sizeof(double)))) return rc;
     // vertex gradients of the optimal cost (cutting-plane closure of leaves, ehm_dev.h): kept by
     // the shared-block kernels of a single-commutation handle (linear or quadratic cost)
-    const bool grads = P->solver_gen == 2 && !P->dp.Wr3 && P->dp.n_delta == 1 &&
-                       !getenv("EHM_NO_CUTS");
+    const bool grads = P->solver_gen == 2 && P->dp.n_delta == 1 && !getenv("EHM_NO_CUTS");
     if (grads && (rc = T->grad.ensure((size_t)cap * (p + 1) * p * sizeof(double)))) return rc;
     T->dt.grad = grads ? T->grad.as<double>() : nullptr;
     T->prob = P;

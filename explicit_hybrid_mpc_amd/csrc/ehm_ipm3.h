@@ -696,8 +696,12 @@ __device__ __forceinline__ void lu_solve(const Lp& L, double rinv, double rhs, i
 // tid + 256 * slot; MPC rows first, extras at m ..).  On exit L.xb holds the best iterate.
 // Every thread returns the same result.
 // ---------------------------------------------------------------------------------------
+// gout (optional, LDS, L.p doubles; point problems): gradient of the optimal value with respect
+// to the parameter, -S^T lambda = sum_i lambda_i Wcm[n+q][i]; NaN unless the solve converged to
+// the tolerances (as in ehm_ipm2.h).
 __device__ __forceinline__ IpmResult ipm_solve(const Lp& L, Block& B, const double (&b)[RS],
-                                      bool sign_only, double step_frac) {
+                                      bool sign_only, double step_frac,
+                                      double* gout = nullptr) {
     int tid = pin(B.tid), lane = tid & 63;
     const int wave = B.wave;
     const int m = L.m, m_lp = L.m_lp;
@@ -948,6 +952,34 @@ __device__ __forceinline__ IpmResult ipm_solve(const Lp& L, Block& B, const doub
         atomicAdd(&g_prof3[17], (unsigned long long)wall_clock64() - prof_w0);
     }
 #endif
+    if (gout) {
+        // lam is the multiplier of the LAST iterate = the returned one when the loop left
+        // through the convergence test
+        const bool conv = (res.status == 0) && (res.merit <= 1.0);
+        for (int q0 = 0; q0 < L.p; q0 += 4) {
+            double mx2[2] = {0.0, 0.0}, sm4[4] = {0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+            for (int c = 0; c < 4; ++c) {
+                if (q0 + c < L.p) {
+                    const double* col = L.Wcm + (size_t)(L.n + q0 + c) * L.ldc;
+                    double a = 0.0;
+#pragma unroll
+                    for (int sl = 0; sl < RS; ++sl) {
+                        const int i = tid + NT * sl;
+                        if (i < m) a = fma(col[i], lam[sl], a);
+                    }
+                    sm4[c] = a;
+                }
+            }
+            block_reduce(B, mx2, sm4);
+            if (tid == 0) {
+#pragma unroll
+                for (int c = 0; c < 4; ++c)
+                    if (q0 + c < L.p) gout[q0 + c] = conv ? sm4[c] : __builtin_nan("");
+            }
+        }
+        __syncthreads();
+    }
     if (res.status != 0 && res.merit <= EHM3_ACCEPT_MERIT) res.status = 0;
     res.margin = fabs(res.obj);
     return res;

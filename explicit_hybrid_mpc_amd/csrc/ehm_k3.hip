@@ -17,14 +17,17 @@ namespace EHM3_NS {
 struct NodeBuf {
     double* rec;    // node record / simplex vertices (+ vertex costs)
     double* th;     // p doubles (parameter / midpoint)
+    double* g;      // p doubles: gradient of the optimal cost from a point solve
 };
 __device__ __forceinline__ void carve_node(NodeBuf& nb, double* base, int p, int n_u) {
     const int nrec = (rec_doubles(p, n_u) + 7) & ~7;
     nb.rec = base;
     nb.th = base + nrec;
+    nb.g = nb.th + 8 + 64;
 }
 __host__ __device__ inline size_t node_doubles(int p, int n_u) {
-    return (size_t)((rec_doubles(p, n_u) + 7) & ~7) + 8 + 64;   // + reduction scratch
+    // + parameter + reduction scratch + gradient
+    return (size_t)((rec_doubles(p, n_u) + 7) & ~7) + 8 + 64 + 8;
 }
 
 // P_theta_delta at one parameter value (lib/oracle.py:141-173) or its phase-one form
@@ -261,6 +264,30 @@ EHM3_KERNEL void k3_lcss_decide(
         const double* rec = T.rec + (size_t)id * T.rec_stride;
         for (int k = tid; k < nrec; k += NT) nb.rec[k] = rec[k];
         __syncthreads();
+        if (T.grad && sign_only) {
+            // tangent-plane bound of t* (ehm_dev.h, cut_bound), evaluated
+            // by the first wavefront in the LP workspace that is still free: negative => closed
+            if (B.wave == 0) {
+                const double bnd0 = cut_bound(nb.rec, T.grad + (size_t)id * (P.p + 1) * P.p, P.p,
+                                              P.eps_a, P.eps_r, B.lane, L.M);
+                if (B.lane == 0) L.M[4000] = bnd0;
+            }
+            __syncthreads();
+            const double bnd = L.M[4000];
+            __syncthreads();
+            if (bnd < -EHM_ROUTE_TOL * (1.0 + fabs(nb.rec[rec_off_vcost(P.p)]))) {
+                if (tid == 0) {
+                    atomicAdd(&cnt->cert_closed, 1ULL);
+                    T.tstar[id] = bnd;
+                    open_flag[f] = 0;
+                    T.flags[id] |= 1;
+                    atomicMin(&cnt->min_margin_bits,
+                              (unsigned long long)__double_as_longlong(-bnd));
+                }
+                __syncthreads();
+                continue;
+            }
+        }
         IpmResult r;
         int its = 0;
         for (int attempt = 0; attempt < EHM3_ATTEMPTS; ++attempt) {
@@ -325,7 +352,7 @@ EHM3_KERNEL void k3_lcss_expand(
         for (int attempt = 0; attempt < EHM3_ATTEMPTS; ++attempt) {
             double b[RS];
             assemble_point(L, mid, false, b, pin(tid));
-            r = ipm_solve(L, B, b, false, step_fraction(attempt));
+            r = ipm_solve(L, B, b, false, step_fraction(attempt), T.grad ? nb.g : nullptr);
             its += r.iters;
             if (r.status == 0) break;
         }
@@ -336,6 +363,16 @@ EHM3_KERNEL void k3_lcss_expand(
             T.flags[id] |= 16;
         }
         const int c0 = child_base + 2 * f;
+        if (T.grad) {       // the children inherit the vertex gradients, the midpoint's is new
+            const int ng = (p + 1) * p;
+            const double* gp_ = T.grad + (size_t)id * ng;
+            double* g0 = T.grad + (size_t)c0 * ng;
+            for (int k = tid; k < ng; k += NT) {
+                const double gv = gp_[k];
+                g0[k] = (k >= bi * p && k < bi * p + p) ? nb.g[k - bi * p] : gv;
+                g0[ng + k] = (k >= bj * p && k < bj * p + p) ? nb.g[k - bj * p] : gv;
+            }
+        }
         double* rec0 = T.rec + (size_t)c0 * T.rec_stride;
         double* rec1 = rec0 + T.rec_stride;
         const int ov = rec_off_vcost(p), ou = rec_off_vinput(p);
@@ -396,13 +433,14 @@ EHM3_KERNEL void k3_vertex_solve(
         for (int attempt = 0; attempt < EHM3_ATTEMPTS; ++attempt) {
             double b[RS];
             assemble_point(L, nb.th, false, b, pin(tid));
-            r = ipm_solve(L, B, b, false, step_fraction(attempt));
+            r = ipm_solve(L, B, b, false, step_fraction(attempt), T.grad ? nb.g : nullptr);
             its += r.iters;
             if (r.status == 0) break;
         }
         r.iters = its;
         count_solve(cnt, r, tid);
         if (r.status != 0 && tid == 0) atomicAdd(&cnt->errors, 1ULL);
+        if (T.grad && tid < p) T.grad[((size_t)id * (p + 1) + v) * p + tid] = nb.g[tid];
         if (tid == 0) rec[rec_off_vcost(p) + v] = r.obj;
         if (tid < n_u) rec[rec_off_vinput(p) + v * n_u + tid] = L.xb[tid];
         __syncthreads();
