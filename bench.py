@@ -281,8 +281,10 @@ def main():
         gp.set_option('mid_first', 0)
     hybrid = args.workload == 'config3'
     static = (args.balance == 'static' or hybrid) and not args.status_dir
-    persistent = (args.engine == 1 and (world == 1 or static) and args.solver == 2 and
-                  not wide and not hybrid and not args.status_dir)
+    # both balancing modes run the persistent frontier kernel: static = one launch per rank,
+    # dynamic = budgeted rounds of it
+    persistent = (args.engine == 1 and args.solver == 2 and not wide and not hybrid and
+                  not args.status_dir)
     # (the persistent kernel exists at one solver width, k2_persist, and -- where a pair of
     # instances is compiled, as for this workload -- at two, kp_persist; the library picks)
     kname = 'k3_lcss_decide' if wide else 'k2_simplex_batch' if hybrid else (
@@ -326,7 +328,9 @@ def main():
             gp, roots, action='ecc', max_nodes=args.max_nodes,
             min_frontier=args.shard_min_frontier, sweeps_per_round=args.sweeps_per_round,
             device=xdev, export=False, status=publisher,
-            publish_status=bool(args.status_dir))
+            publish_status=bool(args.status_dir),
+            engine='persistent' if (args.engine == 1 and args.solver == 2 and not wide and
+                                    not hybrid) else 'sweeps')
         info['rounds'] = rounds
         info['moved'] = sum(len(e['ids']) for e in log if e['kind'] == 'give')
         return info
@@ -505,6 +509,10 @@ def main():
                                 'depth %d replicated, the nodes of that depth dealt by a hash of '
                                 'their path (static; no data-path collective)' % deal_depth
                                 if static else
+                                ': rank 0 owns the roots; budgeted rounds of the persistent '
+                                'kernel (4096 node visits, doubling), after each an all-gather of '
+                                'the frontier sizes and point-to-point node records'
+                                if (args.engine == 1 and args.solver == 2 and not wide) else
                                 ', rebalanced every %d sweeps (all-gather of frontier sizes + '
                                 'point-to-point node records)' % args.sweeps_per_round),
                 'rebalance_rounds_per_step': float(mx[len(keys) + 4]) / K,

@@ -91,6 +91,17 @@ def _objects():
     return objs
 
 
+def _regenerate_kp():
+    """ehm_kp.hip is derived from k2_persist in ehm_k2.hip (tools/gen_kp.py): keep it in step."""
+    k2 = os.path.join(SRC_DIR, 'ehm_k2.hip')
+    kp = os.path.join(SRC_DIR, 'ehm_kp.hip')
+    gen = os.path.normpath(os.path.join(HERE, '..', 'tools', 'gen_kp.py'))
+    if os.path.exists(gen) and (not os.path.exists(kp) or
+                                os.path.getmtime(kp) < max(os.path.getmtime(k2),
+                                                           os.path.getmtime(gen))):
+        subprocess.check_call([os.environ.get('PYTHON', 'python'), gen])
+
+
 def _stale(obj, src, dep_t):
     return (not os.path.exists(obj) or
             os.path.getmtime(obj) < max(dep_t, os.path.getmtime(src)))
@@ -110,6 +121,7 @@ def build(force=False, verbose=False, jobs=None):
     if not force and not is_stale():
         return LIB
     os.makedirs(OBJ_DIR, exist_ok=True)
+    _regenerate_kp()
     hipcc = _hipcc()
     dep_t = _dep_mtime()
     todo = [(o, s, f) for (o, s, f) in _objects() if force or _stale(o, s, dep_t)]

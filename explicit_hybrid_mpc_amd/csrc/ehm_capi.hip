@@ -517,6 +517,8 @@ struct ehm_tree {
     // persistent engine: node ids follow the allocation order; the export relabels them to the
     // breadth-first order of the level-synchronous engine (perm[new id] = device id)
     bool unordered = false;
+    bool keep_ids = false;   // runs that exchanged nodes with other ranks: the transfer logs name
+                             // device ids, the export must not renumber
     std::vector<int32_t> perm;
     // state of a run in progress (ehm_partition_begin .. ehm_partition_finish)
     struct Run {
@@ -2014,6 +2016,23 @@ int ehm_partition_begin(ehm_problem* P, int64_t n_roots, const double* root_vert
     R.n_nodes = n_roots;
     R.nf = n_roots;
     R.cur_is_a = true;
+    const bool start_empty = R.shard_world > 1 && R.shard_rank > 0 && opts &&
+                             opts->shard_min_frontier < 0;
+    if (start_empty && P->dp.n_delta == 1) {
+        // dynamic balancing from a single source: rank 0 owns the roots, the others start with an
+        // empty frontier and are fed by the rebalancing rounds (ehm_partition_give)
+        std::vector<uint8_t> fl((size_t)n_roots, (uint8_t)(2 | 4));
+        HIP_TRY(hipMemcpyAsync(T->dt.flags, fl.data(), fl.size(), hipMemcpyHostToDevice,
+                               P->stream), EHM_E_HIP);
+        HIP_TRY(hipStreamSynchronize(P->stream), EHM_E_HIP);
+        R.nf = 0;
+        R.sharded = true;
+        R.pre_nodes = n_roots;
+        P->active_run = T;
+        *out = T;
+        return EHM_OK;
+    }
+    if (R.shard_world > 1 && opts && opts->shard_min_frontier < 0) R.sharded = true;
     if (P->dp.n_delta > 1) {
         // multi-commutation problems: the device engine of ehm_hybrid.h
         RUN_TRY(hy_begin(T, n_roots, init));
@@ -2054,7 +2073,7 @@ int ehm_partition_begin(ehm_problem* P, int64_t n_roots, const double* root_vert
 
 // engine = 1: the whole run in ONE launch of the persistent frontier kernel (ehm_k2.hip,
 // k2_persist).  Single rank, shared-block kernels only; anything else uses the sweeps.
-static int persistent_run(ehm_tree* T) {
+static int persistent_run(ehm_tree* T, long long max_pops = 0) {
     ehm_problem* P = T->prob;
     auto& R = T->run;
     K2Cfg cfg;
@@ -2117,11 +2136,11 @@ static int persistent_run(ehm_tree* T) {
     const int32_t* cur = (R.cur_is_a ? P->fr_a : P->fr_b).as<int32_t>();
     HIP_TRY(hipMemcpyAsync(slots, cur, (size_t)R.nf * 4, hipMemcpyDeviceToDevice, P->stream),
             EHM_E_HIP);
-    PersistDeal deal{0, 0, 1, 0};
+    PersistDeal deal{0, 0, 0, 1, 0};
     T->dt.code = nullptr;
     if (R.deal_depth > 0 && R.shard_world > 1 && R.sweeps == 0) {
         // one launch from the roots, dealt over the ranks at a tree depth (PersistDeal)
-        deal = PersistDeal{R.deal_depth, R.shard_rank, R.shard_world,
+        deal = PersistDeal{0, R.deal_depth, R.shard_rank, R.shard_world,
                            getenv("EHM_DEAL_LOW_BITS") ? 0 : 1};
         if ((rc = T->code.ensure((size_t)T->cap * 4))) return rc;
         T->dt.code = T->code.as<uint32_t>();
@@ -2131,6 +2150,8 @@ static int persistent_run(ehm_tree* T) {
                                P->stream), EHM_E_HIP);
         HIP_TRY(hipStreamSynchronize(P->stream), EHM_E_HIP);
     }
+    // budgeted launch (ehm_partition_advance): queue positions >= pop_limit stay unprocessed
+    if (max_pops > 0 && max_pops < n_slots) deal.pop_limit = (int)max_pops;
     PersistCtl h{};
     h.head = 0;
     h.tail = (int)R.nf;
@@ -2157,9 +2178,20 @@ static int persistent_run(ehm_tree* T) {
     if (h.abort == 1)
         return fail(EHM_E_CAPACITY, "node pool exhausted at %d nodes (max_nodes=%lld)",
                     h.n_nodes, T->limit);
-    if (h.abort != 0 || h.pending != 0)
-        return fail(EHM_E_HIP, "persistent frontier kernel stopped early (abort=%d, pending=%d)",
-                    h.abort, h.pending);
+    // what a budgeted launch leaves: the contiguous queue slice [pop_limit, tail)
+    const long long left_over =
+        (deal.pop_limit > 0 && h.tail > deal.pop_limit) ? (long long)h.tail - deal.pop_limit : 0;
+    if (h.abort != 0 || h.pending != left_over)
+        return fail(EHM_E_HIP, "persistent frontier kernel stopped early (abort=%d, pending=%d, "
+                               "expected %lld)", h.abort, h.pending, left_over);
+    if (left_over > 0) {
+        DevBuf& fb = P->fr_a;
+        if ((rc = fb.ensure((size_t)left_over * 4 * 2))) return rc;
+        HIP_TRY(hipMemcpyAsync(fb.ptr, slots + deal.pop_limit, (size_t)left_over * 4,
+                               hipMemcpyDeviceToDevice, P->stream), EHM_E_HIP);
+        HIP_TRY(hipStreamSynchronize(P->stream), EHM_E_HIP);
+        R.cur_is_a = true;
+    }
     R.ref_solves += (long long)h.closed + 3LL * (long long)h.splits;
     if (deal.world > 1) {
         // replicated on every rank: everything above the deal depth (and the nodes AT it, which
@@ -2171,12 +2203,31 @@ static int persistent_run(ehm_tree* T) {
     }
     R.n_closed += (long long)h.closed;
     R.n_nodes = h.n_nodes;
-    R.truncated = h.truncated;
-    R.depth = h.max_depth_seen;
-    R.sweeps = h.max_depth_seen + 1;
-    R.nf = 0;
+    R.truncated = R.truncated || h.truncated;
+    R.depth = std::max(R.depth, h.max_depth_seen);
+    R.sweeps = R.depth + 1;
+    R.nf = left_over;
     T->unordered = true;
     return EHM_OK;
+}
+
+// Up to max_pops node visits of the persistent frontier kernel (<= 0: to completion), then the
+// unprocessed part of its queue becomes the live frontier again -- what ehm_partition_take /
+// ehm_partition_give move between ranks.  The rebalancing rounds of the multi-GPU driver
+// (explicit_hybrid_mpc_amd/distributed.py, engine='persistent') are this call + one all-gather.
+int ehm_partition_advance(ehm_tree* T, int64_t max_pops, int64_t* frontier_size) {
+    if (!T || !T->run.active) return fail(EHM_E_INVALID, "no partition run in progress");
+    ehm_problem* P = T->prob;
+    auto& R = T->run;
+    if (T->hy || P->solver_gen != 2 || P->dp.Wr3)
+        return fail(EHM_E_INVALID, "ehm_partition_advance: needs a single-commutation problem on "
+                                   "the shared-block kernels (use ehm_partition_step)");
+    HIP_TRY(hipSetDevice(P->device), EHM_E_HIP);
+    int rc = EHM_OK;
+    T->keep_ids = true;
+    if (R.nf > 0) rc = persistent_run(T, max_pops > 0 ? (long long)max_pops : 0);
+    if (frontier_size) *frontier_size = R.nf;
+    return rc;
 }
 
 // Runs up to max_sweeps frontier sweeps (<= 0: until the frontier is empty).
@@ -2609,7 +2660,8 @@ int ehm_tree_export(const ehm_tree* Tc, double* vertices, int32_t* left, int32_t
     const int p = P->dp.p, n_u = P->dp.n_u, stride = T->dt.rec_stride;
     const int nR = (p + 1) * p;
     std::vector<int32_t> inv;
-    if (T->unordered) {
+    const bool relabel = T->unordered && !T->keep_ids;
+    if (relabel) {
         // breadth-first relabelling = the numbering of the level-synchronous engine: roots in
         // order, then per level the two children of every split node in parent order
         std::vector<int32_t> l((size_t)n);
@@ -2632,7 +2684,7 @@ int ehm_tree_export(const ehm_tree* Tc, double* vertices, int32_t* left, int32_t
         for (long long k = 0; k < n; ++k) inv[(size_t)T->perm[(size_t)k]] = (int32_t)k;
     }
     auto src = [&](long long k) -> size_t {
-        return T->unordered ? (size_t)T->perm[(size_t)k] : (size_t)k;
+        return relabel ? (size_t)T->perm[(size_t)k] : (size_t)k;
     };
     if (vertices || vcost || vinput) {
         std::vector<double> rec((size_t)n * stride);
@@ -2651,12 +2703,12 @@ int ehm_tree_export(const ehm_tree* Tc, double* vertices, int32_t* left, int32_t
         HIP_TRY(hipMemcpy(l.data(), T->dt.left, (size_t)n * 4, hipMemcpyDeviceToHost), EHM_E_HIP);
         for (long long k = 0; k < n; ++k) {
             int32_t c = l[src(k)];
-            if (c >= 0 && T->unordered) c = inv[(size_t)c];
+            if (c >= 0 && relabel) c = inv[(size_t)c];
             if (left) left[k] = c;
             if (right) right[k] = c < 0 ? -1 : c + 1;
         }
     }
-    if (!T->unordered) {
+    if (!relabel) {
         if (delta_idx)
             HIP_TRY(hipMemcpy(delta_idx, T->dt.didx, (size_t)n * 4, hipMemcpyDeviceToHost),
                     EHM_E_HIP);

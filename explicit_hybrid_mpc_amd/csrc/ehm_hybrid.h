@@ -705,7 +705,7 @@ struct HyState {
     std::vector<int> snap_kind;          // LP kind of that launch
     HyCtr h{};
     int fail_delta = -1;                 // test hook: vertex solves of this commutation "fail"
-    PersistDeal deal{0, 0, 1, 1};        // sharded runs: deal depth / rank / world
+    PersistDeal deal{0, 0, 0, 1, 1};     // sharded runs: deal depth / rank / world
     void release() {
         DevBuf* all[] = {&vf, &cand, &black, &neg, &tneg, &fr_ecc[0], &fr_ecc[1], &fr_lcss[0], &fr_lcss[1],
                          &known1, &ask, &slk, &vall, &redo, &koff, &src, &dst, &dcomm, &dsel2, &cnt,
@@ -1191,7 +1191,7 @@ static int hy_begin(ehm_tree* T, int64_t n_roots, const ehm_node_init* init) {
     if (R.shard_world > 1) {
         if (R.deal_depth <= 0)
             return fail(EHM_E_INVALID, "sharded multi-commutation runs need ehm_run_opts.deal_depth");
-        H.deal = PersistDeal{R.deal_depth, R.shard_rank, R.shard_world, 1};
+        H.deal = PersistDeal{0, R.deal_depth, R.shard_rank, R.shard_world, 1};
         if ((rc = T->code.ensure((size_t)T->cap * 4))) return rc;
         T->dt.code = T->code.as<uint32_t>();
         std::vector<uint32_t> codes((size_t)n_roots);

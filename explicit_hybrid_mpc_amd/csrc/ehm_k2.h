@@ -71,6 +71,10 @@ struct PersistCtl {
 // a node created AT that depth is pursued by rank (path code % world) only -- the others flag
 // it "owned by another rank" (bit2) and do not queue it.  world <= 1: no dealing.
 struct PersistDeal {
+    // pop_limit > 0: budgeted launch -- a wavefront that draws queue position >= pop_limit
+    // leaves; the queue is consumed in order, so what stays unprocessed is the contiguous
+    // slice [pop_limit, tail) (ehm_partition_advance: rebalancing rounds between launches)
+    int pop_limit;
     int depth, rank, world;
     int mix;        // 1 (default) = multiplicative hash of the path code; 0 = its low bits, i.e.
                     // the last turns of the path (measured: 12 % imbalance at 8 ranks against 5 %)

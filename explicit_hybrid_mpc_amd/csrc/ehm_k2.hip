@@ -374,7 +374,8 @@ __global__ __launch_bounds__(EHM_K2_THREADS) void k2_persist(
         int id = -1;
         if (lane0 == 0) {
             const int idx = atomicAdd(&ctl->head, 1);
-            if (idx < n_slots) {
+            if (idx < ((deal.pop_limit > 0 && deal.pop_limit < n_slots) ? deal.pop_limit
+                                                                        : n_slots)) {
                 for (;;) {
                     id = __hip_atomic_load(&slots[idx], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                     if (id >= 0) break;

@@ -198,7 +198,8 @@ def _publish(status, worker, run, live, device, rank, force=False):
 
 def run_balanced(gp, roots, action='ecc', init=None, max_nodes=0, min_frontier=1024,
                  sweeps_per_round=3, tolerance=0.1, min_move=16, device=None, export=False,
-                 with_volume=False, run_factory=None, status=None, publish_status=False):
+                 with_volume=False, run_factory=None, status=None, publish_status=False,
+                 engine='sweeps', pops_per_round=4096, pops_max=1 << 17):
     """
     One partition over all ranks with periodic rebalancing of the live frontiers.
     Returns (FlatTree or info dict of THIS rank's share, transfer log, rounds).
@@ -206,12 +207,18 @@ def run_balanced(gp, roots, action='ecc', init=None, max_nodes=0, min_frontier=1
     (the CPU tests emulate it).
     publish_status (same value on EVERY rank) adds one all-gather of the ranks' progress
     counters per round; rank 0 passes them to ``status`` (a status.MainStatusPublisher).
+    engine='persistent': the rounds are budgeted launches of the persistent frontier kernel
+    (``PartitionRun.advance``: pops_per_round node visits, doubling every round up to pops_max)
+    instead of sweeps; rank 0 owns the roots, the other ranks start empty and are fed by the
+    first rounds -- nothing is replicated.
     """
     import torch.distributed as dist
     rank, _, world = env_rank_world()
     if not (dist.is_available() and dist.is_initialized()):
         world, rank = 1, 0
-    shard = shard_spec(rank, world, min_frontier)
+    persistent = engine == 'persistent'
+    shard = shard_spec(rank, world, -1 if persistent else min_frontier)
+    budget = int(pops_per_round)
     if run_factory is not None:
         run = run_factory(shard)
     else:
@@ -237,7 +244,11 @@ def run_balanced(gp, roots, action='ecc', init=None, max_nodes=0, min_frontier=1
     while True:
         err = None
         try:
-            n = run.step(sweeps_per_round if (world > 1 or publish_status) else 0)
+            if persistent:
+                n = run.advance(budget if (world > 1 or publish_status) else 0)
+                budget = min(2 * budget, int(pops_max))
+            else:
+                n = run.step(sweeps_per_round if (world > 1 or publish_status) else 0)
         except Exception as e:      # reported to the other ranks below, then re-raised
             err, n = e, -1
         if world == 1:

@@ -401,6 +401,16 @@ class PartitionRun:
         self.frontier = int(n.value)
         return self.frontier
 
+    def advance(self, max_pops=0):
+        """
+        Up to max_pops node visits of the persistent frontier kernel (0 = to completion); what
+        is left of its queue is the live frontier again (ehm_partition_advance).
+        """
+        n = ctypes.c_int64(0)
+        check(self._lib.ehm_partition_advance(self._tree, int(max_pops), ctypes.addressof(n)))
+        self.frontier = int(n.value)
+        return self.frontier
+
     def progress(self):
         """Volume filled / simplex count / LP solves so far (ehm_partition_progress)."""
         pr = _capi.Progress()

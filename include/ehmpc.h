@@ -284,6 +284,13 @@ typedef struct ehm_progress {
                                publisher counts (simplex_count += 1 per split,
                                lib/worker.py:274,327,107-109)                           */
 } ehm_progress;
+/* Up to max_pops node visits of the persistent frontier kernel (<= 0: to completion); the
+ * unprocessed part of its device queue -- a contiguous slice, the queue is consumed in order --
+ * becomes the live frontier again, so ehm_partition_take / _give can move nodes between ranks
+ * before the next call.  Single-commutation problems on the shared-block kernels.
+ * Dynamic multi-GPU runs: ehm_run_opts.shard_min_frontier < 0 makes every rank but 0 start with
+ * an EMPTY frontier (rank 0 owns the roots); the rebalancing rounds feed them. */
+int ehm_partition_advance(ehm_tree* tree, int64_t max_pops, int64_t* frontier_size);
 /* Pool occupancy of a run in progress, without touching the device: nodes allocated so far and
  * the capacity of this run (max_nodes).  The multi-GPU driver checks a receiver's free pool
  * before it plans a transfer (explicit_hybrid_mpc_amd/distributed.py). */

@@ -71,3 +71,58 @@ def test_moved_frontier_nodes_give_the_same_tree():
     own = [int(p.info['n_closed']) - int(p.info['replicated_closed']) * (r > 0)
            for r, p in enumerate(parts)]
     assert sum(own) == int(np.sum((ref.flags & 1) > 0))
+
+
+def test_budgeted_persistent_rounds_from_a_single_source():
+    """
+    ehm_partition_advance: rounds of the PERSISTENT frontier kernel with a pop budget; what is
+    left of its device queue is the frontier the ranks rebalance.  Rank 0 owns the roots, rank 1
+    starts empty (shard_min_frontier < 0) and is fed by the first rounds; nothing is replicated.
+    """
+    from explicit_hybrid_mpc_amd import distributed, engine, examples
+    from explicit_hybrid_mpc_amd import tools as ehm_tools
+    mpc = helpers.make_instance('lin', 0)
+    can = mpc.compile()
+    V = examples.box_vertices(examples.theta_box(mpc))
+    roots, locs = ehm_tools.delaunay_roots(V)
+    gps = [engine.GpuProblem(can, 1., 1.) for _ in range(3)]
+    eps_a = float(np.max(gps[0].solve_pt(0.12 * V)[0]))
+    for g in gps:
+        g.set_eps(eps_a, 1e-2)
+    ref = gps[2].partition(roots, action='ecc')
+    world = 2
+    runs = [gps[r].begin(roots, shard=(r, world, -1)) for r in range(world)]
+    assert runs[1].advance(10) == 0                     # nothing to do yet
+    logs = [[] for _ in range(world)]
+    rnd, moved, budget = 0, 0, 64
+    while True:
+        counts = [run.advance(budget) for run in runs]
+        budget = min(2 * budget, 4096)
+        if sum(counts) == 0:
+            break
+        for donor, receiver, n in distributed.balance_plan(counts, tolerance=0.02, min_move=4):
+            ids, rec, meta = runs[donor].take(n)
+            first = runs[receiver].give(rec, meta)
+            logs[donor].append(dict(kind='give', round=rnd, peer=receiver, ids=ids))
+            logs[receiver].append(dict(kind='recv', round=rnd, peer=donor, first=first, count=n))
+            moved += n
+        rnd += 1
+    parts = [run.finish(export=True) for run in runs]
+    for g in gps:
+        g.close()
+    assert moved > 0 and rnd >= 3
+    assert parts[1].info['n_closed'] > 0.2 * ref.info['n_closed']      # rank 1 really worked
+    received = distributed.resolve_received(parts, logs, locs)
+    merged = distributed.merge_flat(parts, locs, received)
+    assert merged.n_nodes == ref.n_nodes
+    rloc, mloc = ref.locations(locs), merged.locations(locs)
+    ridx = {n: k for k, n in enumerate(rloc)}
+    assert set(rloc) == set(mloc)
+    for k, name in enumerate(mloc):
+        j = ridx[name]
+        assert np.array_equal(merged.vertices[k], ref.vertices[j])
+        assert merged.is_leaf(k) == ref.is_leaf(j)
+        assert (merged.flags[k] & 1) == (ref.flags[j] & 1)
+        assert not (merged.flags[k] & 4)
+        assert np.allclose(merged.vertex_costs[k], ref.vertex_costs[j], rtol=1e-9, atol=1e-12)
+    assert sum(int(p.info['n_closed']) for p in parts) == int(np.sum((ref.flags & 1) > 0))
