@@ -92,6 +92,14 @@ class CpuRun:
         p, n_u = np.array(roots[0]).shape[1], self.U[0].shape[1]
         self.p, self.n_u = p, n_u
         self.nrec = (p + 1) * p + (p + 1) + (p + 1) * n_u
+        if self.world > 1 and self.min_frontier < 0:
+            # dynamic balancing from a single source (ehm_run_opts.shard_min_frontier < 0):
+            # rank 0 owns the roots, the others start empty
+            self.sharded = True
+            if self.rank > 0:
+                for i in self.frontier:
+                    self.F[i] |= 4
+                self.frontier = []
 
     def _add(self, R, c, u, flag):
         self.V.append(R); self.L.append(-1); self.Rr.append(-1); self.C.append(c)
@@ -130,6 +138,29 @@ class CpuRun:
             done += 1
         return len(self.frontier)
 
+    def advance(self, max_pops=0):
+        """Emulation of ehm_partition_advance: the frontier is a FIFO queue, max_pops visits."""
+        from oracle import geometry
+        queue, done = list(self.frontier), 0
+        while queue and (max_pops <= 0 or done < max_pops):
+            i = queue.pop(0)
+            done += 1
+            t, _ = self.orc.slack(self.V[i], self.C[i], 0)
+            self.T[i] = t
+            if not (t >= 0.):
+                self.F[i] |= 1
+                continue
+            S1, S2, (a, b) = geometry.split_along_longest_edge(self.V[i])
+            u_mid, J_mid, _ = self.orc.P_theta_delta(S1[a], self.d0)
+            c1, c2 = self.C[i].copy(), self.C[i].copy()
+            u1, u2 = self.U[i].copy(), self.U[i].copy()
+            c1[a], c2[b], u1[a], u2[b] = J_mid, J_mid, u_mid, u_mid
+            self.L[i] = self._add(S1, c1, u1, 2)
+            self.Rr[i] = self._add(S2, c2, u2, 2)
+            queue += [self.L[i], self.Rr[i]]
+        self.frontier = queue
+        return len(self.frontier)
+
     def take(self, count):
         ids = np.array(self.frontier[len(self.frontier) - count:], dtype=np.int32)
         self.frontier = self.frontier[:len(self.frontier) - count]
@@ -160,7 +191,7 @@ class CpuRun:
                         np.ones((1, self.mpc.N)))
 
 
-def _worker_balanced(rank, world, port, out_dir):
+def _worker_balanced(rank, world, port, out_dir, engine='sweeps'):
     os.environ.update(RANK=str(rank), LOCAL_RANK=str(rank), WORLD_SIZE=str(world),
                       MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port))
     import pickle
@@ -171,6 +202,7 @@ def _worker_balanced(rank, world, port, out_dir):
     roots, locs = helpers.roots_of(mpc)
     part, log, rounds = distributed.run_balanced(
         None, roots, min_frontier=6, sweeps_per_round=1, tolerance=0., min_move=1, export=True,
+        engine=engine, pops_per_round=3, pops_max=24,
         run_factory=lambda shard: CpuRun(mpc, 0.3, 0.02, roots, shard))
     with open(os.path.join(out_dir, 'bal%d.pkl' % rank), 'wb') as f:
         pickle.dump(dict(part=part, log=log, rounds=rounds), f)
@@ -251,15 +283,20 @@ def test_balance_plan_is_deterministic_and_evens_out():
     assert donors.isdisjoint({r for _, r, _ in plan})                 # nobody relays
 
 
-def test_two_ranks_rebalance_and_merge(tmp_path):
-    """run_balanced over gloo: frontier nodes really move, and the merged tree is the tree."""
+@pytest.mark.parametrize('engine', ['sweeps', 'persistent'])
+def test_two_ranks_rebalance_and_merge(tmp_path, engine):
+    """
+    run_balanced over gloo: frontier nodes really move, and the merged tree is the tree.
+    'sweeps': sweep rounds after a deal by position; 'persistent': budgeted rounds of the
+    (emulated) persistent kernel from a single source -- rank 1 starts with nothing.
+    """
     import pickle
     from explicit_hybrid_mpc_amd import distributed
     s = socket.socket()
     s.bind(('127.0.0.1', 0))
     port = s.getsockname()[1]
     s.close()
-    mp.spawn(_worker_balanced, args=(2, port, str(tmp_path)), nprocs=2, join=True)
+    mp.spawn(_worker_balanced, args=(2, port, str(tmp_path), engine), nprocs=2, join=True)
     outs = [pickle.load(open(str(tmp_path / ('bal%d.pkl' % r)), 'rb')) for r in range(2)]
     moved = sum(len(e['ids']) for o in outs for e in o['log'] if e['kind'] == 'give')
     got = sum(e['count'] for o in outs for e in o['log'] if e['kind'] == 'recv')
