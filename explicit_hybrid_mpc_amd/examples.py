@@ -118,6 +118,43 @@ def pwa_mpc(seed=0, n_x=4, n_u=2, N=5, rho=1.05, n_random=8, r_weight=0.1, kink=
     return mpc
 
 
+def pwa4_mpc(seed=0, n_x=8, n_u=3, N=4, rho=1.02, kink=0.25, overlap=0.05, r_weight=0.1):
+    """
+    The SHAPE of config 5 (n_x = 8, n_u = 3, 4 integer modes): the four modes are the sign
+    patterns of (x_1, x_2), each admissible on its quadrant widened by ``overlap``; the dynamics
+    matrices differ in their first two columns.  With N = 4 its 4^4 = 256 commutations can be
+    enumerated (the engine's limit); config 5 proper (N = 8: 65 536 of them) needs the
+    branch-and-bound over mode prefixes of DESIGN.md section 7c.
+    """
+    rng = np.random.default_rng(seed)
+    M = rng.standard_normal((n_x, n_x))
+    A0 = rho * M / np.max(np.abs(np.linalg.eigvals(M)))
+    B = rng.standard_normal((n_x, n_u))
+    d1 = kink * rng.standard_normal(n_x)
+    d2 = kink * rng.standard_normal(n_x)
+    A, regions = [], []
+    for s1 in (1., -1.):
+        for s2 in (1., -1.):
+            Ai = A0.copy()
+            if s1 < 0:
+                Ai[:, 0] += d1
+            if s2 < 0:
+                Ai[:, 1] += d2
+            A.append(Ai)
+            H = np.zeros((2, n_x))
+            H[0, 0], H[1, 1] = -s1, -s2          # s1 x_1 >= -overlap, s2 x_2 >= -overlap
+            regions.append((H, overlap * np.ones(2)))
+    Gx = np.vstack([np.eye(n_x), -np.eye(n_x)])
+    gx = np.ones(2 * n_x)
+    Gu = np.vstack([np.eye(n_u), -np.eye(n_u)])
+    gu = np.ones(2 * n_u)
+    mpc = PWAMPC(A, [B] * 4, [np.zeros(n_x)] * 4, regions, Gx, gx, Gu, gu,
+                 Q=np.eye(n_x), R=r_weight * np.eye(n_u), N=N,
+                 name='pwa4_nx%d_nu%d_N%d_seed%d' % (n_x, n_u, N, seed))
+    THETA_SCALE.setdefault(mpc.name, 0.2)
+    return mpc
+
+
 def integrator_chain_mpc(n_axes=3, N=10, T=0.1, x_max=(1., 1.), u_max=1., r_weight=0.1):
     """
     Config 4: n_x = 2*n_axes "quadrotor" made of independent double integrators with box

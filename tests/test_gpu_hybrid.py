@@ -303,3 +303,81 @@ def test_hybrid_engine_on_the_wide_kernels():
                           ref['commutation'].astype(int)):
             assert np.allclose(flat.vertex_costs[kd], ref['vertex_costs'], rtol=RTOL, atol=RTOL)
     assert decided >= 1
+
+
+def test_config5_shaped_instance_on_the_engine():
+    """
+    The shape of BASELINE.json's configs[4] -- n_x = 8, n_u = 3, 4 integer modes, 9-vertex
+    simplices -- with a horizon short enough to enumerate its commutations (N = 4: 256, the
+    engine's limit; config 5 proper needs the prefix branch-and-bound of DESIGN.md 7c):
+    P_theta, V_R, bar_E_delta_R, bar_D_delta_R and a truncated partition against the CPU oracle.
+    """
+    from explicit_hybrid_mpc_amd import engine, examples
+    from oracle.oracle_cpu import OracleCPU
+    from oracle.partition_cpu import PartitionCPU
+    mpc = examples.pwa4_mpc()
+    can = mpc.compile()
+    assert (can.p, can.n_u, can.n_delta, can.delta_size) == (8, 3, 256, 4)
+    gp = engine.GpuProblem(can, 1., 1.)
+    half = examples.theta_box(mpc)
+    V = examples.box_vertices(half)
+    J = gp.solve_pt(V[::32])[0]
+    assert np.isfinite(J).all()
+    eps_a, eps_r = 0.25 * float(np.max(J)), 0.5
+    gp.set_eps(eps_a, eps_r)
+    orc = OracleCPU(mpc, eps_a, eps_r)
+    orc.memoize = True
+    # a2 / a3: P_theta
+    th = V[[3, 77, 200]]
+    Jd, ud, dd = gp.solve_pt(th)
+    for k in range(len(th)):
+        u, delta, Jc, _ = orc.P_theta(th[k])
+        assert abs(Jd[k] - Jc) <= RTOL * (1 + abs(Jc))
+        assert np.array_equal(can.deltas[dd[k]].astype(int), delta.astype(int))
+    # two 9-vertex simplices: one around a point off the mode boundaries, one straddling x_1 = 0
+    rng = np.random.default_rng(5)
+    E = np.vstack([np.zeros(8), np.eye(8)]) - 1. / 9.
+    roots = np.array([0.5 * half * np.array([1, 1, -1, 1, -1, 1, 1, -1.]) + 0.08 * half * E,
+                      0.4 * half * np.array([0, 1, 1, -1, 1, -1, 1, 1.]) + 0.15 * half * E])
+    # a4: V_R
+    didx, vJ, vu = gp.v_r(roots)
+    for k in range(2):
+        delta, vx = orc.V_R(roots[k])
+        if delta is None:
+            assert didx[k] < 0
+            continue
+        assert np.array_equal(can.deltas[didx[k]].astype(int), delta.astype(int))
+        assert np.allclose(vJ[k], [v[1] for v in vx], rtol=RTOL, atol=RTOL)
+    # a5 / a6 on the simplex that has a commutation
+    k = int(np.argmax(didx >= 0))
+    assert didx[k] >= 0
+    closed, tb = gp.bar_e(roots[k:k + 1], vJ[k:k + 1])
+    t_all = [orc.slack(roots[k], vJ[k], d)[0] for d in range(can.n_delta)]
+    assert abs(tb[0] - max(t_all)) <= 1e-7 * (1 + abs(max(t_all)))
+    assert bool(closed[0]) == orc.bar_E_delta_R(roots[k], vJ[k])
+    ds, ths, vJ2, vu2, vs = gp.bar_d(roots[k:k + 1], vJ[k:k + 1], can.deltas[didx[k]][None])
+    dstar, theta_star, vx, var_small = orc.bar_D_delta_R(roots[k], vJ[k], can.deltas[didx[k]])
+    if dstar is None:
+        assert ds[0] < 0
+    else:
+        assert np.array_equal(can.deltas[ds[0]].astype(int), dstar.astype(int))
+        assert bool(vs[0]) == bool(var_small)
+    # truncated partition of the two simplices on the device engine; its top against the oracle
+    flat = gp.partition(roots, action='ecc', max_depth=3, max_nodes=1 << 16)
+    gp.close()
+    assert flat.info['lp_solves'] > 0
+    per_micp = flat.info['lp_solves'] / max(flat.info['ref_solves'], 1)
+    assert 1 < per_micp < can.n_delta * 10      # LPs solved per reference-equivalent oracle call
+    loc = flat.locations(['a', 'b'])
+    pos = {name: i for i, name in enumerate(loc)}
+    cpu = PartitionCPU(orc, max_nodes=2)
+    cpu.run([roots[0], roots[1]], ['a', 'b'], 'ecc')
+    checked = 0
+    for name, ref in cpu.nodes.items():
+        kd = pos[name]
+        assert np.array_equal(flat.vertices[kd], ref['vertices']), name
+        if ref['commutation'] is not None and flat.delta_idx[kd] >= 0 and np.array_equal(
+                flat.deltas[flat.delta_idx[kd]].astype(int), ref['commutation'].astype(int)):
+            assert np.allclose(flat.vertex_costs[kd], ref['vertex_costs'], rtol=RTOL, atol=RTOL)
+            checked += 1
+    assert checked >= 1
