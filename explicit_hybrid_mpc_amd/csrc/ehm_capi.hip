@@ -1862,6 +1862,35 @@ static int read_counters(ehm_problem* P, DevCounters& c) {
 // the ranks all-gather their frontier sizes and move node records from the longest frontiers
 // to the shortest.
 
+// flat export (ehm_tree_export): node k of the output is device node perm[k] (or k); its record
+// is split into the caller's three arrays, its child index renumbered through inv
+__global__ void k_export_gather(DevTree T, const int32_t* __restrict__ perm,
+                                const int32_t* __restrict__ inv, long long k0, long long nk,
+                                int n_u, double* __restrict__ out_v, double* __restrict__ out_c,
+                                double* __restrict__ out_u, double* __restrict__ out_t,
+                                int32_t* __restrict__ out_l, int32_t* __restrict__ out_r,
+                                int32_t* __restrict__ out_d, uint8_t* __restrict__ out_f) {
+    const int p = T.p, nR = (p + 1) * p, nc = p + 1, nu = (p + 1) * n_u, nrec = nR + nc + nu;
+    const long long t = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= nk * nrec) return;
+    const long long k = t / nrec;
+    const int e = (int)(t - k * nrec);
+    const long long id = perm ? perm[k0 + k] : k0 + k;
+    const double v = T.rec[(size_t)id * T.rec_stride + e];
+    if (e < nR) out_v[k * nR + e] = v;
+    else if (e < nR + nc) out_c[k * nc + (e - nR)] = v;
+    else out_u[k * nu + (e - nR - nc)] = v;
+    if (e == 0) {
+        out_t[k] = T.tstar[id];
+        int32_t c = T.left[id];
+        if (c >= 0 && inv) c = inv[c];
+        out_l[k] = c;
+        out_r[k] = (c < 0) ? -1 : c + 1;
+        out_d[k] = T.didx[id];
+        out_f[k] = T.flags[id];
+    }
+}
+
 // gather / scatter of node records for the frontier hand-over
 __global__ void k_take_nodes(DevTree T, const int32_t* __restrict__ ids, int n, int nrec,
                              double* __restrict__ rec_out, int32_t* __restrict__ meta_out) {
@@ -2620,30 +2649,24 @@ int ehm_tree_info_get(const ehm_tree* Tc, ehm_tree_info* out) {
     if (!Tc || !out) return fail(EHM_E_INVALID, "null argument");
     ehm_tree* T = const_cast<ehm_tree*>(Tc);
     if (T->info.volume_closed < 0.0 && !T->skip_volume) {
-        // sum of closed-leaf volumes (lib/worker.py:374-375), computed from the export
+        // sum of closed-leaf volumes (lib/worker.py:374-375): a reduction kernel over the pool
         ehm_problem* P = T->prob;
         HIP_TRY(hipSetDevice(P->device), EHM_E_HIP);
         const long long n = T->info.n_nodes;
-        const int p = P->dp.p, stride = T->dt.rec_stride, nR = (p + 1) * p;
-        std::vector<double> rec((size_t)n * stride);
-        std::vector<uint8_t> flags((size_t)n);
-        HIP_TRY(hipMemcpy(rec.data(), T->dt.rec, rec.size() * 8, hipMemcpyDeviceToHost), EHM_E_HIP);
-        HIP_TRY(hipMemcpy(flags.data(), T->dt.flags, flags.size(), hipMemcpyDeviceToHost),
-                EHM_E_HIP);
-        std::vector<double> verts;
-        for (long long k = 0; k < n; ++k)
-            if (flags[(size_t)k] & 1)
-                verts.insert(verts.end(), rec.begin() + (size_t)k * stride,
-                             rec.begin() + (size_t)k * stride + nR);
-        const long long nc = (long long)(verts.size() / nR);
-        std::vector<double> vol((size_t)nc);
-        if (nc > 0) {
-            int rc = ehm_volume_batch(P->device, nc, p, verts.data(), vol.data());
+        const int blocks = (int)((n + 255) / 256);
+        double vol = 0.0;
+        if (blocks > 0) {
+            int rc = P->out3.ensure((size_t)blocks * sizeof(double));
             if (rc) return rc;
+            hipLaunchKernelGGL(k_closed_volume, dim3(blocks), dim3(256), 0, P->stream, T->dt, 0LL,
+                               n, P->out3.as<double>());
+            std::vector<double> part((size_t)blocks);
+            HIP_TRY(hipMemcpyAsync(part.data(), P->out3.ptr, part.size() * sizeof(double),
+                                   hipMemcpyDeviceToHost, P->stream), EHM_E_HIP);
+            HIP_TRY(hipStreamSynchronize(P->stream), EHM_E_HIP);
+            for (double v : part) vol += v;
         }
-        double s = 0.0;
-        for (double v : vol) s += v;
-        T->info.volume_closed = s;
+        T->info.volume_closed = vol;
     }
     *out = T->info;
     return EHM_OK;
@@ -2683,57 +2706,61 @@ int ehm_tree_export(const ehm_tree* Tc, double* vertices, int32_t* left, int32_t
         inv.assign((size_t)n, -1);
         for (long long k = 0; k < n; ++k) inv[(size_t)T->perm[(size_t)k]] = (int32_t)k;
     }
-    auto src = [&](long long k) -> size_t {
-        return relabel ? (size_t)T->perm[(size_t)k] : (size_t)k;
-    };
-    if (vertices || vcost || vinput) {
-        std::vector<double> rec((size_t)n * stride);
-        HIP_TRY(hipMemcpy(rec.data(), T->dt.rec, rec.size() * 8, hipMemcpyDeviceToHost), EHM_E_HIP);
-        for (long long k = 0; k < n; ++k) {
-            const double* r = rec.data() + src(k) * stride;
-            if (vertices) std::memcpy(vertices + (size_t)k * nR, r, nR * 8);
-            if (vcost) std::memcpy(vcost + (size_t)k * (p + 1), r + rec_off_vcost(p), (p + 1) * 8);
-            if (vinput)
-                std::memcpy(vinput + (size_t)k * (p + 1) * n_u, r + rec_off_vinput(p),
-                            (size_t)(p + 1) * n_u * 8);
+    // The records are gathered ON THE DEVICE into the caller's layout and numbering (one pass
+    // over a chunk of nodes, coalesced writes), then copied out slice by slice: no host-side
+    // staging copy of the whole pool, no per-node memcpy.
+    DevBuf d_perm, d_inv, stage;
+    int rc = EHM_OK;
+    if (relabel) {
+        if ((rc = d_perm.ensure((size_t)n * 4)) || (rc = d_inv.ensure((size_t)n * 4))) return rc;
+        HIP_TRY(hipMemcpyAsync(d_perm.ptr, T->perm.data(), (size_t)n * 4, hipMemcpyHostToDevice,
+                               P->stream), EHM_E_HIP);
+        HIP_TRY(hipMemcpyAsync(d_inv.ptr, inv.data(), (size_t)n * 4, hipMemcpyHostToDevice,
+                               P->stream), EHM_E_HIP);
+    }
+    const int nc = p + 1, nu = (p + 1) * n_u, nrec = nR + nc + nu;
+    const long long chunk = std::min<long long>(n, 1LL << 18);
+    // staging per chunk: records (nrec doubles) | tstar | left | right | didx | flags
+    const size_t per_node = (size_t)nrec * 8 + 8 + 4 + 4 + 4 + 1;
+    if ((rc = stage.ensure((size_t)chunk * per_node + 64))) {
+        d_perm.release(); d_inv.release();
+        return rc;
+    }
+    auto cleanup = [&]() { d_perm.release(); d_inv.release(); stage.release(); };
+    for (long long k0 = 0; k0 < n; k0 += chunk) {
+        const long long nk = std::min(chunk, n - k0);
+        double* s_v = stage.as<double>();
+        double* s_c = s_v + (size_t)nk * nR;
+        double* s_u = s_c + (size_t)nk * nc;
+        double* s_t = s_u + (size_t)nk * nu;
+        int32_t* s_l = reinterpret_cast<int32_t*>(s_t + nk);
+        int32_t* s_r = s_l + nk;
+        int32_t* s_d = s_r + nk;
+        uint8_t* s_f = reinterpret_cast<uint8_t*>(s_d + nk);
+        hipLaunchKernelGGL(k_export_gather, dim3((unsigned)((nk * nrec + 255) / 256)), dim3(256), 0,
+                           P->stream, T->dt, relabel ? d_perm.as<int32_t>() : (const int32_t*)nullptr,
+                           relabel ? d_inv.as<int32_t>() : (const int32_t*)nullptr, k0, nk, n_u, s_v,
+                           s_c, s_u, s_t, s_l, s_r, s_d, s_f);
+        hipError_t e = hipGetLastError();
+#define EXP_COPY(dst, srcp, bytes)                                                         \
+        if (e == hipSuccess && (dst))                                                      \
+            e = hipMemcpyAsync((dst), (srcp), (bytes), hipMemcpyDeviceToHost, P->stream)
+        EXP_COPY(vertices ? vertices + (size_t)k0 * nR : nullptr, s_v, (size_t)nk * nR * 8);
+        EXP_COPY(vcost ? vcost + (size_t)k0 * nc : nullptr, s_c, (size_t)nk * nc * 8);
+        EXP_COPY(vinput ? vinput + (size_t)k0 * nu : nullptr, s_u, (size_t)nk * nu * 8);
+        EXP_COPY(tstar ? tstar + k0 : nullptr, s_t, (size_t)nk * 8);
+        EXP_COPY(left ? left + k0 : nullptr, s_l, (size_t)nk * 4);
+        EXP_COPY(right ? right + k0 : nullptr, s_r, (size_t)nk * 4);
+        EXP_COPY(delta_idx ? delta_idx + k0 : nullptr, s_d, (size_t)nk * 4);
+        EXP_COPY(flags ? flags + k0 : nullptr, s_f, (size_t)nk);
+#undef EXP_COPY
+        if (e == hipSuccess) e = hipStreamSynchronize(P->stream);   // the stage is reused
+        if (e != hipSuccess) {
+            cleanup();
+            return fail(EHM_E_HIP, "tree export failed: %s", hipGetErrorString(e));
         }
     }
-    if (left || right) {
-        std::vector<int32_t> l((size_t)n);
-        HIP_TRY(hipMemcpy(l.data(), T->dt.left, (size_t)n * 4, hipMemcpyDeviceToHost), EHM_E_HIP);
-        for (long long k = 0; k < n; ++k) {
-            int32_t c = l[src(k)];
-            if (c >= 0 && relabel) c = inv[(size_t)c];
-            if (left) left[k] = c;
-            if (right) right[k] = c < 0 ? -1 : c + 1;
-        }
-    }
-    if (!relabel) {
-        if (delta_idx)
-            HIP_TRY(hipMemcpy(delta_idx, T->dt.didx, (size_t)n * 4, hipMemcpyDeviceToHost),
-                    EHM_E_HIP);
-        if (flags)
-            HIP_TRY(hipMemcpy(flags, T->dt.flags, (size_t)n, hipMemcpyDeviceToHost), EHM_E_HIP);
-        if (tstar)
-            HIP_TRY(hipMemcpy(tstar, T->dt.tstar, (size_t)n * 8, hipMemcpyDeviceToHost),
-                    EHM_E_HIP);
-        return EHM_OK;
-    }
-    if (delta_idx) {
-        std::vector<int32_t> t((size_t)n);
-        HIP_TRY(hipMemcpy(t.data(), T->dt.didx, (size_t)n * 4, hipMemcpyDeviceToHost), EHM_E_HIP);
-        for (long long k = 0; k < n; ++k) delta_idx[k] = t[src(k)];
-    }
-    if (flags) {
-        std::vector<uint8_t> t((size_t)n);
-        HIP_TRY(hipMemcpy(t.data(), T->dt.flags, (size_t)n, hipMemcpyDeviceToHost), EHM_E_HIP);
-        for (long long k = 0; k < n; ++k) flags[k] = t[src(k)];
-    }
-    if (tstar) {
-        std::vector<double> t((size_t)n);
-        HIP_TRY(hipMemcpy(t.data(), T->dt.tstar, (size_t)n * 8, hipMemcpyDeviceToHost), EHM_E_HIP);
-        for (long long k = 0; k < n; ++k) tstar[k] = t[src(k)];
-    }
+    cleanup();
     return EHM_OK;
 }
 
