@@ -394,10 +394,30 @@ class PartitionRun:
         self.nrec = (can.p + 1) * can.p + (can.p + 1) + (can.p + 1) * can.n_u
         self.frontier = n_roots
 
+    def abort(self):
+        """Release the device tree of a run that will not be finished (the handle is free again)."""
+        if getattr(self, '_tree', None):
+            self._lib.ehm_tree_destroy(self._tree)
+            self._tree = ctypes.c_void_p()
+
+    def __del__(self):
+        try:
+            self.abort()
+        except Exception:
+            pass
+
+    def _checked(self, rc):
+        """A failed engine call ends the run: one run at a time per handle, so let go of it."""
+        if rc != _capi.EHM_OK:
+            msg = _capi.load().ehm_last_error().decode('utf-8', 'replace')
+            self.abort()
+            raise _capi.EhmError(rc, msg)
+
     def step(self, max_sweeps=0):
         """Up to max_sweeps frontier sweeps (0 = until done); returns the live frontier size."""
         n = ctypes.c_int64(0)
-        check(self._lib.ehm_partition_step(self._tree, int(max_sweeps), ctypes.addressof(n)))
+        self._checked(self._lib.ehm_partition_step(self._tree, int(max_sweeps),
+                                                   ctypes.addressof(n)))
         self.frontier = int(n.value)
         return self.frontier
 
@@ -407,7 +427,8 @@ class PartitionRun:
         is left of its queue is the live frontier again (ehm_partition_advance).
         """
         n = ctypes.c_int64(0)
-        check(self._lib.ehm_partition_advance(self._tree, int(max_pops), ctypes.addressof(n)))
+        self._checked(self._lib.ehm_partition_advance(self._tree, int(max_pops),
+                                                      ctypes.addressof(n)))
         self.frontier = int(n.value)
         return self.frontier
 
