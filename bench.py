@@ -131,6 +131,29 @@ def _cpu_worker(job):
     return orc.n_solves, part.visits, time.perf_counter() - t0
 
 
+def usable_cores():
+    """Cores this process may really use: the affinity mask and the cgroup CPU quota cap
+    os.cpu_count() (a container on a 256-thread host is typically given far fewer)."""
+    n = os.cpu_count() or 1
+    try:
+        n = min(n, len(os.sched_getaffinity(0)))
+    except (AttributeError, OSError):
+        pass
+    try:
+        quota, period = open('/sys/fs/cgroup/cpu.max').read().split()[:2]       # cgroup v2
+        if quota != 'max':
+            n = min(n, max(1, int(float(quota) / float(period) + 0.5)))
+    except (OSError, ValueError):
+        try:                                                                    # cgroup v1
+            quota = int(open('/sys/fs/cgroup/cpu/cpu.cfs_quota_us').read())
+            period = int(open('/sys/fs/cgroup/cpu/cpu.cfs_period_us').read())
+            if quota > 0:
+                n = min(n, max(1, int(quota / float(period) + 0.5)))
+        except (OSError, ValueError):
+            pass
+    return n
+
+
 def cpu_baseline(workload, seed, eps_a, eps_r, seconds):
     """
     The oracle (CPU restatement of lib/worker.py + lib/oracle.py, HiGHS) on ALL host cores, laid
@@ -144,7 +167,8 @@ def cpu_baseline(workload, seed, eps_a, eps_r, seconds):
     from oracle.partition_cpu import PartitionCPU
     from oracle import geometry
     from explicit_hybrid_mpc_amd import examples
-    cores = os.cpu_count() or 1
+    host_cores = os.cpu_count() or 1
+    cores = usable_cores()
     mpc = make_mpc(workload, seed)
     V = examples.box_vertices(examples.theta_box(mpc))
     roots, locs = geometry.delaunay_simplices(V)
@@ -185,9 +209,10 @@ def cpu_baseline(workload, seed, eps_a, eps_r, seconds):
     solves = sum(r[0] for r in res)
     visits = sum(r[1] for r in res)
     busy = max(r[2] for r in res)
-    return dict(value=solves / busy, unit='LP solves/s', cores=n_proc, host_cores=cores,
+    return dict(value=solves / busy, unit='LP solves/s', cores=n_proc, host_cores=host_cores,
+                usable_cores=cores,
                 kind='port',
-                sample='%d processes (one per core; the top of the partition, %d node visits / '
+                sample='%d processes (one per usable core: affinity / cgroup quota; the top of the partition, %d node visits / '
                        '%d LP solves in %.1f s on one core, produced %d tasks, dealt round-robin), '
                        '%.1f s each on the same partition: %d node visits, %d HiGHS LP solves '
                        '(oracle/partition_cpu.py; %.1f s wall incl. process start)' %

@@ -23,9 +23,12 @@ namespace EHM2_NS {
     carve_node(nb, sm + shared_doubles(P) + (size_t)wave * wave_doubles, P.p, P.n_u)
 
 // ---- a2: P_theta_delta batch / its feasibility form; instances sorted by commutation -----
+// (compiled once per kind: with the kind a compile-time constant the assembly of the other kinds
+// is not in the kernel, which is what keeps it near the register budget)
+template <int feas>
 __global__ __launch_bounds__(EHM_K2_THREADS) void k2_point_batch(
     DevProblem P, long long n_inst, const double* __restrict__ theta,
-    const int32_t* __restrict__ seg, int feas, double* __restrict__ J, double* __restrict__ u0,
+    const int32_t* __restrict__ seg, double* __restrict__ J, double* __restrict__ u0,
     int32_t* __restrict__ status, int32_t* __restrict__ iters, DevCounters* cnt,
     int wave_doubles, K2Gather G) {
     K2_PROLOGUE();
@@ -83,9 +86,10 @@ __global__ __launch_bounds__(EHM_K2_THREADS) void k2_point_batch(
 }
 
 // ---- a5 / a7': problems over a simplex, one commutation per instance (sorted) -------------
+template <int mode>
 __global__ __launch_bounds__(EHM_K2_THREADS) void k2_simplex_batch(
     DevProblem P, long long n_inst, const double* __restrict__ R,
-    const double* __restrict__ Vbar, const int32_t* __restrict__ seg, int mode,
+    const double* __restrict__ Vbar, const int32_t* __restrict__ seg,
     double* __restrict__ obj, double* __restrict__ alpha, int32_t* __restrict__ status,
     int32_t* __restrict__ iters, DevCounters* cnt, int wave_doubles, K2Gather G) {
     K2_PROLOGUE();
@@ -856,7 +860,10 @@ namespace {
 using namespace EHM2_NS;
 
 hipError_t set_lds(int bytes) {
-    const void* ks[] = {(const void*)k2_point_batch, (const void*)k2_simplex_batch,
+    const void* ks[] = {(const void*)k2_point_batch<0>, (const void*)k2_point_batch<1>,
+                        (const void*)k2_simplex_batch<SX_MIN>,
+                        (const void*)k2_simplex_batch<SX_SLACK>,
+                        (const void*)k2_simplex_batch<SX_FEAS>,
                         (const void*)k2_lcss_decide, (const void*)k2_lcss_expand,
                         (const void*)k2_vertex_solve, (const void*)k2_persist};
     for (const void* k : ks) {
@@ -874,15 +881,23 @@ size_t shared_doubles_for(const DevProblem& P) { return shared_doubles(P); }
 void l_point(const K2Launch& L, DevProblem P, long long n_inst, const double* theta,
              const int32_t* seg, int feas, double* J, double* u0, int32_t* status,
              int32_t* iters, DevCounters* cnt, K2Gather G) {
-    hipLaunchKernelGGL(k2_point_batch, dim3(L.grid), dim3(L.threads), L.lds_bytes, L.stream, P,
-                       n_inst, theta, seg, feas, J, u0, status, iters, cnt, L.wave_doubles, G);
+    if (feas)
+        hipLaunchKernelGGL(k2_point_batch<1>, dim3(L.grid), dim3(L.threads), L.lds_bytes, L.stream,
+                           P, n_inst, theta, seg, J, u0, status, iters, cnt, L.wave_doubles, G);
+    else
+        hipLaunchKernelGGL(k2_point_batch<0>, dim3(L.grid), dim3(L.threads), L.lds_bytes, L.stream,
+                           P, n_inst, theta, seg, J, u0, status, iters, cnt, L.wave_doubles, G);
 }
 void l_simplex(const K2Launch& L, DevProblem P, long long n_inst, const double* R,
                const double* Vbar, const int32_t* seg, int mode, double* obj, double* alpha,
                int32_t* status, int32_t* iters, DevCounters* cnt, K2Gather G) {
-    hipLaunchKernelGGL(k2_simplex_batch, dim3(L.grid), dim3(L.threads), L.lds_bytes, L.stream,
-                       P, n_inst, R, Vbar, seg, mode, obj, alpha, status, iters, cnt,
-                       L.wave_doubles, G);
+#define K2_SX_LAUNCH(M)                                                                      \
+    hipLaunchKernelGGL(k2_simplex_batch<M>, dim3(L.grid), dim3(L.threads), L.lds_bytes, L.stream, \
+                       P, n_inst, R, Vbar, seg, obj, alpha, status, iters, cnt, L.wave_doubles, G)
+    if (mode == SX_SLACK) K2_SX_LAUNCH(SX_SLACK);
+    else if (mode == SX_FEAS) K2_SX_LAUNCH(SX_FEAS);
+    else K2_SX_LAUNCH(SX_MIN);
+#undef K2_SX_LAUNCH
 }
 void l_decide(const K2Launch& L, DevProblem P, DevTree T, const int32_t* frontier, int nf,
               int32_t* open_flag, DevCounters* cnt, int sign_only) {
