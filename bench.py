@@ -302,6 +302,7 @@ def main():
     if not wide:
         gp.set_solver(args.solver)
     gp.set_option('decide_full', 1 if args.decide_full else 0)
+    gp.set_option('timing', 1)           # kernel seconds / solves by kind of the hybrid engine
     if args.no_mid_first:
         gp.set_option('mid_first', 0)
     hybrid = args.workload == 'config3'

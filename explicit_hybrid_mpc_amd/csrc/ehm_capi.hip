@@ -481,6 +481,8 @@ struct ehm_problem {
     bool v1_ok = false;      // the generation-1 kernels fit this problem
     int decide_full = 0;     // 1 = the suboptimality test solves to full accuracy (no sign-only stop)
     int mid_first = 1;       // 1 = persistent kernel with the midpoint solve first (default)
+    int hy_timing = 0;       // 1 = event pairs + counter snapshots around every batch of the
+                             // multi-commutation engine (kernel seconds, solves by kind)
     int solver_gen = 2;      // 1 = one wavefront per workgroup (ehm_kernels.h), 2 = ehm_k2.hip
     DevBuf seg;              // commutation segment offsets of a sorted batch
     std::set<const K2Api*> k2_ready;
@@ -925,6 +927,10 @@ int ehm_problem_set_option(ehm_problem* P, const char* name, double value) {
     if (!strcmp(name, "solver")) return ehm_problem_set_solver(P, (int)value);
     if (!strcmp(name, "decide_full")) {
         P->decide_full = value != 0.0;
+        return EHM_OK;
+    }
+    if (!strcmp(name, "timing")) {
+        P->hy_timing = value != 0.0;
         return EHM_OK;
     }
     if (!strcmp(name, "mid_first")) {

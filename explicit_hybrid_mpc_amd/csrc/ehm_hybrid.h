@@ -776,6 +776,7 @@ struct HyList {      // the work list sitting in H.src / H.dst / seg
 
 // event pair + counter snapshot around a batched launch: kernel seconds and iterations by LP kind
 static void hy_stamp(ehm_tree* T) {
+    if (!T->prob->hy_timing) return;
     hipEvent_t e;
     (void)hipEventCreate(&e);
     (void)hipEventRecord(e, T->prob->stream);
@@ -783,6 +784,7 @@ static void hy_stamp(ehm_tree* T) {
 }
 static void hy_after_batch(ehm_tree* T, int lp_kind, int family) {
     HyState& H = *T->hy;
+    if (!T->prob->hy_timing) return;
     hy_stamp(T);
     T->run.ev_kind.push_back(family);
     if (H.snap_kind.size() < HY_MAX_SNAPS) {

@@ -104,7 +104,10 @@ int ehm_problem_set_solver(ehm_problem* prob, int generation);
  * accuracy (EHM_DECIDE_FULL=1 at create time does the same); "mid_first" (0|1, default 1): the
  * persistent frontier kernel solves a node's midpoint problem before its suboptimality test and
  * skips the test when the midpoint already proves the node open (42 % of the open nodes of the
- * bench tree; identical tree, tests/test_gpu_kernel_generations.py; EHM_MID_FIRST=0|1). */
+ * bench tree; identical tree, tests/test_gpu_kernel_generations.py; EHM_MID_FIRST=0|1);
+ * "timing" (0|1, default 0): multi-commutation runs record an event pair and a counter snapshot
+ * around every batched launch, so that ehm_tree_info carries kernel seconds and solves by problem
+ * kind (bench.py sets it; ~25 extra stream commands per sweep otherwise spared). */
 int ehm_problem_set_option(ehm_problem* prob, const char* name, double value);
 /* Environment switches read by the library (experiments and A/B measurements; none is needed):
  *   EHM_SOLVER=1|2, EHM_DECIDE_FULL=1   at ehm_problem_create, as the options above;
