@@ -290,9 +290,11 @@ def main():
     wide = args.workload == 'config4'
     hybrid = args.workload == 'config3'
     if args.abs_frac is None:
-        args.abs_frac = {'config4': 0.4, 'config3': CONFIG3[0]}.get(args.workload, 0.02)
+        args.abs_frac = {'config4': 0.4, 'config3': CONFIG3[0],
+                         'config2q': 0.1}.get(args.workload, 0.02)
     if args.eps_r is None:
-        args.eps_r = {'config4': 0.25, 'config3': CONFIG3[1]}.get(args.workload, 1e-2)
+        args.eps_r = {'config4': 0.25, 'config3': CONFIG3[1],
+                      'config2q': 0.1}.get(args.workload, 1e-2)
     if args.max_depth is None:
         args.max_depth = CONFIG3[2] if hybrid else 0
     quad = args.workload == 'config2q'
