@@ -381,3 +381,60 @@ def test_config5_shaped_instance_on_the_engine():
             assert np.allclose(flat.vertex_costs[kd], ref['vertex_costs'], rtol=RTOL, atol=RTOL)
             checked += 1
     assert checked >= 1
+
+
+def test_cwh_z_job3_subforests_identical_to_cpu_oracle():
+    """
+    The reference's own law at depth: third cwh_z job (make_jobs.sh:60-66: abs_frac 0.1, rel_err
+    0.1; 9 484 leaves, 81 commutations, QP / QCQP oracles).  Nodes sampled from the device tree
+    are grown again by the CPU oracle (uncondensed models, oracle/qp_numpy.py; a few visits
+    each); what it decides must be what the device decided.
+    """
+    from explicit_hybrid_mpc_amd import examples
+    from oracle.oracle_cpu import OracleCPU, SolverError
+    from oracle.partition_cpu import PartitionCPU
+    from oracle.satellite_cpu import SatelliteZCPU
+    from oracle import geometry
+    full_set, part, oracle = examples.example('cwh_z', abs_frac=0.1, rel_err=0.1)
+    roots, locs = geometry.delaunay_simplices(full_set)
+    flat = oracle.gpu.partition(np.array(roots), action='ecc', max_nodes=1 << 20)
+    eps_a, eps_r = oracle.eps_a, oracle.eps_r
+    oracle.close()
+    assert flat.info['n_leaves'] == 9484 and flat.info['swaps'] > 0
+    total = np.prod(2 * examples.theta_box(oracle.mpc))
+    assert abs(flat.info['volume_closed'] - total) <= 1e-9 * total
+    loc = flat.locations(locs)
+    pos = {name: k for k, name in enumerate(loc)}
+    tol = 1e-6 * (1. + np.abs(flat.vertex_costs[:, 0]))
+    cand = [k for k in range(flat.n_nodes) if (flat.flags[k] & 2) and not flat.is_leaf(k)
+            and len(loc[k]) >= 8]
+    rng = np.random.default_rng(3)
+    picks = rng.choice(cand, size=20, replace=False)
+    orc = OracleCPU(SatelliteZCPU(4), eps_a, eps_r)
+    orc.memoize = True
+    decided = 0
+    for k in picks:
+        root = dict(vertices=flat.vertices[k].copy(),
+                    commutation=flat.deltas[flat.delta_idx[k]].copy(),
+                    vertex_costs=flat.vertex_costs[k].copy(),
+                    vertex_inputs=flat.vertex_inputs[k].copy(),
+                    is_epsilon_suboptimal=False, leaf=True)
+        cpu = PartitionCPU(orc, max_nodes=6)
+        try:
+            cpu.run([root], [loc[k]], 'lcss')
+        except SolverError:
+            continue                # the checker's own QP method gave up on this instance
+        for name, ref in cpu.nodes.items():
+            kd = pos[name]
+            assert np.array_equal(flat.vertices[kd], ref['vertices']), name
+            if ref['leaf'] and not ref['is_epsilon_suboptimal']:
+                continue
+            if abs(flat.tstar[kd]) < tol[kd]:
+                continue            # near-threshold: two solvers may part ways here
+            assert flat.is_leaf(kd) == ref['leaf'], name
+            assert bool(flat.flags[kd] & 1) == ref['is_epsilon_suboptimal'], name
+            assert np.array_equal(flat.deltas[flat.delta_idx[kd]].astype(int),
+                                  ref['commutation'].astype(int)), name
+            assert np.allclose(flat.vertex_costs[kd], ref['vertex_costs'], rtol=1e-6, atol=1e-9)
+            decided += 1
+    assert decided >= 50
