@@ -37,6 +37,9 @@ KPM_INSTANCES = KP_INSTANCES
 # wide kernels (ehm_k3.hip): row slots per thread, rows <= 256 * slots; must match the
 # ehm_k3_api_* getters in ehm_capi.hip
 K3_RS = (2, 4)
+# the single-width persistent kernel of ehm_k2.hip (quadratic handles, unlisted width pairs) runs
+# the midpoint-first flow, like the ehm_kpm objects
+MIDFIRST = '-DEHM_PERSIST_MIDFIRST=1'
 FLAGS = ['--offload-arch=gfx950', '-O3', '-std=c++17', '-fPIC', '-Wno-unused-result']
 # experiments: extra -D flags and an alternative output name, e.g.
 #   EHM_BUILD_FLAGS="-DEHM2_UNROLL=2" EHM_BUILD_TAG=u2 python -m explicit_hybrid_mpc_amd.build
@@ -68,12 +71,12 @@ def _objects():
         for sl in K2_SLOTS:
             objs.append((os.path.join(OBJ_DIR, 'ehm_k2_%d_%d.o' % (np_, sl)),
                          os.path.join(SRC_DIR, 'ehm_k2.hip'),
-                         ['-DEHM_NP=%d' % np_, '-DEHM_SLOTS=%d' % sl]))
+                         ['-DEHM_NP=%d' % np_, '-DEHM_SLOTS=%d' % sl, MIDFIRST]))
     for np_ in K2Q_NPS:
         for sl in K2_SLOTS:
             objs.append((os.path.join(OBJ_DIR, 'ehm_k2q_%d_%d.o' % (np_, sl)),
                          os.path.join(SRC_DIR, 'ehm_k2.hip'),
-                         ['-DEHM_NP=%d' % np_, '-DEHM_SLOTS=%d' % sl, '-DEHM2_QUAD=1']))
+                         ['-DEHM_NP=%d' % np_, '-DEHM_SLOTS=%d' % sl, '-DEHM2_QUAD=1', MIDFIRST]))
     for npd, npe, sl in KP_INSTANCES:
         objs.append((os.path.join(OBJ_DIR, 'ehm_kp_%d_%d_%d.o' % (npd, npe, sl)),
                      os.path.join(SRC_DIR, 'ehm_kp.hip'),

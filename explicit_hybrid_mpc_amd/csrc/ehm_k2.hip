@@ -427,8 +427,8 @@ __global__ __launch_bounds__(EHM_K2_THREADS) void k2_persist(
             }
         }
 #if EHM_PERSIST_MIDFIRST
-        // Midpoint first (EHM_PERSIST_MIDFIRST objects; NOT yet validated on the device, off by
-        // default -- DESIGN.md section 7c item 1): after the tangent-plane bound has taken out 97 %
+        // Midpoint first (-DEHM_PERSIST_MIDFIRST=1, how every instance is built since round 2;
+        // validated on the device: identical tree): after the tangent-plane bound has taken out 97 %
         // of the closed leaves, almost every node that reaches an LP is open and needs its midpoint
         // solve anyway.  Doing that solve FIRST gives a witness: at theta = mid the interpolated
         // cost is (V_bi + V_bj)/2 and the optimal cost is the solve's optimum, so
@@ -874,7 +874,10 @@ hipError_t set_lds(int bytes) {
 }
 
 size_t wave_doubles_for(const DevProblem& P, int n_lp, int ne) {
-    return k2_node_doubles(P.p, P.n_u) + wave_lp_doubles(n_lp, ne);
+    // (+16: the midpoint-first flow of k2_persist parks the midpoint solve's input and gradient
+    // in the last 16 doubles of the wavefront's workspace)
+    return k2_node_doubles(P.p, P.n_u) + wave_lp_doubles(n_lp, ne) +
+           (EHM_PERSIST_MIDFIRST ? 16 : 0);
 }
 size_t shared_doubles_for(const DevProblem& P) { return shared_doubles(P); }
 
