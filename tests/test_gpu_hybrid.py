@@ -438,3 +438,27 @@ def test_cwh_z_job3_subforests_identical_to_cpu_oracle():
             assert np.allclose(flat.vertex_costs[kd], ref['vertex_costs'], rtol=1e-6, atol=1e-9)
             decided += 1
     assert decided >= 50
+
+
+def test_hybrid_capacity_and_infeasible_set_errors():
+    """Error behaviour of the device engine: node pool exhausted -> EHM_E_CAPACITY (and the
+    handle is usable again); a set with infeasible regions -> the reference's RuntimeError
+    (lib/worker.py:266)."""
+    from explicit_hybrid_mpc_amd import engine, examples
+    from explicit_hybrid_mpc_amd._capi import EhmError, EHM_E_CAPACITY, EHM_E_INFEASIBLE
+    mpc = helpers.make_instance('pwa_small', 0)
+    eps_a = helpers.eps_a_rule(mpc, 0.25)
+    roots, locs = helpers.roots_of(mpc)
+    gp = engine.GpuProblem(mpc.compile(), eps_a, 0.2)
+    full = gp.partition(np.array(roots), action='ecc')
+    with pytest.raises(EhmError) as e:
+        gp.partition(np.array(roots), action='ecc', max_nodes=full.n_nodes // 3)
+    assert e.value.code == EHM_E_CAPACITY
+    again = gp.partition(np.array(roots), action='ecc')
+    assert again.n_nodes == full.n_nodes
+    from oracle import geometry
+    big, _ = geometry.delaunay_simplices(30 * examples.box_vertices(examples.theta_box(mpc)))
+    with pytest.raises(RuntimeError, match='Theta contains infeasible regions') as e:
+        gp.partition(np.array(big), action='ecc')
+    assert e.value.code == EHM_E_INFEASIBLE
+    gp.close()
