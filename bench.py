@@ -308,7 +308,7 @@ def main():
     if args.no_mid_first:
         gp.set_option('mid_first', 0)
     hybrid = args.workload == 'config3'
-    static = (args.balance == 'static' or hybrid) and not args.status_dir
+    static = args.balance == 'static' and not args.status_dir
     # both balancing modes run the persistent frontier kernel: static = one launch per rank,
     # dynamic = budgeted rounds of it
     persistent = (args.engine == 1 and args.solver == 2 and not wide and not hybrid and
@@ -335,7 +335,7 @@ def main():
     shard = distributed.shard_spec(rank, world, args.shard_min_frontier)
     # static: ONE persistent launch per rank from the roots, dealt at a tree depth by path code
     deal_depth = distributed.deal_depth_for(len(roots), world, 64 if hybrid else 2048) \
-        if ((static or hybrid) and world > 1) else 0
+        if (static and world > 1) else 0
 
     xdev = ('cuda:%d' % device_index) if backend == 'nccl' else None
     publisher = None
@@ -355,7 +355,7 @@ def main():
         info, log, rounds = distributed.run_balanced(
             gp, roots, action='ecc', max_nodes=args.max_nodes,
             min_frontier=args.shard_min_frontier, sweeps_per_round=args.sweeps_per_round,
-            device=xdev, export=False, status=publisher,
+            device=xdev, export=False, status=publisher, max_depth=args.max_depth,
             publish_status=bool(args.status_dir),
             engine='persistent' if (args.engine == 1 and args.solver == 2 and not wide and
                                     not hybrid) else 'sweeps')

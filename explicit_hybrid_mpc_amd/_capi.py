@@ -33,7 +33,7 @@ EXPORTED = [
     'ehm_problem_set_option', 'ehm_partition_begin', 'ehm_partition_step',
     'ehm_partition_take', 'ehm_partition_give', 'ehm_partition_finish',
     'ehm_explicit_create', 'ehm_explicit_eval_batch', 'ehm_explicit_destroy',
-    'ehm_explicit_last_error', 'ehm_partition_progress', 'ehm_partition_counts', 'ehm_partition_advance', 'ehm_problem_set_quadratic',
+    'ehm_explicit_last_error', 'ehm_partition_progress', 'ehm_partition_counts', 'ehm_partition_advance', 'ehm_partition_movable', 'ehm_problem_set_quadratic',
     'ehm_feas_all_batch', 'ehm_lcss_batch',
 ]
 
@@ -154,6 +154,7 @@ def load(build_if_missing=True):
     lib.ehm_partition_progress.argtypes = [vp, ctypes.POINTER(Progress)]
     lib.ehm_partition_counts.argtypes = [vp, vp, vp]
     lib.ehm_partition_advance.argtypes = [vp, i64, vp]
+    lib.ehm_partition_movable.argtypes = [vp, vp, vp]
     lib.ehm_explicit_create.argtypes = [i32, i64, i32, i32, i32, vp, vp, vp, vp,
                                         ctypes.POINTER(vp)]
     lib.ehm_explicit_eval_batch.argtypes = [vp, i64, vp, vp, vp, vp, vp]

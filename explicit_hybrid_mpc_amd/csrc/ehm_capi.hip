@@ -2421,7 +2421,10 @@ int ehm_partition_take(ehm_tree* T, int64_t count, int32_t* node_ids, double* re
         return fail(EHM_E_INVALID, "bad argument");
     ehm_problem* P = T->prob;
     auto& R = T->run;
-    if (T->hy) return fail(EHM_E_INVALID, "take/give: not available for multi-commutation runs");
+    if (T->hy) {
+        HIP_TRY(hipSetDevice(P->device), EHM_E_HIP);
+        return hy_take(T, count, node_ids, records, meta);
+    }
     if (count > R.nf) return fail(EHM_E_INVALID, "cannot take %lld of %lld frontier nodes",
                                   (long long)count, (long long)R.nf);
     if (count == 0) return EHM_OK;
@@ -2453,7 +2456,10 @@ int ehm_partition_give(ehm_tree* T, int64_t count, const double* records, const 
         return fail(EHM_E_INVALID, "bad argument");
     ehm_problem* P = T->prob;
     auto& R = T->run;
-    if (T->hy) return fail(EHM_E_INVALID, "take/give: not available for multi-commutation runs");
+    if (T->hy) {
+        HIP_TRY(hipSetDevice(P->device), EHM_E_HIP);
+        return hy_give(T, count, records, meta, first_id);
+    }
     if (first_id) *first_id = (int32_t)R.n_nodes;
     if (count == 0) return EHM_OK;
     if (R.n_nodes + count > T->limit)
@@ -2494,6 +2500,19 @@ int ehm_partition_counts(const ehm_tree* T, int64_t* n_nodes, int64_t* max_nodes
     if (!T || !T->run.active) return fail(EHM_E_INVALID, "no partition run in progress");
     if (n_nodes) *n_nodes = T->run.n_nodes;
     if (max_nodes) *max_nodes = T->limit;
+    return EHM_OK;
+}
+
+// What ehm_partition_take can hand over right now and how wide one record is: single-commutation
+// runs move any frontier node as rec_doubles doubles; multi-commutation runs move lcss nodes only
+// (ecc nodes carry no data yet), each with its bit rows appended (ehm_hybrid.h).
+int ehm_partition_movable(const ehm_tree* T, int64_t* movable, int32_t* record_doubles) {
+    if (!T || !T->run.active) return fail(EHM_E_INVALID, "no partition run in progress");
+    const DevProblem& dp = T->prob->dp;
+    if (movable) *movable = T->hy ? T->hy->n_lcss : T->run.nf;
+    if (record_doubles)
+        *record_doubles = T->hy ? hy_record_doubles(dp.p, dp.n_u, T->hy->nw)
+                                : rec_doubles(dp.p, dp.n_u);
     return EHM_OK;
 }
 

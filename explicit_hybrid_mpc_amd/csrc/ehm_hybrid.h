@@ -1190,7 +1190,7 @@ static int hy_begin(ehm_tree* T, int64_t n_roots, const ehm_node_init* init) {
     HIP_TRY(hipMemcpyAsync(H.ctr.ptr, &h, sizeof h, hipMemcpyHostToDevice, P->stream), EHM_E_HIP);
     HIP_TRY(hipStreamSynchronize(P->stream), EHM_E_HIP);      // didx / flags / h leave scope
     T->dt.code = nullptr;
-    if (R.shard_world > 1) {
+    if (R.shard_world > 1 && R.shard_min >= 0) {
         if (R.deal_depth <= 0)
             return fail(EHM_E_INVALID, "sharded multi-commutation runs need ehm_run_opts.deal_depth");
         H.deal = PersistDeal{0, R.deal_depth, R.shard_rank, R.shard_world, 1};
@@ -1218,6 +1218,23 @@ static int hy_begin(ehm_tree* T, int64_t n_roots, const ehm_node_init* init) {
                            (const hy_u64*)nullptr, H.ask.as<hy_u64>(), H.tau.as<double>(),
                            EHM_FEAS_TOL, H.vf.as<hy_u64>() + (size_t)r0 * nw);
         P->launches += 2;
+    }
+    if (R.shard_world > 1 && R.shard_rank > 0 && R.shard_min < 0) {
+        // dynamic balancing from a single source: this rank starts with nothing
+        std::vector<uint8_t> fl((size_t)n_roots, (uint8_t)(flags[0] | 4));
+        HIP_TRY(hipMemcpyAsync(T->dt.flags, fl.data(), fl.size(), hipMemcpyHostToDevice,
+                               P->stream), EHM_E_HIP);
+        HIP_TRY(hipStreamSynchronize(P->stream), EHM_E_HIP);
+        H.cur = 0;
+        H.n_ecc = H.n_lcss = 0;
+        R.nf = 0;
+        R.sharded = true;
+        R.pre_nodes = n_roots;
+        T->unordered = true;
+        T->keep_ids = true;
+        int rc2;
+        if ((rc2 = H.fr_lcss[0].ensure(4096)) || (rc2 = H.fr_ecc[0].ensure(4096))) return rc2;
+        return EHM_OK;
     }
     DevBuf& f0 = (R.action == 1) ? H.fr_lcss[0] : H.fr_ecc[0];
     if ((rc = f0.ensure((size_t)n_roots * 4))) return rc;
@@ -1251,5 +1268,148 @@ static int hy_kind_totals(ehm_tree* T, int64_t (&solves)[5], int64_t (&iters)[5]
         iters[H.snap_kind[i]] += (int64_t)(c[i].ipm_iters - prev.ipm_iters);
         prev = c[i];
     }
+    return EHM_OK;
+}
+
+// ---- frontier hand-over between ranks (ehm_partition_take / _give for multi-commutation runs) ---
+// A node travels with what the engine knows about it: record | vf rows | cand | neg | black (bit
+// rows as raw 64-bit words in double slots) | tneg.  Only lcss nodes (they carry data) move.
+__host__ __device__ inline int hy_record_doubles(int p, int n_u, int nw) {
+    return rec_doubles(p, n_u) + (p + 1 + 3) * nw + 1;
+}
+__global__ void hy_take_nodes(DevTree T, const int32_t* __restrict__ ids, int n, int nw,
+                              const hy_u64* __restrict__ vf, const hy_u64* __restrict__ cand,
+                              const hy_u64* __restrict__ neg, const hy_u64* __restrict__ black,
+                              const double* __restrict__ tneg, double* __restrict__ out,
+                              int32_t* __restrict__ meta) {
+    const int k = blockIdx.x;
+    if (k >= n) return;
+    const int id = ids[k];
+    const int p = T.p, nv = p + 1, nrec = rec_doubles(p, T.n_u);
+    const int W = hy_record_doubles(p, T.n_u, nw);
+    double* row = out + (size_t)k * W;
+    const double* r = T.rec + (size_t)id * T.rec_stride;
+    for (int q = threadIdx.x; q < nrec; q += blockDim.x) row[q] = r[q];
+    hy_u64* bits = reinterpret_cast<hy_u64*>(row + nrec);
+    for (int q = threadIdx.x; q < nv * nw; q += blockDim.x) bits[q] = vf[(size_t)id * nv * nw + q];
+    for (int q = threadIdx.x; q < nw; q += blockDim.x) {
+        bits[nv * nw + q] = cand[(size_t)id * nw + q];
+        bits[(nv + 1) * nw + q] = neg[(size_t)id * nw + q];
+        bits[(nv + 2) * nw + q] = black[(size_t)id * nw + q];
+    }
+    if (threadIdx.x == 0) {
+        row[W - 1] = tneg[id];
+        meta[2 * k] = T.didx[id];
+        meta[2 * k + 1] = T.depth[id];
+        T.flags[id] |= 4;                      // subtree now owned by another rank
+    }
+}
+__global__ void hy_give_nodes(DevTree T, int first, int n, int nw, const double* __restrict__ in,
+                              const int32_t* __restrict__ meta, hy_u64* __restrict__ vf,
+                              hy_u64* __restrict__ cand, hy_u64* __restrict__ neg,
+                              hy_u64* __restrict__ black, double* __restrict__ tneg,
+                              int32_t* __restrict__ frontier, int frontier_at) {
+    const int k = blockIdx.x;
+    if (k >= n) return;
+    const int id = first + k;
+    const int p = T.p, nv = p + 1, nrec = rec_doubles(p, T.n_u);
+    const int W = hy_record_doubles(p, T.n_u, nw);
+    const double* row = in + (size_t)k * W;
+    double* r = T.rec + (size_t)id * T.rec_stride;
+    for (int q = threadIdx.x; q < nrec; q += blockDim.x) r[q] = row[q];
+    const hy_u64* bits = reinterpret_cast<const hy_u64*>(row + nrec);
+    for (int q = threadIdx.x; q < nv * nw; q += blockDim.x) vf[(size_t)id * nv * nw + q] = bits[q];
+    for (int q = threadIdx.x; q < nw; q += blockDim.x) {
+        cand[(size_t)id * nw + q] = bits[nv * nw + q];
+        neg[(size_t)id * nw + q] = bits[(nv + 1) * nw + q];
+        black[(size_t)id * nw + q] = bits[(nv + 2) * nw + q];
+    }
+    if (threadIdx.x == 0) {
+        tneg[id] = row[W - 1];
+        T.left[id] = -1;
+        T.didx[id] = meta[2 * k];
+        T.depth[id] = meta[2 * k + 1];
+        T.flags[id] = 2 | 32;                  // has data, received from another rank
+        T.tstar[id] = 0.0;
+        if (T.code) T.code[id] = 0u;
+        frontier[frontier_at + k] = id;
+    }
+}
+
+static int hy_take(ehm_tree* T, int64_t count, int32_t* node_ids, double* records, int32_t* meta) {
+    ehm_problem* P = T->prob;
+    HyState& H = *T->hy;
+    auto& R = T->run;
+    if (count > H.n_lcss)
+        return fail(EHM_E_INVALID, "cannot take %lld of %lld movable frontier nodes",
+                    (long long)count, H.n_lcss);
+    if (count == 0) return EHM_OK;
+    const int W = hy_record_doubles(P->dp.p, P->dp.n_u, H.nw);
+    int rc;
+    if ((rc = P->out0.ensure((size_t)count * W * sizeof(double)))) return rc;
+    if ((rc = P->out2.ensure((size_t)count * 2 * sizeof(int32_t)))) return rc;
+    const int32_t* cur = H.fr_lcss[H.cur].as<int32_t>() + (H.n_lcss - count);
+    hipLaunchKernelGGL(hy_take_nodes, dim3((unsigned)count), dim3(64), 0, P->stream, T->dt, cur,
+                       (int)count, H.nw, H.vf.as<hy_u64>(), H.cand.as<hy_u64>(),
+                       H.neg.as<hy_u64>(), H.black.as<hy_u64>(), H.tneg.as<double>(),
+                       P->out0.as<double>(), P->out2.as<int32_t>());
+    HIP_TRY(hipMemcpyAsync(node_ids, cur, (size_t)count * 4, hipMemcpyDeviceToHost, P->stream),
+            EHM_E_HIP);
+    HIP_TRY(hipMemcpyAsync(records, P->out0.ptr, (size_t)count * W * sizeof(double),
+                           hipMemcpyDeviceToHost, P->stream), EHM_E_HIP);
+    HIP_TRY(hipMemcpyAsync(meta, P->out2.ptr, (size_t)count * 2 * sizeof(int32_t),
+                           hipMemcpyDeviceToHost, P->stream), EHM_E_HIP);
+    HIP_TRY(hipStreamSynchronize(P->stream), EHM_E_HIP);
+    H.n_lcss -= count;
+    R.nf -= count;
+    R.given += count;
+    T->keep_ids = true;
+    return EHM_OK;
+}
+
+static int hy_give(ehm_tree* T, int64_t count, const double* records, const int32_t* meta,
+                   int32_t* first_id) {
+    ehm_problem* P = T->prob;
+    HyState& H = *T->hy;
+    auto& R = T->run;
+    if (first_id) *first_id = (int32_t)R.n_nodes;
+    if (count == 0) return EHM_OK;
+    if (R.n_nodes + count > T->limit)
+        return fail(EHM_E_CAPACITY, "node pool exhausted at %lld nodes (max_nodes=%lld)",
+                    R.n_nodes, T->limit);
+    const int W = hy_record_doubles(P->dp.p, P->dp.n_u, H.nw);
+    int rc;
+    if ((rc = P->in0.ensure((size_t)count * W * sizeof(double)))) return rc;
+    if ((rc = P->in1.ensure((size_t)count * 2 * sizeof(int32_t)))) return rc;
+    DevBuf& fb = H.fr_lcss[H.cur];
+    if ((long long)fb.cap < (H.n_lcss + count) * 4) {
+        DevBuf bigger;
+        if ((rc = bigger.ensure((size_t)(H.n_lcss + count) * 4 * 2))) return rc;
+        if (H.n_lcss > 0)
+            HIP_TRY(hipMemcpyAsync(bigger.ptr, fb.ptr, (size_t)H.n_lcss * 4,
+                                   hipMemcpyDeviceToDevice, P->stream), EHM_E_HIP);
+        HIP_TRY(hipStreamSynchronize(P->stream), EHM_E_HIP);
+        std::swap(bigger, fb);
+        bigger.release();
+    }
+    HIP_TRY(hipMemcpyAsync(P->in0.ptr, records, (size_t)count * W * sizeof(double),
+                           hipMemcpyHostToDevice, P->stream), EHM_E_HIP);
+    HIP_TRY(hipMemcpyAsync(P->in1.ptr, meta, (size_t)count * 2 * sizeof(int32_t),
+                           hipMemcpyHostToDevice, P->stream), EHM_E_HIP);
+    hipLaunchKernelGGL(hy_give_nodes, dim3((unsigned)count), dim3(64), 0, P->stream, T->dt,
+                       (int)R.n_nodes, (int)count, H.nw, P->in0.as<double>(),
+                       P->in1.as<int32_t>(), H.vf.as<hy_u64>(), H.cand.as<hy_u64>(),
+                       H.neg.as<hy_u64>(), H.black.as<hy_u64>(), H.tneg.as<double>(),
+                       fb.as<int32_t>(), (int)H.n_lcss);
+    // the device-side allocation counter follows
+    HyCtr* ctr = H.ctr.as<HyCtr>();
+    const int n_new = (int)(R.n_nodes + count);
+    HIP_TRY(hipMemcpyAsync(&ctr->n_nodes, &n_new, 4, hipMemcpyHostToDevice, P->stream), EHM_E_HIP);
+    HIP_TRY(hipStreamSynchronize(P->stream), EHM_E_HIP);
+    R.n_nodes += count;
+    H.n_lcss += count;
+    R.nf += count;
+    R.received += count;
+    T->keep_ids = true;
     return EHM_OK;
 }

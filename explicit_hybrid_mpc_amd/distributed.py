@@ -199,7 +199,7 @@ def _publish(status, worker, run, live, device, rank, force=False):
 def run_balanced(gp, roots, action='ecc', init=None, max_nodes=0, min_frontier=1024,
                  sweeps_per_round=3, tolerance=0.1, min_move=16, device=None, export=False,
                  with_volume=False, run_factory=None, status=None, publish_status=False,
-                 engine='sweeps', pops_per_round=4096, pops_max=1 << 17):
+                 engine='sweeps', pops_per_round=4096, pops_max=1 << 17, max_depth=0):
     """
     One partition over all ranks with periodic rebalancing of the live frontiers.
     Returns (FlatTree or info dict of THIS rank's share, transfer log, rounds).
@@ -217,13 +217,16 @@ def run_balanced(gp, roots, action='ecc', init=None, max_nodes=0, min_frontier=1
     if not (dist.is_available() and dist.is_initialized()):
         world, rank = 1, 0
     persistent = engine == 'persistent'
-    shard = shard_spec(rank, world, -1 if persistent else min_frontier)
+    # multi-commutation problems are balanced from a single source too (sweep rounds)
+    hybrid = gp is not None and getattr(gp.can, 'n_delta', 1) > 1
+    persistent = persistent and not hybrid
+    shard = shard_spec(rank, world, -1 if (persistent or hybrid) else min_frontier)
     budget = int(pops_per_round)
     if run_factory is not None:
         run = run_factory(shard)
     else:
         run = gp.begin(roots, action=action, init=init, max_nodes=max_nodes, shard=shard,
-                       with_volume=with_volume)
+                       with_volume=with_volume, max_depth=max_depth)
     log, rnd = [], 0
     worker = None
     if publish_status:
@@ -263,7 +266,8 @@ def run_balanced(gp, roots, action='ecc', init=None, max_nodes=0, min_frontier=1
             continue
         # frontier size (-1 = this rank failed) and free pool of every rank: ONE small all-gather
         free = run.free_nodes() if (err is None and hasattr(run, 'free_nodes')) else (1 << 62)
-        info = allgather_counts([n, free], device=device)
+        mov = run.movable() if (err is None and hasattr(run, 'movable')) else max(n, 0)
+        info = allgather_counts([n, free, mov], device=device)
         if (info[:, 0] < 0).any():
             fail_everywhere(err, [int(r) for r in np.nonzero(info[:, 0] < 0)[0]])
         if publish_status:
@@ -276,7 +280,8 @@ def run_balanced(gp, roots, action='ecc', init=None, max_nodes=0, min_frontier=1
         # a receiver is never sent more than its pool can take (every rank derives the same plan)
         room = [int(v) for v in info[:, 1]]
         plan = []
-        for donor, receiver, k in balance_plan(counts, tolerance, min_move):
+        # planned on what can move (multi-commutation runs: nodes that carry data)
+        for donor, receiver, k in balance_plan(info[:, 2], tolerance, min_move):
             k = min(k, max(0, room[receiver] - 2 * int(counts[receiver]) - 64))
             if k >= min_move:
                 plan.append((donor, receiver, k))

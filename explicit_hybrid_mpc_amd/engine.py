@@ -391,7 +391,9 @@ class PartitionRun:
         check(self._lib.ehm_partition_begin(gp._handle, n_roots, ptr(roots), init_struct,
                                             ctypes.byref(opts), ctypes.byref(self._tree)))
         del keep
-        self.nrec = (can.p + 1) * can.p + (can.p + 1) + (can.p + 1) * can.n_u
+        w = ctypes.c_int32(0)
+        check(self._lib.ehm_partition_movable(self._tree, None, ctypes.addressof(w)))
+        self.nrec = int(w.value)       # doubles per travelling record (hybrid: + bit rows)
         self.frontier = n_roots
 
     def abort(self):
@@ -438,6 +440,12 @@ class PartitionRun:
         check(self._lib.ehm_partition_progress(self._tree, ctypes.byref(pr)))
         return {name: getattr(pr, name) for name, _ in _capi.Progress._fields_
                 if name != 'reserved'}
+
+    def movable(self):
+        """Frontier nodes ``take`` can hand over right now (hybrid runs: lcss nodes only)."""
+        n = ctypes.c_int64(0)
+        check(self._lib.ehm_partition_movable(self._tree, ctypes.addressof(n), None))
+        return int(n.value)
 
     def free_nodes(self):
         """Node records this run may still allocate (ehm_partition_counts)."""

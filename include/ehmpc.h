@@ -298,6 +298,12 @@ int ehm_partition_advance(ehm_tree* tree, int64_t max_pops, int64_t* frontier_si
  * the capacity of this run (max_nodes).  The multi-GPU driver checks a receiver's free pool
  * before it plans a transfer (explicit_hybrid_mpc_amd/distributed.py). */
 int ehm_partition_counts(const ehm_tree* tree, int64_t* n_nodes, int64_t* max_nodes);
+/* What ehm_partition_take can hand over right now, and the width of one record in doubles:
+ * single-commutation runs move any frontier node ([vertices | costs | inputs]); multi-commutation
+ * runs move lcss nodes only, each with the engine's bit rows appended (feasibility per vertex,
+ * candidates, inherited verdicts, blacklist: csrc/ehm_hybrid.h).  records of take / give are
+ * [count][record_doubles]. */
+int ehm_partition_movable(const ehm_tree* tree, int64_t* movable, int32_t* record_doubles);
 int ehm_partition_progress(ehm_tree* tree, ehm_progress* out);
 
 typedef struct ehm_tree_info {

@@ -126,3 +126,53 @@ def test_budgeted_persistent_rounds_from_a_single_source():
         assert not (merged.flags[k] & 4)
         assert np.allclose(merged.vertex_costs[k], ref.vertex_costs[j], rtol=1e-9, atol=1e-12)
     assert sum(int(p.info['n_closed']) for p in parts) == int(np.sum((ref.flags & 1) > 0))
+
+
+def test_hybrid_nodes_travel_with_their_bit_rows():
+    """
+    take / give on the multi-commutation engine: a node moves with its feasibility rows,
+    candidate set, inherited verdicts and blacklist.  Rank 0 owns the roots, rank 1 starts empty;
+    the merged shares are the tree one run grows (commutations included).
+    """
+    from explicit_hybrid_mpc_amd import distributed, engine
+    mpc = helpers.make_instance('pwa_small', 0)
+    eps_a = helpers.eps_a_rule(mpc, 0.25)
+    roots, locs = helpers.roots_of(mpc)
+    roots = np.array(roots)
+    gps = [engine.GpuProblem(mpc.compile(), eps_a, 0.2) for _ in range(3)]
+    ref = gps[2].partition(roots, action='ecc')
+    world = 2
+    runs = [gps[r].begin(roots, shard=(r, world, -1)) for r in range(world)]
+    assert runs[0].nrec > 2 * 3 + 3 + 3          # record + bit rows
+    logs = [[] for _ in range(world)]
+    rnd = moved = 0
+    while True:
+        counts = [run.step(1) for run in runs]
+        if sum(counts) == 0:
+            break
+        mov = [run.movable() for run in runs]
+        for donor, receiver, n in distributed.balance_plan(mov, tolerance=0.02, min_move=2):
+            ids, rec, meta = runs[donor].take(n)
+            first = runs[receiver].give(rec, meta)
+            logs[donor].append(dict(kind='give', round=rnd, peer=receiver, ids=ids))
+            logs[receiver].append(dict(kind='recv', round=rnd, peer=donor, first=first, count=n))
+            moved += n
+        rnd += 1
+    parts = [run.finish(export=True) for run in runs]
+    for g in gps:
+        g.close()
+    assert moved > 0 and parts[1].info['n_closed'] > 0
+    received = distributed.resolve_received(parts, logs, locs)
+    merged = distributed.merge_flat(parts, locs, received)
+    assert merged.n_nodes == ref.n_nodes
+    rloc, mloc = ref.locations(locs), merged.locations(locs)
+    ridx = {n: k for k, n in enumerate(rloc)}
+    assert set(rloc) == set(mloc)
+    for k, name in enumerate(mloc):
+        j = ridx[name]
+        assert np.array_equal(merged.vertices[k], ref.vertices[j])
+        assert merged.is_leaf(k) == ref.is_leaf(j)
+        assert (merged.flags[k] & 3) == (ref.flags[j] & 3)
+        assert merged.delta_idx[k] == ref.delta_idx[j]
+        assert np.allclose(merged.vertex_costs[k], ref.vertex_costs[j], rtol=1e-9, atol=1e-12)
+    assert sum(int(p.info['n_closed']) for p in parts) == int(np.sum((ref.flags & 1) > 0))
