@@ -1,0 +1,74 @@
+"""
+The bounds a branch-and-bound over mode prefixes would use (DESIGN.md section 7c item 1,
+oracle/prefix_bb.py), checked against enumeration on instances small enough to enumerate, and
+the search itself on config 5's shape at N = 8 (65 536 sequences).  CPU only.
+"""
+
+import itertools
+import numpy as np
+
+from explicit_hybrid_mpc_amd import examples
+from oracle import prefix_bb
+from oracle.oracle_cpu import OracleCPU
+from tests import helpers
+
+
+def test_prefix_relaxations_bound_every_completion():
+    mpc = helpers.make_instance('pwa_small', 0)          # 2 modes, N = 3: 8 sequences
+    orc = OracleCPU(mpc, 0.05, 0.2)
+    half = examples.theta_box(mpc)
+    rng = np.random.default_rng(0)
+    seqs = orc.sequences
+    for trial in range(6):
+        theta = rng.uniform(-0.9, 0.9, 2) * half
+        J_full = {s: (orc._point(theta, d)[2] if orc._point(theta, d)[0] else np.inf)
+                  for d, s in enumerate(seqs)}
+        R = theta + 0.15 * half * rng.uniform(-1, 1, (3, 2))
+        R = np.clip(R, -half, half)
+        V_bar = rng.uniform(0.5, 1.5, 3) * max(0.1, min(v for v in J_full.values()
+                                                        if np.isfinite(v)) if any(
+            np.isfinite(v) for v in J_full.values()) else 0.1)
+        t_full = {s: orc.slack(R, V_bar, d)[0] for d, s in enumerate(seqs)}
+        for k in range(1, mpc.N + 1):
+            for prefix in itertools.product(range(mpc.delta_size), repeat=k):
+                comp = [s for s in seqs if s[:k] == prefix]
+                lb = prefix_bb.prefix_cost(mpc, prefix, theta)
+                assert lb <= min(J_full[s] for s in comp) + 1e-8
+                ub = prefix_bb.prefix_slack(mpc, prefix, R, V_bar, orc.eps_a, orc.eps_r)
+                assert ub >= max(t_full[s] for s in comp) - 1e-8
+                if k == mpc.N:                       # a full sequence is no relaxation
+                    assert abs(lb - J_full[prefix]) <= 1e-8 or not np.isfinite(J_full[prefix])
+
+
+def test_best_first_search_equals_enumeration():
+    mpc = examples.pwa4_mpc()                            # 4 modes, N = 4: 256 sequences
+    orc = OracleCPU(mpc, 1., 1.)
+    V = examples.box_vertices(examples.theta_box(mpc))
+    for v in V[[5, 130]]:
+        u, delta, J, _ = orc.P_theta(v)
+        Jb, seq, n_lp = prefix_bb.p_theta_bb(mpc, v)
+        assert abs(Jb - J) <= 1e-7 * (1 + abs(J))
+        assert np.array_equal(mpc.sequence_to_delta(seq).astype(int), delta.astype(int))
+        assert n_lp < 0.5 * len(orc.sequences)           # and it looked at far fewer problems
+
+
+def test_config5_scale_search():
+    """n_x = 8, n_u = 3, 4 modes, N = 8: P_theta and a bar_E verdict among 65 536 sequences."""
+    mpc = examples.pwa4_mpc(N=8)
+    V = examples.box_vertices(examples.theta_box(mpc))
+    theta = V[37]
+    J, seq, n_lp = prefix_bb.p_theta_bb(mpc, theta)
+    assert np.isfinite(J) and len(seq) == 8
+    assert n_lp < 4 ** 8 / 50                            # a small fraction of the enumeration
+    # its optimum is the optimum of the sequence it names
+    from oracle.lp_models import FixedCommutationModel
+    res = prefix_bb._solve(FixedCommutationModel(mpc, seq).lp_point(theta))
+    assert res.status == 0 and abs(res.fun - J) <= 1e-8 * (1 + abs(J))
+    # a simplex around theta with vertex costs far above the optimum: some sequence is better
+    # by more than the tolerance somewhere (not closed); with huge tolerances: closed
+    E = np.vstack([np.zeros(8), np.eye(8)]) - 1. / 9.
+    R = 0.9 * theta + 0.02 * examples.theta_box(mpc) * E
+    closed, n1 = prefix_bb.bar_e_bb(mpc, R, np.full(9, 3. * J), 0.1 * J, 0.1)
+    assert not closed and n1 < 4 ** 8 / 50
+    closed, n2 = prefix_bb.bar_e_bb(mpc, R, np.full(9, 1.01 * J), 10. * J, 10.)
+    assert closed and n2 <= 4                            # every first-step prefix already has t* < 0
