@@ -33,8 +33,9 @@ EXPORTED = [
     'ehm_problem_set_option', 'ehm_partition_begin', 'ehm_partition_step',
     'ehm_partition_take', 'ehm_partition_give', 'ehm_partition_finish',
     'ehm_explicit_create', 'ehm_explicit_eval_batch', 'ehm_explicit_destroy',
-    'ehm_explicit_last_error', 'ehm_partition_progress', 'ehm_partition_counts', 'ehm_partition_advance', 'ehm_partition_movable', 'ehm_problem_set_quadratic',
-    'ehm_feas_all_batch', 'ehm_lcss_batch',
+    'ehm_explicit_last_error', 'ehm_partition_progress', 'ehm_partition_counts', 'ehm_partition_advance', 'ehm_problem_set_quadratic',
+    'ehm_feas_all_batch', 'ehm_lcss_batch', 'ehm_partition_movable',
+    'ehm_problem_update_blocks', 'ehm_simplex_idx_batch', 'ehm_point_idx_batch',
 ]
 
 
@@ -155,6 +156,9 @@ def load(build_if_missing=True):
     lib.ehm_partition_counts.argtypes = [vp, vp, vp]
     lib.ehm_partition_advance.argtypes = [vp, i64, vp]
     lib.ehm_partition_movable.argtypes = [vp, vp, vp]
+    lib.ehm_problem_update_blocks.argtypes = [vp, i32, i32, vp, vp, vp]
+    lib.ehm_simplex_idx_batch.argtypes = [vp, i64, vp, vp, vp, i32, vp, vp, vp]
+    lib.ehm_point_idx_batch.argtypes = [vp, i64, vp, vp, i32, vp, vp, vp]
     lib.ehm_explicit_create.argtypes = [i32, i64, i32, i32, i32, vp, vp, vp, vp,
                                         ctypes.POINTER(vp)]
     lib.ehm_explicit_eval_batch.argtypes = [vp, i64, vp, vp, vp, vp, vp]

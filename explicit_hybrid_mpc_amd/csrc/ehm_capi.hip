@@ -798,6 +798,61 @@ int ehm_problem_create(const ehm_problem_desc* d, int device, ehm_problem** out)
     return EHM_OK;
 }
 
+// Replaces the constant blocks of commutation slots [first, first + count): G [count][m][n],
+// w [count][m], S [count][m][p] (row-major, as in ehm_problem_desc).  Every image the kernels
+// read is rebuilt for those slots.  This is what lets a caller use the commutation table as a
+// CACHE of problems it generates on the fly -- the prefix relaxations of a branch-and-bound over
+// mode sequences (explicit_hybrid_mpc_amd/sequences.py) -- instead of a fixed enumeration.
+int ehm_problem_update_blocks(ehm_problem* P, int32_t first, int32_t count, const double* G,
+                              const double* w, const double* S) {
+    if (!P || !G || !w || !S || first < 0 || count < 0 || first + count > P->dp.n_delta)
+        return fail(EHM_E_INVALID, "bad argument");
+    if (P->active_run) return fail(EHM_E_INVALID, "a partition run is active on this handle");
+    if (count == 0) return EHM_OK;
+    HIP_TRY(hipSetDevice(P->device), EHM_E_HIP);
+    HIP_TRY(hipStreamSynchronize(P->stream), EHM_E_HIP);
+    const int n = P->dp.n, m = P->dp.m, p = P->dp.p, nd = P->dp.n_delta;
+    const size_t nG = (size_t)nd * n * m, nS = (size_t)nd * p * m;
+    double* dGt = P->consts.as<double>();
+    double* dSt = dGt + nG;
+    double* dw = dSt + nS;
+    const int lda = P->dp.lda2, ncw = P->dp.ncw2, mpad = P->dp.mpad3;
+    std::vector<double> gt((size_t)count * n * m), st((size_t)count * p * m),
+        img2((size_t)count * ncw * lda, 0.0), img3(P->dp.Wr3 ? (size_t)count * mpad * 64 : 0, 0.0);
+    for (int k = 0; k < count; ++k) {
+        double* b2 = img2.data() + (size_t)k * ncw * lda;
+        double* b3 = img3.empty() ? nullptr : img3.data() + (size_t)k * mpad * 64;
+        for (int i = 0; i < m; ++i) {
+            for (int j = 0; j < n; ++j) {
+                const double v = G[((size_t)k * m + i) * n + j];
+                gt[((size_t)k * n + j) * m + i] = v;
+                b2[(size_t)j * lda + i] = v;
+                if (b3) b3[(size_t)i * 64 + j] = v;
+            }
+            for (int q = 0; q < p; ++q) {
+                const double v = S[((size_t)k * m + i) * p + q];
+                st[((size_t)k * p + q) * m + i] = v;
+                b2[(size_t)(n + q) * lda + i] = -v;
+                if (b3) b3[(size_t)i * 64 + n + q] = -v;
+            }
+            b2[(size_t)(n + p) * lda + i] = -1.0;
+            if (b3) b3[(size_t)i * 64 + n + p] = -1.0;
+        }
+    }
+    HIP_TRY(hipMemcpy(dGt + (size_t)first * n * m, gt.data(), gt.size() * 8, hipMemcpyHostToDevice),
+            EHM_E_HIP);
+    HIP_TRY(hipMemcpy(dSt + (size_t)first * p * m, st.data(), st.size() * 8, hipMemcpyHostToDevice),
+            EHM_E_HIP);
+    HIP_TRY(hipMemcpy(dw + (size_t)first * m, w, (size_t)count * m * 8, hipMemcpyHostToDevice),
+            EHM_E_HIP);
+    HIP_TRY(hipMemcpy(P->wc2.as<double>() + (size_t)first * ncw * lda, img2.data(), img2.size() * 8,
+                      hipMemcpyHostToDevice), EHM_E_HIP);
+    if (!img3.empty())
+        HIP_TRY(hipMemcpy(P->wr3.as<double>() + (size_t)first * mpad * 64, img3.data(),
+                          img3.size() * 8, hipMemcpyHostToDevice), EHM_E_HIP);
+    return EHM_OK;
+}
+
 int ehm_problem_destroy(ehm_problem* P) {
     if (!P) return EHM_OK;
     (void)hipSetDevice(P->device);
@@ -1234,6 +1289,30 @@ int ehm_slack_batch(ehm_problem* P, int64_t n_inst, const double* R, const doubl
     int rc = map_deltas(P, n_inst, delta, didx);
     if (rc) return rc;
     return simplex_batch(P, n_inst, R, Vbar, didx.data(), 1, tstar, alpha, status);
+}
+
+// The batched problems with the commutation given as a SLOT INDEX of the table instead of a 0/1
+// vector (callers that manage the table themselves, ehm_problem_update_blocks).
+// mode: 0 = min over the simplex, 1 = suboptimality-test slack, 2 = phase one over the simplex.
+int ehm_simplex_idx_batch(ehm_problem* P, int64_t n_inst, const double* R, const double* Vbar,
+                          const int32_t* slot, int32_t mode, double* obj, double* alpha,
+                          int32_t* status) {
+    if (!P || !R || !slot || !obj || n_inst < 0 || mode < 0 || mode > 2 ||
+        (mode == SX_SLACK && !Vbar))
+        return fail(EHM_E_INVALID, "bad argument");
+    for (int64_t k = 0; k < n_inst; ++k)
+        if (slot[k] < 0 || slot[k] >= P->dp.n_delta)
+            return fail(EHM_E_INVALID, "instance %lld: slot %d out of range", (long long)k, slot[k]);
+    return simplex_batch(P, n_inst, R, Vbar, slot, mode, obj, alpha, status);
+}
+// feas = 1: phase-one form (tau out in J).
+int ehm_point_idx_batch(ehm_problem* P, int64_t n_inst, const double* theta, const int32_t* slot,
+                        int32_t feas, double* J, double* u0, int32_t* status) {
+    if (!P || !theta || !slot || !J || n_inst < 0) return fail(EHM_E_INVALID, "bad argument");
+    for (int64_t k = 0; k < n_inst; ++k)
+        if (slot[k] < 0 || slot[k] >= P->dp.n_delta)
+            return fail(EHM_E_INVALID, "instance %lld: slot %d out of range", (long long)k, slot[k]);
+    return point_batch(P, n_inst, theta, slot, feas ? 1 : 0, J, u0, status, nullptr);
 }
 
 int ehm_min_simplex_batch(ehm_problem* P, int64_t n_inst, const double* R,

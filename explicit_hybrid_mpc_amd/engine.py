@@ -265,6 +265,39 @@ class GpuProblem:
         return (closed.astype(bool), tb, cand_out.astype(bool), didx, ths, vJ, vu,
                 vs.astype(bool))
 
+    # -- the commutation table as a cache of generated problems -------------------------------
+    def update_blocks(self, first, G, w, S):
+        """Replace the blocks of slots first .. first+len(G)-1 (ehm_problem_update_blocks)."""
+        G, w, S = f64(G), f64(w), f64(S)
+        check(self._lib.ehm_problem_update_blocks(self._handle, int(first), int(G.shape[0]),
+                                                  ptr(G), ptr(w), ptr(S)))
+
+    def simplex_idx(self, R, slot, mode, Vbar=None):
+        """Problems over simplices with the commutation as a slot index: (obj, alpha, status).
+        mode 0 = min, 1 = suboptimality-test slack, 2 = phase one."""
+        R = f64(R).reshape(-1, self.can.p + 1, self.can.p)
+        n = R.shape[0]
+        slot = np.ascontiguousarray(slot, dtype=np.int32).reshape(n)
+        V = None if Vbar is None else f64(Vbar).reshape(n, self.can.p + 1)
+        obj = np.empty(n)
+        alpha = np.empty((n, self.can.p + 1))
+        status = np.empty(n, dtype=np.int32)
+        check(self._lib.ehm_simplex_idx_batch(self._handle, n, ptr(R), ptr(V), ptr(slot),
+                                              int(mode), ptr(obj), ptr(alpha), ptr(status)))
+        return obj, alpha, status
+
+    def point_idx(self, theta, slot, feas=False):
+        """P_theta_delta (or its phase-one form) with slot indices: (J or tau, u0, status)."""
+        theta = f64(np.atleast_2d(theta))
+        n = theta.shape[0]
+        slot = np.ascontiguousarray(slot, dtype=np.int32).reshape(n)
+        J = np.empty(n)
+        u0 = np.empty((n, self.can.n_u))
+        status = np.empty(n, dtype=np.int32)
+        check(self._lib.ehm_point_idx_batch(self._handle, n, ptr(theta), ptr(slot),
+                                            1 if feas else 0, ptr(J), ptr(u0), ptr(status)))
+        return J, u0, status
+
     # -- partition ------------------------------------------------------------------------------
     def partition(self, roots, action='ecc', init=None, max_nodes=0, max_depth=0, engine=1,
                   export=True, shard=None, with_volume=True, status=None, status_sweeps=1,

@@ -149,8 +149,27 @@ class PWAMPC:
 
     # -- commutations ---------------------------------------------------------------
     def mode_sequences(self):
-        """All mode sequences, lexicographic with step 0 most significant."""
+        """
+        The admissible mode sequences, lexicographic with step 0 most significant: all of them,
+        or the subset a caller has restricted the instance to (``restrict``).
+        """
+        if getattr(self, '_sequences', None) is not None:
+            return list(self._sequences)
         return list(itertools.product(range(self.delta_size), repeat=self.N))
+
+    def restrict(self, sequences):
+        """
+        A copy of this instance whose commutation set is ``sequences`` (sorted into enumeration
+        order): what a search over mode prefixes found feasible on a region
+        (``sequences.feasible_sequences``) -- the sequences outside cannot be feasible there, so
+        every oracle restricted to the region returns what it would with all of them.
+        """
+        import copy
+        out = copy.copy(self)
+        out._sequences = sorted(tuple(int(i) for i in s) for s in sequences)
+        out._canonical = None
+        out.name = '%s_restricted%d' % (self.name, len(out._sequences))
+        return out
 
     def sequence_to_delta(self, seq):
         """Mode sequence -> reference-layout 0/1 vector (lib/mpc_library.py:160)."""
@@ -239,6 +258,56 @@ class PWAMPC:
             G = np.vstack([G, np.zeros((m_pad - m, n))])
             w = np.concatenate([w, np.ones(m_pad - m)])
             S = np.vstack([S, np.zeros((m_pad - m, n_x))])
+        return G, w, S
+
+    def condense_prefix(self, prefix):
+        """
+        (G, w, S) of the RELAXATION shared by every mode sequence that starts with ``prefix``
+        (k = len(prefix) steps fixed): the rows that involve the states x_j, j > k -- state
+        constraints, mode regions of the steps >= k -- become 0 <= 1, the epigraph rows of the
+        stage costs of x_j, j > k, become e_j >= 0.  Same variables and the same m rows as a
+        full sequence, so it is one more block of the commutation table.  Its optimal cost is a
+        lower bound, its suboptimality-test optimum an upper bound, and its feasibility a
+        necessary condition for every completion (the uncondensed
+        statement is oracle/prefix_bb.py).  Infinity-norm costs.
+        """
+        if self.cost_type != 'inf':
+            raise ValueError('prefix relaxations are implemented for the infinity-norm cost')
+        prefix = tuple(int(i) for i in prefix)
+        k, N, n_u = len(prefix), self.N, self.n_u
+        seq = prefix + (0,) * (N - k)
+        widest = max(range(self.delta_size),
+                     key=lambda i: 0 if self.regions[i] is None else self.regions[i][0].shape[0])
+        m_pad = self.n_rows_per_sequence((widest,) * N)      # the m of the compiled table
+        G, w, S = self._condense(seq, m_pad)
+        nU = N * n_u
+        nGx, nGu, nQ, nR = self.Gx.shape[0], self.Gu.shape[0], self.Q.shape[0], self.R.shape[0]
+        row = 0
+        for kk in range(1, N + 1):                       # state constraints of x_kk
+            if kk > k:
+                G[row:row + nGx] = 0.
+                w[row:row + nGx] = 1.
+                S[row:row + nGx] = 0.
+            row += nGx
+        row += N * nGu                                   # input constraints: kept
+        for kk in range(1, N + 1):                       # +-Q x_kk <= ex_kk
+            for _ in range(2):
+                if kk > k:
+                    G[row:row + nQ] = 0.
+                    G[row:row + nQ, nU + (kk - 1)] = -1.
+                    w[row:row + nQ] = 0.
+                    S[row:row + nQ] = 0.
+                row += nQ
+        row += 2 * N * nR                                # input-cost epigraphs: kept
+        for kk in range(N):                              # mode regions of x_kk
+            r = self.regions[seq[kk]]
+            if r is not None:
+                nr = r[0].shape[0]
+                if kk >= k:
+                    G[row:row + nr] = 0.
+                    w[row:row + nr] = 1.
+                    S[row:row + nr] = 0.
+                row += nr
         return G, w, S
 
     def _quadratic_cost(self, seq):

@@ -96,6 +96,24 @@ int ehm_problem_set_eps(ehm_problem* prob, double eps_a, double eps_r);
  * commutation's constant LP block in LDS per workgroup, several wavefronts per workgroup;
  * 1 = one wavefront per workgroup with a private copy of the LP (first build, kept as an
  * on-device cross-check).  Environment override at create time: EHM_SOLVER=1|2. */
+/* Replaces the constant blocks of commutation slots [first, first + count) (G [count][m][n],
+ * w [count][m], S [count][m][p], row-major like ehm_problem_desc) and rebuilds every image the
+ * kernels read for them.  With it the commutation table is a cache of problems generated on the
+ * fly: the prefix relaxations of a search over mode sequences -- what the reference leaves to the
+ * MICP solver's branch-and-bound (lib/oracle.py:42-46, 89-102, lib/global_vars.py:25) --
+ * explicit_hybrid_mpc_amd/sequences.py.  Not while a partition run is active. */
+int ehm_problem_update_blocks(ehm_problem* prob, int32_t first, int32_t count, const double* G,
+                              const double* w, const double* S);
+/* Batched problems with the commutation given as a slot index of the table (not as a 0/1
+ * vector): problems over a simplex (mode 0 = min, 1 = suboptimality-test slack, 2 = phase one;
+ * the a5 / a7' problems of lib/oracle.py:74-79, 89-97) and P_theta_delta / its phase-one form
+ * (lib/oracle.py:141-173). */
+int ehm_simplex_idx_batch(ehm_problem* prob, int64_t n_inst, const double* R, const double* Vbar,
+                          const int32_t* slot, int32_t mode, double* obj, double* alpha,
+                          int32_t* status);
+int ehm_point_idx_batch(ehm_problem* prob, int64_t n_inst, const double* theta,
+                        const int32_t* slot, int32_t feas, double* J, double* u0,
+                        int32_t* status);
 int ehm_problem_set_solver(ehm_problem* prob, int generation);
 /* Named options: "solver" (1|2, as above); "decide_full" (0|1): by default the
  * suboptimality-test sweep of ehm_partition_run stops each LP as soon as the SIGN of its

@@ -109,3 +109,147 @@ def bar_e_bb(mpc, R, V_bar, eps_a, eps_r):
         for t, child in sorted(kids):                # most promising child on top of the stack
             stack.append(child)
     return True, n_lp
+
+
+def prefix_feasible_on(mpc, prefix, R):
+    """Is the relaxation of ``prefix`` feasible somewhere on the simplex R?"""
+    return _solve(PrefixModel(mpc, prefix).lp_min_over_simplex(R)).status == 0
+
+
+def feasible_sequences(mpc, simplices):
+    """
+    The mode sequences that are feasible somewhere on the union of the simplices, by
+    depth-first search over prefixes (the CPU statement of
+    explicit_hybrid_mpc_amd/sequences.py).  Returns (sorted sequences, LPs solved).
+    """
+    n_modes, N = mpc.delta_size, mpc.N
+    out, stack, n_lp = [], [()], 0
+    while stack:
+        prefix = stack.pop()
+        for i in range(n_modes):
+            child = prefix + (i,)
+            ok = False
+            for R in simplices:
+                n_lp += 1
+                if prefix_feasible_on(mpc, child, R):
+                    ok = True
+                    break
+            if ok:
+                (out if len(child) == N else stack).append(child)
+    return sorted(out), n_lp
+
+
+def prefix_min_on(mpc, prefix, R):
+    """Minimum over the simplex of the prefix relaxation's optimal cost; +inf if infeasible."""
+    res = _solve(PrefixModel(mpc, prefix).lp_min_over_simplex(R))
+    return float(res.fun) if res.status == 0 else np.inf
+
+
+def relevant_sequences(mpc, simplices, tie_tol=1e-6):
+    """
+    CPU statement of explicit_hybrid_mpc_amd/sequences.py ``relevant_sequences``: the sequences
+    whose cost can be below U somewhere on the region, U = the largest vertex cost of the
+    sequence a greedy dive finds, plus V_R's canonical answer on the region (the first sequence
+    in enumeration order that is feasible at every vertex).
+    Returns (sorted sequences, U, incumbent, LPs solved).
+    """
+    n_modes, N = mpc.delta_size, mpc.N
+    n_lp = 0
+
+    def cost(prefix):
+        nonlocal n_lp
+        n_lp += len(simplices)
+        return min(prefix_min_on(mpc, prefix, R) for R in simplices)
+    dive = ()
+    for _ in range(N):
+        kids = [dive + (i,) for i in range(n_modes)]
+        dive = kids[int(np.argmin([cost(k) for k in kids]))]
+    verts = np.unique(np.asarray(simplices).reshape(-1, np.asarray(simplices).shape[-1]), axis=0)
+    U = max(prefix_cost(mpc, dive, v) for v in verts)
+    n_lp += len(verts)
+    if not np.isfinite(U):
+        raise ValueError('incumbent infeasible at a vertex')
+    bound = U + tie_tol * (1. + abs(U))
+    alive = [()]
+    for _ in range(N):
+        alive = [pre + (i,) for pre in alive for i in range(n_modes)
+                 if cost(pre + (i,)) <= bound]
+    first = first_feasible_sequence(mpc, verts)
+    return sorted(set(alive) | {first}), U, dive, n_lp
+
+
+def first_feasible_sequence(mpc, points):
+    """First sequence in enumeration order feasible at every point (depth-first, lexicographic)."""
+    stack = [()]
+    while stack:
+        prefix = stack.pop()
+        good = [prefix + (i,) for i in range(mpc.delta_size)
+                if all(np.isfinite(prefix_cost(mpc, prefix + (i,), v)) for v in points)]
+        if good and len(good[0]) == mpc.N:
+            return good[0]
+        stack.extend(reversed(good))
+    return None
+
+
+class CpuPrefixTable:
+    """
+    The pair solvers of explicit_hybrid_mpc_amd/sequences.PrefixTable on the uncondensed
+    relaxations with HiGHS: lets the CPU tests run the searches written on those solvers
+    (sequences.PrefixSearch, bnb.PrefixOracle) without a device.
+    """
+
+    def __init__(self, mpc, eps_a=1., eps_r=1.):
+        from explicit_hybrid_mpc_amd.sequences import PrefixSearch
+        self.mpc = mpc
+        self.eps_a, self.eps_r = eps_a, eps_r
+        self.lp_solves = 0
+        self._models = {}
+        for name in ('min_cost_on', 'vertex_costs', 'feasible_at_all', 'first_feasible',
+                     'feasible_on'):
+            setattr(self, name, getattr(PrefixSearch, name).__get__(self))
+
+    def set_eps(self, eps_a, eps_r):
+        self.eps_a, self.eps_r = eps_a, eps_r
+
+    def close(self):
+        pass
+
+    def _model(self, prefix):
+        prefix = tuple(prefix)
+        if prefix not in self._models:
+            self._models[prefix] = PrefixModel(self.mpc, prefix)
+        return self._models[prefix]
+
+    def solve_points(self, prefixes, thetas, feasibility_only=False):
+        thetas = np.asarray(thetas, dtype=np.float64).reshape(len(prefixes), -1)
+        J = np.full(len(prefixes), np.inf)
+        u0 = np.zeros((len(prefixes), self.mpc.n_u))
+        for k, q in enumerate(prefixes):
+            m = self._model(q)
+            res = _solve(m.lp_point(thetas[k]))
+            self.lp_solves += 1
+            if res.status == 0:
+                J[k] = 0. if feasibility_only else res.fun
+                u0[k] = m.u0(res.x)
+        return J, u0
+
+    def solve_min(self, prefixes, simplices):
+        J = np.full(len(prefixes), np.inf)
+        for k, q in enumerate(prefixes):
+            res = _solve(self._model(q).lp_min_over_simplex(simplices[k]))
+            self.lp_solves += 1
+            if res.status == 0:
+                J[k] = res.fun
+        return J
+
+    def solve_slack(self, prefixes, simplices, vbars):
+        na = np.asarray(simplices).shape[1]
+        t = np.full(len(prefixes), -np.inf)
+        alpha = np.zeros((len(prefixes), na))
+        for k, q in enumerate(prefixes):
+            res = _solve(self._model(q).lp_bar_E(simplices[k], vbars[k], self.eps_a, self.eps_r))
+            self.lp_solves += 1
+            if res.status == 0:
+                t[k] = -res.fun
+                alpha[k] = res.x[-1 - na:-1]
+        return t, alpha

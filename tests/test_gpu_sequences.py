@@ -1,0 +1,210 @@
+"""
+BASELINE.json configs[4]'s shape (n_x = 8, n_u = 3, 4 modes, N = 8: 65 536 mode sequences) on the
+device: the commutation table of a region found by a search over mode PREFIXES
+(explicit_hybrid_mpc_amd/sequences.py), checked against the CPU statement
+(oracle/prefix_bb.py), against the FULL enumeration solved on the device, and used by the
+partition engine.
+"""
+
+import itertools
+import numpy as np
+import pytest
+
+from tests import helpers
+
+pytestmark = pytest.mark.gpu
+
+RTOL = 1e-6        # FP64 interior point vs HiGHS / vs itself on another table
+
+
+def region(mpc, frac=0.9, size=0.02, corner=37):
+    from explicit_hybrid_mpc_amd import examples
+    half = examples.theta_box(mpc)
+    p = half.size
+    E = np.vstack([np.zeros(p), np.eye(p)]) - 1. / (p + 1)
+    return frac * examples.box_vertices(half)[corner] + size * half * E
+
+
+def test_slot_entry_points_and_table_updates():
+    """ehm_simplex_idx_batch / ehm_point_idx_batch address the table by slot;
+    ehm_problem_update_blocks replaces blocks in place (every image the kernels read)."""
+    from explicit_hybrid_mpc_amd import engine
+    from explicit_hybrid_mpc_amd._capi import EhmError
+    mpc = helpers.make_instance('pwa_small', 0)
+    can = mpc.compile()
+    gp = engine.GpuProblem(can, 0.05, 0.2)
+    rng = np.random.default_rng(0)
+    R = np.array(helpers.random_simplices(mpc, rng, 6))
+    nd = can.n_delta
+    slot = np.arange(6, dtype=np.int32) % nd
+    tau, _, _ = gp.simplex_idx(R, slot, mode=2)
+    ok = tau <= 1e-8
+    assert ok.any()
+    J, alpha, st = gp.simplex_idx(R[ok], slot[ok], mode=0)
+    Jref = gp.min_simplex(R[ok], can.deltas[slot[ok]])[0]
+    assert np.allclose(J, Jref, rtol=1e-12, atol=1e-12)
+    assert np.allclose(alpha.sum(axis=1), 1., atol=1e-9)
+    theta = R[ok].mean(axis=1)
+    Jp = gp.point_idx(theta, slot[ok])[0]
+    Jpr = gp.solve_ptd(theta, can.deltas[slot[ok]])[0]
+    assert np.allclose(Jp, Jpr, rtol=1e-12, atol=1e-12)
+    # swap blocks 0 and 1: slot 0 now answers as slot 1 did
+    a = gp.point_idx(theta, np.zeros(theta.shape[0], dtype=np.int32), feas=True)[0]
+    b = gp.point_idx(theta, np.ones(theta.shape[0], dtype=np.int32), feas=True)[0]
+    gp.update_blocks(0, can.G[[1, 0]], can.w[[1, 0]], can.S[[1, 0]])
+    a2 = gp.point_idx(theta, np.zeros(theta.shape[0], dtype=np.int32), feas=True)[0]
+    b2 = gp.point_idx(theta, np.ones(theta.shape[0], dtype=np.int32), feas=True)[0]
+    assert np.array_equal(a, b2) and np.array_equal(b, a2)
+    with pytest.raises(EhmError):
+        gp.simplex_idx(R, np.full(6, nd, dtype=np.int32), mode=0)
+    with pytest.raises(EhmError):
+        gp.update_blocks(nd - 1, can.G[:2], can.w[:2], can.S[:2])
+    gp.close()
+
+
+def test_prefix_relaxations_on_the_device_match_the_uncondensed_lps():
+    """The condensed prefix blocks (PWAMPC.condense_prefix) solve to the optima of the
+    uncondensed relaxations (oracle/prefix_bb.PrefixModel, HiGHS)."""
+    from explicit_hybrid_mpc_amd import examples, sequences
+    from oracle import prefix_bb
+    mpc = examples.pwa4_mpc(N=8)
+    R = region(mpc)
+    table = sequences.PrefixTable(mpc, slots=64)
+    prefixes = [(3,), (3, 0), (1, 2), (3, 0, 1), (3, 0, 1, 1, 1), (0, 0, 0, 0, 0, 0),
+                (3, 0, 1, 1, 1, 1, 1, 1), (2, 2, 2, 2, 2, 2, 2, 2)]
+    got = table.min_cost_on(prefixes, R[None])
+    table.close()
+    ref = np.array([prefix_bb.prefix_min_on(mpc, pre, R) for pre in prefixes])
+    assert np.array_equal(np.isfinite(got), np.isfinite(ref))
+    fin = np.isfinite(ref)
+    assert fin.sum() >= 4
+    assert np.allclose(got[fin], ref[fin], rtol=RTOL, atol=RTOL)
+
+
+def test_region_table_found_on_the_device_equals_the_cpu_search():
+    from explicit_hybrid_mpc_amd import examples, sequences
+    from oracle import prefix_bb
+    mpc = examples.pwa4_mpc(N=8)
+    R = region(mpc)
+    seqs, info = sequences.relevant_sequences(mpc, R[None])
+    ref, U, dive, _ = prefix_bb.relevant_sequences(mpc, [R])
+    assert info['incumbent'] == dive and abs(info['upper_bound'] - U) <= RTOL * (1 + U)
+    assert seqs == ref and info['first_feasible'] in seqs
+    assert 8 <= len(seqs) <= 256 and info['enumeration'] == 65536
+    # the search solved a few thousand LPs, not 65 536 x (phase one + minimum)
+    assert info['lp_solves'] < 0.05 * 65536
+    print('\\nregion table: %d of 65 536 sequences, levels %s, %d LPs'
+          % (len(seqs), info['alive_per_level'], info['lp_solves']))
+    # feasibility alone prunes nothing on this system (the inputs reach every mode region)
+    with pytest.raises(ValueError):
+        sequences.feasible_sequences(mpc, R[None])
+    # a region ten times wider keeps more than the engine's table holds: reported, not cut
+    with pytest.raises(ValueError) as err:
+        sequences.relevant_sequences(mpc, region(mpc, 0.6, 0.2)[None])
+    assert 'exceeds 256' in str(err.value)
+
+
+def test_region_table_reproduces_the_full_enumeration():
+    """
+    P_theta over ALL 65 536 sequences, solved on the device table by table, at points of the
+    region: the optimal cost and the canonical minimiser are the ones the region's 42-entry table
+    gives; and no sequence outside the table is below the bound U anywhere it was sampled.
+    """
+    from explicit_hybrid_mpc_amd import examples, sequences, engine
+    mpc = examples.pwa4_mpc(N=8)
+    R = region(mpc)
+    table = sequences.PrefixTable(mpc, slots=2048)
+    seqs, info = sequences.relevant_sequences(mpc, R[None], table=table)
+    rng = np.random.default_rng(3)
+    theta = np.vstack([R.mean(axis=0), rng.dirichlet(np.ones(9), size=3) @ R, R])
+    npts = theta.shape[0]
+    everything = list(itertools.product(range(4), repeat=8))
+    J_all = np.empty((len(everything), npts))
+    for k0 in range(0, len(everything), table.slots):
+        chunk = everything[k0:k0 + table.slots]
+        table._load(chunk)
+        slot = np.repeat(np.arange(len(chunk), dtype=np.int32), npts)
+        th = np.tile(theta, (len(chunk), 1))
+        tau = table.gp.point_idx(th, slot, feas=True)[0]
+        J = table.gp.point_idx(th, slot)[0]
+        J_all[k0:k0 + len(chunk)] = np.where(tau <= 1e-8, J, np.inf).reshape(len(chunk), npts)
+    table.close()
+    in_table = np.array([s in set(seqs) for s in everything])
+    U = info['upper_bound']
+    assert np.all(J_all[~in_table] > U)                 # the pruning argument, sampled
+    best = J_all.min(axis=0)
+    assert np.all(best <= U + 1e-9)
+    # canonical rule: lowest enumeration index within the tie tolerance
+    tie = J_all <= best + 1e-6 * (1 + np.abs(best))
+    first = tie.argmax(axis=0)
+    assert all(in_table[k] for k in first)
+    # V_R's canonical answer: the first sequence feasible at all 9 vertices
+    at_vertices = np.isfinite(J_all[:, 4:]).all(axis=1)
+    assert everything[int(at_vertices.argmax())] == info['first_feasible']
+    assert info['first_feasible'] in seqs
+    gp = engine.GpuProblem(mpc.restrict(seqs).compile(), 1., 1.)
+    Jr, _, dr = gp.solve_pt(theta)
+    d_vr = gp.v_r(R[None])[0]
+    gp.close()
+    assert seqs[int(d_vr[0])] == info['first_feasible']
+    assert np.allclose(Jr, best, rtol=RTOL, atol=RTOL)
+    assert [seqs[d] for d in dr] == [everything[k] for k in first]
+
+
+REGION_VISITS = 14      # CPU visits of the regional partition (about 200 LPs per oracle call)
+
+
+def test_partition_of_a_region_on_its_table():
+    """
+    The multi-commutation engine (csrc/ehm_hybrid.h) on a region's table -- 205 of the 65 536
+    sequences, 40-column / 368-row LPs on the wide kernels -- against the CPU oracle on the same
+    table: the part of the tree the CPU finishes in REGION_VISITS visits is the device's.
+    """
+    from explicit_hybrid_mpc_amd import examples, sequences, engine
+    from oracle.oracle_cpu import OracleCPU
+    from oracle.partition_cpu import PartitionCPU
+    mpc = examples.pwa4_mpc(N=8)
+    R = region(mpc, 0.9, 0.04)
+    seqs, info = sequences.relevant_sequences(mpc, R[None])
+    assert 64 < len(seqs) <= 256
+    sub = mpc.restrict(seqs)
+    can = sub.compile()
+    assert (can.n, can.m) == (40, 368)
+    gp = engine.GpuProblem(can, 1., 1.)
+    J = gp.solve_pt(R)[0]
+    eps_a, eps_r = 1e-3 * float(J.max()), 2e-3
+    gp.set_eps(eps_a, eps_r)
+    flat = gp.partition(R[None], action='ecc', max_nodes=1 << 18)
+    gp.close()
+    used = len(set(flat.delta_idx[flat.delta_idx >= 0].tolist()))
+    print('\nregional partition on %d sequences: %d nodes, %d leaves, depth %d, %d commutations '
+          'used, %d LPs, %.3f s, margin %.2e'
+          % (len(seqs), flat.n_nodes, flat.info['n_leaves'], flat.info['max_depth'], used,
+             flat.info['lp_solves'], flat.info['device_seconds'], flat.info['min_margin']))
+    assert flat.info['truncated'] == 0 and flat.n_nodes >= 3
+    assert flat.info['min_margin'] > 1e-6
+    assert abs(flat.info['volume_closed'] - helpers_volume(R)) <= 1e-9 * helpers_volume(R)
+    orc = OracleCPU(sub, eps_a, eps_r)
+    orc.memoize = True
+    cpu = PartitionCPU(orc, max_nodes=REGION_VISITS)
+    cpu.run([R], [''], 'ecc')
+    assert cpu.min_margin > 1e-6
+    loc = flat.locations([''])
+    pos = {name: k for k, name in enumerate(loc)}
+    decided = 0
+    for name, ref in cpu.nodes.items():
+        k = pos[name]                   # KeyError = the CPU split a node the device did not
+        assert np.array_equal(flat.vertices[k], ref['vertices']), name
+        if (not ref['leaf']) or ref['is_epsilon_suboptimal']:
+            assert flat.is_leaf(k) == ref['leaf'], name
+            assert bool(flat.flags[k] & 1) == ref['is_epsilon_suboptimal'], name
+            assert np.array_equal(flat.deltas[flat.delta_idx[k]].astype(int),
+                                  ref['commutation'].astype(int)), name
+            assert np.allclose(flat.vertex_costs[k], ref['vertex_costs'], rtol=RTOL, atol=RTOL)
+            decided += 1
+    assert decided >= min(3, flat.n_nodes)
+
+
+def helpers_volume(R):
+    from math import factorial
+    return abs(np.linalg.det(R[1:] - R[0])) / factorial(R.shape[1])

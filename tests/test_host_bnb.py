@@ -1,0 +1,114 @@
+"""
+The branch-and-bound oracles and the partition driver of explicit_hybrid_mpc_amd/bnb.py (host
+logic), run on a CPU stand-in for the device table (oracle/prefix_bb.CpuPrefixTable: the same
+pair solvers, HiGHS) against the ENUMERATING CPU oracle: same canonical answers, same tree.
+"""
+
+import numpy as np
+
+from explicit_hybrid_mpc_amd import bnb, examples
+from explicit_hybrid_mpc_amd.tree import Tree, NodeData
+from oracle import prefix_bb, geometry
+from oracle.oracle_cpu import OracleCPU
+from oracle.partition_cpu import PartitionCPU
+from tests import helpers
+
+
+def _same_bar_d(r1, r2):
+    assert (r1[0] is None) == (r2[0] is None)
+    if r1[0] is not None:
+        assert np.array_equal(r1[0].astype(int), r2[0].astype(int))
+        assert np.allclose(r1[1], r2[1], atol=1e-7) and r1[3] == r2[3]
+        assert np.allclose([v[1] for v in r1[2]], [v[1] for v in r2[2]], atol=1e-8)
+    return r1[0] is not None
+
+
+def test_oracles_equal_enumeration_on_a_small_instance():
+    mpc = helpers.make_instance('pwa_small', 0)          # 2 modes, N = 3
+    eps_a = helpers.eps_a_rule(mpc, 0.25)
+    full = OracleCPU(mpc, eps_a, 0.2)
+    bo = bnb.PrefixOracle(mpc, eps_a, 0.2, table=prefix_bb.CpuPrefixTable(mpc))
+    rng = np.random.default_rng(0)
+    half = examples.theta_box(mpc)
+    for _ in range(20):
+        th = rng.uniform(-1, 1, 2) * half
+        a, b = full.P_theta(th), bo.P_theta(th)
+        assert (a[1] is None) == (b[1] is None)
+        assert full.P_theta(th, check_feasibility=True) == bo.P_theta(th, check_feasibility=True)
+        if a[1] is not None:
+            assert abs(a[2] - b[2]) < 1e-8 and np.array_equal(a[1], b[1])
+            assert np.allclose(a[0], b[0], atol=1e-7)
+            c = bo.P_theta_delta(th, a[1])
+            assert abs(c[1] - a[2]) < 1e-8 and bo.P_theta_delta(th, a[1], check_feasibility=True)
+    n_open = n_swap = 0
+    for R in helpers.random_simplices(mpc, rng, 60, scale_lo=-1.):
+        d1, vx1 = full.V_R(R)
+        d2, vx2 = bo.V_R(R)
+        assert (d1 is None) == (d2 is None)
+        if d1 is None:
+            continue
+        assert np.array_equal(d1, d2)
+        V = np.array([v[1] for v in vx1])
+        assert np.allclose(V, [v[1] for v in vx2], atol=1e-8)
+        e1, e2 = full.bar_E_delta_R(R, V), bo.bar_E_delta_R(R, V)
+        assert e1 == e2
+        n_open += not e1
+        n_swap += _same_bar_d(full.bar_D_delta_R(R, V, d1), bo.bar_D_delta_R(R, V, d1))
+    assert n_open >= 3 and n_swap >= 1
+
+
+def test_driver_grows_the_tree_of_the_enumerating_partition():
+    mpc = helpers.make_instance('pwa_small', 0)
+    eps_a = helpers.eps_a_rule(mpc, 0.25)
+    roots, locs = helpers.roots_of(mpc)
+    cpu = PartitionCPU(OracleCPU(mpc, eps_a, 0.2))
+    cpu.run(roots, locs, 'ecc')
+    bo = bnb.PrefixOracle(mpc, eps_a, 0.2, table=prefix_bb.CpuPrefixTable(mpc))
+    n = 0
+    for R, loc in zip(roots, locs):
+        branch = Tree(NodeData(vertices=np.array(R)))
+        stats = bnb.grow(bo, branch, 'ecc', handoff=False, split=geometry.split_along_longest_edge)
+        assert not stats['truncated'] and stats['host_visits'] > 0
+        for node, name in branch.walk(loc):
+            ref = cpu.nodes[name]
+            n += 1
+            assert np.array_equal(node.data.vertices, ref['vertices'])
+            assert node.is_leaf() == ref['leaf']
+            assert node.data.is_epsilon_suboptimal == ref['is_epsilon_suboptimal']
+            if ref['commutation'] is None:           # split by ecc: no record (lib/tree.py:34-39)
+                assert not hasattr(node.data, 'commutation')
+                continue
+            assert np.array_equal(node.data.commutation.astype(int),
+                                  ref['commutation'].astype(int))
+            assert np.allclose(node.data.vertex_costs, ref['vertex_costs'], atol=1e-8)
+    assert n == len(cpu.nodes) and n > 20
+    # a budget of visits leaves an incomplete tree and says so
+    branch = Tree(NodeData(vertices=np.array(roots[0])))
+    assert bnb.grow(bo, branch, 'ecc', handoff=False, max_visits=2,
+                    split=geometry.split_along_longest_edge)['truncated']
+
+
+def test_oracles_equal_enumeration_at_256_sequences():
+    """4 modes, N = 4 (examples.pwa4_mpc): the searches look at a fraction of the 256 sequences
+    and return the enumeration's canonical answers."""
+    mpc = examples.pwa4_mpc()
+    half = examples.theta_box(mpc)
+    E = np.vstack([np.zeros(8), np.eye(8)]) - 1. / 9.
+    R = 0.7 * examples.box_vertices(half)[37] + 0.25 * half * E
+    table = prefix_bb.CpuPrefixTable(mpc)
+    J0 = table.solve_points([(3, 0, 0, 0)], R[:1])[0][0]
+    eps_a, eps_r = 0.02 * J0, 0.02
+    full = OracleCPU(mpc, eps_a, eps_r)
+    full.memoize = True
+    bo = bnb.PrefixOracle(mpc, eps_a, eps_r, table=table)
+    th = R.mean(axis=0)
+    a, b = full.P_theta(th), bo.P_theta(th)
+    assert abs(a[2] - b[2]) < 1e-8 and np.array_equal(a[1], b[1])
+    d1, vx1 = full.V_R(R)
+    d2, vx2 = bo.V_R(R)
+    assert np.array_equal(d1, d2)
+    V = np.array([v[1] for v in vx1])
+    assert full.bar_E_delta_R(R, V) == bo.bar_E_delta_R(R, V) == False
+    before = table.lp_solves
+    assert _same_bar_d(full.bar_D_delta_R(R, V, d1), bo.bar_D_delta_R(R, V, d1))
+    assert table.lp_solves - before < 0.5 * 256 * 10     # enumeration: 256 x (9 + 1) problems

@@ -72,3 +72,46 @@ def test_config5_scale_search():
     assert not closed and n1 < 4 ** 8 / 50
     closed, n2 = prefix_bb.bar_e_bb(mpc, R, np.full(9, 1.01 * J), 10. * J, 10.)
     assert closed and n2 <= 4                            # every first-step prefix already has t* < 0
+
+
+def test_region_table_keeps_every_oracle_answer():
+    """
+    The cost-pruned table of a region (sequences.relevant_sequences is the
+    device version): on 4 modes x N = 4 (256 sequences, enumerable) the oracles restricted to the
+    table return what they return on the full enumeration -- P_theta at points of the region,
+    V_R on it, and the partition's first decisions (bar_E / bar_D with the canonical rule).
+    """
+    from oracle.partition_cpu import PartitionCPU
+    mpc = examples.pwa4_mpc()
+    half = examples.theta_box(mpc)
+    E = np.vstack([np.zeros(8), np.eye(8)]) - 1. / 9.
+    R = 0.8 * examples.box_vertices(half)[37] + 0.08 * half * E
+    seqs, U, dive, n_lp = prefix_bb.relevant_sequences(mpc, [R])
+    assert 2 <= len(seqs) < 64 and dive in seqs
+    sub = mpc.restrict(seqs)
+    assert sub.mode_sequences() == seqs and sub.compile().n_delta == len(seqs)
+    assert mpc.compile().n_delta == 256                 # the original is untouched
+    full = OracleCPU(mpc, 0.004, 0.01)
+    part = OracleCPU(sub, 0.004, 0.01)
+    rng = np.random.default_rng(1)
+    for a in rng.dirichlet(np.ones(9), size=3):
+        u1, d1, J1, _ = full.P_theta(a @ R)
+        u2, d2, J2, _ = part.P_theta(a @ R)
+        assert abs(J1 - J2) <= 1e-9 and np.array_equal(d1, d2) and J1 <= U + 1e-9
+    d1, vx1 = full.V_R(R)
+    d2, vx2 = part.V_R(R)
+    assert np.array_equal(d1, d2)
+    assert np.allclose([v[1] for v in vx1], [v[1] for v in vx2], atol=1e-9)
+    # the first visits of the partition of R: ecc, then lcss (bar_E, bar_D) on the root
+    trees = []
+    for orc in (full, part):
+        cpu = PartitionCPU(orc, max_nodes=3)
+        cpu.run([R], [''], 'ecc')
+        trees.append(cpu.nodes)
+    assert set(trees[0]) == set(trees[1]) and len(trees[0]) >= 3
+    for name in trees[0]:
+        a, b = trees[0][name], trees[1][name]
+        assert a['leaf'] == b['leaf'] and a['is_epsilon_suboptimal'] == b['is_epsilon_suboptimal']
+        if a['commutation'] is not None:
+            assert np.array_equal(a['commutation'], b['commutation'])
+            assert np.allclose(a['vertex_costs'], b['vertex_costs'], atol=1e-9)
