@@ -122,12 +122,9 @@ def test_region_table_reproduces_the_full_enumeration():
     J_all = np.empty((len(everything), npts))
     for k0 in range(0, len(everything), table.slots):
         chunk = everything[k0:k0 + table.slots]
-        table._load(chunk)
-        slot = np.repeat(np.arange(len(chunk), dtype=np.int32), npts)
-        th = np.tile(theta, (len(chunk), 1))
-        tau = table.gp.point_idx(th, slot, feas=True)[0]
-        J = table.gp.point_idx(th, slot)[0]
-        J_all[k0:k0 + len(chunk)] = np.where(tau <= 1e-8, J, np.inf).reshape(len(chunk), npts)
+        pairs = [q for q in chunk for _ in range(npts)]
+        J = table.solve_points(pairs, np.tile(theta, (len(chunk), 1)))[0]
+        J_all[k0:k0 + len(chunk)] = J.reshape(len(chunk), npts)
     table.close()
     in_table = np.array([s in set(seqs) for s in everything])
     U = info['upper_bound']
@@ -208,3 +205,170 @@ def test_partition_of_a_region_on_its_table():
 def helpers_volume(R):
     from math import factorial
     return abs(np.linalg.det(R[1:] - R[0])) / factorial(R.shape[1])
+
+
+# ---------------------------------------------------------------------------------------------
+# branch-and-bound oracles and the partition driver (explicit_hybrid_mpc_amd/bnb.py)
+# ---------------------------------------------------------------------------------------------
+def _walk_equal(branch, flat, n_min):
+    """The Tree grown by bnb.grow against a FlatTree of the enumerating engine (one root)."""
+    loc = flat.locations([''])
+    pos = {name: k for k, name in enumerate(loc)}
+    n = 0
+    for node, name in branch.walk(''):
+        k = pos[name]
+        n += 1
+        assert np.array_equal(node.data.vertices, flat.vertices[k]), name
+        assert node.is_leaf() == flat.is_leaf(k), name
+        assert node.data.is_epsilon_suboptimal == bool(flat.flags[k] & 1), name
+        if flat.flags[k] & 2:
+            assert np.array_equal(np.asarray(node.data.commutation).astype(int),
+                                  flat.deltas[flat.delta_idx[k]].astype(int)), name
+            assert np.allclose(node.data.vertex_costs, flat.vertex_costs[k],
+                               rtol=RTOL, atol=RTOL), name
+    assert n == flat.n_nodes and n >= n_min
+
+
+@pytest.mark.parametrize('frac,size,eps', [(0.6, 0.35, 0.05), (0.7, 0.25, 0.02)])
+@pytest.mark.parametrize('handoff', [False, True])
+def test_driver_with_search_oracles_grows_the_enumerating_engines_tree(handoff, frac, size, eps):
+    """
+    4 modes, N = 4: all 256 sequences fit the device engine, which is the reference here.  The
+    driver of bnb.py -- branch-and-bound oracles at the top, region tables of at most 128
+    sequences handed to the engine below -- must grow the same tree, node for node.
+    """
+    from explicit_hybrid_mpc_amd import examples, engine, bnb
+    from explicit_hybrid_mpc_amd.tree import Tree, NodeData
+    mpc = examples.pwa4_mpc()
+    R = region(mpc, frac, size)
+    gp = engine.GpuProblem(mpc.compile(), 1., 1.)
+    J = gp.solve_pt(R)[0]
+    eps_a, eps_r = eps * float(J.max()), eps
+    gp.set_eps(eps_a, eps_r)
+    flat = gp.partition(R[None], action='ecc', max_nodes=1 << 18)
+    gp.close()
+    assert flat.info['truncated'] == 0 and flat.info['min_margin'] > 1e-6
+    orc = bnb.PrefixOracle(mpc, eps_a, eps_r, slots=1024)
+    branch = Tree(NodeData(vertices=R.copy()))
+    stats = bnb.grow(orc, branch, 'ecc', handoff=handoff, table_max=128)
+    print('\nN=4 driver (handoff=%s): %d nodes; %s; oracle calls %s, %d prefixes expanded, %d LPs'
+          % (handoff, flat.n_nodes, {k: v for k, v in stats.items() if k != 'table_sizes'},
+             orc.calls, orc.n_expanded, orc.table.lp_solves))
+    orc.close()
+    assert not stats['truncated']
+    if handoff:
+        assert stats['handoffs'] >= 1 and max(stats['table_sizes']) <= 128
+    _walk_equal(branch, flat, 15)
+
+
+def test_search_oracles_equal_the_full_enumeration_at_65536_sequences():
+    """
+    N = 8 on a region whose table (2 734 sequences) does not fit the engine: bar_E, bar_D and
+    V_R by branch and bound against the same problems ENUMERATED on the device (65 536 slack
+    LPs, vertex feasibility of every candidate).
+    """
+    from explicit_hybrid_mpc_amd import examples, bnb, sequences
+    mpc = examples.pwa4_mpc(N=8)
+    R = region(mpc, 0.6, 0.05)
+    table = sequences.PrefixTable(mpc, slots=2048)
+    with pytest.raises(sequences.TableTooLarge):
+        sequences.relevant_sequences(mpc, R[None], table=table)
+    J0 = table.solve_min([()], R[None])[0]
+    assert abs(J0) < 1e-7                              # the empty prefix has no state-cost rows
+    orc = bnb.PrefixOracle(mpc, 1., 1., table=table)
+    delta, vx = orc.V_R(R)
+    V = np.array([v[1] for v in vx])
+    eps_a, eps_r = 0.01 * float(V.max()), 0.01
+    orc.eps_a, orc.eps_r = eps_a, eps_r
+    table.set_eps(eps_a, eps_r)
+    lp0, ex0 = table.lp_solves, orc.n_expanded
+    closed = orc.bar_E_delta_R(R, V)
+    star = orc.bar_D_delta_R(R, V, delta)
+    print('\nN=8 region root: V_R -> %s; bar_E closed=%s; bar_D -> %s; %d prefixes expanded, '
+          '%d LPs (enumeration: 65 536 x 2 + vertex problems)'
+          % (orc.sequence_of(delta), closed, None if star[0] is None else
+             orc.sequence_of(star[0]), orc.n_expanded - ex0, table.lp_solves - lp0))
+    assert table.lp_solves - lp0 < 0.2 * 65536
+    # the enumeration, 2 048 sequences per table load
+    everything = list(itertools.product(range(4), repeat=8))
+    t_all = np.empty(len(everything))
+    a_all = np.empty((len(everything), 9))
+    for k0 in range(0, len(everything), table.slots):
+        chunk = everything[k0:k0 + table.slots]
+        t, a = table.solve_slack(chunk, np.tile(R, (len(chunk), 1, 1)), np.tile(V, (len(chunk), 1)))
+        ok = np.flatnonzero(t >= 0.)
+        feas = table.feasible_at_all([chunk[k] for k in ok], R)
+        t[ok[~feas]] = -np.inf
+        t_all[k0:k0 + len(chunk)] = t
+        a_all[k0:k0 + len(chunk)] = a
+    assert closed == (not (t_all.max() >= 0.))
+    if t_all.max() >= 0.:
+        t_max = t_all.max()
+        first = int(np.argmax(t_all >= t_max - 1e-6 * (1 + abs(t_max))))
+        if everything[first] == orc.sequence_of(delta):
+            assert star[0] is None
+        else:
+            assert orc.sequence_of(star[0]) == everything[first]
+            assert np.allclose(star[1], a_all[first] @ R, atol=1e-6)
+    else:
+        assert star[0] is None
+    # V_R: the first sequence feasible at all 9 vertices
+    first_seq = orc.sequence_of(delta)
+    before = [q for q in everything[:everything.index(first_seq)]]
+    if before:
+        assert not table.feasible_at_all(before[-512:], R).any()
+    table.close()
+
+
+def _grow_and_check(mpc, R, eps, max_visits, label):
+    from explicit_hybrid_mpc_amd import bnb, tools
+    from explicit_hybrid_mpc_amd.tree import Tree, NodeData
+    orc = bnb.PrefixOracle(mpc, 1., 1., slots=4096)
+    J = [orc.P_theta(v)[2] for v in R[:2]]
+    eps_a = eps[0] * max(J)
+    orc.eps_a, orc.eps_r = eps_a, eps[1]
+    orc.table.set_eps(eps_a, eps[1])
+    branch = Tree(NodeData(vertices=R.copy()))
+    stats = bnb.grow(orc, branch, 'ecc', max_visits=max_visits)
+    leaves = list(branch.leaves())
+    closed = [n for n, _ in leaves if n.data.is_epsilon_suboptimal]
+    print('\n%s: %d nodes, %d leaves (%d closed); %s; oracle calls %s; %d prefixes expanded, '
+          '%d LPs, %d table blocks loaded'
+          % (label, sum(1 for _ in branch.walk()), len(leaves), len(closed), stats, orc.calls,
+             orc.n_expanded, orc.table.lp_solves, orc.table.blocks_loaded))
+    orc.close()
+    vol = sum(tools.simplex_volume(n.data.vertices) for n, _ in leaves)
+    assert abs(vol - tools.simplex_volume(R)) <= 1e-9 * vol
+    for n, _ in closed:
+        assert len(n.data.vertex_costs) == 9 and np.all(np.isfinite(n.data.vertex_costs))
+        assert len(n.data.commutation) == 32
+    return stats, leaves, closed
+
+
+def test_driver_on_a_region_whose_table_does_not_fit():
+    """
+    N = 8, a region with 397 relevant sequences: the top of its tree is grown with the search
+    oracles on the host, the node whose table fits (200 sequences) goes to the device engine.
+    """
+    from explicit_hybrid_mpc_amd import examples
+    mpc = examples.pwa4_mpc(N=8)
+    stats, leaves, closed = _grow_and_check(mpc, region(mpc, 0.9, 0.05), (0.005, 0.005), 40,
+                                            'N=8 region')
+    assert not stats['truncated'] and len(closed) == len(leaves)
+    assert stats['host_visits'] >= 1 and stats['handoffs'] >= 1
+    assert stats['tables_too_large'] >= 1 and max(stats['table_sizes']) <= 256
+
+
+def test_driver_at_the_top_of_the_config5_tree():
+    """
+    N = 8 from a simplex that spans the whole box Theta (a Kuhn simplex: 1/8! of it), with
+    BASELINE.json's tolerances (abs_frac 0.5, eps_r 1.0): a budget of host visits with the
+    search oracles -- ecc splits until a sequence is feasible at all 9 vertices, then lcss.
+    """
+    from explicit_hybrid_mpc_amd import examples
+    mpc = examples.pwa4_mpc(N=8)
+    half = examples.theta_box(mpc)
+    R = np.array([-half + 2 * half * (np.arange(8) < k) for k in range(9)])
+    stats, leaves, closed = _grow_and_check(mpc, R, (0.5, 1.0), 40, 'N=8 whole-box simplex')
+    assert stats['host_visits'] == 40 and stats['truncated']
+    assert len(closed) >= 3 and len(leaves) >= 10

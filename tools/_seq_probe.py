@@ -1,28 +1,27 @@
-"""Exploration: regional partitions at config-5 shape for a few regions / tolerances."""
+"""Exploration: the bnb driver at N = 8 on a Kuhn simplex of the whole box (config 5's top)."""
 import sys, time, numpy as np
 sys.path.insert(0, '.')
-from explicit_hybrid_mpc_amd import examples, engine, sequences
+from explicit_hybrid_mpc_amd import examples, bnb
+from explicit_hybrid_mpc_amd.tree import Tree, NodeData
 mpc = examples.pwa4_mpc(N=8)
 half = examples.theta_box(mpc)
-E = np.vstack([np.zeros(8), np.eye(8)]) - 1. / 9
-V = examples.box_vertices(half)
-table = sequences.PrefixTable(mpc, slots=1024)
-for frac, size in ((0.9, 0.04), (0.9, 0.02)):
-    R = frac * V[37] + size * half * E
-    seqs, info = sequences.relevant_sequences(mpc, R[None], table=table)
-    can = mpc.restrict(seqs).compile()
-    gp = engine.GpuProblem(can, 1., 1.)
-    J = gp.solve_pt(R)[0]
-    print(frac, size, len(seqs), 'J', J.min(), J.max(), flush=True)
-    for eps in ((1e-3, 2e-3), (2e-4, 5e-4), (5e-5, 1e-4)):
-        gp.set_eps(eps[0] * float(J.max()), eps[1])
-        t = time.time()
-        try:
-            flat = gp.partition(R[None], action='ecc', max_nodes=1 << 19, max_depth=40)
-            print(' ', eps, 'nodes', flat.n_nodes, 'leaves', flat.info['n_leaves'], 'depth', flat.info['max_depth'],
-              'trunc', flat.info['truncated'], 'lp', flat.info['lp_solves'], 'used', len(set(flat.delta_idx[flat.delta_idx>=0].tolist())),
-              'margin %.2e' % flat.info['min_margin'], 'dev %.3fs' % flat.info['device_seconds'], '%.2fs' % (time.time() - t), flush=True)
-        except Exception as e:
-            print(' ', eps, 'failed', e, flush=True)
-    gp.close()
-table.close()
+p = 8
+R = np.array([-half + 2 * half * (np.arange(p) < k) for k in range(p + 1)])
+orc = bnb.PrefixOracle(mpc, 1., 1., slots=8192)
+t = time.time()
+J = [orc.P_theta(v)[2] for v in R]
+print('vertex optimal costs', np.round(J, 4), 'LPs', orc.table.lp_solves, 'expanded', orc.n_expanded, '%.1fs' % (time.time() - t), flush=True)
+Jm = max(J)
+for eps_a_frac, eps_r in ((0.5, 1.0), (0.2, 0.3)):
+    orc.eps_a, orc.eps_r = eps_a_frac * Jm, eps_r
+    orc.table.set_eps(orc.eps_a, eps_r)
+    lp0, ex0 = orc.table.lp_solves, orc.n_expanded
+    t = time.time()
+    branch = Tree(NodeData(vertices=R.copy()))
+    stats = bnb.grow(orc, branch, 'ecc', max_visits=40, log=lambda s: print('  ', s, flush=True))
+    leaves = list(branch.leaves())
+    print(eps_a_frac, eps_r, 'nodes', sum(1 for _ in branch.walk()), 'leaves', len(leaves),
+          'closed', sum(1 for n, _ in leaves if n.data.is_epsilon_suboptimal), stats,
+          'calls', orc.calls, 'LPs', orc.table.lp_solves - lp0, 'expanded', orc.n_expanded - ex0,
+          'blocks', orc.table.blocks_loaded, '%.1fs' % (time.time() - t), flush=True)
+orc.close()
