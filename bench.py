@@ -265,6 +265,9 @@ def main():
     ap.add_argument('--no-mid-first', action='store_true',
                     help='persistent kernel WITHOUT the midpoint solve before the suboptimality '
                          'test (the round-1 flow; A/B measurements)')
+    ap.add_argument('--no-inherit-witness', action='store_true',
+                    help='open nodes do NOT hand the point that proved them open to their '
+                         'children (A/B measurements)')
     ap.add_argument('--engine', type=int, default=1,
                     help='1 = persistent frontier kernel (one launch per partition; single rank, '
                          'shared-block kernels), 0 = level-synchronous sweeps')
@@ -307,6 +310,8 @@ def main():
     gp.set_option('timing', 1)           # kernel seconds / solves by kind of the hybrid engine
     if args.no_mid_first:
         gp.set_option('mid_first', 0)
+    if args.no_inherit_witness:
+        gp.set_option('inherit_witness', 0)
     hybrid = args.workload == 'config3'
     static = args.balance == 'static' and not args.status_dir
     # both balancing modes run the persistent frontier kernel: static = one launch per rank,
@@ -407,7 +412,7 @@ def main():
         del flat
     # totals over ranks (max time, summed work)
     keys = ['lp_solves', 'ipm_iters', 'n_nodes', 'n_closed', 'ref_solves', 'decide_solves',
-            'decide_iters', 'cert_closed', 'witness_open']
+            'decide_iters', 'cert_closed', 'witness_open', 'witness_inherited']
     if rank > 0:
         # the top of the tree is grown identically on every rank: count it once (rank 0)
         for i in infos:
@@ -448,7 +453,8 @@ def main():
         grad_bytes = 8 * (p + 1) * p if agg['cert_closed'] > 0 else 0
         closed, nodes = agg['n_closed'], agg['n_nodes']
         splits = (nodes - K * len(roots)) / 2.
-        visits = agg['decide_solves'] + agg['cert_closed'] + agg['witness_open']
+        visits = (agg['decide_solves'] + agg['cert_closed'] + agg['witness_open'] +
+                  agg['witness_inherited'])
         if persistent:
             # ONE kernel per partition: suboptimality tests AND splits / midpoint solves
             flops, flops_x = sum(f_survey), sum(f_exec)
@@ -517,6 +523,7 @@ def main():
                 'reference_equivalent_solves_per_s': agg['ref_solves'] / elapsed_max,
                 'leaves_closed_without_lp_per_step': agg['cert_closed'] / K,
                 'nodes_proved_open_by_midpoint_per_step': agg['witness_open'] / K,
+                'nodes_proved_open_by_inherited_witness_per_step': agg['witness_inherited'] / K,
                 'mean_ipm_iterations': agg['ipm_iters'] / max(agg['lp_solves'], 1),
                 'sweeps': info0['sweeps'], 'tree_depth': info0['max_depth'],
                 'min_decision_margin': info0['min_margin'],

@@ -481,6 +481,8 @@ struct ehm_problem {
     bool v1_ok = false;      // the generation-1 kernels fit this problem
     int decide_full = 0;     // 1 = the suboptimality test solves to full accuracy (no sign-only stop)
     int mid_first = 1;       // 1 = persistent kernel with the midpoint solve first (default)
+    int inherit_wit = 1;     // 1 = open nodes hand the point that proved them open to the child
+                             // that contains it (DevTree::wit; option "inherit_witness")
     int hy_timing = 0;       // 1 = event pairs + counter snapshots around every batch of the
                              // multi-commutation engine (kernel seconds, solves by kind)
     int solver_gen = 2;      // 1 = one wavefront per workgroup (ehm_kernels.h), 2 = ehm_k2.hip
@@ -491,7 +493,7 @@ struct ehm_problem {
     // cost milliseconds): the pool of the last destroyed tree and the frontier scratch
     struct PoolCache {
         long long cap = 0;
-        DevBuf rec, left, didx, depth, flags, tstar, grad;
+        DevBuf rec, left, didx, depth, flags, tstar, grad, wit;
     } pool_cache;
     DevBuf fr_a, fr_b, open_flag, open_list, d_count;
     DevBuf pq_slots, pq_ctl;   // persistent engine: queue slots, control block
@@ -513,7 +515,7 @@ struct ehm_tree {
     DevTree dt{};
     long long cap = 0;       // allocated node records (a cached pool may be larger than asked for)
     long long limit = 0;     // max_nodes of this run: the capacity the caller agreed to
-    DevBuf rec, left, didx, depth, flags, tstar, grad, code;
+    DevBuf rec, left, didx, depth, flags, tstar, grad, code, wit;
     ehm_tree_info info{};
     int skip_volume = 0;
     // persistent engine: node ids follow the allocation order; the export relabels them to the
@@ -864,7 +866,7 @@ int ehm_problem_destroy(ehm_problem* P) {
     P->seg.release();
     P->pool_cache.rec.release(); P->pool_cache.left.release(); P->pool_cache.didx.release();
     P->pool_cache.depth.release(); P->pool_cache.flags.release(); P->pool_cache.tstar.release();
-    P->pool_cache.grad.release();
+    P->pool_cache.grad.release(); P->pool_cache.wit.release();
     P->fr_a.release(); P->fr_b.release(); P->open_flag.release(); P->open_list.release();
     P->d_count.release();
     P->pq_slots.release(); P->pq_ctl.release();
@@ -990,6 +992,10 @@ int ehm_problem_set_option(ehm_problem* P, const char* name, double value) {
     }
     if (!strcmp(name, "mid_first")) {
         P->mid_first = value != 0.0;
+        return EHM_OK;
+    }
+    if (!strcmp(name, "inherit_witness")) {
+        P->inherit_wit = value != 0.0;
         return EHM_OK;
     }
     return fail(EHM_E_INVALID, "unknown option '%s'", name);
@@ -1889,11 +1895,12 @@ int ehm_tree_destroy(ehm_tree* T) {
         auto& c = T->prob->pool_cache;
         std::swap(c.rec, T->rec); std::swap(c.left, T->left); std::swap(c.didx, T->didx);
         std::swap(c.depth, T->depth); std::swap(c.flags, T->flags); std::swap(c.tstar, T->tstar);
-        std::swap(c.grad, T->grad);
+        std::swap(c.grad, T->grad); std::swap(c.wit, T->wit);
         c.cap = T->cap;
     }
     T->rec.release(); T->left.release(); T->didx.release(); T->depth.release();
     T->flags.release(); T->tstar.release(); T->grad.release(); T->code.release();
+    T->wit.release();
     delete T;
     return EHM_OK;
 }
@@ -1906,7 +1913,7 @@ static int tree_alloc(ehm_tree* T, ehm_problem* P, long long cap) {
         auto& c = P->pool_cache;
         std::swap(c.rec, T->rec); std::swap(c.left, T->left); std::swap(c.didx, T->didx);
         std::swap(c.depth, T->depth); std::swap(c.flags, T->flags); std::swap(c.tstar, T->tstar);
-        std::swap(c.grad, T->grad);
+        std::swap(c.grad, T->grad); std::swap(c.wit, T->wit);
         cap = c.cap;
         c.cap = 0;
     }
@@ -1921,6 +1928,12 @@ static int tree_alloc(ehm_tree* T, ehm_problem* P, long long cap) {
     const bool grads = P->solver_gen == 2 && P->dp.n_delta == 1 && !getenv("EHM_NO_CUTS");
     if (grads && (rc = T->grad.ensure((size_t)cap * (p + 1) * p * sizeof(double)))) return rc;
     T->dt.grad = grads ? T->grad.as<double>() : nullptr;
+    // witnesses handed from an open node to its child (DevTree::wit): linear costs, the
+    // midpoint-first persistent kernel; every kernel that creates nodes clears or writes them
+    const bool wits = grads && !P->quadratic && P->mid_first && P->inherit_wit &&
+                      !getenv("EHM_NO_WITNESS");
+    if (wits && (rc = T->wit.ensure((size_t)cap * (p + 2) * sizeof(double)))) return rc;
+    T->dt.wit = wits ? T->wit.as<double>() : nullptr;
     T->prob = P;
     T->cap = cap;
     T->dt.rec = T->rec.as<double>();
@@ -2004,6 +2017,9 @@ __global__ void k_give_nodes(DevTree T, int first, int n, int nrec,
         for (int q = threadIdx.x; q < ng; q += blockDim.x)
             T.grad[(size_t)id * ng + q] = __builtin_nan("");
     }
+    if (T.wit)          // nor do witnesses
+        for (int q = threadIdx.x; q < T.p + 2; q += blockDim.x)
+            T.wit[(size_t)id * (T.p + 2) + q] = 0.0;
     if (threadIdx.x == 0) {
         T.left[id] = -1;
         T.didx[id] = meta_in[2 * k];
@@ -2116,6 +2132,10 @@ int ehm_partition_begin(ehm_problem* P, int64_t n_roots, const double* root_vert
         hipError_t e = hipMemsetAsync(T->dt.grad, 0xFF, (size_t)n_roots * (p + 1) * p * 8,
                                       P->stream);
         if (e != hipSuccess) RUN_TRY(fail(EHM_E_HIP, "gradient buffer init failed"));
+    }
+    if (T->dt.wit) {        // roots carry no witness
+        hipError_t e = hipMemsetAsync(T->dt.wit, 0, (size_t)n_roots * (p + 2) * 8, P->stream);
+        if (e != hipSuccess) RUN_TRY(fail(EHM_E_HIP, "witness buffer init failed"));
     }
     {
         unsigned long long inf_bits = 0x7FF0000000000000ULL;
@@ -2692,6 +2712,7 @@ int ehm_partition_finish(ehm_tree* T) {
     T->info.decide_iters = (int64_t)(c1.slack_iters - R.c0.slack_iters);
     T->info.cert_closed = (int64_t)(c1.cert_closed - R.c0.cert_closed);
     T->info.witness_open = (int64_t)(c1.wit_open - R.c0.wit_open);
+    T->info.witness_inherited = (int64_t)(c1.wit_inherited - R.c0.wit_inherited);
     T->info.near_threshold = (int64_t)(c1.routed - R.c0.routed);
     T->info.replicated_closed = R.pre_closed;
     T->info.replicated_nodes = R.pre_nodes;

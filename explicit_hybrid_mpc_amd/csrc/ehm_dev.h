@@ -62,7 +62,24 @@ struct DevTree {
     // the ranks by it (code % world: the last turns of the path, so the descendants of one
     // ancestor spread over all ranks).  Null otherwise.
     uint32_t* code;
+    // wit[k][p+2]: a point of node k at which it is known NOT to be epsilon-suboptimal yet --
+    // [0] an upper bound c_w of the optimal cost at theta_w, [1..p+1] the barycentric weights
+    // of theta_w in the node's vertices.  It comes from the suboptimality-test LP of an
+    // ancestor (the iterate that proved that ancestor open) and travels down to the child that
+    // contains it: where  min(Vbar(theta_w) - c_w - eps_a, Vbar(theta_w) - (1+eps_r) c_w)  is
+    // still positive with the CHILD's vertex costs, the child is open without an LP of its own
+    // (persistent frontier kernel).  c_w includes the safety amount
+    // EHM_WIT_REL x (slack proved at the ancestor).  All zero = no witness (the test then gives
+    // min(-eps_a, 0)).  Null unless the run keeps them.
+    double*  wit;
 };
+
+// The iterate a witness comes from is not exactly feasible: the solver accepted it when its
+// residuals, scaled by 1 + |objective|, were below 1e-3 of the slack it proves
+// (EHM2_SIGN_RES_REL).  The stored cost bound c_w is therefore RAISED by this fraction of that
+// slack -- 20 times the solver's own criterion -- and the witness stops counting once the
+// child's interpolated cost has come that close to it.
+#define EHM_WIT_REL 0.02
 
 // Upper bound of the suboptimality-test optimum t* from the tangent planes of the convex optimal
 // cost at the vertices: V*(theta) >= L_i(theta) = V_i + g_i.(theta - v_i), so with the 2(p+1)
@@ -146,6 +163,7 @@ struct DevCounters {
     unsigned long long cert_closed;       // leaves closed by the cutting-plane bound, no LP
     unsigned long long wit_open;          // nodes proved open by their midpoint solve, no LP
     unsigned long long routed;            // decisions with |t*| < EHM_ROUTE_TOL (full-accuracy LP)
+    unsigned long long wit_inherited;     // nodes proved open by an ancestor's witness, no LP
 };
 
 __host__ __device__ inline int rec_off_vcost(int p) { return (p + 1) * p; }

@@ -291,6 +291,8 @@ __global__ __launch_bounds__(EHM_K2_THREADS) void k2_lcss_expand(
                 g0[ng + k] = (k >= bj * p && k < bj * p + p) ? nb.F[k - bj * p] : gv;
             }
         }
+        if (T.wit && lane < 2 * (p + 2))    // the sweeps do not hand witnesses on (DevTree::wit)
+            T.wit[(size_t)c0 * (p + 2) + lane] = 0.0;
         double* rec0 = T.rec + (size_t)c0 * T.rec_stride;
         double* rec1 = rec0 + T.rec_stride;
         const int ov = rec_off_vcost(p), ou = rec_off_vinput(p);
@@ -370,8 +372,9 @@ __global__ __launch_bounds__(EHM_K2_THREADS) void k2_persist(
     unsigned long long* wst = reinterpret_cast<unsigned long long*>(nb.aug);
     double* wmargin = nb.aug + 16;
     enum { W_SOLVES = 0, W_ITERS, W_STALLED, W_ERRORS, W_SLACK, W_SLACK_ITERS, W_CLOSED, W_SPLITS,
-           W_DEPTH, W_TRUNC, W_CERT, W_WIT, W_ROUTED, W_RCLOSED, W_RSPLITS, W_RSOLVES };
-    if (lane0 < 16) wst[lane0] = 0ULL;
+           W_DEPTH, W_TRUNC, W_CERT, W_WIT, W_ROUTED, W_RCLOSED, W_RSPLITS, W_RSOLVES,
+           W_INH = 17 };        // slot 16 is *wmargin
+    if (lane0 < 18 && lane0 != 16) wst[lane0] = 0ULL;
     if (lane0 == 0) *wmargin = 1e300;
     wsync();
     for (;;) {
@@ -439,7 +442,11 @@ __global__ __launch_bounds__(EHM_K2_THREADS) void k2_persist(
         const int dep = T.depth[id];
         const bool can_split = !(max_depth > 0 && dep >= max_depth);
         double* mid = nb.th;
-        double* stash = nb.rec - 0 + (size_t)wave_doubles - 16;     // last 16 doubles of the wave's LDS
+        // last 32 doubles of the wave's LDS: [0,8) midpoint input, [8,16) midpoint gradient,
+        // [16, 16+p+2) the witness handed on to the children (DevTree::wit)
+        double* stash = nb.rec - 0 + (size_t)wave_doubles - 32;
+        double* wit = stash + 16;
+        bool have_wit = false;
         int bi = 0, bj = 1;
         int its = 0;
         double Jm = 0.0;
@@ -448,6 +455,25 @@ __global__ __launch_bounds__(EHM_K2_THREADS) void k2_persist(
         bool open = false;
         double tst = 0.0, margin = 0.0;
         bool decided = false;
+        if (T.wit && sign_only) {
+            // inherited witness: the point that proved an ancestor open, if it lies in this node
+            const double* wv = T.wit + (size_t)id * (p + 2);
+            if (lane < p + 2) wit[lane] = wv[lane];
+            wsync();
+            const double* Vc = node + rec_off_vcost(p);
+            double vbw = 0.0;
+            for (int q = 0; q <= p; ++q) vbw = fma(wit[1 + q], Vc[q], vbw);
+            const double cw = wit[0];
+            const double tw = fmin(vbw - cw - P.eps_a, vbw - (1.0 + P.eps_r) * cw);
+            if (tw > EHM_ROUTE_TOL * (1.0 + fabs(vbw))) {
+                open = true;
+                decided = true;
+                have_wit = true;
+                tst = tw;
+                margin = tw;
+                if (lane == 0) wst[W_INH] += 1;
+            }
+        }
         if (can_split) {
             longest_edge(node, p, bi, bj);
             if (lane < p) {
@@ -477,7 +503,7 @@ __global__ __launch_bounds__(EHM_K2_THREADS) void k2_persist(
             }
             if (T.grad && lane < p) stash[8 + lane] = nb.F[lane];
             wsync();
-            if (sign_only && mid_conv) {
+            if (sign_only && mid_conv && !decided) {
                 const double* Vc = node + rec_off_vcost(p);
                 const double vb = 0.5 * (Vc[bi] + Vc[bj]);
                 const double tw = fmin(vb - Jm - P.eps_a, vb - (1.0 + P.eps_r) * Jm);
@@ -507,6 +533,24 @@ __global__ __launch_bounds__(EHM_K2_THREADS) void k2_persist(
             open = (tst >= 0.0);
             margin = r.margin;
             const int slack_status = r.status;
+#if !EHM2_QUAD
+            if (T.wit && sign_only && open && slack_status == 0) {
+                // this node's own witness: the accepted iterate's parameter (barycentric) and the
+                // cost of its z, raised by the safety amount (EHM_WIT_REL, ehm_dev.h)
+                const int nz = S.n;
+                double cz = 0.0, sb = 0.0;
+                for (int q = 0; q < nz; ++q) cz = fma(S.cv[q], W.xb[q], cz);
+                for (int q = 0; q < p; ++q) sb += W.xb[nz + q];
+                wsync();
+                if (lane == 0) {
+                    wit[0] = fma(EHM_WIT_REL, margin, cz);
+                    wit[1] = 1.0 - sb;
+                }
+                if (lane < p) wit[2 + lane] = W.xb[nz + lane];
+                have_wit = true;
+                wsync();
+            }
+#endif
             if (lane == 0) {
                 wst[W_SOLVES] += 1;
                 if (dep < deal.depth) wst[W_RSOLVES] += 1;
@@ -578,6 +622,22 @@ __global__ __launch_bounds__(EHM_K2_THREADS) void k2_persist(
                 __hip_atomic_store(g0 + k, a0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                 __hip_atomic_store(g0 + ng + k, a1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             }
+        }
+        if (T.wit && lane < p + 2) {
+            // the witness goes to the child that contains it: child 0 (vertex bi -> midpoint) iff
+            // alpha_bj >= alpha_bi; theta_w = 2 a_i mid + (a_j - a_i) v_j + ... there
+            double* w0 = T.wit + (size_t)c0 * (p + 2);
+            double v0 = 0.0, v1 = 0.0;
+            if (have_wit) {
+                const double ai = wit[1 + bi], aj = wit[1 + bj];
+                const bool to0 = aj >= ai;
+                double v = wit[lane];
+                if (lane == 1 + bi) v = to0 ? 2.0 * ai : ai - aj;
+                if (lane == 1 + bj) v = to0 ? aj - ai : 2.0 * aj;
+                if (to0) v0 = v; else v1 = v;
+            }
+            __hip_atomic_store(w0 + lane, v0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            __hip_atomic_store(w0 + (p + 2) + lane, v1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         }
         if (lane == 0) {
             wst[W_SPLITS] += 1;
@@ -781,6 +841,7 @@ __global__ __launch_bounds__(EHM_K2_THREADS) void k2_persist(
         atomicMin(&cnt->min_margin_bits, (unsigned long long)__double_as_longlong(*wmargin));
         if (wst[W_CERT]) atomicAdd(&cnt->cert_closed, wst[W_CERT]);
         if (wst[W_WIT]) atomicAdd(&cnt->wit_open, wst[W_WIT]);
+        if (wst[W_INH]) atomicAdd(&cnt->wit_inherited, wst[W_INH]);
         if (wst[W_ROUTED]) atomicAdd(&cnt->routed, wst[W_ROUTED]);
         atomicAdd(&ctl->closed, wst[W_CLOSED]);
         atomicAdd(&ctl->splits, wst[W_SPLITS]);
@@ -877,7 +938,7 @@ size_t wave_doubles_for(const DevProblem& P, int n_lp, int ne) {
     // (+16: the midpoint-first flow of k2_persist parks the midpoint solve's input and gradient
     // in the last 16 doubles of the wavefront's workspace)
     return k2_node_doubles(P.p, P.n_u) + wave_lp_doubles(n_lp, ne) +
-           (EHM_PERSIST_MIDFIRST ? 16 : 0);
+           (EHM_PERSIST_MIDFIRST ? 32 : 0);
 }
 size_t shared_doubles_for(const DevProblem& P) { return shared_doubles(P); }
 

@@ -123,6 +123,11 @@ int ehm_problem_set_solver(ehm_problem* prob, int generation);
  * persistent frontier kernel solves a node's midpoint problem before its suboptimality test and
  * skips the test when the midpoint already proves the node open (42 % of the open nodes of the
  * bench tree; identical tree, tests/test_gpu_kernel_generations.py; EHM_MID_FIRST=0|1);
+ * "inherit_witness" (0|1, default 1): a node the suboptimality-test LP finds open hands the
+ * point that proved it (the LP iterate's parameter, with the cost of its decision vector as an
+ * upper bound of the optimal cost there) to the child that contains it; the child is open
+ * without an LP of its own while that point still beats its interpolated vertex costs by the
+ * tolerance plus a safety margin (EHM_NO_WITNESS=1 disables);
  * "timing" (0|1, default 0): multi-commutation runs record an event pair and a counter snapshot
  * around every batched launch, so that ehm_tree_info carries kernel seconds and solves by problem
  * kind (bench.py sets it; ~25 extra stream commands per sweep otherwise spared). */
@@ -366,6 +371,8 @@ typedef struct ehm_tree_info {
      * taken by the suboptimality-test problem solved to full accuracy, never by a shortcut
      * (sign-only stop, tangent-plane bound, midpoint witness, inherited verdict) */
     int64_t near_threshold;
+    int64_t witness_inherited;  /* nodes proved open by the witness of an ancestor's
+                                   suboptimality test (option "inherit_witness"), no LP     */
 } ehm_tree_info;
 
 int ehm_tree_info_get(const ehm_tree* tree, ehm_tree_info* out);

@@ -136,3 +136,55 @@ def test_midpoint_first_flow_grows_the_same_tree():
     assert np.array_equal(new.flags & 1, ref.flags & 1)
     assert rel(new.vertex_costs.ravel(), ref.vertex_costs.ravel()) < RTOL
     assert ((new.tstar >= 0) == (ref.tstar >= 0)).all()
+
+
+def test_inherited_witnesses_grow_the_same_tree():
+    """
+    Option "inherit_witness" (include/ehmpc.h, DevTree::wit): a node the suboptimality-test LP
+    finds open hands the point that proved it to the child that contains it.  Identical tree,
+    fewer LPs; budgeted rounds of the persistent kernel and sharded launches keep the witnesses
+    with the nodes (they live in the node pool), nodes received from another rank carry none.
+    """
+    from explicit_hybrid_mpc_amd import engine, examples
+    from explicit_hybrid_mpc_amd import tools as ehm_tools
+    mpc = helpers.make_instance('lin', 0)
+    gp = engine.GpuProblem(mpc.compile(), 1., 1.)
+    V = examples.box_vertices(examples.theta_box(mpc))
+    gp.set_eps(float(np.max(gp.solve_pt(0.05 * V)[0])), 1e-2)
+    roots, _ = ehm_tools.delaunay_roots(V)
+    gp.set_option('inherit_witness', 0)
+    ref = gp.partition(roots, action='ecc', max_nodes=1 << 22)
+    gp.set_option('decide_full', 1)
+    full = gp.partition(roots, action='ecc', max_nodes=1 << 22)
+    gp.set_option('decide_full', 0)
+    gp.set_option('inherit_witness', 1)
+    new = gp.partition(roots, action='ecc', max_nodes=1 << 22)
+    # the same run in budgeted rounds (ehm_partition_advance)
+    run = gp.begin(roots, action='ecc', max_nodes=1 << 22)
+    n_rounds = 0
+    while True:
+        n_rounds += 1
+        if run.advance(20000) == 0:
+            break
+    rounds = run.finish()
+    assert n_rounds >= 3
+    gp.close()
+    assert ref.info['witness_inherited'] == 0 and full.info['witness_inherited'] == 0
+    assert new.info['witness_inherited'] > 0.1 * new.info['n_leaves']
+    assert new.info['lp_solves'] < 0.93 * ref.info['lp_solves']
+    assert rounds.info['witness_inherited'] > 0
+    for t in (new, full):
+        assert t.n_nodes == ref.n_nodes
+        assert np.array_equal(t.vertices, ref.vertices) and np.array_equal(t.left, ref.left)
+        assert np.array_equal(t.flags & 1, ref.flags & 1)
+        assert rel(t.vertex_costs.ravel(), ref.vertex_costs.ravel()) < RTOL
+        assert ((t.tstar >= 0) == (ref.tstar >= 0)).all()
+    # the run in rounds numbers its nodes in another order: compare the cells themselves
+    assert rounds.n_nodes == ref.n_nodes
+    cells = {ref.vertices[k].tobytes(): (ref.left[k] < 0, ref.flags[k] & 1)
+             for k in range(ref.n_nodes)}
+    assert len(cells) == ref.n_nodes
+    for k in range(rounds.n_nodes):
+        assert cells[rounds.vertices[k].tobytes()] == (rounds.left[k] < 0, rounds.flags[k] & 1)
+    # a decision taken by a witness has a margin above the routing threshold
+    assert new.info['min_margin'] == ref.info['min_margin']

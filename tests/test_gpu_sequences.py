@@ -339,7 +339,7 @@ def _grow_and_check(mpc, R, eps, max_visits, label):
     orc.close()
     vol = sum(tools.simplex_volume(n.data.vertices) for n, _ in leaves)
     assert abs(vol - tools.simplex_volume(R)) <= 1e-9 * vol
-    for n, _ in closed:
+    for n in closed:
         assert len(n.data.vertex_costs) == 9 and np.all(np.isfinite(n.data.vertex_costs))
         assert len(n.data.commutation) == 32
     return stats, leaves, closed

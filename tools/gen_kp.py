@@ -176,8 +176,9 @@ hipError_t set_lds(int bytes) {
 }
 size_t wave_doubles_for(const DevProblem& P, int n_lp_d, int ne_d, int n_lp_e) {
     const size_t a = kd::wave_lp_doubles(n_lp_d, ne_d), b = ke::wave_lp_doubles(n_lp_e, 0);
-    // (+16: the midpoint-first flow parks the midpoint solve's input and gradient there)
-    return k2_node_doubles(P.p, P.n_u) + (a > b ? a : b) + (EHM_PERSIST_MIDFIRST ? 16 : 0);
+    // (+32: the midpoint-first flow parks the midpoint solve's input and gradient and the
+    // node's witness there)
+    return k2_node_doubles(P.p, P.n_u) + (a > b ? a : b) + (EHM_PERSIST_MIDFIRST ? 32 : 0);
 }
 size_t shared_doubles_for(const DevProblem& P) { return kd::shared_doubles(P); }
 void l_persist(const K2Launch& L, DevProblem P, DevTree T, int32_t* slots, int n_slots,
