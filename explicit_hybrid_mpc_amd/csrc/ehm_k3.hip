@@ -288,6 +288,27 @@ EHM3_KERNEL void k3_lcss_decide(
                 continue;
             }
         }
+        if (T.wit && sign_only) {
+            // inherited witness (DevTree::wit): the point that proved an
+            // ancestor open, if this node contains it and it still beats the interpolated cost
+            const double* wv = T.wit + (size_t)id * (P.p + 2);
+            const double* Vc = nb.rec + rec_off_vcost(P.p);
+            double vbw = 0.0;
+            for (int q = 0; q <= P.p; ++q) vbw = fma(wv[1 + q], Vc[q], vbw);
+            const double cw = wv[0];
+            const double tw = fmin(vbw - cw - P.eps_a, vbw - (1.0 + P.eps_r) * cw);
+            if (tw > EHM_ROUTE_TOL * (1.0 + fabs(vbw))) {
+                if (tid == 0) {
+                    atomicAdd(&cnt->wit_inherited, 1ULL);
+                    T.tstar[id] = tw;
+                    open_flag[f] = 1;
+                    atomicMin(&cnt->min_margin_bits,
+                              (unsigned long long)__double_as_longlong(tw));
+                }
+                __syncthreads();
+                continue;           // T.wit[id] stays: the expand kernel hands it on
+            }
+        }
         IpmResult r;
         int its = 0;
         for (int attempt = 0; attempt < EHM3_ATTEMPTS; ++attempt) {
@@ -300,6 +321,22 @@ EHM3_KERNEL void k3_lcss_decide(
         }
         r.iters = its;
         count_solve(cnt, r, tid);
+        if (T.wit && B.wave == 0) {
+            // this node's own witness: the accepted iterate's parameter (barycentric) and the
+            // cost of its z, raised by the safety amount (EHM_WIT_REL); none after a failed solve
+            const bool ok = sign_only && r.status == 0 && -r.obj >= 0.0;
+            double* wv = T.wit + (size_t)id * (P.p + 2);
+            double cz = 0.0;
+            for (int q = B.lane; q < P.n; q += 64) cz = fma(L.cv[q], L.xb[q], cz);
+            cz = wave_sum(cz);
+            const double beta = (B.lane < P.p) ? L.xb[P.n + B.lane] : 0.0;
+            const double sb = wave_sum(beta);
+            if (B.lane < P.p) wv[2 + B.lane] = ok ? beta : 0.0;
+            if (B.lane == 0) {
+                wv[0] = ok ? fma(EHM_WIT_REL, r.margin, cz) : 0.0;
+                wv[1] = ok ? 1.0 - sb : 0.0;
+            }
+        }
         if (tid == 0) {
             if (r.status != 0) {
                 atomicAdd(&cnt->errors, 1ULL);
@@ -372,6 +409,19 @@ EHM3_KERNEL void k3_lcss_expand(
                 g0[k] = (k >= bi * p && k < bi * p + p) ? nb.g[k - bi * p] : gv;
                 g0[ng + k] = (k >= bj * p && k < bj * p + p) ? nb.g[k - bj * p] : gv;
             }
+        }
+        if (T.wit && tid < p + 2) {
+            // the node's witness goes to the child that contains it: child 0 (vertex bi ->
+            // midpoint) iff alpha_bj >= alpha_bi (all zero = none, and stays all zero)
+            const double* wv = T.wit + (size_t)id * (p + 2);
+            double* w0 = T.wit + (size_t)c0 * (p + 2);
+            const double ai = wv[1 + bi], aj = wv[1 + bj];
+            const bool to0 = aj >= ai;
+            double v = wv[tid];
+            if (tid == 1 + bi) v = to0 ? 2.0 * ai : ai - aj;
+            if (tid == 1 + bj) v = to0 ? aj - ai : 2.0 * aj;
+            w0[tid] = to0 ? v : 0.0;
+            w0[(p + 2) + tid] = to0 ? 0.0 : v;
         }
         double* rec0 = T.rec + (size_t)c0 * T.rec_stride;
         double* rec1 = rec0 + T.rec_stride;
