@@ -164,6 +164,8 @@ struct DevCounters {
     unsigned long long wit_open;          // nodes proved open by their midpoint solve, no LP
     unsigned long long routed;            // decisions with |t*| < EHM_ROUTE_TOL (full-accuracy LP)
     unsigned long long wit_inherited;     // nodes proved open by an ancestor's witness, no LP
+    unsigned int ticket;                  // work distribution of the wide sweep kernels: next
+    unsigned int ticket_pad;              // frontier position (zeroed before every launch)
 };
 
 __host__ __device__ inline int rec_off_vcost(int p) { return (p + 1) * p; }

@@ -255,10 +255,17 @@ EHM3_KERNEL void k3_lcss_decide(
     int32_t* __restrict__ open_flag, DevCounters* cnt, int sign_only) {
     K3_PROLOGUE(0);
     const int nrec = rec_doubles(P.p, P.n_u);
-    const int per = (nf + gridDim.x - 1) / gridDim.x;
-    const int lo = blockIdx.x * per;
-    const int hi = (lo + per < nf) ? lo + per : nf;
-    for (int f = lo; f < hi; ++f) {
+    // Workgroups draw frontier positions from a ticket (DevCounters::ticket, zeroed by the
+    // launcher): a node costs anything between a tangent-plane bound and a 20-iteration LP, and
+    // neighbours in the frontier are siblings with alike costs -- contiguous shares per
+    // workgroup took 29 % longer on config 4, interleaved ones 8 %.
+    __shared__ int s_ticket;
+    for (;;) {
+        __syncthreads();
+        if (tid0 == 0) s_ticket = (int)atomicAdd(&cnt->ticket, 1u);
+        __syncthreads();
+        const int f = s_ticket;
+        if (f >= nf) break;
         tid = pin(tid0);
         const int id = frontier[f];
         const double* rec = T.rec + (size_t)id * T.rec_stride;
@@ -365,10 +372,13 @@ EHM3_KERNEL void k3_lcss_expand(
     K3_PROLOGUE(0);
     const int p = P.p, n_u = P.n_u;
     const int nrec = rec_doubles(p, n_u);
-    const int per = (n_open + gridDim.x - 1) / gridDim.x;
-    const int lo = blockIdx.x * per;
-    const int hi = (lo + per < n_open) ? lo + per : n_open;
-    for (int f = lo; f < hi; ++f) {
+    __shared__ int s_ticket;
+    for (;;) {
+        __syncthreads();
+        if (tid0 == 0) s_ticket = (int)atomicAdd(&cnt->ticket, 1u);
+        __syncthreads();
+        const int f = s_ticket;
+        if (f >= n_open) break;
         tid = pin(tid0);
         const int id = open_list[f];
         const double* rec = T.rec + (size_t)id * T.rec_stride;
@@ -568,11 +578,13 @@ void l_simplex(const K2Launch& L, DevProblem P, long long n_inst, const double* 
 }
 void l_decide(const K2Launch& L, DevProblem P, DevTree T, const int32_t* frontier, int nf,
               int32_t* open_flag, DevCounters* cnt, int sign_only) {
+    (void)hipMemsetAsync(&cnt->ticket, 0, sizeof(unsigned int), L.stream);
     hipLaunchKernelGGL(k3_lcss_decide, dim3(L.grid), dim3(L.threads), L.lds_bytes, L.stream, P,
                        T, frontier, nf, open_flag, cnt, sign_only);
 }
 void l_expand(const K2Launch& L, DevProblem P, DevTree T, const int32_t* open_list, int n_open,
               int child_base, int32_t* next_frontier, DevCounters* cnt) {
+    (void)hipMemsetAsync(&cnt->ticket, 0, sizeof(unsigned int), L.stream);
     hipLaunchKernelGGL(k3_lcss_expand, dim3(L.grid), dim3(L.threads), L.lds_bytes, L.stream, P,
                        T, open_list, n_open, child_base, next_frontier, cnt);
 }
