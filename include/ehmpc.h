@@ -92,10 +92,6 @@ int ehm_problem_set_quadratic(ehm_problem* prob, const double* H, const double* 
                               const double* c0);
 /* Re-set eps_a / eps_r (examples.create_oracle builds a second Oracle, lib/examples.py:43-46). */
 int ehm_problem_set_eps(ehm_problem* prob, double eps_a, double eps_r);
-/* Kernel generation used by this handle's launches: 2 (default) = one copy of the
- * commutation's constant LP block in LDS per workgroup, several wavefronts per workgroup;
- * 1 = one wavefront per workgroup with a private copy of the LP (first build, kept as an
- * on-device cross-check).  Environment override at create time: EHM_SOLVER=1|2. */
 /* Replaces the constant blocks of commutation slots [first, first + count) (G [count][m][n],
  * w [count][m], S [count][m][p], row-major like ehm_problem_desc) and rebuilds every image the
  * kernels read for them.  With it the commutation table is a cache of problems generated on the
@@ -114,6 +110,10 @@ int ehm_simplex_idx_batch(ehm_problem* prob, int64_t n_inst, const double* R, co
 int ehm_point_idx_batch(ehm_problem* prob, int64_t n_inst, const double* theta,
                         const int32_t* slot, int32_t feas, double* J, double* u0,
                         int32_t* status);
+/* Kernel generation used by this handle's launches: 2 (default) = one copy of the
+ * commutation's constant LP block in LDS per workgroup, several wavefronts per workgroup;
+ * 1 = one wavefront per workgroup with a private copy of the LP (first build, kept as an
+ * on-device cross-check).  Environment override at create time: EHM_SOLVER=1|2. */
 int ehm_problem_set_solver(ehm_problem* prob, int generation);
 /* Named options: "solver" (1|2, as above); "decide_full" (0|1): by default the
  * suboptimality-test sweep of ehm_partition_run stops each LP as soon as the SIGN of its
