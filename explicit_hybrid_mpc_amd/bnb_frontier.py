@@ -1,0 +1,390 @@
+"""
+The searches of ``bnb.PrefixOracle`` for MANY nodes at once, and the partition driver on top of
+them: all open nodes of the tree are visited together, and every step of every node's search --
+one expansion of a best-first queue, one level of a lexicographic descent -- goes into the SAME
+batched launch (``sequences.PrefixTable.solve_*`` take (prefix, point / simplex) pairs, so the
+pairs of different nodes simply share a call).  ``bnb.grow`` pays ~40 launches per node visit;
+here a visit round of thousands of nodes pays about as many in total.
+
+Every function reproduces its one-node counterpart in ``bnb.py`` decision for decision (the CPU
+tests run both on the same table); the driver visits the nodes in another order, which does not
+matter -- a node's fate depends on its own record only (lib/worker.py:241-417).
+"""
+
+import heapq
+import numpy as np
+
+from . import sequences
+from .bnb import BATCH, PLATEAU, TIE_TOL, SolverError, _rel, _set_record
+from .tree import NodeData
+
+
+def _kids(q, n_modes):
+    return [q + (i,) for i in range(n_modes)]
+
+
+def first_feasible_many(table, point_sets, excludes=None):
+    """``PrefixSearch.first_feasible`` for a list of point sets: list of sequences / None."""
+    mpc = table.mpc
+    n_modes, N = mpc.delta_size, mpc.N
+    n = len(point_sets)
+    point_sets = [np.asarray(ps, dtype=np.float64).reshape(-1, mpc.n_x) for ps in point_sets]
+    excludes = excludes or [()] * n
+    stacks = [[()] for _ in range(n)]
+    out = [None] * n
+    active = list(range(n))
+    while active:
+        pre, pts, kid_of = [], [], {}
+        for j in active:
+            kids = _kids(stacks[j].pop(), n_modes)
+            kid_of[j] = kids
+            for k in kids:
+                pre.extend([k] * len(point_sets[j]))
+                pts.append(point_sets[j])
+        J = table.solve_points(pre, np.vstack(pts), feasibility_only=True)[0]
+        pos, still = 0, []
+        for j in active:
+            npts = len(point_sets[j])
+            ok = np.isfinite(J[pos:pos + n_modes * npts]).reshape(n_modes, npts).all(axis=1)
+            pos += n_modes * npts
+            good = [k for k, g in zip(kid_of[j], ok) if g and k not in excludes[j]]
+            if good and len(good[0]) == N:
+                out[j] = good[0]
+                continue
+            stacks[j].extend(reversed(good))
+            if stacks[j]:
+                still.append(j)
+        active = still
+    return out
+
+
+def bar_e_many(oracle, Rs, Vs):
+    """``PrefixOracle.bar_E_delta_R`` for many nodes: (list of bool, list of margins)."""
+    table, mpc = oracle.table, oracle.mpc
+    n_modes, N = mpc.delta_size, mpc.N
+    n = len(Rs)
+    heaps = [[(-np.inf, ())] for _ in range(n)]
+    refuted = [np.inf] * n
+    closed, margin = [None] * n, [np.inf] * n
+    active = list(range(n))
+    oracle.calls['bar_E'] += n
+    while active:
+        pre, Rp, Vp, kid_of = [], [], [], {}
+        for j in active:
+            batch = [heapq.heappop(heaps[j])[1] for _ in range(min(BATCH, len(heaps[j])))]
+            oracle.n_expanded += len(batch)
+            kids = [k for q in batch for k in _kids(q, n_modes)]
+            kid_of[j] = kids
+            pre.extend(kids)
+            Rp.extend([Rs[j]] * len(kids))
+            Vp.extend([Vs[j]] * len(kids))
+        t, _ = table.solve_slack(pre, np.array(Rp), np.array(Vp))
+        pos, still = 0, []
+        for j in active:
+            kids = kid_of[j]
+            tj = t[pos:pos + len(kids)]
+            pos += len(kids)
+            for q, tq in zip(kids, tj):
+                if not tq >= 0.:
+                    refuted[j] = min(refuted[j], abs(tq))
+                elif len(q) == N:
+                    closed[j], margin[j] = False, abs(tq)
+                    break
+                else:
+                    heapq.heappush(heaps[j], (-tq, q))
+            if closed[j] is None:
+                if heaps[j]:
+                    still.append(j)
+                else:
+                    closed[j], margin[j] = True, refuted[j]
+        active = still
+    return closed, margin
+
+
+def bar_d_many(oracle, Rs, Vs, deltas_ref):
+    """``PrefixOracle.bar_D_delta_R`` for many nodes: list of its 4-tuples."""
+    table, mpc = oracle.table, oracle.mpc
+    n_modes, N = mpc.delta_size, mpc.N
+    n = len(Rs)
+    oracle.calls['bar_D'] += n
+    refs = [oracle.sequence_of(d) for d in deltas_ref]
+    phase = [1] * n
+    heaps = [[(-np.inf, ())] for _ in range(n)]
+    best = [-np.inf] * n
+    limit = [0.] * n
+    stacks = [None] * n
+    star = [None] * n                    # (sequence, alpha) once found; False = none exists
+
+    def floor(j):
+        return max(0., best[j] + PLATEAU * _rel(best[j])) if np.isfinite(best[j]) else 0.
+    active = list(range(n))
+    while active:
+        pre, Rp, Vp, kid_of = [], [], [], {}
+        for j in active:
+            if phase[j] == 1:
+                batch = []
+                while heaps[j] and len(batch) < BATCH and -heaps[j][0][0] >= floor(j):
+                    batch.append(heapq.heappop(heaps[j])[1])
+                oracle.n_expanded += len(batch)
+                kids = [k for q in batch for k in _kids(q, n_modes)]
+            else:
+                oracle.n_expanded += 1
+                kids = _kids(stacks[j].pop(), n_modes)
+            kid_of[j] = kids
+            pre.extend(kids)
+            Rp.extend([Rs[j]] * len(kids))
+            Vp.extend([Vs[j]] * len(kids))
+        t, alpha = table.solve_slack(pre, np.array(Rp), np.array(Vp))
+        # feasibility at every vertex, for the prefixes whose slack bound is not negative
+        live = np.flatnonzero(t >= 0.)
+        if live.size:
+            nv = Rs[0].shape[0]
+            vp = [pre[k] for k in live for _ in range(nv)]
+            vt = np.vstack([Rp[k] for k in live])
+            ok = np.isfinite(table.solve_points(vp, vt, feasibility_only=True)[0])
+            ok = ok.reshape(live.size, nv).all(axis=1)
+            t[live[~ok]] = -np.inf
+        pos, still = 0, []
+        for j in active:
+            kids = kid_of[j]
+            tj, aj = t[pos:pos + len(kids)], alpha[pos:pos + len(kids)]
+            pos += len(kids)
+            if phase[j] == 1:
+                for q, tq in zip(kids, tj):
+                    if not tq >= 0.:
+                        continue
+                    if len(q) == N:
+                        best[j] = max(best[j], tq)
+                    else:
+                        heapq.heappush(heaps[j], (-tq, q))
+                if not (heaps[j] and -heaps[j][0][0] >= floor(j)):
+                    if not np.isfinite(best[j]):
+                        star[j] = False
+                        continue
+                    phase[j] = 2
+                    limit[j] = max(0., best[j] - TIE_TOL * _rel(best[j]))
+                    stacks[j] = [()]
+                still.append(j)
+            else:
+                good = [(k, a) for k, tk, a in zip(kids, tj, aj) if tk >= limit[j]]
+                if good and len(good[0][0]) == N:
+                    star[j] = good[0]
+                    continue
+                stacks[j].extend(k for k, _ in reversed(good))
+                if not stacks[j]:
+                    raise SolverError('bar_D: the slack found in phase one was not reproduced')
+                still.append(j)
+        active = still
+    # the winners' vertex solves and variability checks, one call each
+    out = [(None, None, None, None)] * n
+    win = [j for j in range(n) if star[j] and star[j][0] != refs[j]]
+    if not win:
+        return out
+    nv = Rs[0].shape[0]
+    Jv, uv = table.solve_points([star[j][0] for j in win for _ in range(nv)],
+                                np.vstack([Rs[j] for j in win]))
+    Jv, uv = Jv.reshape(len(win), nv), uv.reshape(len(win), nv, -1)
+    thetas = np.array([star[j][1] @ Rs[j] for j in win])
+    Jmin = table.solve_min([refs[j] for j in win], np.array([Rs[j] for j in win]))
+    Jth = table.solve_points([star[j][0] for j in win], thetas)[0]
+    for w, j in enumerate(win):
+        if not (np.all(np.isfinite(Jv[w])) and np.isfinite(Jmin[w]) and np.isfinite(Jth[w])):
+            # a failed solve: the blacklist-and-retry path of the one-node oracle
+            oracle.calls['bar_D'] -= 1
+            out[j] = oracle.bar_D_delta_R(Rs[j], Vs[j], deltas_ref[j])
+            continue
+        vx = [(uv[w, i].copy(), float(Jv[w, i]), 0.) for i in range(nv)]
+        rhs = max(oracle.eps_a, oracle.eps_r * float(Jth[w]))
+        small = bool(np.max(Vs[j]) - float(Jmin[w]) < rhs)
+        out[j] = (oracle.delta_of(star[j][0]), thetas[w], vx, small)
+    return out
+
+
+def region_tables_many(oracle, Rs, commutations, Us, table_max):
+    """
+    Region tables (``sequences.relevant_sequences``) of many lcss nodes: the bound U of a node
+    is the largest vertex cost of ITS commutation (feasible at every vertex, so V* <= U on the
+    node).  Returns a list of sorted sequence lists, None where more than ``table_max`` survive.
+    """
+    table, mpc = oracle.table, oracle.mpc
+    n_modes = mpc.delta_size
+    n = len(Rs)
+    alive = [[()] for _ in range(n)]
+    bounds = [u + TIE_TOL * (1. + abs(u)) for u in Us]
+    active = list(range(n))
+    for _ in range(mpc.N):
+        if not active:
+            break
+        pre, Rp, owner = [], [], []
+        for j in active:
+            cand = [q + (i,) for q in alive[j] for i in range(n_modes)]
+            alive[j] = cand
+            pre.extend(cand)
+            Rp.extend([Rs[j]] * len(cand))
+        cost = table.solve_min(pre, np.array(Rp))
+        pos, still = 0, []
+        for j in active:
+            c = cost[pos:pos + len(alive[j])]
+            pos += len(alive[j])
+            alive[j] = [q for q, cq in zip(alive[j], c) if cq <= bounds[j]]
+            if len(alive[j]) > table_max:
+                alive[j] = None
+            else:
+                still.append(j)
+        active = still
+    out = []
+    for j in range(n):
+        if alive[j] is None:
+            out.append(None)
+            continue
+        seqs = sorted(set(alive[j]) | {oracle.sequence_of(commutations[j])})
+        out.append(seqs if len(seqs) <= table_max else None)
+    return out
+
+
+def _hand_off(oracle, nodes, table_max, engine_opts, stats):
+    """Nodes (lcss, open) whose region table fits go to the device engine; returns the rest."""
+    from . import engine, partition
+    mpc = oracle.mpc
+    Rs = [np.asarray(nd.data.vertices, dtype=np.float64) for nd in nodes]
+    tables = region_tables_many(oracle, Rs, [nd.data.commutation for nd in nodes],
+                                [float(np.max(nd.data.vertex_costs)) for nd in nodes], table_max)
+    keep = []
+    for k, (nd, R, seqs) in enumerate(zip(nodes, Rs, tables)):
+        if seqs is None:
+            stats['tables_too_large'] += 1
+            keep.append(k)
+            continue
+        gp = engine.GpuProblem(mpc.restrict(seqs).compile(), oracle.eps_a, oracle.eps_r,
+                               device=getattr(oracle.table, 'device', 0))
+        try:
+            init = dict(delta=np.asarray(nd.data.commutation, dtype=np.float64)[None],
+                        vertex_costs=np.asarray(nd.data.vertex_costs)[None],
+                        vertex_inputs=np.asarray(nd.data.vertex_inputs)[None])
+            flat = gp.partition(R[None], action='lcss', init=init, **(engine_opts or {}))
+        finally:
+            gp.close()
+        partition.graft_flat(flat, [nd])
+        stats['handoffs'] += 1
+        stats['handoff_nodes'] += flat.n_nodes
+        stats['handoff_leaves'] += int(flat.info['n_leaves'])
+        stats['table_sizes'].append(len(seqs))
+    return keep
+
+
+def grow_frontier(oracle, branch, action='ecc', table_max=256, max_visits=None, handoff=True,
+                  engine_opts=None, split_batch=None, round_cap=4096, log=None):
+    """
+    ``bnb.grow`` with all pending nodes visited together (module docstring).  Same arguments and
+    the same tree; ``round_cap`` bounds the nodes of one round, ``split_batch(R (n,p+1,p)) ->
+    (S1, S2, ij)`` replaces the device bisection kernel (``engine.split_batch``).  Hand-off: an
+    lcss node that bar_E leaves OPEN goes to the device engine when its region table -- bounded
+    with its own commutation's vertex costs -- has at most ``table_max`` sequences (a node that
+    closes at once needs no table).
+    """
+    from . import engine
+    split_batch = split_batch or (lambda R: engine.split_batch(R, device=getattr(
+        oracle.table, 'device', 0)))
+    mpc = oracle.mpc
+    stats = dict(host_visits=0, rounds=0, handoffs=0, handoff_nodes=0, handoff_leaves=0,
+                 table_sizes=[], tables_too_large=0, truncated=False)
+    # one Tree or a list of them (the Delaunay roots of the set: their nodes share the rounds)
+    work = [(b, action) for b in (branch if isinstance(branch, (list, tuple)) else [branch])]
+    while work:
+        if max_visits is not None and stats['host_visits'] >= max_visits:
+            stats['truncated'] = True
+            break
+        cap = round_cap if max_visits is None else min(round_cap,
+                                                       max_visits - stats['host_visits'])
+        batch, work = work[:cap], work[cap:]
+        stats['rounds'] += 1
+        ecc = [nd for nd, act in batch if act == 'ecc']
+        lcss = [nd for nd, act in batch if act != 'ecc']
+        stats['host_visits'] += len(ecc) + len(lcss)
+        if log:
+            log('round %d: %d ecc + %d lcss nodes, %d waiting' %
+                (stats['rounds'], len(ecc), len(lcss), len(work)))
+        to_split = []                       # (node, commutation or None, costs, inputs)
+        if ecc:                             # lib/worker.py:241-283
+            Rs = [np.asarray(nd.data.vertices, dtype=np.float64) for nd in ecc]
+            oracle.calls['P_theta'] += len(ecc)
+            oracle.calls['V_R'] += len(ecc)
+            if any(s is None for s in first_feasible_many(
+                    oracle.table, [np.average(R, axis=0)[None] for R in Rs])):
+                raise RuntimeError('STOP, Theta contains infeasible regions')
+            found = first_feasible_many(oracle.table, Rs)
+            have = [k for k, s in enumerate(found) if s is not None]
+            if have:
+                nv = Rs[0].shape[0]
+                Jv, uv = oracle.table.solve_points([found[k] for k in have for _ in range(nv)],
+                                                   np.vstack([Rs[k] for k in have]))
+                Jv, uv = Jv.reshape(len(have), nv), uv.reshape(len(have), nv, -1)
+            for w, k in enumerate(have):
+                if not np.all(np.isfinite(Jv[w])):      # lib/oracle.py:214-218: blacklist, retry
+                    oracle.calls['V_R'] -= 1
+                    delta, vx = oracle.V_R(Rs[k])
+                    if delta is None:
+                        found[k] = None
+                        continue
+                else:
+                    delta = oracle.delta_of(found[k])
+                    vx = [(uv[w, i].copy(), float(Jv[w, i]), 0.) for i in range(nv)]
+                _set_record(ecc[k].data, delta, vx)
+                work.append((ecc[k], 'lcss'))
+            to_split += [(ecc[k], None, None, None) for k, s in enumerate(found) if s is None]
+        if lcss:                            # lib/worker.py:340-417
+            Rs = [np.asarray(nd.data.vertices, dtype=np.float64) for nd in lcss]
+            Vs = [np.asarray(nd.data.vertex_costs, dtype=np.float64) for nd in lcss]
+            closed, margins = bar_e_many(oracle, Rs, Vs)
+            oracle.last_margin = min([oracle.last_margin] + margins)
+            opened = [k for k, c in enumerate(closed) if not c]
+            for k, c in enumerate(closed):
+                if c:
+                    lcss[k].data.is_epsilon_suboptimal = True
+            if handoff and opened:          # the open ones: to the engine where the table fits
+                keep = _hand_off(oracle, [lcss[k] for k in opened], table_max, engine_opts, stats)
+                opened = [opened[k] for k in keep]
+            res = bar_d_many(oracle, [Rs[k] for k in opened], [Vs[k] for k in opened],
+                             [lcss[k].data.commutation for k in opened]) if opened else []
+            for k, (delta_star, theta_star, new_vx, small) in zip(opened, res):
+                data = lcss[k].data
+                if delta_star is None:
+                    to_split.append((lcss[k], data.commutation, data.vertex_costs,
+                                     data.vertex_inputs))
+                    continue
+                costs = np.array([v[1] for v in new_vx])
+                inputs = np.array([v[0] for v in new_vx])
+                if small:                   # lib/worker.py:396-401
+                    data.commutation, data.vertex_costs, data.vertex_inputs = (delta_star, costs,
+                                                                                inputs)
+                    work.append((lcss[k], 'lcss'))
+                else:
+                    to_split.append((lcss[k], delta_star, costs, inputs))
+        if to_split:
+            S1, S2, ij = split_batch(np.array([np.asarray(nd.data.vertices, dtype=np.float64)
+                                               for nd, _, _, _ in to_split]))
+            with_data = [k for k, item in enumerate(to_split) if item[1] is not None]
+            if with_data:
+                mids = np.array([S1[k][ij[k][0]] for k in with_data])
+                Jm, um = oracle.table.solve_points(
+                    [oracle.sequence_of(to_split[k][1]) for k in with_data], mids)
+            for w, k in enumerate(with_data):
+                nd, delta, costs, inputs = to_split[k]
+                i, j = int(ij[k][0]), int(ij[k][1])
+                if not np.isfinite(Jm[w]):
+                    raise SolverError('midpoint solve of the adopted commutation failed')
+                in_1, in_2, co_1, co_2 = inputs.copy(), inputs.copy(), costs.copy(), costs.copy()
+                in_1[i], in_2[j] = um[w], um[w]
+                co_1[i], co_2[j] = Jm[w], Jm[w]
+                nd.grow(NodeData(vertices=S1[k].copy(), commutation=delta, vertex_costs=co_1,
+                                 vertex_inputs=in_1),
+                        NodeData(vertices=S2[k].copy(), commutation=delta, vertex_costs=co_2,
+                                 vertex_inputs=in_2))
+                work.append((nd.left, 'lcss'))
+                work.append((nd.right, 'lcss'))
+            for k, (nd, delta, _, _) in enumerate(to_split):
+                if delta is None:
+                    nd.grow(NodeData(vertices=S1[k].copy()), NodeData(vertices=S2[k].copy()))
+                    work.append((nd.left, 'ecc'))
+                    work.append((nd.right, 'ecc'))
+    return stats

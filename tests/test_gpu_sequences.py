@@ -229,15 +229,18 @@ def _walk_equal(branch, flat, n_min):
     assert n == flat.n_nodes and n >= n_min
 
 
+@pytest.mark.parametrize('frontier', [False, True])
 @pytest.mark.parametrize('frac,size,eps', [(0.6, 0.35, 0.05), (0.7, 0.25, 0.02)])
 @pytest.mark.parametrize('handoff', [False, True])
-def test_driver_with_search_oracles_grows_the_enumerating_engines_tree(handoff, frac, size, eps):
+def test_driver_with_search_oracles_grows_the_enumerating_engines_tree(handoff, frac, size, eps,
+                                                                       frontier):
     """
     4 modes, N = 4: all 256 sequences fit the device engine, which is the reference here.  The
     driver of bnb.py -- branch-and-bound oracles at the top, region tables of at most 128
-    sequences handed to the engine below -- must grow the same tree, node for node.
+    sequences handed to the engine below -- must grow the same tree, node for node; so must the
+    frontier-wide driver (bnb_frontier.grow_frontier: all open nodes' searches in shared launches).
     """
-    from explicit_hybrid_mpc_amd import examples, engine, bnb
+    from explicit_hybrid_mpc_amd import examples, engine, bnb, bnb_frontier
     from explicit_hybrid_mpc_amd.tree import Tree, NodeData
     mpc = examples.pwa4_mpc()
     R = region(mpc, frac, size)
@@ -250,9 +253,10 @@ def test_driver_with_search_oracles_grows_the_enumerating_engines_tree(handoff, 
     assert flat.info['truncated'] == 0 and flat.info['min_margin'] > 1e-6
     orc = bnb.PrefixOracle(mpc, eps_a, eps_r, slots=1024)
     branch = Tree(NodeData(vertices=R.copy()))
-    stats = bnb.grow(orc, branch, 'ecc', handoff=handoff, table_max=128)
-    print('\nN=4 driver (handoff=%s): %d nodes; %s; oracle calls %s, %d prefixes expanded, %d LPs'
-          % (handoff, flat.n_nodes, {k: v for k, v in stats.items() if k != 'table_sizes'},
+    grow = bnb_frontier.grow_frontier if frontier else bnb.grow
+    stats = grow(orc, branch, 'ecc', handoff=handoff, table_max=128)
+    print('\nN=4 driver (handoff=%s, frontier-wide=%s): %d nodes; %s; oracle calls %s, %d prefixes '
+          'expanded, %d LPs' % (handoff, frontier, flat.n_nodes, {k: v for k, v in stats.items() if k != 'table_sizes'},
              orc.calls, orc.n_expanded, orc.table.lp_solves))
     orc.close()
     assert not stats['truncated']
@@ -320,8 +324,9 @@ def test_search_oracles_equal_the_full_enumeration_at_65536_sequences():
     table.close()
 
 
-def _grow_and_check(mpc, R, eps, max_visits, label):
-    from explicit_hybrid_mpc_amd import bnb, tools
+def _grow_and_check(mpc, R, eps, max_visits, label, frontier=False):
+    import time
+    from explicit_hybrid_mpc_amd import bnb, bnb_frontier, tools
     from explicit_hybrid_mpc_amd.tree import Tree, NodeData
     orc = bnb.PrefixOracle(mpc, 1., 1., slots=4096)
     J = [orc.P_theta(v)[2] for v in R[:2]]
@@ -329,13 +334,16 @@ def _grow_and_check(mpc, R, eps, max_visits, label):
     orc.eps_a, orc.eps_r = eps_a, eps[1]
     orc.table.set_eps(eps_a, eps[1])
     branch = Tree(NodeData(vertices=R.copy()))
-    stats = bnb.grow(orc, branch, 'ecc', max_visits=max_visits)
+    t0 = time.time()
+    grow = bnb_frontier.grow_frontier if frontier else bnb.grow
+    stats = grow(orc, branch, 'ecc', max_visits=max_visits)
+    seconds = time.time() - t0
     leaves = list(branch.leaves())
     closed = [n for n, _ in leaves if n.data.is_epsilon_suboptimal]
-    print('\n%s: %d nodes, %d leaves (%d closed); %s; oracle calls %s; %d prefixes expanded, '
-          '%d LPs, %d table blocks loaded'
-          % (label, sum(1 for _ in branch.walk()), len(leaves), len(closed), stats, orc.calls,
-             orc.n_expanded, orc.table.lp_solves, orc.table.blocks_loaded))
+    print('\n%s: %d nodes, %d leaves (%d closed) in %.1f s; %s; oracle calls %s; %d prefixes '
+          'expanded, %d LPs, %d table blocks loaded'
+          % (label, sum(1 for _ in branch.walk()), len(leaves), len(closed), seconds, stats,
+             orc.calls, orc.n_expanded, orc.table.lp_solves, orc.table.blocks_loaded))
     orc.close()
     vol = sum(tools.simplex_volume(n.data.vertices) for n, _ in leaves)
     assert abs(vol - tools.simplex_volume(R)) <= 1e-9 * vol
@@ -372,3 +380,16 @@ def test_driver_at_the_top_of_the_config5_tree():
     stats, leaves, closed = _grow_and_check(mpc, R, (0.5, 1.0), 40, 'N=8 whole-box simplex')
     assert stats['host_visits'] == 40 and stats['truncated']
     assert len(closed) >= 3 and len(leaves) >= 10
+
+
+def test_frontier_wide_driver_at_the_top_of_the_config5_tree():
+    """The run of the previous test with ALL pending nodes visited together
+    (bnb_frontier.grow_frontier): a hundred times the visits in comparable time."""
+    from explicit_hybrid_mpc_amd import examples
+    mpc = examples.pwa4_mpc(N=8)
+    half = examples.theta_box(mpc)
+    R = np.array([-half + 2 * half * (np.arange(8) < k) for k in range(9)])
+    stats, leaves, closed = _grow_and_check(mpc, R, (0.5, 1.0), 4000,
+                                            'N=8 whole-box simplex, frontier-wide', frontier=True)
+    assert stats['host_visits'] == 4000 and stats['truncated'] and stats['rounds'] <= 20
+    assert len(leaves) >= 3000                  # breadth first: the ecc phase of the whole cell

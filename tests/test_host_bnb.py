@@ -112,3 +112,62 @@ def test_oracles_equal_enumeration_at_256_sequences():
     before = table.lp_solves
     assert _same_bar_d(full.bar_D_delta_R(R, V, d1), bo.bar_D_delta_R(R, V, d1))
     assert table.lp_solves - before < 0.5 * 256 * 10     # enumeration: 256 x (9 + 1) problems
+
+
+def _host_split_batch(R):
+    out = [geometry.split_along_longest_edge(r) for r in R]
+    return (np.array([o[0] for o in out]), np.array([o[1] for o in out]),
+            np.array([o[2] for o in out], dtype=np.int32))
+
+
+def test_frontier_wide_searches_equal_the_one_node_searches():
+    """bnb_frontier: every node's search step in one shared call -- same answers, same tree."""
+    from explicit_hybrid_mpc_amd import bnb_frontier
+    mpc = helpers.make_instance('pwa_small', 0)
+    eps_a = helpers.eps_a_rule(mpc, 0.25)
+    table = prefix_bb.CpuPrefixTable(mpc)
+    bo = bnb.PrefixOracle(mpc, eps_a, 0.2, table=table)
+    rng = np.random.default_rng(2)
+    Rs = [np.array(R) for R in helpers.random_simplices(mpc, rng, 25, scale_lo=-1.)]
+    one = [table.first_feasible(R) for R in Rs]
+    assert bnb_frontier.first_feasible_many(table, Rs) == one
+    assert any(s is not None for s in one)
+    have = [k for k, s in enumerate(one) if s is not None]
+    Rh = [Rs[k] for k in have]
+    Vh = [np.array([v[1] for v in bo._vertex_solves(Rs[k], one[k])]) for k in have]
+    dh = [bo.delta_of(one[k]) for k in have]
+    closed, margins = bnb_frontier.bar_e_many(bo, Rh, Vh)
+    for R, V, c, m in zip(Rh, Vh, closed, margins):
+        assert bo.bar_E_delta_R(R, V) == c and bo.last_margin == m
+    many = bnb_frontier.bar_d_many(bo, Rh, Vh, dh)
+    n_star = 0
+    for R, V, d, got in zip(Rh, Vh, dh, many):
+        n_star += _same_bar_d(bo.bar_D_delta_R(R, V, d), got)
+    assert n_star >= 1
+    # the driver: the tree of bnb.grow (and so of the enumerating partition)
+    roots, locs = helpers.roots_of(mpc)
+    for R in roots:
+        a = Tree(NodeData(vertices=np.array(R)))
+        b = Tree(NodeData(vertices=np.array(R)))
+        bnb.grow(bo, a, 'ecc', handoff=False, split=geometry.split_along_longest_edge)
+        stats = bnb_frontier.grow_frontier(bo, b, 'ecc', handoff=False,
+                                           split_batch=_host_split_batch, round_cap=7)
+        assert not stats['truncated'] and stats['rounds'] > 2
+        na = {loc: nd for nd, loc in a.walk()}
+        nb = {loc: nd for nd, loc in b.walk()}
+        assert set(na) == set(nb)
+        for loc, x in na.items():
+            y = nb[loc]
+            assert np.array_equal(x.data.vertices, y.data.vertices)
+            assert x.is_leaf() == y.is_leaf()
+            assert x.data.is_epsilon_suboptimal == y.data.is_epsilon_suboptimal
+            assert hasattr(x.data, 'commutation') == hasattr(y.data, 'commutation')
+            if hasattr(x.data, 'commutation'):
+                assert np.array_equal(x.data.commutation, y.data.commutation)
+                assert np.allclose(x.data.vertex_costs, y.data.vertex_costs, atol=1e-12)
+                assert np.allclose(x.data.vertex_inputs, y.data.vertex_inputs, atol=1e-9)
+    # a budget of visits is respected
+    c = Tree(NodeData(vertices=np.array(roots[0])))
+    stats = bnb_frontier.grow_frontier(bo, c, 'ecc', handoff=False, max_visits=3,
+                                       split_batch=_host_split_batch)
+    assert stats['truncated'] and stats['host_visits'] == 3

@@ -2,7 +2,7 @@
 or a budget of host visits."""
 import sys, time, numpy as np
 sys.path.insert(0, '.')
-from explicit_hybrid_mpc_amd import examples, bnb
+from explicit_hybrid_mpc_amd import examples, bnb, bnb_frontier
 from explicit_hybrid_mpc_amd.tree import Tree, NodeData
 budget = int(sys.argv[1]) if len(sys.argv) > 1 else 600
 mpc = examples.pwa4_mpc(N=8)
@@ -16,7 +16,12 @@ orc.eps_a, orc.eps_r = 0.5 * Jm, 1.0
 orc.table.set_eps(orc.eps_a, 1.0)
 t = time.time()
 branch = Tree(NodeData(vertices=R.copy()))
-stats = bnb.grow(orc, branch, 'ecc', max_visits=budget)
+frontier = len(sys.argv) > 2 and sys.argv[2] == 'frontier'
+if frontier:
+    stats = bnb_frontier.grow_frontier(orc, branch, 'ecc', max_visits=budget, round_cap=16384,
+                                       log=lambda m: print('  ', m, '%.1fs' % (time.time() - t), flush=True))
+else:
+    stats = bnb.grow(orc, branch, 'ecc', max_visits=budget)
 leaves = list(branch.leaves())
 depth = max(len(loc) for _, loc in leaves)
 print('budget', budget, 'nodes', sum(1 for _ in branch.walk()), 'leaves', len(leaves), 'depth', depth,
