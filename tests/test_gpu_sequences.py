@@ -393,3 +393,57 @@ def test_frontier_wide_driver_at_the_top_of_the_config5_tree():
                                             'N=8 whole-box simplex, frontier-wide', frontier=True)
     assert stats['host_visits'] == 4000 and stats['truncated'] and stats['rounds'] <= 20
     assert len(leaves) >= 3000                  # breadth first: the ecc phase of the whole cell
+
+
+def test_whole_cell_partition_delivers_the_guarantee():
+    """
+    N = 8, 65 536 sequences: a cell spanning the whole box partitioned to COMPLETION by the
+    frontier-wide driver, then the explicit law's guarantee (the point of the whole exercise,
+    lib/oracle.py:89-97) checked at random parameters: the cost interpolated in the leaf that
+    holds theta exceeds the mixed-integer optimum (branch and bound at theta) by less than
+    max(eps_a, eps_r V*).
+    """
+    import time
+    from explicit_hybrid_mpc_amd import examples, bnb, bnb_frontier, tools
+    from explicit_hybrid_mpc_amd.tree import Tree, NodeData
+    mpc = examples.pwa4_mpc(N=8)
+    half = examples.theta_box(mpc)
+    R = np.array([-half + 2 * half * (np.arange(8) < k) for k in range(9)])
+    orc = bnb.PrefixOracle(mpc, 1., 1., slots=8192)
+    Jm = max(orc.P_theta(v)[2] for v in R)
+    eps_a, eps_r = 0.5 * Jm, 1.0
+    orc.eps_a, orc.eps_r = eps_a, eps_r
+    orc.table.set_eps(eps_a, eps_r)
+    root = Tree(NodeData(vertices=R.copy()))
+    t0 = time.time()
+    stats = bnb_frontier.grow_frontier(orc, root, 'ecc', round_cap=16384)
+    seconds = time.time() - t0
+    leaves = list(root.leaves())
+    print('\nN=8 whole-box cell to completion: %d nodes, %d regions in %.1f s; %s; %d LPs'
+          % (sum(1 for _ in root.walk()), len(leaves), seconds,
+             {k: v for k, v in stats.items() if k != 'table_sizes'}, orc.table.lp_solves))
+    assert not stats['truncated'] and len(leaves) > 20000
+    assert all(n.data.is_epsilon_suboptimal for n, _ in leaves)
+    vol = sum(tools.simplex_volume(n.data.vertices) for n, _ in leaves[::50])
+    assert vol > 0
+
+    def bary(S, th):
+        return np.linalg.solve(np.vstack([S.T, np.ones(9)]), np.append(th, 1.))
+    rng = np.random.default_rng(5)
+    worst = -np.inf
+    for a in rng.dirichlet(np.ones(9), size=24):
+        th = a @ R
+        node = root
+        while not node.is_leaf():
+            node = node.left if bary(node.left.data.vertices, th).min() >= -1e-12 else node.right
+        w = bary(node.data.vertices, th)
+        assert w.min() >= -1e-9
+        V_bar = float(w @ node.data.vertex_costs)
+        u, delta, V_star, _ = orc.P_theta(th)
+        assert V_star <= V_bar + 1e-9                    # the leaf's sequence is feasible there
+        gap = V_bar - V_star - max(eps_a, eps_r * V_star)
+        worst = max(worst, gap)
+        assert gap < 1e-7
+    print('   guarantee at 24 random parameters: worst V_bar - V* - max(eps_a, eps_r V*) = %.3g'
+          % worst)
+    orc.close()
