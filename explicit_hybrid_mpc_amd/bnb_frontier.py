@@ -24,30 +24,39 @@ def _kids(q, n_modes):
 
 
 def first_feasible_many(table, point_sets, excludes=None):
-    """``PrefixSearch.first_feasible`` for a list of point sets: list of sequences / None."""
+    """``PrefixSearch.first_feasible`` for a list of point sets OF ONE SIZE: list of sequences /
+    None.  The pairs of a step are described by index arrays (``solve_points_idx``): the Python
+    work per step is per node, not per (prefix, point) pair."""
     mpc = table.mpc
     n_modes, N = mpc.delta_size, mpc.N
     n = len(point_sets)
-    point_sets = [np.asarray(ps, dtype=np.float64).reshape(-1, mpc.n_x) for ps in point_sets]
+    if not n:
+        return []
+    points = np.asarray(point_sets, dtype=np.float64).reshape(n, -1, mpc.n_x)
+    npts = points.shape[1]
     excludes = excludes or [()] * n
     stacks = [[()] for _ in range(n)]
     out = [None] * n
     active = list(range(n))
     while active:
-        pre, pts, kid_of = [], [], {}
-        for j in active:
-            kids = _kids(stacks[j].pop(), n_modes)
-            kid_of[j] = kids
-            for k in kids:
-                pre.extend([k] * len(point_sets[j]))
-                pts.append(point_sets[j])
-        J = table.solve_points(pre, np.vstack(pts), feasibility_only=True)[0]
-        pos, still = 0, []
-        for j in active:
-            npts = len(point_sets[j])
-            ok = np.isfinite(J[pos:pos + n_modes * npts]).reshape(n_modes, npts).all(axis=1)
-            pos += n_modes * npts
-            good = [k for k, g in zip(kid_of[j], ok) if g and k not in excludes[j]]
+        uniq, where, kid_idx = [], {}, np.empty((len(active), n_modes), dtype=np.int64)
+        for a, j in enumerate(active):
+            q = stacks[j].pop()
+            for i in range(n_modes):
+                k = q + (i,)
+                u = where.get(k)
+                if u is None:
+                    u = where[k] = len(uniq)
+                    uniq.append(k)
+                kid_idx[a, i] = u
+        idx = np.repeat(kid_idx.reshape(-1), npts)
+        thetas = np.repeat(points[active][:, None], n_modes, axis=1).reshape(-1, mpc.n_x)
+        J = table.solve_points_idx(uniq, idx, thetas, feasibility_only=True)[0]
+        ok = np.isfinite(J).reshape(len(active), n_modes, npts).all(axis=2)
+        still = []
+        for a, j in enumerate(active):
+            good = [uniq[kid_idx[a, i]] for i in range(n_modes)
+                    if ok[a, i] and uniq[kid_idx[a, i]] not in excludes[j]]
             if good and len(good[0]) == N:
                 out[j] = good[0]
                 continue

@@ -163,11 +163,16 @@ EHM3_KERNEL void k3_point_batch(
     int32_t* __restrict__ status, int32_t* __restrict__ iters, DevCounters* cnt, K2Gather G) {
     K3_PROLOGUE(0);
     if (G.n_dev) n_inst = *G.n_dev;
-    const long long per = (n_inst + gridDim.x - 1) / gridDim.x;
-    const long long lo = (long long)blockIdx.x * per;
-    const long long hi = (lo + per < n_inst) ? lo + per : n_inst;
+    // instances are drawn from a ticket (DevCounters::ticket, zeroed by the launcher; see
+    // k3_lcss_decide): phase-one problems end after 4 iterations, ranked ones after 10
+    __shared__ unsigned int s_ticket;
     int d = 0;
-    for (long long inst = lo; inst < hi; ++inst) {
+    for (;;) {
+        __syncthreads();
+        if (tid0 == 0) s_ticket = atomicAdd(&cnt->ticket, 1u);
+        __syncthreads();
+        const long long inst = (long long)s_ticket;
+        if (inst >= n_inst) break;
         tid = pin(tid0);
         while (d + 1 < P.n_delta && seg[d + 1] <= inst) ++d;
         carve_lp(L, sm + node_doubles(P.p, P.n_u), P, d);
@@ -206,11 +211,16 @@ EHM3_KERNEL void k3_simplex_batch(
     const int p = P.p;
     const int nR = (p + 1) * p;
     if (G.n_dev) n_inst = *G.n_dev;
-    const long long per = (n_inst + gridDim.x - 1) / gridDim.x;
-    const long long lo = (long long)blockIdx.x * per;
-    const long long hi = (lo + per < n_inst) ? lo + per : n_inst;
+    // instances are drawn from a ticket (DevCounters::ticket, zeroed by the launcher; see
+    // k3_lcss_decide): phase-one problems end after 4 iterations, ranked ones after 10
+    __shared__ unsigned int s_ticket;
     int d = 0;
-    for (long long inst = lo; inst < hi; ++inst) {
+    for (;;) {
+        __syncthreads();
+        if (tid0 == 0) s_ticket = atomicAdd(&cnt->ticket, 1u);
+        __syncthreads();
+        const long long inst = (long long)s_ticket;
+        if (inst >= n_inst) break;
         tid = pin(tid0);
         while (d + 1 < P.n_delta && seg[d + 1] <= inst) ++d;
         carve_lp(L, sm + node_doubles(P.p, P.n_u), P, d);
@@ -567,12 +577,14 @@ size_t shared_doubles_for(const DevProblem&) { return 0; }
 void l_point(const K2Launch& L, DevProblem P, long long n_inst, const double* theta,
              const int32_t* seg, int feas, double* J, double* u0, int32_t* status,
              int32_t* iters, DevCounters* cnt, K2Gather G) {
+    (void)hipMemsetAsync(&cnt->ticket, 0, sizeof(unsigned int), L.stream);
     hipLaunchKernelGGL(k3_point_batch, dim3(L.grid), dim3(L.threads), L.lds_bytes, L.stream, P,
                        n_inst, theta, seg, feas, J, u0, status, iters, cnt, G);
 }
 void l_simplex(const K2Launch& L, DevProblem P, long long n_inst, const double* R,
                const double* Vbar, const int32_t* seg, int mode, double* obj, double* alpha,
                int32_t* status, int32_t* iters, DevCounters* cnt, K2Gather G) {
+    (void)hipMemsetAsync(&cnt->ticket, 0, sizeof(unsigned int), L.stream);
     hipLaunchKernelGGL(k3_simplex_batch, dim3(L.grid), dim3(L.threads), L.lds_bytes, L.stream,
                        P, n_inst, R, Vbar, seg, mode, obj, alpha, status, iters, cnt, G);
 }

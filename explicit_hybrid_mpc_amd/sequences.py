@@ -62,6 +62,11 @@ class PrefixSearch:
     """Searches over prefixes written on the three pair solvers of a table (``solve_points``,
     ``solve_min``, ``solve_slack``); the device table below provides them."""
 
+    def solve_points_idx(self, uniq, idx, thetas, feasibility_only=False):
+        """``solve_points`` with the prefixes given as indices into the list ``uniq`` (the device
+        table turns them into slots without touching the pairs one by one)."""
+        return self.solve_points([uniq[i] for i in idx], thetas, feasibility_only)
+
     def min_cost_on(self, prefixes, simplices):
         """
         For every prefix: the minimum of its relaxation's optimal cost over the union of the
@@ -186,6 +191,30 @@ class PrefixTable(PrefixSearch):
             yield idx, self._ensure([prefixes[k] for k in idx])
 
     # -- pair solvers -------------------------------------------------------------------------
+    def solve_points_idx(self, uniq, idx, thetas, feasibility_only=False):
+        idx = np.asarray(idx, dtype=np.int64)
+        thetas = np.asarray(thetas, dtype=np.float64).reshape(idx.size, -1)
+        J = np.full(idx.size, np.inf)
+        u0 = np.zeros((idx.size, self.mpc.n_u))
+        for c0 in range(0, len(uniq), self.slots):
+            part = uniq[c0:c0 + self.slots]
+            sel = np.flatnonzero((idx >= c0) & (idx < c0 + len(part))) if len(uniq) > self.slots \
+                else np.arange(idx.size)
+            if not sel.size:
+                continue
+            slot = self._ensure(part)[idx[sel] - c0]
+            tau = self.gp.point_idx(thetas[sel], slot, feas=True)[0]
+            self.lp_solves += sel.size
+            ok = tau <= FEAS_TOL
+            if feasibility_only:
+                J[sel[ok]] = 0.
+            elif ok.any():
+                Jk, uk, _ = self.gp.point_idx(thetas[sel[ok]], slot[ok])
+                self.lp_solves += int(ok.sum())
+                J[sel[ok]] = Jk
+                u0[sel[ok]] = uk
+        return J, u0
+
     def solve_points(self, prefixes, thetas, feasibility_only=False):
         """(J, u0): optimal cost (+inf: infeasible) and first input of prefix k at point k."""
         thetas = np.asarray(thetas, dtype=np.float64).reshape(len(prefixes), -1)

@@ -205,7 +205,7 @@ class CpuPrefixTable:
         self.lp_solves = 0
         self._models = {}
         for name in ('min_cost_on', 'vertex_costs', 'feasible_at_all', 'first_feasible',
-                     'feasible_on'):
+                     'feasible_on', 'solve_points_idx'):
             setattr(self, name, getattr(PrefixSearch, name).__get__(self))
 
     def set_eps(self, eps_a, eps_r):
