@@ -431,6 +431,7 @@ def test_whole_cell_partition_delivers_the_guarantee():
         return np.linalg.solve(np.vstack([S.T, np.ones(9)]), np.append(th, 1.))
     rng = np.random.default_rng(5)
     worst = -np.inf
+    thetas, u_leaf = [], []
     for a in rng.dirichlet(np.ones(9), size=24):
         th = a @ R
         node = root
@@ -439,6 +440,8 @@ def test_whole_cell_partition_delivers_the_guarantee():
         w = bary(node.data.vertices, th)
         assert w.min() >= -1e-9
         V_bar = float(w @ node.data.vertex_costs)
+        thetas.append(th)
+        u_leaf.append(w @ node.data.vertex_inputs)
         u, delta, V_star, _ = orc.P_theta(th)
         assert V_star <= V_bar + 1e-9                    # the leaf's sequence is feasible there
         gap = V_bar - V_star - max(eps_a, eps_r * V_star)
@@ -446,4 +449,11 @@ def test_whole_cell_partition_delivers_the_guarantee():
         assert gap < 1e-7
     print('   guarantee at 24 random parameters: worst V_bar - V* - max(eps_a, eps_r V*) = %.3g'
           % worst)
+    # the consumer: the explicit law evaluated on the device from this tree (lib/mpc_library.py:
+    # 662-792) returns the inputs interpolated in those leaves
+    from explicit_hybrid_mpc_amd import explicit
+    law = explicit.ExplicitMPC(root, orc)
+    U = law.evaluate(np.array(thetas))
+    law.close()
+    assert np.allclose(U, np.array(u_leaf), rtol=1e-9, atol=1e-9)
     orc.close()
