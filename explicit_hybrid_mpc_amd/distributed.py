@@ -384,3 +384,27 @@ def merge_flat(parts, root_locations=None, received=None):
     return FlatTree(take('vertices'), np.array(left, dtype=np.int32),
                     np.array(right, dtype=np.int32), take('delta_idx'), take('vertex_costs'),
                     take('vertex_inputs'), flags, take('tstar'), info, parts[0].deltas)
+
+
+def grow_roots_sharded(oracle, roots, action='ecc', **kw):
+    """
+    The search-oracle driver (``bnb_frontier.grow_frontier``: problems whose mode sequences
+    cannot be enumerated) over the ranks: root ``k`` of the list -- the Delaunay roots of the
+    set -- belongs to rank ``k % world``; the roots of a rank share their visit rounds.  The
+    subtrees are independent, so the data path has no collective (weak scaling over the
+    roots); the counts are all-gathered at the end.
+    Returns (the list of roots with THIS rank's roots grown in place, stats of this rank,
+    (world, 3) array of every rank's [host visits, leaves, roots]).
+    """
+    import torch.distributed as dist
+    from . import bnb_frontier
+    rank, _, world = env_rank_world()
+    if not (dist.is_available() and dist.is_initialized()):
+        world, rank = 1, 0
+    mine = [r for k, r in enumerate(roots) if k % world == rank]
+    stats = bnb_frontier.grow_frontier(oracle, mine, action, **kw) if mine else \
+        dict(host_visits=0, rounds=0, truncated=False)
+    leaves = sum(1 for r in mine for _ in r.leaves())
+    counts = allgather_counts([stats['host_visits'], leaves, len(mine)],
+                              device=kw.get('device'))
+    return roots, stats, counts

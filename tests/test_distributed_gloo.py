@@ -368,3 +368,64 @@ def test_a_failing_rank_stops_every_rank(tmp_path):
     outs = [open(str(tmp_path / ('fail%d.txt' % r))).read() for r in range(2)]
     assert outs[1].startswith('raised: libehmpc error -4')
     assert outs[0].startswith('raised: partition run failed on rank(s) [1]')
+
+
+def _worker_roots(rank, world, port, out_dir):
+    os.environ.update(RANK=str(rank), LOCAL_RANK=str(rank), WORLD_SIZE=str(world),
+                      MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port))
+    import pickle
+    import torch.distributed as dist
+    from explicit_hybrid_mpc_amd import bnb, bnb_frontier, distributed
+    from explicit_hybrid_mpc_amd.tree import Tree, NodeData
+    from oracle import prefix_bb, geometry
+    distributed.init_process_group('gloo')
+    mpc = helpers.make_instance('pwa_small', 0)
+    eps_a = helpers.eps_a_rule(mpc, 0.25)
+    orc = bnb.PrefixOracle(mpc, eps_a, 0.2, table=prefix_bb.CpuPrefixTable(mpc))
+    roots, locs = helpers.roots_of(mpc)
+    trees = [Tree(NodeData(vertices=np.array(R))) for R in roots]
+
+    def split_batch(R):
+        out = [geometry.split_along_longest_edge(r) for r in R]
+        return (np.array([o[0] for o in out]), np.array([o[1] for o in out]),
+                np.array([o[2] for o in out], dtype=np.int32))
+    trees, stats, counts = distributed.grow_roots_sharded(orc, trees, 'ecc', handoff=False,
+                                                          split_batch=split_batch)
+    mine = {k: [(loc, nd.is_leaf(), nd.data.is_epsilon_suboptimal) for nd, loc in t.walk(locs[k])]
+            for k, t in enumerate(trees) if k % world == rank}
+    with open(os.path.join(out_dir, 'roots%d.pkl' % rank), 'wb') as f:
+        pickle.dump(dict(mine=mine, counts=counts, stats=stats), f)
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_two_ranks_share_the_roots_of_the_search_driver(tmp_path):
+    """distributed.grow_roots_sharded: the roots of the set dealt over the ranks, each rank's
+    roots grown by the frontier-wide search driver (CPU stand-in for the device table); the
+    union is the enumerating CPU partition."""
+    import pickle
+    from oracle.oracle_cpu import OracleCPU
+    from oracle.partition_cpu import PartitionCPU
+    s = socket.socket()
+    s.bind(('127.0.0.1', 0))
+    port = s.getsockname()[1]
+    s.close()
+    mp.spawn(_worker_roots, args=(2, port, str(tmp_path)), nprocs=2, join=True)
+    outs = [pickle.load(open(str(tmp_path / ('roots%d.pkl' % r)), 'rb')) for r in range(2)]
+    mpc = helpers.make_instance('pwa_small', 0)
+    roots, locs = helpers.roots_of(mpc)
+    cpu = PartitionCPU(OracleCPU(mpc, helpers.eps_a_rule(mpc, 0.25), 0.2))
+    cpu.run(roots, locs, 'ecc')
+    got = {}
+    for o in outs:
+        for k, nodes in o['mine'].items():
+            for loc, leaf, closed in nodes:
+                got[loc] = (leaf, closed)
+    assert set(got) == set(cpu.nodes)
+    for loc, nd in cpu.nodes.items():
+        assert got[loc] == (nd['leaf'], nd['is_epsilon_suboptimal'])
+    counts = outs[0]['counts']
+    assert counts.shape == (2, 3) and counts[:, 2].sum() == len(roots)
+    assert counts[:, 1].sum() == sum(1 for nd in cpu.nodes.values() if nd['leaf'])
+    assert np.array_equal(outs[0]['counts'], outs[1]['counts'])
+    assert all(c > 0 for c in counts[:, 0])
