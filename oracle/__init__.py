@@ -35,6 +35,13 @@ What is restated and from where (paths into the reference tree):
 * ``oracle/cut_bound.py`` restates the device's tangent-plane bound of the suboptimality-test
   optimum with HiGHS duals (not a reference function: a check that the bound never falls below
   the optimum the reference's ``bar_E_delta_R`` problem has).
+* ``oracle/prefix_bb.py`` restates on the uncondensed models the relaxations and searches over
+  mode prefixes the product uses where the reference relies on its solver's branch-and-bound
+  (``lib/oracle.py:42-46, 89-102``; product: ``sequences.py``, ``bnb.py``), and offers a HiGHS
+  stand-in of the device table so the CPU tests can run those searches;
+  ``oracle/milp_check.py`` states ``P_theta`` as ONE mixed-integer LP (binary mode
+  indicators, big-M dynamics -- the reference's own formulation) for HiGHS' branch-and-bound:
+  the independent pin of enumeration and prefix search on small instances.
 * node semantics of the partition algorithms -- ``lib/worker.py:241-417`` (``ecc``,
   ``lcss``): ``oracle/partition_cpu.py`` (iterative, same per-node oracle sequence).
 

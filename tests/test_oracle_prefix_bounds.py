@@ -115,3 +115,35 @@ def test_region_table_keeps_every_oracle_answer():
         if a['commutation'] is not None:
             assert np.array_equal(a['commutation'], b['commutation'])
             assert np.allclose(a['vertex_costs'], b['vertex_costs'], atol=1e-9)
+
+
+def test_p_theta_against_an_independent_milp():
+    """
+    P_theta three ways on instances HiGHS' own branch-and-bound handles in seconds: ONE
+    mixed-integer LP with binary mode indicators and big-M dynamics (oracle/milp_check.py: the
+    reference's formulation, lib/oracle.py:42-46), the enumeration of the fixed-sequence LPs
+    (OracleCPU) and the best-first search over mode prefixes.  Same optimal cost; the MILP's
+    sequence attains it.
+    """
+    from oracle import milp_check
+    from oracle.lp_models import FixedCommutationModel
+    cases = [(helpers.make_instance('pwa_small', 0), 6), (examples.pwa4_mpc(N=3), 3)]
+    rng = np.random.default_rng(4)
+    compared = 0
+    for mpc, n_pts in cases:
+        orc = OracleCPU(mpc, 1., 1.)
+        half = examples.theta_box(mpc)
+        for _ in range(n_pts):
+            theta = rng.uniform(-0.9, 0.9, half.size) * half
+            J_milp, seq = milp_check.p_theta_milp(mpc, theta)
+            u, delta, J_enum, _ = orc.P_theta(theta)
+            if delta is None:
+                assert not np.isfinite(J_milp)
+                continue
+            assert abs(J_milp - J_enum) <= 1e-7 * (1 + abs(J_enum))
+            J_bb, seq_bb, _ = prefix_bb.p_theta_bb(mpc, theta)
+            assert abs(J_bb - J_enum) <= 1e-8 * (1 + abs(J_enum))
+            res = prefix_bb._solve(FixedCommutationModel(mpc, seq).lp_point(theta))
+            assert res.status == 0 and abs(res.fun - J_milp) <= 1e-7 * (1 + abs(J_milp))
+            compared += 1
+    assert compared >= 6
