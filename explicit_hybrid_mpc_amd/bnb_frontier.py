@@ -67,6 +67,81 @@ def first_feasible_many(table, point_sets, excludes=None):
     return out
 
 
+def p_theta_many(oracle, thetas):
+    """``PrefixOracle.P_theta`` for many parameters: list of (u0, delta, J) -- (None, None, None)
+    where no sequence is feasible.  Both phases of every parameter's search run in lockstep."""
+    table, mpc = oracle.table, oracle.mpc
+    n_modes, N = mpc.delta_size, mpc.N
+    thetas = np.asarray(thetas, dtype=np.float64).reshape(-1, mpc.n_x)
+    n = thetas.shape[0]
+    oracle.calls['P_theta'] += n
+    phase = [1] * n
+    heaps = [[(0., ())] for _ in range(n)]
+    best = [np.inf] * n
+    limit = [np.inf] * n
+    stacks = [None] * n
+    out = [(None, None, None)] * n
+
+    def cut(j):
+        return best[j] - PLATEAU * _rel(best[j]) if np.isfinite(best[j]) else np.inf
+    active = list(range(n))
+    while active:
+        uniq, where, idx, owner, kid_of = [], {}, [], [], {}
+        for j in active:
+            if phase[j] == 1:
+                batch = []
+                while heaps[j] and len(batch) < BATCH and heaps[j][0][0] < cut(j):
+                    batch.append(heapq.heappop(heaps[j])[1])
+                oracle.n_expanded += len(batch)
+                kids = [k for q in batch for k in _kids(q, n_modes)]
+            else:
+                oracle.n_expanded += 1
+                kids = _kids(stacks[j].pop(), n_modes)
+            kid_of[j] = kids
+            for k in kids:
+                u = where.get(k)
+                if u is None:
+                    u = where[k] = len(uniq)
+                    uniq.append(k)
+                idx.append(u)
+            owner.extend([j] * len(kids))
+        J, u0 = table.solve_points_idx(uniq, np.array(idx, dtype=np.int64),
+                                       thetas[np.array(owner, dtype=np.int64)])
+        pos, still = 0, []
+        for j in active:
+            kids = kid_of[j]
+            Jj, uj = J[pos:pos + len(kids)], u0[pos:pos + len(kids)]
+            pos += len(kids)
+            if phase[j] == 1:
+                for q, jq in zip(kids, Jj):
+                    if not np.isfinite(jq):
+                        continue
+                    if len(q) == N:
+                        best[j] = min(best[j], jq)
+                    else:
+                        heapq.heappush(heaps[j], (jq, q))
+                if not (heaps[j] and heaps[j][0][0] < cut(j)):
+                    if not np.isfinite(best[j]):
+                        continue                    # infeasible parameter
+                    phase[j] = 2
+                    limit[j] = best[j] + TIE_TOL * _rel(best[j])
+                    stacks[j] = [()]
+                still.append(j)
+            else:
+                good = [(k, jk, u) for k, jk, u in zip(kids, Jj, uj) if jk <= limit[j]]
+                if good and len(good[0][0]) == N:
+                    k, jk, u = good[0]
+                    out[j] = (u.copy(), oracle.delta_of(k), float(jk))
+                    continue
+                stacks[j].extend(k for k, _, _ in reversed(good))
+                if not stacks[j]:
+                    raise SolverError('P_theta: the optimum found in phase one was not '
+                                      'reproduced')
+                still.append(j)
+        active = still
+    return out
+
+
 def bar_e_many(oracle, Rs, Vs):
     """``PrefixOracle.bar_E_delta_R`` for many nodes: (list of bool, list of margins)."""
     table, mpc = oracle.table, oracle.mpc

@@ -430,30 +430,33 @@ def test_whole_cell_partition_delivers_the_guarantee():
     def bary(S, th):
         return np.linalg.solve(np.vstack([S.T, np.ones(9)]), np.append(th, 1.))
     rng = np.random.default_rng(5)
-    worst = -np.inf
-    thetas, u_leaf = [], []
-    for a in rng.dirichlet(np.ones(9), size=24):
-        th = a @ R
+    thetas = rng.dirichlet(np.ones(9), size=400) @ R
+    V_bar, u_leaf = [], []
+    for th in thetas:
         node = root
         while not node.is_leaf():
             node = node.left if bary(node.left.data.vertices, th).min() >= -1e-12 else node.right
         w = bary(node.data.vertices, th)
         assert w.min() >= -1e-9
-        V_bar = float(w @ node.data.vertex_costs)
-        thetas.append(th)
+        V_bar.append(float(w @ node.data.vertex_costs))
         u_leaf.append(w @ node.data.vertex_inputs)
-        u, delta, V_star, _ = orc.P_theta(th)
-        assert V_star <= V_bar + 1e-9                    # the leaf's sequence is feasible there
-        gap = V_bar - V_star - max(eps_a, eps_r * V_star)
-        worst = max(worst, gap)
-        assert gap < 1e-7
-    print('   guarantee at 24 random parameters: worst V_bar - V* - max(eps_a, eps_r V*) = %.3g'
-          % worst)
+    t0 = time.time()
+    sol = bnb_frontier.p_theta_many(orc, thetas)       # the mixed-integer optimum at each of them
+    V_star = np.array([s[2] for s in sol])
+    V_bar = np.array(V_bar)
+    assert np.all(V_star <= V_bar + 1e-9)                # the leaf's sequence is feasible there
+    gap = V_bar - V_star - np.maximum(eps_a, eps_r * V_star)
+    print('   guarantee at %d random parameters (P_theta by search, %.1f s): worst V_bar - V* - '
+          'max(eps_a, eps_r V*) = %.3g' % (len(thetas), time.time() - t0, gap.max()))
+    assert gap.max() < 1e-7
+    # the lockstep search is the one-parameter search
+    one = orc.P_theta(thetas[0])
+    assert np.array_equal(one[1], sol[0][1]) and abs(one[2] - sol[0][2]) <= 1e-12
     # the consumer: the explicit law evaluated on the device from this tree (lib/mpc_library.py:
     # 662-792) returns the inputs interpolated in those leaves
     from explicit_hybrid_mpc_amd import explicit
     law = explicit.ExplicitMPC(root, orc)
-    U = law.evaluate(np.array(thetas))
+    U = law.evaluate(thetas)
     law.close()
     assert np.allclose(U, np.array(u_leaf), rtol=1e-9, atol=1e-9)
     orc.close()

@@ -129,6 +129,14 @@ def test_frontier_wide_searches_equal_the_one_node_searches():
     bo = bnb.PrefixOracle(mpc, eps_a, 0.2, table=table)
     rng = np.random.default_rng(2)
     Rs = [np.array(R) for R in helpers.random_simplices(mpc, rng, 25, scale_lo=-1.)]
+    # P_theta at many parameters in lockstep
+    half = examples.theta_box(mpc)
+    thetas = rng.uniform(-1, 1, (12, 2)) * half
+    for th, (u, d, J) in zip(thetas, bnb_frontier.p_theta_many(bo, thetas)):
+        a = bo.P_theta(th)
+        assert (a[1] is None) == (d is None)
+        if d is not None:
+            assert np.array_equal(a[1], d) and a[2] == J and np.array_equal(a[0], u)
     one = [table.first_feasible(R) for R in Rs]
     assert bnb_frontier.first_feasible_many(table, Rs) == one
     assert any(s is not None for s in one)
