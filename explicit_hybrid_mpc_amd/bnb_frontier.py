@@ -14,7 +14,6 @@ matter -- a node's fate depends on its own record only (lib/worker.py:241-417).
 import heapq
 import numpy as np
 
-from . import sequences
 from .bnb import BATCH, PLATEAU, TIE_TOL, SolverError, _rel, _set_record
 from .tree import NodeData
 
@@ -299,7 +298,7 @@ def region_tables_many(oracle, Rs, commutations, Us, table_max):
     for _ in range(mpc.N):
         if not active:
             break
-        pre, Rp, owner = [], [], []
+        pre, Rp = [], []
         for j in active:
             cand = [q + (i,) for q in alive[j] for i in range(n_modes)]
             alive[j] = cand
