@@ -66,7 +66,8 @@ struct DevTree {
     // [0] an upper bound c_w of the optimal cost at theta_w, [1..p+1] the barycentric weights
     // of theta_w in the node's vertices.  It comes from the suboptimality-test LP of an
     // ancestor (the iterate that proved that ancestor open) and travels down to the child that
-    // contains it: where  min(Vbar(theta_w) - c_w - eps_a, Vbar(theta_w) - (1+eps_r) c_w)  is
+    // contains it -- its sibling gets the point's projection onto the shared face
+    // (witness_for_children) --: where  min(Vbar(theta_w) - c_w - eps_a, Vbar(theta_w) - (1+eps_r) c_w)  is
     // still positive with the CHILD's vertex costs, the child is open without an LP of its own
     // (persistent frontier kernel).  c_w includes the safety amount
     // EHM_WIT_REL x (slack proved at the ancestor).  All zero = no witness (the test then gives
@@ -80,6 +81,35 @@ struct DevTree {
 // slack -- 20 times the solver's own criterion -- and the witness stops counting once the
 // child's interpolated cost has come that close to it.
 #define EHM_WIT_REL 0.02
+
+// Children's witnesses (DevTree::wit) from the parent's: wit = [c_w, alpha_0..alpha_p] in the
+// parent's vertices, Vc its vertex costs, (bi, bj) the split edge; lane < p + 2 computes entry
+// `lane` of child 0 (vertex bi -> midpoint) in v0 and of child 1 (vertex bj -> midpoint) in v1.
+// The child that contains theta_w keeps it (weights 2 a_far at the midpoint, a_near - a_far at
+// the vertex it keeps); the other one gets theta_w slid towards ITS vertex of the edge until the
+// shared face (weights equal), mu = (a_near - a_far) / (1 + a_near - a_far), with the cost bound
+// (1 - mu) c_w + mu V_far: there the midpoint carries 2 (1 - mu) a_near and the kept vertex 0.
+__device__ __forceinline__ void witness_for_children(const double* wit, const double* Vc, int bi,
+                                                     int bj, int lane, double& v0, double& v1) {
+    const double ai = wit[1 + bi], aj = wit[1 + bj];
+    const bool to0 = aj >= ai;              // child 0 holds theta_w
+    const double an = to0 ? aj : ai, af = to0 ? ai : aj;
+    const int far = to0 ? bi : bj;          // the other child's own vertex of the edge
+    const int near = to0 ? bj : bi;
+    const double mu = (an - af) / (1.0 + an - af);
+    double vh = wit[lane], vo = (1.0 - mu) * wit[lane];
+    if (lane == 0) vo = fma(mu, Vc[far], vo);
+    if (lane == 1 + far) {                  // holder: the midpoint; other: its kept vertex
+        vh = 2.0 * af;
+        vo = 0.0;
+    }
+    if (lane == 1 + near) {                 // holder: its kept vertex; other: the midpoint
+        vh = an - af;
+        vo = 2.0 * (1.0 - mu) * an;
+    }
+    v0 = to0 ? vh : vo;
+    v1 = to0 ? vo : vh;
+}
 
 // Upper bound of the suboptimality-test optimum t* from the tangent planes of the convex optimal
 // cost at the vertices: V*(theta) >= L_i(theta) = V_i + g_i.(theta - v_i), so with the 2(p+1)

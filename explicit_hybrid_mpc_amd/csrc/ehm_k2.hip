@@ -625,16 +625,14 @@ __global__ __launch_bounds__(EHM_K2_THREADS) void k2_persist(
         }
         if (T.wit && lane < p + 2) {
             // the witness goes to the child that contains it: child 0 (vertex bi -> midpoint) iff
-            // alpha_bj >= alpha_bi; theta_w = 2 a_i mid + (a_j - a_i) v_j + ... there
+            // alpha_bj >= alpha_bi; theta_w = 2 a_i mid + (a_j - a_i) v_j + ... there.  The OTHER
+            // child gets the point where the segment from theta_w to the parent's vertex on its
+            // side meets the shared face, with the cost bound (1 - mu) c_w + mu V_vertex (a convex
+            // combination of two feasible decision vectors is feasible, the cost is linear)
             double* w0 = T.wit + (size_t)c0 * (p + 2);
             double v0 = 0.0, v1 = 0.0;
             if (have_wit) {
-                const double ai = wit[1 + bi], aj = wit[1 + bj];
-                const bool to0 = aj >= ai;
-                double v = wit[lane];
-                if (lane == 1 + bi) v = to0 ? 2.0 * ai : ai - aj;
-                if (lane == 1 + bj) v = to0 ? aj - ai : 2.0 * aj;
-                if (to0) v0 = v; else v1 = v;
+                witness_for_children(wit, node + rec_off_vcost(p), bi, bj, lane, v0, v1);
             }
             __hip_atomic_store(w0 + lane, v0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             __hip_atomic_store(w0 + (p + 2) + lane, v1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);

@@ -431,17 +431,15 @@ EHM3_KERNEL void k3_lcss_expand(
             }
         }
         if (T.wit && tid < p + 2) {
-            // the node's witness goes to the child that contains it: child 0 (vertex bi ->
-            // midpoint) iff alpha_bj >= alpha_bi (all zero = none, and stays all zero)
+            // the node's witness goes to the child that contains it, its projection onto the
+            // shared face to the other one (witness_for_children; all zero = none, stays so)
             const double* wv = T.wit + (size_t)id * (p + 2);
             double* w0 = T.wit + (size_t)c0 * (p + 2);
-            const double ai = wv[1 + bi], aj = wv[1 + bj];
-            const bool to0 = aj >= ai;
-            double v = wv[tid];
-            if (tid == 1 + bi) v = to0 ? 2.0 * ai : ai - aj;
-            if (tid == 1 + bj) v = to0 ? aj - ai : 2.0 * aj;
-            w0[tid] = to0 ? v : 0.0;
-            w0[(p + 2) + tid] = to0 ? 0.0 : v;
+            double v0, v1;
+            witness_for_children(wv, node + rec_off_vcost(p), bi, bj, tid, v0, v1);
+            const bool none = wv[0] == 0.0 && wv[1 + bi] == 0.0 && wv[1 + bj] == 0.0;
+            w0[tid] = none ? 0.0 : v0;
+            w0[(p + 2) + tid] = none ? 0.0 : v1;
         }
         double* rec0 = T.rec + (size_t)c0 * T.rec_stride;
         double* rec1 = rec0 + T.rec_stride;

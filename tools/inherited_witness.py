@@ -57,6 +57,11 @@ wit_theta = np.zeros((N, p))
 wit_c = np.zeros(N)
 has = np.zeros(N, dtype=bool)
 saved = 0
+projected_given = 0
+PROJECT = len(sys.argv) > 3 and sys.argv[3] == 'project'
+split_ij = {}
+for q, kk in enumerate(internal):
+    split_ij[kk] = (int(i_new[q]), int(j_new[q]))
 chain = np.zeros(N, dtype=int)
 lp_open = 0
 for k in range(N):
@@ -85,6 +90,7 @@ for k in range(N):
         th, c = theta_w[q], c_w[q]
         ch = 0
     # hand the witness to the child that contains it
+    holder = None
     for child in (left[k], right[k]):
         Rc = flat.vertices[child]
         A = np.vstack([Rc.T, np.ones(p + 1)])
@@ -94,6 +100,24 @@ for k in range(N):
             continue
         if a.min() >= -1e-9:
             has[child], wit_theta[child], wit_c[child], chain[child] = True, th, c, ch
+            holder = child
             break
-print('suboptimality-test LPs on open nodes: today %d, with inherited witnesses %d (%.1f %% fewer); '
-      'longest chain %d' % (len(need), lp_open, 100. * saved / max(1, len(need)), chain.max()))
+    if PROJECT and holder is not None:
+        # the other child: slide the witness towards the parent's vertex on its side until the
+        # shared face; (1 - mu) c_w + mu V_v bounds the optimal cost there (convex combination
+        # of feasible decision vectors)
+        other = right[k] if holder == left[k] else left[k]
+        Rk = flat.vertices[k]
+        a = np.linalg.solve(np.vstack([Rk.T, np.ones(p + 1)]), np.append(th, 1.))
+        kk = int(np.nonzero(internal == k)[0][0]) if False else None
+        i_, j_ = split_ij[k]
+        # holder keeps v_j (child 0, alpha_j >= alpha_i) or v_i (child 1)
+        far, near = (i_, j_) if a[j_] >= a[i_] else (j_, i_)
+        mu = (a[near] - a[far]) / (1. + a[near] - a[far])
+        th2 = (1 - mu) * th + mu * Rk[far]
+        c2 = (1 - mu) * c + mu * flat.vertex_costs[k][far]
+        has[other], wit_theta[other], wit_c[other], chain[other] = True, th2, c2, ch
+        projected_given += 1
+print('suboptimality-test LPs on open nodes: today %d, with inherited witnesses%s %d (%.1f %% fewer); '
+      'longest chain %d' % (len(need), ' + face projection' if PROJECT else '', lp_open,
+                            100. * saved / max(1, len(need)), chain.max()))
