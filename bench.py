@@ -494,6 +494,12 @@ def main():
             'value': agg['lp_solves'] / elapsed_max,
             'unit': 'LP solves/s',
             'regions_per_s': closed / elapsed_max,
+            'oracle_calls_answered_per_s': agg['ref_solves'] / elapsed_max,
+            'value_note': 'value counts the LP solves EXECUTED; the same partition issues '
+                          'reference_equivalent_solves_per_step oracle calls whatever the engine '
+                          'does, and every call a bound or a witness answers without an LP lowers '
+                          'value while ms_per_step falls -- compare ms_per_step, regions_per_s and '
+                          'oracle_calls_answered_per_s between builds',
             'n_gpus': world, 'steps': K, 'warmup': args.warmup,
             'ms_per_step': 1e3 * elapsed_max / K,
             'ms_export': ms_export,
