@@ -179,3 +179,40 @@ def test_frontier_wide_searches_equal_the_one_node_searches():
     stats = bnb_frontier.grow_frontier(bo, c, 'ecc', handoff=False, max_visits=3,
                                        split_batch=_host_split_batch)
     assert stats['truncated'] and stats['host_visits'] == 3
+
+
+def test_region_tables_of_many_nodes():
+    """bnb_frontier.region_tables_many (bound = the node's own commutation's vertex costs) against
+    the one-region search with the same bound, and its soundness: the enumerating oracle's bar_D
+    answer on the node lies in the table."""
+    from explicit_hybrid_mpc_amd import bnb_frontier
+    mpc = examples.pwa4_mpc()                            # 4 modes, N = 4: 256 sequences
+    half = examples.theta_box(mpc)
+    E = np.vstack([np.zeros(8), np.eye(8)]) - 1. / 9.
+    V = examples.box_vertices(half)
+    table = prefix_bb.CpuPrefixTable(mpc)
+    bo = bnb.PrefixOracle(mpc, 0.01, 0.02, table=table)
+    Rs = [0.8 * V[37] + 0.08 * half * E, 0.7 * V[100] + 0.05 * half * E]
+    comms, costs = [], []
+    for R in Rs:
+        delta, vx = bo.V_R(R)
+        comms.append(delta)
+        costs.append(np.array([v[1] for v in vx]))
+    tables = bnb_frontier.region_tables_many(bo, Rs, comms, [float(c.max()) for c in costs], 256)
+    full = OracleCPU(mpc, 0.01, 0.02)
+    for R, delta, c, seqs in zip(Rs, comms, costs, tables):
+        assert seqs is not None and bo.sequence_of(delta) in seqs and len(seqs) < 256
+        # the same levels one region at a time
+        U = float(c.max())
+        alive = [()]
+        for _ in range(mpc.N):
+            cand = [q + (i,) for q in alive for i in range(4)]
+            alive = [q for q, v in zip(cand, table.min_cost_on(cand, R[None]))
+                     if v <= U + 1e-6 * (1 + abs(U))]
+        assert sorted(set(alive) | {bo.sequence_of(delta)}) == seqs
+        star = full.bar_D_delta_R(R, c, delta)[0]
+        if star is not None:
+            assert bo.sequence_of(star) in seqs
+    # a table limit that is too small is reported as None, not cut
+    assert bnb_frontier.region_tables_many(bo, Rs[:1], comms[:1], [float(costs[0].max())], 2) \
+        == [None]
