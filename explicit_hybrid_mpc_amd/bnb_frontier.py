@@ -23,47 +23,9 @@ def _kids(q, n_modes):
 
 
 def first_feasible_many(table, point_sets, excludes=None):
-    """``PrefixSearch.first_feasible`` for a list of point sets OF ONE SIZE: list of sequences /
-    None.  The pairs of a step are described by index arrays (``solve_points_idx``): the Python
-    work per step is per node, not per (prefix, point) pair."""
-    mpc = table.mpc
-    n_modes, N = mpc.delta_size, mpc.N
-    n = len(point_sets)
-    if not n:
-        return []
-    points = np.asarray(point_sets, dtype=np.float64).reshape(n, -1, mpc.n_x)
-    npts = points.shape[1]
-    excludes = excludes or [()] * n
-    stacks = [[()] for _ in range(n)]
-    out = [None] * n
-    active = list(range(n))
-    while active:
-        uniq, where, kid_idx = [], {}, np.empty((len(active), n_modes), dtype=np.int64)
-        for a, j in enumerate(active):
-            q = stacks[j].pop()
-            for i in range(n_modes):
-                k = q + (i,)
-                u = where.get(k)
-                if u is None:
-                    u = where[k] = len(uniq)
-                    uniq.append(k)
-                kid_idx[a, i] = u
-        idx = np.repeat(kid_idx.reshape(-1), npts)
-        thetas = np.repeat(points[active][:, None], n_modes, axis=1).reshape(-1, mpc.n_x)
-        J = table.solve_points_idx(uniq, idx, thetas, feasibility_only=True)[0]
-        ok = np.isfinite(J).reshape(len(active), n_modes, npts).all(axis=2)
-        still = []
-        for a, j in enumerate(active):
-            good = [uniq[kid_idx[a, i]] for i in range(n_modes)
-                    if ok[a, i] and uniq[kid_idx[a, i]] not in excludes[j]]
-            if good and len(good[0]) == N:
-                out[j] = good[0]
-                continue
-            stacks[j].extend(reversed(good))
-            if stacks[j]:
-                still.append(j)
-        active = still
-    return out
+    """``PrefixSearch.first_feasible_many`` (sequences.py: all descents in lockstep, phase-one
+    verdicts remembered per prefix and point)."""
+    return table.first_feasible_many(point_sets, excludes)
 
 
 def p_theta_many(oracle, thetas):
@@ -200,6 +162,7 @@ def bar_d_many(oracle, Rs, Vs, deltas_ref):
 
     def floor(j):
         return max(0., best[j] + PLATEAU * _rel(best[j])) if np.isfinite(best[j]) else 0.
+    vid_of = {id(R): table.point_ids(R) for R in Rs}      # the vertices' ids, once per node
     active = list(range(n))
     while active:
         pre, Rp, Vp, kid_of = [], [], [], {}
@@ -221,11 +184,8 @@ def bar_d_many(oracle, Rs, Vs, deltas_ref):
         # feasibility at every vertex, for the prefixes whose slack bound is not negative
         live = np.flatnonzero(t >= 0.)
         if live.size:
-            nv = Rs[0].shape[0]
-            vp = [pre[k] for k in live for _ in range(nv)]
-            vt = np.vstack([Rp[k] for k in live])
-            ok = np.isfinite(table.solve_points(vp, vt, feasibility_only=True)[0])
-            ok = ok.reshape(live.size, nv).all(axis=1)
+            ok = table.feasible_sets([pre[k] for k in live], [Rp[k] for k in live],
+                                     [vid_of[id(Rp[k])] for k in live])
             t[live[~ok]] = -np.inf
         pos, still = 0, []
         for j in active:

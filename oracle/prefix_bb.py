@@ -205,7 +205,9 @@ class CpuPrefixTable:
         self.lp_solves = 0
         self._models = {}
         for name in ('min_cost_on', 'vertex_costs', 'feasible_at_all', 'first_feasible',
-                     'feasible_on', 'solve_points_idx'):
+                     'feasible_on', 'solve_points_idx', 'point_ids', 'feasible_sets',
+                     'first_feasible_many'):
+            setattr(self, 'FEAS_MEMO_LIMIT', PrefixSearch.FEAS_MEMO_LIMIT)
             setattr(self, name, getattr(PrefixSearch, name).__get__(self))
 
     def set_eps(self, eps_a, eps_r):
