@@ -346,12 +346,15 @@ def grow(oracle, branch, action='ecc', table_max=256, max_visits=None, handoff=T
                 continue
         stats['host_visits'] += 1
         if act == 'ecc':                            # lib/worker.py:241-283
-            c_R = np.average(R, axis=0)
-            if not oracle.P_theta(theta=c_R, check_feasibility=True):
-                raise RuntimeError('STOP, Theta contains infeasible regions')
             delta_hat, vx = oracle.V_R(R)
+            # lib/worker.py:264-266 checks the barycentre first; a sequence feasible at every
+            # vertex is feasible there too, so only a cell V_R finds nothing for needs the check
+            if delta_hat is None and not oracle.P_theta(theta=np.average(R, axis=0),
+                                                        check_feasibility=True):
+                raise RuntimeError('STOP, Theta contains infeasible regions')
             if delta_hat is None:
-                S_1, S_2 = split_longest_edge(R)[:2]
+                S_1, S_2, v_idx = split_longest_edge(R)
+                oracle.table.register_midpoints([S_1[v_idx[0]]], [R[v_idx[0]]], [R[v_idx[1]]])
                 node.grow(NodeData(vertices=S_1), NodeData(vertices=S_2))
                 work.append((node.right, 'ecc'))
                 work.append((node.left, 'ecc'))
@@ -379,6 +382,7 @@ def grow(oracle, branch, action='ecc', table_max=256, max_visits=None, handoff=T
             continue
         S_1, S_2, v_idx = split_longest_edge(R)
         v_mid = S_1[v_idx[0]]
+        oracle.table.register_midpoints([v_mid], [R[v_idx[0]]], [R[v_idx[1]]])
         u_mid, V_mid = oracle.P_theta_delta(theta=v_mid, delta=delta_star)[:2]
         in_1, in_2 = new_inputs.copy(), new_inputs.copy()
         co_1, co_2 = new_costs.copy(), new_costs.copy()

@@ -350,12 +350,16 @@ def grow_frontier(oracle, branch, action='ecc', table_max=256, max_visits=None, 
         to_split = []                       # (node, commutation or None, costs, inputs)
         if ecc:                             # lib/worker.py:241-283
             Rs = [np.asarray(nd.data.vertices, dtype=np.float64) for nd in ecc]
-            oracle.calls['P_theta'] += len(ecc)
             oracle.calls['V_R'] += len(ecc)
-            if any(s is None for s in first_feasible_many(
-                    oracle.table, [np.average(R, axis=0)[None] for R in Rs])):
-                raise RuntimeError('STOP, Theta contains infeasible regions')
             found = first_feasible_many(oracle.table, Rs)
+            # lib/worker.py:264-266 checks the barycentre first; a sequence feasible at every
+            # vertex is feasible there too (its feasible set is convex), so only the cells V_R
+            # finds nothing for need the check
+            none = [k for k, s in enumerate(found) if s is None]
+            oracle.calls['P_theta'] += len(none)
+            if any(s is None for s in first_feasible_many(
+                    oracle.table, [np.average(Rs[k], axis=0)[None] for k in none])):
+                raise RuntimeError('STOP, Theta contains infeasible regions')
             have = [k for k, s in enumerate(found) if s is not None]
             if have:
                 nv = Rs[0].shape[0]
@@ -404,8 +408,12 @@ def grow_frontier(oracle, branch, action='ecc', table_max=256, max_visits=None, 
                 else:
                     to_split.append((lcss[k], delta_star, costs, inputs))
         if to_split:
-            S1, S2, ij = split_batch(np.array([np.asarray(nd.data.vertices, dtype=np.float64)
-                                               for nd, _, _, _ in to_split]))
+            Rsplit = np.array([np.asarray(nd.data.vertices, dtype=np.float64)
+                               for nd, _, _, _ in to_split])
+            S1, S2, ij = split_batch(Rsplit)
+            rows = np.arange(len(to_split))
+            oracle.table.register_midpoints(S1[rows, ij[:, 0]], Rsplit[rows, ij[:, 0]],
+                                            Rsplit[rows, ij[:, 1]])
             with_data = [k for k, item in enumerate(to_split) if item[1] is not None]
             if with_data:
                 mids = np.array([S1[k][ij[k][0]] for k in with_data])

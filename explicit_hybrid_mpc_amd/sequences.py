@@ -105,6 +105,16 @@ class PrefixSearch:
             out.append(i)
         return out
 
+    def register_midpoints(self, mids, ends_a, ends_b):
+        """
+        Tell the memo that ``mids[k]`` is the midpoint of ``ends_a[k]`` and ``ends_b[k]`` (the
+        bisections of the partition): a relaxation feasible at both ends is feasible at the
+        midpoint -- its feasible parameters form a convex set -- and needs no LP there.
+        """
+        mid_of = self.__dict__.setdefault('_mid_of', {})
+        for m, a, b in zip(self.point_ids(mids), self.point_ids(ends_a), self.point_ids(ends_b)):
+            mid_of[m] = (a, b)
+
     def feasible_sets(self, prefixes, point_sets, ids=None):
         """
         For every k: is the relaxation of ``prefixes[k]`` feasible at EVERY point of
@@ -112,8 +122,10 @@ class PrefixSearch:
         them)?  One batched launch for the pairs the memo does not hold.
         """
         memo = self.__dict__.setdefault('_feas', {})
+        mid_of = self.__dict__.setdefault('_mid_of', {})
         if self.__dict__.get('_feas_n', 0) > self.FEAS_MEMO_LIMIT:
             memo.clear()
+            mid_of.clear()
             self.__dict__['_pid'] = {}
             self.__dict__['_feas_n'] = 0
             ids = None
@@ -128,6 +140,10 @@ class PrefixSearch:
             for t, v in enumerate(vid):
                 r = known.get(v)
                 if r is None:
+                    ends = mid_of.get(v)
+                    if ends is not None and known.get(ends[0]) and known.get(ends[1]):
+                        known[v] = True         # feasible at both ends of the bisected edge
+                        continue
                     need.append(t)
                 elif not r:
                     flags[k] = False

@@ -206,7 +206,7 @@ class CpuPrefixTable:
         self._models = {}
         for name in ('min_cost_on', 'vertex_costs', 'feasible_at_all', 'first_feasible',
                      'feasible_on', 'solve_points_idx', 'point_ids', 'feasible_sets',
-                     'first_feasible_many'):
+                     'first_feasible_many', 'register_midpoints'):
             setattr(self, 'FEAS_MEMO_LIMIT', PrefixSearch.FEAS_MEMO_LIMIT)
             setattr(self, name, getattr(PrefixSearch, name).__get__(self))
 
