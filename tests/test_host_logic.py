@@ -212,3 +212,42 @@ def test_deep_pickles_do_not_overflow_the_c_stack(tmp_path):
         tree_io.dump_reference(root, str(tmp_path / 'x.pkl'), depth_hint=50)
     with pytest.raises(ValueError):
         tree_io.load_reference(path, depth_hint=10 ** 7)
+
+
+def test_bench_helpers_quote_only_profiles_of_this_code(tmp_path, monkeypatch):
+    """bench.py: the committed PMC summaries carry the hash of the kernel sources they were taken
+    on and are quoted for those sources only; the flop formulas and the core count are sane."""
+    import json
+    import bench
+    sha = bench.kernel_source_hash()
+    assert len(sha) == 16 and sha == bench.kernel_source_hash()
+    # the committed summaries of the four workloads name the kernel sources they belong to
+    for summary, kernel in (('pmc_summary_bench.json', 'kp_persist'),
+                            ('pmc_summary_wide.json', 'k3_lcss_decide'),
+                            ('pmc_summary_config3.json', 'k2_simplex_batch'),
+                            ('pmc_summary_quad.json', 'k2_persist')):
+        traffic, source = bench.pmc_traffic(kernel, summary)
+        # quoted (taken on these sources) or refused as stale -- never silently quoted for
+        # other code, never unreadable
+        assert (traffic is not None and traffic > 0 and source.endswith(summary)) or \
+            (traffic is None and source.startswith('stale')), (summary, source)
+    # a summary taken on other sources is refused, with the reason
+    root = tmp_path / 'profiles' / 'r2'
+    root.mkdir(parents=True)
+    doc = json.load(open(os.path.join(bench.ROOT, 'profiles', 'r2', 'pmc_summary_bench.json')))
+    doc['kernel_source_sha'] = '0' * 16
+    (root / 'pmc_summary_bench.json').write_text(json.dumps(doc))
+    csrc = tmp_path / 'explicit_hybrid_mpc_amd' / 'csrc'
+    csrc.mkdir(parents=True)
+    (csrc / 'a.hip').write_text('// other code')
+    monkeypatch.setattr(bench, 'ROOT', str(tmp_path))
+    traffic, why = bench.pmc_traffic('kp_persist', 'pmc_summary_bench.json')
+    assert traffic is None and why.startswith('stale')
+    assert bench.pmc_traffic('no_such_kernel', 'pmc_summary_bench.json')[0] is None
+    assert bench.pmc_traffic('kp_persist', 'no_such_summary.json')[0] is None
+    # SURVEY 8(d) formula at config 2's suboptimality-test LP, and what the solver executes
+    assert bench.flops_per_iteration(25, 167) == 2 * 167 * 625 + 25 ** 3 / 3. + 8 * 167 * 25 + 2500
+    assert bench.np_capacity(25) == 28 and bench.np_capacity(20) == 20
+    assert 0 < bench.flops_executed_per_iteration(25, 24, 167, 28) < bench.flops_per_iteration(25, 167)
+    assert bench.node_bytes(4, 2, 5) == 301
+    assert 1 <= bench.usable_cores() <= (os.cpu_count() or 1)
