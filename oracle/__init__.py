@@ -39,9 +39,10 @@ What is restated and from where (paths into the reference tree):
   mode prefixes the product uses where the reference relies on its solver's branch-and-bound
   (``lib/oracle.py:42-46, 89-102``; product: ``sequences.py``, ``bnb.py``), and offers a HiGHS
   stand-in of the device table so the CPU tests can run those searches;
-  ``oracle/milp_check.py`` states ``P_theta`` as ONE mixed-integer LP (binary mode
-  indicators, big-M dynamics -- the reference's own formulation) for HiGHS' branch-and-bound:
-  the independent pin of enumeration and prefix search on small instances.
+  ``oracle/milp_check.py`` states ``P_theta`` and the ``bar_E`` problem each as ONE
+  mixed-integer LP (binary mode indicators, big-M dynamics -- the reference's own
+  formulation, lib/oracle.py:42-46, 89-97) for HiGHS' branch-and-bound: the independent pin
+  of enumeration and prefix search on small instances.
 * node semantics of the partition algorithms -- ``lib/worker.py:241-417`` (``ecc``,
   ``lcss``): ``oracle/partition_cpu.py`` (iterative, same per-node oracle sequence).
 

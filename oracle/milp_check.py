@@ -18,8 +18,8 @@ import numpy as np
 from scipy.optimize import milp, LinearConstraint, Bounds
 
 
-def p_theta_milp(mpc, theta, big_m=50.):
-    """(optimal cost, mode sequence) of the mixed-integer LP; (inf, None) if infeasible."""
+def _model(mpc, big_m, extra_cols=0):
+    """Rows of the mixed-integer model WITHOUT the x_0 condition; ``extra_cols`` more columns."""
     assert mpc.cost_type == 'inf'
     N, nx, nu, nm = mpc.N, mpc.n_x, mpc.n_u, mpc.delta_size
     ox = 0                              # x_0 .. x_N
@@ -28,7 +28,7 @@ def p_theta_milp(mpc, theta, big_m=50.):
     od = oz + N * nm * nx               # d_{k,i}
     oex = od + N * nm                   # ex_1 .. ex_N
     oeu = oex + N                       # eu_0 .. eu_{N-1}
-    nv = oeu + N
+    nv = oeu + N + extra_cols
     X = lambda k: slice(ox + k * nx, ox + (k + 1) * nx)
     U = lambda k: slice(ou + k * nu, ou + (k + 1) * nu)
     Z = lambda k, i: slice(oz + (k * nm + i) * nx, oz + (k * nm + i + 1) * nx)
@@ -42,9 +42,6 @@ def p_theta_milp(mpc, theta, big_m=50.):
 
     def blank(n):
         return np.zeros((n, nv))
-    r = blank(nx)
-    r[:, X(0)] = np.eye(nx)
-    add(r, np.asarray(theta, dtype=float), np.asarray(theta, dtype=float))
     for k in range(N):
         r = blank(1)
         for i in range(nm):
@@ -88,18 +85,68 @@ def p_theta_milp(mpc, theta, big_m=50.):
             r[:, U(k)] = sgn * mpc.R
             r[:, oeu + k] = -1.
             add(r, np.full(mpc.R.shape[0], -np.inf), np.zeros(mpc.R.shape[0]))
-    c = np.zeros(nv)
-    c[oex:] = 1.
+    cost = np.zeros(nv)
+    cost[oex:oeu + N] = 1.
     integrality = np.zeros(nv)
     integrality[od:oex] = 1
     lb = np.full(nv, -np.inf)
     ub = np.full(nv, np.inf)
     lb[od:oex], ub[od:oex] = 0., 1.
-    res = milp(c, constraints=LinearConstraint(np.vstack(rows), np.concatenate(lo),
-                                               np.concatenate(hi)),
-               integrality=integrality, bounds=Bounds(lb, ub),
+    return dict(rows=rows, lo=lo, hi=hi, cost=cost, integrality=integrality, lb=lb, ub=ub,
+                nv=nv, x0=X(0), d=slice(od, oex), tail=oeu + N, add=add, blank=blank)
+
+
+def _solve(M, c):
+    res = milp(c, constraints=LinearConstraint(np.vstack(M['rows']), np.concatenate(M['lo']),
+                                               np.concatenate(M['hi'])),
+               integrality=M['integrality'], bounds=Bounds(M['lb'], M['ub']),
                options=dict(mip_rel_gap=1e-10))
+    return res
+
+
+def p_theta_milp(mpc, theta, big_m=50.):
+    """(optimal cost, mode sequence) of the mixed-integer LP; (inf, None) if infeasible."""
+    M = _model(mpc, big_m)
+    r = M['blank'](mpc.n_x)
+    r[:, M['x0']] = np.eye(mpc.n_x)
+    M['add'](r, np.asarray(theta, dtype=float), np.asarray(theta, dtype=float))
+    res = _solve(M, M['cost'])
     if res.status != 0:
         return np.inf, None
-    d = np.rint(res.x[od:oex]).reshape(N, nm)
+    d = np.rint(res.x[M['d']]).reshape(mpc.N, mpc.delta_size)
     return float(res.fun), tuple(int(i) for i in d.argmax(axis=1))
+
+
+def bar_e_milp(mpc, R, V_bar, eps_a, eps_r, big_m=50.):
+    """
+    The reference's bar_E problem (lib/oracle.py:89-97) as ONE mixed-integer LP in decision form:
+    maximise t over the modes, the parameter theta = sum_i alpha_i v_i in the simplex and the
+    trajectory, subject to  sum alpha_i V_i - V - eps_a >= t,  sum alpha_i V_i - (1+eps_r) V >= t.
+    Returns (t_max, mode sequence); (-inf, None) if no mode sequence is feasible on the simplex.
+    The reference's feasibility problem is feasible iff t_max >= 0.
+    """
+    R = np.asarray(R, dtype=float)
+    na = R.shape[0]
+    M = _model(mpc, big_m, extra_cols=na + 1)
+    oa, ot = M['tail'], M['tail'] + na
+    r = M['blank'](mpc.n_x)                       # x_0 = sum alpha_i v_i
+    r[:, M['x0']] = np.eye(mpc.n_x)
+    r[:, oa:oa + na] = -R.T
+    M['add'](r, np.zeros(mpc.n_x), np.zeros(mpc.n_x))
+    r = M['blank'](1)
+    r[0, oa:oa + na] = 1.
+    M['add'](r, [1.], [1.])
+    M['lb'][oa:oa + na] = 0.
+    for scale, shift in ((1., eps_a), (1. + eps_r, 0.)):
+        r = M['blank'](1)                         # sum alpha V_i - scale * V - t >= shift
+        r[0, oa:oa + na] = np.asarray(V_bar, dtype=float)
+        r[0, :] -= scale * M['cost']
+        r[0, ot] = -1.
+        M['add'](r, [shift], [np.inf])
+    c = np.zeros(M['nv'])
+    c[ot] = -1.
+    res = _solve(M, c)
+    if res.status != 0:
+        return -np.inf, None
+    d = np.rint(res.x[M['d']]).reshape(mpc.N, mpc.delta_size)
+    return float(-res.fun), tuple(int(i) for i in d.argmax(axis=1))

@@ -147,3 +147,33 @@ def test_p_theta_against_an_independent_milp():
             assert res.status == 0 and abs(res.fun - J_milp) <= 1e-7 * (1 + abs(J_milp))
             compared += 1
     assert compared >= 6
+
+
+def test_bar_e_against_an_independent_milp():
+    """
+    The suboptimality test as the reference states it -- ONE mixed-integer problem over modes,
+    parameter and trajectory (lib/oracle.py:89-97) -- solved by HiGHS' branch-and-bound
+    (oracle/milp_check.bar_e_milp), against the enumeration of the fixed-sequence slack LPs
+    (OracleCPU) and the prefix search: the same largest slack, hence the same verdict.
+    """
+    from oracle import milp_check
+    mpc = helpers.make_instance('pwa_small', 0)
+    eps_a = helpers.eps_a_rule(mpc, 0.25)
+    orc = OracleCPU(mpc, eps_a, 0.2)
+    rng = np.random.default_rng(7)
+    n_open = n_closed = 0
+    for R in helpers.random_simplices(mpc, rng, 14, scale_lo=-1.5):
+        delta, vx = orc.V_R(R)
+        if delta is None:
+            continue
+        V = np.array([v[1] for v in vx])
+        t_enum = max(orc.slack(R, V, d)[0] for d in range(len(orc.models)))
+        t_milp, seq = milp_check.bar_e_milp(mpc, R, V, eps_a, 0.2)
+        assert abs(t_milp - t_enum) <= 1e-7 * (1 + abs(t_enum)), (t_milp, t_enum)
+        closed = orc.bar_E_delta_R(R, V)
+        assert closed == (not (t_milp >= 0.))
+        closed_bb, _ = prefix_bb.bar_e_bb(mpc, R, V, eps_a, 0.2)
+        assert closed_bb == closed
+        n_open += not closed
+        n_closed += closed
+    assert n_open >= 2 and n_closed >= 2
