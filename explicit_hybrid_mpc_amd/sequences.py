@@ -62,6 +62,13 @@ class PrefixSearch:
     """Searches over prefixes written on the three pair solvers of a table (``solve_points``,
     ``solve_min``, ``solve_slack``); the device table below provides them."""
 
+    def init_search(self):
+        """State of the feasibility memo (``feasible_sets``); every table calls it once."""
+        self._pid = {}          # parameter point (bytes) -> id
+        self._feas = {}         # prefix -> {point id: phase-one verdict}
+        self._mid_of = {}       # point id of a bisection midpoint -> ids of the edge's ends
+        self._feas_n = 0
+
     def solve_points_idx(self, uniq, idx, thetas, feasibility_only=False):
         """``solve_points`` with the prefixes given as indices into the list ``uniq`` (the device
         table turns them into slots without touching the pairs one by one)."""
@@ -95,7 +102,7 @@ class PrefixSearch:
 
     def point_ids(self, points):
         """Integer ids of parameter points (by value), the keys of the feasibility memo."""
-        pid = self.__dict__.setdefault('_pid', {})
+        pid = self._pid
         out = []
         for pt in np.ascontiguousarray(points, dtype=np.float64).reshape(-1, self.mpc.n_x):
             key = pt.tobytes()
@@ -111,7 +118,7 @@ class PrefixSearch:
         bisections of the partition): a relaxation feasible at both ends is feasible at the
         midpoint -- its feasible parameters form a convex set -- and needs no LP there.
         """
-        mid_of = self.__dict__.setdefault('_mid_of', {})
+        mid_of = self._mid_of
         for m, a, b in zip(self.point_ids(mids), self.point_ids(ends_a), self.point_ids(ends_b)):
             mid_of[m] = (a, b)
 
@@ -121,14 +128,10 @@ class PrefixSearch:
         ``point_sets[k]`` ((npts, p) arrays; ``ids[k]`` their ``point_ids`` if the caller has
         them)?  One batched launch for the pairs the memo does not hold.
         """
-        memo = self.__dict__.setdefault('_feas', {})
-        mid_of = self.__dict__.setdefault('_mid_of', {})
-        if self.__dict__.get('_feas_n', 0) > self.FEAS_MEMO_LIMIT:
-            memo.clear()
-            mid_of.clear()
-            self.__dict__['_pid'] = {}
-            self.__dict__['_feas_n'] = 0
+        if self._feas_n > self.FEAS_MEMO_LIMIT:
+            self.init_search()
             ids = None
+        memo, mid_of = self._feas, self._mid_of
         flags = np.ones(len(prefixes), dtype=bool)
         uniq, where, idx, pts, ask = [], {}, [], [], []
         for k, q in enumerate(prefixes):
@@ -167,7 +170,7 @@ class PrefixSearch:
                 known[v] = bool(good)
                 if not good:
                     flags[k] = False
-            self.__dict__['_feas_n'] = self.__dict__.get('_feas_n', 0) + len(ask)
+            self._feas_n += len(ask)
         return flags
 
     def feasible_at_all(self, prefixes, points):
@@ -254,6 +257,7 @@ class PrefixTable(PrefixSearch):
         self.blocks_loaded = 0
         self._slot_of = {}
         self._blocks = {}
+        self.init_search()
 
     def close(self):
         self.gp.close()

@@ -191,24 +191,24 @@ def first_feasible_sequence(mpc, points):
     return None
 
 
-class CpuPrefixTable:
+def _prefix_search_base():
+    from explicit_hybrid_mpc_amd.sequences import PrefixSearch
+    return PrefixSearch
+
+
+class CpuPrefixTable(_prefix_search_base()):
     """
     The pair solvers of explicit_hybrid_mpc_amd/sequences.PrefixTable on the uncondensed
     relaxations with HiGHS: lets the CPU tests run the searches written on those solvers
-    (sequences.PrefixSearch, bnb.PrefixOracle) without a device.
+    (sequences.PrefixSearch, bnb.PrefixOracle, bnb_frontier) without a device.
     """
 
     def __init__(self, mpc, eps_a=1., eps_r=1.):
-        from explicit_hybrid_mpc_amd.sequences import PrefixSearch
         self.mpc = mpc
         self.eps_a, self.eps_r = eps_a, eps_r
         self.lp_solves = 0
         self._models = {}
-        for name in ('min_cost_on', 'vertex_costs', 'feasible_at_all', 'first_feasible',
-                     'feasible_on', 'solve_points_idx', 'point_ids', 'feasible_sets',
-                     'first_feasible_many', 'register_midpoints'):
-            setattr(self, 'FEAS_MEMO_LIMIT', PrefixSearch.FEAS_MEMO_LIMIT)
-            setattr(self, name, getattr(PrefixSearch, name).__get__(self))
+        self.init_search()
 
     def set_eps(self, eps_a, eps_r):
         self.eps_a, self.eps_r = eps_a, eps_r

@@ -216,3 +216,91 @@ def test_region_tables_of_many_nodes():
     # a table limit that is too small is reported as None, not cut
     assert bnb_frontier.region_tables_many(bo, Rs[:1], comms[:1], [float(costs[0].max())], 2) \
         == [None]
+
+
+class _StubDeviceProblem:
+    """Stands in for engine.GpuProblem under sequences.PrefixTable: keeps the blocks the table
+    writes into its slots and solves the point problems on them with HiGHS -- the CONDENSED
+    form  min c'z  s.t.  G z <= w + S theta  (phase one: min tau, G z - tau <= w + S theta)."""
+
+    def __init__(self, can, eps_a, eps_r, device=0):
+        self.can = can
+        self.G, self.w, self.S = can.G.copy(), can.w.copy(), can.S.copy()
+        self.updates = []
+
+    def set_eps(self, eps_a, eps_r):
+        pass
+
+    def close(self):
+        pass
+
+    def update_blocks(self, first, G, w, S):
+        n = G.shape[0]
+        assert 0 <= first and first + n <= self.G.shape[0]
+        self.G[first:first + n], self.w[first:first + n], self.S[first:first + n] = G, w, S
+        self.updates.append((first, n))
+
+    def point_idx(self, theta, slot, feas=False):
+        from scipy.optimize import linprog
+        theta = np.atleast_2d(theta)
+        J = np.zeros(theta.shape[0])
+        u0 = np.zeros((theta.shape[0], self.can.n_u))
+        for k, (th, s) in enumerate(zip(theta, slot)):
+            G, rhs = self.G[s], self.w[s] + self.S[s] @ th
+            if feas:
+                A = np.hstack([G, -np.ones((G.shape[0], 1))])
+                c = np.zeros(A.shape[1])
+                c[-1] = 1.
+                res = linprog(c, A_ub=A, b_ub=rhs, bounds=[(None, None)] * G.shape[1] + [(-1., None)],
+                              method='highs')
+                J[k] = res.fun
+            else:
+                res = linprog(self.can.c, A_ub=G, b_ub=rhs, bounds=(None, None), method='highs')
+                J[k] = res.fun
+                u0[k] = res.x[:self.can.n_u]
+        return J, u0, np.zeros(theta.shape[0], dtype=np.int32)
+
+
+def test_device_table_bookkeeping_on_a_stub(monkeypatch):
+    """
+    sequences.PrefixTable itself (slots, the prefix -> slot map, chunking over more prefixes
+    than slots, index-array pairs, the feasibility memo with midpoint inference) on a stub of
+    the device problem that solves the CONDENSED blocks with HiGHS: the condensed prefix
+    relaxations (PWAMPC.condense_prefix) give the optima of the uncondensed ones
+    (oracle/prefix_bb.PrefixModel), whatever the slot traffic.
+    """
+    from explicit_hybrid_mpc_amd import sequences
+    monkeypatch.setattr(sequences.engine, 'GpuProblem', _StubDeviceProblem)
+    mpc = helpers.make_instance('pwa_small', 0)                  # 2 modes, N = 3
+    table = sequences.PrefixTable(mpc, slots=4)
+    ref = prefix_bb.CpuPrefixTable(mpc)
+    half = examples.theta_box(mpc)
+    rng = np.random.default_rng(3)
+    prefixes = [(), (0,), (1,), (0, 1), (1, 0), (1, 1, 0), (0, 0, 0), (1, 0, 1), (0, 1, 1)]
+    pairs = [prefixes[k] for k in rng.integers(0, len(prefixes), 40)]
+    thetas = rng.uniform(-1, 1, (40, 2)) * half
+    J, u0 = table.solve_points(pairs, thetas)
+    Jr, ur = ref.solve_points(pairs, thetas)
+    assert np.array_equal(np.isfinite(J), np.isfinite(Jr)) and np.isfinite(J).sum() >= 10
+    fin = np.isfinite(J)
+    assert np.allclose(J[fin], Jr[fin], rtol=1e-8, atol=1e-9)
+    # nine prefixes through four slots: several table loads, never more than four blocks at once
+    assert len(table.gp.updates) >= 3 and all(n <= 4 for _, n in table.gp.updates)
+    assert table.blocks_loaded >= len(set(pairs))
+    # the index-array form is the tuple form
+    uniq = sorted(set(pairs))
+    idx = np.array([uniq.index(q) for q in pairs])
+    J2, _ = table.solve_points_idx(uniq, idx, thetas)
+    assert np.array_equal(np.isfinite(J2), fin) and np.allclose(J2[fin], J[fin], atol=1e-12)
+    # feasibility memo: the second question costs nothing; a midpoint of two feasible points is
+    # taken as feasible without an LP
+    R = np.array(helpers.random_simplices(mpc, rng, 1, scale_lo=-2.)[0])
+    seq = table.first_feasible(R)
+    assert seq == ref.first_feasible(R)
+    before = table.lp_solves
+    assert table.first_feasible(R) == seq and table.lp_solves == before
+    if seq is not None:
+        mid = 0.5 * (R[0] + R[1])
+        table.register_midpoints([mid], [R[0]], [R[1]])
+        assert table.feasible_at_all([seq], mid[None])[0] and table.lp_solves == before
+    table.close()
