@@ -303,4 +303,8 @@ def test_device_table_bookkeeping_on_a_stub(monkeypatch):
         mid = 0.5 * (R[0] + R[1])
         table.register_midpoints([mid], [R[0]], [R[1]])
         assert table.feasible_at_all([seq], mid[None])[0] and table.lp_solves == before
+    # a full memo is dropped and rebuilt: same answers
+    table.FEAS_MEMO_LIMIT = -1
+    assert table.first_feasible(R) == seq and table.lp_solves > before
+    assert len(table._feas) > 0 and table._feas_n > 0
     table.close()
