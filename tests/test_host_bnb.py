@@ -225,14 +225,51 @@ class _StubDeviceProblem:
 
     def __init__(self, can, eps_a, eps_r, device=0):
         self.can = can
+        self.eps_a, self.eps_r = eps_a, eps_r
         self.G, self.w, self.S = can.G.copy(), can.w.copy(), can.S.copy()
         self.updates = []
 
     def set_eps(self, eps_a, eps_r):
-        pass
+        self.eps_a, self.eps_r = eps_a, eps_r
 
     def close(self):
         pass
+
+    def simplex_idx(self, R, slot, mode, Vbar=None):
+        """mode 0: min cost over the simplex; 1: suboptimality-test slack; 2: phase one."""
+        from scipy.optimize import linprog
+        R = np.asarray(R, dtype=np.float64)
+        n, na = self.can.n, R.shape[1]
+        obj = np.zeros(R.shape[0])
+        alpha = np.zeros((R.shape[0], na))
+        for k, s in enumerate(slot):
+            G, w, S = self.G[s], self.w[s], self.S[s]
+            m = G.shape[0]
+            extra = 0 if mode == 0 else 1
+            A = np.zeros((m + (2 if mode == 1 else 0), n + na + extra))
+            A[:m, :n], A[:m, n:n + na] = G, -S @ R[k].T
+            b = np.concatenate([w, np.zeros(2 if mode == 1 else 0)])
+            c = np.zeros(n + na + extra)
+            bounds = [(None, None)] * n + [(0., None)] * na
+            if mode == 0:
+                c[:n] = self.can.c
+            elif mode == 2:
+                A[:m, -1] = -1.
+                c[-1] = 1.
+                bounds.append((-1., None))
+            else:                                   # t <= Vbar'a - c'z - eps_a, <= Vbar'a - (1+eps_r) c'z
+                for r, scale, shift in ((m, 1., self.eps_a), (m + 1, 1. + self.eps_r, 0.)):
+                    A[r, :n], A[r, n:n + na], A[r, -1] = scale * self.can.c, -Vbar[k], 1.
+                    b[r] = -shift
+                c[-1] = -1.
+                bounds.append((None, None))
+            Aeq = np.zeros((1, A.shape[1]))
+            Aeq[0, n:n + na] = 1.
+            res = linprog(c, A_ub=A, b_ub=b, A_eq=Aeq, b_eq=[1.], bounds=bounds, method='highs')
+            assert res.status == 0, (mode, res.message)
+            obj[k] = -res.fun if mode == 1 else res.fun
+            alpha[k] = res.x[n:n + na]
+        return obj, alpha, np.zeros(R.shape[0], dtype=np.int32)
 
     def update_blocks(self, first, G, w, S):
         n = G.shape[0]
@@ -308,3 +345,72 @@ def test_device_table_bookkeeping_on_a_stub(monkeypatch):
     assert table.first_feasible(R) == seq and table.lp_solves > before
     assert len(table._feas) > 0 and table._feas_n > 0
     table.close()
+
+
+def test_searches_on_the_device_table_class_with_a_stub_device(monkeypatch):
+    """
+    The code the GPU tests run -- sequences.PrefixTable under bnb.PrefixOracle, the region-table
+    search and the frontier-wide driver -- with the device problem replaced by the HiGHS stub on
+    the CONDENSED blocks: same answers as on the uncondensed stand-in, same tree as the
+    enumerating CPU partition.
+    """
+    from explicit_hybrid_mpc_amd import sequences, bnb_frontier
+    monkeypatch.setattr(sequences.engine, 'GpuProblem', _StubDeviceProblem)
+    mpc = helpers.make_instance('pwa_small', 0)
+    eps_a = helpers.eps_a_rule(mpc, 0.25)
+    dev = bnb.PrefixOracle(mpc, eps_a, 0.2, slots=6)             # creates a sequences.PrefixTable
+    assert isinstance(dev.table, sequences.PrefixTable)
+    ref = bnb.PrefixOracle(mpc, eps_a, 0.2, table=prefix_bb.CpuPrefixTable(mpc))
+    rng = np.random.default_rng(11)
+    n_star = n_tables = 0
+    for R in helpers.random_simplices(mpc, rng, 10, scale_lo=-1.):
+        R = np.array(R)
+        d1, vx1 = ref.V_R(R)
+        d2, vx2 = dev.V_R(R)
+        assert (d1 is None) == (d2 is None)
+        if d1 is None:
+            continue
+        assert np.array_equal(d1, d2)
+        V = np.array([v[1] for v in vx1])
+        assert np.allclose(V, [v[1] for v in vx2], rtol=1e-8, atol=1e-9)
+        assert ref.bar_E_delta_R(R, V) == dev.bar_E_delta_R(R, V)
+        a, b = ref.bar_D_delta_R(R, V, d1), dev.bar_D_delta_R(R, V, d1)
+        assert (a[0] is None) == (b[0] is None)
+        if a[0] is not None:
+            n_star += 1
+            assert np.array_equal(a[0], b[0]) and np.allclose(a[1], b[1], atol=1e-6) and a[3] == b[3]
+        outcome = []
+        for table in (dev.table, ref.table):
+            try:
+                outcome.append(sequences.relevant_sequences(mpc, R[None], table=table)[0])
+            except ValueError as e:              # NoIncumbent / TableTooLarge: on both or neither
+                outcome.append(type(e).__name__)
+        assert outcome[0] == outcome[1]
+        n_tables += not isinstance(outcome[0], str)
+    assert n_star >= 1 and n_tables >= 1
+    th = rng.uniform(-0.8, 0.8, (5, 2)) * examples.theta_box(mpc)
+    for (u1, dd1, J1), (u2, dd2, J2) in zip(bnb_frontier.p_theta_many(dev, th),
+                                            bnb_frontier.p_theta_many(ref, th)):
+        assert (dd1 is None) == (dd2 is None)
+        if dd1 is not None:
+            assert np.array_equal(dd1, dd2) and abs(J1 - J2) <= 1e-8 * (1 + abs(J2))
+    # the frontier-wide driver on the device-table class: the enumerating CPU partition's tree
+    roots, locs = helpers.roots_of(mpc)
+    cpu = PartitionCPU(OracleCPU(mpc, eps_a, 0.2))
+    cpu.run(roots, locs, 'ecc')
+    trees = [Tree(NodeData(vertices=np.array(R))) for R in roots]
+    stats = bnb_frontier.grow_frontier(dev, trees, 'ecc', handoff=False,
+                                       split_batch=_host_split_batch)
+    assert not stats['truncated']
+    n = 0
+    for t, loc0 in zip(trees, locs):
+        for nd, loc in t.walk(loc0):
+            r = cpu.nodes[loc]
+            n += 1
+            assert nd.is_leaf() == r['leaf']
+            assert nd.data.is_epsilon_suboptimal == r['is_epsilon_suboptimal']
+            if r['commutation'] is not None:
+                assert np.array_equal(nd.data.commutation.astype(int), r['commutation'].astype(int))
+                assert np.allclose(nd.data.vertex_costs, r['vertex_costs'], rtol=1e-7, atol=1e-8)
+    assert n == len(cpu.nodes)
+    dev.close()
