@@ -168,6 +168,8 @@ class PWAMPC:
         out = copy.copy(self)
         out._sequences = sorted(tuple(int(i) for i in s) for s in sequences)
         out._canonical = None
+        out._prefix_template = None
+        out._prefix_pred = {}
         out.name = '%s_restricted%d' % (self.name, len(out._sequences))
         return out
 
@@ -261,6 +263,66 @@ class PWAMPC:
         return G, w, S
 
     def condense_prefix(self, prefix):
+        """
+        ``_condense_prefix_reference`` (see there for what the block is), built directly: the
+        rows that do not depend on the modes come from a template, the prediction matrices of
+        a prefix from its parent's (cached), and only the rows of the decided steps are
+        computed.  Bit-identical to the reference form (tests/test_host_logic.py).
+        """
+        if self.cost_type != 'inf':
+            raise ValueError('prefix relaxations are implemented for the infinity-norm cost')
+        prefix = tuple(int(i) for i in prefix)
+        k, N, n_u, n_x = len(prefix), self.N, self.n_u, self.n_x
+        nU = N * n_u
+        nGx, nGu, nQ, nR = self.Gx.shape[0], self.Gu.shape[0], self.Q.shape[0], self.R.shape[0]
+        tpl = getattr(self, '_prefix_template', None)
+        if tpl is None:
+            G, w, S = self._condense_prefix_reference(())
+            tpl = self._prefix_template = (G, w, S)
+            self._prefix_pred = {(): (np.eye(n_x), np.zeros((n_x, nU)), np.zeros(n_x))}
+        G, w, S = tpl[0].copy(), tpl[1].copy(), tpl[2].copy()
+        pred = self._prefix_pred
+        if len(pred) > 200000:
+            pred.clear()
+            pred[()] = (np.eye(n_x), np.zeros((n_x, nU)), np.zeros(n_x))
+        states = [pred[()]]                              # (Phi_j, Gam_j, om_j), j = 0..k
+        for j in range(k):
+            q = prefix[:j + 1]
+            st = pred.get(q)
+            if st is None:
+                Phi, Gam, om = states[j]
+                A, B, wv = self.A[q[j]], self.B[q[j]], self.w[q[j]]
+                G_next = A @ Gam
+                G_next[:, j * n_u:(j + 1) * n_u] += B
+                st = pred[q] = (A @ Phi, G_next, A @ om + wv)
+            states.append(st)
+        off_q = N * nGx + N * nGu
+        off_r = off_q + 2 * N * nQ + 2 * N * nR
+        row_r = off_r
+        for kk in range(1, k + 1):
+            Phi, Gam, om = states[kk]
+            r0 = (kk - 1) * nGx                          # state constraints of x_kk
+            G[r0:r0 + nGx, :nU] = self.Gx @ Gam
+            w[r0:r0 + nGx] = self.gx - self.Gx @ om
+            S[r0:r0 + nGx] = -self.Gx @ Phi
+            for b, sgn in enumerate((1., -1.)):          # +-Q x_kk <= ex_kk
+                r0 = off_q + (2 * (kk - 1) + b) * nQ
+                G[r0:r0 + nQ, :nU] = sgn * self.Q @ Gam
+                w[r0:r0 + nQ] = -sgn * self.Q @ om
+                S[r0:r0 + nQ] = -sgn * self.Q @ Phi
+        for kk in range(k):                              # mode regions of x_kk, kk < k
+            reg = self.regions[prefix[kk]]
+            if reg is not None:
+                Hx, hx = reg
+                Phi, Gam, om = states[kk]
+                nr = Hx.shape[0]
+                G[row_r:row_r + nr, :nU] = Hx @ Gam
+                w[row_r:row_r + nr] = hx - Hx @ om
+                S[row_r:row_r + nr] = -Hx @ Phi
+                row_r += nr
+        return G, w, S
+
+    def _condense_prefix_reference(self, prefix):
         """
         (G, w, S) of the RELAXATION shared by every mode sequence that starts with ``prefix``
         (k = len(prefix) steps fixed): the rows that involve the states x_j, j > k -- state

@@ -251,3 +251,36 @@ def test_bench_helpers_quote_only_profiles_of_this_code(tmp_path, monkeypatch):
     assert 0 < bench.flops_executed_per_iteration(25, 24, 167, 28) < bench.flops_per_iteration(25, 167)
     assert bench.node_bytes(4, 2, 5) == 301
     assert 1 <= bench.usable_cores() <= (os.cpu_count() or 1)
+
+
+def test_prefix_blocks_built_incrementally_are_the_reference_blocks():
+    """PWAMPC.condense_prefix (template + cached predictions, only the decided steps' rows
+    computed) is bit-identical to the plain form -- also when the mode regions have different
+    numbers of rows or are absent."""
+    from explicit_hybrid_mpc_amd import mpc_library
+    base = helpers.make_instance('pwa_small', 0)
+    H1, h1 = base.regions[1]
+    uneven = mpc_library.PWAMPC(base.A, base.B, base.w,
+                                [base.regions[0], (np.vstack([H1, H1[:1]]), np.append(h1, h1[0] + 1.))],
+                                base.Gx, base.gx, base.Gu, base.gu, base.Q, base.R, base.N,
+                                name='uneven')
+    free = mpc_library.PWAMPC(base.A, base.B, base.w, [base.regions[0], None],
+                              base.Gx, base.gx, base.Gu, base.gu, base.Q, base.R, base.N,
+                              name='one_free_mode')
+    rng = np.random.default_rng(0)
+    for mpc in (base, uneven, free, examples.pwa4_mpc(N=8)):
+        prefixes = [()] + [tuple(int(i) for i in rng.integers(0, mpc.delta_size,
+                                                              rng.integers(1, mpc.N + 1)))
+                           for _ in range(60)]
+        for q in prefixes + prefixes[:10]:              # the second pass hits the cache
+            new, ref = mpc.condense_prefix(q), mpc._condense_prefix_reference(q)
+            assert all(np.array_equal(a, b) for a, b in zip(new, ref)), (mpc.name, q)
+        # a full prefix is the block of the compiled table
+        full = tuple(int(i) for i in rng.integers(0, mpc.delta_size, mpc.N))
+        G, w, S = mpc.condense_prefix(full)
+        Gc, wc, Sc = mpc._condense(full, G.shape[0])
+        assert np.array_equal(G, Gc) and np.array_equal(w, wc) and np.array_equal(S, Sc)
+    # a restricted copy does not share the caches
+    sub = base.restrict([(0, 0, 0), (1, 0, 1)])
+    assert all(np.array_equal(a, b) for a, b in zip(sub.condense_prefix((1, 0)),
+                                                    base._condense_prefix_reference((1, 0))))
