@@ -39,6 +39,15 @@ EXPORTED = [
 ]
 
 
+# every symbol include/ehm_search.h declares (host bookkeeping of the prefix searches)
+EXPORTED_SEARCH = [
+    'ehm_search_create', 'ehm_search_destroy', 'ehm_search_last_error', 'ehm_search_point_ids',
+    'ehm_search_register_midpoints', 'ehm_search_forget', 'ehm_search_counts',
+    'ehm_search_query', 'ehm_search_asks', 'ehm_search_answer', 'ehm_search_descent_begin',
+    'ehm_search_descent_step', 'ehm_search_descent_result',
+]
+
+
 class EhmError(RuntimeError):
     def __init__(self, code, message):
         super().__init__('libehmpc error %d: %s' % (code, message))
@@ -173,6 +182,23 @@ def load(build_if_missing=True):
         if name not in ('ehm_last_error', 'ehm_version', 'ehm_stream',
                         'ehm_explicit_last_error'):
             fn.restype = i32
+    lib.ehm_search_last_error.restype = ctypes.c_char_p
+    lib.ehm_search_create.argtypes = [i32, i32, i32, ctypes.POINTER(vp)]
+    lib.ehm_search_destroy.argtypes = [vp]
+    lib.ehm_search_point_ids.argtypes = [vp, i64, vp, vp]
+    lib.ehm_search_register_midpoints.argtypes = [vp, i64, vp, vp, vp]
+    lib.ehm_search_forget.argtypes = [vp]
+    lib.ehm_search_counts.argtypes = [vp, vp]
+    lib.ehm_search_query.argtypes = [vp, i64, vp, vp, vp, vp, ctypes.POINTER(i64),
+                                     ctypes.POINTER(i64)]
+    lib.ehm_search_asks.argtypes = [vp, vp, vp, vp]
+    lib.ehm_search_answer.argtypes = [vp, vp, vp]
+    lib.ehm_search_descent_begin.argtypes = [vp, i64, vp, vp, vp, vp]
+    lib.ehm_search_descent_step.argtypes = [vp, vp, ctypes.POINTER(i64), ctypes.POINTER(i64)]
+    lib.ehm_search_descent_result.argtypes = [vp, vp, ctypes.POINTER(i64)]
+    for name in EXPORTED_SEARCH:
+        if name != 'ehm_search_last_error':
+            getattr(lib, name).restype = i32
     _lib = lib
     return lib
 
@@ -180,6 +206,11 @@ def load(build_if_missing=True):
 def check(rc):
     if rc != EHM_OK:
         raise EhmError(rc, load().ehm_last_error().decode('utf-8', 'replace'))
+
+
+def check_search(rc):
+    if rc != EHM_OK:
+        raise EhmError(rc, load().ehm_search_last_error().decode('utf-8', 'replace'))
 
 
 def f64(a):

@@ -57,9 +57,22 @@ def _hipcc():
     raise RuntimeError('hipcc not found: libehmpc.so cannot be built')
 
 
+def _cxx():
+    for cand in (os.environ.get('CXX'), shutil.which('g++'), shutil.which('c++')):
+        if cand and os.path.exists(cand):
+            return cand
+    return _hipcc()
+
+
 def _dep_mtime():
     deps = [os.path.join(SRC_DIR, h) for h in HEADERS] + [__file__]
     return max(os.path.getmtime(os.path.normpath(d)) for d in deps)
+
+
+SEARCH_SRC = os.path.join(SRC_DIR, 'ehm_search.cpp')      # host C++ only (include/ehm_search.h)
+SEARCH_OBJ = os.path.join(OBJ_DIR, 'ehm_search.o')
+SEARCH_DEPS = [SEARCH_SRC, os.path.normpath(os.path.join(HERE, '..', 'include', 'ehm_search.h')),
+               os.path.normpath(os.path.join(HERE, '..', 'include', 'ehmpc.h'))]
 
 
 def _objects():
@@ -116,7 +129,7 @@ def is_stale():
     t = os.path.getmtime(LIB)
     srcs = [os.path.join(SRC_DIR, f)
             for f in ('ehm_capi.hip', 'ehm_k2.hip', 'ehm_k3.hip', 'ehm_kp.hip', 'ehm_explicit.hip')]
-    return max([_dep_mtime()] + [os.path.getmtime(s) for s in srcs]) > t
+    return max([_dep_mtime()] + [os.path.getmtime(s) for s in srcs + SEARCH_DEPS]) > t
 
 
 def build(force=False, verbose=False, jobs=None):
@@ -139,7 +152,15 @@ def build(force=False, verbose=False, jobs=None):
     jobs = jobs or max(1, (os.cpu_count() or 2))
     with ThreadPoolExecutor(max_workers=jobs) as pool:
         list(pool.map(compile_one, todo))
+    # the searches' host bookkeeping: plain C++, no device code
+    if force or not os.path.exists(SEARCH_OBJ) or \
+            os.path.getmtime(SEARCH_OBJ) < max(os.path.getmtime(d) for d in SEARCH_DEPS):
+        cmd = [_cxx(), '-O2', '-std=c++17', '-fPIC', '-Wall', '-c', SEARCH_SRC, '-o', SEARCH_OBJ]
+        if verbose:
+            print(' '.join(cmd))
+        subprocess.check_call(cmd)
     cmd = [hipcc, '--offload-arch=gfx950', '-shared', '-fPIC'] + [o for (o, _, _) in _objects()]
+    cmd += [SEARCH_OBJ]
     cmd += ['-o', LIB]
     if verbose:
         print(' '.join(cmd))

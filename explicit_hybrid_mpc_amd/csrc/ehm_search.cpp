@@ -1,0 +1,487 @@
+// ehm_search.cpp -- host-side bookkeeping of the searches over mode prefixes (include/ehm_search.h).
+//
+// Plain C++ (no device code): point ids by value, the memo of phase-one verdicts per
+// (prefix, point) with midpoint inference, de-duplication of the pairs one launch has to solve, and
+// the lockstep lexicographic descents that give V_R's canonical answer (lib/oracle.py:175-218).
+// The Python of explicit_hybrid_mpc_amd/sequences.py drives it and owns the launches.
+
+#include "../../include/ehm_search.h"
+#include "../../include/ehmpc.h"
+
+#include <cstdarg>
+#include <cstdio>
+#include <cstring>
+#include <new>
+#include <unordered_map>
+#include <vector>
+
+namespace {
+
+thread_local char g_err[256] = "";
+
+int fail(int code, const char* fmt, ...) {
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(g_err, sizeof g_err, fmt, ap);
+    va_end(ap);
+    return code;
+}
+
+inline uint64_t mix(uint64_t x) {          // splitmix64 finaliser
+    x ^= x >> 30; x *= 0xbf58476d1ce4e5b9ull;
+    x ^= x >> 27; x *= 0x94d049bb133111ebull;
+    x ^= x >> 31;
+    return x;
+}
+
+constexpr uint64_t EMPTY = ~0ull;
+constexpr int PID_BITS = 38;               // key = code << 38 | point id
+constexpr uint64_t CODE_LIMIT = 1ull << 26;
+
+// open-addressing map  uint64 key -> int32 value  (keys never removed one by one)
+struct Memo {
+    std::vector<uint64_t> key;
+    std::vector<int32_t> val;
+    size_t used = 0, mask = 0;
+    Memo() { rehash(1 << 16); }
+    void rehash(size_t cap) {
+        std::vector<uint64_t> k(cap, EMPTY);
+        std::vector<int32_t> v(cap, 0);
+        size_t m = cap - 1;
+        for (size_t i = 0; i < key.size(); ++i)
+            if (key[i] != EMPTY) {
+                size_t h = mix(key[i]) & m;
+                while (k[h] != EMPTY) h = (h + 1) & m;
+                k[h] = key[i]; v[h] = val[i];
+            }
+        key.swap(k); val.swap(v); mask = m;
+    }
+    void clear() { key.assign(1 << 16, EMPTY); val.assign(1 << 16, 0); used = 0; mask = (1 << 16) - 1; }
+    // slot of `k` (existing or the empty slot it would take)
+    inline size_t slot(uint64_t k) const {
+        size_t h = mix(k) & mask;
+        while (key[h] != EMPTY && key[h] != k) h = (h + 1) & mask;
+        return h;
+    }
+    inline int32_t get(uint64_t k) const {             // -1 = absent
+        size_t h = slot(k);
+        return key[h] == EMPTY ? -1 : val[h];
+    }
+    inline void put(uint64_t k, int32_t v) {
+        size_t h = slot(k);
+        if (key[h] == EMPTY) {
+            if ((used + 1) * 10 > (mask + 1) * 6) { rehash((mask + 1) * 2); h = slot(k); }
+            key[h] = k; ++used;
+        }
+        val[h] = v;
+    }
+};
+
+struct Pref { uint64_t code; int32_t len; };
+
+struct Descent {
+    int64_t pb, pe;                        // its points in ehm_search::d_pid
+    int64_t eb, ee;                        // its excluded sequences in ehm_search::d_excl
+    std::vector<Pref> stack;
+    int64_t result = -1;                   // code of the sequence found
+    bool done = false;
+};
+
+}  // namespace
+
+struct ehm_search {
+    int p, n_modes, N;
+    std::vector<uint64_t> pw;              // (n_modes + 1)^i
+    // points
+    std::vector<double> coord;
+    std::vector<int64_t> table;            // open addressing over point ids
+    size_t tmask = 0;
+    std::vector<int64_t> mid_a, mid_b;
+    // verdicts
+    Memo memo;
+    int64_t n_asked = 0, n_shared = 0;
+    // the pending launch
+    std::vector<uint64_t> ask_code;
+    std::vector<int64_t> ask_pid, ask_prefix;
+    std::vector<uint64_t> uniq_code;
+    std::unordered_map<uint64_t, int64_t> uniq_of;
+    std::vector<std::pair<int64_t, int64_t>> deps;     // (ask, set)
+    int64_t pending_sets = -1;                         // sets of the pending query, -1 = none
+    std::vector<int64_t> need;                         // scratch
+    // descents
+    std::vector<Descent> desc;
+    std::vector<int64_t> d_pid;
+    std::vector<uint64_t> d_excl;
+    std::vector<int64_t> active;
+    std::vector<uint64_t> kid_code;
+    std::vector<int64_t> kid_b, kid_e;
+    std::vector<uint8_t> kid_flag;
+    bool step_pending = false;
+    int64_t steps = 0;
+
+    inline uint64_t key_of(uint64_t code, int64_t pid) const {
+        return (code << PID_BITS) | (uint64_t)pid;
+    }
+    uint64_t hash_point(const double* x) const {
+        uint64_t h = 0x9e3779b97f4a7c15ull;
+        for (int i = 0; i < p; ++i) {
+            uint64_t b;
+            memcpy(&b, x + i, 8);
+            h = mix(h ^ b);
+        }
+        return h;
+    }
+    void grow_points() {
+        size_t cap = table.empty() ? (1u << 12) : table.size() * 2;
+        std::vector<int64_t> t(cap, -1);
+        size_t m = cap - 1;
+        int64_t n = (int64_t)(coord.size() / p);
+        for (int64_t id = 0; id < n; ++id) {
+            size_t h = hash_point(&coord[id * p]) & m;
+            while (t[h] >= 0) h = (h + 1) & m;
+            t[h] = id;
+        }
+        table.swap(t); tmask = m;
+    }
+    int64_t point_id(const double* x) {
+        int64_t n = (int64_t)(coord.size() / p);
+        if (table.empty() || (size_t)(n + 1) * 10 > table.size() * 6) grow_points();
+        size_t h = hash_point(x) & tmask;
+        while (table[h] >= 0) {
+            if (!memcmp(&coord[table[h] * p], x, 8 * p)) return table[h];
+            h = (h + 1) & tmask;
+        }
+        table[h] = n;
+        coord.insert(coord.end(), x, x + p);
+        mid_a.push_back(-1); mid_b.push_back(-1);
+        return n;
+    }
+
+    // The questions of one launch.  Set k: prefix code[k] at the points pid[sb[k] .. se[k]).
+    void query(int64_t n_sets, const uint64_t* code, const int64_t* sb, const int64_t* se,
+               const int64_t* pid, uint8_t* flags) {
+        ask_code.clear(); ask_pid.clear(); ask_prefix.clear();
+        uniq_code.clear(); uniq_of.clear(); deps.clear();
+        for (int64_t k = 0; k < n_sets; ++k) {
+            const uint64_t c = code[k];
+            bool yes = true;
+            need.clear();
+            for (int64_t t = sb[k]; t < se[k]; ++t) {
+                const int64_t v = pid[t];
+                const int32_t r = memo.get(key_of(c, v));
+                if (r == 1) continue;
+                if (r == 0) { yes = false; break; }
+                if (r < 0) {
+                    const int64_t a = mid_a[v];
+                    if (a >= 0 && memo.get(key_of(c, a)) == 1 &&
+                        memo.get(key_of(c, mid_b[v])) == 1) {
+                        memo.put(key_of(c, v), 1);     // feasible at both ends of the edge
+                        continue;
+                    }
+                    need.push_back(-1 - v);            // a pair nobody has asked for yet
+                } else {
+                    need.push_back(r - 2);             // pending: another search asked already
+                }
+            }
+            flags[k] = yes ? 1 : 0;
+            if (!yes) continue;
+            for (int64_t q : need) {
+                int64_t a = q;
+                if (q < 0) {
+                    const int64_t v = -1 - q;
+                    const int32_t r = memo.get(key_of(c, v));
+                    if (r >= 2) {                      // the same point twice in one set
+                        a = r - 2;
+                    } else {
+                        a = (int64_t)ask_code.size();
+                        memo.put(key_of(c, v), (int32_t)(2 + a));
+                        ask_code.push_back(c);
+                        ask_pid.push_back(v);
+                        auto it = uniq_of.find(c);
+                        if (it == uniq_of.end()) {
+                            it = uniq_of.emplace(c, (int64_t)uniq_code.size()).first;
+                            uniq_code.push_back(c);
+                        }
+                        ask_prefix.push_back(it->second);
+                    }
+                } else {
+                    ++n_shared;
+                }
+                deps.emplace_back(a, k);
+            }
+        }
+        n_asked += (int64_t)ask_code.size();
+    }
+    void answer(const uint8_t* feasible, uint8_t* flags) {
+        for (size_t a = 0; a < ask_code.size(); ++a)
+            memo.put(key_of(ask_code[a], ask_pid[a]), feasible[a] ? 1 : 0);
+        for (const auto& d : deps)
+            if (!feasible[d.first]) flags[d.second] = 0;
+        ask_code.clear(); ask_pid.clear(); ask_prefix.clear(); deps.clear();
+    }
+
+    // descents: pop one prefix per active descent, question its children
+    void descents_ask() {
+        kid_code.clear(); kid_b.clear(); kid_e.clear();
+        for (int64_t j : active) {
+            Descent& d = desc[j];
+            const Pref q = d.stack.back();             // stays on top until the answers are in
+            for (int i = 0; i < n_modes; ++i) {
+                kid_code.push_back(q.code + (uint64_t)(i + 1) * pw[q.len]);
+                kid_b.push_back(d.pb); kid_e.push_back(d.pe);
+            }
+        }
+        kid_flag.assign(kid_code.size(), 1);
+        query((int64_t)kid_code.size(), kid_code.data(), kid_b.data(), kid_e.data(), d_pid.data(),
+              kid_flag.data());
+        ++steps;
+    }
+    void descents_advance() {
+        std::vector<int64_t> still;
+        for (size_t a = 0; a < active.size(); ++a) {
+            Descent& d = desc[active[a]];
+            const Pref q = d.stack.back();
+            d.stack.pop_back();
+            const int32_t len = q.len + 1;
+            // children in enumeration order; the first admissible full sequence ends the descent
+            size_t first_good = d.stack.size();
+            for (int i = n_modes - 1; i >= 0; --i) {
+                const size_t k = a * n_modes + i;
+                if (!kid_flag[k]) continue;
+                bool excl = false;
+                if (len == N)
+                    for (int64_t e = d.eb; e < d.ee; ++e) excl |= d_excl[e] == kid_code[k];
+                if (!excl) d.stack.push_back(Pref{kid_code[k], len});
+            }
+            if (len == N && d.stack.size() > first_good) {
+                d.result = (int64_t)d.stack.back().code;       // lowest mode among the good ones
+                d.done = true;
+                d.stack.clear();
+            } else if (d.stack.empty()) {
+                d.done = true;
+            } else {
+                still.push_back(active[a]);
+            }
+        }
+        active.swap(still);
+    }
+};
+
+extern "C" {
+
+const char* ehm_search_last_error(void) { return g_err; }
+
+int ehm_search_create(int32_t p, int32_t n_modes, int32_t N, ehm_search** out) {
+    if (!out) return fail(EHM_E_INVALID, "ehm_search_create: out is NULL");
+    if (p < 1 || p > EHM_MAX_P || n_modes < 1 || N < 1)
+        return fail(EHM_E_INVALID, "ehm_search_create: p=%d n_modes=%d N=%d", p, n_modes, N);
+    std::vector<uint64_t> pw(N + 1, 1);
+    for (int i = 1; i <= N; ++i) {
+        pw[i] = pw[i - 1] * (uint64_t)(n_modes + 1);
+        if (pw[i] >= CODE_LIMIT)
+            return fail(EHM_E_INVALID, "ehm_search_create: (n_modes + 1)^N = %d^%d exceeds 2^26",
+                        n_modes + 1, N);
+    }
+    ehm_search* s = new (std::nothrow) ehm_search();
+    if (!s) return fail(EHM_E_CAPACITY, "ehm_search_create: out of memory");
+    s->p = p; s->n_modes = n_modes; s->N = N; s->pw = pw;
+    *out = s;
+    return EHM_OK;
+}
+
+int ehm_search_destroy(ehm_search* s) {
+    delete s;
+    return EHM_OK;
+}
+
+int ehm_search_point_ids(ehm_search* s, int64_t n, const double* points, int64_t* ids) {
+    if (!s || n < 0 || (n && (!points || !ids)))
+        return fail(EHM_E_INVALID, "ehm_search_point_ids: bad argument");
+    if ((int64_t)(s->coord.size() / s->p) + n >= (int64_t)1 << PID_BITS)
+        return fail(EHM_E_CAPACITY, "ehm_search_point_ids: more than 2^38 points");
+    try {
+        for (int64_t k = 0; k < n; ++k) ids[k] = s->point_id(points + k * s->p);
+    } catch (const std::bad_alloc&) {
+        return fail(EHM_E_CAPACITY, "ehm_search_point_ids: out of memory");
+    }
+    return EHM_OK;
+}
+
+int ehm_search_register_midpoints(ehm_search* s, int64_t n, const int64_t* mid, const int64_t* a,
+                                  const int64_t* b) {
+    if (!s || n < 0 || (n && (!mid || !a || !b)))
+        return fail(EHM_E_INVALID, "ehm_search_register_midpoints: bad argument");
+    const int64_t np_ = (int64_t)s->mid_a.size();
+    for (int64_t k = 0; k < n; ++k) {
+        if (mid[k] < 0 || mid[k] >= np_ || a[k] < 0 || a[k] >= np_ || b[k] < 0 || b[k] >= np_)
+            return fail(EHM_E_INVALID, "ehm_search_register_midpoints: unknown point id");
+        s->mid_a[mid[k]] = a[k];
+        s->mid_b[mid[k]] = b[k];
+    }
+    return EHM_OK;
+}
+
+int ehm_search_forget(ehm_search* s) {
+    if (!s) return fail(EHM_E_INVALID, "ehm_search_forget: NULL handle");
+    if (s->pending_sets >= 0 || s->step_pending)
+        return fail(EHM_E_INVALID, "ehm_search_forget: a launch is pending");
+    s->memo.clear();
+    return EHM_OK;
+}
+
+int ehm_search_counts(const ehm_search* s, int64_t counts[4]) {
+    if (!s || !counts) return fail(EHM_E_INVALID, "ehm_search_counts: bad argument");
+    counts[0] = (int64_t)s->memo.used;
+    counts[1] = (int64_t)(s->coord.size() / s->p);
+    counts[2] = s->n_asked;
+    counts[3] = s->n_shared;
+    return EHM_OK;
+}
+
+static int check_sets(const ehm_search* s, const char* who, int64_t n_sets, const uint64_t* code,
+                      const int64_t* set_begin, const int64_t* point_id) {
+    const int64_t np_ = (int64_t)s->mid_a.size();
+    const uint64_t top = s->pw[s->N];
+    for (int64_t k = 0; k < n_sets; ++k) {
+        if (code && code[k] >= top) return fail(EHM_E_INVALID, "%s: prefix code out of range", who);
+        if (set_begin[k + 1] < set_begin[k]) return fail(EHM_E_INVALID, "%s: set_begin decreases", who);
+    }
+    for (int64_t t = set_begin[0]; t < set_begin[n_sets]; ++t)
+        if (point_id[t] < 0 || point_id[t] >= np_)
+            return fail(EHM_E_INVALID, "%s: unknown point id", who);
+    return EHM_OK;
+}
+
+int ehm_search_query(ehm_search* s, int64_t n_sets, const uint64_t* code, const int64_t* set_begin,
+                     const int64_t* point_id, uint8_t* flags, int64_t* n_ask, int64_t* n_prefix) {
+    if (!s || n_sets < 0 || !set_begin || !n_ask || !n_prefix || (n_sets && (!code || !flags)))
+        return fail(EHM_E_INVALID, "ehm_search_query: bad argument");
+    if (s->pending_sets >= 0 || s->step_pending)
+        return fail(EHM_E_INVALID, "ehm_search_query: the pairs of the previous launch are pending");
+    if (set_begin[n_sets] > set_begin[0] && !point_id)
+        return fail(EHM_E_INVALID, "ehm_search_query: point_id is NULL");
+    if (int rc = check_sets(s, "ehm_search_query", n_sets, code, set_begin, point_id)) return rc;
+    try {
+        s->query(n_sets, code, set_begin, set_begin + 1, point_id, flags);
+    } catch (const std::bad_alloc&) {
+        return fail(EHM_E_CAPACITY, "ehm_search_query: out of memory");
+    }
+    *n_ask = (int64_t)s->ask_code.size();
+    *n_prefix = (int64_t)s->uniq_code.size();
+    if (*n_ask) s->pending_sets = n_sets;
+    return EHM_OK;
+}
+
+int ehm_search_asks(const ehm_search* s, uint64_t* prefix_code, int64_t* prefix_index,
+                    double* theta) {
+    if (!s) return fail(EHM_E_INVALID, "ehm_search_asks: NULL handle");
+    const size_t na = s->ask_code.size();
+    if (na && (!prefix_code || !prefix_index || !theta))
+        return fail(EHM_E_INVALID, "ehm_search_asks: NULL output");
+    if (!s->uniq_code.empty())
+        memcpy(prefix_code, s->uniq_code.data(), 8 * s->uniq_code.size());
+    for (size_t a = 0; a < na; ++a) {
+        prefix_index[a] = s->ask_prefix[a];
+        memcpy(theta + a * s->p, &s->coord[s->ask_pid[a] * s->p], 8 * s->p);
+    }
+    return EHM_OK;
+}
+
+int ehm_search_answer(ehm_search* s, const uint8_t* feasible, uint8_t* flags) {
+    if (!s || !feasible || !flags) return fail(EHM_E_INVALID, "ehm_search_answer: bad argument");
+    if (s->pending_sets < 0) return fail(EHM_E_INVALID, "ehm_search_answer: nothing is pending");
+    try {
+        s->answer(feasible, flags);
+    } catch (const std::bad_alloc&) {
+        return fail(EHM_E_CAPACITY, "ehm_search_answer: out of memory");
+    }
+    s->pending_sets = -1;
+    return EHM_OK;
+}
+
+int ehm_search_descent_begin(ehm_search* s, int64_t n, const int64_t* set_begin,
+                             const int64_t* point_id, const int64_t* excl_begin,
+                             const uint64_t* excluded) {
+    if (!s || n < 0 || !set_begin)
+        return fail(EHM_E_INVALID, "ehm_search_descent_begin: bad argument");
+    if (s->pending_sets >= 0 || s->step_pending)
+        return fail(EHM_E_INVALID, "ehm_search_descent_begin: a launch is pending");
+    if (set_begin[n] > set_begin[0] && !point_id)
+        return fail(EHM_E_INVALID, "ehm_search_descent_begin: point_id is NULL");
+    if (int rc = check_sets(s, "ehm_search_descent_begin", n, nullptr, set_begin, point_id))
+        return rc;
+    if (excl_begin && excl_begin[n] > excl_begin[0] && !excluded)
+        return fail(EHM_E_INVALID, "ehm_search_descent_begin: excluded is NULL");
+    try {
+        s->desc.assign((size_t)n, Descent());
+        s->d_pid.assign(point_id + set_begin[0], point_id + set_begin[n]);
+        s->d_excl.clear();
+        if (excl_begin) s->d_excl.assign(excluded + excl_begin[0], excluded + excl_begin[n]);
+        s->active.clear();
+        for (int64_t j = 0; j < n; ++j) {
+            Descent& d = s->desc[j];
+            d.pb = set_begin[j] - set_begin[0];
+            d.pe = set_begin[j + 1] - set_begin[0];
+            d.eb = excl_begin ? excl_begin[j] - excl_begin[0] : 0;
+            d.ee = excl_begin ? excl_begin[j + 1] - excl_begin[0] : 0;
+            d.stack.push_back(Pref{0, 0});
+            s->active.push_back(j);
+        }
+    } catch (const std::bad_alloc&) {
+        return fail(EHM_E_CAPACITY, "ehm_search_descent_begin: out of memory");
+    }
+    s->steps = 0;
+    return EHM_OK;
+}
+
+int ehm_search_descent_step(ehm_search* s, const uint8_t* feasible, int64_t* n_ask,
+                            int64_t* n_prefix) {
+    if (!s || !n_ask || !n_prefix)
+        return fail(EHM_E_INVALID, "ehm_search_descent_step: bad argument");
+    if (s->pending_sets >= 0)
+        return fail(EHM_E_INVALID, "ehm_search_descent_step: a query is pending");
+    try {
+        if (s->step_pending) {
+            if (!feasible)
+                return fail(EHM_E_INVALID, "ehm_search_descent_step: the verdicts of the pending "
+                                           "pairs are missing");
+            s->answer(feasible, s->kid_flag.data());
+            s->step_pending = false;
+            s->descents_advance();
+        }
+        while (!s->active.empty()) {
+            s->descents_ask();
+            if (!s->ask_code.empty()) {
+                s->step_pending = true;
+                break;
+            }
+            s->descents_advance();
+        }
+    } catch (const std::bad_alloc&) {
+        return fail(EHM_E_CAPACITY, "ehm_search_descent_step: out of memory");
+    }
+    *n_ask = (int64_t)s->ask_code.size();
+    *n_prefix = (int64_t)s->uniq_code.size();
+    return EHM_OK;
+}
+
+int ehm_search_descent_result(ehm_search* s, int32_t* sequence, int64_t* steps) {
+    if (!s || (!s->desc.empty() && !sequence))
+        return fail(EHM_E_INVALID, "ehm_search_descent_result: bad argument");
+    if (s->step_pending || !s->active.empty())
+        return fail(EHM_E_INVALID, "ehm_search_descent_result: the descents are not finished");
+    const uint64_t base = (uint64_t)s->n_modes + 1;
+    for (size_t j = 0; j < s->desc.size(); ++j) {
+        int32_t* out = sequence + j * s->N;
+        if (s->desc[j].result < 0) {
+            for (int i = 0; i < s->N; ++i) out[i] = -1;
+            continue;
+        }
+        uint64_t c = (uint64_t)s->desc[j].result;
+        for (int i = 0; i < s->N; ++i) { out[i] = (int32_t)(c % base) - 1; c /= base; }
+    }
+    if (steps) *steps = s->steps;
+    return EHM_OK;
+}
+
+}  // extern "C"

@@ -44,8 +44,11 @@ a config-5 tree needs beyond this.
 
 import numpy as np
 
+import ctypes
+
 from .mpc_library import CanonicalLP
-from . import engine
+from . import engine, _capi
+from ._capi import ptr
 
 FEAS_TOL = 1e-8          # EHM_FEAS_TOL of csrc/ehm_capi.hip
 
@@ -60,14 +63,56 @@ class NoIncumbent(ValueError):
 
 class PrefixSearch:
     """Searches over prefixes written on the three pair solvers of a table (``solve_points``,
-    ``solve_min``, ``solve_slack``); the device table below provides them."""
+    ``solve_min``, ``solve_slack``); the device table below provides them.  The bookkeeping
+    between two launches -- point ids, the memo of phase-one verdicts, the lockstep descents --
+    is native (include/ehm_search.h, csrc/ehm_search.cpp)."""
 
     def init_search(self):
-        """State of the feasibility memo (``feasible_sets``); every table calls it once."""
-        self._pid = {}          # parameter point (bytes) -> id
-        self._feas = {}         # prefix -> {point id: phase-one verdict}
-        self._mid_of = {}       # point id of a bisection midpoint -> ids of the edge's ends
-        self._feas_n = 0
+        """Creates the native search state (``ehm_search``); every table calls it once."""
+        self._lib = _capi.load()
+        h = ctypes.c_void_p()
+        _capi.check_search(self._lib.ehm_search_create(self.mpc.n_x, self.mpc.delta_size,
+                                                       self.mpc.N, ctypes.byref(h)))
+        self._search = h
+        self._code_of = {(): 0}         # prefix -> its integer code (ehm_search.h), and back
+        self._prefix_of = {0: ()}
+        self._feas_n = 0                # pairs solved since the verdicts were last forgotten
+
+    def close_search(self):
+        h, self._search = getattr(self, '_search', None), None
+        if h:
+            self._lib.ehm_search_destroy(h)
+
+    def __del__(self):
+        try:
+            self.close_search()
+        except Exception:
+            pass
+
+    def _code(self, q):
+        c = self._code_of.get(q)
+        if c is None:
+            c = self._code(q[:-1]) + (int(q[-1]) + 1) * (self.mpc.delta_size + 1) ** (len(q) - 1)
+            self._code_of[q] = c
+            self._prefix_of.setdefault(c, tuple(int(i) for i in q))
+        return c
+
+    def _prefix(self, c):
+        q = self._prefix_of.get(c)
+        if q is None:
+            base, x, digits = self.mpc.delta_size + 1, c, []
+            while x:
+                digits.append(x % base - 1)
+                x //= base
+            q = self._prefix_of[c] = tuple(digits)
+            self._code_of[q] = c
+        return q
+
+    def search_counts(self):
+        """(verdicts held, points, pairs handed out, pairs shared by searches of one launch)."""
+        out = np.zeros(4, dtype=np.int64)
+        _capi.check_search(self._lib.ehm_search_counts(self._search, ptr(out)))
+        return tuple(int(v) for v in out)
 
     def solve_points_idx(self, uniq, idx, thetas, feasibility_only=False):
         """``solve_points`` with the prefixes given as indices into the list ``uniq`` (the device
@@ -95,22 +140,19 @@ class PrefixSearch:
     # -- feasibility of (prefix, point) pairs, remembered --------------------------------------
     # The searches ask the same questions again and again: the children of a node share all but
     # one of its vertices, and their descents visit the same prefixes.  Phase-one verdicts are
-    # kept per prefix and point (a dict of point ids per prefix); only the pairs nothing is known
-    # about go to the solver.  On the 8-dimensional cell of DESIGN.md section 3.3e that is the
-    # new midpoint of every node -- one vertex in nine.
+    # kept per prefix and point; only the pairs nothing is known about go to the solver, and a
+    # pair several searches of one launch ask for goes once.  On the 8-dimensional cell of
+    # DESIGN.md section 3.3e that is the new midpoint of every node -- one vertex in nine, asked
+    # by both children of the node in the same launch.
     FEAS_MEMO_LIMIT = 3000000
 
     def point_ids(self, points):
         """Integer ids of parameter points (by value), the keys of the feasibility memo."""
-        pid = self._pid
-        out = []
-        for pt in np.ascontiguousarray(points, dtype=np.float64).reshape(-1, self.mpc.n_x):
-            key = pt.tobytes()
-            i = pid.get(key)
-            if i is None:
-                i = pid[key] = len(pid)
-            out.append(i)
-        return out
+        pts = np.ascontiguousarray(points, dtype=np.float64).reshape(-1, self.mpc.n_x)
+        ids = np.empty(pts.shape[0], dtype=np.int64)
+        _capi.check_search(self._lib.ehm_search_point_ids(self._search, pts.shape[0], ptr(pts),
+                                                          ptr(ids)))
+        return ids
 
     def register_midpoints(self, mids, ends_a, ends_b):
         """
@@ -118,9 +160,26 @@ class PrefixSearch:
         bisections of the partition): a relaxation feasible at both ends is feasible at the
         midpoint -- its feasible parameters form a convex set -- and needs no LP there.
         """
-        mid_of = self._mid_of
-        for m, a, b in zip(self.point_ids(mids), self.point_ids(ends_a), self.point_ids(ends_b)):
-            mid_of[m] = (a, b)
+        m, a, b = self.point_ids(mids), self.point_ids(ends_a), self.point_ids(ends_b)
+        _capi.check_search(self._lib.ehm_search_register_midpoints(self._search, m.size, ptr(m),
+                                                                   ptr(a), ptr(b)))
+
+    def _forget_if_full(self):
+        if self._feas_n > self.FEAS_MEMO_LIMIT:
+            _capi.check_search(self._lib.ehm_search_forget(self._search))
+            self._feas_n = 0
+
+    def _solve_pending(self, n_ask, n_prefix):
+        """One phase-one launch over the pairs the native state has pending; their verdicts."""
+        codes = np.empty(n_prefix, dtype=np.uint64)
+        idx = np.empty(n_ask, dtype=np.int64)
+        thetas = np.empty((n_ask, self.mpc.n_x))
+        _capi.check_search(self._lib.ehm_search_asks(self._search, ptr(codes), ptr(idx),
+                                                     ptr(thetas)))
+        J = self.solve_points_idx([self._prefix(int(c)) for c in codes], idx, thetas,
+                                  feasibility_only=True)[0]
+        self._feas_n += n_ask
+        return np.ascontiguousarray(np.isfinite(J), dtype=np.uint8)
 
     def feasible_sets(self, prefixes, point_sets, ids=None):
         """
@@ -128,50 +187,30 @@ class PrefixSearch:
         ``point_sets[k]`` ((npts, p) arrays; ``ids[k]`` their ``point_ids`` if the caller has
         them)?  One batched launch for the pairs the memo does not hold.
         """
-        if self._feas_n > self.FEAS_MEMO_LIMIT:
-            self.init_search()
-            ids = None
-        memo, mid_of = self._feas, self._mid_of
-        flags = np.ones(len(prefixes), dtype=bool)
-        uniq, where, idx, pts, ask = [], {}, [], [], []
-        for k, q in enumerate(prefixes):
-            known = memo.get(q)
-            if known is None:
-                known = memo[q] = {}
-            vid = ids[k] if ids is not None else self.point_ids(point_sets[k])
-            need = []
-            for t, v in enumerate(vid):
-                r = known.get(v)
-                if r is None:
-                    ends = mid_of.get(v)
-                    if ends is not None and known.get(ends[0]) and known.get(ends[1]):
-                        known[v] = True         # feasible at both ends of the bisected edge
-                        continue
-                    need.append(t)
-                elif not r:
-                    flags[k] = False
-                    break
-            if not flags[k] or not need:
-                continue
-            u = where.get(q)
-            if u is None:
-                u = where[q] = len(uniq)
-                uniq.append(q)
-            ps = np.asarray(point_sets[k], dtype=np.float64).reshape(-1, self.mpc.n_x)
-            for t in need:
-                idx.append(u)
-                pts.append(ps[t])
-                ask.append((k, known, vid[t]))
-        if ask:
-            J = self.solve_points_idx(uniq, np.array(idx, dtype=np.int64), np.array(pts),
-                                      feasibility_only=True)[0]
-            ok = np.isfinite(J)
-            for (k, known, v), good in zip(ask, ok):
-                known[v] = bool(good)
-                if not good:
-                    flags[k] = False
-            self._feas_n += len(ask)
-        return flags
+        n = len(prefixes)
+        flags = np.ones(n, dtype=np.uint8)
+        if not n:
+            return flags.astype(bool)
+        self._forget_if_full()
+        if ids is None:
+            sets = [np.asarray(ps, dtype=np.float64).reshape(-1, self.mpc.n_x)
+                    for ps in point_sets]
+            sizes = [ps.shape[0] for ps in sets]
+            pid = self.point_ids(np.vstack(sets))
+        else:
+            sizes = [len(v) for v in ids]
+            pid = np.ascontiguousarray(np.concatenate(ids), dtype=np.int64)
+        begin = np.zeros(n + 1, dtype=np.int64)
+        np.cumsum(sizes, out=begin[1:])
+        codes = np.fromiter((self._code(q) for q in prefixes), dtype=np.uint64, count=n)
+        n_ask, n_prefix = ctypes.c_int64(), ctypes.c_int64()
+        _capi.check_search(self._lib.ehm_search_query(
+            self._search, n, ptr(codes), ptr(begin), ptr(pid), ptr(flags), ctypes.byref(n_ask),
+            ctypes.byref(n_prefix)))
+        if n_ask.value:
+            ok = self._solve_pending(n_ask.value, n_prefix.value)
+            _capi.check_search(self._lib.ehm_search_answer(self._search, ptr(ok), ptr(flags)))
+        return flags.astype(bool)
 
     def feasible_at_all(self, prefixes, points):
         """For every prefix: is its relaxation feasible at every one of the points?"""
@@ -179,48 +218,45 @@ class PrefixSearch:
             return np.zeros(0, dtype=bool)
         points = np.asarray(points, dtype=np.float64).reshape(-1, self.mpc.n_x)
         vid = self.point_ids(points)
-        return self.feasible_sets(list(prefixes), [points] * len(prefixes),
-                                  [vid] * len(prefixes))
+        return self.feasible_sets(list(prefixes), None, [vid] * len(prefixes))
 
     def first_feasible_many(self, point_sets, excludes=None):
         """
         For every point set: the first mode sequence, in enumeration order, that is feasible at
         every point of it (V_R's canonical answer, lib/oracle.py:175-218), None if there is
         none.  Depth-first in lexicographic order -- a prefix whose relaxation is infeasible at a
-        point is not extended --, all descents in lockstep: one ``feasible_sets`` call per step.
+        point is not extended --, all descents in lockstep (``ehm_search_descent_*``): the native
+        state walks every descent as far as remembered verdicts carry it, and one phase-one
+        launch per step decides the pairs nothing is known about.
         ``excludes[k]``: full sequences to skip (the reference's blacklist, lib/oracle.py:198).
         """
-        n_modes, N = self.mpc.delta_size, self.mpc.N
-        n = len(point_sets)
-        point_sets = [np.asarray(ps, dtype=np.float64).reshape(-1, self.mpc.n_x)
-                      for ps in point_sets]
-        ids = [self.point_ids(ps) for ps in point_sets]
-        excludes = excludes or [()] * n
-        stacks = [[()] for _ in range(n)]
-        out = [None] * n
-        active = list(range(n))
-        while active:
-            kids, sets, vids = [], [], []
-            for j in active:
-                q = stacks[j].pop()
-                for i in range(n_modes):
-                    kids.append(q + (i,))
-                    sets.append(point_sets[j])
-                    vids.append(ids[j])
-            ok = self.feasible_sets(kids, sets, vids)
-            still = []
-            for a, j in enumerate(active):
-                mine = kids[a * n_modes:(a + 1) * n_modes]
-                good = [k for k, g in zip(mine, ok[a * n_modes:(a + 1) * n_modes])
-                        if g and k not in excludes[j]]
-                if good and len(good[0]) == N:
-                    out[j] = good[0]
-                    continue
-                stacks[j].extend(reversed(good))
-                if stacks[j]:
-                    still.append(j)
-            active = still
-        return out
+        n, N = len(point_sets), self.mpc.N
+        if not n:
+            return []
+        self._forget_if_full()
+        sets = [np.asarray(ps, dtype=np.float64).reshape(-1, self.mpc.n_x) for ps in point_sets]
+        begin = np.zeros(n + 1, dtype=np.int64)
+        np.cumsum([ps.shape[0] for ps in sets], out=begin[1:])
+        pid = self.point_ids(np.vstack(sets))
+        ex_begin = ex_codes = None
+        if excludes is not None and any(len(e) for e in excludes):
+            ex_begin = np.zeros(n + 1, dtype=np.int64)
+            np.cumsum([len(e) for e in excludes], out=ex_begin[1:])
+            ex_codes = np.array([self._code(tuple(q)) for e in excludes for q in e],
+                                dtype=np.uint64)
+        _capi.check_search(self._lib.ehm_search_descent_begin(
+            self._search, n, ptr(begin), ptr(pid), ptr(ex_begin), ptr(ex_codes)))
+        n_ask, n_prefix = ctypes.c_int64(), ctypes.c_int64()
+        ok = None
+        while True:
+            _capi.check_search(self._lib.ehm_search_descent_step(
+                self._search, ptr(ok), ctypes.byref(n_ask), ctypes.byref(n_prefix)))
+            if not n_ask.value:
+                break
+            ok = self._solve_pending(n_ask.value, n_prefix.value)
+        seq = np.empty((n, N), dtype=np.int32)
+        _capi.check_search(self._lib.ehm_search_descent_result(self._search, ptr(seq), None))
+        return [tuple(int(i) for i in row) if row[0] >= 0 else None for row in seq]
 
     def first_feasible(self, points, exclude=()):
         """``first_feasible_many`` for one point set."""
@@ -260,6 +296,7 @@ class PrefixTable(PrefixSearch):
         self.init_search()
 
     def close(self):
+        self.close_search()
         self.gp.close()
 
     def set_eps(self, eps_a, eps_r):

@@ -1,0 +1,150 @@
+"""
+The feasibility memo and the lockstep descents of ``sequences.PrefixSearch`` as plain Python dicts
+and lists -- the statement the native bookkeeping (include/ehm_search.h, csrc/ehm_search.cpp)
+replaced.  Test infrastructure: ``tests/test_host_search.py`` runs both on the same solver and
+compares verdicts, sequences and the partition they grow.  (This form solves a pair once per
+SEARCH that asks for it; the native state solves it once per launch.)
+"""
+
+import numpy as np
+
+
+class PyPrefixSearch:
+    """Mix in BEFORE a table class: overrides the memo methods of ``PrefixSearch``."""
+
+    def init_search(self):
+        """State of the feasibility memo (``feasible_sets``); every table calls it once."""
+        self._pid = {}          # parameter point (bytes) -> id
+        self._feas = {}         # prefix -> {point id: phase-one verdict}
+        self._mid_of = {}       # point id of a bisection midpoint -> ids of the edge's ends
+        self._feas_n = 0
+
+    # -- feasibility of (prefix, point) pairs, remembered --------------------------------------
+    # The searches ask the same questions again and again: the children of a node share all but
+    # one of its vertices, and their descents visit the same prefixes.  Phase-one verdicts are
+    # kept per prefix and point (a dict of point ids per prefix); only the pairs nothing is known
+    # about go to the solver.  On the 8-dimensional cell of DESIGN.md section 3.3e that is the
+    # new midpoint of every node -- one vertex in nine.
+    FEAS_MEMO_LIMIT = 3000000
+
+    def point_ids(self, points):
+        """Integer ids of parameter points (by value), the keys of the feasibility memo."""
+        pid = self._pid
+        out = []
+        for pt in np.ascontiguousarray(points, dtype=np.float64).reshape(-1, self.mpc.n_x):
+            key = pt.tobytes()
+            i = pid.get(key)
+            if i is None:
+                i = pid[key] = len(pid)
+            out.append(i)
+        return out
+
+    def register_midpoints(self, mids, ends_a, ends_b):
+        """
+        Tell the memo that ``mids[k]`` is the midpoint of ``ends_a[k]`` and ``ends_b[k]`` (the
+        bisections of the partition): a relaxation feasible at both ends is feasible at the
+        midpoint -- its feasible parameters form a convex set -- and needs no LP there.
+        """
+        mid_of = self._mid_of
+        for m, a, b in zip(self.point_ids(mids), self.point_ids(ends_a), self.point_ids(ends_b)):
+            mid_of[m] = (a, b)
+
+    def feasible_sets(self, prefixes, point_sets, ids=None):
+        """
+        For every k: is the relaxation of ``prefixes[k]`` feasible at EVERY point of
+        ``point_sets[k]`` ((npts, p) arrays; ``ids[k]`` their ``point_ids`` if the caller has
+        them)?  One batched launch for the pairs the memo does not hold.
+        """
+        if self._feas_n > self.FEAS_MEMO_LIMIT:
+            self.init_search()
+            ids = None
+        memo, mid_of = self._feas, self._mid_of
+        flags = np.ones(len(prefixes), dtype=bool)
+        uniq, where, idx, pts, ask = [], {}, [], [], []
+        for k, q in enumerate(prefixes):
+            known = memo.get(q)
+            if known is None:
+                known = memo[q] = {}
+            vid = ids[k] if ids is not None else self.point_ids(point_sets[k])
+            need = []
+            for t, v in enumerate(vid):
+                r = known.get(v)
+                if r is None:
+                    ends = mid_of.get(v)
+                    if ends is not None and known.get(ends[0]) and known.get(ends[1]):
+                        known[v] = True         # feasible at both ends of the bisected edge
+                        continue
+                    need.append(t)
+                elif not r:
+                    flags[k] = False
+                    break
+            if not flags[k] or not need:
+                continue
+            u = where.get(q)
+            if u is None:
+                u = where[q] = len(uniq)
+                uniq.append(q)
+            ps = np.asarray(point_sets[k], dtype=np.float64).reshape(-1, self.mpc.n_x)
+            for t in need:
+                idx.append(u)
+                pts.append(ps[t])
+                ask.append((k, known, vid[t]))
+        if ask:
+            J = self.solve_points_idx(uniq, np.array(idx, dtype=np.int64), np.array(pts),
+                                      feasibility_only=True)[0]
+            ok = np.isfinite(J)
+            for (k, known, v), good in zip(ask, ok):
+                known[v] = bool(good)
+                if not good:
+                    flags[k] = False
+            self._feas_n += len(ask)
+        return flags
+
+    def feasible_at_all(self, prefixes, points):
+        """For every prefix: is its relaxation feasible at every one of the points?"""
+        if not len(prefixes):
+            return np.zeros(0, dtype=bool)
+        points = np.asarray(points, dtype=np.float64).reshape(-1, self.mpc.n_x)
+        vid = self.point_ids(points)
+        return self.feasible_sets(list(prefixes), [points] * len(prefixes),
+                                  [vid] * len(prefixes))
+
+    def first_feasible_many(self, point_sets, excludes=None):
+        """
+        For every point set: the first mode sequence, in enumeration order, that is feasible at
+        every point of it (V_R's canonical answer, lib/oracle.py:175-218), None if there is
+        none.  Depth-first in lexicographic order -- a prefix whose relaxation is infeasible at a
+        point is not extended --, all descents in lockstep: one ``feasible_sets`` call per step.
+        ``excludes[k]``: full sequences to skip (the reference's blacklist, lib/oracle.py:198).
+        """
+        n_modes, N = self.mpc.delta_size, self.mpc.N
+        n = len(point_sets)
+        point_sets = [np.asarray(ps, dtype=np.float64).reshape(-1, self.mpc.n_x)
+                      for ps in point_sets]
+        ids = [self.point_ids(ps) for ps in point_sets]
+        excludes = excludes or [()] * n
+        stacks = [[()] for _ in range(n)]
+        out = [None] * n
+        active = list(range(n))
+        while active:
+            kids, sets, vids = [], [], []
+            for j in active:
+                q = stacks[j].pop()
+                for i in range(n_modes):
+                    kids.append(q + (i,))
+                    sets.append(point_sets[j])
+                    vids.append(ids[j])
+            ok = self.feasible_sets(kids, sets, vids)
+            still = []
+            for a, j in enumerate(active):
+                mine = kids[a * n_modes:(a + 1) * n_modes]
+                good = [k for k, g in zip(mine, ok[a * n_modes:(a + 1) * n_modes])
+                        if g and k not in excludes[j]]
+                if good and len(good[0]) == N:
+                    out[j] = good[0]
+                    continue
+                stacks[j].extend(reversed(good))
+                if stacks[j]:
+                    still.append(j)
+            active = still
+        return out

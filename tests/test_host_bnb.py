@@ -343,7 +343,7 @@ def test_device_table_bookkeeping_on_a_stub(monkeypatch):
     # a full memo is dropped and rebuilt: same answers
     table.FEAS_MEMO_LIMIT = -1
     assert table.first_feasible(R) == seq and table.lp_solves > before
-    assert len(table._feas) > 0 and table._feas_n > 0
+    assert table.search_counts()[0] > 0 and table._feas_n > 0
     table.close()
 
 

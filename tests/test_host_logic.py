@@ -32,6 +32,13 @@ def test_library_exports_every_declared_symbol():
                          capture_output=True, text=True).stdout
     for name in declared:
         assert re.search(r'\bT %s\b' % name, out), name
+    # the host bookkeeping of the prefix searches (include/ehm_search.h), same library
+    header = open(os.path.join(ROOT, 'include', 'ehm_search.h')).read()
+    declared = set(re.findall(r'\b(ehm_search_[a-z_]+)\s*\(', header))
+    assert declared == set(_capi.EXPORTED_SEARCH), declared ^ set(_capi.EXPORTED_SEARCH)
+    for name in declared:
+        assert hasattr(lib, name), name
+        assert re.search(r'\bT %s\b' % name, out), name
 
 
 def test_no_cpu_fallback_without_a_gpu():

@@ -1,0 +1,214 @@
+"""
+The native bookkeeping of the prefix searches (include/ehm_search.h, csrc/ehm_search.cpp: point
+ids, the memo of phase-one verdicts with midpoint inference, one problem per pair and launch, the
+lockstep descents of V_R) -- host code, so it is tested here without a device:
+
+  * on a synthetic solver whose feasible sets are intersections of half-spaces (convex, shrinking
+    with the prefix, like the relaxations'), against brute-force enumeration;
+  * against the plain-Python statement it replaced (tests/prefix_search_py.py) on the HiGHS
+    stand-in of the table, search by search and on the tree the driver grows.
+"""
+
+import ctypes
+import itertools
+
+import numpy as np
+import pytest
+
+from explicit_hybrid_mpc_amd import _capi, bnb, bnb_frontier, examples, sequences
+from explicit_hybrid_mpc_amd._capi import ptr
+from explicit_hybrid_mpc_amd.tree import Tree, NodeData
+from oracle import prefix_bb
+from tests import helpers
+from tests.prefix_search_py import PyPrefixSearch
+from tests.test_host_bnb import _host_split_batch
+
+
+class _Shape:
+    def __init__(self, n_x, delta_size, N):
+        self.n_x, self.delta_size, self.N, self.n_u = n_x, delta_size, N, 1
+
+
+class HalfSpaceTable(sequences.PrefixSearch):
+    """Prefix q is feasible at theta iff  a[i, q_i] . theta <= b[i, q_i]  for every i < len(q)."""
+
+    def __init__(self, n_x=3, delta_size=3, N=4, seed=0):
+        self.mpc = _Shape(n_x, delta_size, N)
+        rng = np.random.default_rng(seed)
+        self.a = rng.normal(size=(N, delta_size, n_x))
+        self.b = rng.uniform(-0.2, 1.2, size=(N, delta_size))
+        self.asked = []
+        self.init_search()
+
+    def feasible(self, q, theta):
+        return all(self.a[i, d] @ theta <= self.b[i, d] for i, d in enumerate(q))
+
+    def solve_points(self, prefixes, thetas, feasibility_only=False):
+        thetas = np.asarray(thetas).reshape(len(prefixes), -1)
+        J = np.full(len(prefixes), np.inf)
+        for k, q in enumerate(prefixes):
+            self.asked.append((tuple(q), thetas[k].tobytes()))
+            if self.feasible(q, thetas[k]):
+                J[k] = 0.
+        return J, np.zeros((len(prefixes), 1))
+
+    def brute_first(self, points, exclude=()):
+        for q in itertools.product(range(self.mpc.delta_size), repeat=self.mpc.N):
+            if q not in exclude and all(self.feasible(q, th) for th in points):
+                return q
+        return None
+
+
+def test_descents_against_enumeration_and_every_pair_solved_once():
+    tab = HalfSpaceTable()
+    rng = np.random.default_rng(1)
+    sets = [rng.uniform(-0.5, 0.5, (4, 3)) * rng.uniform(0.05, 1.) + rng.uniform(-0.3, 0.3, 3)
+            for _ in range(60)]
+    sets += [sets[0].copy(), sets[1][:2].copy()]          # shared points, a ragged set
+    got = tab.first_feasible_many(sets)
+    want = [tab.brute_first(s) for s in sets]
+    assert got == want
+    assert sum(q is not None for q in want) >= 10 and any(q is None for q in want)
+    # nothing was solved twice, although set 0 and its copy descend side by side
+    assert len(tab.asked) == len(set(tab.asked))
+    held, points, handed, shared = tab.search_counts()
+    assert handed == len(tab.asked) and shared > 0 and points == len({p.tobytes() for s in sets for p in s})
+    # a second pass costs nothing
+    n = len(tab.asked)
+    assert tab.first_feasible_many(sets) == want and len(tab.asked) == n
+    # the blacklist (lib/oracle.py:198): skip the first answers
+    have = [k for k, q in enumerate(want) if q is not None][:8]
+    excl = [[want[k]] if k in have else [] for k in range(len(sets))]
+    again = tab.first_feasible_many(sets, excl)
+    for k in range(len(sets)):
+        assert again[k] == tab.brute_first(sets[k], exclude=set(excl[k]))
+    assert all(again[k] != want[k] for k in have)
+    tab.close_search()
+
+
+def test_feasible_sets_and_midpoint_inference():
+    tab = HalfSpaceTable(seed=3)
+    rng = np.random.default_rng(4)
+    prefixes = [q for k in range(1, 4) for q in itertools.product(range(3), repeat=k)]
+    ends_a = rng.uniform(-0.4, 0.4, (30, 3))
+    ends_b = rng.uniform(-0.4, 0.4, (30, 3))
+    pick = [prefixes[k] for k in rng.integers(0, len(prefixes), 200)]
+    sets = [np.array([ends_a[k], ends_b[k]]) for k in rng.integers(0, 30, 200)]
+    flags = tab.feasible_sets(pick, sets)
+    assert np.array_equal(flags, [all(tab.feasible(q, th) for th in s) for q, s in zip(pick, sets)])
+    assert flags.any() and not flags.all()
+    # midpoints of edges whose ends are both known feasible need no problem
+    mids = 0.5 * (ends_a + ends_b)
+    tab.register_midpoints(mids, ends_a, ends_b)
+    n = len(tab.asked)
+    mid_sets = [0.5 * (s[0] + s[1])[None] for s in sets]
+    f2 = tab.feasible_sets(pick, mid_sets)
+    assert np.array_equal(f2, [tab.feasible(q, s[0]) for q, s in zip(pick, mid_sets)])
+    solved = {(q, th) for q, th in tab.asked[n:]}
+    for q, s, ms, ok in zip(pick, sets, mid_sets, flags):
+        if ok:                                          # both ends feasible: inferred
+            assert (q, ms[0].tobytes()) not in solved
+    assert all(f2[k] for k in np.flatnonzero(flags))
+    # ids given by the caller are the ids of the values
+    ids = [tab.point_ids(s) for s in sets]
+    assert np.array_equal(tab.feasible_sets(pick, None, ids), flags) and len(tab.asked) == n + len(solved)
+    # forgetting drops the verdicts, not the ids or the midpoints
+    tab.FEAS_MEMO_LIMIT = -1
+    assert np.array_equal(tab.feasible_sets(pick, None, ids), flags)
+    assert tab.search_counts()[0] > 0 and len(tab.asked) > n + len(solved)
+    tab.close_search()
+
+
+def test_protocol_errors_are_reported():
+    lib = _capi.load()
+    h = ctypes.c_void_p()
+    assert lib.ehm_search_create(8, 5, 12, ctypes.byref(h)) == _capi.EHM_E_INVALID     # 6^12 > 2^26
+    assert b'2^26' in lib.ehm_search_last_error()
+    assert lib.ehm_search_create(9, 2, 3, ctypes.byref(h)) == _capi.EHM_E_INVALID      # p > EHM_MAX_P
+    _capi.check_search(lib.ehm_search_create(2, 2, 3, ctypes.byref(h)))
+    pts = np.array([[0., 0.], [1., 0.], [0., 0.]])
+    ids = np.empty(3, dtype=np.int64)
+    _capi.check_search(lib.ehm_search_point_ids(h, 3, ptr(pts), ptr(ids)))
+    assert list(ids) == [0, 1, 0]
+    codes = np.array([1, 2], dtype=np.uint64)
+    begin = np.array([0, 2, 3], dtype=np.int64)
+    pid = np.array([0, 1, 1], dtype=np.int64)
+    flags = np.zeros(2, dtype=np.uint8)
+    na, npre = ctypes.c_int64(), ctypes.c_int64()
+    bad = np.array([0, 7, 1], dtype=np.int64)
+    assert lib.ehm_search_query(h, 2, ptr(codes), ptr(begin), ptr(bad), ptr(flags),
+                                ctypes.byref(na), ctypes.byref(npre)) == _capi.EHM_E_INVALID
+    big = np.array([1, 27], dtype=np.uint64)                                            # 27 = 3^3
+    assert lib.ehm_search_query(h, 2, ptr(big), ptr(begin), ptr(pid), ptr(flags),
+                                ctypes.byref(na), ctypes.byref(npre)) == _capi.EHM_E_INVALID
+    _capi.check_search(lib.ehm_search_query(h, 2, ptr(codes), ptr(begin), ptr(pid), ptr(flags),
+                                            ctypes.byref(na), ctypes.byref(npre)))
+    assert (na.value, npre.value) == (3, 2) and list(flags) == [1, 1]
+    # a second question, a descent or forgetting while the pairs are pending: refused
+    assert lib.ehm_search_query(h, 2, ptr(codes), ptr(begin), ptr(pid), ptr(flags),
+                                ctypes.byref(na), ctypes.byref(npre)) == _capi.EHM_E_INVALID
+    assert lib.ehm_search_forget(h) == _capi.EHM_E_INVALID
+    assert lib.ehm_search_descent_begin(h, 1, ptr(begin), ptr(pid), None, None) == _capi.EHM_E_INVALID
+    pc, pi, th = np.empty(2, dtype=np.uint64), np.empty(3, dtype=np.int64), np.empty((3, 2))
+    _capi.check_search(lib.ehm_search_asks(h, ptr(pc), ptr(pi), ptr(th)))
+    assert list(pc) == [1, 2] and list(pi) == [0, 0, 1] and np.array_equal(th, pts[[0, 1, 1]])
+    ok = np.array([1, 0, 1], dtype=np.uint8)
+    _capi.check_search(lib.ehm_search_answer(h, ptr(ok), ptr(flags)))
+    assert list(flags) == [0, 1]
+    assert lib.ehm_search_answer(h, ptr(ok), ptr(flags)) == _capi.EHM_E_INVALID          # nothing pending
+    # descents: a result before they are finished is refused
+    _capi.check_search(lib.ehm_search_descent_begin(h, 1, ptr(begin), ptr(pid), None, None))
+    _capi.check_search(lib.ehm_search_descent_step(h, None, ctypes.byref(na), ctypes.byref(npre)))
+    assert na.value > 0
+    seq = np.empty((1, 3), dtype=np.int32)
+    assert lib.ehm_search_descent_result(h, ptr(seq), None) == _capi.EHM_E_INVALID
+    assert lib.ehm_search_descent_step(h, None, ctypes.byref(na), ctypes.byref(npre)) == _capi.EHM_E_INVALID
+    while na.value:
+        v = np.ones(na.value, dtype=np.uint8)
+        _capi.check_search(lib.ehm_search_descent_step(h, ptr(v), ctypes.byref(na), ctypes.byref(npre)))
+    _capi.check_search(lib.ehm_search_descent_result(h, ptr(seq), None))
+    # prefix (0,) was answered infeasible at point 1 above and is remembered: mode 1 first
+    assert list(seq[0]) == [1, 0, 0]
+    lib.ehm_search_destroy(h)
+
+
+class _PyTable(PyPrefixSearch, prefix_bb.CpuPrefixTable):
+    """The HiGHS stand-in of the table with the plain-Python memo and descents."""
+
+
+def test_native_bookkeeping_equals_the_python_statement_on_the_cpu_table():
+    mpc = helpers.make_instance('pwa_small', 0)
+    eps_a = helpers.eps_a_rule(mpc, 0.25)
+    nat = bnb.PrefixOracle(mpc, eps_a, 0.2, table=prefix_bb.CpuPrefixTable(mpc))
+    py = bnb.PrefixOracle(mpc, eps_a, 0.2, table=_PyTable(mpc))
+    assert not hasattr(py.table, '_search') and nat.table._search
+    rng = np.random.default_rng(5)
+    Rs = [np.array(R) for R in helpers.random_simplices(mpc, rng, 12, scale_lo=-1.5)]
+    a = nat.table.first_feasible_many(Rs + Rs[:3])
+    b = py.table.first_feasible_many(Rs + Rs[:3])
+    assert a == b and any(q is not None for q in a)
+    assert nat.table.lp_solves < py.table.lp_solves          # shared pairs are solved once
+    # the frontier-wide driver on both: the same tree
+    roots, _ = helpers.roots_of(mpc)
+    trees = []
+    for orc in (nat, py):
+        ts = [Tree(NodeData(vertices=np.array(R))) for R in roots]
+        stats = bnb_frontier.grow_frontier(orc, ts, 'ecc', handoff=False,
+                                           split_batch=_host_split_batch)
+        assert not stats['truncated']
+        trees.append(ts)
+    n = 0
+    for t1, t2 in zip(*trees):
+        w1, w2 = list(t1.walk()), list(t2.walk())
+        assert [loc for _, loc in w1] == [loc for _, loc in w2]
+        for (n1, _), (n2, _) in zip(w1, w2):
+            n += 1
+            assert np.array_equal(n1.data.vertices, n2.data.vertices)
+            assert n1.data.is_epsilon_suboptimal == n2.data.is_epsilon_suboptimal
+            c1, c2 = getattr(n1.data, 'commutation', None), getattr(n2.data, 'commutation', None)
+            assert (c1 is None) == (c2 is None)
+            if c1 is not None:
+                assert np.array_equal(c1, c2)
+                assert np.allclose(n1.data.vertex_costs, n2.data.vertex_costs, rtol=1e-9, atol=1e-10)
+    assert n > len(roots)
+    assert nat.table.lp_solves < py.table.lp_solves
