@@ -330,9 +330,11 @@ def grow_frontier(oracle, branch, action='ecc', table_max=256, max_visits=None, 
         oracle.table, 'device', 0)))
     mpc = oracle.mpc
     stats = dict(host_visits=0, rounds=0, handoffs=0, handoff_nodes=0, handoff_leaves=0,
-                 table_sizes=[], tables_too_large=0, truncated=False)
+                 table_sizes=[], tables_too_large=0, truncated=False, witness_hits=0)
     # one Tree or a list of them (the Delaunay roots of the set: their nodes share the rounds)
-    work = [(b, action) for b in (branch if isinstance(branch, (list, tuple)) else [branch])]
+    # work items: (node, action, witness) -- the witness of an ecc node is a mode sequence that was
+    # feasible at its parent's barycentre (None at a root)
+    work = [(b, action, None) for b in (branch if isinstance(branch, (list, tuple)) else [branch])]
     while work:
         if max_visits is not None and stats['host_visits'] >= max_visits:
             stats['truncated'] = True
@@ -341,31 +343,44 @@ def grow_frontier(oracle, branch, action='ecc', table_max=256, max_visits=None, 
                                                        max_visits - stats['host_visits'])
         batch, work = work[:cap], work[cap:]
         stats['rounds'] += 1
-        ecc = [nd for nd, act in batch if act == 'ecc']
-        lcss = [nd for nd, act in batch if act != 'ecc']
+        ecc = [nd for nd, act, _ in batch if act == 'ecc']
+        witness = [wit for _, act, wit in batch if act == 'ecc']
+        lcss = [nd for nd, act, _ in batch if act != 'ecc']
         stats['host_visits'] += len(ecc) + len(lcss)
         if log:
             log('round %d: %d ecc + %d lcss nodes, %d waiting' %
                 (stats['rounds'], len(ecc), len(lcss), len(work)))
-        to_split = []                       # (node, commutation or None, costs, inputs)
+        to_split = []       # (node, commutation, costs, inputs) or (ecc node, None, None, witness)
         if ecc:                             # lib/worker.py:241-283
             Rs = [np.asarray(nd.data.vertices, dtype=np.float64) for nd in ecc]
             oracle.calls['V_R'] += len(ecc)
             found = first_feasible_many(oracle.table, Rs)
             # lib/worker.py:264-266 checks the barycentre first; a sequence feasible at every
             # vertex is feasible there too (its feasible set is convex), so only the cells V_R
-            # finds nothing for need the check
+            # finds nothing for need the check.  It asks whether ANY sequence is feasible at the
+            # barycentre: the one that was at the parent's barycentre is tried first (one
+            # problem), the lexicographic descent runs only where that one fails.
             none = [k for k, s in enumerate(found) if s is None]
             oracle.calls['P_theta'] += len(none)
-            if any(s is None for s in first_feasible_many(
-                    oracle.table, [np.average(Rs[k], axis=0)[None] for k in none])):
+            bary = [np.average(Rs[k], axis=0)[None] for k in none]
+            tried = [i for i, k in enumerate(none) if witness[k] is not None]
+            held = np.zeros(len(none), dtype=bool)
+            if tried:
+                held[tried] = oracle.table.feasible_sets([witness[none[i]] for i in tried],
+                                                         [bary[i] for i in tried])
+            stats['witness_hits'] += int(held.sum())
+            miss = [i for i in range(len(none)) if not held[i]]
+            fresh = first_feasible_many(oracle.table, [bary[i] for i in miss])
+            if any(s is None for s in fresh):
                 raise RuntimeError('STOP, Theta contains infeasible regions')
+            for i, s in zip(miss, fresh):
+                witness[none[i]] = s
             have = [k for k, s in enumerate(found) if s is not None]
             if have:
                 nv = Rs[0].shape[0]
-                Jv, uv = oracle.table.solve_points([found[k] for k in have for _ in range(nv)],
-                                                   np.vstack([Rs[k] for k in have]))
-                Jv, uv = Jv.reshape(len(have), nv), uv.reshape(len(have), nv, -1)
+                # the descents have just established feasibility at every vertex: no phase one;
+                # an optimum a neighbouring cell has computed already is not computed again
+                Jv, uv = oracle.table.optima_at([found[k] for k in have], [Rs[k] for k in have])
             for w, k in enumerate(have):
                 if not np.all(np.isfinite(Jv[w])):      # lib/oracle.py:214-218: blacklist, retry
                     oracle.calls['V_R'] -= 1
@@ -377,8 +392,8 @@ def grow_frontier(oracle, branch, action='ecc', table_max=256, max_visits=None, 
                     delta = oracle.delta_of(found[k])
                     vx = [(uv[w, i].copy(), float(Jv[w, i]), 0.) for i in range(nv)]
                 _set_record(ecc[k].data, delta, vx)
-                work.append((ecc[k], 'lcss'))
-            to_split += [(ecc[k], None, None, None) for k, s in enumerate(found) if s is None]
+                work.append((ecc[k], 'lcss', None))
+            to_split += [(ecc[k], None, None, witness[k]) for k, s in enumerate(found) if s is None]
         if lcss:                            # lib/worker.py:340-417
             Rs = [np.asarray(nd.data.vertices, dtype=np.float64) for nd in lcss]
             Vs = [np.asarray(nd.data.vertex_costs, dtype=np.float64) for nd in lcss]
@@ -404,7 +419,7 @@ def grow_frontier(oracle, branch, action='ecc', table_max=256, max_visits=None, 
                 if small:                   # lib/worker.py:396-401
                     data.commutation, data.vertex_costs, data.vertex_inputs = (delta_star, costs,
                                                                                 inputs)
-                    work.append((lcss[k], 'lcss'))
+                    work.append((lcss[k], 'lcss', None))
                 else:
                     to_split.append((lcss[k], delta_star, costs, inputs))
         if to_split:
@@ -417,8 +432,11 @@ def grow_frontier(oracle, branch, action='ecc', table_max=256, max_visits=None, 
             with_data = [k for k, item in enumerate(to_split) if item[1] is not None]
             if with_data:
                 mids = np.array([S1[k][ij[k][0]] for k in with_data])
-                Jm, um = oracle.table.solve_points(
-                    [oracle.sequence_of(to_split[k][1]) for k in with_data], mids)
+                # feasible at both ends of the edge, so feasible at its midpoint: no phase one;
+                # the cells around an edge that hold the same commutation share the optimum
+                Jm, um = oracle.table.optima_at(
+                    [oracle.sequence_of(to_split[k][1]) for k in with_data], mids[:, None, :])
+                Jm, um = Jm[:, 0], um[:, 0]
             for w, k in enumerate(with_data):
                 nd, delta, costs, inputs = to_split[k]
                 i, j = int(ij[k][0]), int(ij[k][1])
@@ -431,11 +449,11 @@ def grow_frontier(oracle, branch, action='ecc', table_max=256, max_visits=None, 
                                  vertex_inputs=in_1),
                         NodeData(vertices=S2[k].copy(), commutation=delta, vertex_costs=co_2,
                                  vertex_inputs=in_2))
-                work.append((nd.left, 'lcss'))
-                work.append((nd.right, 'lcss'))
-            for k, (nd, delta, _, _) in enumerate(to_split):
+                work.append((nd.left, 'lcss', None))
+                work.append((nd.right, 'lcss', None))
+            for k, (nd, delta, _, wit) in enumerate(to_split):
                 if delta is None:
                     nd.grow(NodeData(vertices=S1[k].copy()), NodeData(vertices=S2[k].copy()))
-                    work.append((nd.left, 'ecc'))
-                    work.append((nd.right, 'ecc'))
+                    work.append((nd.left, 'ecc', wit))
+                    work.append((nd.right, 'ecc', wit))
     return stats

@@ -114,10 +114,11 @@ class PrefixSearch:
         _capi.check_search(self._lib.ehm_search_counts(self._search, ptr(out)))
         return tuple(int(v) for v in out)
 
-    def solve_points_idx(self, uniq, idx, thetas, feasibility_only=False):
+    def solve_points_idx(self, uniq, idx, thetas, feasibility_only=False, known_feasible=False):
         """``solve_points`` with the prefixes given as indices into the list ``uniq`` (the device
         table turns them into slots without touching the pairs one by one)."""
-        return self.solve_points([uniq[i] for i in idx], thetas, feasibility_only)
+        return self.solve_points([uniq[i] for i in idx], thetas, feasibility_only,
+                                 known_feasible=known_feasible)
 
     def min_cost_on(self, prefixes, simplices):
         """
@@ -131,6 +132,47 @@ class PrefixSearch:
         pairs = [q for q in prefixes for _ in range(ns)]
         J = self.solve_min(pairs, np.tile(simplices, (len(prefixes), 1, 1)))
         return J.reshape(len(prefixes), ns).min(axis=1)
+
+    OPTIMA_MEMO_LIMIT = 2000000
+
+    def optima_at(self, sequences, point_sets):
+        """
+        (J [n, nv], u0 [n, nv, n_u]): optimal cost and first input of full sequence k at every
+        point of set k ((nv, p) arrays), for pairs the caller KNOWS to be feasible (see
+        ``solve_points``).  An optimum is a function of the sequence and the point: it is
+        computed once and remembered by (sequence, point id) -- the cells of a partition share
+        their vertices, and neighbours that adopt the same sequence ask for the same optima.
+        """
+        n = len(sequences)
+        sets = np.asarray(point_sets, dtype=np.float64).reshape(n, -1, self.mpc.n_x)
+        nv = sets.shape[1]
+        J = np.empty((n, nv))
+        u0 = np.empty((n, nv, self.mpc.n_u))
+        if not n:
+            return J, u0
+        memo = self.__dict__.setdefault('_optima', {})      # (sequence, point id) -> (J, u0)
+        if len(memo) > self.OPTIMA_MEMO_LIMIT:
+            memo.clear()
+        pid = np.asarray(self.point_ids(sets.reshape(-1, self.mpc.n_x))).reshape(n, nv)
+        keys = [[(self._code(tuple(q)) << 38) | int(v) for v in row]
+                for q, row in zip(sequences, pid)]
+        missing = {}
+        for k, row in enumerate(keys):
+            for t, key in enumerate(row):
+                if key not in memo and key not in missing:
+                    missing[key] = (k, t)
+        if missing:
+            rows = np.array(list(missing.values()), dtype=np.int64)
+            Ja, ua = self.solve_points([tuple(sequences[k]) for k in rows[:, 0]],
+                                       sets[rows[:, 0], rows[:, 1]], known_feasible=True)
+            for a, key in enumerate(missing):
+                memo[key] = (float(Ja[a]), ua[a].copy())
+        for k, row in enumerate(keys):
+            for t, key in enumerate(row):
+                J[k, t], u0[k, t] = memo[key]
+        self.optima_solved = getattr(self, 'optima_solved', 0) + len(missing)
+        self.optima_asked = getattr(self, 'optima_asked', 0) + n * nv
+        return J, u0
 
     def vertex_costs(self, sequence, points):
         """Optimal cost of one full sequence at every point (+inf where infeasible)."""
@@ -340,7 +382,7 @@ class PrefixTable(PrefixSearch):
             yield idx, self._ensure([prefixes[k] for k in idx])
 
     # -- pair solvers -------------------------------------------------------------------------
-    def solve_points_idx(self, uniq, idx, thetas, feasibility_only=False):
+    def solve_points_idx(self, uniq, idx, thetas, feasibility_only=False, known_feasible=False):
         idx = np.asarray(idx, dtype=np.int64)
         thetas = np.asarray(thetas, dtype=np.float64).reshape(idx.size, -1)
         J = np.full(idx.size, np.inf)
@@ -352,34 +394,38 @@ class PrefixTable(PrefixSearch):
             if not sel.size:
                 continue
             slot = self._ensure(part)[idx[sel] - c0]
+            self._solve_chunk(sel, slot, thetas, J, u0, feasibility_only, known_feasible)
+        return J, u0
+
+    def _solve_chunk(self, sel, slot, thetas, J, u0, feasibility_only, known_feasible):
+        """Phase one, then the optimum where it is feasible, of the pairs ``sel`` (their
+        prefixes loaded in ``slot``); with ``known_feasible`` phase one is not run."""
+        if known_feasible:
+            ok = np.ones(sel.size, dtype=bool)
+        else:
             tau = self.gp.point_idx(thetas[sel], slot, feas=True)[0]
             self.lp_solves += sel.size
             ok = tau <= FEAS_TOL
-            if feasibility_only:
-                J[sel[ok]] = 0.
-            elif ok.any():
-                Jk, uk, _ = self.gp.point_idx(thetas[sel[ok]], slot[ok])
-                self.lp_solves += int(ok.sum())
-                J[sel[ok]] = Jk
-                u0[sel[ok]] = uk
-        return J, u0
+        if feasibility_only:
+            J[sel[ok]] = 0.
+        elif ok.any():
+            Jk, uk, _ = self.gp.point_idx(thetas[sel[ok]], slot[ok])
+            self.lp_solves += int(ok.sum())
+            J[sel[ok]] = Jk
+            u0[sel[ok]] = uk
 
-    def solve_points(self, prefixes, thetas, feasibility_only=False):
-        """(J, u0): optimal cost (+inf: infeasible) and first input of prefix k at point k."""
+    def solve_points(self, prefixes, thetas, feasibility_only=False, known_feasible=False):
+        """
+        (J, u0): optimal cost (+inf: infeasible) and first input of prefix k at point k.
+        ``known_feasible``: the caller holds a proof that every pair is feasible -- a remembered
+        phase-one verdict, or convexity (the point is a convex combination of points the prefix
+        is feasible at) -- and phase one, which would only repeat it, is skipped.
+        """
         thetas = np.asarray(thetas, dtype=np.float64).reshape(len(prefixes), -1)
         J = np.full(len(prefixes), np.inf)
         u0 = np.zeros((len(prefixes), self.mpc.n_u))
         for idx, slot in self._chunks(prefixes):
-            tau = self.gp.point_idx(thetas[idx], slot, feas=True)[0]
-            self.lp_solves += idx.size
-            ok = tau <= FEAS_TOL
-            if feasibility_only:
-                J[idx[ok]] = 0.
-            elif ok.any():
-                Jk, uk, _ = self.gp.point_idx(thetas[idx[ok]], slot[ok])
-                self.lp_solves += int(ok.sum())
-                J[idx[ok]] = Jk
-                u0[idx[ok]] = uk
+            self._solve_chunk(idx, slot, thetas, J, u0, feasibility_only, known_feasible)
         return J, u0
 
     def solve_min(self, prefixes, simplices):

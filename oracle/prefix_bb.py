@@ -222,7 +222,8 @@ class CpuPrefixTable(_prefix_search_base()):
             self._models[prefix] = PrefixModel(self.mpc, prefix)
         return self._models[prefix]
 
-    def solve_points(self, prefixes, thetas, feasibility_only=False):
+    def solve_points(self, prefixes, thetas, feasibility_only=False, known_feasible=False):
+        # (known_feasible: the device table skips its phase-one launch; here one LP says both)
         thetas = np.asarray(thetas, dtype=np.float64).reshape(len(prefixes), -1)
         J = np.full(len(prefixes), np.inf)
         u0 = np.zeros((len(prefixes), self.mpc.n_u))

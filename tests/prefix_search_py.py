@@ -18,6 +18,7 @@ class PyPrefixSearch:
         self._feas = {}         # prefix -> {point id: phase-one verdict}
         self._mid_of = {}       # point id of a bisection midpoint -> ids of the edge's ends
         self._feas_n = 0
+        self._code_of, self._prefix_of = {(): 0}, {0: ()}      # (PrefixSearch._code, optima_at)
 
     # -- feasibility of (prefix, point) pairs, remembered --------------------------------------
     # The searches ask the same questions again and again: the children of a node share all but

@@ -43,7 +43,7 @@ class HalfSpaceTable(sequences.PrefixSearch):
     def feasible(self, q, theta):
         return all(self.a[i, d] @ theta <= self.b[i, d] for i, d in enumerate(q))
 
-    def solve_points(self, prefixes, thetas, feasibility_only=False):
+    def solve_points(self, prefixes, thetas, feasibility_only=False, known_feasible=False):
         thetas = np.asarray(thetas).reshape(len(prefixes), -1)
         J = np.full(len(prefixes), np.inf)
         for k, q in enumerate(prefixes):

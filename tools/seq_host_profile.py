@@ -108,6 +108,7 @@ class PooledStubProblem:
     busy = 0.
     launches = 0
     problems = 0
+    by_kind = {}
 
     def __init__(self, can, eps_a, eps_r, device=0):
         self.can = can
@@ -152,6 +153,8 @@ class PooledStubProblem:
         PooledStubProblem.busy += time.perf_counter() - t
         PooledStubProblem.launches += 1
         PooledStubProblem.problems += n
+        kind = 'point phase one' if feas else 'point optimum'
+        PooledStubProblem.by_kind[kind] = PooledStubProblem.by_kind.get(kind, 0) + n
         return J, u0, np.zeros(n, dtype=np.int32)
 
     def simplex_idx(self, R, slot, mode, Vbar=None):
@@ -169,6 +172,8 @@ class PooledStubProblem:
         PooledStubProblem.busy += time.perf_counter() - t
         PooledStubProblem.launches += 1
         PooledStubProblem.problems += n
+        kind = ('simplex min', 'simplex slack', 'simplex phase one')[mode]
+        PooledStubProblem.by_kind[kind] = PooledStubProblem.by_kind.get(kind, 0) + n
         return obj, alpha, np.zeros(n, dtype=np.int32)
 
 
@@ -219,6 +224,7 @@ def main():
     orc.eps_a, orc.eps_r = 0.5 * max(J), 1.0
     orc.table.set_eps(orc.eps_a, 1.0)
     PooledStubProblem.busy = 0.
+    PooledStubProblem.by_kind = {}
     t0 = time.perf_counter()
     branch = Tree(NodeData(vertices=R.copy()))
     run = lambda: bnb_frontier.grow_frontier(
@@ -242,6 +248,7 @@ def main():
               PooledStubProblem.launches, orc.table.blocks_loaded, wall, PooledStubProblem.busy,
               wall - PooledStubProblem.busy,
               1e6 * (wall - PooledStubProblem.busy) / max(stats['host_visits'], 1)), flush=True)
+    print('problems by kind', PooledStubProblem.by_kind, 'oracle calls', dict(orc.calls), flush=True)
     orc.close()
 
 
