@@ -44,7 +44,7 @@ EXPORTED_SEARCH = [
     'ehm_search_create', 'ehm_search_destroy', 'ehm_search_last_error', 'ehm_search_point_ids',
     'ehm_search_register_midpoints', 'ehm_search_forget', 'ehm_search_counts',
     'ehm_search_query', 'ehm_search_asks', 'ehm_search_answer', 'ehm_search_descent_begin',
-    'ehm_search_descent_step', 'ehm_search_descent_result',
+    'ehm_search_descent_step', 'ehm_search_descent_result', 'ehm_search_peek',
 ]
 
 
@@ -192,6 +192,7 @@ def load(build_if_missing=True):
     lib.ehm_search_query.argtypes = [vp, i64, vp, vp, vp, vp, ctypes.POINTER(i64),
                                      ctypes.POINTER(i64)]
     lib.ehm_search_asks.argtypes = [vp, vp, vp, vp]
+    lib.ehm_search_peek.argtypes = [vp, i64, vp, vp, vp]
     lib.ehm_search_answer.argtypes = [vp, vp, vp]
     lib.ehm_search_descent_begin.argtypes = [vp, i64, vp, vp, vp, vp]
     lib.ehm_search_descent_step.argtypes = [vp, vp, ctypes.POINTER(i64), ctypes.POINTER(i64)]

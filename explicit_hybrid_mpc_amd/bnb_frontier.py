@@ -123,7 +123,8 @@ def bar_e_many(oracle, Rs, Vs):
             pre.extend(kids)
             Rp.extend([Rs[j]] * len(kids))
             Vp.extend([Vs[j]] * len(kids))
-        t, _ = table.solve_slack(pre, np.array(Rp), np.array(Vp))
+        Rp = np.array(Rp)
+        t, _ = table.solve_slack(pre, Rp, np.array(Vp), table.feasible_somewhere(pre, Rp))
         pos, still = 0, []
         for j in active:
             kids = kid_of[j]
@@ -180,7 +181,8 @@ def bar_d_many(oracle, Rs, Vs, deltas_ref):
             pre.extend(kids)
             Rp.extend([Rs[j]] * len(kids))
             Vp.extend([Vs[j]] * len(kids))
-        t, alpha = table.solve_slack(pre, np.array(Rp), np.array(Vp))
+        Ra = np.array(Rp)
+        t, alpha = table.solve_slack(pre, Ra, np.array(Vp), table.feasible_somewhere(pre, Ra))
         # feasibility at every vertex, for the prefixes whose slack bound is not negative
         live = np.flatnonzero(t >= 0.)
         if live.size:

@@ -352,6 +352,33 @@ static int check_sets(const ehm_search* s, const char* who, int64_t n_sets, cons
     return EHM_OK;
 }
 
+int ehm_search_peek(ehm_search* s, int64_t n, const uint64_t* code, const int64_t* point_id,
+                    int8_t* verdict) {
+    if (!s || n < 0 || (n && (!code || !point_id || !verdict)))
+        return fail(EHM_E_INVALID, "ehm_search_peek: bad argument");
+    const int64_t np_ = (int64_t)s->mid_a.size();
+    const uint64_t top = s->pw[s->N];
+    try {
+        for (int64_t k = 0; k < n; ++k) {
+            const int64_t v = point_id[k];
+            if (code[k] >= top || v < 0 || v >= np_)
+                return fail(EHM_E_INVALID, "ehm_search_peek: unknown prefix code or point id");
+            const int32_t r = s->memo.get(s->key_of(code[k], v));
+            if (r == 0 || r == 1) { verdict[k] = (int8_t)r; continue; }
+            verdict[k] = -1;
+            const int64_t a = s->mid_a[v];
+            if (r < 0 && a >= 0 && s->memo.get(s->key_of(code[k], a)) == 1 &&
+                s->memo.get(s->key_of(code[k], s->mid_b[v])) == 1) {
+                s->memo.put(s->key_of(code[k], v), 1);
+                verdict[k] = 1;
+            }
+        }
+    } catch (const std::bad_alloc&) {
+        return fail(EHM_E_CAPACITY, "ehm_search_peek: out of memory");
+    }
+    return EHM_OK;
+}
+
 int ehm_search_query(ehm_search* s, int64_t n_sets, const uint64_t* code, const int64_t* set_begin,
                      const int64_t* point_id, uint8_t* flags, int64_t* n_ask, int64_t* n_prefix) {
     if (!s || n_sets < 0 || !set_begin || !n_ask || !n_prefix || (n_sets && (!code || !flags)))

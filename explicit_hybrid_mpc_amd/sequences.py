@@ -254,6 +254,35 @@ class PrefixSearch:
             _capi.check_search(self._lib.ehm_search_answer(self._search, ptr(ok), ptr(flags)))
         return flags.astype(bool)
 
+    def feasible_somewhere(self, prefixes, simplices):
+        """
+        For every k: is the relaxation of ``prefixes[k]`` KNOWN to be feasible at a vertex of
+        ``simplices[k]`` -- then it is feasible on the simplex, and the phase-one problem over the
+        simplex would only repeat that.  Where nothing is held about the pair, the first vertex
+        without a verdict is asked (one point problem, remembered: the cells of a partition share
+        their vertices, so the neighbours that ask about the same prefix get it for nothing).
+        False = not known; the caller solves phase one over the simplex for those.
+        """
+        n = len(prefixes)
+        if not n:
+            return np.zeros(0, dtype=bool)
+        R = np.asarray(simplices, dtype=np.float64).reshape(n, -1, self.mpc.n_x)
+        nv = R.shape[1]
+        pid = self.point_ids(R.reshape(-1, self.mpc.n_x))
+        codes = np.fromiter((self._code(q) for q in prefixes), dtype=np.uint64, count=n)
+        ver = np.empty(n * nv, dtype=np.int8)
+        rep = np.repeat(codes, nv)
+        _capi.check_search(self._lib.ehm_search_peek(self._search, n * nv, ptr(rep), ptr(pid),
+                                                     ptr(ver)))
+        ver, pid = ver.reshape(n, nv), pid.reshape(n, nv)
+        known = (ver == 1).any(axis=1)
+        ask = np.flatnonzero(~known & (ver == -1).any(axis=1))
+        if ask.size:
+            col = (ver[ask] == -1).argmax(axis=1)
+            known[ask] = self.feasible_sets([prefixes[k] for k in ask], None,
+                                            [pid[k, c:c + 1] for k, c in zip(ask, col)])
+        return known
+
     def feasible_at_all(self, prefixes, points):
         """For every prefix: is its relaxation feasible at every one of the points?"""
         if not len(prefixes):
@@ -441,16 +470,22 @@ class PrefixTable(PrefixSearch):
                 self.lp_solves += int(ok.sum())
         return J
 
-    def solve_slack(self, prefixes, simplices, vbars):
-        """(t*, alpha) of the suboptimality test of prefix k on simplex k (-inf: infeasible)."""
+    def solve_slack(self, prefixes, simplices, vbars, known_feasible=None):
+        """(t*, alpha) of the suboptimality test of prefix k on simplex k (-inf: infeasible);
+        ``known_feasible``: mask of the pairs whose relaxation is known to be feasible on the
+        simplex (``feasible_somewhere``) -- phase one runs for the others only."""
         simplices = np.asarray(simplices, dtype=np.float64)
         vbars = np.asarray(vbars, dtype=np.float64)
         t = np.full(len(prefixes), -np.inf)
         alpha = np.zeros((len(prefixes), simplices.shape[1]))
         for idx, slot in self._chunks(prefixes):
-            tau = self.gp.simplex_idx(simplices[idx], slot, mode=2)[0]
-            self.lp_solves += idx.size
-            ok = tau <= FEAS_TOL
+            ok = np.ones(idx.size, dtype=bool)
+            todo = np.arange(idx.size) if known_feasible is None else \
+                np.flatnonzero(~np.asarray(known_feasible, dtype=bool)[idx])
+            if todo.size:
+                tau = self.gp.simplex_idx(simplices[idx[todo]], slot[todo], mode=2)[0]
+                self.lp_solves += todo.size
+                ok[todo] = tau <= FEAS_TOL
             if ok.any():
                 tk, ak, _ = self.gp.simplex_idx(simplices[idx[ok]], slot[ok], mode=1,
                                                 Vbar=vbars[idx[ok]])

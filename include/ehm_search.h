@@ -57,6 +57,11 @@ int ehm_search_forget(ehm_search* s);
  * second search of the same launch asked for again (answered once). */
 int ehm_search_counts(const ehm_search* s, int64_t counts[4]);
 
+/* What is held about n (prefix, point) pairs: verdict[k] = 1 feasible (a held verdict, or both
+ * ends of the bisected edge the point is the midpoint of), 0 infeasible, -1 nothing. */
+int ehm_search_peek(ehm_search* s, int64_t n, const uint64_t* code, const int64_t* point_id,
+                    int8_t* verdict);
+
 /* n_sets questions "is the relaxation of prefix code[k] feasible at EVERY point
  * point_id[set_begin[k] .. set_begin[k+1])?".  flags[k] = 0 where a held verdict already says
  * no; the pairs that need a problem are pending afterwards (*n_ask of them over *n_prefix

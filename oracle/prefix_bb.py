@@ -245,7 +245,7 @@ class CpuPrefixTable(_prefix_search_base()):
                 J[k] = res.fun
         return J
 
-    def solve_slack(self, prefixes, simplices, vbars):
+    def solve_slack(self, prefixes, simplices, vbars, known_feasible=None):
         na = np.asarray(simplices).shape[1]
         t = np.full(len(prefixes), -np.inf)
         alpha = np.zeros((len(prefixes), na))

@@ -20,6 +20,10 @@ class PyPrefixSearch:
         self._feas_n = 0
         self._code_of, self._prefix_of = {(): 0}, {0: ()}      # (PrefixSearch._code, optima_at)
 
+    def feasible_somewhere(self, prefixes, simplices):
+        """Nothing is claimed: phase one over the simplex runs for every pair."""
+        return np.zeros(len(prefixes), dtype=bool)
+
     # -- feasibility of (prefix, point) pairs, remembered --------------------------------------
     # The searches ask the same questions again and again: the children of a node share all but
     # one of its vertices, and their descents visit the same prefixes.  Phase-one verdicts are

@@ -211,4 +211,3 @@ def test_native_bookkeeping_equals_the_python_statement_on_the_cpu_table():
                 assert np.array_equal(c1, c2)
                 assert np.allclose(n1.data.vertex_costs, n2.data.vertex_costs, rtol=1e-9, atol=1e-10)
     assert n > len(roots)
-    assert nat.table.lp_solves < py.table.lp_solves
