@@ -61,6 +61,7 @@ class PrefixOracle:
         self.table.set_eps(eps_a, eps_r)
         self.last_margin = np.inf
         self.n_expanded = 0          # prefixes expanded (search-tree nodes)
+        self.n_inherited = 0         # prefixes answered from what a node or its ancestors solved
         self.n_blacklisted = 0
         self.calls = dict(P_theta=0, V_R=0, bar_E=0, bar_D=0)
 

@@ -103,8 +103,36 @@ def p_theta_many(oracle, thetas):
     return out
 
 
-def bar_e_many(oracle, Rs, Vs):
-    """``PrefixOracle.bar_E_delta_R`` for many nodes: (list of bool, list of margins)."""
+INHERIT_GUARD = 1e-7     # an inherited bound refutes only if it is below -INHERIT_GUARD (1 + max |V|)
+
+
+def _lookup(kids, exact, bound, guard, N):
+    """
+    What is already known about the suboptimality-test optimum t* of the prefixes ``kids`` on a
+    node: ``exact`` holds values solved on THIS node (same simplex, same vertex costs: (t, alpha
+    or None)), ``bound`` upper bounds inherited from an ancestor (module docstring of
+    ``grow_frontier``) -- those only refute.  Returns the list of (t, alpha) or None per kid.
+    """
+    out = [None] * len(kids)
+    for i, k in enumerate(kids):
+        hit = exact.get(k) if exact else None
+        if hit is not None and (hit[0] < 0. or len(k) < N or hit[1] is not None):
+            out[i] = hit
+        elif bound:
+            tb = bound.get(k)
+            if tb is not None and tb < -guard:
+                out[i] = (tb, None)
+    return out
+
+
+def bar_e_many(oracle, Rs, Vs, bound=None, learned=None, incumbents=None):
+    """
+    ``PrefixOracle.bar_E_delta_R`` for many nodes: (list of bool, list of margins).
+    ``bound[j]``: upper bounds of t* per prefix inherited from node j's ancestors (a prefix they
+    refute needs no problem); ``learned[j]`` (a dict, filled here): the optima solved on node j;
+    ``incumbents[j]``: a full sequence tried first (the parent's best-slack sequence) -- where
+    its slack is not negative the node is open and the search is not run.
+    """
     table, mpc = oracle.table, oracle.mpc
     n_modes, N = mpc.delta_size, mpc.N
     n = len(Rs)
@@ -113,24 +141,45 @@ def bar_e_many(oracle, Rs, Vs):
     closed, margin = [None] * n, [np.inf] * n
     active = list(range(n))
     oracle.calls['bar_E'] += n
+    guard = [INHERIT_GUARD * (1. + float(np.max(np.abs(V)))) for V in Vs]
+    seeded = [j for j in range(n) if incumbents and incumbents[j] is not None]
+    if seeded:
+        Rw = np.array([Rs[j] for j in seeded])
+        tw, aw = table.solve_slack([incumbents[j] for j in seeded], Rw,
+                                   np.array([Vs[j] for j in seeded]),
+                                   table.feasible_somewhere([incumbents[j] for j in seeded], Rw))
+        for w, j in enumerate(seeded):
+            if learned is not None:
+                learned[j][incumbents[j]] = (float(tw[w]), aw[w].copy())
+            if tw[w] >= 0.:
+                closed[j], margin[j] = False, abs(float(tw[w]))
+        active = [j for j in active if closed[j] is None]
     while active:
-        pre, Rp, Vp, kid_of = [], [], [], {}
+        pre, Rp, Vp, kid_of, val_of, ask_of = [], [], [], {}, {}, {}
         for j in active:
             batch = [heapq.heappop(heaps[j])[1] for _ in range(min(BATCH, len(heaps[j])))]
             oracle.n_expanded += len(batch)
             kids = [k for q in batch for k in _kids(q, n_modes)]
             kid_of[j] = kids
-            pre.extend(kids)
-            Rp.extend([Rs[j]] * len(kids))
-            Vp.extend([Vs[j]] * len(kids))
-        Rp = np.array(Rp)
-        t, _ = table.solve_slack(pre, Rp, np.array(Vp), table.feasible_somewhere(pre, Rp))
+            val_of[j] = _lookup(kids, learned[j] if learned else None,
+                                bound[j] if bound else None, guard[j], N)
+            ask_of[j] = [i for i, v in enumerate(val_of[j]) if v is None]
+            pre.extend(kids[i] for i in ask_of[j])
+            Rp.extend([Rs[j]] * len(ask_of[j]))
+            Vp.extend([Vs[j]] * len(ask_of[j]))
+        oracle.n_inherited += sum(len(kid_of[j]) - len(ask_of[j]) for j in active)
+        if pre:
+            Rp = np.array(Rp)
+            t, _ = table.solve_slack(pre, Rp, np.array(Vp), table.feasible_somewhere(pre, Rp))
         pos, still = 0, []
         for j in active:
-            kids = kid_of[j]
-            tj = t[pos:pos + len(kids)]
-            pos += len(kids)
-            for q, tq in zip(kids, tj):
+            kids, vals = kid_of[j], val_of[j]
+            for i in ask_of[j]:
+                vals[i] = (float(t[pos]), None)
+                if learned is not None:
+                    learned[j][kids[i]] = vals[i]
+                pos += 1
+            for q, (tq, _) in zip(kids, vals):
                 if not tq >= 0.:
                     refuted[j] = min(refuted[j], abs(tq))
                 elif len(q) == N:
@@ -147,8 +196,17 @@ def bar_e_many(oracle, Rs, Vs):
     return closed, margin
 
 
-def bar_d_many(oracle, Rs, Vs, deltas_ref):
-    """``PrefixOracle.bar_D_delta_R`` for many nodes: list of its 4-tuples."""
+def bar_d_many(oracle, Rs, Vs, deltas_ref, bound=None, learned=None, incumbents=None,
+               stars=None):
+    """
+    ``PrefixOracle.bar_D_delta_R`` for many nodes: list of its 4-tuples.  ``bound`` / ``learned``
+    as in ``bar_e_many`` (``learned[j]`` may come in holding what bar_E solved on the node: the
+    same problems); a prefix solved in the first phase is not solved again in the second.
+    ``incumbents[j]``: a full sequence to evaluate first (the best-slack sequence of node j's
+    parent): its slack is a value the maximum cannot fall below, so every prefix whose inherited
+    bound lies under it is never solved.  ``stars`` (a list, filled here): the best-slack
+    sequence found per node, None where there is none.
+    """
     table, mpc = oracle.table, oracle.mpc
     n_modes, N = mpc.delta_size, mpc.N
     n = len(Rs)
@@ -160,13 +218,34 @@ def bar_d_many(oracle, Rs, Vs, deltas_ref):
     limit = [0.] * n
     stacks = [None] * n
     star = [None] * n                    # (sequence, alpha) once found; False = none exists
+    if learned is None:
+        learned = [dict() for _ in range(n)]
+    guard = [INHERIT_GUARD * (1. + float(np.max(np.abs(V)))) for V in Vs]
 
     def floor(j):
         return max(0., best[j] + PLATEAU * _rel(best[j])) if np.isfinite(best[j]) else 0.
-    vid_of = {id(R): table.point_ids(R) for R in Rs}      # the vertices' ids, once per node
+    vid = [table.point_ids(R) for R in Rs]                # the vertices' ids, once per node
+    # warm start: the parent's best-slack sequence, evaluated on the node itself
+    seeded = [j for j in range(n) if incumbents and incumbents[j] is not None
+              and incumbents[j] not in learned[j]]
+    if seeded:
+        Rw = np.array([Rs[j] for j in seeded])
+        tw, aw = table.solve_slack([incumbents[j] for j in seeded], Rw,
+                                   np.array([Vs[j] for j in seeded]),
+                                   table.feasible_somewhere([incumbents[j] for j in seeded], Rw))
+        for w, j in enumerate(seeded):
+            learned[j][incumbents[j]] = (float(tw[w]), aw[w].copy())
+    warm = [j for j in range(n) if incumbents and incumbents[j] is not None
+            and learned[j][incumbents[j]][0] >= 0.]
+    if warm:
+        ok = table.feasible_sets([incumbents[j] for j in warm], [Rs[j] for j in warm],
+                                 [vid[j] for j in warm])
+        for j, good in zip(warm, ok):
+            if good:
+                best[j] = learned[j][incumbents[j]][0]
     active = list(range(n))
     while active:
-        pre, Rp, Vp, kid_of = [], [], [], {}
+        pre, Rp, Vp, kid_of, val_of, ask_of = [], [], [], {}, {}, {}
         for j in active:
             if phase[j] == 1:
                 batch = []
@@ -174,26 +253,47 @@ def bar_d_many(oracle, Rs, Vs, deltas_ref):
                     batch.append(heapq.heappop(heaps[j])[1])
                 oracle.n_expanded += len(batch)
                 kids = [k for q in batch for k in _kids(q, n_modes)]
+                need = floor(j)
             else:
                 oracle.n_expanded += 1
                 kids = _kids(stacks[j].pop(), n_modes)
+                need = limit[j]
             kid_of[j] = kids
-            pre.extend(kids)
-            Rp.extend([Rs[j]] * len(kids))
-            Vp.extend([Vs[j]] * len(kids))
-        Ra = np.array(Rp)
-        t, alpha = table.solve_slack(pre, Ra, np.array(Vp), table.feasible_somewhere(pre, Ra))
+            val_of[j] = _lookup(kids, learned[j], bound[j] if bound else None, guard[j], N)
+            if bound and bound[j]:
+                # an inherited upper bound below what this phase still accepts: never solved
+                for i, k in enumerate(kids):
+                    if val_of[j][i] is None:
+                        tb = bound[j].get(k)
+                        if tb is not None and tb < need - guard[j]:
+                            val_of[j][i] = (-np.inf, None)
+            ask_of[j] = [i for i, v in enumerate(val_of[j]) if v is None]
+            pre.extend(kids[i] for i in ask_of[j])
+            Rp.extend([Rs[j]] * len(ask_of[j]))
+            Vp.extend([Vs[j]] * len(ask_of[j]))
+        oracle.n_inherited += sum(len(kid_of[j]) - len(ask_of[j]) for j in active)
+        if pre:
+            Ra = np.array(Rp)
+            t, alpha = table.solve_slack(pre, Ra, np.array(Vp), table.feasible_somewhere(pre, Ra))
+        pos = 0
+        for j in active:
+            kids, vals = kid_of[j], val_of[j]
+            for i in ask_of[j]:
+                full = len(kids[i]) == N
+                vals[i] = learned[j][kids[i]] = (float(t[pos]), alpha[pos].copy() if full else None)
+                pos += 1
         # feasibility at every vertex, for the prefixes whose slack bound is not negative
-        live = np.flatnonzero(t >= 0.)
-        if live.size:
-            ok = table.feasible_sets([pre[k] for k in live], [Rp[k] for k in live],
-                                     [vid_of[id(Rp[k])] for k in live])
-            t[live[~ok]] = -np.inf
-        pos, still = 0, []
+        live = [(j, i) for j in active for i, v in enumerate(val_of[j]) if v[0] >= 0.]
+        dead = set()
+        if live:
+            ok = table.feasible_sets([kid_of[j][i] for j, i in live], [Rs[j] for j, _ in live],
+                                     [vid[j] for j, _ in live])
+            dead = {ji for ji, good in zip(live, ok) if not good}
+        still = []
         for j in active:
             kids = kid_of[j]
-            tj, aj = t[pos:pos + len(kids)], alpha[pos:pos + len(kids)]
-            pos += len(kids)
+            tj = [(-np.inf if (j, i) in dead else v[0]) for i, v in enumerate(val_of[j])]
+            aj = [v[1] for v in val_of[j]]
             if phase[j] == 1:
                 for q, tq in zip(kids, tj):
                     if not tq >= 0.:
@@ -220,6 +320,8 @@ def bar_d_many(oracle, Rs, Vs, deltas_ref):
                     raise SolverError('bar_D: the slack found in phase one was not reproduced')
                 still.append(j)
         active = still
+    if stars is not None:
+        stars[:] = [st[0] if st else None for st in star]
     # the winners' vertex solves and variability checks, one call each
     out = [(None, None, None, None)] * n
     win = [j for j in range(n) if star[j] and star[j][0] != refs[j]]
@@ -348,11 +450,16 @@ def grow_frontier(oracle, branch, action='ecc', table_max=256, max_visits=None, 
         ecc = [nd for nd, act, _ in batch if act == 'ecc']
         witness = [wit for _, act, wit in batch if act == 'ecc']
         lcss = [nd for nd, act, _ in batch if act != 'ecc']
+        # an lcss node's third entry: (upper bounds of t* per prefix proven on its ancestors, the
+        # parent's best-slack sequence), or None
+        bounds = [b[0] if b else None for _, act, b in batch if act != 'ecc']
+        incumbents = [b[1] if b else None for _, act, b in batch if act != 'ecc']
         stats['host_visits'] += len(ecc) + len(lcss)
         if log:
             log('round %d: %d ecc + %d lcss nodes, %d waiting' %
                 (stats['rounds'], len(ecc), len(lcss), len(work)))
-        to_split = []       # (node, commutation, costs, inputs) or (ecc node, None, None, witness)
+        # (node, commutation, costs, inputs, inherited bounds) or (ecc node, None, None, witness, None)
+        to_split = []
         if ecc:                             # lib/worker.py:241-283
             Rs = [np.asarray(nd.data.vertices, dtype=np.float64) for nd in ecc]
             oracle.calls['V_R'] += len(ecc)
@@ -395,11 +502,13 @@ def grow_frontier(oracle, branch, action='ecc', table_max=256, max_visits=None, 
                     vx = [(uv[w, i].copy(), float(Jv[w, i]), 0.) for i in range(nv)]
                 _set_record(ecc[k].data, delta, vx)
                 work.append((ecc[k], 'lcss', None))
-            to_split += [(ecc[k], None, None, witness[k]) for k, s in enumerate(found) if s is None]
+            to_split += [(ecc[k], None, None, witness[k], None)
+                         for k, s in enumerate(found) if s is None]
         if lcss:                            # lib/worker.py:340-417
             Rs = [np.asarray(nd.data.vertices, dtype=np.float64) for nd in lcss]
             Vs = [np.asarray(nd.data.vertex_costs, dtype=np.float64) for nd in lcss]
-            closed, margins = bar_e_many(oracle, Rs, Vs)
+            learned = [dict() for _ in lcss]
+            closed, margins = bar_e_many(oracle, Rs, Vs, bounds, learned, incumbents)
             oracle.last_margin = min([oracle.last_margin] + margins)
             opened = [k for k, c in enumerate(closed) if not c]
             for k, c in enumerate(closed):
@@ -408,25 +517,38 @@ def grow_frontier(oracle, branch, action='ecc', table_max=256, max_visits=None, 
             if handoff and opened:          # the open ones: to the engine where the table fits
                 keep = _hand_off(oracle, [lcss[k] for k in opened], table_max, engine_opts, stats)
                 opened = [opened[k] for k in keep]
+            stars = []
             res = bar_d_many(oracle, [Rs[k] for k in opened], [Vs[k] for k in opened],
-                             [lcss[k].data.commutation for k in opened]) if opened else []
-            for k, (delta_star, theta_star, new_vx, small) in zip(opened, res):
+                             [lcss[k].data.commutation for k in opened],
+                             [bounds[k] for k in opened], [learned[k] for k in opened],
+                             [incumbents[k] for k in opened], stars) if opened else []
+            for w, (k, (delta_star, theta_star, new_vx, small)) in enumerate(zip(opened, res)):
                 data = lcss[k].data
+                # what the children inherit: the optima solved on this node bound theirs from
+                # above (on top of what the node inherited itself), and its best-slack sequence
+                # is the first thing their searches evaluate
+                down = dict(bounds[k]) if bounds[k] else {}
+                down.update((q, v[0]) for q, v in learned[k].items())
+                down = (down, stars[w])
                 if delta_star is None:
                     to_split.append((lcss[k], data.commutation, data.vertex_costs,
-                                     data.vertex_inputs))
+                                     data.vertex_inputs, down))
                     continue
                 costs = np.array([v[1] for v in new_vx])
                 inputs = np.array([v[0] for v in new_vx])
+                # the bounds were proven against the interpolation of the OLD vertex costs: they
+                # hold below the new ones only if those are nowhere larger
+                if not np.all(costs <= np.asarray(data.vertex_costs)):
+                    down = (None, down[1])
                 if small:                   # lib/worker.py:396-401
                     data.commutation, data.vertex_costs, data.vertex_inputs = (delta_star, costs,
                                                                                 inputs)
-                    work.append((lcss[k], 'lcss', None))
+                    work.append((lcss[k], 'lcss', down))
                 else:
-                    to_split.append((lcss[k], delta_star, costs, inputs))
+                    to_split.append((lcss[k], delta_star, costs, inputs, down))
         if to_split:
             Rsplit = np.array([np.asarray(nd.data.vertices, dtype=np.float64)
-                               for nd, _, _, _ in to_split])
+                               for nd, _, _, _, _ in to_split])
             S1, S2, ij = split_batch(Rsplit)
             rows = np.arange(len(to_split))
             oracle.table.register_midpoints(S1[rows, ij[:, 0]], Rsplit[rows, ij[:, 0]],
@@ -440,7 +562,7 @@ def grow_frontier(oracle, branch, action='ecc', table_max=256, max_visits=None, 
                     [oracle.sequence_of(to_split[k][1]) for k in with_data], mids[:, None, :])
                 Jm, um = Jm[:, 0], um[:, 0]
             for w, k in enumerate(with_data):
-                nd, delta, costs, inputs = to_split[k]
+                nd, delta, costs, inputs, down = to_split[k]
                 i, j = int(ij[k][0]), int(ij[k][1])
                 if not np.isfinite(Jm[w]):
                     raise SolverError('midpoint solve of the adopted commutation failed')
@@ -451,9 +573,9 @@ def grow_frontier(oracle, branch, action='ecc', table_max=256, max_visits=None, 
                                  vertex_inputs=in_1),
                         NodeData(vertices=S2[k].copy(), commutation=delta, vertex_costs=co_2,
                                  vertex_inputs=in_2))
-                work.append((nd.left, 'lcss', None))
-                work.append((nd.right, 'lcss', None))
-            for k, (nd, delta, _, wit) in enumerate(to_split):
+                work.append((nd.left, 'lcss', down))
+                work.append((nd.right, 'lcss', down))
+            for k, (nd, delta, _, wit, _) in enumerate(to_split):
                 if delta is None:
                     nd.grow(NodeData(vertices=S1[k].copy()), NodeData(vertices=S2[k].copy()))
                     work.append((nd.left, 'ecc', wit))

@@ -221,8 +221,11 @@ def main():
     R = np.array([-half + 2 * half * (np.arange(p) < k) for k in range(p + 1)])
     orc = bnb.PrefixOracle(mpc, 1., 1., slots=2048)
     J = [orc.P_theta(v)[2] for v in R]
-    orc.eps_a, orc.eps_r = 0.5 * max(J), 1.0
-    orc.table.set_eps(orc.eps_a, 1.0)
+    # config-5 tolerances of DESIGN.md 3.3e by default; EHM_EPS_A_FRAC / EHM_EPS_R tighten them
+    # (then the suboptimality-test searches do real work)
+    orc.eps_a = float(os.environ.get('EHM_EPS_A_FRAC', '0.5')) * max(J)
+    orc.eps_r = float(os.environ.get('EHM_EPS_R', '1.0'))
+    orc.table.set_eps(orc.eps_a, orc.eps_r)
     PooledStubProblem.busy = 0.
     PooledStubProblem.by_kind = {}
     t0 = time.perf_counter()
