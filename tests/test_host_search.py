@@ -211,3 +211,70 @@ def test_native_bookkeeping_equals_the_python_statement_on_the_cpu_table():
                 assert np.array_equal(c1, c2)
                 assert np.allclose(n1.data.vertex_costs, n2.data.vertex_costs, rtol=1e-9, atol=1e-10)
     assert n > len(roots)
+
+
+def test_warm_started_searches_grow_the_enumerating_partition():
+    """
+    bnb_frontier with everything it inherits -- bounds of t* proven on the ancestors, the
+    parent's best-slack sequence tried first, bar_E's optima reused by bar_D, the barycentre
+    witness, remembered vertex optima -- at a tolerance where lcss refines over several levels:
+    the tree of the ENUMERATING CPU partition (every commutation, every node from scratch), and
+    the same answers from bar_e_many / bar_d_many with and without what they are handed.
+    """
+    from oracle.oracle_cpu import OracleCPU
+    from oracle.partition_cpu import PartitionCPU
+    mpc = helpers.make_instance('pwa_small', 0)
+    eps_a = helpers.eps_a_rule(mpc, 0.2)     # (tighter, this instance refines along a cost jump
+    eps_r = 0.1                              # for ever -- DESIGN.md section 6, config 3)
+    roots, locs = helpers.roots_of(mpc)
+    cpu = PartitionCPU(OracleCPU(mpc, eps_a, eps_r))
+    cpu.run(roots, locs, 'ecc')
+    orc = bnb.PrefixOracle(mpc, eps_a, eps_r, table=prefix_bb.CpuPrefixTable(mpc))
+    trees = [Tree(NodeData(vertices=np.array(R))) for R in roots]
+    stats = bnb_frontier.grow_frontier(orc, trees, 'ecc', handoff=False,
+                                       split_batch=_host_split_batch)
+    assert not stats['truncated']
+    assert orc.n_inherited > 20                      # the searches did lean on their ancestors
+    n = depth = 0
+    for t, loc0 in zip(trees, locs):
+        for nd, loc in t.walk(loc0):
+            r = cpu.nodes[loc]
+            n += 1
+            depth = max(depth, len(loc) - len(loc0))
+            assert np.array_equal(nd.data.vertices, r['vertices'])
+            assert nd.is_leaf() == r['leaf']
+            assert nd.data.is_epsilon_suboptimal == r['is_epsilon_suboptimal']
+            if r['commutation'] is not None:
+                assert np.array_equal(nd.data.commutation.astype(int), r['commutation'].astype(int))
+                assert np.allclose(nd.data.vertex_costs, r['vertex_costs'], rtol=1e-7, atol=1e-8)
+    assert n == len(cpu.nodes) and depth >= 4
+    # the two searches on inner nodes, with and without the parent's knowledge
+    inner = [(nd, loc) for t, loc0 in zip(trees, locs) for nd, loc in t.walk(loc0)
+             if not nd.is_leaf() and hasattr(nd.data, 'commutation')][:12]
+    assert len(inner) >= 4
+    compared = 0
+    for nd, _ in inner:
+        for kid in (nd.left, nd.right):
+            if not hasattr(kid.data, 'commutation'):
+                continue
+            R, V = np.asarray(nd.data.vertices), np.asarray(nd.data.vertex_costs)
+            learned, stars = [dict()], []
+            bnb_frontier.bar_e_many(orc, [R], [V], None, learned)
+            bnb_frontier.bar_d_many(orc, [R], [V], [nd.data.commutation], None, learned, None, stars)
+            Rk, Vk = np.asarray(kid.data.vertices), np.asarray(kid.data.vertex_costs)
+            if not np.array_equal(kid.data.commutation, nd.data.commutation) or \
+                    not np.all(np.delete(Vk, np.flatnonzero(np.any(Rk != R, axis=1))) <=
+                               np.delete(V, np.flatnonzero(np.any(Rk != R, axis=1)))):
+                continue                              # the bounds do not carry over (grow_frontier)
+            bound = {q: v[0] for q, v in learned[0].items()}
+            cold = bnb_frontier.bar_e_many(orc, [Rk], [Vk])[0]
+            warm = bnb_frontier.bar_e_many(orc, [Rk], [Vk], [bound], [dict()], [stars[0]])[0]
+            assert cold == warm
+            compared += 1
+            a = bnb_frontier.bar_d_many(orc, [Rk], [Vk], [kid.data.commutation])[0]
+            b = bnb_frontier.bar_d_many(orc, [Rk], [Vk], [kid.data.commutation], [bound], [dict()],
+                                        [stars[0]])[0]
+            assert (a[0] is None) == (b[0] is None)
+            if a[0] is not None:
+                assert np.array_equal(a[0], b[0]) and np.allclose(a[1], b[1], atol=1e-9) and a[3] == b[3]
+    assert compared >= 3
