@@ -332,7 +332,9 @@ def bar_d_many(oracle, Rs, Vs, deltas_ref, bound=None, learned=None, incumbents=
                                 np.vstack([Rs[j] for j in win]))
     Jv, uv = Jv.reshape(len(win), nv), uv.reshape(len(win), nv, -1)
     thetas = np.array([star[j][1] @ Rs[j] for j in win])
-    Jmin = table.solve_min([refs[j] for j in win], np.array([Rs[j] for j in win]))
+    # (the node's own commutation is feasible at every vertex: no phase one over the simplex)
+    Jmin = table.solve_min([refs[j] for j in win], np.array([Rs[j] for j in win]),
+                           np.ones(len(win), dtype=bool))
     Jth = table.solve_points([star[j][0] for j in win], thetas)[0]
     for w, j in enumerate(win):
         if not (np.all(np.isfinite(Jv[w])) and np.isfinite(Jmin[w]) and np.isfinite(Jth[w])):
@@ -368,7 +370,8 @@ def region_tables_many(oracle, Rs, commutations, Us, table_max):
             alive[j] = cand
             pre.extend(cand)
             Rp.extend([Rs[j]] * len(cand))
-        cost = table.solve_min(pre, np.array(Rp))
+        Ra = np.array(Rp)
+        cost = table.solve_min(pre, Ra, table.feasible_somewhere(pre, Ra))
         pos, still = 0, []
         for j in active:
             c = cost[pos:pos + len(alive[j])]

@@ -457,14 +457,19 @@ class PrefixTable(PrefixSearch):
             self._solve_chunk(idx, slot, thetas, J, u0, feasibility_only, known_feasible)
         return J, u0
 
-    def solve_min(self, prefixes, simplices):
-        """Minimum over simplex k of the optimal cost of prefix k (+inf: infeasible on it)."""
+    def solve_min(self, prefixes, simplices, known_feasible=None):
+        """Minimum over simplex k of the optimal cost of prefix k (+inf: infeasible on it);
+        ``known_feasible`` as in ``solve_slack``."""
         simplices = np.asarray(simplices, dtype=np.float64)
         J = np.full(len(prefixes), np.inf)
         for idx, slot in self._chunks(prefixes):
-            tau = self.gp.simplex_idx(simplices[idx], slot, mode=2)[0]
-            self.lp_solves += idx.size
-            ok = tau <= FEAS_TOL
+            ok = np.ones(idx.size, dtype=bool)
+            todo = np.arange(idx.size) if known_feasible is None else \
+                np.flatnonzero(~np.asarray(known_feasible, dtype=bool)[idx])
+            if todo.size:
+                tau = self.gp.simplex_idx(simplices[idx[todo]], slot[todo], mode=2)[0]
+                self.lp_solves += todo.size
+                ok[todo] = tau <= FEAS_TOL
             if ok.any():
                 J[idx[ok]] = self.gp.simplex_idx(simplices[idx[ok]], slot[ok], mode=0)[0]
                 self.lp_solves += int(ok.sum())
