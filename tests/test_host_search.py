@@ -278,3 +278,27 @@ def test_warm_started_searches_grow_the_enumerating_partition():
             if a[0] is not None:
                 assert np.array_equal(a[0], b[0]) and np.allclose(a[1], b[1], atol=1e-9) and a[3] == b[3]
     assert compared >= 3
+
+
+def test_tables_grow_past_their_first_sizes():
+    """Enough points (> 4096 x 0.6) and verdicts (> 65536 x 0.6) to rehash both tables several
+    times: ids stay ids of values, verdicts stay verdicts."""
+    tab = HalfSpaceTable(n_x=3, delta_size=3, N=4, seed=7)
+    rng = np.random.default_rng(8)
+    pts = rng.uniform(-0.6, 0.6, (12000, 3))
+    ids = tab.point_ids(pts)
+    assert np.array_equal(ids, np.arange(12000))
+    assert np.array_equal(tab.point_ids(pts[::-1]), ids[::-1])           # by value, any order
+    prefixes = [q for k in range(1, 5) for q in itertools.product(range(3), repeat=k)]
+    pick = [prefixes[k] for k in rng.integers(0, len(prefixes), 60000)]
+    which = rng.integers(0, 12000, (60000, 2))
+    idl = [ids[w] for w in which]
+    flags = tab.feasible_sets(pick, None, idl)
+    want = np.array([tab.feasible(q, pts[w[0]]) and tab.feasible(q, pts[w[1]])
+                     for q, w in zip(pick, which)])
+    assert np.array_equal(flags, want)
+    held = tab.search_counts()[0]
+    assert held > 65536 and len(tab.asked) == len(set(tab.asked)) == held
+    n = len(tab.asked)
+    assert np.array_equal(tab.feasible_sets(pick, None, idl), want) and len(tab.asked) == n
+    tab.close_search()
