@@ -28,5 +28,8 @@ print('budget', budget, 'nodes', sum(1 for _ in branch.walk()), 'leaves', len(le
       'closed', sum(1 for n, _ in leaves if n.data.is_epsilon_suboptimal),
       {k: v for k, v in stats.items() if k != 'table_sizes'}, 'tables', sorted(stats['table_sizes'])[-5:],
       'calls', orc.calls, 'LPs', orc.table.lp_solves, 'expanded', orc.n_expanded,
-      'blocks', orc.table.blocks_loaded, '%.1fs' % (time.time() - t), flush=True)
+      'inherited', orc.n_inherited, 'blocks', orc.table.blocks_loaded,
+      'memo (verdicts, points, pairs solved, pairs shared)', orc.table.search_counts(),
+      'optima asked / solved', getattr(orc.table, 'optima_asked', 0),
+      getattr(orc.table, 'optima_solved', 0), '%.1fs' % (time.time() - t), flush=True)
 orc.close()
