@@ -539,10 +539,12 @@ def grow_frontier(oracle, branch, action='ecc', table_max=256, max_visits=None, 
                     continue
                 costs = np.array([v[1] for v in new_vx])
                 inputs = np.array([v[0] for v in new_vx])
-                # the bounds were proven against the interpolation of the OLD vertex costs: they
-                # hold below the new ones only if those are nowhere larger
-                if not np.all(costs <= np.asarray(data.vertex_costs)):
-                    down = (None, down[1])
+                # the bounds were proven against the interpolation of the OLD vertex costs; where
+                # the adopted commutation's are larger the interpolant rises by at most the
+                # largest increase, and so does every t*
+                rise = float(np.max(costs - np.asarray(data.vertex_costs)))
+                if rise > 0.:
+                    down = ({q: t + rise for q, t in down[0].items()}, down[1])
                 if small:                   # lib/worker.py:396-401
                     data.commutation, data.vertex_costs, data.vertex_inputs = (delta_star, costs,
                                                                                 inputs)
