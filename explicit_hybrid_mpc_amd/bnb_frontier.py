@@ -104,6 +104,15 @@ def p_theta_many(oracle, thetas):
 
 
 INHERIT_GUARD = 1e-7     # an inherited bound refutes only if it is below -INHERIT_GUARD (1 + max |V|)
+LAUNCH_TARGET = 4096     # problems a best-first step aims at per launch
+
+
+def _batch_size(n_active, n_modes):
+    """Prefixes one search expands per step: BATCH (bnb.py) when few searches share the launch --
+    latency counts, the launch is far from full --, fewer when thousands do: the launch is full
+    anyway and every prefix expanded ahead of its turn is problems solved for nothing."""
+    return max(1, min(BATCH, LAUNCH_TARGET // max(1, n_active * n_modes)))
+
 
 
 def _lookup(kids, exact, bound, guard, N):
@@ -156,8 +165,9 @@ def bar_e_many(oracle, Rs, Vs, bound=None, learned=None, incumbents=None):
         active = [j for j in active if closed[j] is None]
     while active:
         pre, Rp, Vp, kid_of, val_of, ask_of = [], [], [], {}, {}, {}
+        width = _batch_size(len(active), n_modes)
         for j in active:
-            batch = [heapq.heappop(heaps[j])[1] for _ in range(min(BATCH, len(heaps[j])))]
+            batch = [heapq.heappop(heaps[j])[1] for _ in range(min(width, len(heaps[j])))]
             oracle.n_expanded += len(batch)
             kids = [k for q in batch for k in _kids(q, n_modes)]
             kid_of[j] = kids
@@ -246,10 +256,11 @@ def bar_d_many(oracle, Rs, Vs, deltas_ref, bound=None, learned=None, incumbents=
     active = list(range(n))
     while active:
         pre, Rp, Vp, kid_of, val_of, ask_of = [], [], [], {}, {}, {}
+        width = _batch_size(len(active), n_modes)
         for j in active:
             if phase[j] == 1:
                 batch = []
-                while heaps[j] and len(batch) < BATCH and -heaps[j][0][0] >= floor(j):
+                while heaps[j] and len(batch) < width and -heaps[j][0][0] >= floor(j):
                     batch.append(heapq.heappop(heaps[j])[1])
                 oracle.n_expanded += len(batch)
                 kids = [k for q in batch for k in _kids(q, n_modes)]
