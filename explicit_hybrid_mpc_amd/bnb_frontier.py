@@ -103,7 +103,8 @@ def p_theta_many(oracle, thetas):
     return out
 
 
-INHERIT_GUARD = 1e-7     # an inherited bound refutes only if it is below -INHERIT_GUARD (1 + max |V|)
+INHERIT_GUARD = 1e-6     # an inherited bound counts only by more than INHERIT_GUARD (1 + max |V|): ten
+                         # times the accuracy the device solver's optima are compared at (1e-7)
 LAUNCH_TARGET = 4096     # problems a best-first step aims at per launch
 
 
