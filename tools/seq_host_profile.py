@@ -241,6 +241,7 @@ def main():
         pr = cProfile.Profile()
         stats = pr.runcall(run)
         pstats.Stats(pr).sort_stats('cumulative').print_stats(35)
+        pstats.Stats(pr).sort_stats('tottime').print_stats(30)
     else:
         stats = run()
     wall = time.perf_counter() - t0
