@@ -16,3 +16,6 @@ timeout 300 python tools/_seq_probe.py 150000 frontier > gpurun_out/next_seq_pro
 tail -3 gpurun_out/next_seq_probe.txt
 timeout 300 python bench.py --steps 3 --warmup 1 > gpurun_out/next_bench.json 2> gpurun_out/next_bench.err
 tail -c 600 gpurun_out/next_bench.json
+# Then (a second call): tools/next_round/README.md -- apply midpoint_table.patch, rebuild, and run
+#   python -m pytest tests/test_gpu_kernel_generations.py -k shared_midpoint -s
+#   python -m pytest tests -m gpu -x -q ; python bench.py
