@@ -291,13 +291,3 @@ def test_prefix_blocks_built_incrementally_are_the_reference_blocks():
     sub = base.restrict([(0, 0, 0), (1, 0, 1)])
     assert all(np.array_equal(a, b) for a, b in zip(sub.condense_prefix((1, 0)),
                                                     base._condense_prefix_reference((1, 0))))
-
-
-def test_prepared_patch_still_applies():
-    """tools/next_round/midpoint_table.patch (prepared without a device, tools/next_round/README.md)
-    must keep applying to the tree until it has been tried on one."""
-    patch = os.path.join(ROOT, 'tools', 'next_round', 'midpoint_table.patch')
-    if not os.path.exists(patch) or not os.path.isdir(os.path.join(ROOT, '.git')):
-        pytest.skip('no prepared patch / not a git checkout')
-    out = subprocess.run(['git', 'apply', '--check', patch], cwd=ROOT, capture_output=True, text=True)
-    assert out.returncode == 0, out.stderr
