@@ -486,7 +486,8 @@ def grow_frontier(oracle, branch, action='ecc', table_max=256, max_visits=None, 
             # problem), the lexicographic descent runs only where that one fails.
             none = [k for k, s in enumerate(found) if s is None]
             oracle.calls['P_theta'] += len(none)
-            bary = [np.average(Rs[k], axis=0)[None] for k in none]
+            centres = np.mean(np.array([Rs[k] for k in none]), axis=1) if none else np.zeros((0, 1))
+            bary = [centres[i:i + 1] for i in range(len(none))]
             tried = [i for i, k in enumerate(none) if witness[k] is not None]
             held = np.zeros(len(none), dtype=bool)
             if tried:
