@@ -45,6 +45,7 @@ EXPORTED_SEARCH = [
     'ehm_search_register_midpoints', 'ehm_search_forget', 'ehm_search_counts',
     'ehm_search_query', 'ehm_search_asks', 'ehm_search_answer', 'ehm_search_descent_begin',
     'ehm_search_descent_step', 'ehm_search_descent_result', 'ehm_search_peek',
+    'ehm_search_abandon',
 ]
 
 
@@ -188,6 +189,7 @@ def load(build_if_missing=True):
     lib.ehm_search_point_ids.argtypes = [vp, i64, vp, vp]
     lib.ehm_search_register_midpoints.argtypes = [vp, i64, vp, vp, vp]
     lib.ehm_search_forget.argtypes = [vp]
+    lib.ehm_search_abandon.argtypes = [vp]
     lib.ehm_search_counts.argtypes = [vp, vp]
     lib.ehm_search_query.argtypes = [vp, i64, vp, vp, vp, vp, ctypes.POINTER(i64),
                                      ctypes.POINTER(i64)]

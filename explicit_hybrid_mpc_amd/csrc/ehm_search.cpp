@@ -321,6 +321,19 @@ int ehm_search_register_midpoints(ehm_search* s, int64_t n, const int64_t* mid, 
     return EHM_OK;
 }
 
+int ehm_search_abandon(ehm_search* s) {
+    if (!s) return fail(EHM_E_INVALID, "ehm_search_abandon: NULL handle");
+    for (size_t a = 0; a < s->ask_code.size(); ++a)        // -1 reads as "nothing held"
+        s->memo.put(s->key_of(s->ask_code[a], s->ask_pid[a]), -1);
+    s->ask_code.clear(); s->ask_pid.clear(); s->ask_prefix.clear();
+    s->uniq_code.clear(); s->uniq_of.clear(); s->deps.clear();
+    s->pending_sets = -1;
+    s->step_pending = false;
+    s->active.clear();
+    s->desc.clear();
+    return EHM_OK;
+}
+
 int ehm_search_forget(ehm_search* s) {
     if (!s) return fail(EHM_E_INVALID, "ehm_search_forget: NULL handle");
     if (s->pending_sets >= 0 || s->step_pending)
@@ -441,9 +454,12 @@ int ehm_search_descent_begin(ehm_search* s, int64_t n, const int64_t* set_begin,
         return fail(EHM_E_INVALID, "ehm_search_descent_begin: excluded is NULL");
     try {
         s->desc.assign((size_t)n, Descent());
-        s->d_pid.assign(point_id + set_begin[0], point_id + set_begin[n]);
+        s->d_pid.clear();
+        if (set_begin[n] > set_begin[0])
+            s->d_pid.assign(point_id + set_begin[0], point_id + set_begin[n]);
         s->d_excl.clear();
-        if (excl_begin) s->d_excl.assign(excluded + excl_begin[0], excluded + excl_begin[n]);
+        if (excl_begin && excl_begin[n] > excl_begin[0])
+            s->d_excl.assign(excluded + excl_begin[0], excluded + excl_begin[n]);
         s->active.clear();
         for (int64_t j = 0; j < n; ++j) {
             Descent& d = s->desc[j];

@@ -218,8 +218,13 @@ class PrefixSearch:
         thetas = np.empty((n_ask, self.mpc.n_x))
         _capi.check_search(self._lib.ehm_search_asks(self._search, ptr(codes), ptr(idx),
                                                      ptr(thetas)))
-        J = self.solve_points_idx([self._prefix(int(c)) for c in codes], idx, thetas,
-                                  feasibility_only=True)[0]
+        try:
+            J = self.solve_points_idx([self._prefix(int(c)) for c in codes], idx, thetas,
+                                      feasibility_only=True)[0]
+        except BaseException:
+            # the launch failed: its pairs are unknown again, the native state stays usable
+            self._lib.ehm_search_abandon(self._search)
+            raise
         self._feas_n += n_ask
         return np.ascontiguousarray(np.isfinite(J), dtype=np.uint8)
 

@@ -51,6 +51,9 @@ int ehm_search_point_ids(ehm_search* s, int64_t n, const double* points, int64_t
  * lib/tools.py:191-257): a relaxation feasible at both ends needs no problem at the midpoint. */
 int ehm_search_register_midpoints(ehm_search* s, int64_t n, const int64_t* mid, const int64_t* a,
                                   const int64_t* b);
+/* Give up the pending launch (its solver failed): the pairs it was to decide are unknown again,
+ * unfinished descents are dropped.  The handle is usable afterwards. */
+int ehm_search_abandon(ehm_search* s);
 /* Forget the verdicts (ids and midpoints stay valid). */
 int ehm_search_forget(ehm_search* s);
 /* counts[0] = verdicts held, [1] = points, [2] = pairs handed out so far, [3] = pairs that a

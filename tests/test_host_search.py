@@ -302,3 +302,26 @@ def test_tables_grow_past_their_first_sizes():
     n = len(tab.asked)
     assert np.array_equal(tab.feasible_sets(pick, None, idl), want) and len(tab.asked) == n
     tab.close_search()
+
+
+def test_a_failed_launch_leaves_the_search_state_usable():
+    tab = HalfSpaceTable(seed=9)
+    rng = np.random.default_rng(10)
+    sets = [rng.uniform(-0.4, 0.4, (3, 3)) for _ in range(20)]
+    good = tab.solve_points
+    calls = {'n': 0}
+
+    def flaky(prefixes, thetas, feasibility_only=False, known_feasible=False):
+        calls['n'] += 1
+        if calls['n'] == 3:
+            raise RuntimeError('device lost')
+        return good(prefixes, thetas, feasibility_only, known_feasible)
+    tab.solve_points = flaky
+    with pytest.raises(RuntimeError):
+        tab.first_feasible_many(sets)
+    # nothing is pending, what the failed launch was to decide is simply unknown again
+    assert tab.first_feasible_many(sets) == [tab.brute_first(s) for s in sets]
+    prefixes = [(0,), (1,), (2, 0)]
+    assert np.array_equal(tab.feasible_sets(prefixes, [sets[0]] * 3),
+                          [all(tab.feasible(q, th) for th in sets[0]) for q in prefixes])
+    tab.close_search()
