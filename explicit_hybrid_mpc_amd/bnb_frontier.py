@@ -120,8 +120,8 @@ def _lookup(kids, exact, bound, guard, N):
     """
     What is already known about the suboptimality-test optimum t* of the prefixes ``kids`` on a
     node: ``exact`` holds values solved on THIS node (same simplex, same vertex costs: (t, alpha
-    or None)), ``bound`` upper bounds inherited from an ancestor (module docstring of
-    ``grow_frontier``) -- those only refute.  Returns the list of (t, alpha) or None per kid.
+    or None)), ``bound`` upper bounds inherited from an ancestor (docstring of ``grow_frontier``) --
+    those only refute.  Returns the list of (t, alpha) or None per kid.
     """
     out = [None] * len(kids)
     for i, k in enumerate(kids):
@@ -443,6 +443,15 @@ def grow_frontier(oracle, branch, action='ecc', table_max=256, max_visits=None, 
     lcss node that bar_E leaves OPEN goes to the device engine when its region table -- bounded
     with its own commutation's vertex costs -- has at most ``table_max`` sequences (a node that
     closes at once needs no table).
+
+    What a node hands to its children (none of it changes a verdict, all of it saves problems):
+    an ecc node the sequence that was feasible at its barycentre (tried first at theirs); an lcss
+    node the optima its suboptimality-test searches solved -- a child lies inside its parent and,
+    the optimal cost of a commutation being convex, the interpolant of its vertex costs lies
+    below the parent's, so for every prefix t*(child) <= t*(parent) (+ the largest increase of a
+    vertex cost where a commutation with larger costs is adopted): upper bounds that refute, or
+    keep below the incumbent, without a solve -- and its best-slack sequence, which the
+    children's searches evaluate first.
     """
     from . import engine
     split_batch = split_batch or (lambda R: engine.split_batch(R, device=getattr(
