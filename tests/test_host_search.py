@@ -325,3 +325,45 @@ def test_a_failed_launch_leaves_the_search_state_usable():
     assert np.array_equal(tab.feasible_sets(prefixes, [sets[0]] * 3),
                           [all(tab.feasible(q, th) for th in sets[0]) for q in prefixes])
     tab.close_search()
+
+
+class _PyHalfSpace(PyPrefixSearch, HalfSpaceTable):
+    """The synthetic solver under the plain-Python memo and descents."""
+
+
+@pytest.mark.parametrize('seed', [0, 1, 2])
+def test_random_operation_sequences_against_the_python_statement(seed):
+    """The same random sequence of questions, midpoint registrations and memo resets put to the
+    native state and to the Python statement: the same answers throughout."""
+    nat, py = HalfSpaceTable(seed=20 + seed), _PyHalfSpace(seed=20 + seed)
+    rng = np.random.default_rng(seed)
+    pool = rng.uniform(-0.5, 0.5, (40, 3))
+    prefixes = [q for k in range(1, 5) for q in itertools.product(range(3), repeat=k)]
+    for step in range(120):
+        op = rng.integers(0, 10)
+        if op < 4:                                   # feasible_sets on ragged sets
+            n = int(rng.integers(1, 12))
+            pick = [prefixes[k] for k in rng.integers(0, len(prefixes), n)]
+            sets = [pool[rng.integers(0, len(pool), int(rng.integers(1, 5)))] for _ in range(n)]
+            assert np.array_equal(nat.feasible_sets(pick, sets), py.feasible_sets(pick, sets)), step
+        elif op < 7:                                 # descents, some with a blacklist
+            n = int(rng.integers(1, 8))
+            sets = [pool[rng.integers(0, len(pool), int(rng.integers(1, 4)))] for _ in range(n)]
+            excl = None
+            if op == 6:
+                excl = [[prefixes[k] for k in rng.integers(len(prefixes) - 81, len(prefixes), 3)]
+                        for _ in range(n)]
+            assert nat.first_feasible_many(sets, excl) == py.first_feasible_many(sets, excl), step
+        elif op < 9:                                 # new points: midpoints of known ones
+            i, j = rng.integers(0, len(pool), (2, 5))
+            mids = 0.5 * (pool[i] + pool[j])
+            nat.register_midpoints(mids, pool[i], pool[j])
+            py.register_midpoints(mids, pool[i], pool[j])
+            pool = np.vstack([pool, mids])
+        else:                                        # the memo is dropped
+            nat.FEAS_MEMO_LIMIT = py.FEAS_MEMO_LIMIT = -1
+            q = prefixes[int(rng.integers(0, len(prefixes)))]
+            assert np.array_equal(nat.feasible_sets([q], [pool[:2]]), py.feasible_sets([q], [pool[:2]]))
+            nat.FEAS_MEMO_LIMIT = py.FEAS_MEMO_LIMIT = 3000000
+    assert len(nat.asked) <= len(py.asked)           # never more problems than the Python form
+    nat.close_search()
