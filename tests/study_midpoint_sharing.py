@@ -9,6 +9,8 @@ midpoint LP per split where one per distinct midpoint would do.  This script gro
 instance with the CPU oracle (one process per Delaunay root) and counts both.
 
     python -m tests.study_midpoint_sharing [abs_frac=0.1] [eps_r=0.01] [procs=8] [max_visits_per_root]
+    EHM_STUDY_INSTANCE=config4 selects the six-dimensional single-commutation instance of
+    bench.py --workload config4 (a budget of visits per root keeps it within minutes).
 """
 import multiprocessing as mp
 import sys
@@ -17,12 +19,20 @@ import time
 import numpy as np
 
 
+def _instance(seed):
+    import os
+    from explicit_hybrid_mpc_amd import examples
+    if os.environ.get('EHM_STUDY_INSTANCE') == 'config4':
+        return examples.integrator_chain_mpc()
+    return examples.linear_mpc(seed=seed)
+
+
 def _grow(job):
     seed, eps_a, eps_r, root, loc, max_visits = job
     from explicit_hybrid_mpc_amd import examples
     from oracle.oracle_cpu import OracleCPU
     from oracle.partition_cpu import PartitionCPU
-    orc = OracleCPU(examples.linear_mpc(seed=seed), eps_a, eps_r)
+    orc = OracleCPU(_instance(seed), eps_a, eps_r)
     part = PartitionCPU(orc, max_nodes=max_visits)
     part.run([root], [loc], 'ecc')
     mids, depth = [], []
@@ -44,7 +54,7 @@ def main():
     from explicit_hybrid_mpc_amd import examples
     from oracle.oracle_cpu import OracleCPU
     from oracle import geometry
-    mpc = examples.linear_mpc(seed=0)
+    mpc = _instance(0)
     V = examples.box_vertices(examples.theta_box(mpc))
     eps_a = max(OracleCPU(mpc, 1., 1.).P_theta(abs_frac * v)[2] for v in V)
     roots, locs = geometry.delaunay_simplices(V)
