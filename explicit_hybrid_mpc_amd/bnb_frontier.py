@@ -106,6 +106,7 @@ def p_theta_many(oracle, thetas):
 INHERIT_GUARD = 1e-6     # an inherited bound counts only by more than INHERIT_GUARD (1 + max |V|): ten
                          # times the accuracy the device solver's optima are compared at (1e-7)
 LAUNCH_TARGET = 4096     # problems a best-first step aims at per launch
+INHERIT_MAX = 8192       # bounds a node hands down before the non-refuting ones are dropped
 
 
 def _batch_size(n_active, n_modes):
@@ -554,6 +555,8 @@ def grow_frontier(oracle, branch, action='ecc', table_max=256, max_visits=None, 
                 # is the first thing their searches evaluate
                 down = dict(bounds[k]) if bounds[k] else {}
                 down.update((q, v[0]) for q, v in learned[k].items())
+                if len(down) > INHERIT_MAX:     # keep what refutes; the rest only orders bar_D
+                    down = {q: t for q, t in down.items() if t < 0.}
                 down = (down, stars[w])
                 if delta_star is None:
                     to_split.append((lcss[k], data.commutation, data.vertex_costs,
