@@ -54,8 +54,9 @@ def _solve_points(job):
             J[k - lo] = res.fun
         else:
             res = linprog(c, A_ub=g, b_ub=rhs, bounds=(None, None), method='highs')
-            J[k - lo] = res.fun
-            u0[k - lo] = res.x[:_SH['n_u']]
+            J[k - lo] = res.fun if res.status == 0 else np.nan
+            if res.status == 0:
+                u0[k - lo] = res.x[:_SH['n_u']]
     return J, u0
 
 
@@ -93,7 +94,9 @@ def _solve_simplices(job):
         Aeq = np.zeros((1, A.shape[1]))
         Aeq[0, n:n + na] = 1.
         res = linprog(cc, A_ub=A, b_ub=b, A_eq=Aeq, b_eq=[1.], bounds=bounds, method='highs')
-        obj[k - lo] = (-res.fun if mode == 1 else res.fun) if res.status == 0 else np.inf
+        # (an optimisation problem that comes back infeasible was sent without its phase one:
+        # the device solver would not notice -- counted, must stay 0)
+        obj[k - lo] = (-res.fun if mode == 1 else res.fun) if res.status == 0 else np.nan
         if res.status == 0:
             alpha[k - lo] = res.x[n:n + na]
     return obj, alpha
@@ -154,6 +157,10 @@ class PooledStubProblem:
         PooledStubProblem.launches += 1
         PooledStubProblem.problems += n
         kind = 'point phase one' if feas else 'point optimum'
+        bad = int(np.isnan(J).sum())
+        if bad:
+            PooledStubProblem.by_kind['UNSOLVABLE ' + kind] = \
+                PooledStubProblem.by_kind.get('UNSOLVABLE ' + kind, 0) + bad
         PooledStubProblem.by_kind[kind] = PooledStubProblem.by_kind.get(kind, 0) + n
         return J, u0, np.zeros(n, dtype=np.int32)
 
@@ -173,6 +180,11 @@ class PooledStubProblem:
         PooledStubProblem.launches += 1
         PooledStubProblem.problems += n
         kind = ('simplex min', 'simplex slack', 'simplex phase one')[mode]
+        bad = int(np.isnan(obj).sum())
+        if bad:
+            PooledStubProblem.by_kind['UNSOLVABLE ' + kind] = \
+                PooledStubProblem.by_kind.get('UNSOLVABLE ' + kind, 0) + bad
+            obj = np.where(np.isnan(obj), np.inf, obj)
         PooledStubProblem.by_kind[kind] = PooledStubProblem.by_kind.get(kind, 0) + n
         return obj, alpha, np.zeros(n, dtype=np.int32)
 
