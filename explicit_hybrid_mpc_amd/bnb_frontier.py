@@ -610,4 +610,10 @@ def grow_frontier(oracle, branch, action='ecc', table_max=256, max_visits=None, 
                     nd.grow(NodeData(vertices=S1[k].copy()), NodeData(vertices=S2[k].copy()))
                     work.append((nd.left, 'ecc', wit))
                     work.append((nd.right, 'ecc', wit))
+    # what the searches did not have to solve
+    stats['prefixes_answered_by_inheritance'] = oracle.n_inherited
+    stats['optima_asked_solved'] = (getattr(oracle.table, 'optima_asked', 0),
+                                    getattr(oracle.table, 'optima_solved', 0))
+    if hasattr(oracle.table, 'search_counts') and getattr(oracle.table, '_search', None):
+        stats['memo_verdicts_points_pairs_shared'] = oracle.table.search_counts()
     return stats
