@@ -130,7 +130,8 @@ class PrefixSearch:
         if not len(prefixes):
             return np.zeros(0)
         pairs = [q for q in prefixes for _ in range(ns)]
-        J = self.solve_min(pairs, np.tile(simplices, (len(prefixes), 1, 1)))
+        tiled = np.tile(simplices, (len(prefixes), 1, 1))
+        J = self.solve_min(pairs, tiled, self.feasible_somewhere(pairs, tiled))
         return J.reshape(len(prefixes), ns).min(axis=1)
 
     OPTIMA_MEMO_LIMIT = 2000000
