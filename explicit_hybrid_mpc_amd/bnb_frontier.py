@@ -362,11 +362,17 @@ def bar_d_many(oracle, Rs, Vs, deltas_ref, bound=None, learned=None, incumbents=
     return out
 
 
-def region_tables_many(oracle, Rs, commutations, Us, table_max):
+def region_tables_many(oracle, Rs, commutations, Us, table_max, above=None, costs=None,
+                       excess=None):
     """
     Region tables (``sequences.relevant_sequences``) of many lcss nodes: the bound U of a node
     is the largest vertex cost of ITS commutation (feasible at every vertex, so V* <= U on the
     node).  Returns a list of sorted sequence lists, None where more than ``table_max`` survive.
+    ``above[j]``: minimum costs of prefix relaxations over a region that CONTAINS node j (its
+    parent's, dict prefix -> cost): the minimum over the node is at least that, so a prefix the
+    larger region already prices above U needs no problem; ``costs[j]`` (a dict, filled here):
+    the minima found on node j, for its children; ``excess[j]`` (a list of n zeros, filled
+    here): where the table did not fit, survivors / table_max at the level that broke it.
     """
     table, mpc = oracle.table, oracle.mpc
     n_modes = mpc.delta_size
@@ -377,20 +383,30 @@ def region_tables_many(oracle, Rs, commutations, Us, table_max):
     for _ in range(mpc.N):
         if not active:
             break
-        pre, Rp = [], []
+        pre, Rp, ask_of = [], [], {}
         for j in active:
             cand = [q + (i,) for q in alive[j] for i in range(n_modes)]
+            if above is not None and above[j]:
+                known = above[j]
+                cand = [q for q in cand if not known.get(q, -np.inf) > bounds[j]]
+                oracle.n_inherited += n_modes * len(alive[j]) - len(cand)
             alive[j] = cand
             pre.extend(cand)
             Rp.extend([Rs[j]] * len(cand))
+        if not pre:
+            break
         Ra = np.array(Rp)
         cost = table.solve_min(pre, Ra, table.feasible_somewhere(pre, Ra))
         pos, still = 0, []
         for j in active:
             c = cost[pos:pos + len(alive[j])]
             pos += len(alive[j])
+            if costs is not None:
+                costs[j].update(zip(alive[j], (float(v) for v in c)))
             alive[j] = [q for q, cq in zip(alive[j], c) if cq <= bounds[j]]
             if len(alive[j]) > table_max:
+                if excess is not None:
+                    excess[j] = len(alive[j]) / float(table_max)
                 alive[j] = None
             else:
                 still.append(j)
@@ -405,13 +421,15 @@ def region_tables_many(oracle, Rs, commutations, Us, table_max):
     return out
 
 
-def _hand_off(oracle, nodes, table_max, engine_opts, stats):
-    """Nodes (lcss, open) whose region table fits go to the device engine; returns the rest."""
+def _hand_off(oracle, nodes, table_max, engine_opts, stats, above=None, costs=None, excess=None):
+    """Nodes (lcss, open) whose region table fits go to the device engine; returns the rest.
+    ``above`` / ``costs``: see ``region_tables_many``."""
     from . import engine, partition
     mpc = oracle.mpc
     Rs = [np.asarray(nd.data.vertices, dtype=np.float64) for nd in nodes]
     tables = region_tables_many(oracle, Rs, [nd.data.commutation for nd in nodes],
-                                [float(np.max(nd.data.vertex_costs)) for nd in nodes], table_max)
+                                [float(np.max(nd.data.vertex_costs)) for nd in nodes], table_max,
+                                above, costs, excess)
     keep = []
     for k, (nd, R, seqs) in enumerate(zip(nodes, Rs, tables)):
         if seqs is None:
@@ -436,14 +454,18 @@ def _hand_off(oracle, nodes, table_max, engine_opts, stats):
 
 
 def grow_frontier(oracle, branch, action='ecc', table_max=256, max_visits=None, handoff=True,
-                  engine_opts=None, split_batch=None, round_cap=4096, log=None):
+                  engine_opts=None, split_batch=None, round_cap=4096, log=None,
+                  table_backoff=False):
     """
     ``bnb.grow`` with all pending nodes visited together (module docstring).  Same arguments and
     the same tree; ``round_cap`` bounds the nodes of one round, ``split_batch(R (n,p+1,p)) ->
     (S1, S2, ij)`` replaces the device bisection kernel (``engine.split_batch``).  Hand-off: an
     lcss node that bar_E leaves OPEN goes to the device engine when its region table -- bounded
     with its own commutation's vertex costs -- has at most ``table_max`` sequences (a node that
-    closes at once needs no table).
+    closes at once needs no table).  ``table_backoff``: a node whose table did not fit by a
+    factor f lets floor(log2 f) generations of its descendants pass before a table is tried
+    again (a failed attempt costs more problems than the node's searches; the tree does not
+    depend on it -- off by default until it has been measured on the device).
 
     What a node hands to its children (none of it changes a verdict, all of it saves problems):
     an ecc node the sequence that was feasible at its barycentre (tried first at theirs); an lcss
@@ -459,7 +481,8 @@ def grow_frontier(oracle, branch, action='ecc', table_max=256, max_visits=None, 
         oracle.table, 'device', 0)))
     mpc = oracle.mpc
     stats = dict(host_visits=0, rounds=0, handoffs=0, handoff_nodes=0, handoff_leaves=0,
-                 table_sizes=[], tables_too_large=0, truncated=False, witness_hits=0)
+                 table_sizes=[], tables_too_large=0, truncated=False, witness_hits=0,
+                 table_attempts_skipped=0)
     # one Tree or a list of them (the Delaunay roots of the set: their nodes share the rounds)
     # work items: (node, action, witness) -- the witness of an ecc node is a mode sequence that was
     # feasible at its parent's barycentre (None at a root)
@@ -479,6 +502,8 @@ def grow_frontier(oracle, branch, action='ecc', table_max=256, max_visits=None, 
         # parent's best-slack sequence), or None
         bounds = [b[0] if b else None for _, act, b in batch if act != 'ecc']
         incumbents = [b[1] if b else None for _, act, b in batch if act != 'ecc']
+        region_costs = [b[2] if b else None for _, act, b in batch if act != 'ecc']
+        waits = [b[3] if b else 0 for _, act, b in batch if act != 'ecc']
         stats['host_visits'] += len(ecc) + len(lcss)
         if log:
             log('round %d: %d ecc + %d lcss nodes, %d waiting' %
@@ -540,9 +565,21 @@ def grow_frontier(oracle, branch, action='ecc', table_max=256, max_visits=None, 
             for k, c in enumerate(closed):
                 if c:
                     lcss[k].data.is_epsilon_suboptimal = True
+            table_costs = {}
+            next_wait = {k: max(0, waits[k] - 1) for k in opened}
             if handoff and opened:          # the open ones: to the engine where the table fits
-                keep = _hand_off(oracle, [lcss[k] for k in opened], table_max, engine_opts, stats)
-                opened = [opened[k] for k in keep]
+                tried = [k for k in opened if not (table_backoff and waits[k] > 0)]
+                stats['table_attempts_skipped'] += len(opened) - len(tried)
+                table_costs = {k: dict() for k in tried}
+                excess = [0.] * len(tried)
+                keep = _hand_off(oracle, [lcss[k] for k in tried], table_max, engine_opts, stats,
+                                 [region_costs[k] for k in tried],
+                                 [table_costs[k] for k in tried], excess) if tried else []
+                for k, f in zip(tried, excess):
+                    if f >= 2.:
+                        next_wait[k] = int(np.floor(np.log2(f)))
+                kept = {tried[k] for k in keep}
+                opened = [k for k in opened if k in kept or k not in table_costs]
             stars = []
             res = bar_d_many(oracle, [Rs[k] for k in opened], [Vs[k] for k in opened],
                              [lcss[k].data.commutation for k in opened],
@@ -557,7 +594,13 @@ def grow_frontier(oracle, branch, action='ecc', table_max=256, max_visits=None, 
                 down.update((q, v[0]) for q, v in learned[k].items())
                 if len(down) > INHERIT_MAX:     # keep what refutes; the rest only orders bar_D
                     down = {q: t for q, t in down.items() if t < 0.}
-                down = (down, stars[w])
+                # the minima of prefix relaxations over this node, for the children's region
+                # tables (a child's minimum is at least its parent's: geometry alone)
+                below = dict(region_costs[k]) if region_costs[k] else {}
+                below.update(table_costs.get(k, {}))
+                if len(below) > INHERIT_MAX:
+                    below = {}
+                down = (down, stars[w], below, next_wait[k])
                 if delta_star is None:
                     to_split.append((lcss[k], data.commutation, data.vertex_costs,
                                      data.vertex_inputs, down))
@@ -569,7 +612,7 @@ def grow_frontier(oracle, branch, action='ecc', table_max=256, max_visits=None, 
                 # largest increase, and so does every t*
                 rise = float(np.max(costs - np.asarray(data.vertex_costs)))
                 if rise > 0.:
-                    down = ({q: t + rise for q, t in down[0].items()}, down[1])
+                    down = ({q: t + rise for q, t in down[0].items()}, down[1], down[2], down[3])
                 if small:                   # lib/worker.py:396-401
                     data.commutation, data.vertex_costs, data.vertex_inputs = (delta_star, costs,
                                                                                 inputs)

@@ -242,8 +242,27 @@ def main():
     PooledStubProblem.by_kind = {}
     t0 = time.perf_counter()
     branch = Tree(NodeData(vertices=R.copy()))
+    tables = bool(os.environ.get('EHM_TABLES'))
+    if tables:
+        # region tables as the hand-off computes them for every open lcss node, WITHOUT the device
+        # engine behind them (nothing is handed off): what the tables themselves cost;
+        # EHM_TABLES=cold computes them without what the parents found
+        cold = os.environ['EHM_TABLES'] == 'cold'
+
+        def tables_only(oracle, nodes, table_max, engine_opts, stats, above=None, costs=None,
+                        excess=None):
+            Rs = [np.asarray(nd.data.vertices, dtype=np.float64) for nd in nodes]
+            out = bnb_frontier.region_tables_many(
+                oracle, Rs, [nd.data.commutation for nd in nodes],
+                [float(np.max(nd.data.vertex_costs)) for nd in nodes], table_max,
+                None if cold else above, costs, excess)
+            stats['table_sizes'] += [len(t) for t in out if t is not None]
+            stats['tables_too_large'] += sum(t is None for t in out)
+            return list(range(len(nodes)))
+        bnb_frontier._hand_off = tables_only
     run = lambda: bnb_frontier.grow_frontier(
-        orc, branch, 'ecc', max_visits=visits, round_cap=16384, handoff=False,
+        orc, branch, 'ecc', max_visits=visits, round_cap=16384, handoff=tables,
+        table_backoff=bool(os.environ.get('EHM_TABLE_BACKOFF')),
         split_batch=host_split_batch,
         log=lambda m: print('  ', m, '%.1fs (solver stand-in %.1fs)' % (
             time.perf_counter() - t0, PooledStubProblem.busy), flush=True))
@@ -264,7 +283,9 @@ def main():
               PooledStubProblem.launches, orc.table.blocks_loaded, wall, PooledStubProblem.busy,
               wall - PooledStubProblem.busy,
               1e6 * (wall - PooledStubProblem.busy) / max(stats['host_visits'], 1)), flush=True)
-    print('problems by kind', PooledStubProblem.by_kind, 'oracle calls', dict(orc.calls), flush=True)
+    print('problems by kind', PooledStubProblem.by_kind, 'oracle calls', dict(orc.calls),
+          'driver', {k: (v if k != 'table_sizes' else sorted(v)[-5:]) for k, v in stats.items()},
+          flush=True)
     orc.close()
 
 
