@@ -367,3 +367,44 @@ def test_random_operation_sequences_against_the_python_statement(seed):
             nat.FEAS_MEMO_LIMIT = py.FEAS_MEMO_LIMIT = 3000000
     assert len(nat.asked) <= len(py.asked)           # never more problems than the Python form
     nat.close_search()
+
+
+def test_region_tables_with_the_parents_minima():
+    """region_tables_many with ``above``: a child's minimum of a prefix relaxation is at least its
+    parent's, so what the parent's region prices above the child's bound is not solved again --
+    the same tables from fewer problems; the level that breaks a table is reported."""
+    mpc = examples.pwa4_mpc()                            # 4 modes, N = 4: 256 sequences
+    half = examples.theta_box(mpc)
+    E = np.vstack([np.zeros(8), np.eye(8)]) - 1. / 9.
+    V = examples.box_vertices(half)
+    table = prefix_bb.CpuPrefixTable(mpc)
+    bo = bnb.PrefixOracle(mpc, 0.01, 0.02, table=table)
+    parents = [0.8 * V[37] + 0.08 * half * E, 0.7 * V[100] + 0.05 * half * E]
+    kids = [0.5 * (R + R[k]) for R, k in zip(parents, (0, 3))]          # inside their parents
+    def record(Rs):
+        comms, tops = [], []
+        for R in Rs:
+            delta, vx = bo.V_R(R)
+            comms.append(delta)
+            tops.append(max(v[1] for v in vx))
+        return comms, tops
+    pc, pt = record(parents)
+    minima = [dict(), dict()]
+    ptab = bnb_frontier.region_tables_many(bo, parents, pc, pt, 256, None, minima)
+    assert all(t is not None for t in ptab) and all(len(m) > 50 for m in minima)
+    kc, kt = record(kids)
+    n0 = table.lp_solves
+    cold = bnb_frontier.region_tables_many(bo, kids, kc, kt, 256)
+    n1 = table.lp_solves
+    own = [dict(), dict()]
+    warm = bnb_frontier.region_tables_many(bo, kids, kc, kt, 256, minima, own)
+    n2 = table.lp_solves
+    assert warm == cold and all(t is not None for t in cold)
+    assert n2 - n1 < n1 - n0
+    for m_kid, m_par in zip(own, minima):                # the bound itself
+        for q, c in m_kid.items():
+            if q in m_par and np.isfinite(m_par[q]):
+                assert c >= m_par[q] - 1e-7 * (1 + abs(c))
+    excess = [0., 0.]
+    assert bnb_frontier.region_tables_many(bo, kids, kc, kt, 4, None, None, excess) == [None, None]
+    assert all(f > 1. for f in excess)
