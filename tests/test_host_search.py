@@ -408,3 +408,60 @@ def test_region_tables_with_the_parents_minima():
     excess = [0., 0.]
     assert bnb_frontier.region_tables_many(bo, kids, kc, kt, 4, None, None, excess) == [None, None]
     assert all(f > 1. for f in excess)
+
+
+def test_driver_bookkeeping_when_some_nodes_are_handed_off(monkeypatch):
+    """The hand-off removes nodes from a round between bar_E and bar_D; what the remaining ones
+    inherit and hand down must stay aligned with them.  The device engine is replaced by a stand-in
+    that takes every other open node (and leaves it to the enumerating CPU partition to finish),
+    with and without the back-off of table attempts: the rest of the tree is the enumerating
+    partition's."""
+    from oracle.oracle_cpu import OracleCPU
+    from oracle.partition_cpu import PartitionCPU
+    mpc = helpers.make_instance('pwa_small', 0)
+    eps_a, eps_r = helpers.eps_a_rule(mpc, 0.2), 0.1
+    roots, locs = helpers.roots_of(mpc)
+    cpu = PartitionCPU(OracleCPU(mpc, eps_a, eps_r))
+    cpu.run(roots, locs, 'ecc')
+    for backoff in (False, True):
+        orc = bnb.PrefixOracle(mpc, eps_a, eps_r, table=prefix_bb.CpuPrefixTable(mpc))
+        taken = []
+
+        def fake_hand_off(oracle, nodes, table_max, engine_opts, stats, above=None, costs=None,
+                          excess=None):
+            Rs = [np.asarray(nd.data.vertices) for nd in nodes]
+            tabs = bnb_frontier.region_tables_many(
+                oracle, Rs, [nd.data.commutation for nd in nodes],
+                [float(np.max(nd.data.vertex_costs)) for nd in nodes], table_max, above, costs,
+                excess)
+            keep = []
+            for k, nd in enumerate(nodes):
+                if tabs[k] is not None and len(taken) % 2 == 0:
+                    taken.append(nd)                     # "the engine grows this subtree"
+                    stats['handoffs'] += 1
+                else:
+                    if tabs[k] is not None:
+                        taken.append(None)
+                    keep.append(k)
+            return keep
+        monkeypatch.setattr(bnb_frontier, '_hand_off', fake_hand_off)
+        trees = [Tree(NodeData(vertices=np.array(R))) for R in roots]
+        stats = bnb_frontier.grow_frontier(orc, trees, 'ecc', handoff=True, table_max=8,
+                                           split_batch=_host_split_batch, table_backoff=backoff)
+        assert not stats['truncated']
+        handed = {id(nd) for nd in taken if nd is not None}
+        n = 0
+        for t, loc0 in zip(trees, locs):
+            for nd, loc in t.walk(loc0):
+                r = cpu.nodes[loc]
+                assert np.array_equal(nd.data.vertices, r['vertices'])
+                if id(nd) in handed:
+                    assert nd.is_leaf() and not r['is_epsilon_suboptimal']     # left to the engine
+                    continue
+                n += 1
+                assert nd.is_leaf() == r['leaf']
+                assert nd.data.is_epsilon_suboptimal == r['is_epsilon_suboptimal']
+                if r['commutation'] is not None:
+                    assert np.array_equal(nd.data.commutation.astype(int),
+                                          r['commutation'].astype(int))
+        assert n > len(roots) and stats['handoffs'] == len(handed) >= 1
