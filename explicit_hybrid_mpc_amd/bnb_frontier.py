@@ -383,7 +383,7 @@ def region_tables_many(oracle, Rs, commutations, Us, table_max, above=None, cost
     for _ in range(mpc.N):
         if not active:
             break
-        pre, Rp, ask_of = [], [], {}
+        pre, Rp = [], []
         for j in active:
             cand = [q + (i,) for q in alive[j] for i in range(n_modes)]
             if above is not None and above[j]:

@@ -71,7 +71,7 @@ def test_descents_against_enumeration_and_every_pair_solved_once():
     assert sum(q is not None for q in want) >= 10 and any(q is None for q in want)
     # nothing was solved twice, although set 0 and its copy descend side by side
     assert len(tab.asked) == len(set(tab.asked))
-    held, points, handed, shared = tab.search_counts()
+    _, points, handed, shared = tab.search_counts()
     assert handed == len(tab.asked) and shared > 0 and points == len({p.tobytes() for s in sets for p in s})
     # a second pass costs nothing
     n = len(tab.asked)

@@ -116,7 +116,6 @@ class PooledStubProblem:
     def __init__(self, can, eps_a, eps_r, device=0):
         self.can = can
         self.eps_a, self.eps_r = eps_a, eps_r
-        slots, m, n = can.G.shape
         p = can.S.shape[2]
         _SH['G'], _SH['w'], _SH['S'] = _shared(can.G.shape), _shared(can.w.shape), _shared(can.S.shape)
         _SH['G'][:], _SH['w'][:], _SH['S'][:] = can.G, can.w, can.S
