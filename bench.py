@@ -412,7 +412,8 @@ def main():
         del flat
     # totals over ranks (max time, summed work)
     keys = ['lp_solves', 'ipm_iters', 'n_nodes', 'n_closed', 'ref_solves', 'decide_solves',
-            'decide_iters', 'cert_closed', 'witness_open', 'witness_inherited']
+            'decide_iters', 'cert_closed', 'witness_open', 'witness_inherited',
+            'midpoints_shared']
     if rank > 0:
         # the top of the tree is grown identically on every rank: count it once (rank 0)
         for i in infos:
@@ -530,6 +531,7 @@ def main():
                 'leaves_closed_without_lp_per_step': agg['cert_closed'] / K,
                 'nodes_proved_open_by_midpoint_per_step': agg['witness_open'] / K,
                 'nodes_proved_open_by_inherited_witness_per_step': agg['witness_inherited'] / K,
+                'midpoint_optima_taken_from_the_table_per_step': agg['midpoints_shared'] / K,
                 'mean_ipm_iterations': agg['ipm_iters'] / max(agg['lp_solves'], 1),
                 'sweeps': info0['sweeps'], 'tree_depth': info0['max_depth'],
                 'min_decision_margin': info0['min_margin'],

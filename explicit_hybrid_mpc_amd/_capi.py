@@ -91,7 +91,8 @@ class TreeInfo(ctypes.Structure):
                 ('cert_closed', ctypes.c_int64), ('witness_open', ctypes.c_int64),
                 ('swaps', ctypes.c_int64), ('blacklisted', ctypes.c_int64),
                 ('kind_solves', ctypes.c_int64 * 5), ('kind_iters', ctypes.c_int64 * 5),
-                ('near_threshold', ctypes.c_int64), ('witness_inherited', ctypes.c_int64)]
+                ('near_threshold', ctypes.c_int64), ('witness_inherited', ctypes.c_int64),
+                ('midpoints_shared', ctypes.c_int64)]
 
 
 class Progress(ctypes.Structure):

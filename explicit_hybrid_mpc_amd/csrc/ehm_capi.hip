@@ -483,6 +483,9 @@ struct ehm_problem {
     int mid_first = 1;       // 1 = persistent kernel with the midpoint solve first (default)
     int inherit_wit = 1;     // 1 = open nodes hand the point that proved them open to the child
                              // that contains it (DevTree::wit; option "inherit_witness")
+    int share_mid = 1;       // 1 = the persistent kernel keeps a table of midpoint optima: the
+                             // simplices around an edge solve its midpoint once (DevTree::mt;
+                             // option "share_midpoints")
     int hy_timing = 0;       // 1 = event pairs + counter snapshots around every batch of the
                              // multi-commutation engine (kernel seconds, solves by kind)
     int solver_gen = 2;      // 1 = one wavefront per workgroup (ehm_kernels.h), 2 = ehm_k2.hip
@@ -493,13 +496,16 @@ struct ehm_problem {
     // cost milliseconds): the pool of the last destroyed tree and the frontier scratch
     struct PoolCache {
         long long cap = 0;
-        DevBuf rec, left, didx, depth, flags, tstar, grad, wit;
+        DevBuf rec, left, didx, depth, flags, tstar, grad, wit, mt_state, mt_data;
     } pool_cache;
     DevBuf fr_a, fr_b, open_flag, open_list, d_count;
     DevBuf pq_slots, pq_ctl;   // persistent engine: queue slots, control block
     DevBuf in0, in1, in2, out0, out1, out2, out3;
     DevCounters* d_cnt = nullptr;
     struct ehm_tree* active_run = nullptr;   // the partition run that owns the scratch above
+    // every tree made from this handle that is still alive: ehm_problem_destroy detaches them, so
+    // a tree destroyed (or asked about) AFTER its problem never touches freed memory
+    std::vector<struct ehm_tree*> trees;
     long long launches = 0;
     long long fallbacks = 0;   // LPs handed from the generation-2 to the generation-1 kernels
     long long slivers = 0;     // (simplex, commutation) pairs dropped as interior-free (slack_all)
@@ -510,12 +516,13 @@ struct ehm_problem {
 struct HyState;      // multi-commutation engine (ehm_hybrid.h)
 
 struct ehm_tree {
-    ehm_problem* prob = nullptr;
+    ehm_problem* prob = nullptr;     // nullptr once the problem handle has been destroyed
+    int device = 0;
     HyState* hy = nullptr;
     DevTree dt{};
     long long cap = 0;       // allocated node records (a cached pool may be larger than asked for)
     long long limit = 0;     // max_nodes of this run: the capacity the caller agreed to
-    DevBuf rec, left, didx, depth, flags, tstar, grad, code, wit;
+    DevBuf rec, left, didx, depth, flags, tstar, grad, code, wit, mt_state, mt_data;
     ehm_tree_info info{};
     int skip_volume = 0;
     // persistent engine: node ids follow the allocation order; the export relabels them to the
@@ -859,6 +866,14 @@ int ehm_problem_destroy(ehm_problem* P) {
     if (!P) return EHM_OK;
     (void)hipSetDevice(P->device);
     if (P->stream) (void)hipStreamSynchronize(P->stream);
+    // an unfinished run, or a finished tree the caller still holds, outlives the handle as an
+    // orphan: its own buffers stay valid until ehm_tree_destroy, everything else is refused
+    for (ehm_tree* T : P->trees) {
+        T->prob = nullptr;
+        T->run.active = false;
+    }
+    P->trees.clear();
+    P->active_run = nullptr;
     P->consts.release();
     P->wc2.release();
     P->wr3.release();
@@ -996,6 +1011,10 @@ int ehm_problem_set_option(ehm_problem* P, const char* name, double value) {
     }
     if (!strcmp(name, "inherit_witness")) {
         P->inherit_wit = value != 0.0;
+        return EHM_OK;
+    }
+    if (!strcmp(name, "share_midpoints")) {
+        P->share_mid = value != 0.0;
         return EHM_OK;
     }
     return fail(EHM_E_INVALID, "unknown option '%s'", name);
@@ -1879,8 +1898,12 @@ static int read_counters(ehm_problem* P, DevCounters& c);
 
 int ehm_tree_destroy(ehm_tree* T) {
     if (!T) return EHM_OK;
-    if (T->prob) (void)hipSetDevice(T->prob->device);
+    (void)hipSetDevice(T->device);
     if (T->prob && T->prob->active_run == T) T->prob->active_run = nullptr;
+    if (T->prob) {
+        auto& v = T->prob->trees;
+        v.erase(std::remove(v.begin(), v.end(), T), v.end());
+    }
     if (T->hy) {
         T->hy->release();
         delete T->hy;
@@ -1896,11 +1919,12 @@ int ehm_tree_destroy(ehm_tree* T) {
         std::swap(c.rec, T->rec); std::swap(c.left, T->left); std::swap(c.didx, T->didx);
         std::swap(c.depth, T->depth); std::swap(c.flags, T->flags); std::swap(c.tstar, T->tstar);
         std::swap(c.grad, T->grad); std::swap(c.wit, T->wit);
+        std::swap(c.mt_state, T->mt_state); std::swap(c.mt_data, T->mt_data);
         c.cap = T->cap;
     }
     T->rec.release(); T->left.release(); T->didx.release(); T->depth.release();
     T->flags.release(); T->tstar.release(); T->grad.release(); T->code.release();
-    T->wit.release();
+    T->wit.release(); T->mt_state.release(); T->mt_data.release();
     delete T;
     return EHM_OK;
 }
@@ -1914,6 +1938,7 @@ static int tree_alloc(ehm_tree* T, ehm_problem* P, long long cap) {
         std::swap(c.rec, T->rec); std::swap(c.left, T->left); std::swap(c.didx, T->didx);
         std::swap(c.depth, T->depth); std::swap(c.flags, T->flags); std::swap(c.tstar, T->tstar);
         std::swap(c.grad, T->grad); std::swap(c.wit, T->wit);
+        std::swap(c.mt_state, T->mt_state); std::swap(c.mt_data, T->mt_data);
         cap = c.cap;
         c.cap = 0;
     }
@@ -1934,7 +1959,24 @@ static int tree_alloc(ehm_tree* T, ehm_problem* P, long long cap) {
                       !getenv("EHM_NO_WITNESS");
     if (wits && (rc = T->wit.ensure((size_t)cap * (p + 2) * sizeof(double)))) return rc;
     T->dt.wit = wits ? T->wit.as<double>() : nullptr;
+    // table of midpoint optima (ehm_midtable.h): single commutation, linear cost, the
+    // midpoint-first persistent kernel.  One slot per two node records (a power of two): a
+    // partition has at most one distinct midpoint per split = per two nodes, and 7-8 splits
+    // share one in practice, so the table stays below 1/8 full
+    const bool mids = grads && !P->quadratic && P->mid_first && P->share_mid &&
+                      !getenv("EHM_NO_MIDTABLE");
+    T->dt.mt = MidTable{nullptr, nullptr, 0u};
+    if (mids) {
+        unsigned long long slots = 1024;
+        while (slots < (unsigned long long)cap / 2 && slots < (1ull << 30)) slots <<= 1;
+        if ((rc = T->mt_state.ensure((size_t)slots * sizeof(unsigned long long)))) return rc;
+        if ((rc = T->mt_data.ensure((size_t)slots * MT_DOUBLES * sizeof(double)))) return rc;
+        T->dt.mt = MidTable{T->mt_state.as<unsigned long long>(), T->mt_data.as<double>(),
+                            (unsigned int)(slots - 1)};
+    }
     T->prob = P;
+    T->device = P->device;
+    if (std::find(P->trees.begin(), P->trees.end(), T) == P->trees.end()) P->trees.push_back(T);
     T->cap = cap;
     T->dt.rec = T->rec.as<double>();
     T->dt.left = T->left.as<int32_t>();
@@ -2136,6 +2178,10 @@ int ehm_partition_begin(ehm_problem* P, int64_t n_roots, const double* root_vert
     if (T->dt.wit) {        // roots carry no witness
         hipError_t e = hipMemsetAsync(T->dt.wit, 0, (size_t)n_roots * (p + 2) * 8, P->stream);
         if (e != hipSuccess) RUN_TRY(fail(EHM_E_HIP, "witness buffer init failed"));
+    }
+    if (T->dt.mt.state) {   // an empty table (the payload needs no clearing)
+        hipError_t e = hipMemsetAsync(T->dt.mt.state, 0, ((size_t)T->dt.mt.mask + 1) * 8, P->stream);
+        if (e != hipSuccess) RUN_TRY(fail(EHM_E_HIP, "midpoint table init failed"));
     }
     {
         unsigned long long inf_bits = 0x7FF0000000000000ULL;
@@ -2713,6 +2759,7 @@ int ehm_partition_finish(ehm_tree* T) {
     T->info.cert_closed = (int64_t)(c1.cert_closed - R.c0.cert_closed);
     T->info.witness_open = (int64_t)(c1.wit_open - R.c0.wit_open);
     T->info.witness_inherited = (int64_t)(c1.wit_inherited - R.c0.wit_inherited);
+    T->info.midpoints_shared = (int64_t)(c1.mid_shared - R.c0.mid_shared);
     T->info.near_threshold = (int64_t)(c1.routed - R.c0.routed);
     T->info.replicated_closed = R.pre_closed;
     T->info.replicated_nodes = R.pre_nodes;
@@ -2772,6 +2819,7 @@ int ehm_partition_run(ehm_problem* P, int64_t n_roots, const double* root_vertic
 
 int ehm_tree_info_get(const ehm_tree* Tc, ehm_tree_info* out) {
     if (!Tc || !out) return fail(EHM_E_INVALID, "null argument");
+    if (!Tc->prob) return fail(EHM_E_INVALID, "the problem handle of this tree was destroyed");
     ehm_tree* T = const_cast<ehm_tree*>(Tc);
     if (T->info.volume_closed < 0.0 && !T->skip_volume) {
         // sum of closed-leaf volumes (lib/worker.py:374-375): a reduction kernel over the pool
@@ -2801,6 +2849,7 @@ int ehm_tree_export(const ehm_tree* Tc, double* vertices, int32_t* left, int32_t
                     int32_t* delta_idx, double* vcost, double* vinput, uint8_t* flags,
                     double* tstar) {
     if (!Tc) return fail(EHM_E_INVALID, "null tree");
+    if (!Tc->prob) return fail(EHM_E_INVALID, "the problem handle of this tree was destroyed");
     ehm_tree* T = const_cast<ehm_tree*>(Tc);
     ehm_problem* P = T->prob;
     HIP_TRY(hipSetDevice(P->device), EHM_E_HIP);

@@ -40,6 +40,10 @@ struct DevProblem {
     const double* c0q;  // [n_delta]
 };
 
+}  // namespace ehm
+#include "ehm_midtable.h"
+namespace ehm {
+
 // Node pool of the partition tree (structure of arrays of fixed-size records).
 //   rec[k] = [ vertices (p+1)*p | vertex_costs (p+1) | vertex_inputs (p+1)*n_u ]  (doubles)
 // which is the payload of the reference's NodeData (lib/tree.py:31-39).
@@ -73,6 +77,9 @@ struct DevTree {
     // EHM_WIT_REL x (slack proved at the ancestor).  All zero = no witness (the test then gives
     // min(-eps_a, 0)).  Null unless the run keeps them.
     double*  wit;
+    // table of midpoint optima shared by the wavefronts of the persistent frontier kernel
+    // (ehm_midtable.h); state == nullptr unless the run keeps one
+    MidTable mt;
 };
 
 // The iterate a witness comes from is not exactly feasible: the solver accepted it when its
@@ -194,6 +201,7 @@ struct DevCounters {
     unsigned long long wit_open;          // nodes proved open by their midpoint solve, no LP
     unsigned long long routed;            // decisions with |t*| < EHM_ROUTE_TOL (full-accuracy LP)
     unsigned long long wit_inherited;     // nodes proved open by an ancestor's witness, no LP
+    unsigned long long mid_shared;        // midpoint optima taken from the table, no LP
     unsigned int ticket;                  // work distribution of the wide sweep kernels: next
     unsigned int ticket_pad;              // frontier position (zeroed before every launch)
 };

@@ -373,8 +373,8 @@ __global__ __launch_bounds__(EHM_K2_THREADS) void k2_persist(
     double* wmargin = nb.aug + 16;
     enum { W_SOLVES = 0, W_ITERS, W_STALLED, W_ERRORS, W_SLACK, W_SLACK_ITERS, W_CLOSED, W_SPLITS,
            W_DEPTH, W_TRUNC, W_CERT, W_WIT, W_ROUTED, W_RCLOSED, W_RSPLITS, W_RSOLVES,
-           W_INH = 17 };        // slot 16 is *wmargin
-    if (lane0 < 18 && lane0 != 16) wst[lane0] = 0ULL;
+           W_INH = 17, W_MT = 18, W_MTPARK = 19 };        // slot 16 is *wmargin
+    if (lane0 < 20 && lane0 != 16) wst[lane0] = 0ULL;
     if (lane0 == 0) *wmargin = 1e300;
     wsync();
     for (;;) {
@@ -447,6 +447,7 @@ __global__ __launch_bounds__(EHM_K2_THREADS) void k2_persist(
         double* stash = nb.rec - 0 + (size_t)wave_doubles - 32;
         double* wit = stash + 16;
         bool have_wit = false;
+        int mt_res = MT_NONE;       // table of midpoint optima (ehm_midtable.h)
         int bi = 0, bj = 1;
         int its = 0;
         double Jm = 0.0;
@@ -481,6 +482,39 @@ __global__ __launch_bounds__(EHM_K2_THREADS) void k2_persist(
                 mid[lane] = (node[bi * p + lane] + node[bj * p + lane]) / 2.0;
             }
             wsync();
+            if (T.mt.state) {
+                // the simplices around an edge all ask for this midpoint: solve it once
+                unsigned int mt_i = 0u;
+                int mt_slot = 0;
+                const unsigned long long mt_tg = mt_tag(mid, p, T.mt.mask, &mt_i);
+                if (lane == 0)
+                    mt_res = mt_claim(T.mt, mt_tg, mt_i, t_start, EHM_PERSIST_WATCHDOG_TICKS,
+                                      &mt_slot);
+                mt_res = __builtin_amdgcn_readfirstlane(mt_res);
+                mt_slot = __builtin_amdgcn_readfirstlane(mt_slot);
+                if (mt_res == MT_HIT) {
+                    bool same = false;
+                    const double ev = mt_read(T.mt, mt_slot, lane, mid, p, &same);
+                    if (!same) {
+                        mt_res = MT_NONE;               // another midpoint with this tag
+                    } else {
+                        // entry layout: ehm_midtable.h
+                        const int word = (int)__shfl(ev, 9);
+                        Jm = __shfl(ev, 8);
+                        mid_status = word & 0xff;
+                        mid_conv = ((word >> 8) & 1) != 0;
+                        mid_iters = 0;                  // no iterations were spent here
+                        if (lane >= 10 && lane < 10 + n_u) stash[lane - 10] = ev;
+                        if (T.grad && lane >= 18 && lane < 18 + p) stash[8 + lane - 18] = ev;
+                        if (lane == 0) wst[W_MT] += 1;
+                    }
+                }
+                // what the code after the solve needs, parked in LDS: registers are what this
+                // kernel is short of while it solves
+                if (lane == 0) wst[W_MTPARK] = (unsigned long long)mt_res |
+                                               ((unsigned long long)mt_slot << 2);
+            }
+            if (mt_res != MT_HIT)
             {
             Wave Wm;
             IpmResult rm;
@@ -501,8 +535,19 @@ __global__ __launch_bounds__(EHM_K2_THREADS) void k2_persist(
             mid_iters = its;
             if (lane < n_u) stash[lane] = Wm.xb[lane];
             }
-            if (T.grad && lane < p) stash[8 + lane] = nb.F[lane];
+            if (mt_res != MT_HIT && T.grad && lane < p) stash[8 + lane] = nb.F[lane];
             wsync();
+            if (T.mt.state) {
+                const unsigned long long park = wst[W_MTPARK];
+                mt_res = (int)(park & 3ull);
+                if (mt_res == MT_OWN) {
+                    unsigned int mt_i = 0u;
+                    const unsigned long long mt_tg = mt_tag(mid, p, T.mt.mask, &mt_i);
+                    mt_publish(T.mt, (int)(park >> 2), mt_tg, lane, mid, p, Jm, mid_status,
+                               mid_conv ? 1 : 0, mid_iters, stash, n_u,
+                               T.grad ? stash + 8 : nullptr);
+                }
+            }
             if (sign_only && mid_conv && !decided) {
                 const double* Vc = node + rec_off_vcost(p);
                 const double vb = 0.5 * (Vc[bi] + Vc[bj]);
@@ -566,9 +611,11 @@ __global__ __launch_bounds__(EHM_K2_THREADS) void k2_persist(
         }
         if (lane == 0) {
             if (can_split) {        // the midpoint solve was done, whatever became of the node
-                wst[W_SOLVES] += 1;
-                if (dep < deal.depth) wst[W_RSOLVES] += 1;
-                wst[W_ITERS] += (unsigned long long)mid_iters;
+                if (mt_res != MT_HIT) {     // ... by this wavefront (else: taken from the table)
+                    wst[W_SOLVES] += 1;
+                    if (dep < deal.depth) wst[W_RSOLVES] += 1;
+                    wst[W_ITERS] += (unsigned long long)mid_iters;
+                }
                 if (mid_status != 0 && open) {
                     wst[W_STALLED] += 1;
                     wst[W_ERRORS] += 1;
@@ -840,6 +887,7 @@ __global__ __launch_bounds__(EHM_K2_THREADS) void k2_persist(
         if (wst[W_CERT]) atomicAdd(&cnt->cert_closed, wst[W_CERT]);
         if (wst[W_WIT]) atomicAdd(&cnt->wit_open, wst[W_WIT]);
         if (wst[W_INH]) atomicAdd(&cnt->wit_inherited, wst[W_INH]);
+        if (wst[W_MT]) atomicAdd(&cnt->mid_shared, wst[W_MT]);
         if (wst[W_ROUTED]) atomicAdd(&cnt->routed, wst[W_ROUTED]);
         atomicAdd(&ctl->closed, wst[W_CLOSED]);
         atomicAdd(&ctl->splits, wst[W_SPLITS]);

@@ -128,6 +128,11 @@ int ehm_problem_set_solver(ehm_problem* prob, int generation);
  * upper bound of the optimal cost there) to the child that contains it; the child is open
  * without an LP of its own while that point still beats its interpolated vertex costs by the
  * tolerance plus a safety margin (EHM_NO_WITNESS=1 disables);
+ * "share_midpoints" (0|1, default 1): the persistent frontier kernel keeps a table of midpoint
+ * optima in device memory -- the simplices around an edge all bisect it at the same point and,
+ * with one commutation, solve the same problem there; the first to ask solves and publishes,
+ * the others take the entry (csrc/ehm_midtable.h; identical tree, ehm_tree_info.midpoints_shared
+ * counts the problems saved; EHM_NO_MIDTABLE=1 disables);
  * "timing" (0|1, default 0): multi-commutation runs record an event pair and a counter snapshot
  * around every batched launch, so that ehm_tree_info carries kernel seconds and solves by problem
  * kind (bench.py sets it; ~25 extra stream commands per sweep otherwise spared). */
@@ -373,6 +378,8 @@ typedef struct ehm_tree_info {
     int64_t near_threshold;
     int64_t witness_inherited;  /* nodes proved open by the witness of an ancestor's
                                    suboptimality test (option "inherit_witness"), no LP     */
+    int64_t midpoints_shared;   /* splits whose midpoint optimum another simplex around the same
+                                   edge had solved already (option "share_midpoints"), no LP */
 } ehm_tree_info;
 
 int ehm_tree_info_get(const ehm_tree* tree, ehm_tree_info* out);

@@ -188,3 +188,57 @@ def test_inherited_witnesses_grow_the_same_tree():
         assert cells[rounds.vertices[k].tobytes()] == (rounds.left[k] < 0, rounds.flags[k] & 1)
     # a decision taken by a witness has a margin above the routing threshold
     assert new.info['min_margin'] == ref.info['min_margin']
+
+
+def test_shared_midpoint_optima_grow_the_same_tree():
+    """
+    Option "share_midpoints" (include/ehmpc.h, csrc/ehm_midtable.h): the simplices around an edge
+    ask for the same midpoint problem; the first wavefront to ask solves and publishes it, the
+    others take the entry.  Bit-identical tree and vertex data (an LP's optimum does not depend on
+    who solves it), most midpoint problems gone; the same in budgeted rounds of the kernel.
+    """
+    from explicit_hybrid_mpc_amd import engine, examples
+    from explicit_hybrid_mpc_amd import tools as ehm_tools
+    mpc = helpers.make_instance('lin', 0)
+    gp = engine.GpuProblem(mpc.compile(), 1., 1.)
+    V = examples.box_vertices(examples.theta_box(mpc))
+    gp.set_eps(float(np.max(gp.solve_pt(0.05 * V)[0])), 1e-2)
+    roots, _ = ehm_tools.delaunay_roots(V)
+    gp.set_option('share_midpoints', 0)
+    ref = gp.partition(roots, action='ecc', max_nodes=1 << 22)
+    gp.set_option('share_midpoints', 1)
+    new = gp.partition(roots, action='ecc', max_nodes=1 << 22)
+    again = gp.partition(roots, action='ecc', max_nodes=1 << 22)      # a second run: table cleared
+    run = gp.begin(roots, action='ecc', max_nodes=1 << 22)
+    while run.advance(20000):
+        pass
+    rounds = run.finish()
+    gp.close()
+    splits = (ref.n_nodes - len(roots)) // 2
+    print('\nshare_midpoints: %d splits, %d midpoint optima taken from the table (%.1f per solve), '
+          'LP solves %d -> %d, device seconds %.4f -> %.4f' % (
+              splits, new.info['midpoints_shared'],
+              splits / max(splits - new.info['midpoints_shared'], 1),
+              ref.info['lp_solves'], new.info['lp_solves'],
+              ref.info['device_seconds'], new.info['device_seconds']))
+    assert ref.info['midpoints_shared'] == 0
+    assert new.info['midpoints_shared'] > 0.5 * splits
+    assert new.info['lp_solves'] + new.info['midpoints_shared'] == ref.info['lp_solves']
+    assert again.info['lp_solves'] + again.info['midpoints_shared'] == ref.info['lp_solves']
+    # (the slot a midpoint lands in depends on who came first; the count of hits only through
+    # neighbourhoods of 16 full slots, which a table 1/8 full practically never has)
+    assert abs(again.info['midpoints_shared'] - new.info['midpoints_shared']) <= 1e-3 * splits
+    assert rounds.info['midpoints_shared'] > 0.5 * splits
+    for t in (new, again):
+        assert t.n_nodes == ref.n_nodes
+        assert np.array_equal(t.vertices, ref.vertices) and np.array_equal(t.left, ref.left)
+        assert np.array_equal(t.flags, ref.flags)
+        assert np.array_equal(t.vertex_costs, ref.vertex_costs)           # bit for bit
+        assert np.array_equal(t.vertex_inputs, ref.vertex_inputs)
+        assert np.array_equal(t.tstar, ref.tstar)
+    assert rounds.n_nodes == ref.n_nodes
+    cells = {ref.vertices[k].tobytes(): (ref.left[k] < 0, ref.flags[k] & 1, ref.vertex_costs[k].tobytes())
+             for k in range(ref.n_nodes)}
+    for k in range(rounds.n_nodes):
+        assert cells[rounds.vertices[k].tobytes()] == (rounds.left[k] < 0, rounds.flags[k] & 1,
+                                                       rounds.vertex_costs[k].tobytes())

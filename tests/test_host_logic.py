@@ -291,3 +291,15 @@ def test_prefix_blocks_built_incrementally_are_the_reference_blocks():
     sub = base.restrict([(0, 0, 0), (1, 0, 1)])
     assert all(np.array_equal(a, b) for a, b in zip(sub.condense_prefix((1, 0)),
                                                     base._condense_prefix_reference((1, 0))))
+
+
+def test_midpoint_table_protocol_under_threads(tmp_path):
+    """csrc/ehm_midtable.h compiled for the host (device builtins mapped onto GCC atomics and
+    fences), eight threads as wavefronts: every request gets the value of its key, every key is
+    solved exactly once, nobody hangs (tests/native/midtable_stress.cpp)."""
+    exe = str(tmp_path / 'midtable_stress')
+    src = os.path.join(ROOT, 'tests', 'native', 'midtable_stress.cpp')
+    subprocess.run(['g++', '-O2', '-std=c++17', '-pthread', '-include', 'algorithm', src, '-o', exe],
+                   check=True)
+    out = subprocess.run([exe], capture_output=True, text=True, timeout=120)
+    assert out.returncode == 0 and 'OK' in out.stdout, out.stdout + out.stderr
