@@ -563,6 +563,17 @@ def main():
                 'lp_solves_per_rank': [int(v) for v in per_rank],
                 'load_imbalance_max_over_mean': distributed.imbalance(per_rank),
             },
+            # where the wavefronts of the persistent kernel spent their time (fractions of the
+            # summed residency; in-kernel 100 MHz clock, ehm_tree_info.persist_ticks)
+            'persist_ticks': (lambda t: None if not t or not t[0] else {
+                'starved_waiting_for_a_queue_slot': t[1] / t[0],
+                'waiting_for_a_midpoint_being_solved': t[2] / t[0],
+                'midpoint_solves': t[3] / t[0], 'suboptimality_test_solves': t[4] / t[0],
+                'everything_else': 1. - (t[1] + t[2] + t[3] + t[4]) / t[0],
+                'midpoint_waits_per_step': t[5] / K,
+                'mean_resident_ms_per_wavefront': t[0] / 1e5 / K / (256 * 12),
+            })([float(sum(i['persist_ticks'][q] for i in infos)) for q in range(6)]
+               if persistent else None),
             'roofline': {
                 # the path is compute-bound on FP64; the contract's two values are
                 # "hbm" | "mfma": the wide kernels form their normal matrix on the matrix cores,

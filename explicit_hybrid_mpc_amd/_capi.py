@@ -92,7 +92,8 @@ class TreeInfo(ctypes.Structure):
                 ('swaps', ctypes.c_int64), ('blacklisted', ctypes.c_int64),
                 ('kind_solves', ctypes.c_int64 * 5), ('kind_iters', ctypes.c_int64 * 5),
                 ('near_threshold', ctypes.c_int64), ('witness_inherited', ctypes.c_int64),
-                ('midpoints_shared', ctypes.c_int64)]
+                ('midpoints_shared', ctypes.c_int64),
+                ('persist_ticks', ctypes.c_int64 * 6)]
 
 
 class Progress(ctypes.Structure):

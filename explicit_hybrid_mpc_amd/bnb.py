@@ -196,7 +196,7 @@ class PrefixOracle:
     # -- lib/oracle.py:220-283 ---------------------------------------------------------------
     def in_variability_ball(self, R, V_delta_R, delta_ref, delta_star, theta_star):
         R = np.asarray(R, dtype=np.float64)
-        Jmin = self.table.solve_min([self.sequence_of(delta_ref)], R[None])[0]
+        Jmin = self.table.solve_min([self.sequence_of(delta_ref)], R[None], exact=True)[0]
         J = self.table.solve_points([self.sequence_of(delta_star)],
                                     np.asarray(theta_star, dtype=np.float64)[None])[0][0]
         if not (np.isfinite(Jmin) and np.isfinite(J)):

@@ -449,13 +449,14 @@ def _hand_off(oracle, nodes, table_max, engine_opts, stats, above=None, costs=No
         stats['handoffs'] += 1
         stats['handoff_nodes'] += flat.n_nodes
         stats['handoff_leaves'] += int(flat.info['n_leaves'])
+        stats['regions'] = stats.get('regions', 0) + int(flat.info['n_closed'])
         stats['table_sizes'].append(len(seqs))
     return keep
 
 
 def grow_frontier(oracle, branch, action='ecc', table_max=256, max_visits=None, handoff=True,
                   engine_opts=None, split_batch=None, round_cap=4096, log=None,
-                  table_backoff=False):
+                  table_backoff=False, order='fifo', min_regions=None):
     """
     ``bnb.grow`` with all pending nodes visited together (module docstring).  Same arguments and
     the same tree; ``round_cap`` bounds the nodes of one round, ``split_batch(R (n,p+1,p)) ->
@@ -466,6 +467,14 @@ def grow_frontier(oracle, branch, action='ecc', table_max=256, max_visits=None, 
     factor f lets floor(log2 f) generations of its descendants pass before a table is tried
     again (a failed attempt costs more problems than the node's searches; the tree does not
     depend on it -- off by default until it has been measured on the device).
+
+    ``order``: 'fifo' visits the tree level by level; 'deepest' takes the deepest pending nodes
+    first (rounds of up to ``round_cap`` nodes) -- the order of the reference's workers, whose
+    ``lcss`` recursion finishes the left subtree before it touches the right one
+    (lib/worker.py:403-417): subtrees are COMPLETED, so a run that is stopped early
+    (``max_visits``, or ``min_regions`` closed leaves reached) has spent its visits on regions
+    that are final instead of on an ever wider open frontier.  The tree of a run to completion
+    does not depend on the order.
 
     What a node hands to its children (none of it changes a verdict, all of it saves problems):
     an ecc node the sequence that was feasible at its barycentre (tried first at theirs); an lcss
@@ -482,18 +491,31 @@ def grow_frontier(oracle, branch, action='ecc', table_max=256, max_visits=None, 
     mpc = oracle.mpc
     stats = dict(host_visits=0, rounds=0, handoffs=0, handoff_nodes=0, handoff_leaves=0,
                  table_sizes=[], tables_too_large=0, truncated=False, witness_hits=0,
-                 table_attempts_skipped=0)
+                 table_attempts_skipped=0, regions=0)
     # one Tree or a list of them (the Delaunay roots of the set: their nodes share the rounds)
     # work items: (node, action, witness) -- the witness of an ecc node is a mode sequence that was
     # feasible at its parent's barycentre (None at a root)
     work = [(b, action, None) for b in (branch if isinstance(branch, (list, tuple)) else [branch])]
+    depth_of = {id(nd): 0 for nd, _, _ in work}       # pending nodes only
     while work:
         if max_visits is not None and stats['host_visits'] >= max_visits:
             stats['truncated'] = True
             break
+        if min_regions is not None and stats['regions'] >= min_regions:
+            stats['truncated'] = True
+            break
         cap = round_cap if max_visits is None else min(round_cap,
                                                        max_visits - stats['host_visits'])
+        if order == 'deepest':
+            work.sort(key=lambda item: -depth_of[id(item[0])])      # stable: ties keep their order
         batch, work = work[:cap], work[cap:]
+        depth_in = {id(item[0]): depth_of.pop(id(item[0])) for item in batch}
+
+        def push(node, act, extra, parent):
+            # a node visited again (lcss after ecc, a swap in place) keeps its depth; a child is
+            # one level below its parent
+            depth_of[id(node)] = depth_in[id(parent)] + (0 if node is parent else 1)
+            work.append((node, act, extra))
         stats['rounds'] += 1
         ecc = [nd for nd, act, _ in batch if act == 'ecc']
         witness = [wit for _, act, wit in batch if act == 'ecc']
@@ -552,7 +574,7 @@ def grow_frontier(oracle, branch, action='ecc', table_max=256, max_visits=None, 
                     delta = oracle.delta_of(found[k])
                     vx = [(uv[w, i].copy(), float(Jv[w, i]), 0.) for i in range(nv)]
                 _set_record(ecc[k].data, delta, vx)
-                work.append((ecc[k], 'lcss', None))
+                push(ecc[k], 'lcss', None, ecc[k])
             to_split += [(ecc[k], None, None, witness[k], None)
                          for k, s in enumerate(found) if s is None]
         if lcss:                            # lib/worker.py:340-417
@@ -565,6 +587,7 @@ def grow_frontier(oracle, branch, action='ecc', table_max=256, max_visits=None, 
             for k, c in enumerate(closed):
                 if c:
                     lcss[k].data.is_epsilon_suboptimal = True
+                    stats['regions'] += 1
             table_costs = {}
             next_wait = {k: max(0, waits[k] - 1) for k in opened}
             if handoff and opened:          # the open ones: to the engine where the table fits
@@ -616,7 +639,7 @@ def grow_frontier(oracle, branch, action='ecc', table_max=256, max_visits=None, 
                 if small:                   # lib/worker.py:396-401
                     data.commutation, data.vertex_costs, data.vertex_inputs = (delta_star, costs,
                                                                                 inputs)
-                    work.append((lcss[k], 'lcss', down))
+                    push(lcss[k], 'lcss', down, lcss[k])
                 else:
                     to_split.append((lcss[k], delta_star, costs, inputs, down))
         if to_split:
@@ -646,13 +669,13 @@ def grow_frontier(oracle, branch, action='ecc', table_max=256, max_visits=None, 
                                  vertex_inputs=in_1),
                         NodeData(vertices=S2[k].copy(), commutation=delta, vertex_costs=co_2,
                                  vertex_inputs=in_2))
-                work.append((nd.left, 'lcss', down))
-                work.append((nd.right, 'lcss', down))
+                push(nd.left, 'lcss', down, nd)
+                push(nd.right, 'lcss', down, nd)
             for k, (nd, delta, _, wit, _) in enumerate(to_split):
                 if delta is None:
                     nd.grow(NodeData(vertices=S1[k].copy()), NodeData(vertices=S2[k].copy()))
-                    work.append((nd.left, 'ecc', wit))
-                    work.append((nd.right, 'ecc', wit))
+                    push(nd.left, 'ecc', wit, nd)
+                    push(nd.right, 'ecc', wit, nd)
     # what the searches did not have to solve
     stats['prefixes_answered_by_inheritance'] = oracle.n_inherited
     stats['optima_asked_solved'] = (getattr(oracle.table, 'optima_asked', 0),

@@ -2760,6 +2760,7 @@ int ehm_partition_finish(ehm_tree* T) {
     T->info.witness_open = (int64_t)(c1.wit_open - R.c0.wit_open);
     T->info.witness_inherited = (int64_t)(c1.wit_inherited - R.c0.wit_inherited);
     T->info.midpoints_shared = (int64_t)(c1.mid_shared - R.c0.mid_shared);
+    for (int k = 0; k < 6; ++k) T->info.persist_ticks[k] = (int64_t)(c1.prof[k] - R.c0.prof[k]);
     T->info.near_threshold = (int64_t)(c1.routed - R.c0.routed);
     T->info.replicated_closed = R.pre_closed;
     T->info.replicated_nodes = R.pre_nodes;

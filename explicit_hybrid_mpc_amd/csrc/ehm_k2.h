@@ -12,7 +12,7 @@
 #define EHM_K2_THREADS 768
 #endif
 
-#define K2_AUG_MIN 24
+#define K2_AUG_MIN 32
 // Near-threshold routing (hard part 1): a node's close / split decision may be
 // taken by a shortcut -- sign-only stop of the suboptimality-test LP, tangent-plane bound,
 // midpoint witness, inherited negative verdict -- only when it establishes |t*| >= this

@@ -373,8 +373,9 @@ __global__ __launch_bounds__(EHM_K2_THREADS) void k2_persist(
     double* wmargin = nb.aug + 16;
     enum { W_SOLVES = 0, W_ITERS, W_STALLED, W_ERRORS, W_SLACK, W_SLACK_ITERS, W_CLOSED, W_SPLITS,
            W_DEPTH, W_TRUNC, W_CERT, W_WIT, W_ROUTED, W_RCLOSED, W_RSPLITS, W_RSOLVES,
-           W_INH = 17, W_MT = 18, W_MTPARK = 19 };        // slot 16 is *wmargin
-    if (lane0 < 20 && lane0 != 16) wst[lane0] = 0ULL;
+           W_INH = 17, W_MT = 18, W_MTPARK = 19,           // slot 16 is *wmargin
+           W_TQ = 20, W_TMT = 21, W_TMID = 22, W_TSLK = 23, W_NMT = 24 };   // DevCounters::prof
+    if (lane0 < 25 && lane0 != 16) wst[lane0] = 0ULL;
     if (lane0 == 0) *wmargin = 1e300;
     wsync();
     for (;;) {
@@ -383,9 +384,11 @@ __global__ __launch_bounds__(EHM_K2_THREADS) void k2_persist(
             const int idx = atomicAdd(&ctl->head, 1);
             if (idx < ((deal.pop_limit > 0 && deal.pop_limit < n_slots) ? deal.pop_limit
                                                                         : n_slots)) {
+                long long t_q = 0;
                 for (;;) {
                     id = __hip_atomic_load(&slots[idx], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                     if (id >= 0) break;
+                    if (!t_q) t_q = wall_clock64();
                     if (__hip_atomic_load(&ctl->pending, __ATOMIC_RELAXED,
                                           __HIP_MEMORY_SCOPE_AGENT) <= 0 ||
                         __hip_atomic_load(&ctl->abort, __ATOMIC_RELAXED,
@@ -397,6 +400,7 @@ __global__ __launch_bounds__(EHM_K2_THREADS) void k2_persist(
                     }
                     __builtin_amdgcn_s_sleep(64);
                 }
+                if (t_q) wst[W_TQ] += (unsigned long long)(wall_clock64() - t_q);
             }
         }
         id = __builtin_amdgcn_readfirstlane(id);
@@ -487,9 +491,15 @@ __global__ __launch_bounds__(EHM_K2_THREADS) void k2_persist(
                 unsigned int mt_i = 0u;
                 int mt_slot = 0;
                 const unsigned long long mt_tg = mt_tag(mid, p, T.mt.mask, &mt_i);
-                if (lane == 0)
+                if (lane == 0) {
+                    long long waited = 0;
                     mt_res = mt_claim(T.mt, mt_tg, mt_i, t_start, EHM_PERSIST_WATCHDOG_TICKS,
-                                      &mt_slot);
+                                      &mt_slot, &waited);
+                    if (waited) {
+                        wst[W_TMT] += (unsigned long long)waited;
+                        wst[W_NMT] += 1;
+                    }
+                }
                 mt_res = __builtin_amdgcn_readfirstlane(mt_res);
                 mt_slot = __builtin_amdgcn_readfirstlane(mt_slot);
                 if (mt_res == MT_HIT) {
@@ -516,6 +526,7 @@ __global__ __launch_bounds__(EHM_K2_THREADS) void k2_persist(
             }
             if (mt_res != MT_HIT)
             {
+            const long long t_mid = wall_clock64();
             Wave Wm;
             IpmResult rm;
             for (int attempt = 0; attempt < EHM2_ATTEMPTS; ++attempt) {
@@ -534,6 +545,7 @@ __global__ __launch_bounds__(EHM_K2_THREADS) void k2_persist(
             mid_conv = (rm.status == 0) && (rm.merit <= 1.0);    // not merely "accepted"
             mid_iters = its;
             if (lane < n_u) stash[lane] = Wm.xb[lane];
+            if (lane == 0) wst[W_TMID] += (unsigned long long)(wall_clock64() - t_mid);
             }
             if (mt_res != MT_HIT && T.grad && lane < p) stash[8 + lane] = nb.F[lane];
             wsync();
@@ -562,6 +574,7 @@ __global__ __launch_bounds__(EHM_K2_THREADS) void k2_persist(
             }
         }
         if (!decided) {
+            const long long t_slk = wall_clock64();
             Wave W;
             IpmResult r;
             its = 0;
@@ -597,6 +610,7 @@ __global__ __launch_bounds__(EHM_K2_THREADS) void k2_persist(
             }
 #endif
             if (lane == 0) {
+                wst[W_TSLK] += (unsigned long long)(wall_clock64() - t_slk);
                 wst[W_SOLVES] += 1;
                 if (dep < deal.depth) wst[W_RSOLVES] += 1;
                 wst[W_ITERS] += (unsigned long long)its;
@@ -888,6 +902,12 @@ __global__ __launch_bounds__(EHM_K2_THREADS) void k2_persist(
         if (wst[W_WIT]) atomicAdd(&cnt->wit_open, wst[W_WIT]);
         if (wst[W_INH]) atomicAdd(&cnt->wit_inherited, wst[W_INH]);
         if (wst[W_MT]) atomicAdd(&cnt->mid_shared, wst[W_MT]);
+        atomicAdd(&cnt->prof[0], (unsigned long long)(wall_clock64() - t_start));
+        if (wst[W_TQ]) atomicAdd(&cnt->prof[1], wst[W_TQ]);
+        if (wst[W_TMT]) atomicAdd(&cnt->prof[2], wst[W_TMT]);
+        if (wst[W_TMID]) atomicAdd(&cnt->prof[3], wst[W_TMID]);
+        if (wst[W_TSLK]) atomicAdd(&cnt->prof[4], wst[W_TSLK]);
+        if (wst[W_NMT]) atomicAdd(&cnt->prof[5], wst[W_NMT]);
         if (wst[W_ROUTED]) atomicAdd(&cnt->routed, wst[W_ROUTED]);
         atomicAdd(&ctl->closed, wst[W_CLOSED]);
         atomicAdd(&ctl->splits, wst[W_SPLITS]);

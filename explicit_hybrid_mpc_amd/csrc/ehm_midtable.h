@@ -51,7 +51,8 @@ __device__ inline unsigned long long mt_tag(const double* mid, int p, unsigned i
 // MT_HIT: *slot holds a published entry with this tag; MT_NONE: neighbourhood full or the wait
 // ran into the watchdog -- solve without the table.
 __device__ inline int mt_claim(const MidTable& M, unsigned long long tag, unsigned int idx,
-                               long long t_start, long long watchdog_ticks, int* slot) {
+                               long long t_start, long long watchdog_ticks, int* slot,
+                               long long* waited = nullptr) {
     for (int probe = 0; probe < MT_PROBES; ++probe, idx = (idx + 1u) & M.mask) {
         unsigned long long s = __hip_atomic_load(&M.state[idx], __ATOMIC_RELAXED,
                                                  __HIP_MEMORY_SCOPE_AGENT);
@@ -66,10 +67,14 @@ __device__ inline int mt_claim(const MidTable& M, unsigned long long tag, unsign
             s = expect;                 // somebody else took it: look at what it holds now
         }
         if ((s & ~3ull) != tag) continue;
-        while ((s & 3ull) != 3ull) {    // claimed by a wavefront that is solving it right now
-            if (wall_clock64() - t_start > watchdog_ticks) return MT_NONE;
-            __builtin_amdgcn_s_sleep(8);
-            s = __hip_atomic_load(&M.state[idx], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if ((s & 3ull) != 3ull) {       // claimed by a wavefront that is solving it right now
+            const long long t_wait = wall_clock64();
+            do {
+                if (wall_clock64() - t_start > watchdog_ticks) return MT_NONE;
+                __builtin_amdgcn_s_sleep(8);
+                s = __hip_atomic_load(&M.state[idx], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            } while ((s & 3ull) != 3ull);
+            if (waited) *waited += wall_clock64() - t_wait;
         }
         *slot = (int)idx;
         return MT_HIT;

@@ -139,26 +139,52 @@ def balance_plan(counts, tolerance=0.1, min_move=16):
 
 
 def _exchange(run, plan, rank, device, rnd, log):
-    """Execute this rank's part of a plan: donors take + send, receivers recv + give."""
+    """
+    Execute this rank's part of a plan: donors take + send, receivers recv + give.  EVERY planned
+    send / recv pair is completed even after a failure on this rank -- a donor whose ``take`` raised
+    sends a poison block (NaN meta words) of the planned size, a receiver whose ``give`` raised
+    keeps draining its planned receives -- so no peer is left blocked in a point-to-point call; the
+    first error is raised once the plan is through, and the status all-gather that follows in
+    ``run_balanced`` stops every rank.  (After a failure the run's device tree is gone:
+    ``PartitionRun._checked`` releases it; ``run`` cannot be continued.)
+    """
     import torch
     import torch.distributed as dist
     nrec = run.nrec
+    err = None
     for donor, receiver, n in plan:
         if rank == donor:
-            ids, rec, meta = run.take(n)
-            buf = np.concatenate([rec, meta.astype(np.float64)], axis=1)
+            buf = None
+            if err is None:
+                try:
+                    ids, rec, meta = run.take(n)
+                    buf = np.concatenate([rec, meta.astype(np.float64)], axis=1)
+                except Exception as e:
+                    err = e
+            if buf is None:
+                buf = np.full((n, nrec + 2), np.nan)
             t = torch.from_numpy(np.ascontiguousarray(buf))
             if device is not None:
                 t = t.to(device)
             dist.send(t, dst=receiver)
-            log.append(dict(kind='give', round=rnd, peer=receiver, ids=ids))
+            if err is None:
+                log.append(dict(kind='give', round=rnd, peer=receiver, ids=ids))
         elif rank == receiver:
             t = torch.empty((n, nrec + 2), dtype=torch.float64,
                             device=device if device is not None else 'cpu')
             dist.recv(t, src=donor)
             buf = t.cpu().numpy()
-            first = run.give(buf[:, :nrec], np.rint(buf[:, nrec:]).astype(np.int32))
-            log.append(dict(kind='recv', round=rnd, peer=donor, first=first, count=n))
+            if np.isnan(buf[:, nrec:]).any():
+                err = err or RuntimeError('rank %d could not hand over the %d nodes planned for '
+                                          'rank %d' % (donor, n, rank))
+            elif err is None:
+                try:
+                    first = run.give(buf[:, :nrec], np.rint(buf[:, nrec:]).astype(np.int32))
+                    log.append(dict(kind='recv', round=rnd, peer=donor, first=first, count=n))
+                except Exception as e:
+                    err = e
+    if err is not None:
+        raise err
 
 
 def allgather_floats(values, device=None):
@@ -386,7 +412,7 @@ def merge_flat(parts, root_locations=None, received=None):
                     take('vertex_inputs'), flags, take('tstar'), info, parts[0].deltas)
 
 
-def grow_roots_sharded(oracle, roots, action='ecc', **kw):
+def grow_roots_sharded(oracle, roots, action='ecc', device=None, **kw):
     """
     The search-oracle driver (``bnb_frontier.grow_frontier``: problems whose mode sequences
     cannot be enumerated) over the ranks: root ``k`` of the list -- the Delaunay roots of the
@@ -394,7 +420,9 @@ def grow_roots_sharded(oracle, roots, action='ecc', **kw):
     subtrees are independent, so the data path has no collective (weak scaling over the
     roots); the counts are all-gathered at the end.
     Returns (the list of roots with THIS rank's roots grown in place, stats of this rank,
-    (world, 3) array of every rank's [host visits, leaves, roots]).
+    (world, 3) array of every rank's [host visits, leaves, roots]).  ``device``: where the final
+    all-gather's tensors live ('cuda:k' under the nccl = RCCL backend, which cannot move host
+    tensors; default: the oracle table's device there, the host under gloo).
     """
     import torch.distributed as dist
     from . import bnb_frontier
@@ -405,6 +433,7 @@ def grow_roots_sharded(oracle, roots, action='ecc', **kw):
     stats = bnb_frontier.grow_frontier(oracle, mine, action, **kw) if mine else \
         dict(host_visits=0, rounds=0, truncated=False)
     leaves = sum(1 for r in mine for _ in r.leaves())
-    counts = allgather_counts([stats['host_visits'], leaves, len(mine)],
-                              device=kw.get('device'))
+    if device is None and world > 1 and dist.get_backend() == 'nccl':
+        device = 'cuda:%d' % int(getattr(oracle.table, 'device', 0))
+    counts = allgather_counts([stats['host_visits'], leaves, len(mine)], device=device)
     return roots, stats, counts

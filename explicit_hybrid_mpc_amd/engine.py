@@ -9,6 +9,7 @@ lib/worker.py:241-417 executed as frontier sweeps on the GPU.
 """
 
 import ctypes
+import weakref
 import numpy as np
 
 from . import _capi
@@ -103,6 +104,12 @@ class GpuProblem:
 
     def close(self):
         if getattr(self, '_handle', None) is not None and self._handle:
+            # an unfinished run goes first: its tree swaps its node pool into this handle's cache
+            # (the library also detaches every tree still alive, ehm_problem_destroy)
+            run = getattr(self, '_live_run', None)
+            run = run() if run is not None else None
+            if run is not None:
+                run.abort()
             self._lib.ehm_problem_destroy(self._handle)
             self._handle = ctypes.c_void_p()
 
@@ -428,6 +435,7 @@ class PartitionRun:
         check(self._lib.ehm_partition_movable(self._tree, None, ctypes.addressof(w)))
         self.nrec = int(w.value)       # doubles per travelling record (hybrid: + bit rows)
         self.frontier = n_roots
+        gp._live_run = weakref.ref(self)
 
     def abort(self):
         """Release the device tree of a run that will not be finished (the handle is free again)."""

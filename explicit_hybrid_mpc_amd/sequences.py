@@ -368,6 +368,12 @@ class PrefixTable(PrefixSearch):
         self.gp = engine.GpuProblem(can, eps_a, eps_r, device=device)
         self.lp_solves = 0
         self.blocks_loaded = 0
+        # solves the device reported as stalled (status != 0: neither converged nor within the
+        # acceptance band of csrc/ehm_ipm3.h): an optimum becomes +inf (the callers' blacklist /
+        # retry paths, lib/oracle.py:214-218, 406-414, see it as a failed vertex solve), a slack
+        # or a minimum over a simplex raises, a phase one whose last iterate is not feasible raises
+        self.stalled = 0
+        self.stalled_relaxations = 0    # of them: relaxations answered by "no information"
         self._slot_of = {}
         self._blocks = {}
         self.init_search()
@@ -438,16 +444,60 @@ class PrefixTable(PrefixSearch):
         if known_feasible:
             ok = np.ones(sel.size, dtype=bool)
         else:
-            tau = self.gp.point_idx(thetas[sel], slot, feas=True)[0]
+            tau, _, st = self.gp.point_idx(thetas[sel], slot, feas=True)
             self.lp_solves += sel.size
-            ok = tau <= FEAS_TOL
+            ok = self._phase_one_verdict(tau, st)
         if feasibility_only:
             J[sel[ok]] = 0.
         elif ok.any():
-            Jk, uk, _ = self.gp.point_idx(thetas[sel[ok]], slot[ok])
+            Jk, uk, st = self.gp.point_idx(thetas[sel[ok]], slot[ok])
             self.lp_solves += int(ok.sum())
-            J[sel[ok]] = Jk
+            bad = st != 0
+            self.stalled += int(bad.sum())
+            J[sel[ok]] = np.where(bad, np.inf, Jk)      # a failed solve, not an optimum
             u0[sel[ok]] = uk
+
+    def _phase_one_verdict(self, tau, status):
+        """Feasible <=> tau* <= FEAS_TOL.  A stalled phase one whose last iterate already is
+        feasible (tau <= FEAS_TOL at a primal-feasible iterate) proves feasibility; one that is not
+        proves nothing -- it must not pass for "infeasible" and silently prune a prefix."""
+        ok = tau <= FEAS_TOL
+        unknown = (status != 0) & ~ok
+        self.stalled += int((status != 0).sum())
+        if unknown.any():
+            from .oracle import SolverError
+            raise SolverError('%d phase-one problem(s) stalled above the feasibility tolerance '
+                              '(smallest tau %.3g): verdict unknown' %
+                              (int(unknown.sum()), float(np.min(tau[unknown]))))
+        return ok
+
+    def _settle_stalled(self, values, status, simplices, slot, prefixes, what, infeasible_value,
+                        unknown_value, full_is_error):
+        """
+        An optimisation over a simplex that stalled.  If the pair was taken as feasible without
+        its phase one (``known_feasible``) the simplex may be an interior-free sliver of the
+        relaxation's feasible set -- phase one decides (the rule of csrc/ehm_hybrid.h).  A stalled
+        problem that IS feasible has no usable value.  Where the value only serves as a bound
+        (every relaxation = proper prefix; minima in a region-table search) ``unknown_value`` --
+        the bound that prunes nothing -- is always valid: the searches expand the prefix's
+        children instead.  Where it is an answer (a full sequence's slack, the minimum of
+        in_variability_ball): SolverError, never a silent verdict.
+        """
+        bad = np.flatnonzero(status != 0)
+        if bad.size:
+            self.stalled += int(bad.size)
+            tau, _, st = self.gp.simplex_idx(simplices[bad], slot[bad], mode=2)
+            self.lp_solves += int(bad.size)
+            feasible = (tau <= FEAS_TOL) | (st != 0)
+            full = np.array([len(prefixes[k]) == self.mpc.N for k in bad], dtype=bool)
+            if full_is_error and (feasible & full).any():
+                from .oracle import SolverError
+                raise SolverError('%d %s problem(s) of full mode sequences did not converge on '
+                                  'the device' % (int((feasible & full).sum()), what))
+            values = values.copy()
+            values[bad] = np.where(feasible, unknown_value, infeasible_value)
+            self.stalled_relaxations += int(feasible.sum())
+        return values
 
     def solve_points(self, prefixes, thetas, feasibility_only=False, known_feasible=False):
         """
@@ -463,9 +513,11 @@ class PrefixTable(PrefixSearch):
             self._solve_chunk(idx, slot, thetas, J, u0, feasibility_only, known_feasible)
         return J, u0
 
-    def solve_min(self, prefixes, simplices, known_feasible=None):
+    def solve_min(self, prefixes, simplices, known_feasible=None, exact=False):
         """Minimum over simplex k of the optimal cost of prefix k (+inf: infeasible on it);
-        ``known_feasible`` as in ``solve_slack``."""
+        ``known_feasible`` as in ``solve_slack``.  A stalled solve gives -inf (as a pruning
+        bound: "keep it"); ``exact``: the minima of full sequences are ANSWERS
+        (in_variability_ball) -- a stalled one raises."""
         simplices = np.asarray(simplices, dtype=np.float64)
         J = np.full(len(prefixes), np.inf)
         for idx, slot in self._chunks(prefixes):
@@ -473,11 +525,16 @@ class PrefixTable(PrefixSearch):
             todo = np.arange(idx.size) if known_feasible is None else \
                 np.flatnonzero(~np.asarray(known_feasible, dtype=bool)[idx])
             if todo.size:
-                tau = self.gp.simplex_idx(simplices[idx[todo]], slot[todo], mode=2)[0]
+                tau, _, st = self.gp.simplex_idx(simplices[idx[todo]], slot[todo], mode=2)
                 self.lp_solves += todo.size
-                ok[todo] = tau <= FEAS_TOL
+                ok[todo] = self._phase_one_verdict(tau, st)
             if ok.any():
-                J[idx[ok]] = self.gp.simplex_idx(simplices[idx[ok]], slot[ok], mode=0)[0]
+                Jk, _, st = self.gp.simplex_idx(simplices[idx[ok]], slot[ok], mode=0)
+                # (a minimum is only ever a pruning bound: -inf keeps the prefix / the sequence)
+                J[idx[ok]] = self._settle_stalled(Jk, st, simplices[idx[ok]], slot[ok],
+                                                  [prefixes[k] for k in idx[ok]],
+                                                  'minimum-over-a-simplex', np.inf, -np.inf,
+                                                  exact)
                 self.lp_solves += int(ok.sum())
         return J
 
@@ -494,12 +551,15 @@ class PrefixTable(PrefixSearch):
             todo = np.arange(idx.size) if known_feasible is None else \
                 np.flatnonzero(~np.asarray(known_feasible, dtype=bool)[idx])
             if todo.size:
-                tau = self.gp.simplex_idx(simplices[idx[todo]], slot[todo], mode=2)[0]
+                tau, _, st = self.gp.simplex_idx(simplices[idx[todo]], slot[todo], mode=2)
                 self.lp_solves += todo.size
-                ok[todo] = tau <= FEAS_TOL
+                ok[todo] = self._phase_one_verdict(tau, st)
             if ok.any():
-                tk, ak, _ = self.gp.simplex_idx(simplices[idx[ok]], slot[ok], mode=1,
-                                                Vbar=vbars[idx[ok]])
+                tk, ak, st = self.gp.simplex_idx(simplices[idx[ok]], slot[ok], mode=1,
+                                                 Vbar=vbars[idx[ok]])
+                tk = self._settle_stalled(tk, st, simplices[idx[ok]], slot[ok],
+                                          [prefixes[k] for k in idx[ok]],
+                                          'suboptimality-test', -np.inf, np.inf, True)
                 self.lp_solves += int(ok.sum())
                 t[idx[ok]] = tk
                 alpha[idx[ok]] = ak

@@ -40,7 +40,10 @@ def _as_reference_module():
 # overflow (a segfault instead of RecursionError), so the (un)pickling runs in a thread whose
 # stack is sized for the depth; beyond MAX_DEPTH the call fails with a clear error.
 MAX_DEPTH = 200000
-_STACK_BYTES_PER_LEVEL = 2048      # measured: ~0.5 KB of C stack per pickled level, 4x margin
+_STACK_BYTES_PER_LEVEL = 8192      # C stack per TREE level: the pickler nests ~4 save() calls per
+                                   # level (Tree -> __dict__ -> child list -> Tree) at ~0.5 KB
+                                   # each, 4x margin
+_STACK_MAX = 2 << 30
 _lock = threading.Lock()           # sys.modules['tree'] / the recursion limit are process-global
 
 
@@ -57,11 +60,18 @@ def _run_deep(fn, depth_hint):
     with _lock:
         old_limit, old_stack = sys.getrecursionlimit(), threading.stack_size()
         sys.setrecursionlimit(max(old_limit, 10 * depth_hint + 1000))
-        threading.stack_size(max(64 << 20, (10 * depth_hint + 1000) * _STACK_BYTES_PER_LEVEL))
+        # (the recursion limit is process-wide while this runs; the lock serialises callers)
+        stack = min(_STACK_MAX, max(64 << 20, (depth_hint + 1000) * _STACK_BYTES_PER_LEVEL))
+        threading.stack_size(stack)
         try:
             with _as_reference_module():
                 t = threading.Thread(target=work)
-                t.start()
+                try:
+                    t.start()
+                except (RuntimeError, MemoryError) as e:
+                    raise MemoryError('cannot start a thread with a %d MB stack for a tree of '
+                                      'depth %d (address-space limit?): %s' %
+                                      (stack >> 20, depth_hint, e))
                 t.join()
         finally:
             threading.stack_size(old_stack)

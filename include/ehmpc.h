@@ -380,6 +380,11 @@ typedef struct ehm_tree_info {
                                    suboptimality test (option "inherit_witness"), no LP     */
     int64_t midpoints_shared;   /* splits whose midpoint optimum another simplex around the same
                                    edge had solved already (option "share_midpoints"), no LP */
+    /* persistent frontier kernel: where its wavefronts spent their time, in ticks of the 100 MHz
+     * wall clock summed over all of them: [0] resident, [1] waiting for a queue slot to be filled
+     * (starved), [2] waiting for a midpoint optimum another wavefront was solving, [3] in midpoint
+     * solves, [4] in suboptimality-test solves; [5] = number of waits of kind [2] */
+    int64_t persist_ticks[6];
 } ehm_tree_info;
 
 int ehm_tree_info_get(const ehm_tree* tree, ehm_tree_info* out);

@@ -236,7 +236,7 @@ class CpuPrefixTable(_prefix_search_base()):
                 u0[k] = m.u0(res.x)
         return J, u0
 
-    def solve_min(self, prefixes, simplices, known_feasible=None):
+    def solve_min(self, prefixes, simplices, known_feasible=None, exact=False):
         J = np.full(len(prefixes), np.inf)
         for k, q in enumerate(prefixes):
             res = _solve(self._model(q).lp_min_over_simplex(simplices[k]))

@@ -370,6 +370,52 @@ def test_a_failing_rank_stops_every_rank(tmp_path):
     assert outs[0].startswith('raised: partition run failed on rank(s) [1]')
 
 
+class _FailingTake(CpuRun):
+    """The donor's hand-over fails in the middle of a plan (a device error inside ehm_partition_take)."""
+
+    def take(self, count):
+        raise RuntimeError('libehmpc error -2: take failed (emulated)')
+
+    def free_nodes(self):
+        return 1 << 20
+
+
+def _worker_failing_take(rank, world, port, out_dir):
+    os.environ.update(RANK=str(rank), LOCAL_RANK=str(rank), WORLD_SIZE=str(world),
+                      MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port))
+    import torch.distributed as dist
+    from explicit_hybrid_mpc_amd import distributed
+    distributed.init_process_group('gloo')
+    mpc = helpers.make_instance('di', 0)
+    roots, locs = helpers.roots_of(mpc)
+    try:
+        distributed.run_balanced(
+            None, roots, min_frontier=-1, sweeps_per_round=1, tolerance=0., min_move=1,
+            run_factory=lambda shard: _FailingTake(mpc, 0.3, 0.02, roots, shard))
+        outcome = 'finished'
+    except RuntimeError as e:
+        outcome = 'raised: %s' % e
+    with open(os.path.join(out_dir, 'take%d.txt' % rank), 'w') as f:
+        f.write(outcome)
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_a_failing_hand_over_does_not_leave_the_receiver_waiting(tmp_path):
+    """
+    A donor whose take() raises mid-plan still completes its planned send (a poison block), so
+    the receiver is not left in dist.recv for ever; both ranks then fail together.
+    """
+    s = socket.socket()
+    s.bind(('127.0.0.1', 0))
+    port = s.getsockname()[1]
+    s.close()
+    mp.spawn(_worker_failing_take, args=(2, port, str(tmp_path)), nprocs=2, join=True)
+    outs = [open(str(tmp_path / ('take%d.txt' % r))).read() for r in range(2)]
+    assert all(o.startswith('raised:') for o in outs), outs
+    assert any('take failed' in o for o in outs)
+
+
 def _worker_roots(rank, world, port, out_dir):
     os.environ.update(RANK=str(rank), LOCAL_RANK=str(rank), WORLD_SIZE=str(world),
                       MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port))

@@ -4,6 +4,7 @@ logic), run on a CPU stand-in for the device table (oracle/prefix_bb.CpuPrefixTa
 pair solvers, HiGHS) against the ENUMERATING CPU oracle: same canonical answers, same tree.
 """
 
+import pytest
 import numpy as np
 
 from explicit_hybrid_mpc_amd import bnb, examples
@@ -414,3 +415,103 @@ def test_searches_on_the_device_table_class_with_a_stub_device(monkeypatch):
                 assert np.allclose(nd.data.vertex_costs, r['vertex_costs'], rtol=1e-7, atol=1e-8)
     assert n == len(cpu.nodes)
     dev.close()
+
+
+class _StallingStub(_StubDeviceProblem):
+    """The stub with a solver that reports chosen problems as stalled (status 1)."""
+    stall_points = stall_phase_one = stall_slack = False
+    infeasible_sliver = False
+
+    def point_idx(self, theta, slot, feas=False):
+        J, u0, st = super().point_idx(theta, slot, feas)
+        if (feas and self.stall_phase_one) or (not feas and self.stall_points):
+            st = st.copy()
+            st[0] = 1
+            if feas:
+                J = J.copy()
+                J[0] = 1e-3             # a last iterate that is NOT feasible
+        return J, u0, st
+
+    def simplex_idx(self, R, slot, mode, Vbar=None):
+        obj, alpha, st = super().simplex_idx(R, slot, mode, Vbar)
+        if mode == 1 and self.stall_slack:
+            st = st.copy()
+            st[0] = 1
+        if mode == 2 and self.infeasible_sliver:
+            obj = obj.copy()
+            obj[0] = 1e-3
+        return obj, alpha, st
+
+
+def test_stalled_device_solves_are_never_taken_for_answers(monkeypatch):
+    """
+    sequences.PrefixTable honours the solver status of every launch: a stalled optimum is +inf (a
+    failed vertex solve for the callers' blacklist / retry paths, lib/oracle.py:214-218, 406-414),
+    a stalled phase one that has not reached the tolerance raises instead of pruning its prefix,
+    a stalled suboptimality test is settled by phase one (interior-free sliver: infeasible) or
+    raises -- never a silent verdict (the enumerating Oracle raises SolverError there too).
+    """
+    from explicit_hybrid_mpc_amd import sequences
+    from explicit_hybrid_mpc_amd.oracle import SolverError
+    monkeypatch.setattr(sequences.engine, 'GpuProblem', _StallingStub)
+    mpc = helpers.make_instance('pwa_small', 0)
+    table = sequences.PrefixTable(mpc, slots=8)
+    rng = np.random.default_rng(5)
+    R = np.array(helpers.random_simplices(mpc, rng, 1, scale_lo=-2.)[0])
+    seq = table.first_feasible(R)
+    assert seq is not None
+    pairs, thetas = [seq, seq], np.array([R[0], R[1]])
+    J0, _ = table.solve_points(pairs, thetas, known_feasible=True)
+    assert np.isfinite(J0).all() and table.stalled == 0
+    table.gp.stall_points = True
+    J1, _ = table.solve_points(pairs, thetas, known_feasible=True)
+    assert np.isinf(J1[0]) and J1[1] == J0[1] and table.stalled == 1
+    table.gp.stall_points = False
+    table.gp.stall_phase_one = True
+    with pytest.raises(SolverError):
+        table.solve_points(pairs, thetas)
+    table.gp.stall_phase_one = False
+    V = np.array([table.solve_points([seq], v[None], known_feasible=True)[0][0] for v in R])
+    t0, _ = table.solve_slack([seq], R[None], V[None], known_feasible=[True])
+    assert np.isfinite(t0[0])
+    table.gp.stall_slack = True
+    with pytest.raises(SolverError):            # feasible on the simplex, yet no value
+        table.solve_slack([seq], R[None], V[None], known_feasible=[True])
+    table.gp.infeasible_sliver = True           # phase one says: nothing of it on this simplex
+    t1, _ = table.solve_slack([seq], R[None], V[None], known_feasible=[True])
+    assert t1[0] == -np.inf
+    table.close()
+
+
+def test_deepest_first_order_grows_the_same_tree_and_finishes_regions_first():
+    """
+    grow_frontier(order='deepest') -- the order of the reference's recursive workers
+    (lib/worker.py:403-417) -- ends with the tree of the level-by-level order; stopped early it
+    has closed more regions for the same number of node visits.
+    """
+    from explicit_hybrid_mpc_amd import bnb_frontier
+    mpc = helpers.make_instance('pwa_small', 0)
+    eps_a = helpers.eps_a_rule(mpc, 0.25)
+    roots, locs = helpers.roots_of(mpc)
+
+    def run(**kw):
+        orc = bnb.PrefixOracle(mpc, eps_a, 0.2, table=prefix_bb.CpuPrefixTable(mpc))
+        trees = [Tree(NodeData(vertices=np.array(R))) for R in roots]
+        stats = bnb_frontier.grow_frontier(orc, trees, 'ecc', handoff=False,
+                                           split_batch=_host_split_batch, **kw)
+        cells = {}
+        for t, loc0 in zip(trees, locs):
+            for nd, loc in t.walk(loc0):
+                cells[loc] = (nd.is_leaf(), bool(nd.data.is_epsilon_suboptimal))
+        return stats, cells
+    s_fifo, fifo = run()
+    s_deep, deep = run(order='deepest', round_cap=3)
+    assert not s_fifo['truncated'] and not s_deep['truncated']
+    assert fifo == deep and s_deep['regions'] == s_fifo['regions'] == sum(
+        1 for leaf, closed in fifo.values() if leaf and closed)
+    budget = s_fifo['host_visits'] // 2
+    a, _ = run(max_visits=budget, round_cap=3)
+    b, _ = run(max_visits=budget, round_cap=3, order='deepest')
+    assert a['truncated'] and b['truncated'] and b['regions'] >= a['regions']
+    c, _ = run(min_regions=3, round_cap=3, order='deepest')
+    assert c['truncated'] and 3 <= c['regions'] < s_fifo['regions']

@@ -4,7 +4,7 @@ tolerance on the device, with a clock on every layer: where do the seconds of
 ``bnb_frontier.grow_frontier`` go -- LP launches, block condensation / upload, hand-offs to the
 multi-commutation engine, the interpreter in between.
 
-    python tools/config5_probe.py ABS_FRAC EPS_R VISITS [TABLE_MAX] [ROUND_CAP] [backoff]
+    python tools/config5_probe.py ABS_FRAC EPS_R VISITS [TABLE_MAX] [ROUND_CAP] [backoff|-] [fifo|deepest] [MIN_REGIONS]
 
 One cell of the box (the Kuhn simplex on the main diagonal, 1/8! of Theta); eps_a by
 lib/examples.py:42-46 (largest P_theta cost at abs_frac x the box vertices).
@@ -43,6 +43,8 @@ def main():
     table_max = int(sys.argv[4]) if len(sys.argv) > 4 else 256
     round_cap = int(sys.argv[5]) if len(sys.argv) > 5 else 4096
     backoff = len(sys.argv) > 6 and sys.argv[6] == 'backoff'
+    order = sys.argv[7] if len(sys.argv) > 7 else 'fifo'
+    min_regions = int(sys.argv[8]) if len(sys.argv) > 8 else None
     for name in ('point_idx', 'simplex_idx', 'update_blocks', 'partition'):
         clocked(engine.GpuProblem, name)
     clocked(engine.GpuProblem, '__init__', 'problem_create')
@@ -72,7 +74,7 @@ def main():
     branch = Tree(NodeData(vertices=R.copy()))
     stats = bnb_frontier.grow_frontier(
         orc, branch, 'ecc', max_visits=visits, round_cap=round_cap, table_max=table_max,
-        table_backoff=backoff,
+        table_backoff=backoff, order=order, min_regions=min_regions,
         log=lambda m: print('  ', m, '%.1fs' % (time.perf_counter() - t), flush=True))
     wall = time.perf_counter() - t
     leaves = list(branch.leaves())
