@@ -34,7 +34,7 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 
-CONFIG3 = (0.5, 1.0, 24)     # abs_frac, eps_r, max_depth of --workload config3
+CONFIG3 = (0.1, 1e-2, 18)    # abs_frac, eps_r, max_depth of --workload config3 (eps as config 2)
 FP64_PEAK_TFLOPS = 78.6     # MI355X FP64 vector = FP32 vector / 2 (157.3 TF, MI355X_MICROARCH.md)
 HBM_PEAK_GBS = 8000.0
 
@@ -86,7 +86,7 @@ def pmc_traffic(kernel, summary):
     the kernel sources it was measured on (tools/pmc_summary.py); a profile of OTHER code is not
     quoted: returns (None, reason).
     """
-    for rnd in ('r2', 'r1'):
+    for rnd in ('r3', 'r2', 'r1'):
         path = os.path.join(ROOT, 'profiles', rnd, summary)
         if os.path.exists(path):
             break
@@ -220,13 +220,13 @@ def cpu_baseline(workload, seed, eps_a, eps_r, seconds):
                         wall))
 
 
-def main():
+def parse_args(argv=None):
     ap = argparse.ArgumentParser()
     ap.add_argument('--gpus', type=int, default=1)
     ap.add_argument('--steps', type=int, default=3)
     ap.add_argument('--warmup', type=int, default=1)
     ap.add_argument('--seed', type=int, default=0)
-    ap.add_argument('--workload', choices=['config2', 'config3', 'config4', 'config2q'],
+    ap.add_argument('--workload', choices=['config2', 'config3', 'config4', 'config2q', 'config5'],
                     default='config2',
                     help='config2 = the BASELINE.json metric (default); config3 = the 2-mode PWA '
                          'hybrid instance (32 commutations, mixed-integer oracles on the device '
@@ -260,6 +260,18 @@ def main():
                          'progress read-back (and, N > 1, one all-gather) per round -- off by '
                          'default, the headline number is measured without it')
     ap.add_argument('--cpu-seconds', type=float, default=15.)
+    ap.add_argument('--secondary-cpu-seconds', type=float, default=6.,
+                    help='CPU-baseline time of each entry of the "secondary" list')
+    ap.add_argument('--no-secondary', action='store_true',
+                    help='headline only: skip the few steps of config3 / config4 / config2q / '
+                         'config5 that the default invocation appends as "secondary"')
+    ap.add_argument('--regions', type=int, default=0,
+                    help='config5: regions to close per rank before a step stops (default: none, the '
+                         'cells are grown to completion)')
+    ap.add_argument('--cells', type=int, default=0,
+                    help='config5: Kuhn cells of the box that are grown (default: one per rank)')
+    ap.add_argument('--max-visits', type=int, default=None,
+                    help='config5: cap on the node visits of a step')
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--solver', type=int, default=2, help='kernel generation (1 or 2)')
     ap.add_argument('--no-mid-first', action='store_true',
@@ -273,20 +285,17 @@ def main():
                          'shared-block kernels), 0 = level-synchronous sweeps')
     ap.add_argument('--decide-full', action='store_true',
                     help='solve the suboptimality-test LPs to full accuracy (no sign-only stop)')
-    args = ap.parse_args()
+    return ap.parse_args(argv)
 
+
+
+def measure(args, ctx):
+    """One workload on the process group of ``ctx``; rank 0 returns the result line (a dict)."""
     import torch
     import torch.distributed as dist
     from explicit_hybrid_mpc_amd import distributed
-    # "nccl" is RCCL on ROCm; EHM_BENCH_BACKEND=gloo lets several ranks share one GPU (tests)
-    backend = os.environ.get('EHM_BENCH_BACKEND', 'nccl')
-    rank, local_rank, world = distributed.init_process_group(backend)
-    n_dev = max(torch.cuda.device_count(), 1)
-    device_index = local_rank % n_dev
-    torch.cuda.set_device(device_index)
-    if world != args.gpus and rank == 0:
-        sys.stderr.write('bench.py: --gpus %d but WORLD_SIZE=%d; using WORLD_SIZE\n' %
-                         (args.gpus, world))
+    backend, rank, world, device_index = (ctx['backend'], ctx['rank'], ctx['world'],
+                                          ctx['device_index'])
     from explicit_hybrid_mpc_amd import engine, examples
     from explicit_hybrid_mpc_amd import tools as ehm_tools
 
@@ -398,8 +407,6 @@ def main():
         sys.stderr.write('bench.py rank %d: %s\n' % (
             rank, failure if failure is not None else 'another rank failed'))
         gp.close()
-        if world > 1:
-            dist.destroy_process_group()
         raise SystemExit(1)
     # what the caller gets back: one more partition WITH the flat export (device -> host copy of
     # every record + breadth-first relabelling), outside the timed region, reported next to it
@@ -413,7 +420,7 @@ def main():
     # totals over ranks (max time, summed work)
     keys = ['lp_solves', 'ipm_iters', 'n_nodes', 'n_closed', 'ref_solves', 'decide_solves',
             'decide_iters', 'cert_closed', 'witness_open', 'witness_inherited',
-            'midpoints_shared']
+            'midpoints_shared', 'witness_table']
     if rank > 0:
         # the top of the tree is grown identically on every rank: count it once (rank 0)
         for i in infos:
@@ -436,6 +443,7 @@ def main():
     expand_s = float(mx[len(keys) + 2])
     kind_solves = [float(v) for v in tot[len(keys) + 5:len(keys) + 10]]
     kind_iters = [float(v) for v in tot[len(keys) + 10:len(keys) + 15]]
+    out = None
     if rank == 0:
         K = args.steps
         info0 = infos[-1]
@@ -455,7 +463,7 @@ def main():
         closed, nodes = agg['n_closed'], agg['n_nodes']
         splits = (nodes - K * len(roots)) / 2.
         visits = (agg['decide_solves'] + agg['cert_closed'] + agg['witness_open'] +
-                  agg['witness_inherited'])
+                  agg['witness_inherited'] + agg['witness_table'])
         if persistent:
             # ONE kernel per partition: suboptimality tests AND splits / midpoint solves
             flops, flops_x = sum(f_survey), sum(f_exec)
@@ -532,6 +540,8 @@ def main():
                 'nodes_proved_open_by_midpoint_per_step': agg['witness_open'] / K,
                 'nodes_proved_open_by_inherited_witness_per_step': agg['witness_inherited'] / K,
                 'midpoint_optima_taken_from_the_table_per_step': agg['midpoints_shared'] / K,
+                'nodes_proved_open_by_another_edges_midpoint_in_the_table_per_step':
+                    agg['witness_table'] / K,
                 'mean_ipm_iterations': agg['ipm_iters'] / max(agg['lp_solves'], 1),
                 'sweeps': info0['sweeps'], 'tree_depth': info0['max_depth'],
                 'min_decision_margin': info0['min_margin'],
@@ -569,10 +579,11 @@ def main():
                 'starved_waiting_for_a_queue_slot': t[1] / t[0],
                 'waiting_for_a_midpoint_being_solved': t[2] / t[0],
                 'midpoint_solves': t[3] / t[0], 'suboptimality_test_solves': t[4] / t[0],
-                'everything_else': 1. - (t[1] + t[2] + t[3] + t[4]) / t[0],
-                'midpoint_waits_per_step': t[5] / K,
+                'from_pop_to_midpoint_claim': t[6] / t[0], 'child_records_and_pushes': t[7] / t[0],
+                'everything_else': 1. - (t[1] + t[2] + t[3] + t[4] + t[6] + t[7]) / t[0],
+                'midpoint_waits_per_step': t[5] / K, 'nodes_put_back_per_step': t[8] / K,
                 'mean_resident_ms_per_wavefront': t[0] / 1e5 / K / (256 * 12),
-            })([float(sum(i['persist_ticks'][q] for i in infos)) for q in range(6)]
+            })([float(sum(i['persist_ticks'][q] for i in infos)) for q in range(10)]
                if persistent else None),
             'roofline': {
                 # the path is compute-bound on FP64; the contract's two values are
@@ -623,11 +634,335 @@ def main():
                                                args.cpu_seconds)
         else:
             out['cpu_baseline'] = None
-        print(json.dumps(out))
     gp.close()
+    return out
+
+
+# ---- config 5: mode sequences that cannot be enumerated -----------------------------------------
+CONFIG5 = dict(abs_frac=0.2, eps_r=1e-3, regions=1 << 30, N=8)    # regions: the cell(s) to completion
+
+
+def kuhn_cell(half, k):
+    """The k-th Kuhn simplex of the box [-half, half] (one of p! that tile it): the corner path
+    of the k-th cyclic rotation of the coordinate order."""
+    p = len(half)
+    order = np.roll(np.arange(p), -(k % p))
+    R = np.tile(-np.asarray(half, dtype=np.float64), (p + 1, 1))
+    for step in range(1, p + 1):
+        R[step:, order[step - 1]] = half[order[step - 1]]
+    return R
+
+
+def _cpu5_worker(job):
+    """One host core: the search driver on the CPU statement of the table (HiGHS on the
+    uncondensed relaxations, oracle/prefix_bb.py) on its own cell, for a bounded wall time."""
+    seed, eps_a, eps_r, cell, seconds = job
+    from explicit_hybrid_mpc_amd import bnb, bnb_frontier, examples
+    from explicit_hybrid_mpc_amd.tree import NodeData, Tree
+    from oracle import geometry, prefix_bb
+    mpc = examples.pwa4_mpc(N=CONFIG5['N'], seed=seed)
+    orc = bnb.PrefixOracle(mpc, eps_a, eps_r, table=prefix_bb.CpuPrefixTable(mpc))
+
+    def split_batch(R):
+        S1, S2, ij = [], [], []
+        for r in R:
+            a, b, e = geometry.split_along_longest_edge(r)
+            S1.append(a), S2.append(b), ij.append(e)
+        return np.array(S1), np.array(S2), np.array(ij)
+    t0 = time.perf_counter()
+    tree = Tree(NodeData(vertices=kuhn_cell(examples.theta_box(mpc), cell)))
+    stats = bnb_frontier.grow_frontier(orc, tree, 'ecc', handoff=False, split_batch=split_batch,
+                                       round_cap=4, order='lcss-first', deadline=t0 + seconds)
+    return orc.table.lp_solves, stats['host_visits'], stats['regions'], time.perf_counter() - t0
+
+
+def cpu_baseline_config5(seed, eps_a, eps_r, seconds):
+    """The same search driver (bnb_frontier.grow_frontier on bnb.PrefixOracle) with the CPU
+    statement of the table, one process per usable core, each on its own cell of the box."""
+    import multiprocessing as mp
+    cores = usable_cores()
+    saved = {k: os.environ.get(k) for k in ('OMP_NUM_THREADS', 'OPENBLAS_NUM_THREADS',
+                                            'MKL_NUM_THREADS')}
+    os.environ.update({k: '1' for k in saved})
+    t1 = time.perf_counter()
+    try:
+        with mp.get_context('spawn').Pool(cores) as pool:
+            res = pool.map_async(_cpu5_worker, [(seed, eps_a, eps_r, c, seconds)
+                                                for c in range(cores)]).get(timeout=6 * seconds + 180)
+    finally:
+        for k, v in saved.items():
+            if v is None:
+                os.environ.pop(k, None)
+            else:
+                os.environ[k] = v
+    wall = time.perf_counter() - t1
+    busy = max(r[3] for r in res)
+    return dict(value=sum(r[0] for r in res) / busy, unit='LP solves/s', cores=cores,
+                host_cores=os.cpu_count() or 1, usable_cores=cores, kind='port',
+                regions_per_s=sum(r[2] for r in res) / busy,
+                node_visits_per_s=sum(r[1] for r in res) / busy,
+                sample='%d processes (one per usable core), each the search driver of the device '
+                       'path on the CPU statement of the table (oracle/prefix_bb.py: HiGHS on the '
+                       'uncondensed prefix relaxations) on its own Kuhn cell of the box, %.1f s '
+                       'each (rounds of 4 nodes): %d node visits, %d LP solves, %d regions closed '
+                       '(%.1f s wall incl. process start)' %
+                       (cores, busy, sum(r[1] for r in res), sum(r[0] for r in res),
+                        sum(r[2] for r in res), wall))
+
+
+def measure_config5(args, ctx):
+    """
+    BASELINE.json configs[4]: n_x = 8, n_u = 3, four modes, N = 8 (65 536 mode sequences),
+    eps_r = 1e-3.  A step grows ``--cells`` Kuhn cells of the box (rank r: cells r, r + world,
+    ...: independent roots, no data-path collective -- "weak" scaling over the cells) with the
+    search oracles of bnb.PrefixOracle until ``--regions`` regions are closed per rank: every
+    mixed-integer oracle call is a branch-and-bound over mode prefixes whose relaxations are LPs
+    solved on the device (sequences.PrefixTable: blocks of the commutation table written on
+    demand).  Everything the searches remember is dropped before every step; the table's blocks
+    (problem data) stay resident.
+    """
+    import torch
+    import torch.distributed as dist
+    from explicit_hybrid_mpc_amd import bnb, bnb_frontier, distributed, examples
+    from explicit_hybrid_mpc_amd.tree import NodeData, Tree
+    backend, rank, world, device_index = (ctx['backend'], ctx['rank'], ctx['world'],
+                                          ctx['device_index'])
+    abs_frac = CONFIG5['abs_frac'] if args.abs_frac is None else args.abs_frac
+    eps_r = CONFIG5['eps_r'] if args.eps_r is None else args.eps_r
+    regions = args.regions or CONFIG5['regions']
+    n_cells = args.cells or world
+    mpc = examples.pwa4_mpc(N=CONFIG5['N'], seed=args.seed)
+    half = examples.theta_box(mpc)
+    V = examples.box_vertices(half)
+    orc = bnb.PrefixOracle(mpc, 1., 1., slots=8192, device=device_index)
+    t_eps = time.perf_counter()
+    # eps_a by the reference's rule (lib/examples.py:42-46): 2^p P_theta searches in lockstep
+    eps_a = float(np.max([j for _, _, j in bnb_frontier.p_theta_many(orc, abs_frac * V)]))
+    t_eps = time.perf_counter() - t_eps
+    orc.eps_a, orc.eps_r = eps_a, eps_r
+    orc.table.set_eps(eps_a, eps_r)
+    my_cells = list(range(rank, n_cells, world))
+
+    def snapshot():
+        st = orc.table.gp.stats()
+        return dict(lp=orc.table.lp_solves, iters=st['ipm_iters'], dev=st['lp_solves'],
+                    secs=list(st['batch_seconds']), launches=list(st['batch_launches']),
+                    calls=dict(orc.calls), expanded=orc.n_expanded,
+                    hist=orc.table.by_length.copy(), stalled=orc.table.stalled)
+
+    def step():
+        orc.table.forget()
+        trees = [Tree(NodeData(vertices=kuhn_cell(half, c))) for c in my_cells]
+        stats = bnb_frontier.grow_frontier(orc, trees, 'ecc', order='lcss-first',
+                                           table_backoff=True, round_cap=2048,
+                                           min_regions=regions, max_visits=args.max_visits)
+        return stats, trees
+
+    def barrier():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    failure = None
+    try:
+        for _ in range(args.warmup):
+            step()
+    except Exception as e:
+        failure = e
+    barrier()
+    s0 = snapshot()
+    t0 = time.perf_counter()
+    runs = []
+    try:
+        if failure is None:
+            runs = [step() for _ in range(args.steps)]
+    except Exception as e:
+        failure = e
+    barrier()
+    elapsed = time.perf_counter() - t0
+    s1 = snapshot()
+    red_dev = ('cuda:%d' % device_index) if backend == 'nccl' else 'cpu'
+    _, any_failed = distributed.allreduce_counters([0. if failure is None else 1.], device=red_dev)
+    if any_failed[0] > 0:
+        sys.stderr.write('bench.py rank %d: %s\n' % (
+            rank, failure if failure is not None else 'another rank failed'))
+        orc.close()
+        raise RuntimeError('config5 failed: %s' % (failure,))
+    K = args.steps
+    nodes = leaves = closed = depth = 0
+    for _, trees in runs:
+        for t in trees:
+            for nd, loc in t.walk():
+                nodes += 1
+                if nd.is_leaf():
+                    leaves += 1
+                    closed += bool(nd.data.is_epsilon_suboptimal)
+                    depth = max(depth, len(loc))
+    calls = {k: s1['calls'][k] - s0['calls'][k] for k in s1['calls']}
+    hist = s1['hist'] - s0['hist']
+    local = [float(s1['lp'] - s0['lp']), float(s1['iters'] - s0['iters']), float(nodes),
+             float(closed), float(sum(calls.values())), elapsed,
+             s1['secs'][0] - s0['secs'][0], s1['secs'][1] - s0['secs'][1],
+             float(s1['launches'][1] - s0['launches'][1]),
+             float(sum(st['host_visits'] for st, _ in runs))]
+    tot, mx = distributed.allreduce_counters(local, device=red_dev)
+    out = None
+    if rank == 0:
+        can = orc.table.gp.can
+        n, m, p = can.n, can.m, can.p
+        lp, iters, nodes_t, closed_t, micp, elapsed_max = (tot[0], tot[1], tot[2], tot[3], tot[4],
+                                                          float(mx[5]))
+        point_s, simplex_s = float(mx[6]), float(mx[7])
+        mean_it = iters / max(lp, 1.)
+        # dominant kernel: the batched problems over a simplex on the wide kernels
+        # (k3_simplex_batch); iterations by kind are not counted separately: every kind is
+        # priced at the mean over all LPs of the step
+        dims = {2: (n + p + 1, m + p + 2), 3: (n + p, m + p + 1), 4: (n + p + 1, m + p + 3)}
+        flops = sum(float(hist[k].sum()) * mean_it * flops_per_iteration(*dims[k]) for k in dims)
+        n_sx = float(sum(hist[k].sum() for k in dims))
+        hbm_alg = n_sx * (12 + 8 * ((p + 1) * p + (p + 1)) + 8 + 8 * (p + 1) + 4)
+        achieved = flops / max(simplex_s, 1e-12) / 1e12
+        out = {
+            'metric': 'oracle LP solves/sec + final regions/sec, 4-state 2-input N=5 hybrid MPC',
+            'value': lp / elapsed_max, 'unit': 'LP solves/s',
+            'regions_per_s': closed_t / elapsed_max,
+            'oracle_calls_answered_per_s': micp / elapsed_max,
+            'n_gpus': world, 'steps': K, 'warmup': args.warmup,
+            'ms_per_step': 1e3 * elapsed_max / K, 'ms_export': None,
+            'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None, 'dtype': 'f64',
+            'data': 'synthetic',
+            'config': {
+                'workload': 'configs[4] (NOT the headline configuration): n_x=8 n_u=3 N=8 p=8, 4 '
+                            'modes = %d mode sequences (searched by branch-and-bound over mode '
+                            'prefixes, never enumerated), inf-norm LP oracle (relaxation blocks '
+                            'n=%d m=%d), seed %d, eps_r=%g, eps_a=%.6g (abs_frac=%g), %d Kuhn '
+                            'cell(s) of the box, grown until %d regions are closed per rank' % (
+                                mpc.delta_size ** mpc.N, n, m, args.seed, eps_r, eps_a, abs_frac,
+                                n_cells, regions),
+                'regions_per_step': closed_t / K, 'nodes_per_step': nodes_t / K,
+                'open_leaves_per_step': (leaves - closed) / K if world == 1 else None,
+                'tree_depth': depth,
+                'node_visits_per_step': tot[9] / K,
+                'lp_solves_per_step': lp / K,
+                'mixed_integer_oracle_calls_per_step': {k: v / K for k, v in calls.items()},
+                'lp_solves_per_mixed_integer_oracle_call': lp / max(micp, 1.),
+                'reference_equivalent_solves_per_step': micp / K,
+                'mean_ipm_iterations': mean_it,
+                'lp_solves_by_kind_and_prefix_length_per_step': {
+                    kind: (row / float(K)).tolist() for kind, row in zip(
+                        ('point_phase_one', 'point', 'simplex_phase_one', 'min_over_simplex',
+                         'slack'), hist)},
+                'prefixes_expanded_per_step': (s1['expanded'] - s0['expanded']) / K,
+                'stalled_device_solves': s1['stalled'] - s0['stalled'],
+                'handoffs_to_the_enumerating_engine_per_step':
+                    sum(st['handoffs'] for st, _ in runs) / K,
+                'eps_a_seconds': t_eps,
+                'kernels': 'wide (one workgroup per LP, MFMA normal matrix) through the batched '
+                           'oracles ehm_simplex_idx_batch / ehm_point_idx_batch',
+                'engine': 'host-driven searches (bnb_frontier.grow_frontier: all pending nodes '
+                          'share the launches; native memo of phase-one verdicts, '
+                          'csrc/ehm_search.cpp), LPs on the device',
+                'order': 'cells that hold a commutation first, deepest first; rounds of 2048 nodes',
+                'parallelism': '%d cell(s) over %d GPU(s): cell k on rank k mod world, no '
+                               'data-path collective' % (n_cells, world),
+            },
+            'roofline': {
+                'bound': 'mfma', 'kernel': 'k3_simplex_batch',
+                'note': 'LPs over a simplex (slack n=%d m=%d) on the wide kernels: normal matrix '
+                        'on v_mfma_f64_16x16x4_f64; flops = LPs by kind x the MEAN iteration '
+                        'count of the step x SURVEY 8(d) flops per iteration; kernel seconds by '
+                        'HIP events around every launch (ehm_counters.batch_seconds)' %
+                        (dims[4][0], dims[4][1]),
+                'achieved': achieved, 'peak': FP64_PEAK_TFLOPS, 'unit': 'TFLOP/s',
+                'frac': achieved / FP64_PEAK_TFLOPS,
+                'flop_per_ipm_iteration': flops_per_iteration(*dims[4]),
+                'traffic': None, 'traffic_source': 'no PMC profile of this workload',
+                'algorithmic_bytes_per_launch': hbm_alg / max(tot[8], 1.),
+                'kernel_seconds': simplex_s, 'launches': tot[8],
+                'point_kernel_seconds': point_s,
+                'device_share_of_the_step': (simplex_s + point_s) / elapsed_max,
+                'hbm': {'achieved': hbm_alg / max(simplex_s, 1e-12) / 1e9, 'peak': HBM_PEAK_GBS,
+                        'unit': 'GB/s',
+                        'frac': hbm_alg / max(simplex_s, 1e-12) / 1e9 / HBM_PEAK_GBS},
+            },
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            out['cpu_baseline'] = cpu_baseline_config5(args.seed, eps_a, eps_r, args.cpu_seconds)
+        else:
+            out['cpu_baseline'] = None
+    orc.close()
+    return out
+
+
+# what the default invocation measures after the headline: (workload, steps, warmup)
+SECONDARY = (('config3', 2, 1), ('config4', 2, 1), ('config2q', 5, 2), ('config5', 1, 0))
+SECONDARY_KEYS = ('value', 'unit', 'ms_per_step', 'regions_per_s', 'oracle_calls_answered_per_s',
+                  'steps', 'warmup', 'roofline', 'cpu_baseline')
+SECONDARY_CONFIG_KEYS = ('workload', 'regions_per_step', 'nodes_per_step', 'lp_solves_per_step',
+                         'open_leaves_at_max_depth_per_step', 'open_leaves_per_step',
+                         'tree_depth', 'mean_ipm_iterations',
+                         'midpoint_optima_taken_from_the_table_per_step',
+                         'lp_solves_per_mixed_integer_oracle_call',
+                         'mixed_integer_oracle_calls_per_step', 'node_visits_per_step', 'engine',
+                         'kernels')
+
+
+def secondary_line(args, ctx, workload, steps, warmup):
+    """One of the other BASELINE.json configurations, for a few steps, as an entry of the
+    headline line's "secondary" list."""
+    import copy
+    a = copy.copy(args)
+    a.workload, a.steps, a.warmup = workload, steps, warmup
+    a.abs_frac = a.eps_r = a.max_depth = None
+    a.cpu_seconds = args.secondary_cpu_seconds
+    a.regions = a.cells = 0
+    a.status_dir = None
+    a.engine, a.solver, a.decide_full = 1, 2, False
+    a.no_mid_first = a.no_inherit_witness = False
+    t0 = time.perf_counter()
+    try:
+        full = (measure_config5 if workload == 'config5' else measure)(a, ctx)
+    except (Exception, SystemExit) as e:       # a failing secondary workload must not cost the headline
+        return {'workload': workload, 'error': '%s: %s' % (type(e).__name__, e)}
+    line = {k: full.get(k) for k in SECONDARY_KEYS}
+    line['name'] = workload
+    line['workload'] = full['config']['workload']
+    line['config'] = {k: full['config'][k] for k in SECONDARY_CONFIG_KEYS if k in full['config']}
+    line['wall_seconds'] = time.perf_counter() - t0
+    return line
+
+
+def main():
+    args = parse_args()
+    import torch
+    import torch.distributed as dist
+    from explicit_hybrid_mpc_amd import distributed
+    # "nccl" is RCCL on ROCm; EHM_BENCH_BACKEND=gloo lets several ranks share one GPU (tests)
+    backend = os.environ.get('EHM_BENCH_BACKEND', 'nccl')
+    rank, local_rank, world = distributed.init_process_group(backend)
+    n_dev = max(torch.cuda.device_count(), 1)
+    device_index = local_rank % n_dev
+    torch.cuda.set_device(device_index)
+    if world != args.gpus and rank == 0:
+        sys.stderr.write('bench.py: --gpus %d but WORLD_SIZE=%d; using WORLD_SIZE\n' %
+                         (args.gpus, world))
+    ctx = dict(backend=backend, rank=rank, world=world, device_index=device_index)
+    rc = 0
+    try:
+        out = (measure_config5 if args.workload == 'config5' else measure)(args, ctx)
+        if (rank == 0 and world == 1 and args.workload == 'config2' and not args.no_secondary
+                and not args.status_dir):
+            out['secondary'] = [secondary_line(args, ctx, *w) for w in SECONDARY]
+        if rank == 0:
+            print(json.dumps(out))
+    except SystemExit as e:
+        rc = e.code or 1
     if world > 1:
-        dist.barrier()
+        if rc == 0:
+            dist.barrier()
         dist.destroy_process_group()
+    if rc:
+        raise SystemExit(rc)
 
 
 if __name__ == '__main__':

@@ -93,7 +93,7 @@ class TreeInfo(ctypes.Structure):
                 ('kind_solves', ctypes.c_int64 * 5), ('kind_iters', ctypes.c_int64 * 5),
                 ('near_threshold', ctypes.c_int64), ('witness_inherited', ctypes.c_int64),
                 ('midpoints_shared', ctypes.c_int64),
-                ('persist_ticks', ctypes.c_int64 * 6)]
+                ('persist_ticks', ctypes.c_int64 * 10), ('witness_table', ctypes.c_int64)]
 
 
 class Progress(ctypes.Structure):
@@ -107,7 +107,8 @@ class Progress(ctypes.Structure):
 class Counters(ctypes.Structure):
     _fields_ = [('lp_solves', ctypes.c_int64), ('ipm_iters', ctypes.c_int64),
                 ('kernel_launches', ctypes.c_int64), ('stalled', ctypes.c_int64),
-                ('fallbacks', ctypes.c_int64), ('slivers', ctypes.c_int64)]
+                ('fallbacks', ctypes.c_int64), ('slivers', ctypes.c_int64),
+                ('batch_seconds', ctypes.c_double * 2), ('batch_launches', ctypes.c_int64 * 2)]
 
 
 _lib = None

@@ -12,6 +12,8 @@ matter -- a node's fate depends on its own record only (lib/worker.py:241-417).
 """
 
 import heapq
+import time
+
 import numpy as np
 
 from .bnb import BATCH, PLATEAU, TIE_TOL, SolverError, _rel, _set_record
@@ -456,7 +458,7 @@ def _hand_off(oracle, nodes, table_max, engine_opts, stats, above=None, costs=No
 
 def grow_frontier(oracle, branch, action='ecc', table_max=256, max_visits=None, handoff=True,
                   engine_opts=None, split_batch=None, round_cap=4096, log=None,
-                  table_backoff=False, order='fifo', min_regions=None):
+                  table_backoff=False, order='fifo', min_regions=None, deadline=None):
     """
     ``bnb.grow`` with all pending nodes visited together (module docstring).  Same arguments and
     the same tree; ``round_cap`` bounds the nodes of one round, ``split_batch(R (n,p+1,p)) ->
@@ -468,13 +470,16 @@ def grow_frontier(oracle, branch, action='ecc', table_max=256, max_visits=None, 
     again (a failed attempt costs more problems than the node's searches; the tree does not
     depend on it -- off by default until it has been measured on the device).
 
-    ``order``: 'fifo' visits the tree level by level; 'deepest' takes the deepest pending nodes
+    ``order``: 'fifo' visits the tree level by level; 'lcss-first' takes the cells that hold a
+    commutation first, deepest first (the feasibility bisection of ecc is driven only where no
+    lcss work is pending); 'deepest' takes the deepest pending nodes
     first (rounds of up to ``round_cap`` nodes) -- the order of the reference's workers, whose
     ``lcss`` recursion finishes the left subtree before it touches the right one
     (lib/worker.py:403-417): subtrees are COMPLETED, so a run that is stopped early
     (``max_visits``, or ``min_regions`` closed leaves reached) has spent its visits on regions
     that are final instead of on an ever wider open frontier.  The tree of a run to completion
-    does not depend on the order.
+    does not depend on the order.  ``deadline``: a ``time.perf_counter()`` value after which no
+    further round is started.
 
     What a node hands to its children (none of it changes a verdict, all of it saves problems):
     an ecc node the sequence that was feasible at its barycentre (tried first at theirs); an lcss
@@ -504,10 +509,16 @@ def grow_frontier(oracle, branch, action='ecc', table_max=256, max_visits=None, 
         if min_regions is not None and stats['regions'] >= min_regions:
             stats['truncated'] = True
             break
+        if deadline is not None and time.perf_counter() >= deadline:    # checked between rounds
+            stats['truncated'] = True
+            break
         cap = round_cap if max_visits is None else min(round_cap,
                                                        max_visits - stats['host_visits'])
         if order == 'deepest':
             work.sort(key=lambda item: -depth_of[id(item[0])])      # stable: ties keep their order
+        elif order == 'lcss-first':
+            # cells that hold a commutation before cells that still look for one, deepest first
+            work.sort(key=lambda item: (item[1] == 'ecc', -depth_of[id(item[0])]))
         batch, work = work[:cap], work[cap:]
         depth_in = {id(item[0]): depth_of.pop(id(item[0])) for item in batch}
 

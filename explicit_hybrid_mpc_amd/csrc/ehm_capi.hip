@@ -506,6 +506,11 @@ struct ehm_problem {
     // every tree made from this handle that is still alive: ehm_problem_destroy detaches them, so
     // a tree destroyed (or asked about) AFTER its problem never touches freed memory
     std::vector<struct ehm_tree*> trees;
+    // batched oracles (point_batch / simplex_batch): device time of their kernels, by HIP events
+    // on the handle's stream around every launch ([0] point problems, [1] problems over a simplex)
+    hipEvent_t bev[2] = {nullptr, nullptr};
+    double batch_seconds[2] = {0.0, 0.0};
+    long long batch_launches[2] = {0, 0};
     long long launches = 0;
     long long fallbacks = 0;   // LPs handed from the generation-2 to the generation-1 kernels
     long long slivers = 0;     // (simplex, commutation) pairs dropped as interior-free (slack_all)
@@ -699,6 +704,8 @@ int ehm_problem_create(const ehm_problem_desc* d, int device, ehm_problem** out)
     hipDeviceProp_t prop;
     if (hipGetDeviceProperties(&prop, device) == hipSuccess) P->num_cu = prop.multiProcessorCount;
     HIP_TRY(hipStreamCreate(&P->stream), EHM_E_NO_DEVICE);
+    (void)hipEventCreate(&P->bev[0]);
+    (void)hipEventCreate(&P->bev[1]);
     const int n = d->n, m = d->m, p = d->p, nd = d->n_delta;
     // transpose to column-major per commutation
     const size_t nG = (size_t)nd * n * m, nS = (size_t)nd * p * m, nw = (size_t)nd * m;
@@ -888,6 +895,8 @@ int ehm_problem_destroy(ehm_problem* P) {
     P->in0.release(); P->in1.release(); P->in2.release();
     P->out0.release(); P->out1.release(); P->out2.release(); P->out3.release();
     if (P->d_cnt) (void)hipFree(P->d_cnt);
+    for (hipEvent_t e : P->bev)
+        if (e) (void)hipEventDestroy(e);
     if (P->stream) (void)hipStreamDestroy(P->stream);
     delete P;
     return EHM_OK;
@@ -1040,6 +1049,10 @@ int ehm_stats(ehm_problem* P, ehm_counters* out) {
     out->kernel_launches = P->launches;
     out->fallbacks = P->fallbacks;
     out->slivers = P->slivers;
+    for (int k = 0; k < 2; ++k) {
+        out->batch_seconds[k] = P->batch_seconds[k];
+        out->batch_launches[k] = P->batch_launches[k];
+    }
     return EHM_OK;
 }
 
@@ -1079,9 +1092,11 @@ static int point_batch(ehm_problem* P, int64_t n_inst, const double* theta,
         K2Cfg cfg;
         if ((rc = k2_config(P, feas ? LP_FEAS : LP_POINT, feas ? LP_FEAS : LP_POINT, n_inst, cfg)))
             return rc;
+        (void)hipEventRecord(P->bev[0], P->stream);
         cfg.api->point(cfg.L, P->dp, (long long)n_inst, P->in0.as<double>(),
                        P->seg.as<int32_t>(), feas, P->out0.as<double>(), P->out1.as<double>(),
                        d_status, d_iters, P->d_cnt, K2Gather{});
+        (void)hipEventRecord(P->bev[1], P->stream);
         P->launches++;
         HIP_TRY(hipGetLastError(), EHM_E_HIP);
         std::vector<double> Js((size_t)n_inst), us(u0 ? (size_t)n_inst * n_u : 0);
@@ -1096,6 +1111,13 @@ static int point_batch(ehm_problem* P, int64_t n_inst, const double* theta,
         HIP_TRY(hipMemcpyAsync(its.data(), d_iters, (size_t)n_inst * sizeof(int32_t),
                                hipMemcpyDeviceToHost, P->stream), EHM_E_HIP);
         HIP_TRY(hipStreamSynchronize(P->stream), EHM_E_HIP);
+        {
+            float ms = 0.f;
+            if (hipEventElapsedTime(&ms, P->bev[0], P->bev[1]) == hipSuccess) {
+                P->batch_seconds[0] += 1e-3 * ms;
+                P->batch_launches[0]++;
+            }
+        }
         std::vector<int64_t> bad;
         for (int64_t k = 0; k < n_inst; ++k) {
             const int64_t o = order[(size_t)k];
@@ -1232,10 +1254,12 @@ static int simplex_batch(ehm_problem* P, int64_t n_inst, const double* R, const 
                          : (slack == SX_FEAS) ? LP_FEAS_SIMPLEX : LP_MIN_SIMPLEX;
         K2Cfg cfg;
         if ((rc = k2_config(P, kind, kind, n_inst, cfg))) return rc;
+        (void)hipEventRecord(P->bev[0], P->stream);
         cfg.api->simplex(cfg.L, P->dp, (long long)n_inst, P->in0.as<double>(),
                          P->in2.as<double>(), P->seg.as<int32_t>(), slack, P->out0.as<double>(),
                          alpha ? P->out1.as<double>() : (double*)nullptr, d_status,
                          d_status + n_inst, P->d_cnt, K2Gather{});
+        (void)hipEventRecord(P->bev[1], P->stream);
         P->launches++;
         HIP_TRY(hipGetLastError(), EHM_E_HIP);
         std::vector<double> objs((size_t)n_inst), als(alpha ? (size_t)n_inst * nv : 0);
@@ -1248,6 +1272,13 @@ static int simplex_batch(ehm_problem* P, int64_t n_inst, const double* R, const 
         HIP_TRY(hipMemcpyAsync(sts.data(), d_status, (size_t)n_inst * sizeof(int32_t),
                                hipMemcpyDeviceToHost, P->stream), EHM_E_HIP);
         HIP_TRY(hipStreamSynchronize(P->stream), EHM_E_HIP);
+        {
+            float ms = 0.f;
+            if (hipEventElapsedTime(&ms, P->bev[0], P->bev[1]) == hipSuccess) {
+                P->batch_seconds[1] += 1e-3 * ms;
+                P->batch_launches[1]++;
+            }
+        }
         std::vector<int64_t> bad;
         for (int64_t k = 0; k < n_inst; ++k) {
             const int64_t o = order[(size_t)k];
@@ -2306,7 +2337,8 @@ static int persistent_run(ehm_tree* T, long long max_pops = 0) {
         }
     }
     const long long waves = (long long)cfg.L.grid * (cfg.L.threads / 64);
-    const long long n_slots = T->limit + waves + 64;
+    // (+ limit / 2: a node whose midpoint is being solved elsewhere is put back, at most once)
+    const long long n_slots = T->limit + T->limit / 2 + waves + 64;
     if (n_slots > 0x7fffffffLL || T->limit > 0x7fffffffLL)
         return fail(EHM_E_INVALID, "node pool too large for the persistent engine");
     if ((rc = P->pq_slots.ensure((size_t)n_slots * 4))) return rc;
@@ -2760,7 +2792,8 @@ int ehm_partition_finish(ehm_tree* T) {
     T->info.witness_open = (int64_t)(c1.wit_open - R.c0.wit_open);
     T->info.witness_inherited = (int64_t)(c1.wit_inherited - R.c0.wit_inherited);
     T->info.midpoints_shared = (int64_t)(c1.mid_shared - R.c0.mid_shared);
-    for (int k = 0; k < 6; ++k) T->info.persist_ticks[k] = (int64_t)(c1.prof[k] - R.c0.prof[k]);
+    T->info.witness_table = (int64_t)(c1.wit_table - R.c0.wit_table);
+    for (int k = 0; k < 10; ++k) T->info.persist_ticks[k] = (int64_t)(c1.prof[k] - R.c0.prof[k]);
     T->info.near_threshold = (int64_t)(c1.routed - R.c0.routed);
     T->info.replicated_closed = R.pre_closed;
     T->info.replicated_nodes = R.pre_nodes;

@@ -202,11 +202,16 @@ struct DevCounters {
     unsigned long long routed;            // decisions with |t*| < EHM_ROUTE_TOL (full-accuracy LP)
     unsigned long long wit_inherited;     // nodes proved open by an ancestor's witness, no LP
     unsigned long long mid_shared;        // midpoint optima taken from the table, no LP
+    unsigned long long wit_table;         // nodes proved open by ANOTHER edge's midpoint optimum
+                                          // found in the table (a neighbour had bisected it)
     // persistent frontier kernel, 100 MHz wall-clock ticks summed over the wavefronts: [0] resident,
     // [1] waiting for a queue slot to be filled, [2] waiting for a midpoint another wavefront is
     // solving, [3] inside midpoint solves, [4] inside suboptimality-test solves; [5] = number of
     // waits of kind [2]
-    unsigned long long prof[6];
+    // [6] from the pop to the midpoint claim (record load, tangent-plane bound, inherited witness,
+    // longest edge), [7] child records + queue pushes, [8] nodes put back because their midpoint
+    // was being solved elsewhere
+    unsigned long long prof[10];
     unsigned int ticket;                  // work distribution of the wide sweep kernels: next
     unsigned int ticket_pad;              // frontier position (zeroed before every launch)
 };

@@ -19,6 +19,9 @@
 // (relative to 1 + |V_0|); every closer call is decided by the LP solved to FULL accuracy
 // (tolerances 1e-10), like the CPU oracle's.  ehm_tree_info.near_threshold counts those.
 #define EHM_ROUTE_TOL 1e-6
+// persistent frontier kernel: queue-slot mark of a node that has been put back once (its midpoint
+// optimum was being solved by another wavefront)
+#define EHM_REQUEUED 0x40000000
 
 namespace ehm {
 

@@ -374,8 +374,9 @@ __global__ __launch_bounds__(EHM_K2_THREADS) void k2_persist(
     enum { W_SOLVES = 0, W_ITERS, W_STALLED, W_ERRORS, W_SLACK, W_SLACK_ITERS, W_CLOSED, W_SPLITS,
            W_DEPTH, W_TRUNC, W_CERT, W_WIT, W_ROUTED, W_RCLOSED, W_RSPLITS, W_RSOLVES,
            W_INH = 17, W_MT = 18, W_MTPARK = 19,           // slot 16 is *wmargin
-           W_TQ = 20, W_TMT = 21, W_TMID = 22, W_TSLK = 23, W_NMT = 24 };   // DevCounters::prof
-    if (lane0 < 25 && lane0 != 16) wst[lane0] = 0ULL;
+           W_TQ = 20, W_TMT = 21, W_TMID = 22, W_TSLK = 23, W_NMT = 24,     // DevCounters::prof
+           W_WITT = 25, W_TPRE = 26, W_TPOST = 27, W_REQ = 28 };
+    if (lane0 < 29 && lane0 != 16) wst[lane0] = 0ULL;
     if (lane0 == 0) *wmargin = 1e300;
     wsync();
     for (;;) {
@@ -405,6 +406,10 @@ __global__ __launch_bounds__(EHM_K2_THREADS) void k2_persist(
         }
         id = __builtin_amdgcn_readfirstlane(id);
         if (id < 0) break;
+        // a node that was put back once (its midpoint was being solved elsewhere) carries a mark
+        const bool came_back = (id & EHM_REQUEUED) != 0;
+        id &= ~EHM_REQUEUED;
+        const long long t_pre = wall_clock64();
         // acquire (L1 / non-local L2 invalidate): the record behind the slot is visible
         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
         const int lane = pin(lane0);
@@ -492,9 +497,28 @@ __global__ __launch_bounds__(EHM_K2_THREADS) void k2_persist(
                 int mt_slot = 0;
                 const unsigned long long mt_tg = mt_tag(mid, p, T.mt.mask, &mt_i);
                 if (lane == 0) {
+                    wst[W_TPRE] += (unsigned long long)(wall_clock64() - t_pre);
                     long long waited = 0;
+                    // A node whose fate is known (inherited witness) needs nothing but this
+                    // optimum: if another wavefront is solving it right now, the node goes back
+                    // into the queue -- once -- and this wavefront takes another one instead of
+                    // sleeping through the solve.  (Not in budgeted launches: their left-over
+                    // must stay the contiguous slice behind the pop limit.)
+                    const bool may_requeue = decided && !came_back && deal.pop_limit <= 0 &&
+                                             id < EHM_REQUEUED;
                     mt_res = mt_claim(T.mt, mt_tg, mt_i, t_start, EHM_PERSIST_WATCHDOG_TICKS,
-                                      &mt_slot, &waited);
+                                      &mt_slot, &waited, may_requeue);
+                    if (mt_res == MT_BUSY) {
+                        const int t = atomicAdd(&ctl->tail, 1);
+                        if (t < n_slots) {
+                            __hip_atomic_store(&slots[t], id | EHM_REQUEUED, __ATOMIC_RELAXED,
+                                               __HIP_MEMORY_SCOPE_AGENT);
+                            wst[W_REQ] += 1;
+                        } else {            // no room behind the tail: wait after all
+                            mt_res = mt_claim(T.mt, mt_tg, mt_i, t_start,
+                                              EHM_PERSIST_WATCHDOG_TICKS, &mt_slot, &waited);
+                        }
+                    }
                     if (waited) {
                         wst[W_TMT] += (unsigned long long)waited;
                         wst[W_NMT] += 1;
@@ -502,6 +526,10 @@ __global__ __launch_bounds__(EHM_K2_THREADS) void k2_persist(
                 }
                 mt_res = __builtin_amdgcn_readfirstlane(mt_res);
                 mt_slot = __builtin_amdgcn_readfirstlane(mt_slot);
+                if (mt_res == MT_BUSY) {    // put back: still pending, somebody else's visit
+                    wsync();
+                    continue;
+                }
                 if (mt_res == MT_HIT) {
                     bool same = false;
                     const double ev = mt_read(T.mt, mt_slot, lane, mid, p, &same);
@@ -573,6 +601,69 @@ __global__ __launch_bounds__(EHM_K2_THREADS) void k2_persist(
                 }
             }
         }
+#if !EHM2_QUAD
+        if (!decided && T.mt.state && sign_only) {
+            // The OTHER edges' midpoints.  A neighbour that has bisected one of this simplex's
+            // edges left the optimal cost at that edge's midpoint in the table; like the node's
+            // own midpoint it is a candidate witness -- V*(mid') known, interpolated cost
+            // (V_a + V_b)/2 -- and, unlike it, a point that stays in the interior of an edge of the
+            // children, so they inherit it.  Lane e looks edge e up (read-only, nobody waits).
+            const double* Vc = node + rec_off_vcost(p);
+            double tw_l = -1e300, J_l = 0.0;
+            int ea = 0, eb = 1, slot_l = -1;
+            const int n_edges = (p + 1) * p / 2;
+            double em[8];
+            if (lane < n_edges) {
+                int rem = lane;
+                while (rem >= p - ea) { rem -= (p - ea); ++ea; }
+                eb = ea + 1 + rem;
+                if (!(ea == bi && eb == bj)) {
+                    {
+#pragma clang fp contract(off)
+                        for (int k = 0; k < p; ++k) em[k] = (node[ea * p + k] + node[eb * p + k]) / 2.0;
+                    }
+                    unsigned int e_i = 0u;
+                    const unsigned long long e_tg = mt_tag(em, p, T.mt.mask, &e_i);
+                    slot_l = mt_find(T.mt, e_tg, e_i);
+                }
+            }
+            if (__builtin_amdgcn_ballot_w64(slot_l >= 0) != 0ull) {
+                __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+                if (slot_l >= 0) {
+                    const double* e = T.mt.data + (size_t)slot_l * MT_DOUBLES;
+                    bool same = true;
+                    for (int k = 0; k < p; ++k)
+                        same = same && __double_as_longlong(e[k]) == __double_as_longlong(em[k]);
+                    const int word = (int)e[9];
+                    if (same && (word & 0xff) == 0 && ((word >> 8) & 1)) {   // converged optimum
+                        J_l = e[8];
+                        const double vb = 0.5 * (Vc[ea] + Vc[eb]);
+                        const double tw = fmin(vb - J_l - P.eps_a, vb - (1.0 + P.eps_r) * J_l);
+                        if (tw > EHM_ROUTE_TOL * (1.0 + fabs(vb))) tw_l = tw;
+                    }
+                }
+                const unsigned long long won = __builtin_amdgcn_ballot_w64(tw_l > -1e299);
+                if (won != 0ull) {
+                    // first edge (enumeration order) whose midpoint proves the node open
+                    const int src = __builtin_ctzll(won);
+                    const double tw = __shfl(tw_l, src);
+                    const double Jw = __shfl(J_l, src);
+                    const int wa = __shfl(ea, src), wb = __shfl(eb, src);
+                    open = true;
+                    decided = true;
+                    tst = tw;
+                    margin = tw;
+                    if (T.wit) {
+                        if (lane == 0) wit[0] = Jw;
+                        if (lane <= p) wit[1 + lane] = (lane == wa || lane == wb) ? 0.5 : 0.0;
+                        have_wit = true;
+                    }
+                    if (lane == 0) wst[W_WITT] += 1;
+                    wsync();
+                }
+            }
+        }
+#endif
         if (!decided) {
             const long long t_slk = wall_clock64();
             Wave W;
@@ -660,6 +751,7 @@ __global__ __launch_bounds__(EHM_K2_THREADS) void k2_persist(
             continue;
         }
         // ---- children (the midpoint solve is in Jm / stash) --------------------------------------
+        const long long t_post = wall_clock64();
         int c0 = 0;
         if (lane == 0) c0 = atomicAdd(&ctl->n_nodes, 2);
         c0 = __builtin_amdgcn_readfirstlane(c0);
@@ -813,6 +905,7 @@ __global__ __launch_bounds__(EHM_K2_THREADS) void k2_persist(
                 T.flags[id] |= 16;
             }
         }
+        const long long t_post = wall_clock64();
         const double* xmid = W.xb;
 #endif
         double* rec0 = T.rec + (size_t)c0 * T.rec_stride;
@@ -886,6 +979,7 @@ __global__ __launch_bounds__(EHM_K2_THREADS) void k2_persist(
                 atomicMax(&ctl->abort, 1);
                 atomicSub(&ctl->pending, 1);
             }
+            wst[W_TPOST] += (unsigned long long)(wall_clock64() - t_post);
         }
         wsync();
     }
@@ -902,12 +996,16 @@ __global__ __launch_bounds__(EHM_K2_THREADS) void k2_persist(
         if (wst[W_WIT]) atomicAdd(&cnt->wit_open, wst[W_WIT]);
         if (wst[W_INH]) atomicAdd(&cnt->wit_inherited, wst[W_INH]);
         if (wst[W_MT]) atomicAdd(&cnt->mid_shared, wst[W_MT]);
+        if (wst[W_WITT]) atomicAdd(&cnt->wit_table, wst[W_WITT]);
         atomicAdd(&cnt->prof[0], (unsigned long long)(wall_clock64() - t_start));
         if (wst[W_TQ]) atomicAdd(&cnt->prof[1], wst[W_TQ]);
         if (wst[W_TMT]) atomicAdd(&cnt->prof[2], wst[W_TMT]);
         if (wst[W_TMID]) atomicAdd(&cnt->prof[3], wst[W_TMID]);
         if (wst[W_TSLK]) atomicAdd(&cnt->prof[4], wst[W_TSLK]);
         if (wst[W_NMT]) atomicAdd(&cnt->prof[5], wst[W_NMT]);
+        if (wst[W_TPRE]) atomicAdd(&cnt->prof[6], wst[W_TPRE]);
+        if (wst[W_TPOST]) atomicAdd(&cnt->prof[7], wst[W_TPOST]);
+        if (wst[W_REQ]) atomicAdd(&cnt->prof[8], wst[W_REQ]);
         if (wst[W_ROUTED]) atomicAdd(&cnt->routed, wst[W_ROUTED]);
         atomicAdd(&ctl->closed, wst[W_CLOSED]);
         atomicAdd(&ctl->splits, wst[W_SPLITS]);

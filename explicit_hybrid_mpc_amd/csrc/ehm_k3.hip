@@ -383,6 +383,9 @@ EHM3_KERNEL void k3_lcss_expand(
     const int p = P.p, n_u = P.n_u;
     const int nrec = rec_doubles(p, n_u);
     __shared__ int s_ticket;
+    __shared__ int s_mt[3];
+    __shared__ double s_mtv[2];
+    const long long t_start = wall_clock64();
     for (;;) {
         __syncthreads();
         if (tid0 == 0) s_ticket = (int)atomicAdd(&cnt->ticket, 1u);
@@ -405,16 +408,63 @@ EHM3_KERNEL void k3_lcss_expand(
         __syncthreads();
         const int d = T.didx[id];
         IpmResult r;
-        int its = 0;
-        for (int attempt = 0; attempt < EHM3_ATTEMPTS; ++attempt) {
-            double b[RS];
-            assemble_point(L, mid, false, b, pin(tid));
-            r = ipm_solve(L, B, b, false, step_fraction(attempt), T.grad ? nb.g : nullptr);
-            its += r.iters;
-            if (r.status == 0) break;
+        r.obj = 0.0;
+        r.status = 0;
+        // the simplices around an edge all ask for this midpoint (12.5 splits per distinct one on
+        // the config-4 instance): the table of midpoint optima of the persistent kernel
+        // (ehm_midtable.h) serves the sweeps as well -- within a sweep (the owner of a claimed
+        // slot is a workgroup that is running its solve) and from one sweep to the next
+        int mt_res = MT_NONE, mt_slot = 0;
+        unsigned long long mt_tg = 0ull;
+        if (T.mt.state) {
+            unsigned int mt_i = 0u;
+            mt_tg = mt_tag(mid, p, T.mt.mask, &mt_i);
+            if (tid == 0) {
+                int sl = 0;
+                s_mt[0] = mt_claim(T.mt, mt_tg, mt_i, t_start, 60LL * 100000000LL, &sl);
+                s_mt[1] = sl;
+            }
+            __syncthreads();
+            mt_res = s_mt[0];
+            mt_slot = s_mt[1];
+            if (mt_res == MT_HIT) {
+                if (B.wave == 0) {      // entry layout: ehm_midtable.h
+                    bool same = false;
+                    const double ev = mt_read(T.mt, mt_slot, B.lane, mid, p, &same);
+                    if (B.lane == 8) s_mtv[0] = ev;
+                    if (B.lane == 9) s_mtv[1] = ev;
+                    if (B.lane >= 10 && B.lane < 10 + n_u) L.xb[B.lane - 10] = ev;
+                    if (T.grad && B.lane >= 18 && B.lane < 18 + p) nb.g[B.lane - 18] = ev;
+                    if (B.lane == 0) s_mt[2] = same ? 1 : 0;
+                }
+                __syncthreads();
+                if (!s_mt[2]) mt_res = MT_NONE;         // another midpoint with this tag
+                else {
+                    r.obj = s_mtv[0];
+                    r.status = ((int)s_mtv[1]) & 0xff;
+                    if (tid == 0) atomicAdd(&cnt->mid_shared, 1ULL);
+                }
+            }
         }
-        r.iters = its;
-        count_solve(cnt, r, tid);
+        if (mt_res != MT_HIT) {
+            int its = 0;
+            for (int attempt = 0; attempt < EHM3_ATTEMPTS; ++attempt) {
+                double b[RS];
+                assemble_point(L, mid, false, b, pin(tid));
+                r = ipm_solve(L, B, b, false, step_fraction(attempt), T.grad ? nb.g : nullptr);
+                its += r.iters;
+                if (r.status == 0) break;
+            }
+            r.iters = its;
+            count_solve(cnt, r, tid);
+            if (mt_res == MT_OWN) {
+                __syncthreads();
+                if (B.wave == 0)
+                    mt_publish(T.mt, mt_slot, mt_tg, B.lane, mid, p, r.obj, r.status,
+                               (r.status == 0 && r.merit <= 1.0) ? 1 : 0, its, L.xb, n_u,
+                               T.grad ? nb.g : nullptr);
+            }
+        }
         if (r.status != 0 && tid == 0) {
             atomicAdd(&cnt->errors, 1ULL);
             T.flags[id] |= 16;

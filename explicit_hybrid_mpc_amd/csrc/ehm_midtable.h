@@ -26,7 +26,7 @@ namespace ehm {
 constexpr int MT_DOUBLES = 32;   // [0,8) key | [8] J | [9] status | conv << 8 | iters << 16
                                  // | [10,18) first input | [18,26) dJ/dtheta | [26,32) unused
 constexpr int MT_PROBES = 16;
-enum { MT_NONE = 0, MT_OWN = 1, MT_HIT = 2 };
+enum { MT_NONE = 0, MT_OWN = 1, MT_HIT = 2, MT_BUSY = 3 };
 
 struct MidTable {
     unsigned long long* state;   // nullptr: no table (every other engine, option share_midpoints 0)
@@ -49,10 +49,11 @@ __device__ inline unsigned long long mt_tag(const double* mid, int p, unsigned i
 
 // ONE lane: claim or find the slot of `tag`.  MT_OWN: *slot is ours, mt_publish must follow;
 // MT_HIT: *slot holds a published entry with this tag; MT_NONE: neighbourhood full or the wait
-// ran into the watchdog -- solve without the table.
+// ran into the watchdog -- solve without the table; MT_BUSY (only with no_wait): the entry is
+// being solved by another wavefront right now.
 __device__ inline int mt_claim(const MidTable& M, unsigned long long tag, unsigned int idx,
                                long long t_start, long long watchdog_ticks, int* slot,
-                               long long* waited = nullptr) {
+                               long long* waited = nullptr, bool no_wait = false) {
     for (int probe = 0; probe < MT_PROBES; ++probe, idx = (idx + 1u) & M.mask) {
         unsigned long long s = __hip_atomic_load(&M.state[idx], __ATOMIC_RELAXED,
                                                  __HIP_MEMORY_SCOPE_AGENT);
@@ -68,6 +69,10 @@ __device__ inline int mt_claim(const MidTable& M, unsigned long long tag, unsign
         }
         if ((s & ~3ull) != tag) continue;
         if ((s & 3ull) != 3ull) {       // claimed by a wavefront that is solving it right now
+            if (no_wait) {              // the caller has something better to do than to sleep
+                *slot = (int)idx;
+                return MT_BUSY;
+            }
             const long long t_wait = wall_clock64();
             do {
                 if (wall_clock64() - t_start > watchdog_ticks) return MT_NONE;
@@ -80,6 +85,19 @@ __device__ inline int mt_claim(const MidTable& M, unsigned long long tag, unsign
         return MT_HIT;
     }
     return MT_NONE;
+}
+
+// ANY lane, read-only: the slot of a PUBLISHED entry with this tag, or -1 (absent, or still being
+// solved -- nobody waits here).  An empty slot ends the probe sequence: entries are claimed at the
+// first empty slot of their sequence and never removed.
+__device__ inline int mt_find(const MidTable& M, unsigned long long tag, unsigned int idx) {
+    for (int probe = 0; probe < MT_PROBES; ++probe, idx = (idx + 1u) & M.mask) {
+        const unsigned long long s = __hip_atomic_load(&M.state[idx], __ATOMIC_RELAXED,
+                                                       __HIP_MEMORY_SCOPE_AGENT);
+        if (s == 0ull) return -1;
+        if ((s & ~3ull) == tag) return ((s & 3ull) == 3ull) ? (int)idx : -1;
+    }
+    return -1;
 }
 
 // ALL lanes of the owner: write the entry through, then flip the state word.

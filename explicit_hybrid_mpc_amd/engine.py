@@ -396,7 +396,8 @@ class GpuProblem:
     def stats(self):
         c = _capi.Counters()
         check(self._lib.ehm_stats(self._handle, ctypes.byref(c)))
-        return {name: getattr(c, name) for name, _ in _capi.Counters._fields_}
+        return {name: (list(getattr(c, name)) if hasattr(getattr(c, name), '__len__')
+                       else getattr(c, name)) for name, _ in _capi.Counters._fields_}
 
 
 class PartitionRun:

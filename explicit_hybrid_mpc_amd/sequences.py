@@ -78,6 +78,15 @@ class PrefixSearch:
         self._prefix_of = {0: ()}
         self._feas_n = 0                # pairs solved since the verdicts were last forgotten
 
+    def forget(self):
+        """Drops everything the searches remember -- point ids, phase-one verdicts, optima -- so
+        that a second run on this table solves what the first one solved (the blocks loaded in
+        the table are problem data and stay)."""
+        self.close_search()
+        self.init_search()
+        self.__dict__.pop('_optima', None)
+        self.optima_solved = self.optima_asked = 0
+
     def close_search(self):
         h, self._search = getattr(self, '_search', None), None
         if h:
@@ -374,6 +383,10 @@ class PrefixTable(PrefixSearch):
         # or a minimum over a simplex raises, a phase one whose last iterate is not feasible raises
         self.stalled = 0
         self.stalled_relaxations = 0    # of them: relaxations answered by "no information"
+        # problems solved by (kind, prefix length): kind 0 point phase one, 1 point optimum,
+        # 2 simplex phase one, 3 minimum over a simplex, 4 suboptimality test
+        self.by_length = np.zeros((5, mpc.N + 1), dtype=np.int64)
+        self._slot_len = np.zeros(slots, dtype=np.int64)
         self._slot_of = {}
         self._blocks = {}
         self.init_search()
@@ -408,6 +421,7 @@ class PrefixTable(PrefixSearch):
                                   np.stack([b[2] for b in blocks]))
             for k, q in enumerate(missing):
                 self._slot_of[q] = first + k
+                self._slot_len[first + k] = len(q)
             self.blocks_loaded += len(missing)
         return np.array([self._slot_of[q] for q in prefixes], dtype=np.int32)
 
@@ -446,16 +460,22 @@ class PrefixTable(PrefixSearch):
         else:
             tau, _, st = self.gp.point_idx(thetas[sel], slot, feas=True)
             self.lp_solves += sel.size
+            self._tally(0, slot)
             ok = self._phase_one_verdict(tau, st)
         if feasibility_only:
             J[sel[ok]] = 0.
         elif ok.any():
             Jk, uk, st = self.gp.point_idx(thetas[sel[ok]], slot[ok])
             self.lp_solves += int(ok.sum())
+            self._tally(1, slot[ok])
             bad = st != 0
             self.stalled += int(bad.sum())
             J[sel[ok]] = np.where(bad, np.inf, Jk)      # a failed solve, not an optimum
             u0[sel[ok]] = uk
+
+    def _tally(self, kind, slot):
+        self.by_length[kind] += np.bincount(self._slot_len[np.asarray(slot)],
+                                            minlength=self.by_length.shape[1])
 
     def _phase_one_verdict(self, tau, status):
         """Feasible <=> tau* <= FEAS_TOL.  A stalled phase one whose last iterate already is
@@ -527,9 +547,11 @@ class PrefixTable(PrefixSearch):
             if todo.size:
                 tau, _, st = self.gp.simplex_idx(simplices[idx[todo]], slot[todo], mode=2)
                 self.lp_solves += todo.size
+                self._tally(2, slot[todo])
                 ok[todo] = self._phase_one_verdict(tau, st)
             if ok.any():
                 Jk, _, st = self.gp.simplex_idx(simplices[idx[ok]], slot[ok], mode=0)
+                self._tally(3, slot[ok])
                 # (a minimum is only ever a pruning bound: -inf keeps the prefix / the sequence)
                 J[idx[ok]] = self._settle_stalled(Jk, st, simplices[idx[ok]], slot[ok],
                                                   [prefixes[k] for k in idx[ok]],
@@ -553,10 +575,12 @@ class PrefixTable(PrefixSearch):
             if todo.size:
                 tau, _, st = self.gp.simplex_idx(simplices[idx[todo]], slot[todo], mode=2)
                 self.lp_solves += todo.size
+                self._tally(2, slot[todo])
                 ok[todo] = self._phase_one_verdict(tau, st)
             if ok.any():
                 tk, ak, st = self.gp.simplex_idx(simplices[idx[ok]], slot[ok], mode=1,
                                                  Vbar=vbars[idx[ok]])
+                self._tally(4, slot[ok])
                 tk = self._settle_stalled(tk, st, simplices[idx[ok]], slot[ok],
                                           [prefixes[k] for k in idx[ok]],
                                           'suboptimality-test', -np.inf, np.inf, True)

@@ -383,8 +383,14 @@ typedef struct ehm_tree_info {
     /* persistent frontier kernel: where its wavefronts spent their time, in ticks of the 100 MHz
      * wall clock summed over all of them: [0] resident, [1] waiting for a queue slot to be filled
      * (starved), [2] waiting for a midpoint optimum another wavefront was solving, [3] in midpoint
-     * solves, [4] in suboptimality-test solves; [5] = number of waits of kind [2] */
-    int64_t persist_ticks[6];
+     * solves, [4] in suboptimality-test solves; [5] = number of waits of kind [2]; [6] from the
+     * pop of a node to its midpoint claim (record load, tangent-plane bound, inherited witness,
+     * longest edge), [7] child records and queue pushes; [8] = nodes put back into the queue
+     * because another wavefront was solving their midpoint; [9] unused */
+    int64_t persist_ticks[10];
+    int64_t witness_table;      /* nodes proved open by the optimum at the midpoint of one of their
+                                   OTHER edges, left in the table of midpoint optima by a
+                                   neighbouring simplex that had bisected that edge, no LP */
 } ehm_tree_info;
 
 int ehm_tree_info_get(const ehm_tree* tree, ehm_tree_info* out);
@@ -429,6 +435,11 @@ typedef struct ehm_counters {
     int64_t slivers;        /* (simplex, commutation) pairs of the mixed-integer oracles whose
                                phase-one optimum is within 1e-7 of zero AND whose slack problem
                                found no interior: treated as infeasible on that simplex */
+    /* batched oracles on the shared-block / wide kernels: device seconds of their kernels (HIP
+     * events on the handle's stream around each launch) and launches; [0] problems at a point
+     * (ehm_solve_ptd_batch, ehm_point_idx_batch, ...), [1] problems over a simplex */
+    double  batch_seconds[2];
+    int64_t batch_launches[2];
 } ehm_counters;
 int ehm_stats(ehm_problem* prob, ehm_counters* out);
 

@@ -65,6 +65,15 @@ class OracleCPU:
         # depth-first branch-and-bound tends to return: the FIRST commutation (enumeration
         # order) that satisfies the constraints (bar_D: feasible at every vertex and t* >= 0)
         self.bar_d_rule = 'best'
+        # STUDY options for the reference's published leaf counts (lib/post_process.py:489,526;
+        # tools/cwh_leafcount_study.py) -- never used by the parity tests:
+        #   'random' rule: V_R and bar_D return ANY commutation that satisfies their constraints
+        #   (the reference minimises 0, lib/oracle.py:201,347: its solver's choice), drawn with
+        #   ``self.rng``;  ``verdict_tol`` tau: the feasibility problems count as feasible from
+        #   t* >= -tau (1 + |V_0|) on, what a solver that accepts constraint violations of its
+        #   feasibility tolerance does
+        self.rng = None
+        self.verdict_tol = 0.
 
     # -- helpers ---------------------------------------------------------------------
     def delta_index(self, delta):
@@ -181,10 +190,15 @@ class OracleCPU:
         blacklist = set()                      # lib/oracle.py:198 delta_neq_other_deltas
         while True:
             found = None
-            for d in range(len(self.models)):
-                if d not in blacklist and self._feasible_on_vertices(R, d):
-                    found = d
-                    break
+            if self.bar_d_rule == 'random':
+                ok = [d for d in range(len(self.models))
+                      if d not in blacklist and self._feasible_on_vertices(R, d)]
+                found = ok[int(self.rng.integers(len(ok)))] if ok else None
+            else:
+                for d in range(len(self.models)):
+                    if d not in blacklist and self._feasible_on_vertices(R, d):
+                        found = d
+                        break
             if found is None:
                 return None, None
             delta = self.deltas[found].copy()
@@ -206,7 +220,7 @@ class OracleCPU:
     def bar_E_delta_R(self, R, V_delta_R):
         t_best = max(self.slack(R, V_delta_R, d)[0] for d in range(len(self.models)))
         self.last_margin = abs(t_best)
-        return not (t_best >= 0.)
+        return not (t_best >= -self.verdict_tol * (1. + abs(float(np.asarray(V_delta_R)[0]))))
 
     # -- lib/oracle.py:220-283 -----------------------------------------------------------
     def in_variability_ball(self, R, V_delta_R, delta_ref, delta_star, theta_star):
@@ -228,7 +242,7 @@ class OracleCPU:
             if not self._feasible_on_vertices(R, d):
                 continue
             t, alpha = self.slack(R, V_delta_R, d)
-            if t >= 0.:
+            if t >= -self.verdict_tol * (1. + abs(float(np.asarray(V_delta_R)[0]))):
                 cand.append((t, d, alpha))
         blacklist = set()                      # lib/oracle.py:345 delta_blacklist
         while True:
@@ -238,6 +252,8 @@ class OracleCPU:
             t_max = max(c[0] for c in live)
             if self.bar_d_rule == 'first':
                 best = live[0]
+            elif self.bar_d_rule == 'random':
+                best = live[int(self.rng.integers(len(live)))]
             else:
                 best = next(c for c in live if c[0] >= t_max - TIE_TOL * (1. + abs(t_max)))
             delta_star = self.deltas[best[1]].copy()

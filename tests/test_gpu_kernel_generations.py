@@ -221,10 +221,15 @@ def test_shared_midpoint_optima_grow_the_same_tree():
               splits / max(splits - new.info['midpoints_shared'], 1),
               ref.info['lp_solves'], new.info['lp_solves'],
               ref.info['device_seconds'], new.info['device_seconds']))
-    assert ref.info['midpoints_shared'] == 0
+    assert ref.info['midpoints_shared'] == 0 and ref.info['witness_table'] == 0
     assert new.info['midpoints_shared'] > 0.5 * splits
-    assert new.info['lp_solves'] + new.info['midpoints_shared'] == ref.info['lp_solves']
-    assert again.info['lp_solves'] + again.info['midpoints_shared'] == ref.info['lp_solves']
+    # a midpoint optimum taken from the table is a problem not solved; a node proved open by
+    # another edge's midpoint in the table saves its suboptimality test (and hands its children a
+    # different witness than the test's would have been, so there is no exact count)
+    for t in (new, again):
+        assert t.info['lp_solves'] + t.info['midpoints_shared'] <= ref.info['lp_solves']
+        assert t.info['lp_solves'] + t.info['midpoints_shared'] + t.info['witness_table'] >= \
+            ref.info['lp_solves'] - t.info['witness_table']
     # (the slot a midpoint lands in depends on who came first; the count of hits only through
     # neighbourhoods of 16 full slots, which a table 1/8 full practically never has)
     assert abs(again.info['midpoints_shared'] - new.info['midpoints_shared']) <= 1e-3 * splits
@@ -235,7 +240,11 @@ def test_shared_midpoint_optima_grow_the_same_tree():
         assert np.array_equal(t.flags, ref.flags)
         assert np.array_equal(t.vertex_costs, ref.vertex_costs)           # bit for bit
         assert np.array_equal(t.vertex_inputs, ref.vertex_inputs)
-        assert np.array_equal(t.tstar, ref.tstar)
+        # recorded margins: identical except where a table witness decided (a lower bound of the
+        # optimum the suboptimality test would have found: same sign, not larger)
+        differs = t.tstar != ref.tstar
+        assert differs.sum() <= t.info['witness_table']
+        assert np.all(t.tstar[differs] > 0) and np.all(t.tstar[differs] <= ref.tstar[differs] * (1 + 1e-6))
     assert rounds.n_nodes == ref.n_nodes
     cells = {ref.vertices[k].tobytes(): (ref.left[k] < 0, ref.flags[k] & 1, ref.vertex_costs[k].tobytes())
              for k in range(ref.n_nodes)}

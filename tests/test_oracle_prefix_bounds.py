@@ -177,3 +177,62 @@ def test_bar_e_against_an_independent_milp():
         n_open += not closed
         n_closed += closed
     assert n_open >= 2 and n_closed >= 2
+
+
+def test_v_r_and_bar_d_against_independent_milps():
+    """
+    V_R and bar_D as the reference states them -- ONE mixed-integer problem each, with a copy of
+    the trajectory per vertex and one shared mode sequence (lib/oracle.py:57-66, 101-102) --
+    solved by HiGHS' branch-and-bound (oracle/milp_check.v_r_milp / bar_d_milp), against the
+    enumerating oracle: V_R is feasible for the same simplices and the solver's sequence is one
+    the enumeration finds feasible at every vertex (the canonical answer is the FIRST of them);
+    bar_D's optimum is the canonical rule's largest slack over the sequences feasible at every
+    vertex, its sequence attains it, and "no better commutation" coincides.
+    """
+    from oracle import milp_check
+    mpc = helpers.make_instance('pwa_small', 0)
+    eps_a = helpers.eps_a_rule(mpc, 0.25)
+    orc = OracleCPU(mpc, eps_a, 0.2)
+    rng = np.random.default_rng(21)
+    n_feas = n_infeas = n_star = n_none = 0
+    # small simplices (one sequence fits all vertices) and a few that span most of the box
+    some = list(helpers.random_simplices(mpc, rng, 12, scale_lo=-1.5)) + \
+        list(helpers.random_simplices(mpc, rng, 8, scale_lo=-0.15, scale_hi=0.)) + \
+        [np.array(r) for r in helpers.roots_of(mpc)[0]]
+    for R in some:
+        R = np.asarray(R)
+        delta, vx = orc.V_R(R)
+        seq = milp_check.v_r_milp(mpc, R)
+        assert (delta is None) == (seq is None)
+        if delta is None:
+            n_infeas += 1
+            continue
+        n_feas += 1
+        ok = [d for d in range(len(orc.models)) if orc._feasible_on_vertices(R, d)]
+        d_milp = next(d for d in range(len(orc.models))
+                      if tuple(np.asarray(orc.deltas[d]).reshape(mpc.N, -1).argmax(axis=1)) == seq)
+        assert d_milp in ok
+        assert np.array_equal(np.asarray(delta).astype(int), np.asarray(orc.deltas[ok[0]]).astype(int))
+        V = np.array([v[1] for v in vx])
+        t_all = {d: orc.slack(R, V, d)[0] for d in ok}
+        t_enum = max(t_all.values())
+        t_milp, seq_d, theta = milp_check.bar_d_milp(mpc, R, V, eps_a, 0.2)
+        assert abs(t_milp - t_enum) <= 1e-7 * (1 + abs(t_enum)), (t_milp, t_enum)
+        d_star = next(d for d in ok
+                      if tuple(np.asarray(orc.deltas[d]).reshape(mpc.N, -1).argmax(axis=1)) == seq_d)
+        assert t_all[d_star] >= t_enum - 1e-6 * (1 + abs(t_enum))
+        # theta* is a point of the simplex
+        lam = np.linalg.lstsq(np.vstack([R.T, np.ones(R.shape[0])]),
+                              np.concatenate([theta, [1.]]), rcond=None)[0]
+        assert lam.min() >= -1e-7
+        out = orc.bar_D_delta_R(R, V, delta)
+        if t_enum < 0.:
+            assert out[0] is None
+            n_none += 1
+        elif out[0] is not None:
+            # the canonical answer attains the optimum the one-problem statement found
+            d_can = next(d for d in ok if np.array_equal(np.asarray(orc.deltas[d]).astype(int),
+                                                         np.asarray(out[0]).astype(int)))
+            assert t_all[d_can] >= t_milp - 1e-6 * (1 + abs(t_milp))
+            n_star += 1
+    assert n_feas >= 4 and n_infeas >= 1 and n_star + n_none >= 2

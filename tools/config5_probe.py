@@ -4,7 +4,7 @@ tolerance on the device, with a clock on every layer: where do the seconds of
 ``bnb_frontier.grow_frontier`` go -- LP launches, block condensation / upload, hand-offs to the
 multi-commutation engine, the interpreter in between.
 
-    python tools/config5_probe.py ABS_FRAC EPS_R VISITS [TABLE_MAX] [ROUND_CAP] [backoff|-] [fifo|deepest] [MIN_REGIONS]
+    python tools/config5_probe.py ABS_FRAC EPS_R VISITS [TABLE_MAX] [ROUND_CAP] [backoff|-] [fifo|deepest|lcss-first] [MIN_REGIONS]
 
 One cell of the box (the Kuhn simplex on the main diagonal, 1/8! of Theta); eps_a by
 lib/examples.py:42-46 (largest P_theta cost at abs_frac x the box vertices).
@@ -69,6 +69,7 @@ def main():
     orc.eps_a, orc.eps_r = eps_a, eps_r
     orc.table.set_eps(eps_a, eps_r)
     lp0 = orc.table.lp_solves
+    orc.table.by_length[:] = 0
     CLOCK.clear()
     t = time.perf_counter()
     branch = Tree(NodeData(vertices=R.copy()))
@@ -87,6 +88,11 @@ def main():
           float(np.mean(sizes)) if sizes else None)
     print('calls', dict(orc.calls), 'LPs', orc.table.lp_solves - lp0, 'expanded', orc.n_expanded,
           'blocks', orc.table.blocks_loaded)
+    print('stalled', orc.table.stalled, 'of them answered "no information"',
+          orc.table.stalled_relaxations)
+    for kind, row in zip(('point phase one', 'point optimum', 'simplex phase one',
+                          'min over simplex', 'suboptimality test'), orc.table.by_length):
+        print('  LPs by prefix length, %-18s' % kind, row.tolist())
     for k, (n, s) in sorted(CLOCK.items(), key=lambda kv: -kv[1][1]):
         print('  %-20s %8d calls %8.2f s' % (k, n, s))
     orc.close()
