@@ -270,6 +270,11 @@ def parse_args(argv=None):
                          'cells are grown to completion)')
     ap.add_argument('--cells', type=int, default=0,
                     help='config5: Kuhn cells of the box that are grown (default: one per rank)')
+    ap.add_argument('--order', choices=['lcss-first', 'fifo', 'deepest'], default='lcss-first',
+                    help='config5: visiting order of the search driver (bnb_frontier.grow_frontier; '
+                         'the finished tree does not depend on it).  lcss-first (default) '
+                         'completes subtrees; fifo goes level by level -- with --regions it closes '
+                         'the cells that need no refinement first')
     ap.add_argument('--max-visits', type=int, default=None,
                     help='config5: cap on the node visits of a step')
     ap.add_argument('--no-cpu-baseline', action='store_true')
@@ -753,7 +758,7 @@ def measure_config5(args, ctx):
     def step():
         orc.table.forget()
         trees = [Tree(NodeData(vertices=kuhn_cell(half, c))) for c in my_cells]
-        stats = bnb_frontier.grow_frontier(orc, trees, 'ecc', order='lcss-first',
+        stats = bnb_frontier.grow_frontier(orc, trees, 'ecc', order=args.order,
                                            table_backoff=True, round_cap=2048,
                                            min_regions=regions, max_visits=args.max_visits)
         return stats, trees
@@ -862,7 +867,10 @@ def measure_config5(args, ctx):
                 'engine': 'host-driven searches (bnb_frontier.grow_frontier: all pending nodes '
                           'share the launches; native memo of phase-one verdicts, '
                           'csrc/ehm_search.cpp), LPs on the device',
-                'order': 'cells that hold a commutation first, deepest first; rounds of 2048 nodes',
+                'order': {'lcss-first': 'cells that hold a commutation first, deepest first',
+                          'fifo': 'level by level', 'deepest': 'deepest first'}[args.order] +
+                         '; rounds of 2048 nodes',
+                'stopped_early': bool(any(st['truncated'] for st, _ in runs)),
                 'parallelism': '%d cell(s) over %d GPU(s): cell k on rank k mod world, no '
                                'data-path collective' % (n_cells, world),
             },
@@ -916,6 +924,7 @@ def secondary_line(args, ctx, workload, steps, warmup):
     a.abs_frac = a.eps_r = a.max_depth = None
     a.cpu_seconds = args.secondary_cpu_seconds
     a.regions = a.cells = 0
+    a.order, a.max_visits = 'lcss-first', None
     a.status_dir = None
     a.engine, a.solver, a.decide_full = 1, 2, False
     a.no_mid_first = a.no_inherit_witness = False

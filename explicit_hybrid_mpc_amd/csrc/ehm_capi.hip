@@ -483,6 +483,8 @@ struct ehm_problem {
     int mid_first = 1;       // 1 = persistent kernel with the midpoint solve first (default)
     int inherit_wit = 1;     // 1 = open nodes hand the point that proved them open to the child
                              // that contains it (DevTree::wit; option "inherit_witness")
+    int work_first = 1;      // 1 = a wavefront of the persistent kernel that splits a node goes on
+                             // with one child itself and queues the other (option "work_first")
     int share_mid = 1;       // 1 = the persistent kernel keeps a table of midpoint optima: the
                              // simplices around an edge solve its midpoint once (DevTree::mt;
                              // option "share_midpoints")
@@ -1020,6 +1022,10 @@ int ehm_problem_set_option(ehm_problem* P, const char* name, double value) {
     }
     if (!strcmp(name, "inherit_witness")) {
         P->inherit_wit = value != 0.0;
+        return EHM_OK;
+    }
+    if (!strcmp(name, "work_first")) {
+        P->work_first = value != 0.0;
         return EHM_OK;
     }
     if (!strcmp(name, "share_midpoints")) {
@@ -2364,6 +2370,7 @@ static int persistent_run(ehm_tree* T, long long max_pops = 0) {
     }
     // budgeted launch (ehm_partition_advance): queue positions >= pop_limit stay unprocessed
     if (max_pops > 0 && max_pops < n_slots) deal.pop_limit = (int)max_pops;
+    deal.keep = (P->work_first && !getenv("EHM_NO_WORKFIRST")) ? 1 : 0;
     PersistCtl h{};
     h.head = 0;
     h.tail = (int)R.nf;

@@ -701,6 +701,11 @@ struct HyState {
     DevBuf dselV, eoffV, dselT, eoffT, dselM, eoffM;
     DevBuf sp_k, sp_c0, sp_ij, sp_d, mids, Jm, um, mst, midforced, midask, midbits, moff;
     DevBuf ctr;
+    // results of the point problems shared by (parameter, commutation, kind): the simplices
+    // around an edge ask for the same midpoint solve and the same rows of phase-one problems
+    // (K2Gather::pt, ehm_midtable.h); option "share_midpoints"
+    DevBuf pt_state, pt_data;
+    MidTable pt{nullptr, nullptr, 0u};
     DevBuf snaps;                        // DevCounters after every batched launch
     std::vector<int> snap_kind;          // LP kind of that launch
     HyCtr h{};
@@ -713,7 +718,7 @@ struct HyState {
                          &st, &alpha, &act, &best, &ths, &vJ, &vu, &vst, &Jth, &Jth_st, &Jmin,
                          &Jmin_st, &dselV, &eoffV, &dselT, &eoffT, &dselM, &eoffM, &sp_k, &sp_c0,
                          &sp_ij, &sp_d, &mids, &Jm, &um, &mst, &midforced, &midask, &midbits,
-                         &moff, &ctr, &snaps};
+                         &moff, &ctr, &snaps, &pt_state, &pt_data};
         for (DevBuf* b : all) b->release();
     }
 };
@@ -762,6 +767,19 @@ static int hy_alloc(ehm_tree* T) {
     HY_ENSURE(midbits, ch * nw * 8);   HY_ENSURE(moff, ch * 8);
     HY_ENSURE(ctr, sizeof(HyCtr));
     HY_ENSURE(snaps, (size_t)HY_MAX_SNAPS * sizeof(DevCounters));
+    H.pt = MidTable{nullptr, nullptr, 0u};
+    if (P->share_mid && P->solver_gen == 2 && !getenv("EHM_NO_MIDTABLE")) {
+        // distinct (point, commutation) pairs: a few per node on average -- 8 slots per node
+        // record, at most 4 M (a full neighbourhood degrades to "solve it yourself")
+        size_t slots = 4096;
+        while (slots < 8 * cap && slots < ((size_t)1 << 22)) slots <<= 1;
+        HY_ENSURE(pt_state, slots * sizeof(unsigned long long));
+        HY_ENSURE(pt_data, slots * MT_DOUBLES * sizeof(double));
+        H.pt = MidTable{H.pt_state.as<unsigned long long>(), H.pt_data.as<double>(),
+                        (unsigned int)(slots - 1)};
+        HIP_TRY(hipMemsetAsync(H.pt.state, 0, slots * sizeof(unsigned long long), P->stream),
+                EHM_E_HIP);
+    }
 #undef HY_ENSURE
     HIP_TRY(hipMemsetAsync(H.cnt.ptr, 0, (size_t)(3 * nd + 8) * 4, P->stream), EHM_E_HIP);
     return EHM_OK;
@@ -879,6 +897,7 @@ static int hy_run_point(ehm_tree* T, const double* base, int feas, double* J, do
     if (rc) return rc;
     const HyList L = hy_list_of(T);
     K2Gather G{L.src, L.dst, L.n_dev, 0, nullptr, (feas && !P->decide_full) ? 1 : 0};
+    G.pt = T->hy->pt;
     hy_stamp(T);
     cfg.api->point(cfg.L, P->dp, 0, base, L.seg, feas, J, u0, status, nullptr, P->d_cnt, G);
     hy_after_batch(T, feas ? LP_FEAS : LP_POINT, 1);

@@ -81,6 +81,8 @@ struct PersistDeal {
     int depth, rank, world;
     int mix;        // 1 (default) = multiplicative hash of the path code; 0 = its low bits, i.e.
                     // the last turns of the path (measured: 12 % imbalance at 8 ranks against 5 %)
+    int keep;       // 1 = work first: a wavefront that splits a node goes on with one of the
+                    // children itself and queues only the other (option "work_first")
 };
 
 // Optional indirection of the batched oracle kernels: the hybrid partition engine
@@ -95,6 +97,9 @@ struct K2Gather {
     double* grad;           // point solves: dJ/dtheta out, [dst][p]; null = not wanted
     int sign_mode;          // 0 = full accuracy; 1 / 2 = sign-only stop (ehm_ipm2.h), the value
                             // written is then the bound min(|primal|, |dual|) with the sign
+    MidTable pt;            // point batches of the multi-commutation engine: results shared by
+                            // (parameter, commutation, kind) -- the simplices around an edge ask
+                            // for the same problems at its midpoint (state == nullptr: off)
 };
 
 struct K2Launch {

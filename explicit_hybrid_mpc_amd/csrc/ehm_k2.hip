@@ -33,6 +33,7 @@ __global__ __launch_bounds__(EHM_K2_THREADS) void k2_point_batch(
     int wave_doubles, K2Gather G) {
     K2_PROLOGUE();
     if (G.n_dev) n_inst = *G.n_dev;
+    const long long t_start = wall_clock64();
     const long long per = (n_inst + gridDim.x - 1) / gridDim.x;
     const long long lo = (long long)blockIdx.x * per;
     const long long hi = (lo + per < n_inst) ? lo + per : n_inst;
@@ -53,6 +54,42 @@ __global__ __launch_bounds__(EHM_K2_THREADS) void k2_point_batch(
             const long long o = G.dst ? (long long)G.dst[inst] : inst;
             if (lane < P.p) nb.th[lane] = tsrc[lane];
             wsync();
+            // shared results (K2Gather::pt): the first wavefront to ask for (parameter,
+            // commutation, kind) solves and publishes, the others take the entry -- an LP's
+            // optimum does not depend on who solves it
+            int pt_res = MT_NONE, pt_slot = 0;
+            unsigned long long pt_tg = 0ull;
+            const unsigned int pt_kind = (unsigned int)((d * 2 + (feas ? 1 : 0)) * 4 + G.sign_mode);
+            if (G.pt.state && !G.grad) {
+                unsigned int pt_i = 0u;
+                pt_tg = pt_tag(nb.th, P.p, pt_kind, G.pt.mask, &pt_i);
+                if (lane == 0)
+                    pt_res = mt_claim(G.pt, pt_tg, pt_i, t_start, 60LL * 100000000LL, &pt_slot);
+                pt_res = __builtin_amdgcn_readfirstlane(pt_res);
+                pt_slot = __builtin_amdgcn_readfirstlane(pt_slot);
+                if (pt_res == MT_HIT) {
+                    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+                    const double* e = G.pt.data + (size_t)pt_slot * MT_DOUBLES;
+                    const double ev = lane < MT_DOUBLES ? e[lane] : 0.0;
+                    const bool differs =
+                        (lane < P.p && __double_as_longlong(ev) != __double_as_longlong(nb.th[lane])) ||
+                        (lane == 26 && ev != (double)pt_kind);
+                    if (__builtin_amdgcn_ballot_w64(differs) == 0ull) {
+                        const double Jv = __shfl(ev, 8);
+                        const int word = (int)__shfl(ev, 9);
+                        if (lane == 0) {
+                            J[o] = Jv;
+                            if (status) status[o] = word;
+                            if (iters) iters[o] = 0;
+                            atomicAdd(&cnt->mid_shared, 1ULL);
+                        }
+                        if (u0 && lane >= 10 && lane < 10 + P.n_u) u0[o * P.n_u + lane - 10] = ev;
+                        wsync();
+                        continue;
+                    }
+                    pt_res = MT_NONE;           // another problem with this tag
+                }
+            }
             Wave W;
             IpmResult r;
             int its = 0;
@@ -73,12 +110,30 @@ __global__ __launch_bounds__(EHM_K2_THREADS) void k2_point_batch(
 #endif
                 if (lane < P.p) G.grad[o * P.p + lane] = nb.F[lane];
             }
+            const double Jout = (feas && G.sign_mode) ? copysign(r.margin, r.obj) : r.obj;
             if (lane == 0) {
-                J[o] = (feas && G.sign_mode) ? copysign(r.margin, r.obj) : r.obj;
+                J[o] = Jout;
                 if (status) status[o] = r.status;
                 if (iters) iters[o] = r.iters;
             }
             if (u0 && lane < P.n_u) u0[o * P.n_u + lane] = W.xb[lane];
+            if (pt_res == MT_OWN) {
+                double* e = G.pt.data + (size_t)pt_slot * MT_DOUBLES;
+                if (lane < MT_DOUBLES) {
+                    double v = 0.0;
+                    if (lane < 8) v = lane < P.p ? nb.th[lane] : 0.0;
+                    else if (lane == 8) v = Jout;
+                    else if (lane == 9) v = (double)r.status;
+                    else if (lane < 18) v = lane - 10 < P.n_u ? W.xb[lane - 10] : 0.0;
+                    else if (lane == 26) v = (double)pt_kind;
+                    __hip_atomic_store(e + lane, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                }
+                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+                __builtin_amdgcn_s_waitcnt(0);
+                if (lane == 0)
+                    __hip_atomic_store(&G.pt.state[pt_slot], pt_tg | 3ull, __ATOMIC_RELAXED,
+                                       __HIP_MEMORY_SCOPE_AGENT);
+            }
             wsync();
         }
         pos = run_end;
@@ -379,9 +434,14 @@ __global__ __launch_bounds__(EHM_K2_THREADS) void k2_persist(
     if (lane0 < 29 && lane0 != 16) wst[lane0] = 0ULL;
     if (lane0 == 0) *wmargin = 1e300;
     wsync();
+    int keep = -1;          // the child this wavefront goes on with (see "work first" below)
+    const bool keep_child = deal.keep != 0;
     for (;;) {
         int id = -1;
-        if (lane0 == 0) {
+        if (keep >= 0) {
+            id = keep;
+            keep = -1;
+        } else if (lane0 == 0) {
             const int idx = atomicAdd(&ctl->head, 1);
             if (idx < ((deal.pop_limit > 0 && deal.pop_limit < n_slots) ? deal.pop_limit
                                                                         : n_slots)) {
@@ -964,23 +1024,38 @@ __global__ __launch_bounds__(EHM_K2_THREADS) void k2_persist(
         // the write-through stores above have completed (s_waitcnt) before the slots go out
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
         __builtin_amdgcn_s_waitcnt(0);
+        int kept = -1;
         if (lane == 0) {
+            // Work first: the wavefront goes on with ONE of the children itself (its record is
+            // hot, no queue round trip, and the deep chains that end a partition are followed at
+            // once instead of waiting behind the whole frontier at every level); the other child
+            // feeds the queue.  Budgeted launches (pop_limit) queue both: what they leave must be
+            // the contiguous slice behind the pop limit.
             const int nown = own0 + own1;
-            const int t = nown ? atomicAdd(&ctl->tail, nown) : 0;
-            if (t + nown <= n_slots) {
+            int push0 = own0, push1 = own1;
+            if (deal.pop_limit <= 0 && keep_child) {
+                if (own1) { kept = c0 + 1; push1 = 0; }
+                else if (own0) { kept = c0; push0 = 0; }
+            }
+            const int npush = push0 + push1;
+            const int t = npush ? atomicAdd(&ctl->tail, npush) : 0;
+            if (t + npush <= n_slots) {
                 int at = t;
-                if (own0)
+                if (push0)
                     __hip_atomic_store(&slots[at++], c0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                if (own1)
+                if (push1)
                     __hip_atomic_store(&slots[at], c0 + 1, __ATOMIC_RELAXED,
                                        __HIP_MEMORY_SCOPE_AGENT);
-                atomicAdd(&ctl->pending, nown - 1);    // -1 (this node) + its queued children
+                // -1 (this node) + its children, the queued one and the kept one alike
+                if (nown != 1) atomicAdd(&ctl->pending, nown - 1);
             } else {
+                kept = -1;
                 atomicMax(&ctl->abort, 1);
                 atomicSub(&ctl->pending, 1);
             }
             wst[W_TPOST] += (unsigned long long)(wall_clock64() - t_post);
         }
+        keep = __builtin_amdgcn_readfirstlane(kept);
         wsync();
     }
     wsync();

@@ -47,6 +47,21 @@ __device__ inline unsigned long long mt_tag(const double* mid, int p, unsigned i
     return (h | 4ull) & ~3ull;          // never 0, low two bits free for the phase
 }
 
+// The same table keyed by (point, kind): the multi-commutation engine asks for P_theta_delta and
+// its phase-one form at the same parameter with the same commutation from every simplex around an
+// edge or a vertex (entry[26] holds the kind and is compared like the coordinates).
+__device__ inline unsigned long long pt_tag(const double* th, int p, unsigned int kind,
+                                            unsigned int mask, unsigned int* idx) {
+    unsigned long long h = 0x9e3779b97f4a7c15ull ^ ((unsigned long long)kind * 0xd6e8feb86659fd93ull);
+    for (int i = 0; i < p; ++i) {
+        h ^= (unsigned long long)__double_as_longlong(th[i]);
+        h *= 0xbf58476d1ce4e5b9ull;
+        h ^= h >> 29;
+    }
+    *idx = (unsigned int)(h >> 33) & mask;
+    return (h | 4ull) & ~3ull;
+}
+
 // ONE lane: claim or find the slot of `tag`.  MT_OWN: *slot is ours, mt_publish must follow;
 // MT_HIT: *slot holds a published entry with this tag; MT_NONE: neighbourhood full or the wait
 // ran into the watchdog -- solve without the table; MT_BUSY (only with no_wait): the entry is

@@ -51,6 +51,7 @@ from . import engine, _capi
 from ._capi import ptr
 
 FEAS_TOL = 1e-8          # EHM_FEAS_TOL of csrc/ehm_capi.hip
+SLIVER_TOL = 1e-7        # EHM_SLIVER_TOL there
 
 
 class TableTooLarge(ValueError):
@@ -383,6 +384,7 @@ class PrefixTable(PrefixSearch):
         # or a minimum over a simplex raises, a phase one whose last iterate is not feasible raises
         self.stalled = 0
         self.stalled_relaxations = 0    # of them: relaxations answered by "no information"
+        self.slivers = 0                # of them: interior-free pairs, counted as infeasible
         # problems solved by (kind, prefix length): kind 0 point phase one, 1 point optimum,
         # 2 simplex phase one, 3 minimum over a simplex, 4 suboptimality test
         self.by_length = np.zeros((5, mpc.N + 1), dtype=np.int64)
@@ -508,7 +510,15 @@ class PrefixTable(PrefixSearch):
             self.stalled += int(bad.size)
             tau, _, st = self.gp.simplex_idx(simplices[bad], slot[bad], mode=2)
             self.lp_solves += int(bad.size)
-            feasible = (tau <= FEAS_TOL) | (st != 0)
+            # phase one minimises the largest row violation tau (>= -1): an optimum within
+            # SLIVER_TOL of zero means the relaxation's feasible set meets the simplex in a set
+            # WITHOUT interior (a vertex, a face) -- the interior-point solve had nothing to
+            # converge in.  Such a pair counts as infeasible on the simplex, the rule of the
+            # enumerating engine (ehm_counters.slivers, csrc/ehm_capi.hip) and what a simplex
+            # solver at its tolerances reports.
+            sliver = (st == 0) & (tau >= -SLIVER_TOL)
+            self.slivers += int(sliver.sum())
+            feasible = ~sliver & ((tau <= FEAS_TOL) | (st != 0))
             full = np.array([len(prefixes[k]) == self.mpc.N for k in bad], dtype=bool)
             if full_is_error and (feasible & full).any():
                 from .oracle import SolverError

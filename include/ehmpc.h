@@ -132,7 +132,14 @@ int ehm_problem_set_solver(ehm_problem* prob, int generation);
  * optima in device memory -- the simplices around an edge all bisect it at the same point and,
  * with one commutation, solve the same problem there; the first to ask solves and publishes,
  * the others take the entry (csrc/ehm_midtable.h; identical tree, ehm_tree_info.midpoints_shared
- * counts the problems saved; EHM_NO_MIDTABLE=1 disables);
+ * counts the problems saved; EHM_NO_MIDTABLE=1 disables).  The same switch covers the table's
+ * other uses: the level-synchronous wide kernels share their midpoint solves through it, the
+ * persistent kernel looks up the midpoints of a node's OTHER edges as witnesses of openness
+ * (ehm_tree_info.witness_table) and puts a node whose midpoint is being solved elsewhere back
+ * into its queue instead of waiting, and the multi-commutation engine shares the results of its
+ * point problems by (parameter, commutation, kind);
+ * "work_first" (0|1, default 1): a wavefront of the persistent kernel that splits a node goes on
+ * with one of the two children itself and queues the other (EHM_NO_WORKFIRST=1 disables);
  * "timing" (0|1, default 0): multi-commutation runs record an event pair and a counter snapshot
  * around every batched launch, so that ehm_tree_info carries kernel seconds and solves by problem
  * kind (bench.py sets it; ~25 extra stream commands per sweep otherwise spared). */

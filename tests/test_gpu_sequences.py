@@ -498,7 +498,8 @@ def _subforests_against_the_cpu_search(mpc, root, eps_a, eps_r, n_split=10, n_cl
             a, b, e = geometry.split_along_longest_edge(r)
             S1.append(a), S2.append(b), ij.append(e)
         return np.array(S1), np.array(S2), np.array(ij)
-    with_data = [(nd, loc) for nd, loc in root.walk() if nd.data.commutation is not None]
+    with_data = [(nd, loc) for nd, loc in root.walk()
+                 if getattr(nd.data, 'commutation', None) is not None]
     # a node created by an lcss split holds its parent's commutation and has a parent with data
     split = [(nd, loc) for nd, loc in with_data if not nd.is_leaf()]
     closed = [(nd, loc) for nd, loc in with_data if nd.is_leaf()]

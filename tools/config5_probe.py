@@ -9,6 +9,7 @@ multi-commutation engine, the interpreter in between.
 One cell of the box (the Kuhn simplex on the main diagonal, 1/8! of Theta); eps_a by
 lib/examples.py:42-46 (largest P_theta cost at abs_frac x the box vertices).
 """
+import os
 import sys
 import time
 
@@ -58,7 +59,8 @@ def main():
     clocked(type(mpc), 'compile')
     half = examples.theta_box(mpc)
     p = mpc.n_x
-    R = np.array([-half + 2 * half * (np.arange(p) < k) for k in range(p + 1)])
+    import bench
+    R = bench.kuhn_cell(half, int(os.environ.get('EHM_CELL', '0')))      # 0 = the main-diagonal cell
     orc = bnb.PrefixOracle(mpc, 1., 1., slots=8192)
     t0 = time.perf_counter()
     V = examples.box_vertices(half)

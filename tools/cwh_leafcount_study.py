@@ -42,12 +42,16 @@ def run(case):
     orc.bar_d_rule = rule
     orc.rng = np.random.default_rng(seed)
     orc.verdict_tol = tau
+    orc.qp_accept = 1e-6            # like the reference's OPTIMAL_INACCURATE
     part = PartitionCPU(orc)
     t0 = time.time()
-    part.run(roots, locs, 'ecc')
+    try:
+        part.run(roots, locs, 'ecc')
+    except Exception as e:          # a QP the CPU oracle's solver gives up on ends this case only
+        return case, -1, -1, orc.n_solves, time.time() - t0, '%s: %s' % (type(e).__name__, e)
     leaves = part.leaves()
     depth = max(len(loc) for loc in leaves) - min(len(loc) for loc in locs)
-    return case, len(leaves), depth, orc.n_solves, time.time() - t0
+    return case, len(leaves), depth, orc.n_solves, time.time() - t0, ''
 
 
 def main():
@@ -55,14 +59,19 @@ def main():
     procs = int(sys.argv[2]) if len(sys.argv) > 2 else 8
     cases = []
     for job in jobs:
-        cases += [(job, 'best', 0, tau) for tau in (0., 1e-8, 1e-6, 1e-4)]
-        cases += [(job, 'first', 0, 0.)]
-        cases += [(job, 'random', seed, 0.) for seed in range(8 if job == 1 else 4)]
+        if job == 1:
+            cases += [(job, 'best', 0, tau) for tau in (0., 1e-8, 1e-6, 1e-4)]
+            cases += [(job, 'first', 0, 0.)]
+            cases += [(job, 'random', seed, 0.) for seed in range(8)]
+        else:                       # minutes per case: the canonical rule, one tolerance, four draws
+            cases += [(job, 'best', 0, 0.), (job, 'best', 0, 1e-6)]
+            cases += [(job, 'random', seed, 0.) for seed in range(4)]
     with mp.get_context('spawn').Pool(procs) as pool:
-        for (job, rule, seed, tau), leaves, depth, solves, secs in pool.imap_unordered(run, cases):
+        for (job, rule, seed, tau), leaves, depth, solves, secs, err in pool.imap_unordered(run, cases):
             print('job %d (reference: %d leaves, depth %d)  rule %-6s seed %d tau %-7g -> %6d leaves, '
                   'depth %2d, %8d solves, %5.0f s' % (job, JOBS[job][3], JOBS[job][4], rule, seed,
-                                                     tau, leaves, depth, solves, secs), flush=True)
+                                                     tau, leaves, depth, solves, secs) +
+                  ('   FAILED ' + err if err else ''), flush=True)
 
 
 if __name__ == '__main__':

@@ -8,7 +8,7 @@ O=$R/gpurun_out/prof_$TAG
 mkdir -p $O
 cd /tmp; export TMPDIR=/tmp
 # BENCH_ARGS: e.g. "--workload config4" (the wide kernels); the MFMA pass only matters there
-B="python $R/bench.py --no-cpu-baseline ${BENCH_ARGS:-}"
+B="python $R/bench.py --no-cpu-baseline --no-secondary ${BENCH_ARGS:-}"
 rocprofv3 --kernel-trace --stats --output-format csv -d $O/stats -- $B --steps 3 --warmup 1 > $O/stats.log 2>&1
 S="--steps 1 --warmup 0 ${PROFILE_ARGS:-}"
 rocprofv3 --pmc SQ_WAVES SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_INSTS_VALU SQ_INSTS_LDS SQ_INSTS_SALU SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_LDS --output-format csv -d $O/pmc1 -- $B $S > $O/pmc1.log 2>&1
