@@ -672,7 +672,8 @@ __global__ __launch_bounds__(EHM_K2_THREADS) void k2_persist(
             double tw_l = -1e300, J_l = 0.0;
             int ea = 0, eb = 1, slot_l = -1;
             const int n_edges = (p + 1) * p / 2;
-            double em[8];
+            // lane e's midpoint: 8 doubles of the wavefront's LP workspace (free between solves)
+            double* em = nb.lp + 8 * (lane < n_edges ? lane : 0);
             if (lane < n_edges) {
                 int rem = lane;
                 while (rem >= p - ea) { rem -= (p - ea); ++ea; }

@@ -8,7 +8,7 @@ bench workload) the problem at that point is the same LP whoever asks -- so a pa
 midpoint LP per split where one per distinct midpoint would do.  This script grows the config-2
 instance with the CPU oracle (one process per Delaunay root) and counts both.
 
-    python -m tests.study_midpoint_sharing [abs_frac=0.1] [eps_r=0.01] [procs=8] [max_visits_per_root]
+    PYTHONPATH=. python tools/study_midpoint_sharing.py [abs_frac=0.1] [eps_r=0.01] [procs=8] [max_visits_per_root]
     EHM_STUDY_INSTANCE=config4 selects the six-dimensional single-commutation instance of
     bench.py --workload config4 (a budget of visits per root keeps it within minutes).
 """

@@ -19,7 +19,7 @@ warm-started visit would have had to solve:
     ranking:      the parent's best commutation first (an incumbent t0), then only the d with
                   t*_d(parent) >= max(0, t0) - tolerance.
 
-    python -m tests.study_ranking_bounds [job=2]      (job k of make_jobs.sh:60-66; 1..3 on a CPU)
+    PYTHONPATH=. python tools/study_ranking_bounds.py [job=2]      (job k of make_jobs.sh:60-66; 1..3 on a CPU)
 """
 import sys
 import time
