@@ -67,12 +67,15 @@ def np_capacity(n_lp):
 
 
 def kernel_source_hash():
-    """sha256 over the kernel sources: a profile is only quoted for the code it was taken from."""
+    """sha256 over the KERNEL sources: a profile is only quoted for the code it was taken from.
+    Every .hip / .h under csrc/ except ehm_capi.hip -- the C-ABI and its host orchestration; the
+    kernels bench.py prices live in ehm_kp.hip / ehm_k2.hip / ehm_k3.hip and the headers they
+    include, and a host-side edit must not make their committed profiles look stale."""
     import hashlib
     h = hashlib.sha256()
     src = os.path.join(ROOT, 'explicit_hybrid_mpc_amd', 'csrc')
     for name in sorted(os.listdir(src)):
-        if name.endswith(('.hip', '.h')):
+        if name.endswith(('.hip', '.h')) and name != 'ehm_capi.hip':
             h.update(open(os.path.join(src, name), 'rb').read())
     return h.hexdigest()[:16]
 
@@ -422,6 +425,17 @@ def measure(args, ctx):
                             with_volume=False, engine=args.engine, max_depth=args.max_depth)
         ms_export = 1e3 * (time.perf_counter() - t1) - 1e3 * elapsed / args.steps
         del flat
+    # N > 1: the regions of all ranks together must be the regions of ONE unsharded partition (a
+    # node's fate depends on its own record only, so the tree does not depend on who grows which
+    # part of it): rank 0 grows the whole tree once more, outside the timed region, and the line
+    # carries both counts
+    whole = None
+    if world > 1 and rank == 0:
+        try:
+            whole = gp.partition(roots, action='ecc', max_nodes=args.max_nodes, export=False,
+                                 with_volume=False, engine=args.engine, max_depth=args.max_depth)
+        except Exception as e:          # reported, not fatal: the timed numbers stand
+            whole = dict(error=str(e))
     # totals over ranks (max time, summed work)
     keys = ['lp_solves', 'ipm_iters', 'n_nodes', 'n_closed', 'ref_solves', 'decide_solves',
             'decide_iters', 'cert_closed', 'witness_open', 'witness_inherited',
@@ -576,6 +590,11 @@ def measure(args, ctx):
                 'rebalance_rounds_per_step': float(mx[len(keys) + 4]) / K,
                 'nodes_moved_per_step': float(tot[len(keys) + 3]) / K,
                 'lp_solves_per_rank': [int(v) for v in per_rank],
+                'tree_identity': None if whole is None else (
+                    dict(ok=False, error=whole['error']) if 'error' in whole else
+                    dict(regions_of_one_unsharded_partition=int(whole['n_closed']),
+                         regions_summed_over_the_ranks_per_step=closed / K,
+                         ok=bool(abs(closed / K - whole['n_closed']) < 0.5))),
                 'load_imbalance_max_over_mean': distributed.imbalance(per_rank),
             },
             # where the wavefronts of the persistent kernel spent their time (fractions of the
@@ -634,6 +653,10 @@ def measure(args, ctx):
                                 'roofline" is structurally out of reach (SURVEY 8(d))'},
             },
         }
+        ident = out['config']['tree_identity']
+        if ident is not None and not ident.get('ok'):
+            sys.stderr.write('bench.py: the ranks together did NOT grow the tree of one '
+                             'unsharded partition: %s\n' % (ident,))
         if world == 1 and not args.no_cpu_baseline:
             out['cpu_baseline'] = cpu_baseline(args.workload, args.seed, eps_a, args.eps_r,
                                                args.cpu_seconds)

@@ -36,6 +36,7 @@ EXPORTED = [
     'ehm_explicit_last_error', 'ehm_partition_progress', 'ehm_partition_counts', 'ehm_partition_advance', 'ehm_problem_set_quadratic',
     'ehm_feas_all_batch', 'ehm_lcss_batch', 'ehm_partition_movable',
     'ehm_problem_update_blocks', 'ehm_simplex_idx_batch', 'ehm_point_idx_batch',
+    'ehm_abi_sizes',
 ]
 
 
@@ -134,6 +135,16 @@ def load(build_if_missing=True):
     vp = ctypes.c_void_p
     i64 = ctypes.c_int64
     i32 = ctypes.c_int32
+    # the struct mirrors below must be the library's structs: a mirror that is too small would be
+    # overrun by the library's writes (ehm_abi_sizes, include/ehmpc.h)
+    mirrors = (ProblemDesc, RunOpts, NodeInit, Progress, TreeInfo, Counters)
+    sizes = (i64 * len(mirrors))()
+    lib.ehm_abi_sizes.argtypes = [vp, i32]
+    if lib.ehm_abi_sizes(ctypes.addressof(sizes), len(mirrors)) != len(mirrors) or any(
+            int(sizes[k]) != ctypes.sizeof(m) for k, m in enumerate(mirrors)):
+        raise EhmError(EHM_E_INVALID, 'libehmpc.so and its ctypes binding disagree about the public '
+                       'structs: %s against %s (rebuild the library)' % (
+                           [int(v) for v in sizes], [ctypes.sizeof(m) for m in mirrors]))
     lib.ehm_last_error.restype = ctypes.c_char_p
     lib.ehm_version.restype = ctypes.c_char_p
     lib.ehm_stream.restype = vp

@@ -984,6 +984,15 @@ int ehm_problem_set_solver(ehm_problem* P, int generation) {
 }
 
 // wave-primitive self test of the k2 instances: out[5] per instance (see k2_selftest)
+int ehm_abi_sizes(int64_t* sizes, int32_t n) {
+    const int64_t all[] = {(int64_t)sizeof(ehm_problem_desc), (int64_t)sizeof(ehm_run_opts),
+                           (int64_t)sizeof(ehm_node_init),    (int64_t)sizeof(ehm_progress),
+                           (int64_t)sizeof(ehm_tree_info),    (int64_t)sizeof(ehm_counters)};
+    const int32_t known = (int32_t)(sizeof all / sizeof all[0]);
+    for (int32_t k = 0; sizes && k < n && k < known; ++k) sizes[k] = all[k];
+    return known;
+}
+
 int ehm_selftest(int device, double* out, int32_t max_instances, int32_t* n_instances) {
     if (!out || !n_instances) return fail(EHM_E_INVALID, "null argument");
     int ndev = 0;

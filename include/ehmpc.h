@@ -450,6 +450,13 @@ typedef struct ehm_counters {
 } ehm_counters;
 int ehm_stats(ehm_problem* prob, ehm_counters* out);
 
+/* sizeof of the public structs, in this order: ehm_problem_desc, ehm_run_opts, ehm_node_init,
+ * ehm_progress, ehm_tree_info, ehm_counters.  A binding that mirrors the structs (the ctypes
+ * classes of explicit_hybrid_mpc_amd/_capi.py) checks itself against the library it loaded: a
+ * mirror that is too small would be overrun by the library's writes.  Returns the number of
+ * sizes it knows; writes at most n of them.  Needs no device. */
+int ehm_abi_sizes(int64_t* sizes, int32_t n);
+
 /* Device self test of the wave-level primitives (DPP reductions, reciprocal) of every
  * compiled kernel instance: out[5*k .. 5*k+4] for instance k, expected
  * {1072, 99, 25, 1/3, -1}.  Test hook, not part of the reference's surface. */

@@ -303,3 +303,17 @@ def test_midpoint_table_protocol_under_threads(tmp_path):
                    check=True)
     out = subprocess.run([exe], capture_output=True, text=True, timeout=120)
     assert out.returncode == 0 and 'OK' in out.stdout, out.stdout + out.stderr
+
+
+def test_ctypes_mirrors_are_the_librarys_structs():
+    """ehm_abi_sizes (include/ehmpc.h): the ctypes classes of _capi.py have the sizes of the C
+    structs they mirror -- _capi.load() refuses a library it would let overrun its buffers."""
+    import ctypes
+    lib = _capi.load()
+    mirrors = (_capi.ProblemDesc, _capi.RunOpts, _capi.NodeInit, _capi.Progress, _capi.TreeInfo,
+               _capi.Counters)
+    sizes = (ctypes.c_int64 * 8)()
+    n = lib.ehm_abi_sizes(ctypes.addressof(sizes), 8)
+    assert n == len(mirrors)
+    assert [int(sizes[k]) for k in range(n)] == [ctypes.sizeof(m) for m in mirrors]
+    assert lib.ehm_abi_sizes(None, 0) == n
