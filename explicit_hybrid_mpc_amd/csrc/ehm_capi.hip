@@ -626,7 +626,8 @@ struct K2Cfg {
 };
 
 // kind_a / kind_b: the LP kinds the launch may assemble (workspace sized for the larger)
-static int k2_config(ehm_problem* P, int kind_a, int kind_b, long long n_items, K2Cfg& cfg) {
+static int k2_config(ehm_problem* P, int kind_a, int kind_b, long long n_items, K2Cfg& cfg,
+                     bool persist = false) {
     int n_lp, ne, n_lp2, ne2;
     kind_dims(P->dp, kind_a, n_lp, ne);
     kind_dims(P->dp, kind_b, n_lp2, ne2);
@@ -637,16 +638,29 @@ static int k2_config(ehm_problem* P, int kind_a, int kind_b, long long n_items, 
     if (!api)
         return fail(EHM_E_INVALID, "no kernel instance for an LP with %d columns, %d row slots",
                     n_lp, slots);
-    const size_t shared = api->shared_doubles(P->dp);
-    const size_t wave = api->wave_doubles(P->dp, n_lp, ne);
+    const size_t wave = api->wave_doubles(P->dp, n_lp, ne, persist ? 1 : 0);
     const size_t budget = EHM_LDS_BUDGET / sizeof(double);
-    if (shared + wave > budget)
-        return fail(EHM_E_INVALID, "LP does not fit in LDS (%zu + %zu doubles)", shared, wave);
+    // w and c of the commutation behind the constant block in LDS -- unless that costs the
+    // workgroup a wavefront (DevProblem::wc_lds; the wide kernels keep nothing in LDS)
+    long long max_w = api->max_threads / api->threads_per_lp;
+    if (const char* e = getenv("EHM_K2_MAX_WAVES"))     // experiments: cap the LPs per workgroup
+        if (atoi(e) > 0 && api->threads_per_lp == 64) max_w = std::min<long long>(max_w, atoi(e));
+    DevProblem dp = P->dp;
+    dp.wc_lds = 1;
+    const size_t shared1 = api->shared_doubles(dp);
+    dp.wc_lds = 0;
+    const size_t shared0 = api->shared_doubles(dp);
+    if (shared0 + wave > budget)
+        return fail(EHM_E_INVALID, "LP does not fit in LDS (%zu + %zu doubles)", shared0, wave);
+    const long long nw1 = (shared1 + wave <= budget)
+        ? std::min<long long>(max_w, (long long)((budget - shared1) / wave)) : 0;
+    const long long nw0 = std::min<long long>(max_w, (long long)((budget - shared0) / wave));
+    const int wc_lds = (nw1 >= nw0 && nw1 >= 1) ? 1 : 0;
+    const size_t shared = wc_lds ? shared1 : shared0;
     if (api->threads_per_lp > 64 && !P->dp.Wr3)
         return fail(EHM_E_INVALID, "wide kernels selected but their constant image is missing");
     // LPs per workgroup: as many wavefronts as fit (wave-local kernels); exactly one (wide)
-    long long nw = std::min<long long>(api->max_threads / api->threads_per_lp,
-                                       (long long)((budget - shared) / wave));
+    long long nw = wc_lds ? nw1 : nw0;
     nw = std::max(1LL, std::min(nw, n_items));
     const size_t lds = (shared + (size_t)nw * wave) * sizeof(double);
     if (!P->k2_ready.count(api)) {
@@ -664,6 +678,7 @@ static int k2_config(ehm_problem* P, int kind_a, int kind_b, long long n_items, 
     cfg.L.lds_bytes = lds;
     cfg.L.wave_doubles = (int)wave;
     cfg.L.stream = P->stream;
+    cfg.L.wc_lds = wc_lds;
     return EHM_OK;
 }
 
@@ -2303,7 +2318,7 @@ static int persistent_run(ehm_tree* T, long long max_pops = 0) {
     ehm_problem* P = T->prob;
     auto& R = T->run;
     K2Cfg cfg;
-    int rc = k2_config(P, LP_SLACK, LP_POINT, 1LL << 40, cfg);    // the full persistent grid
+    int rc = k2_config(P, LP_SLACK, LP_POINT, 1LL << 40, cfg, true);   // the full persistent grid
     if (rc) return rc;
     if (!cfg.api->persist) return fail(EHM_E_INVALID, "no persistent kernel for this LP size");
     // two solver widths where a pair is compiled: the midpoint LPs have p + 1 columns less
@@ -2328,14 +2343,26 @@ static int persistent_run(ehm_tree* T, long long max_pops = 0) {
                 }
         }
         if (kp) {
-            const size_t shared = kp->shared_doubles(P->dp);
             const size_t wave = kp->wave_doubles(P->dp, n_d, ne_d, n_e);
             const size_t budget = EHM_LDS_BUDGET / sizeof(double);
-            long long nw = std::min<long long>(kp->max_threads / 64,
-                                               (long long)((budget - shared) / wave));
+            // w and c in LDS unless they cost a wavefront (k2_config; at config 2 they do: the
+            // twelfth wavefront of the workgroup)
+            DevProblem dp = P->dp;
+            dp.wc_lds = 1;
+            const size_t shared1 = kp->shared_doubles(dp);
+            dp.wc_lds = 0;
+            const size_t shared0 = kp->shared_doubles(dp);
+            const long long nw1 = (shared1 + wave <= budget)
+                ? std::min<long long>(kp->max_threads / 64, (long long)((budget - shared1) / wave)) : 0;
+            const long long nw0 = (shared0 + wave <= budget)
+                ? std::min<long long>(kp->max_threads / 64, (long long)((budget - shared0) / wave)) : 0;
+            const int wc_lds = (nw1 >= nw0 && nw1 >= 1) ? 1 : 0;
+            const size_t shared = wc_lds ? shared1 : shared0;
+            long long nw = wc_lds ? nw1 : nw0;
             if (shared + wave > budget || nw < 1) {
                 kp = nullptr;
             } else {
+                cfg.L.wc_lds = wc_lds;
                 if (!P->kp_ready.count(kp)) {
                     HIP_TRY(kp->set_lds(EHM_LDS_BUDGET), EHM_E_HIP);
                     P->kp_ready.insert(kp);

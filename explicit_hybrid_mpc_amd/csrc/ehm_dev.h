@@ -23,6 +23,8 @@ struct DevProblem {
     // so that  G z - S psi <= w + S R0  with  psi = theta - R0  (ehm_ipm2.h).
     const double* Wc2;  // [n_delta][ncw2][lda2]
     int lda2, ncw2;
+    int wc_lds;         // shared-block kernels: 1 = w and c of the commutation sit behind Wc in LDS,
+                        // 0 = they are read from device memory (set per launch: K2Launch::wc_lds)
     // wide kernels (ehm_k3.hip, LPs with more than 32 columns): the same block row-major,
     // padded to 64 columns and to mpad3 rows (multiple of 64) with zeros -- operand layout of
     // v_mfma_f64_16x16x4_f64 and of the lane-per-column products (ehm_ipm3.h).  Null when

@@ -191,30 +191,43 @@ __device__ __forceinline__ double frcp(double x) {
 // ---------------------------------------------------------------------------------------
 // LDS layout
 // ---------------------------------------------------------------------------------------
-// Shared by the workgroup (image of DevProblem::Wc2 + w + c of one commutation).
+// Shared by the workgroup: the image of DevProblem::Wc2 of one commutation in LDS.  The right-hand
+// side w and the cost c of that commutation follow it in LDS (P.wc_lds = 1) or are read where they
+// are, in device memory (P.wc_lds = 0): the launcher keeps them in LDS unless the 180 doubles
+// they take at config 2 cost the workgroup a wavefront (the persistent frontier kernel's twelfth).
 struct Shared {
-    const double* Wc;   // [ncw][lda]   G | -S | -1 | 0
+    const double* Wc;   // [ncw][lda]   G | -S | -1 | 0      (LDS)
     const double* wv;   // [m]
     const double* cv;   // [n]
     int n, m, p, lda, ncw;
 };
 __host__ __device__ inline size_t shared_doubles(const DevProblem& P) {
-    return (((size_t)P.ncw2 * P.lda2 + P.m + P.n) + 1) & ~(size_t)1;
+    return (((size_t)P.ncw2 * P.lda2 + (P.wc_lds ? P.m + P.n : 0)) + 1) & ~(size_t)1;
 }
 __device__ inline void carve_shared(Shared& S, double* base, const DevProblem& P) {
     S.n = P.n; S.m = P.m; S.p = P.p; S.lda = P.lda2; S.ncw = P.ncw2;
     S.Wc = base;
-    S.wv = base + (size_t)P.ncw2 * P.lda2;
-    S.cv = S.wv + P.m;
+    if (P.wc_lds) {
+        S.wv = base + (size_t)P.ncw2 * P.lda2;
+        S.cv = S.wv + P.m;
+    } else {
+        S.wv = P.w;     // commutation 0; use_commutation() after a load_shared of another one
+        S.cv = P.c;
+    }
+}
+__device__ inline void use_commutation(Shared& S, const DevProblem& P, int d) {
+    if (!P.wc_lds) S.wv = P.w + (size_t)d * P.m;
 }
 // all threads of the workgroup; caller brackets it with __syncthreads()
 __device__ inline void load_shared(const DevProblem& P, int d, double* base, int tid, int nthr) {
     const int tot = P.ncw2 * P.lda2;
     const double* src = P.Wc2 + (size_t)d * tot;
     for (int k = tid; k < tot; k += nthr) base[k] = src[k];
-    const double* wd = P.w + (size_t)d * P.m;
-    for (int k = tid; k < P.m; k += nthr) base[tot + k] = wd[k];
-    for (int k = tid; k < P.n; k += nthr) base[tot + P.m + k] = P.c[k];
+    if (P.wc_lds) {
+        const double* wd = P.w + (size_t)d * P.m;
+        for (int k = tid; k < P.m; k += nthr) base[tot + k] = wd[k];
+        for (int k = tid; k < P.n; k += nthr) base[tot + P.m + k] = P.c[k];
+    }
 }
 
 // Private to a wavefront.

@@ -35,6 +35,14 @@ __host__ __device__ inline size_t k2_node_doubles(int p, int n_u) {
     return (nrec + aug + (size_t)p * p + 8 + 1) & ~(size_t)1;
 }
 
+// Midpoint-first flow of the persistent frontier kernel: what a node keeps across its
+// suboptimality test, parked behind the wavefront's LP workspace -- [0, n_u) the first input of
+// the midpoint solve, [n_u, n_u + p) its cost gradient, [n_u + p, n_u + 2p + 2) the witness that
+// is handed on to the children (DevTree::wit).
+__host__ __device__ inline int k2_stash_doubles(int p, int n_u) {
+    return (n_u + 2 * p + 2 + 1) & ~1;
+}
+
 // Row layout of an LP with m MPC rows and ne extra rows: MPC row i sits at (lane i%64,
 // slot i/64); the extras follow at xbase (directly behind the MPC rows when they fit into
 // the same slot, otherwise in a slot of their own).  Only the LAST slot can hold extras.
@@ -108,6 +116,7 @@ struct K2Launch {
     size_t lds_bytes;
     int wave_doubles;   // LDS doubles per wavefront
     hipStream_t stream;
+    int wc_lds;         // DevProblem::wc_lds of this launch (the wrappers copy it into P)
 };
 
 // One compiled kernel family: the wave-local instances of ehm_k2.hip (threads_per_lp = 64,
@@ -116,7 +125,8 @@ struct K2Launch {
 struct K2Api {
     int np, slots, max_threads, threads_per_lp;
     hipError_t (*set_lds)(int bytes);
-    size_t (*wave_doubles)(const DevProblem& P, int n_lp, int ne);   // LDS doubles per LP
+    // LDS doubles per LP; persist: with what the midpoint-first persistent kernel parks per node
+    size_t (*wave_doubles)(const DevProblem& P, int n_lp, int ne, int persist);
     size_t (*shared_doubles)(const DevProblem& P);
     void (*point)(const K2Launch&, DevProblem, long long n_inst, const double* theta,
                   const int32_t* seg, int feas, double* J, double* u0, int32_t* status,

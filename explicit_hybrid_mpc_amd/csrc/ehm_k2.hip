@@ -44,6 +44,7 @@ __global__ __launch_bounds__(EHM_K2_THREADS) void k2_point_batch(
         const long long run_end = (seg[d + 1] < hi) ? seg[d + 1] : hi;
         __syncthreads();
         load_shared(P, d, sm, tid, blockDim.x);
+        use_commutation(S, P, d);
         if (tid == 0) s_ctr = (int)(pos - lo);
         __syncthreads();
         for (;;) {
@@ -161,6 +162,7 @@ __global__ __launch_bounds__(EHM_K2_THREADS) void k2_simplex_batch(
         const long long run_end = (seg[d + 1] < hi) ? seg[d + 1] : hi;
         __syncthreads();
         load_shared(P, d, sm, tid, blockDim.x);
+        use_commutation(S, P, d);
         if (tid == 0) s_ctr = (int)(pos - lo);
         __syncthreads();
         for (;;) {
@@ -511,10 +513,11 @@ __global__ __launch_bounds__(EHM_K2_THREADS) void k2_persist(
         const int dep = T.depth[id];
         const bool can_split = !(max_depth > 0 && dep >= max_depth);
         double* mid = nb.th;
-        // last 32 doubles of the wave's LDS: [0,8) midpoint input, [8,16) midpoint gradient,
-        // [16, 16+p+2) the witness handed on to the children (DevTree::wit)
-        double* stash = nb.rec - 0 + (size_t)wave_doubles - 32;
-        double* wit = stash + 16;
+        // the last k2_stash_doubles of the wave's LDS: midpoint input, midpoint gradient,
+        // the witness handed on to the children (DevTree::wit)
+        const int st_g = n_u, st_w = n_u + p;       // layout: k2_stash_doubles (ehm_k2.h)
+        double* stash = nb.rec + (size_t)wave_doubles - k2_stash_doubles(p, n_u);
+        double* wit = stash + st_w;
         bool have_wit = false;
         int mt_res = MT_NONE;       // table of midpoint optima (ehm_midtable.h)
         int bi = 0, bj = 1;
@@ -603,7 +606,7 @@ __global__ __launch_bounds__(EHM_K2_THREADS) void k2_persist(
                         mid_conv = ((word >> 8) & 1) != 0;
                         mid_iters = 0;                  // no iterations were spent here
                         if (lane >= 10 && lane < 10 + n_u) stash[lane - 10] = ev;
-                        if (T.grad && lane >= 18 && lane < 18 + p) stash[8 + lane - 18] = ev;
+                        if (T.grad && lane >= 18 && lane < 18 + p) stash[st_g + lane - 18] = ev;
                         if (lane == 0) wst[W_MT] += 1;
                     }
                 }
@@ -635,7 +638,7 @@ __global__ __launch_bounds__(EHM_K2_THREADS) void k2_persist(
             if (lane < n_u) stash[lane] = Wm.xb[lane];
             if (lane == 0) wst[W_TMID] += (unsigned long long)(wall_clock64() - t_mid);
             }
-            if (mt_res != MT_HIT && T.grad && lane < p) stash[8 + lane] = nb.F[lane];
+            if (mt_res != MT_HIT && T.grad && lane < p) stash[st_g + lane] = nb.F[lane];
             wsync();
             if (T.mt.state) {
                 const unsigned long long park = wst[W_MTPARK];
@@ -645,7 +648,7 @@ __global__ __launch_bounds__(EHM_K2_THREADS) void k2_persist(
                     const unsigned long long mt_tg = mt_tag(mid, p, T.mt.mask, &mt_i);
                     mt_publish(T.mt, (int)(park >> 2), mt_tg, lane, mid, p, Jm, mid_status,
                                mid_conv ? 1 : 0, mid_iters, stash, n_u,
-                               T.grad ? stash + 8 : nullptr);
+                               T.grad ? stash + st_g : nullptr);
                 }
             }
             if (sign_only && mid_conv && !decided) {
@@ -831,8 +834,8 @@ __global__ __launch_bounds__(EHM_K2_THREADS) void k2_persist(
             double* g0 = T.grad + (size_t)c0 * ng;
             for (int k = lane; k < ng; k += 64) {
                 const double gv = gp_[k];
-                const double a0 = (k >= bi * p && k < bi * p + p) ? stash[8 + k - bi * p] : gv;
-                const double a1 = (k >= bj * p && k < bj * p + p) ? stash[8 + k - bj * p] : gv;
+                const double a0 = (k >= bi * p && k < bi * p + p) ? stash[st_g + k - bi * p] : gv;
+                const double a1 = (k >= bj * p && k < bj * p + p) ? stash[st_g + k - bj * p] : gv;
                 __hip_atomic_store(g0 + k, a0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                 __hip_atomic_store(g0 + ng + k, a1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             }
@@ -1174,17 +1177,18 @@ hipError_t set_lds(int bytes) {
     return hipSuccess;
 }
 
-size_t wave_doubles_for(const DevProblem& P, int n_lp, int ne) {
-    // (+16: the midpoint-first flow of k2_persist parks the midpoint solve's input and gradient
-    // in the last 16 doubles of the wavefront's workspace)
+size_t wave_doubles_for(const DevProblem& P, int n_lp, int ne, int persist) {
+    // (+ k2_stash_doubles: what the midpoint-first flow of k2_persist parks per node behind the
+    // wavefront's workspace; the batch and sweep kernels park nothing)
     return k2_node_doubles(P.p, P.n_u) + wave_lp_doubles(n_lp, ne) +
-           (EHM_PERSIST_MIDFIRST ? 32 : 0);
+           ((EHM_PERSIST_MIDFIRST && persist) ? k2_stash_doubles(P.p, P.n_u) : 0);
 }
 size_t shared_doubles_for(const DevProblem& P) { return shared_doubles(P); }
 
 void l_point(const K2Launch& L, DevProblem P, long long n_inst, const double* theta,
              const int32_t* seg, int feas, double* J, double* u0, int32_t* status,
              int32_t* iters, DevCounters* cnt, K2Gather G) {
+    P.wc_lds = L.wc_lds;
     if (feas)
         hipLaunchKernelGGL(k2_point_batch<1>, dim3(L.grid), dim3(L.threads), L.lds_bytes, L.stream,
                            P, n_inst, theta, seg, J, u0, status, iters, cnt, L.wave_doubles, G);
@@ -1195,6 +1199,7 @@ void l_point(const K2Launch& L, DevProblem P, long long n_inst, const double* th
 void l_simplex(const K2Launch& L, DevProblem P, long long n_inst, const double* R,
                const double* Vbar, const int32_t* seg, int mode, double* obj, double* alpha,
                int32_t* status, int32_t* iters, DevCounters* cnt, K2Gather G) {
+    P.wc_lds = L.wc_lds;
 #define K2_SX_LAUNCH(M)                                                                      \
     hipLaunchKernelGGL(k2_simplex_batch<M>, dim3(L.grid), dim3(L.threads), L.lds_bytes, L.stream, \
                        P, n_inst, R, Vbar, seg, obj, alpha, status, iters, cnt, L.wave_doubles, G)
@@ -1205,22 +1210,26 @@ void l_simplex(const K2Launch& L, DevProblem P, long long n_inst, const double* 
 }
 void l_decide(const K2Launch& L, DevProblem P, DevTree T, const int32_t* frontier, int nf,
               int32_t* open_flag, DevCounters* cnt, int sign_only) {
+    P.wc_lds = L.wc_lds;
     hipLaunchKernelGGL(k2_lcss_decide, dim3(L.grid), dim3(L.threads), L.lds_bytes, L.stream, P,
                        T, frontier, nf, open_flag, cnt, L.wave_doubles, sign_only);
 }
 void l_expand(const K2Launch& L, DevProblem P, DevTree T, const int32_t* open_list, int n_open,
               int child_base, int32_t* next_frontier, DevCounters* cnt) {
+    P.wc_lds = L.wc_lds;
     hipLaunchKernelGGL(k2_lcss_expand, dim3(L.grid), dim3(L.threads), L.lds_bytes, L.stream, P,
                        T, open_list, n_open, child_base, next_frontier, cnt, L.wave_doubles);
 }
 void l_vertex(const K2Launch& L, DevProblem P, DevTree T, const int32_t* nodes, int n_nodes,
               DevCounters* cnt) {
+    P.wc_lds = L.wc_lds;
     hipLaunchKernelGGL(k2_vertex_solve, dim3(L.grid), dim3(L.threads), L.lds_bytes, L.stream, P,
                        T, nodes, n_nodes, cnt, L.wave_doubles);
 }
 void l_persist(const K2Launch& L, DevProblem P, DevTree T, int32_t* slots, int n_slots,
                PersistCtl* ctl, int node_cap, DevCounters* cnt, int sign_only, int max_depth,
                PersistDeal deal) {
+    P.wc_lds = L.wc_lds;
     hipLaunchKernelGGL(k2_persist, dim3(L.grid), dim3(L.threads), L.lds_bytes, L.stream, P, T,
                        slots, n_slots, ctl, node_cap, cnt, L.wave_doubles, sign_only, max_depth,
                        deal);

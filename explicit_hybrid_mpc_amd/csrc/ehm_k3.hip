@@ -617,7 +617,7 @@ hipError_t set_lds(int bytes) {
     return hipSuccess;
 }
 
-size_t unit_doubles_for(const DevProblem& P, int /*n_lp*/, int /*ne*/) {
+size_t unit_doubles_for(const DevProblem& P, int /*n_lp*/, int /*ne*/, int /*persist*/) {
     return (node_doubles(P.p, P.n_u) + lp_doubles(P.m) + 1) & ~(size_t)1;
 }
 size_t shared_doubles_for(const DevProblem&) { return 0; }

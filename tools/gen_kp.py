@@ -176,14 +176,15 @@ hipError_t set_lds(int bytes) {
 }
 size_t wave_doubles_for(const DevProblem& P, int n_lp_d, int ne_d, int n_lp_e) {
     const size_t a = kd::wave_lp_doubles(n_lp_d, ne_d), b = ke::wave_lp_doubles(n_lp_e, 0);
-    // (+32: the midpoint-first flow parks the midpoint solve's input and gradient and the
+    // (+ k2_stash_doubles: the midpoint-first flow parks the midpoint solve's input and gradient and the
     // node's witness there)
-    return k2_node_doubles(P.p, P.n_u) + (a > b ? a : b) + (EHM_PERSIST_MIDFIRST ? 32 : 0);
+    return k2_node_doubles(P.p, P.n_u) + (a > b ? a : b) + (EHM_PERSIST_MIDFIRST ? k2_stash_doubles(P.p, P.n_u) : 0);
 }
 size_t shared_doubles_for(const DevProblem& P) { return kd::shared_doubles(P); }
 void l_persist(const K2Launch& L, DevProblem P, DevTree T, int32_t* slots, int n_slots,
                PersistCtl* ctl, int node_cap, DevCounters* cnt, int sign_only, int max_depth,
                PersistDeal deal) {
+    P.wc_lds = L.wc_lds;
     hipLaunchKernelGGL(kp_persist, dim3(L.grid), dim3(L.threads), L.lds_bytes, L.stream, P, T,
                        slots, n_slots, ctl, node_cap, cnt, L.wave_doubles, sign_only, max_depth,
                        deal);
