@@ -278,6 +278,9 @@ def parse_args(argv=None):
                          'the finished tree does not depend on it).  lcss-first (default) '
                          'completes subtrees; fifo goes level by level -- with --regions it closes '
                          'the cells that need no refinement first')
+    ap.add_argument('--round-cap', type=int, default=2048,
+                    help='config5: nodes visited together in one round of the search driver (their '
+                         'problems share the launches)')
     ap.add_argument('--max-visits', type=int, default=None,
                     help='config5: cap on the node visits of a step')
     ap.add_argument('--no-cpu-baseline', action='store_true')
@@ -771,18 +774,25 @@ def measure_config5(args, ctx):
     orc.table.set_eps(eps_a, eps_r)
     my_cells = list(range(rank, n_cells, world))
 
+    # the device table(s): one, or -- where the full model needs the wide kernels -- a table of the
+    # short horizon for the prefixes of few steps next to it (sequences.SplitPrefixTable)
+    parts = [('short', orc.table.short), ('long', orc.table.long)] if hasattr(orc.table, 'short') \
+        else [('long', orc.table)]
+
     def snapshot():
-        st = orc.table.gp.stats()
-        return dict(lp=orc.table.lp_solves, iters=st['ipm_iters'], dev=st['lp_solves'],
-                    secs=list(st['batch_seconds']), launches=list(st['batch_launches']),
-                    calls=dict(orc.calls), expanded=orc.n_expanded,
+        per = {}
+        for name, tb in parts:
+            st = tb.gp.stats()
+            per[name] = dict(lp=tb.lp_solves, iters=st['ipm_iters'], secs=list(st['batch_seconds']),
+                             launches=list(st['batch_launches']), hist=tb.by_length.copy())
+        return dict(lp=orc.table.lp_solves, per=per, calls=dict(orc.calls), expanded=orc.n_expanded,
                     hist=orc.table.by_length.copy(), stalled=orc.table.stalled)
 
     def step():
         orc.table.forget()
         trees = [Tree(NodeData(vertices=kuhn_cell(half, c))) for c in my_cells]
         stats = bnb_frontier.grow_frontier(orc, trees, 'ecc', order=args.order,
-                                           table_backoff=True, round_cap=2048,
+                                           table_backoff=True, round_cap=args.round_cap,
                                            min_regions=regions, max_visits=args.max_visits)
         return stats, trees
 
@@ -828,10 +838,31 @@ def measure_config5(args, ctx):
                     depth = max(depth, len(loc))
     calls = {k: s1['calls'][k] - s0['calls'][k] for k in s1['calls']}
     hist = s1['hist'] - s0['hist']
-    local = [float(s1['lp'] - s0['lp']), float(s1['iters'] - s0['iters']), float(nodes),
-             float(closed), float(sum(calls.values())), elapsed,
-             s1['secs'][0] - s0['secs'][0], s1['secs'][1] - s0['secs'][1],
-             float(s1['launches'][1] - s0['launches'][1]),
+    # per table: LPs, iterations, kernel seconds (HIP events around every batched launch) and the
+    # SURVEY 8(d) flops of its problems over a simplex, priced at the table's own dimensions
+    tables = {}
+    for name, tb in parts:
+        a0, a1 = s0['per'][name], s1['per'][name]
+        can_t = tb.gp.can
+        d_lp, d_it = a1['lp'] - a0['lp'], a1['iters'] - a0['iters']
+        mean_it_t = d_it / max(d_lp, 1.)
+        h = a1['hist'] - a0['hist']
+        dims_t = {2: (can_t.n + can_t.p + 1, can_t.m + can_t.p + 2),
+                  3: (can_t.n + can_t.p, can_t.m + can_t.p + 1),
+                  4: (can_t.n + can_t.p + 1, can_t.m + can_t.p + 3)}
+        tables[name] = dict(
+            lp=float(d_lp), iters=float(d_it), mean_it=mean_it_t, dims=dims_t,
+            point_s=a1['secs'][0] - a0['secs'][0], simplex_s=a1['secs'][1] - a0['secs'][1],
+            simplex_launches=float(a1['launches'][1] - a0['launches'][1]),
+            n_simplex=float(sum(h[k].sum() for k in dims_t)),
+            flops=sum(float(h[k].sum()) * mean_it_t * flops_per_iteration(*dims_t[k])
+                      for k in dims_t))
+    dom = max(tables, key=lambda k: tables[k]['simplex_s'])
+    local = [float(s1['lp'] - s0['lp']), float(sum(t['iters'] for t in tables.values())),
+             float(nodes), float(closed), float(sum(calls.values())), elapsed,
+             sum(t['point_s'] for t in tables.values()),
+             sum(t['simplex_s'] for t in tables.values()),
+             tables[dom]['simplex_launches'],
              float(sum(st['host_visits'] for st, _ in runs))]
     tot, mx = distributed.allreduce_counters(local, device=red_dev)
     out = None
@@ -842,14 +873,16 @@ def measure_config5(args, ctx):
                                                           float(mx[5]))
         point_s, simplex_s = float(mx[6]), float(mx[7])
         mean_it = iters / max(lp, 1.)
-        # dominant kernel: the batched problems over a simplex on the wide kernels
-        # (k3_simplex_batch); iterations by kind are not counted separately: every kind is
-        # priced at the mean over all LPs of the step
-        dims = {2: (n + p + 1, m + p + 2), 3: (n + p, m + p + 1), 4: (n + p + 1, m + p + 3)}
-        flops = sum(float(hist[k].sum()) * mean_it * flops_per_iteration(*dims[k]) for k in dims)
-        n_sx = float(sum(hist[k].sum() for k in dims))
+        # dominant kernel: the batched problems over a simplex of the table that spends the most
+        # kernel time -- the wide kernels (k3_simplex_batch) for the full model, the shared-block
+        # kernels (k2_simplex_batch) for the short-horizon table; iterations by kind are not
+        # counted separately: every kind is priced at the mean over the table's LPs
+        T = tables[dom]
+        dims = T['dims']
+        flops, n_sx = T['flops'], T['n_simplex']
         hbm_alg = n_sx * (12 + 8 * ((p + 1) * p + (p + 1)) + 8 + 8 * (p + 1) + 4)
-        achieved = flops / max(simplex_s, 1e-12) / 1e12
+        dom_s = T['simplex_s']
+        achieved = flops / max(dom_s, 1e-12) / 1e12
         out = {
             'metric': 'oracle LP solves/sec + final regions/sec, 4-state 2-input N=5 hybrid MPC',
             'value': lp / elapsed_max, 'unit': 'LP solves/s',
@@ -885,36 +918,50 @@ def measure_config5(args, ctx):
                 'handoffs_to_the_enumerating_engine_per_step':
                     sum(st['handoffs'] for st, _ in runs) / K,
                 'eps_a_seconds': t_eps,
-                'kernels': 'wide (one workgroup per LP, MFMA normal matrix) through the batched '
-                           'oracles ehm_simplex_idx_batch / ehm_point_idx_batch',
+                'kernels': ('prefixes of <= %d steps: blocks of the law with that horizon on the '
+                            'shared-block kernels (one wavefront per LP); longer prefixes and '
+                            'full sequences: ' % orc.table.short_len
+                            if hasattr(orc.table, 'short') else '') +
+                           'wide kernels (one workgroup per LP, MFMA normal matrix); both through '
+                           'the batched oracles ehm_simplex_idx_batch / ehm_point_idx_batch',
                 'engine': 'host-driven searches (bnb_frontier.grow_frontier: all pending nodes '
                           'share the launches; native memo of phase-one verdicts, '
                           'csrc/ehm_search.cpp), LPs on the device',
                 'order': {'lcss-first': 'cells that hold a commutation first, deepest first',
                           'fifo': 'level by level', 'deepest': 'deepest first'}[args.order] +
-                         '; rounds of 2048 nodes',
+                         '; rounds of %d nodes' % args.round_cap,
                 'stopped_early': bool(any(st['truncated'] for st, _ in runs)),
                 'parallelism': '%d cell(s) over %d GPU(s): cell k on rank k mod world, no '
                                'data-path collective' % (n_cells, world),
             },
             'roofline': {
-                'bound': 'mfma', 'kernel': 'k3_simplex_batch',
-                'note': 'LPs over a simplex (slack n=%d m=%d) on the wide kernels: normal matrix '
-                        'on v_mfma_f64_16x16x4_f64; flops = LPs by kind x the MEAN iteration '
-                        'count of the step x SURVEY 8(d) flops per iteration; kernel seconds by '
-                        'HIP events around every launch (ehm_counters.batch_seconds)' %
-                        (dims[4][0], dims[4][1]),
+                'bound': 'mfma' if dom == 'long' else 'valu-fp64',
+                'kernel': 'k3_simplex_batch' if dom == 'long' else 'k2_simplex_batch',
+                'note': 'LPs over a simplex of the %s table (slack n=%d m=%d) on the %s; flops = '
+                        'its LPs by kind x the MEAN iteration count of its LPs x SURVEY 8(d) '
+                        'flops per iteration; kernel seconds by HIP events around every launch '
+                        '(ehm_counters.batch_seconds)' % (
+                            dom, dims[4][0], dims[4][1],
+                            'wide kernels (normal matrix on v_mfma_f64_16x16x4_f64)'
+                            if dom == 'long' else
+                            'shared-block kernels (one wavefront per LP, FP64 vector FMA)'),
+                'tables': {name: {'lp_solves': t['lp'] / K, 'mean_ipm_iterations': t['mean_it'],
+                                  'simplex_kernel_seconds': t['simplex_s'],
+                                  'point_kernel_seconds': t['point_s'],
+                                  'slack_lp': '%d x %d' % t['dims'][4],
+                                  'simplex_tflops': t['flops'] / max(t['simplex_s'], 1e-12) / 1e12}
+                           for name, t in tables.items()},
                 'achieved': achieved, 'peak': FP64_PEAK_TFLOPS, 'unit': 'TFLOP/s',
                 'frac': achieved / FP64_PEAK_TFLOPS,
                 'flop_per_ipm_iteration': flops_per_iteration(*dims[4]),
                 'traffic': None, 'traffic_source': 'no PMC profile of this workload',
                 'algorithmic_bytes_per_launch': hbm_alg / max(tot[8], 1.),
-                'kernel_seconds': simplex_s, 'launches': tot[8],
-                'point_kernel_seconds': point_s,
+                'kernel_seconds': dom_s, 'launches': tot[8],
+                'point_kernel_seconds': point_s, 'simplex_kernel_seconds_all_tables': simplex_s,
                 'device_share_of_the_step': (simplex_s + point_s) / elapsed_max,
-                'hbm': {'achieved': hbm_alg / max(simplex_s, 1e-12) / 1e9, 'peak': HBM_PEAK_GBS,
+                'hbm': {'achieved': hbm_alg / max(dom_s, 1e-12) / 1e9, 'peak': HBM_PEAK_GBS,
                         'unit': 'GB/s',
-                        'frac': hbm_alg / max(simplex_s, 1e-12) / 1e9 / HBM_PEAK_GBS},
+                        'frac': hbm_alg / max(dom_s, 1e-12) / 1e9 / HBM_PEAK_GBS},
             },
         }
         if world == 1 and not args.no_cpu_baseline:
@@ -947,7 +994,7 @@ def secondary_line(args, ctx, workload, steps, warmup):
     a.abs_frac = a.eps_r = a.max_depth = None
     a.cpu_seconds = args.secondary_cpu_seconds
     a.regions = a.cells = 0
-    a.order, a.max_visits = 'lcss-first', None
+    a.order, a.max_visits, a.round_cap = 'lcss-first', None, 2048
     a.status_dir = None
     a.engine, a.solver, a.decide_full = 1, 2, False
     a.no_mid_first = a.no_inherit_witness = False

@@ -51,13 +51,13 @@ class PrefixOracle:
     ``table``: a ``sequences.PrefixTable`` (created if not given).
     """
 
-    def __init__(self, mpc, eps_a, eps_r, slots=4096, device=0, table=None):
+    def __init__(self, mpc, eps_a, eps_r, slots=4096, device=0, table=None, split=None):
         self.mpc = mpc
         self.eps_a = eps_a
         self.eps_r = eps_r
         self._own = table is None
-        self.table = table if table is not None else sequences.PrefixTable(
-            mpc, slots=slots, device=device, eps_a=eps_a, eps_r=eps_r)
+        self.table = table if table is not None else sequences.make_table(
+            mpc, slots=slots, device=device, eps_a=eps_a, eps_r=eps_r, split=split)
         self.table.set_eps(eps_a, eps_r)
         self.last_margin = np.inf
         self.n_expanded = 0          # prefixes expanded (search-tree nodes)

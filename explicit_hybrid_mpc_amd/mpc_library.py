@@ -157,6 +157,15 @@ class PWAMPC:
             return list(self._sequences)
         return list(itertools.product(range(self.delta_size), repeat=self.N))
 
+    def with_horizon(self, N):
+        """The same law over the first ``N`` steps (infinity-norm cost: the stage costs are a plain
+        sum, so the relaxation of a mode prefix of at most ``N`` steps -- the undecided steps cost
+        nothing and constrain nothing -- is the same problem in either horizon)."""
+        if self.cost_type != 'inf':
+            raise ValueError('with_horizon: the quadratic cost has a terminal term')
+        return PWAMPC(self.A, self.B, self.w, self.regions, self.Gx, self.gx, self.Gu, self.gu,
+                      self.Q, self.R, N, name='%s_first%d' % (self.name, N), cost='inf')
+
     def restrict(self, sequences):
         """
         A copy of this instance whose commutation set is ``sequences`` (sorted into enumeration

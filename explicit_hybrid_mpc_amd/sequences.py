@@ -382,6 +382,9 @@ class PrefixTable(PrefixSearch):
         # acceptance band of csrc/ehm_ipm3.h): an optimum becomes +inf (the callers' blacklist /
         # retry paths, lib/oracle.py:214-218, 406-414, see it as a failed vertex solve), a slack
         # or a minimum over a simplex raises, a phase one whose last iterate is not feasible raises
+        # a prefix of this many steps is a full sequence (its values are answers, not bounds);
+        # None: every block of this table is a relaxation (the short table of SplitPrefixTable)
+        self.full_length = mpc.N
         self.stalled = 0
         self.stalled_relaxations = 0    # of them: relaxations answered by "no information"
         self.slivers = 0                # of them: interior-free pairs, counted as infeasible
@@ -399,6 +402,14 @@ class PrefixTable(PrefixSearch):
 
     def set_eps(self, eps_a, eps_r):
         self.gp.set_eps(eps_a, eps_r)
+
+    def device_stats(self):
+        """ehm_stats of the table's problem handle (solves, iterations, kernel seconds of the
+        batched launches)."""
+        return self.gp.stats()
+
+    def reset_counts(self):
+        self.by_length[:] = 0
 
     # -- the table ----------------------------------------------------------------------------
     def _block(self, prefix):
@@ -519,7 +530,7 @@ class PrefixTable(PrefixSearch):
             sliver = (st == 0) & (tau >= -SLIVER_TOL)
             self.slivers += int(sliver.sum())
             feasible = ~sliver & ((tau <= FEAS_TOL) | (st != 0))
-            full = np.array([len(prefixes[k]) == self.mpc.N for k in bad], dtype=bool)
+            full = np.array([len(prefixes[k]) == self.full_length for k in bad], dtype=bool)
             if full_is_error and (feasible & full).any():
                 from .oracle import SolverError
                 raise SolverError('%d %s problem(s) of full mode sequences did not converge on '
@@ -598,6 +609,150 @@ class PrefixTable(PrefixSearch):
                 t[idx[ok]] = tk
                 alpha[idx[ok]] = ak
         return t, alpha
+
+
+def short_horizon(mpc, max_cols=32, max_rows=256):
+    """The longest horizon k < N whose relaxation blocks fit the shared-block kernels (columns
+    n_k + p + 1 <= 32, rows m_k + p + 3 <= 256: csrc/ehm_capi.hip, ehm_problem_create); 0 if none
+    or if the whole model fits them anyway."""
+    if mpc.cost_type != 'inf':
+        return 0
+    p = mpc.n_x
+    rows_per_step = mpc.Gx.shape[0] + mpc.Gu.shape[0] + 2 * (mpc.Q.shape[0] + mpc.R.shape[0]) + \
+        max((0 if r is None else r[0].shape[0]) for r in mpc.regions)
+    cols_per_step = mpc.n_u + 2
+
+    def fits(k):
+        return cols_per_step * k + p + 1 <= max_cols and rows_per_step * k + p + 3 <= max_rows
+    if fits(mpc.N):
+        return 0
+    k = mpc.N - 1
+    while k >= 1 and not fits(k):
+        k -= 1
+    return max(k, 0)
+
+
+class SplitPrefixTable(PrefixSearch):
+    """
+    Two device tables behind ONE search state.  The relaxation of a mode prefix of k steps
+    constrains and prices the first k steps only; as a block of the full model it is a 49 x 379
+    LP (config 5) of which k/N is alive, and it runs on the wide kernels.  Here every prefix of
+    at most ``short`` steps is solved as a block of the SAME law with horizon ``short``
+    (``PWAMPC.with_horizon``: the same problem, the same optimum, the same first input) -- 29
+    columns x 199 rows at short = 4, a size the shared-block kernels (one wavefront per LP, the
+    constant block in LDS) solve an order of magnitude faster.  On config 5 at its stated
+    tolerance 94 % of the suboptimality-test problems of the searches are such prefixes
+    (DESIGN.md section 3.3e).  Longer prefixes and full sequences go to the table of the full
+    model.  The memo of phase-one verdicts, the point ids and the remembered optima are those of
+    this object (``PrefixSearch``): they are keyed by (prefix, point), whichever table solves.
+    """
+
+    def __init__(self, mpc, short, slots=1024, device=0, eps_a=1., eps_r=1.):
+        assert 1 <= short < mpc.N
+        self.mpc = mpc
+        self.short_len = int(short)
+        self.device = int(device)
+        self.slots = slots
+        self.long = PrefixTable(mpc, slots=slots, device=device, eps_a=eps_a, eps_r=eps_r)
+        # every prefix of <= short steps has a slot of its own: nothing is ever evicted
+        n_short = sum(mpc.delta_size ** k for k in range(self.short_len + 1))
+        self.short = PrefixTable(mpc.with_horizon(self.short_len), slots=max(16, n_short),
+                                 device=device, eps_a=eps_a, eps_r=eps_r)
+        self.short.full_length = None
+        self.gp = self.long.gp          # dimensions of the full model (bench.py, hand-offs)
+        self.init_search()
+
+    def close(self):
+        self.close_search()
+        self.short.close()
+        self.long.close()
+
+    def set_eps(self, eps_a, eps_r):
+        self.short.set_eps(eps_a, eps_r)
+        self.long.set_eps(eps_a, eps_r)
+
+    # -- what the searches and the benchmark read -----------------------------------------------
+    lp_solves = property(lambda self: self.short.lp_solves + self.long.lp_solves)
+    blocks_loaded = property(lambda self: self.short.blocks_loaded + self.long.blocks_loaded)
+    stalled = property(lambda self: self.short.stalled + self.long.stalled)
+    stalled_relaxations = property(lambda self: self.short.stalled_relaxations +
+                                   self.long.stalled_relaxations)
+    slivers = property(lambda self: self.short.slivers + self.long.slivers)
+
+    @property
+    def by_length(self):
+        out = self.long.by_length.copy()
+        out[:, :self.short.by_length.shape[1]] += self.short.by_length
+        return out
+
+    def reset_counts(self):
+        self.short.by_length[:] = 0
+        self.long.by_length[:] = 0
+
+    def device_stats(self):
+        a, b = self.short.gp.stats(), self.long.gp.stats()
+        out = {}
+        for k in a:
+            out[k] = [x + y for x, y in zip(a[k], b[k])] if isinstance(a[k], list) else a[k] + b[k]
+        out['short_table'] = a
+        out['long_table'] = b
+        return out
+
+    # -- pair solvers: split by prefix length, delegate, merge ----------------------------------
+    def _split(self, prefixes):
+        is_short = np.fromiter((len(q) <= self.short_len for q in prefixes), dtype=bool,
+                               count=len(prefixes))
+        return np.flatnonzero(is_short), np.flatnonzero(~is_short)
+
+    def solve_points(self, prefixes, thetas, feasibility_only=False, known_feasible=False):
+        prefixes = [tuple(q) for q in prefixes]
+        thetas = np.asarray(thetas, dtype=np.float64).reshape(len(prefixes), -1)
+        J = np.full(len(prefixes), np.inf)
+        u0 = np.zeros((len(prefixes), self.mpc.n_u))
+        for table, sel in zip((self.short, self.long), self._split(prefixes)):
+            if sel.size:
+                J[sel], u0[sel] = table.solve_points([prefixes[k] for k in sel], thetas[sel],
+                                                     feasibility_only, known_feasible)
+        return J, u0
+
+    def solve_points_idx(self, uniq, idx, thetas, feasibility_only=False, known_feasible=False):
+        idx = np.asarray(idx, dtype=np.int64)
+        return self.solve_points([uniq[i] for i in idx], thetas, feasibility_only, known_feasible)
+
+    def solve_min(self, prefixes, simplices, known_feasible=None, exact=False):
+        prefixes = [tuple(q) for q in prefixes]
+        simplices = np.asarray(simplices, dtype=np.float64)
+        kf = None if known_feasible is None else np.asarray(known_feasible, dtype=bool)
+        J = np.full(len(prefixes), np.inf)
+        for table, sel in zip((self.short, self.long), self._split(prefixes)):
+            if sel.size:
+                J[sel] = table.solve_min([prefixes[k] for k in sel], simplices[sel],
+                                         None if kf is None else kf[sel], exact)
+        return J
+
+    def solve_slack(self, prefixes, simplices, vbars, known_feasible=None):
+        prefixes = [tuple(q) for q in prefixes]
+        simplices = np.asarray(simplices, dtype=np.float64)
+        vbars = np.asarray(vbars, dtype=np.float64)
+        kf = None if known_feasible is None else np.asarray(known_feasible, dtype=bool)
+        t = np.full(len(prefixes), -np.inf)
+        alpha = np.zeros((len(prefixes), simplices.shape[1]))
+        for table, sel in zip((self.short, self.long), self._split(prefixes)):
+            if sel.size:
+                t[sel], alpha[sel] = table.solve_slack([prefixes[k] for k in sel], simplices[sel],
+                                                       vbars[sel],
+                                                       None if kf is None else kf[sel])
+        return t, alpha
+
+
+def make_table(mpc, slots=1024, device=0, eps_a=1., eps_r=1., split=None):
+    """The device table of a law: two tables behind one search state (``SplitPrefixTable``) when
+    the full model needs the wide kernels and a shorter horizon fits the shared-block ones
+    (``split`` = that horizon, None = decide here, 0 = never), else one ``PrefixTable``."""
+    k = short_horizon(mpc) if split is None else int(split)
+    if k >= 1:
+        return SplitPrefixTable(mpc, k, slots=slots, device=device, eps_a=eps_a, eps_r=eps_r)
+    return PrefixTable(mpc, slots=slots, device=device, eps_a=eps_a, eps_r=eps_r)
 
 
 def feasible_sequences(mpc, simplices, max_sequences=256, slots=1024, device=0):

@@ -515,3 +515,70 @@ def test_deepest_first_order_grows_the_same_tree_and_finishes_regions_first():
     assert a['truncated'] and b['truncated'] and b['regions'] >= a['regions']
     c, _ = run(min_regions=3, round_cap=3, order='deepest')
     assert c['truncated'] and 3 <= c['regions'] < s_fifo['regions']
+
+
+def test_short_prefixes_on_a_table_of_the_short_horizon(monkeypatch):
+    """
+    sequences.SplitPrefixTable: prefixes of at most ``short`` steps are solved as blocks of the
+    same law with horizon ``short`` (PWAMPC.with_horizon), the rest as blocks of the full model --
+    the same optima, slacks, minima and verdicts as the one-table form, pair for pair, and the
+    frontier-wide driver on it grows the enumerating CPU partition's tree.  (HiGHS stub of the
+    device problem on the condensed blocks.)
+    """
+    from explicit_hybrid_mpc_amd import sequences, bnb_frontier
+    monkeypatch.setattr(sequences.engine, 'GpuProblem', _StubDeviceProblem)
+    mpc = helpers.make_instance('pwa_small', 0)                  # 2 modes, N = 3
+    assert sequences.short_horizon(mpc) == 0                     # it fits as it is: force the split
+    one = sequences.PrefixTable(mpc, slots=16)
+    two = sequences.SplitPrefixTable(mpc, 2, slots=16)
+    assert two.short.mpc.N == 2 and two.long.mpc.N == 3 and two.short.full_length is None
+    half = examples.theta_box(mpc)
+    rng = np.random.default_rng(17)
+    prefixes = [(), (0,), (1,), (0, 1), (1, 0), (1, 1), (1, 1, 0), (0, 0, 0), (1, 0, 1), (0, 1, 1)]
+    pairs = [prefixes[k] for k in rng.integers(0, len(prefixes), 60)]
+    thetas = rng.uniform(-1, 1, (60, 2)) * half
+    J1, u1 = one.solve_points(pairs, thetas)
+    J2, u2 = two.solve_points(pairs, thetas)
+    assert np.array_equal(np.isfinite(J1), np.isfinite(J2))
+    fin = np.isfinite(J1)
+    assert np.allclose(J1[fin], J2[fin], rtol=1e-9, atol=1e-10)
+    full = np.array([len(q) == 3 for q in pairs])
+    assert np.allclose(u1[fin & full], u2[fin & full], atol=1e-8)     # full sequences: same table
+    assert two.short.lp_solves > 0 and two.long.lp_solves > 0
+    simplices = np.array(helpers.random_simplices(mpc, rng, 60, scale_lo=-1.2))
+    m1, m2 = one.solve_min(pairs, simplices), two.solve_min(pairs, simplices)
+    assert np.array_equal(np.isfinite(m1), np.isfinite(m2))
+    assert np.allclose(m1[np.isfinite(m1)], m2[np.isfinite(m1)], rtol=1e-9, atol=1e-10)
+    V = rng.uniform(0.5, 2., (60, 3))
+    t1, _ = one.solve_slack(pairs, simplices, V)
+    t2, _ = two.solve_slack(pairs, simplices, V)
+    assert np.array_equal(np.isfinite(t1), np.isfinite(t2))
+    assert np.allclose(t1[np.isfinite(t1)], t2[np.isfinite(t1)], rtol=1e-9, atol=1e-10)
+    # counters: the split table reports both halves
+    assert two.lp_solves == two.short.lp_solves + two.long.lp_solves
+    assert two.by_length.sum() == two.short.by_length.sum() + two.long.by_length.sum()
+    assert two.by_length[:, 3].sum() == two.long.by_length[:, 3].sum()
+    assert two.short.by_length[:, :3].sum() == two.short.by_length.sum()     # nothing longer there
+    one.close()
+    # the searches and the driver on the split table
+    eps_a = helpers.eps_a_rule(mpc, 0.25)
+    dev = bnb.PrefixOracle(mpc, eps_a, 0.2, table=two)
+    roots, locs = helpers.roots_of(mpc)
+    cpu = PartitionCPU(OracleCPU(mpc, eps_a, 0.2))
+    cpu.run(roots, locs, 'ecc')
+    trees = [Tree(NodeData(vertices=np.array(R))) for R in roots]
+    stats = bnb_frontier.grow_frontier(dev, trees, 'ecc', handoff=False,
+                                       split_batch=_host_split_batch)
+    assert not stats['truncated']
+    n = 0
+    for t, loc0 in zip(trees, locs):
+        for nd, loc in t.walk(loc0):
+            r = cpu.nodes[loc]
+            n += 1
+            assert nd.is_leaf() == r['leaf']
+            assert nd.data.is_epsilon_suboptimal == r['is_epsilon_suboptimal']
+            if r['commutation'] is not None:
+                assert np.array_equal(nd.data.commutation.astype(int), r['commutation'].astype(int))
+                assert np.allclose(nd.data.vertex_costs, r['vertex_costs'], rtol=1e-7, atol=1e-8)
+    assert n == len(cpu.nodes)
+    two.close()

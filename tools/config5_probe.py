@@ -71,7 +71,7 @@ def main():
     orc.eps_a, orc.eps_r = eps_a, eps_r
     orc.table.set_eps(eps_a, eps_r)
     lp0 = orc.table.lp_solves
-    orc.table.by_length[:] = 0
+    orc.table.reset_counts()
     CLOCK.clear()
     t = time.perf_counter()
     branch = Tree(NodeData(vertices=R.copy()))
