@@ -47,6 +47,9 @@ EXPORTED_SEARCH = [
     'ehm_search_query', 'ehm_search_asks', 'ehm_search_answer', 'ehm_search_descent_begin',
     'ehm_search_descent_step', 'ehm_search_descent_result', 'ehm_search_peek',
     'ehm_search_abandon',
+    'ehm_search_bare_create', 'ehm_search_bare_destroy', 'ehm_search_bare_seed',
+    'ehm_search_bare_bounds', 'ehm_search_bare_step', 'ehm_search_bare_asks',
+    'ehm_search_bare_answer', 'ehm_search_bare_result', 'ehm_search_bare_learned',
 ]
 
 
@@ -213,6 +216,15 @@ def load(build_if_missing=True):
     lib.ehm_search_descent_begin.argtypes = [vp, i64, vp, vp, vp, vp]
     lib.ehm_search_descent_step.argtypes = [vp, vp, ctypes.POINTER(i64), ctypes.POINTER(i64)]
     lib.ehm_search_descent_result.argtypes = [vp, vp, ctypes.POINTER(i64)]
+    lib.ehm_search_bare_create.argtypes = [i32, i32, i32, vp, ctypes.POINTER(vp)]
+    lib.ehm_search_bare_destroy.argtypes = [vp]
+    lib.ehm_search_bare_seed.argtypes = [vp, i32, ctypes.c_uint64, ctypes.c_double, i32]
+    lib.ehm_search_bare_bounds.argtypes = [vp, i32, i64, vp, vp]
+    lib.ehm_search_bare_step.argtypes = [vp, i32, ctypes.POINTER(i64), ctypes.POINTER(i64)]
+    lib.ehm_search_bare_asks.argtypes = [vp, vp, vp]
+    lib.ehm_search_bare_answer.argtypes = [vp, vp, ctypes.POINTER(i64)]
+    lib.ehm_search_bare_result.argtypes = [vp, vp, vp, vp]
+    lib.ehm_search_bare_learned.argtypes = [vp, i32, ctypes.POINTER(i64), vp, vp]
     for name in EXPORTED_SEARCH:
         if name != 'ehm_search_last_error':
             getattr(lib, name).restype = i32

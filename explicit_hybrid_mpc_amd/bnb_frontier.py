@@ -11,11 +11,14 @@ tests run both on the same table); the driver visits the nodes in another order,
 matter -- a node's fate depends on its own record only (lib/worker.py:241-417).
 """
 
+import ctypes
 import heapq
 import time
 
 import numpy as np
 
+from . import _capi
+from ._capi import ptr
 from .bnb import BATCH, PLATEAU, TIE_TOL, SolverError, _rel, _set_record
 from .tree import NodeData
 
@@ -142,72 +145,90 @@ def bar_e_many(oracle, Rs, Vs, bound=None, learned=None, incumbents=None):
     """
     ``PrefixOracle.bar_E_delta_R`` for many nodes: (list of bool, list of margins).
     ``bound[j]``: upper bounds of t* per prefix inherited from node j's ancestors (a prefix they
-    refute needs no problem); ``learned[j]`` (a dict, filled here): the optima solved on node j;
-    ``incumbents[j]``: a full sequence tried first (the parent's best-slack sequence) -- where
-    its slack is not negative the node is open and the search is not run.
+    refute needs no problem); ``learned[j]`` (a dict, filled here for the nodes that stay OPEN --
+    what bar_D and the children go on with; a closed node's values have no reader): the optima
+    solved on node j; ``incumbents[j]``: a full sequence tried first (the parent's best-slack
+    sequence) -- where its slack is not negative the node is open and the search is not run.
+
+    The best-first queues, the expansion of prefixes, the lookup of known values and the
+    verdicts are native (include/ehm_search.h: ehm_search_bare_*); a step of all searches is one
+    call that returns the (prefix code, node) pairs of ONE launch, ``solve_slack_codes`` turns
+    them into slots and gathered simplices with numpy, and the answers go back in one call.  The
+    plain-Python statement of the same search is tests/prefix_search_py.bar_e_many_py.
     """
     table, mpc = oracle.table, oracle.mpc
     n_modes, N = mpc.delta_size, mpc.N
     n = len(Rs)
-    heaps = [[(-np.inf, ())] for _ in range(n)]
-    refuted = [np.inf] * n
-    closed, margin = [None] * n, [np.inf] * n
-    active = list(range(n))
     oracle.calls['bar_E'] += n
-    guard = [INHERIT_GUARD * (1. + float(np.max(np.abs(V)))) for V in Vs]
-    seeded = [j for j in range(n) if incumbents and incumbents[j] is not None]
-    if seeded:
-        Rw = np.array([Rs[j] for j in seeded])
-        tw, aw = table.solve_slack([incumbents[j] for j in seeded], Rw,
-                                   np.array([Vs[j] for j in seeded]),
-                                   table.feasible_somewhere([incumbents[j] for j in seeded], Rw))
-        for w, j in enumerate(seeded):
-            if learned is not None:
-                learned[j][incumbents[j]] = (float(tw[w]), aw[w].copy())
-            if tw[w] >= 0.:
-                closed[j], margin[j] = False, abs(float(tw[w]))
-        active = [j for j in active if closed[j] is None]
-    while active:
-        pre, Rp, Vp, kid_of, val_of, ask_of = [], [], [], {}, {}, {}
-        width = _batch_size(len(active), n_modes)
-        for j in active:
-            batch = [heapq.heappop(heaps[j])[1] for _ in range(min(width, len(heaps[j])))]
-            oracle.n_expanded += len(batch)
-            kids = [k for q in batch for k in _kids(q, n_modes)]
-            kid_of[j] = kids
-            val_of[j] = _lookup(kids, learned[j] if learned else None,
-                                bound[j] if bound else None, guard[j], N)
-            ask_of[j] = [i for i, v in enumerate(val_of[j]) if v is None]
-            pre.extend(kids[i] for i in ask_of[j])
-            Rp.extend([Rs[j]] * len(ask_of[j]))
-            Vp.extend([Vs[j]] * len(ask_of[j]))
-        oracle.n_inherited += sum(len(kid_of[j]) - len(ask_of[j]) for j in active)
-        if pre:
-            Rp = np.array(Rp)
-            t, _ = table.solve_slack(pre, Rp, np.array(Vp), table.feasible_somewhere(pre, Rp))
-        pos, still = 0, []
-        for j in active:
-            kids, vals = kid_of[j], val_of[j]
-            for i in ask_of[j]:
-                vals[i] = (float(t[pos]), None)
+    if not n:
+        return [], []
+    lib = _capi.load()          # (the queues are native whatever keeps the table's memo)
+    Rs_arr = np.ascontiguousarray(np.array(Rs, dtype=np.float64))
+    Vs_arr = np.ascontiguousarray(np.array(Vs, dtype=np.float64))
+    guard = np.ascontiguousarray(INHERIT_GUARD * (1. + np.max(np.abs(Vs_arr), axis=1)))
+    handle = ctypes.c_void_p()
+    _capi.check_search(lib.ehm_search_bare_create(n, n_modes, N, ptr(guard), ctypes.byref(handle)))
+    try:
+        n_active = n
+        seeded = [j for j in range(n) if incumbents and incumbents[j] is not None]
+        if seeded:
+            Rw = Rs_arr[seeded]
+            tw, aw = table.solve_slack([incumbents[j] for j in seeded], Rw, Vs_arr[seeded],
+                                       table.feasible_somewhere([incumbents[j] for j in seeded],
+                                                                Rw))
+            for w, j in enumerate(seeded):
                 if learned is not None:
-                    learned[j][kids[i]] = vals[i]
-                pos += 1
-            for q, (tq, _) in zip(kids, vals):
-                if not tq >= 0.:
-                    refuted[j] = min(refuted[j], abs(tq))
-                elif len(q) == N:
-                    closed[j], margin[j] = False, abs(tq)
-                    break
-                else:
-                    heapq.heappush(heaps[j], (-tq, q))
-            if closed[j] is None:
-                if heaps[j]:
-                    still.append(j)
-                else:
-                    closed[j], margin[j] = True, refuted[j]
-        active = still
-    return closed, margin
+                    learned[j][incumbents[j]] = (float(tw[w]), aw[w].copy())
+                is_open = bool(tw[w] >= 0.)
+                n_active -= is_open
+                _capi.check_search(lib.ehm_search_bare_seed(
+                    handle, j, int(table._code(tuple(incumbents[j]))), float(tw[w]), int(is_open)))
+        for j in range(n):
+            if bound and bound[j]:
+                codes = np.fromiter((table._code(q) for q in bound[j]), dtype=np.uint64,
+                                    count=len(bound[j]))
+                tb = np.fromiter(bound[j].values(), dtype=np.float64, count=len(bound[j]))
+                _capi.check_search(lib.ehm_search_bare_bounds(handle, j, codes.size, ptr(codes),
+                                                              ptr(tb)))
+        pids = np.asarray(table.point_ids(Rs_arr.reshape(-1, Rs_arr.shape[-1]))).reshape(
+            n, Rs_arr.shape[1])
+        n_ask, left = ctypes.c_int64(), ctypes.c_int64(n_active)
+        while left.value > 0:
+            width = _batch_size(int(left.value), n_modes)
+            _capi.check_search(lib.ehm_search_bare_step(handle, width, ctypes.byref(n_ask),
+                                                        ctypes.byref(left)))
+            if not n_ask.value:
+                break
+            codes = np.empty(n_ask.value, dtype=np.uint64)
+            owner = np.empty(n_ask.value, dtype=np.int32)
+            _capi.check_search(lib.ehm_search_bare_asks(handle, ptr(codes), ptr(owner)))
+            t = np.ascontiguousarray(table.solve_slack_codes(codes, owner.astype(np.int64), Rs_arr,
+                                                             Vs_arr, pids), dtype=np.float64)
+            _capi.check_search(lib.ehm_search_bare_answer(handle, ptr(t), ctypes.byref(left)))
+        closed = np.empty(n, dtype=np.int8)
+        margin = np.empty(n, dtype=np.float64)
+        counts = np.zeros(2, dtype=np.int64)
+        _capi.check_search(lib.ehm_search_bare_result(handle, ptr(closed), ptr(margin),
+                                                      ptr(counts)))
+        oracle.n_expanded += int(counts[0])
+        oracle.n_inherited += int(counts[1])
+        if learned is not None:
+            cnt = ctypes.c_int64()
+            for j in np.flatnonzero(closed == 0):
+                _capi.check_search(lib.ehm_search_bare_learned(handle, int(j), ctypes.byref(cnt),
+                                                               None, None))
+                if not cnt.value:
+                    continue
+                codes = np.empty(cnt.value, dtype=np.uint64)
+                vals = np.empty(cnt.value, dtype=np.float64)
+                _capi.check_search(lib.ehm_search_bare_learned(handle, int(j), ctypes.byref(cnt),
+                                                               ptr(codes), ptr(vals)))
+                dst = learned[int(j)]
+                for c, v in zip(codes, vals):
+                    dst[table._prefix(int(c))] = (float(v), None)
+        return [bool(c) for c in closed], [float(m) for m in margin]
+    finally:
+        lib.ehm_search_bare_destroy(handle)
 
 
 def bar_d_many(oracle, Rs, Vs, deltas_ref, bound=None, learned=None, incumbents=None,

@@ -8,6 +8,8 @@
 #include "../../include/ehm_search.h"
 #include "../../include/ehmpc.h"
 
+#include <algorithm>
+#include <cmath>
 #include <cstdarg>
 #include <cstdio>
 #include <cstring>
@@ -524,6 +526,298 @@ int ehm_search_descent_result(ehm_search* s, int32_t* sequence, int64_t* steps) 
         for (int i = 0; i < s->N; ++i) { out[i] = (int32_t)(c % base) - 1; c /= base; }
     }
     if (steps) *steps = s->steps;
+    return EHM_OK;
+}
+
+// ---- the best-first queues of the suboptimality-test searches (bar_E for many nodes) ------------
+//
+// bnb_frontier.bar_e_many, the part that is not a launch: per search a best-first queue of
+// prefixes keyed by the upper bound t of their relaxation's slack, the expansion of the best
+// `width` prefixes into their n_modes children, the lookup of what is already known about a
+// child (a value solved on this node; an upper bound inherited from an ancestor, which only
+// refutes), the list of the pairs a launch has to solve, and -- with the launch's answers -- the
+// verdicts: a child with t < 0 is refuted, a full sequence with t >= 0 proves the node open, any
+// other child goes into the queue; an empty queue closes the node.  Order of expansion, of the
+// ask list and of the ties is that of the Python form (heapq on (-t, prefix tuple)).
+struct BareItem { double t; uint64_t code; int32_t len; };
+
+struct ehm_search_bare {
+    int32_t n = 0, n_modes = 0, N = 0;
+    uint64_t base = 1;
+    std::vector<uint64_t> pw;                               // base^i
+    std::vector<std::vector<BareItem>> heap;
+    std::vector<double> refuted, margin, guard;
+    std::vector<int8_t> state;                              // -1 searching, 0 open, 1 closed
+    std::vector<std::unordered_map<uint64_t, double>> exact, bound;
+    std::vector<std::vector<std::pair<uint64_t, double>>> learned;
+    std::vector<int32_t> active;
+    // the step in flight
+    std::vector<uint64_t> kid_code;
+    std::vector<int32_t> kid_len, kid_owner;
+    std::vector<double> kid_val;
+    std::vector<int8_t> kid_known;
+    std::vector<int64_t> ask;                               // indices into kid_*
+    bool pending = false;
+    int64_t expanded = 0, inherited = 0;
+
+    // heapq order of (-t, prefix tuple): larger t first; ties by the tuples' lexicographic order
+    // (digit by digit from step 0; a prefix sorts before its extensions)
+    bool before(const BareItem& a, const BareItem& b) const {
+        if (a.t != b.t) return a.t > b.t;
+        uint64_t ca = a.code, cb = b.code;
+        const int32_t m = a.len < b.len ? a.len : b.len;
+        for (int32_t i = 0; i < m; ++i) {
+            const uint64_t da = ca % base, db = cb % base;
+            if (da != db) return da < db;
+            ca /= base; cb /= base;
+        }
+        return a.len < b.len;
+    }
+    void push(int32_t j, const BareItem& it) {
+        auto& h = heap[(size_t)j];
+        h.push_back(it);
+        size_t c = h.size() - 1;
+        while (c > 0) {
+            const size_t p = (c - 1) / 2;
+            if (!before(h[c], h[p])) break;
+            std::swap(h[c], h[p]);
+            c = p;
+        }
+    }
+    BareItem pop(int32_t j) {
+        auto& h = heap[(size_t)j];
+        BareItem top = h.front();
+        h.front() = h.back();
+        h.pop_back();
+        size_t p = 0;
+        const size_t n_ = h.size();
+        for (;;) {
+            size_t l = 2 * p + 1, r = l + 1, b = p;
+            if (l < n_ && before(h[l], h[b])) b = l;
+            if (r < n_ && before(h[r], h[b])) b = r;
+            if (b == p) break;
+            std::swap(h[p], h[b]);
+            p = b;
+        }
+        return top;
+    }
+};
+
+int ehm_search_bare_create(int32_t n, int32_t n_modes, int32_t N, const double* guard,
+                           ehm_search_bare** out) {
+    if (!out || n < 0 || n_modes < 1 || N < 1 || (n > 0 && !guard))
+        return fail(EHM_E_INVALID, "ehm_search_bare_create: bad argument");
+    uint64_t lim = 1;
+    for (int i = 0; i < N; ++i) lim *= (uint64_t)n_modes + 1;
+    if (lim >= CODE_LIMIT) return fail(EHM_E_INVALID, "ehm_search_bare_create: (n_modes + 1)^N too large");
+    try {
+        ehm_search_bare* b = new ehm_search_bare();
+        b->n = n; b->n_modes = n_modes; b->N = N; b->base = (uint64_t)n_modes + 1;
+        b->pw.assign((size_t)N + 1, 1);
+        for (int i = 1; i <= N; ++i) b->pw[(size_t)i] = b->pw[(size_t)i - 1] * b->base;
+        b->heap.resize((size_t)n);
+        b->refuted.assign((size_t)n, HUGE_VAL);
+        b->margin.assign((size_t)n, HUGE_VAL);
+        b->guard.assign(guard, guard + n);
+        b->state.assign((size_t)n, -1);
+        b->exact.resize((size_t)n);
+        b->bound.resize((size_t)n);
+        b->learned.resize((size_t)n);
+        for (int32_t j = 0; j < n; ++j) {
+            b->heap[(size_t)j].push_back(BareItem{HUGE_VAL, 0, 0});       // the empty prefix
+            b->active.push_back(j);
+        }
+        *out = b;
+    } catch (const std::bad_alloc&) {
+        return fail(EHM_E_CAPACITY, "ehm_search_bare_create: out of memory");
+    }
+    return EHM_OK;
+}
+
+int ehm_search_bare_destroy(ehm_search_bare* b) {
+    delete b;
+    return EHM_OK;
+}
+
+// A value solved on THIS node before the search (the incumbent the caller tried first): t < 0
+// refutes that sequence when the search reaches it; open != 0: the value proves the node open,
+// its search is not run (margin = |t|).
+int ehm_search_bare_seed(ehm_search_bare* b, int32_t j, uint64_t code, double t, int32_t open) {
+    if (!b || j < 0 || j >= b->n || b->pending)
+        return fail(EHM_E_INVALID, "ehm_search_bare_seed: bad argument");
+    try {
+        b->exact[(size_t)j][code] = t;
+        if (open && b->state[(size_t)j] < 0) {
+            b->state[(size_t)j] = 0;
+            b->margin[(size_t)j] = t < 0 ? -t : t;
+            std::vector<int32_t> keep;
+            for (int32_t a : b->active)
+                if (a != j) keep.push_back(a);
+            b->active.swap(keep);
+        }
+    } catch (const std::bad_alloc&) {
+        return fail(EHM_E_CAPACITY, "ehm_search_bare_seed: out of memory");
+    }
+    return EHM_OK;
+}
+
+// Upper bounds of t inherited from the node's ancestors; only the refuting ones (tb < -guard)
+// are kept.
+int ehm_search_bare_bounds(ehm_search_bare* b, int32_t j, int64_t count, const uint64_t* code,
+                           const double* tb) {
+    if (!b || j < 0 || j >= b->n || count < 0 || (count > 0 && (!code || !tb)) || b->pending)
+        return fail(EHM_E_INVALID, "ehm_search_bare_bounds: bad argument");
+    try {
+        auto& m = b->bound[(size_t)j];
+        const double g = b->guard[(size_t)j];
+        for (int64_t k = 0; k < count; ++k)
+            if (tb[k] < -g) m[code[k]] = tb[k];
+    } catch (const std::bad_alloc&) {
+        return fail(EHM_E_CAPACITY, "ehm_search_bare_bounds: out of memory");
+    }
+    return EHM_OK;
+}
+
+// One expansion of every running search: its best `width` prefixes are popped and expanded.
+// *n_ask pairs need a problem (ehm_search_bare_asks); 0 with *n_active > 0 cannot happen -- a
+// step whose children are all known is finished inside the call and the next one started.
+int ehm_search_bare_step(ehm_search_bare* b, int32_t width, int64_t* n_ask, int64_t* n_active) {
+    if (!b || width < 1 || !n_ask || !n_active || b->pending)
+        return fail(EHM_E_INVALID, "ehm_search_bare_step: bad argument");
+    try {
+        for (;;) {
+            b->kid_code.clear(); b->kid_len.clear(); b->kid_owner.clear();
+            b->kid_val.clear(); b->kid_known.clear(); b->ask.clear();
+            if (b->active.empty()) break;
+            for (int32_t j : b->active) {
+                auto& h = b->heap[(size_t)j];
+                const int32_t take = (int32_t)std::min<size_t>((size_t)width, h.size());
+                std::vector<BareItem> batch;
+                for (int32_t k = 0; k < take; ++k) batch.push_back(b->pop(j));
+                b->expanded += take;
+                const auto& ex = b->exact[(size_t)j];
+                const auto& bd = b->bound[(size_t)j];
+                for (const BareItem& q : batch)
+                    for (int32_t i = 0; i < b->n_modes; ++i) {
+                        const uint64_t c = q.code + (uint64_t)(i + 1) * b->pw[(size_t)q.len];
+                        double v = 0.0;
+                        int8_t known = 0;
+                        auto e = ex.find(c);
+                        if (e != ex.end()) {        // (the caller's seeds carry their maximiser)
+                            v = e->second;
+                            known = 1;
+                        } else {
+                            auto f = bd.find(c);
+                            if (f != bd.end()) { v = f->second; known = 1; }
+                        }
+                        if (known) ++b->inherited;
+                        else b->ask.push_back((int64_t)b->kid_code.size());
+                        b->kid_code.push_back(c);
+                        b->kid_len.push_back(q.len + 1);
+                        b->kid_owner.push_back(j);
+                        b->kid_val.push_back(v);
+                        b->kid_known.push_back(known);
+                    }
+            }
+            if (!b->ask.empty()) {
+                b->pending = true;
+                break;
+            }
+            // nothing to solve: settle this step with what is known and go on
+            b->pending = true;
+            int64_t left = 0;
+            int rc = ehm_search_bare_answer(b, nullptr, &left);
+            if (rc) return rc;
+        }
+    } catch (const std::bad_alloc&) {
+        return fail(EHM_E_CAPACITY, "ehm_search_bare_step: out of memory");
+    }
+    *n_ask = (int64_t)b->ask.size();
+    *n_active = (int64_t)b->active.size();
+    return EHM_OK;
+}
+
+// The pairs of the step in flight: code [n_ask] (prefix), owner [n_ask] (search index).
+int ehm_search_bare_asks(const ehm_search_bare* b, uint64_t* code, int32_t* owner) {
+    if (!b || !b->pending || (!b->ask.empty() && (!code || !owner)))
+        return fail(EHM_E_INVALID, "ehm_search_bare_asks: no step in flight");
+    for (size_t a = 0; a < b->ask.size(); ++a) {
+        code[a] = b->kid_code[(size_t)b->ask[a]];
+        owner[a] = b->kid_owner[(size_t)b->ask[a]];
+    }
+    return EHM_OK;
+}
+
+// The launch's slacks t [n_ask], in the order of ehm_search_bare_asks.
+int ehm_search_bare_answer(ehm_search_bare* b, const double* t, int64_t* n_active) {
+    if (!b || !b->pending || (!b->ask.empty() && !t))
+        return fail(EHM_E_INVALID, "ehm_search_bare_answer: no step in flight");
+    try {
+        for (size_t a = 0; a < b->ask.size(); ++a) {
+            const size_t k = (size_t)b->ask[a];
+            b->kid_val[k] = t[a];
+            b->learned[(size_t)b->kid_owner[k]].emplace_back(b->kid_code[k], t[a]);
+        }
+        // children in the order they were listed, search by search
+        std::vector<int32_t> still;
+        size_t k = 0;
+        for (int32_t j : b->active) {
+            bool open = false;
+            for (; k < b->kid_owner.size() && b->kid_owner[k] == j; ++k) {
+                if (open) continue;                         // (the Python form breaks here)
+                const double tq = b->kid_val[k];
+                if (!(tq >= 0.0)) {
+                    const double a = tq < 0 ? -tq : tq;     // NaN never refutes anything below
+                    if (a < b->refuted[(size_t)j]) b->refuted[(size_t)j] = a;
+                } else if (b->kid_len[k] == b->N) {
+                    b->state[(size_t)j] = 0;
+                    b->margin[(size_t)j] = tq;
+                    open = true;
+                } else {
+                    b->push(j, BareItem{tq, b->kid_code[k], b->kid_len[k]});
+                }
+            }
+            if (open) continue;
+            if (!b->heap[(size_t)j].empty()) still.push_back(j);
+            else {
+                b->state[(size_t)j] = 1;
+                b->margin[(size_t)j] = b->refuted[(size_t)j];
+            }
+        }
+        b->active.swap(still);
+    } catch (const std::bad_alloc&) {
+        return fail(EHM_E_CAPACITY, "ehm_search_bare_answer: out of memory");
+    }
+    b->pending = false;
+    if (n_active) *n_active = (int64_t)b->active.size();
+    return EHM_OK;
+}
+
+// closed [n] (1 = every sequence refuted: epsilon-suboptimal, 0 = open), margin [n];
+// counts[0] = prefixes expanded, counts[1] = children answered without a problem.
+int ehm_search_bare_result(const ehm_search_bare* b, int8_t* closed, double* margin,
+                           int64_t counts[2]) {
+    if (!b || (b->n > 0 && (!closed || !margin)))
+        return fail(EHM_E_INVALID, "ehm_search_bare_result: bad argument");
+    if (b->pending || !b->active.empty())
+        return fail(EHM_E_INVALID, "ehm_search_bare_result: the searches are not finished");
+    for (int32_t j = 0; j < b->n; ++j) {
+        closed[j] = b->state[(size_t)j];
+        margin[j] = b->margin[(size_t)j];
+    }
+    if (counts) { counts[0] = b->expanded; counts[1] = b->inherited; }
+    return EHM_OK;
+}
+
+// The optima search j solved (its "learned" values): count, then code [count] / t [count].
+int ehm_search_bare_learned(const ehm_search_bare* b, int32_t j, int64_t* count, uint64_t* code,
+                            double* t) {
+    if (!b || j < 0 || j >= b->n || !count)
+        return fail(EHM_E_INVALID, "ehm_search_bare_learned: bad argument");
+    const auto& L = b->learned[(size_t)j];
+    *count = (int64_t)L.size();
+    if (code && t)
+        for (size_t k = 0; k < L.size(); ++k) { code[k] = L[k].first; t[k] = L[k].second; }
     return EHM_OK;
 }
 

@@ -299,6 +299,41 @@ class PrefixSearch:
                                             [pid[k, c:c + 1] for k, c in zip(ask, col)])
         return known
 
+    def feasible_somewhere_codes(self, codes, owner, pids):
+        """``feasible_somewhere`` for pairs given as (prefix code k, simplex ``owner[k]``) with the
+        point ids of every simplex's vertices in ``pids`` ((n_simplices, nv)): no per-pair work in
+        the interpreter except for the pairs nothing is known about."""
+        n = len(codes)
+        if not n:
+            return np.zeros(0, dtype=bool)
+        codes = np.ascontiguousarray(codes, dtype=np.uint64)
+        pid = np.ascontiguousarray(pids[owner], dtype=np.int64)
+        nv = pid.shape[1]
+        ver = np.empty(n * nv, dtype=np.int8)
+        rep = np.repeat(codes, nv)
+        flat = np.ascontiguousarray(pid.reshape(-1))
+        _capi.check_search(self._lib.ehm_search_peek(self._search, n * nv, ptr(rep), ptr(flat),
+                                                     ptr(ver)))
+        ver = ver.reshape(n, nv)
+        known = (ver == 1).any(axis=1)
+        ask = np.flatnonzero(~known & (ver == -1).any(axis=1))
+        if ask.size:
+            col = (ver[ask] == -1).argmax(axis=1)
+            known[ask] = self.feasible_sets([self._prefix(int(c)) for c in codes[ask]], None,
+                                            [pid[k, c:c + 1] for k, c in zip(ask, col)])
+        return known
+
+    def solve_slack_codes(self, codes, owner, Rs, Vs, pids):
+        """
+        Slacks t [n] of the suboptimality test of prefix ``codes[k]`` on simplex ``Rs[owner[k]]``
+        with vertex costs ``Vs[owner[k]]`` (the pairs a step of the native best-first queues asks
+        for, include/ehm_search.h).  This generic form goes through ``solve_slack``; the device
+        table maps codes to slots without touching the pairs one by one.
+        """
+        prefixes = [self._prefix(int(c)) for c in codes]
+        Rp = Rs[owner]
+        return self.solve_slack(prefixes, Rp, Vs[owner], self.feasible_somewhere(prefixes, Rp))[0]
+
     def feasible_at_all(self, prefixes, points):
         """For every prefix: is its relaxation feasible at every one of the points?"""
         if not len(prefixes):
@@ -504,7 +539,7 @@ class PrefixTable(PrefixSearch):
                               (int(unknown.sum()), float(np.min(tau[unknown]))))
         return ok
 
-    def _settle_stalled(self, values, status, simplices, slot, prefixes, what, infeasible_value,
+    def _settle_stalled(self, values, status, simplices, slot, lens, what, infeasible_value,
                         unknown_value, full_is_error):
         """
         An optimisation over a simplex that stalled.  If the pair was taken as feasible without
@@ -530,7 +565,8 @@ class PrefixTable(PrefixSearch):
             sliver = (st == 0) & (tau >= -SLIVER_TOL)
             self.slivers += int(sliver.sum())
             feasible = ~sliver & ((tau <= FEAS_TOL) | (st != 0))
-            full = np.array([len(prefixes[k]) == self.full_length for k in bad], dtype=bool)
+            full = (np.asarray(lens)[bad] == self.full_length) if self.full_length is not None \
+                else np.zeros(bad.size, dtype=bool)
             if full_is_error and (feasible & full).any():
                 from .oracle import SolverError
                 raise SolverError('%d %s problem(s) of full mode sequences did not converge on '
@@ -575,7 +611,7 @@ class PrefixTable(PrefixSearch):
                 self._tally(3, slot[ok])
                 # (a minimum is only ever a pruning bound: -inf keeps the prefix / the sequence)
                 J[idx[ok]] = self._settle_stalled(Jk, st, simplices[idx[ok]], slot[ok],
-                                                  [prefixes[k] for k in idx[ok]],
+                                                  [len(prefixes[k]) for k in idx[ok]],
                                                   'minimum-over-a-simplex', np.inf, -np.inf,
                                                   exact)
                 self.lp_solves += int(ok.sum())
@@ -603,12 +639,55 @@ class PrefixTable(PrefixSearch):
                                                  Vbar=vbars[idx[ok]])
                 self._tally(4, slot[ok])
                 tk = self._settle_stalled(tk, st, simplices[idx[ok]], slot[ok],
-                                          [prefixes[k] for k in idx[ok]],
+                                          [len(prefixes[k]) for k in idx[ok]],
                                           'suboptimality-test', -np.inf, np.inf, True)
                 self.lp_solves += int(ok.sum())
                 t[idx[ok]] = tk
                 alpha[idx[ok]] = ak
         return t, alpha
+
+    def slack_by_prefix_index(self, upre, inv, simplices, vbars, known):
+        """Slacks of pairs (distinct prefix ``upre[inv[k]]``, ``simplices[k]``, ``vbars[k]``);
+        ``known[k]``: the relaxation is known to be feasible on the simplex (no phase one).  The
+        search state is not touched: this is the launch side of ``solve_slack_codes``."""
+        n = len(inv)
+        t = np.full(n, -np.inf)
+        lens_u = np.array([len(q) for q in upre], dtype=np.int64)
+        for c0 in range(0, len(upre), self.slots):
+            part = upre[c0:c0 + self.slots]
+            sel = np.flatnonzero((inv >= c0) & (inv < c0 + len(part))) if len(upre) > self.slots \
+                else np.arange(n)
+            if not sel.size:
+                continue
+            slot = self._ensure(part)[inv[sel] - c0]
+            ok = np.asarray(known, dtype=bool)[sel].copy()
+            todo = np.flatnonzero(~ok)
+            if todo.size:
+                tau, _, st = self.gp.simplex_idx(simplices[sel[todo]], slot[todo], mode=2)
+                self.lp_solves += todo.size
+                self._tally(2, slot[todo])
+                ok[todo] = self._phase_one_verdict(tau, st)
+            if ok.any():
+                tk, _, st = self.gp.simplex_idx(simplices[sel[ok]], slot[ok], mode=1,
+                                                Vbar=vbars[sel[ok]])
+                self._tally(4, slot[ok])
+                tk = self._settle_stalled(tk, st, simplices[sel[ok]], slot[ok],
+                                          lens_u[inv[sel[ok]]], 'suboptimality-test', -np.inf,
+                                          np.inf, True)
+                self.lp_solves += int(ok.sum())
+                t[sel[ok]] = tk
+        return t
+
+    def solve_slack_codes(self, codes, owner, Rs, Vs, pids):
+        upre, inv = _unique_prefixes(self, codes)
+        known = self.feasible_somewhere_codes(codes, owner, pids)
+        return self.slack_by_prefix_index(upre, inv, Rs[owner], Vs[owner], known)
+
+
+def _unique_prefixes(table, codes):
+    """(list of distinct prefixes as tuples, index of every pair into it)."""
+    uniq, inv = np.unique(np.asarray(codes, dtype=np.uint64), return_inverse=True)
+    return [table._prefix(int(c)) for c in uniq], inv.astype(np.int64)
 
 
 def short_horizon(mpc, max_cols=32, max_rows=256):
@@ -743,6 +822,25 @@ class SplitPrefixTable(PrefixSearch):
                                                        vbars[sel],
                                                        None if kf is None else kf[sel])
         return t, alpha
+
+
+def _split_solve_slack_codes(self, codes, owner, Rs, Vs, pids):
+    upre, inv = _unique_prefixes(self, codes)
+    known = self.feasible_somewhere_codes(codes, owner, pids)       # this object's memo
+    short_u = np.array([len(q) <= self.short_len for q in upre], dtype=bool)
+    is_short = short_u[inv]
+    t = np.full(len(inv), -np.inf)
+    for table, sel, keep in ((self.short, np.flatnonzero(is_short), short_u),
+                             (self.long, np.flatnonzero(~is_short), ~short_u)):
+        if sel.size:
+            renum = np.cumsum(keep) - 1                             # index among the kept prefixes
+            t[sel] = table.slack_by_prefix_index([q for q, k in zip(upre, keep) if k],
+                                                 renum[inv[sel]], Rs[owner[sel]], Vs[owner[sel]],
+                                                 known[sel])
+    return t
+
+
+SplitPrefixTable.solve_slack_codes = _split_solve_slack_codes
 
 
 def make_table(mpc, slots=1024, device=0, eps_a=1., eps_r=1., split=None):

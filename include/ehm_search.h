@@ -93,6 +93,29 @@ int ehm_search_descent_step(ehm_search* s, const uint8_t* feasible, int64_t* n_a
 /* sequence [n][N] (modes; -1 where none exists), steps = lockstep levels walked. */
 int ehm_search_descent_result(ehm_search* s, int32_t* sequence, int64_t* steps);
 
+/* ---- best-first queues of the suboptimality-test searches (bar_E for many nodes at once) ------
+ * Per search: a queue of prefixes keyed by the upper bound t of their relaxation's slack (the
+ * reference's bar_E in decision form, lib/oracle.py:89-97, 285-309).  A step pops the best `width`
+ * prefixes of every running search and expands them; children whose value is known (a value
+ * seeded by the caller; an inherited upper bound, kept only where it refutes: t < -guard) need no
+ * problem, the rest is the ask list of ONE launch.  With the answers: t < 0 refutes a child, a
+ * full sequence with t >= 0 proves the node open, any other child is queued; an empty queue
+ * closes the node.  Expansion order, ask order and ties are those of heapq on (-t, prefix). */
+typedef struct ehm_search_bare ehm_search_bare;
+int ehm_search_bare_create(int32_t n, int32_t n_modes, int32_t N, const double* guard,
+                           ehm_search_bare** out);
+int ehm_search_bare_destroy(ehm_search_bare* b);
+int ehm_search_bare_seed(ehm_search_bare* b, int32_t j, uint64_t code, double t, int32_t open);
+int ehm_search_bare_bounds(ehm_search_bare* b, int32_t j, int64_t count, const uint64_t* code,
+                           const double* tb);
+int ehm_search_bare_step(ehm_search_bare* b, int32_t width, int64_t* n_ask, int64_t* n_active);
+int ehm_search_bare_asks(const ehm_search_bare* b, uint64_t* code, int32_t* owner);
+int ehm_search_bare_answer(ehm_search_bare* b, const double* t, int64_t* n_active);
+int ehm_search_bare_result(const ehm_search_bare* b, int8_t* closed, double* margin,
+                           int64_t counts[2]);
+int ehm_search_bare_learned(const ehm_search_bare* b, int32_t j, int64_t* count, uint64_t* code,
+                            double* t);
+
 #ifdef __cplusplus
 }
 #endif

@@ -153,3 +153,84 @@ class PyPrefixSearch:
                     still.append(j)
             active = still
         return out
+
+
+# ---- the suboptimality-test searches of many nodes: the plain-Python statement of what
+# bnb_frontier.bar_e_many does with the native queues (include/ehm_search.h: ehm_search_bare_*)
+import heapq                                             # noqa: E402
+
+from explicit_hybrid_mpc_amd import bnb_frontier        # noqa: E402
+
+
+def bar_e_many_py(oracle, Rs, Vs, bound=None, learned=None, incumbents=None):
+    """
+    ``PrefixOracle.bar_E_delta_R`` for many nodes: (list of bool, list of margins).
+    ``bound[j]``: upper bounds of t* per prefix inherited from node j's ancestors (a prefix they
+    refute needs no problem); ``learned[j]`` (a dict, filled here): the optima solved on node j;
+    ``incumbents[j]``: a full sequence tried first (the parent's best-slack sequence) -- where
+    its slack is not negative the node is open and the search is not run.
+    """
+    table, mpc = oracle.table, oracle.mpc
+    n_modes, N = mpc.delta_size, mpc.N
+    n = len(Rs)
+    heaps = [[(-np.inf, ())] for _ in range(n)]
+    refuted = [np.inf] * n
+    closed, margin = [None] * n, [np.inf] * n
+    active = list(range(n))
+    oracle.calls['bar_E'] += n
+    guard = [bnb_frontier.INHERIT_GUARD * (1. + float(np.max(np.abs(V)))) for V in Vs]
+    seeded = [j for j in range(n) if incumbents and incumbents[j] is not None]
+    if seeded:
+        Rw = np.array([Rs[j] for j in seeded])
+        tw, aw = table.solve_slack([incumbents[j] for j in seeded], Rw,
+                                   np.array([Vs[j] for j in seeded]),
+                                   table.feasible_somewhere([incumbents[j] for j in seeded], Rw))
+        for w, j in enumerate(seeded):
+            if learned is not None:
+                learned[j][incumbents[j]] = (float(tw[w]), aw[w].copy())
+            if tw[w] >= 0.:
+                closed[j], margin[j] = False, abs(float(tw[w]))
+        active = [j for j in active if closed[j] is None]
+    while active:
+        pre, Rp, Vp, kid_of, val_of, ask_of = [], [], [], {}, {}, {}
+        width = bnb_frontier._batch_size(len(active), n_modes)
+        for j in active:
+            batch = [heapq.heappop(heaps[j])[1] for _ in range(min(width, len(heaps[j])))]
+            oracle.n_expanded += len(batch)
+            kids = [k for q in batch for k in bnb_frontier._kids(q, n_modes)]
+            kid_of[j] = kids
+            val_of[j] = bnb_frontier._lookup(kids, learned[j] if learned else None,
+                                bound[j] if bound else None, guard[j], N)
+            ask_of[j] = [i for i, v in enumerate(val_of[j]) if v is None]
+            pre.extend(kids[i] for i in ask_of[j])
+            Rp.extend([Rs[j]] * len(ask_of[j]))
+            Vp.extend([Vs[j]] * len(ask_of[j]))
+        oracle.n_inherited += sum(len(kid_of[j]) - len(ask_of[j]) for j in active)
+        if pre:
+            Rp = np.array(Rp)
+            t, _ = table.solve_slack(pre, Rp, np.array(Vp), table.feasible_somewhere(pre, Rp))
+        pos, still = 0, []
+        for j in active:
+            kids, vals = kid_of[j], val_of[j]
+            for i in ask_of[j]:
+                vals[i] = (float(t[pos]), None)
+                if learned is not None:
+                    learned[j][kids[i]] = vals[i]
+                pos += 1
+            for q, (tq, _) in zip(kids, vals):
+                if not tq >= 0.:
+                    refuted[j] = min(refuted[j], abs(tq))
+                elif len(q) == N:
+                    closed[j], margin[j] = False, abs(tq)
+                    break
+                else:
+                    heapq.heappush(heaps[j], (-tq, q))
+            if closed[j] is None:
+                if heaps[j]:
+                    still.append(j)
+                else:
+                    closed[j], margin[j] = True, refuted[j]
+        active = still
+    return closed, margin
+
+

@@ -5,6 +5,8 @@ pair solvers, HiGHS) against the ENUMERATING CPU oracle: same canonical answers,
 """
 
 import pytest
+import itertools
+
 import numpy as np
 
 from explicit_hybrid_mpc_amd import bnb, examples
@@ -582,3 +584,75 @@ def test_short_prefixes_on_a_table_of_the_short_horizon(monkeypatch):
                 assert np.allclose(nd.data.vertex_costs, r['vertex_costs'], rtol=1e-7, atol=1e-8)
     assert n == len(cpu.nodes)
     two.close()
+
+
+@pytest.mark.parametrize('kind', ['cpu', 'stub', 'split'])
+def test_native_queues_of_bar_e_equal_the_python_statement(kind, monkeypatch):
+    """
+    bnb_frontier.bar_e_many keeps its best-first queues natively (include/ehm_search.h:
+    ehm_search_bare_*) and asks the table for (prefix code, node) pairs; the plain-Python statement
+    of the same search (tests/prefix_search_py.bar_e_many_py: heapq on (-t, prefix), dictionaries,
+    per-pair lists) must take the same decisions, report the same margins, expand the same
+    prefixes, solve the SAME problems and leave the same optima for the nodes that stay open --
+    on the HiGHS table of the uncondensed relaxations ('cpu': the generic pair path), on the
+    device-table class over a HiGHS stub ('stub': codes -> slots with numpy) and on the two-table
+    form ('split').  Nodes with and without an incumbent, with and without inherited bounds.
+    """
+    from explicit_hybrid_mpc_amd import sequences, bnb_frontier
+    from tests.prefix_search_py import bar_e_many_py
+    monkeypatch.setattr(sequences.engine, 'GpuProblem', _StubDeviceProblem)
+    mpc = helpers.make_instance('pwa_small', 0)                  # 2 modes, N = 3
+    eps_a = helpers.eps_a_rule(mpc, 0.25)
+
+    def make():
+        if kind == 'cpu':
+            table = prefix_bb.CpuPrefixTable(mpc, eps_a, 0.05)
+        elif kind == 'stub':
+            table = sequences.PrefixTable(mpc, slots=16, eps_a=eps_a, eps_r=0.05)
+        else:
+            table = sequences.SplitPrefixTable(mpc, 2, slots=16, eps_a=eps_a, eps_r=0.05)
+        return bnb.PrefixOracle(mpc, eps_a, 0.05, table=table)
+    ref = bnb.PrefixOracle(mpc, eps_a, 0.05, table=prefix_bb.CpuPrefixTable(mpc, eps_a, 0.05))
+    rng = np.random.default_rng(23)
+    Rs, Vs, incs, bounds = [], [], [], []
+    every = [q for k in range(1, mpc.N + 1)
+             for q in itertools.product(range(mpc.delta_size), repeat=k)]
+    for R in list(helpers.random_simplices(mpc, rng, 40, scale_lo=-1.3)) + \
+            [np.array(r) for r in helpers.roots_of(mpc)[0]]:
+        R = np.array(R)
+        delta, vx = ref.V_R(R)
+        if delta is None:
+            continue
+        V = np.array([v[1] for v in vx])
+        Rs.append(R)
+        Vs.append(V)
+        incs.append(ref.sequence_of(delta) if rng.random() < 0.5 else None)
+        if rng.random() < 0.5:          # inherited upper bounds: some refute, some do not
+            some = [every[i] for i in rng.choice(len(every), size=6, replace=False)]
+            bounds.append({q: float(rng.choice([-1., -1e-9, 0.3])) for q in some})
+        else:
+            bounds.append(None)
+    assert len(Rs) >= 12
+    a, b = make(), make()
+    la, lb = [dict() for _ in Rs], [dict() for _ in Rs]
+    ca, ma = bnb_frontier.bar_e_many(a, Rs, Vs, bounds, la, incs)
+    cb, mb = bar_e_many_py(b, Rs, Vs, bounds, lb, incs)
+    assert ca == cb and any(ca) and not all(ca)
+    assert np.allclose(ma, mb, rtol=1e-12, atol=0.)
+    assert a.n_expanded == b.n_expanded and a.n_inherited == b.n_inherited
+    assert a.table.lp_solves == b.table.lp_solves and a.calls == b.calls
+    for j, closed in enumerate(ca):
+        if closed:
+            continue                    # a closed node's optima have no reader
+        assert set(la[j]) == set(lb[j]), j
+        for q in la[j]:
+            assert la[j][q][0] == lb[j][q][0] or abs(la[j][q][0] - lb[j][q][0]) <= 1e-12
+            assert (la[j][q][1] is None) == (lb[j][q][1] is None)
+    # without incumbents, bounds or a place for the optima
+    c0, m0 = bnb_frontier.bar_e_many(a, Rs[:5], Vs[:5])
+    c1, m1 = bar_e_many_py(b, Rs[:5], Vs[:5])
+    assert c0 == c1 and np.allclose(m0, m1, rtol=1e-12, atol=0.)
+    assert bnb_frontier.bar_e_many(a, [], []) == ([], [])
+    a.close()
+    b.close()
+    ref.close()
