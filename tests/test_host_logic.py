@@ -317,3 +317,65 @@ def test_ctypes_mirrors_are_the_librarys_structs():
     assert n == len(mirrors)
     assert [int(sizes[k]) for k in range(n)] == [ctypes.sizeof(m) for m in mirrors]
     assert lib.ehm_abi_sizes(None, 0) == n
+
+
+def test_config5_helpers_of_the_benchmark():
+    """bench.kuhn_cell: the Kuhn simplices of the rotated coordinate orders are cells of the box
+    (volume |box| / p!, vertices at its corners, the main diagonal in all of them);
+    sequences.short_horizon / make_table: the two-table form exactly where the full model needs
+    the wide kernels and a shorter horizon fits the shared-block ones."""
+    import math
+    import bench
+    from explicit_hybrid_mpc_amd import examples, sequences
+    from oracle import geometry
+    half = np.array([0.2, 0.3, 0.1, 0.25])
+    p = half.size
+    seen = set()
+    for k in range(p):
+        R = bench.kuhn_cell(half, k)
+        assert R.shape == (p + 1, p)
+        assert np.all(np.abs(np.abs(R) - half) == 0)                     # corners of the box
+        assert np.array_equal(R[0], -half) and np.array_equal(R[-1], half)
+        assert abs(geometry.simplex_volume(R) - np.prod(2 * half) / math.factorial(p)) < 1e-15
+        seen.add(R.tobytes())
+    assert len(seen) == p
+    assert np.array_equal(bench.kuhn_cell(half, 0),
+                          np.array([-half + 2 * half * (np.arange(p) < k) for k in range(p + 1)]))
+    big = examples.pwa4_mpc(N=8)
+    assert sequences.short_horizon(big) == 4                  # 29 x 195 fits, 34 columns do not
+    assert sequences.short_horizon(examples.pwa4_mpc(N=4)) == 0          # fits as it is
+    assert sequences.short_horizon(helpers.make_instance('pwa_small', 0)) == 0
+    four = big.with_horizon(4)
+    assert four.N == 4 and four.delta_size == big.delta_size
+    G4, _, _ = four.condense_prefix((2, 1))
+    G8, _, _ = big.condense_prefix((2, 1))
+    assert G4.shape == (184, 20) and G8.shape == (368, 40)      # 29 x 195 against 49 x 379 slack LPs
+    # (that the two blocks are the same PROBLEM: tests/test_host_bnb.py, the split-table test)
+
+
+def test_a_failing_secondary_workload_does_not_cost_the_headline(monkeypatch):
+    """bench.secondary_line: an exception (or SystemExit) of a secondary workload becomes an
+    'error' entry of the list; the fields of a good entry are the documented subset."""
+    import argparse
+    import bench
+    args = bench.parse_args([])
+
+    def boom(a, ctx):
+        raise RuntimeError('no device here')
+    monkeypatch.setattr(bench, 'measure', boom)
+    line = bench.secondary_line(args, {}, 'config3', 2, 1)
+    assert line['workload'] == 'config3' and 'RuntimeError: no device here' in line['error']
+
+    def fine(a, ctx):
+        assert a.workload == 'config4' and (a.steps, a.warmup) == (2, 1)
+        assert a.abs_frac is None and a.eps_r is None and a.cpu_seconds == args.secondary_cpu_seconds
+        return dict(value=1., unit='LP solves/s', ms_per_step=2., regions_per_s=3.,
+                    oracle_calls_answered_per_s=4., steps=2, warmup=1, roofline={'frac': 0.1},
+                    cpu_baseline={'value': 5.}, config={'workload': 'w', 'regions_per_step': 7,
+                                                        'not_copied': 1})
+    monkeypatch.setattr(bench, 'measure', fine)
+    line = bench.secondary_line(args, {}, 'config4', 2, 1)
+    assert line['name'] == 'config4' and line['workload'] == 'w' and line['ms_per_step'] == 2.
+    assert line['config'] == {'workload': 'w', 'regions_per_step': 7}
+    assert line['roofline'] == {'frac': 0.1} and line['cpu_baseline'] == {'value': 5.}
+    assert isinstance(args, argparse.Namespace) and args.workload == 'config2'   # untouched

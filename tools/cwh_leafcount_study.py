@@ -63,9 +63,12 @@ def main():
             cases += [(job, 'best', 0, tau) for tau in (0., 1e-8, 1e-6, 1e-4)]
             cases += [(job, 'first', 0, 0.)]
             cases += [(job, 'random', seed, 0.) for seed in range(8)]
-        else:                       # minutes per case: the canonical rule, one tolerance, four draws
+        elif job == 2:              # minutes per case: the canonical rule, one tolerance, four draws
             cases += [(job, 'best', 0, 0.), (job, 'best', 0, 1e-6)]
             cases += [(job, 'random', seed, 0.) for seed in range(4)]
+        else:                       # hours per case: the canonical rule and two draws
+            cases += [(job, 'best', 0, 0.)]
+            cases += [(job, 'random', seed, 0.) for seed in range(2)]
     with mp.get_context('spawn').Pool(procs) as pool:
         for (job, rule, seed, tau), leaves, depth, solves, secs, err in pool.imap_unordered(run, cases):
             print('job %d (reference: %d leaves, depth %d)  rule %-6s seed %d tau %-7g -> %6d leaves, '
