@@ -7,19 +7,26 @@ A "step" is one complete partition of the synthetic config-2 instance
 configs[1]): feasible-commutation pass over the 22 Delaunay root simplices, then
 epsilon-suboptimal refinement until every leaf is closed.  Problem constants and the
 root simplices are resident in HBM before the timed region; the timed region contains
-everything else (all frontier sweeps, LP solves, child construction).
+everything else (the persistent frontier kernel: all suboptimality tests, midpoint solves, child
+construction).
 
     python bench.py --gpus N --steps K --warmup W
 
-prints ONE JSON line on rank 0.  For N > 1 it is launched by torch.distributed.run with
-one rank per GPU; every rank runs ONE launch of the persistent frontier kernel from the roots:
-the tree above a deal depth (about 2048 nodes per rank) is grown identically everywhere, a node
-created at that depth is pursued only by the rank a hash of its path names -- no collective in the
-data path (`--balance static`, the default; measured by running the shards one after the other:
-1.93x / 3.52x / 5.98x at 2 / 4 / 8 on the 1.6 M-node bench tree, 7.3x at 8 on a 6.9 M-node tree;
-`--balance dynamic` sweeps level by level and rebalances the frontiers with an all-gather of
-their sizes and point-to-point node transfers, explicit_hybrid_mpc_amd/distributed.py).  The
-total work is fixed ("strong" scaling) and `value` is the whole-job LP-solve rate.
+prints ONE JSON line on rank 0.  With N = 1 and the default workload the line also carries
+"secondary": a few steps each of the other BASELINE.json configurations that fit one GPU
+(config3, config4, config2q, config5), every entry with its own roofline and cpu_baseline.
+
+For N > 1 it is launched by torch.distributed.run with one rank per GPU; every rank runs ONE
+launch of the persistent frontier kernel from the roots: the tree above a deal depth is grown
+identically everywhere, a node created at that depth is pursued only by the rank a hash of its
+path names -- no collective in the data path (`--balance static`, the default; measured by running
+the shards one after the other on one GPU: 1.68x / 2.55x / 3.50x at 2 / 4 / 8 on the 1.6 M-node
+bench tree with the round-3 kernel; `--balance dynamic`: budgeted rounds of
+the persistent kernel, an all-gather of the frontier sizes and point-to-point node transfers
+between them, explicit_hybrid_mpc_amd/distributed.py).  The total work is fixed ("strong"
+scaling), `value` is the whole-job LP-solve rate, and rank 0 checks after the timed region that
+the regions of all ranks together are the regions of one unsharded partition
+(`config.tree_identity`).
 """
 
 import argparse
@@ -359,7 +366,10 @@ def measure(args, ctx):
         args.shard_min_frontier = (1024 if static else 64) * world
     shard = distributed.shard_spec(rank, world, args.shard_min_frontier)
     # static: ONE persistent launch per rank from the roots, dealt at a tree depth by path code
-    deal_depth = distributed.deal_depth_for(len(roots), world, 64 if hybrid else 2048) \
+    # (128 nodes per rank at the deal depth: with the round-3 kernel the replicated top of the tree
+    # costs more than the imbalance of an early deal -- 10.6 ms per shard at depth 6 against 11.1 at
+    # depth 10 for 8 shards, profiles/r3/shard_balance_deal_1p6M_nodes.txt)
+    deal_depth = distributed.deal_depth_for(len(roots), world, 64 if hybrid else 128) \
         if (static and world > 1) else 0
 
     xdev = ('cuda:%d' % device_index) if backend == 'nccl' else None
