@@ -465,3 +465,73 @@ def test_driver_bookkeeping_when_some_nodes_are_handed_off(monkeypatch):
                     assert np.array_equal(nd.data.commutation.astype(int),
                                           r['commutation'].astype(int))
         assert n > len(roots) and stats['handoffs'] == len(handed) >= 1
+
+
+def test_best_first_queue_protocol_and_its_error_paths():
+    """ehm_search_bare_* (include/ehm_search.h) on a synthetic slack function: two searches over 2
+    modes x 3 steps advance in lockstep; seeds, refuting bounds, the ask / answer order and the
+    misuse of the protocol (answer without a step, result before the end, bad indices)."""
+    import ctypes
+    from explicit_hybrid_mpc_amd import _capi
+    from explicit_hybrid_mpc_amd._capi import ptr
+    lib = _capi.load()
+    n_modes, N, base = 2, 3, 3
+
+    def code(q):
+        return sum((d + 1) * base ** i for i, d in enumerate(q))
+
+    def prefix(c):
+        out = []
+        while c:
+            out.append(c % base - 1)
+            c //= base
+        return tuple(out)
+    # slack of a prefix: search 0 is refuted everywhere (closed), search 1 is open through (1, 0, 1)
+    def slack(j, q):
+        if j == 0:
+            return -0.5 - 0.1 * len(q)
+        good = (1, 0, 1)
+        return 1.0 - 0.1 * len(q) if q == good[:len(q)] else -0.2
+    guard = np.array([1e-6, 1e-6])
+    h = ctypes.c_void_p()
+    assert lib.ehm_search_bare_create(2, n_modes, N, ptr(guard), ctypes.byref(h)) == 0
+    n_ask, left = ctypes.c_int64(), ctypes.c_int64()
+    # misuse before any step
+    assert lib.ehm_search_bare_answer(h, None, ctypes.byref(left)) != 0
+    assert b'no step in flight' in lib.ehm_search_last_error()
+    closed, margin = np.empty(2, dtype=np.int8), np.empty(2)
+    assert lib.ehm_search_bare_result(h, ptr(closed), ptr(margin), None) != 0
+    assert b'not finished' in lib.ehm_search_last_error()
+    assert lib.ehm_search_bare_seed(h, 5, 0, 0., 0) != 0             # no such search
+    # an inherited bound that refutes (1, 1) for search 1, and one that does not count
+    codes = np.array([code((1, 1)), code((1, 0))], dtype=np.uint64)
+    tb = np.array([-1., -1e-9])
+    assert lib.ehm_search_bare_bounds(h, 1, 2, ptr(codes), ptr(tb)) == 0
+    asked, steps = [], 0
+    while True:
+        assert lib.ehm_search_bare_step(h, 4, ctypes.byref(n_ask), ctypes.byref(left)) == 0
+        if not n_ask.value:
+            break
+        steps += 1
+        c = np.empty(n_ask.value, dtype=np.uint64)
+        o = np.empty(n_ask.value, dtype=np.int32)
+        assert lib.ehm_search_bare_asks(h, ptr(c), ptr(o)) == 0
+        assert lib.ehm_search_bare_step(h, 4, ctypes.byref(n_ask), ctypes.byref(left)) != 0   # in flight
+        asked += [(int(j), prefix(int(q))) for q, j in zip(c, o)]
+        t = np.array([slack(int(j), prefix(int(q))) for q, j in zip(c, o)])
+        assert lib.ehm_search_bare_answer(h, ptr(t), ctypes.byref(left)) == 0
+    counts = np.zeros(2, dtype=np.int64)
+    assert lib.ehm_search_bare_result(h, ptr(closed), ptr(margin), ptr(counts)) == 0
+    assert closed.tolist() == [1, 0] and abs(margin[0] - 0.6) < 1e-12 and abs(margin[1] - 0.7) < 1e-12
+    # search 0 ends after its two one-step relaxations; search 1 never solves the refuted (1, 1)
+    assert (0, (0,)) in asked and (0, (1,)) in asked and not any(j == 0 and len(q) > 1 for j, q in asked)
+    assert (1, (1, 1)) not in asked and (1, (1, 0)) in asked and (1, (1, 0, 1)) in asked
+    assert counts[1] == 1 and steps == 3                     # one child answered by the bound
+    cnt = ctypes.c_int64()
+    assert lib.ehm_search_bare_learned(h, 1, ctypes.byref(cnt), None, None) == 0 and cnt.value >= 5
+    lc, lt = np.empty(cnt.value, dtype=np.uint64), np.empty(cnt.value)
+    assert lib.ehm_search_bare_learned(h, 1, ctypes.byref(cnt), ptr(lc), ptr(lt)) == 0
+    assert dict(zip((prefix(int(c)) for c in lc), lt))[(1, 0, 1)] == 0.7
+    assert lib.ehm_search_bare_destroy(h) == 0
+    # (n_modes + 1)^N beyond the code range is refused
+    assert lib.ehm_search_bare_create(1, 4, 12, ptr(guard), ctypes.byref(h)) != 0
