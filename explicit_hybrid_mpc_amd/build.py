@@ -20,9 +20,14 @@ SRC_DIR = os.path.join(HERE, 'csrc')
 LIB_DIR = os.path.join(HERE, 'lib')
 OBJ_DIR = os.path.join(LIB_DIR, 'obj')
 LIB = os.path.join(LIB_DIR, 'libehmpc.so')
-HEADERS = ['ehm_ipm.h', 'ehm_kernels.h', 'ehm_dev.h', 'ehm_k2.h', 'ehm_ipm2.h', 'ehm_ipm3.h',
-           'ehm_k2_asm.h', 'ehm_hybrid.h',
-           os.path.join('..', '..', 'include', 'ehmpc.h')]
+def _headers():
+    """Every header under csrc/ (each is included by some object: derived from the directory, so a
+    new header cannot be forgotten) + the public C-ABI header."""
+    hs = sorted(f for f in os.listdir(SRC_DIR) if f.endswith('.h'))
+    return hs + [os.path.join('..', '..', 'include', 'ehmpc.h')]
+
+
+HEADERS = _headers()
 # must match EHM_K2_ALL in ehm_capi.hip
 K2_NPS = (8, 12, 16, 20, 24, 28, 32)
 K2_SLOTS = (1, 2, 3, 4)
@@ -30,8 +35,11 @@ K2_SLOTS = (1, 2, 3, 4)
 K2Q_NPS = (8, 16, 24, 32)
 # persistent frontier kernel at two solver widths (ehm_kp.hip): (decide NP, expand NP, slots);
 # must match EHM_KP_ALL in ehm_capi.hip
-KP_INSTANCES = ((16, 8, 2), (16, 8, 3), (20, 12, 2), (20, 12, 3), (24, 16, 2), (24, 16, 3),
-                (28, 20, 2), (28, 20, 3), (32, 24, 2), (32, 24, 3), (32, 24, 4), (28, 20, 4))
+# (widths = FACTORISED columns: ehm_ipm2.h eliminates the epigraph columns of the z-block)
+KP_INSTANCES = tuple((d, e, sl) for (d, e) in ((12, 8), (16, 8), (16, 12), (20, 12), (20, 16),
+                                                (24, 16), (24, 20), (28, 20), (28, 24), (32, 24),
+                                                (32, 28)) for sl in (2, 3)) + \
+    ((16, 12, 4), (28, 20, 4), (32, 24, 4))
 # the same with the midpoint solve first (the default flow; EHM_KPM_ALL in ehm_capi.hip)
 KPM_INSTANCES = KP_INSTANCES
 # wide kernels (ehm_k3.hip): row slots per thread, rows <= 256 * slots; must match the

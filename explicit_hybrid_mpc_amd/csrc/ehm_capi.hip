@@ -39,8 +39,13 @@ EHM_K2Q_ALL(EHM_K2Q_DECL)
 #define EHM_K2Q_ENTRY(NPV, SL) ehm_k2q_api_##NPV##_##SL,
 static const k2_getter g_k2q_getters[] = {EHM_K2Q_ALL(EHM_K2Q_ENTRY)};
 // persistent frontier kernel at two solver widths (ehm_kp.hip): (decide NP, expand NP, slots)
-#define EHM_KP_ALL(X) X(16, 8, 2) X(16, 8, 3) X(20, 12, 2) X(20, 12, 3) X(24, 16, 2) X(24, 16, 3) \
-    X(28, 20, 2) X(28, 20, 3) X(32, 24, 2) X(32, 24, 3) X(32, 24, 4) X(28, 20, 4)
+// (the widths are those of the FACTORISED columns: with the eliminated block of ehm_ipm2.h the
+// suboptimality-test LP of config 2 runs at 16 and its midpoint LP at 12)
+#define EHM_KP_SL(X, D, E) X(D, E, 2) X(D, E, 3)
+#define EHM_KP_ALL(X) EHM_KP_SL(X, 12, 8) EHM_KP_SL(X, 16, 8) EHM_KP_SL(X, 16, 12) \
+    EHM_KP_SL(X, 20, 12) EHM_KP_SL(X, 20, 16) EHM_KP_SL(X, 24, 16) EHM_KP_SL(X, 24, 20) \
+    EHM_KP_SL(X, 28, 20) EHM_KP_SL(X, 28, 24) EHM_KP_SL(X, 32, 24) EHM_KP_SL(X, 32, 28) \
+    X(16, 12, 4) X(28, 20, 4) X(32, 24, 4)
 #define EHM_KP_DECL(D, E, SL) extern "C" const ehm::KpApi* ehm_kp_api_##D##_##E##_##SL();
 EHM_KP_ALL(EHM_KP_DECL)
 #define EHM_KP_ENTRY(D, E, SL) ehm_kp_api_##D##_##E##_##SL,
@@ -473,7 +478,10 @@ struct ehm_problem {
     int delta_len = 0;
     std::vector<uint8_t> deltas;
     DevBuf consts;           // Gt | St | w | c
-    DevBuf wc2;              // [n_delta][n+p+2][m|1]  LDS image for the k2 kernels
+    DevBuf wc2;              // [n_delta][n+p+2][m|1]  LDS image, all columns (wide kernels; the
+                             // shared-block kernels when no column is eliminated)
+    DevBuf wc4;              // [n_delta][tot4]  LDS image without the eliminated columns + their
+                             // tables (DevProblem::Wc4; unused when nd0 == n: Wc4 aliases Wc2)
     DevBuf wr3;              // [n_delta][mpad][64]    row-major image for the wide kernels
     DevBuf quad;             // H | F^T | f0 | C | c1 | c0  (ehm_problem_set_quadratic)
     bool quadratic = false;
@@ -634,7 +642,8 @@ static int k2_config(ehm_problem* P, int kind_a, int kind_b, long long n_items, 
     const int slots = std::max(lp_slots(P->dp.m, ne), lp_slots(P->dp.m, ne2));
     n_lp = std::max(n_lp, n_lp2);
     ne = std::max(ne, ne2);
-    const K2Api* api = k2_pick(n_lp, slots, P->quadratic);
+    // (the instances are sized by the FACTORISED columns: ehm_ipm2.h eliminates [nd0, n))
+    const K2Api* api = k2_pick(n_lp - (P->dp.n - P->dp.nd0), slots, P->quadratic);
     if (!api)
         return fail(EHM_E_INVALID, "no kernel instance for an LP with %d columns, %d row slots",
                     n_lp, slots);
@@ -692,6 +701,97 @@ static void sort_by_commutation(int nd, int64_t n, const int32_t* didx, std::vec
     std::vector<int32_t> pos(seg.begin(), seg.end() - 1);
     order.resize((size_t)n);
     for (int64_t k = 0; k < n; ++k) order[(size_t)pos[(size_t)didx[k]]++] = k;
+}
+
+// ---- eliminated columns (ehm_ipm2.h) ---------------------------------------
+#define EHM_ELIM_MAX_ROWS 16    // rows one eliminated column may have (Shared::LE)
+
+// Largest trailing range [nd0, n) of the z-columns of which, in EVERY commutation, every row holds
+// at most one entry and every column 1..EHM_ELIM_MAX_ROWS entries -- the epigraph variables of an
+// infinity-norm cost (lib/mpc_library.py:530-560).  G: [nd][m][n] row-major.  nd0 = n: none.
+static void elim_detect(const double* G, int nd, int m, int n, int p, int n_u, int& nd0, int& LE) {
+    nd0 = n;
+    LE = 0;
+    std::vector<int> rowcnt((size_t)nd * m, 0);
+    int le = 0;
+    for (int c = n - 1; c >= n_u; --c) {
+        bool ok = true;
+        int colmax = 0;
+        for (int k = 0; k < nd && ok; ++k) {
+            int nnz = 0;
+            for (int i = 0; i < m; ++i)
+                if (G[((size_t)k * m + i) * n + c] != 0.0) {
+                    ++nnz;
+                    if (rowcnt[(size_t)k * m + i] >= 1) ok = false;
+                }
+            if (nnz < 1 || nnz > EHM_ELIM_MAX_ROWS) ok = false;
+            colmax = std::max(colmax, nnz);
+        }
+        if (!ok) break;
+        for (int k = 0; k < nd; ++k)
+            for (int i = 0; i < m; ++i)
+                if (G[((size_t)k * m + i) * n + c] != 0.0) rowcnt[(size_t)k * m + i]++;
+        le = std::max(le, colmax);
+        // the transform of the block's weight rows runs as (column, weight) tasks of one wavefront
+        if ((n - c) * p > 256) break;
+        nd0 = c;
+        LE = le;
+    }
+    if (n - nd0 < 2) {      // not worth a second code path
+        nd0 = n;
+        LE = 0;
+    }
+    LE = (LE + 1) & ~1;
+}
+
+static size_t elim_tot4(int m, int p, int lda, int nd0, int nE, int LE) {
+    const size_t tab = (size_t)nE * LE + ((size_t)nE * LE + m + 1) / 2;
+    return (((size_t)(nd0 + p + 3) * lda + tab) + 1) & ~(size_t)1;
+}
+
+// One commutation's image without the columns [nd0, n) (layout: DevProblem::Wc4).  False when the
+// block is not of the expected shape (a row with two entries, a column with too many).
+static bool elim_image(const double* Gk, const double* Sk, int m, int n, int p, int lda, int nd0,
+                       int LE, double* base, size_t tot4) {
+    const int nE = n - nd0;
+    std::fill(base, base + tot4, 0.0);
+    for (int i = 0; i < m; ++i) {
+        for (int j = 0; j < nd0; ++j) base[(size_t)j * lda + i] = Gk[(size_t)i * n + j];
+        for (int q = 0; q < p; ++q) base[(size_t)(nd0 + q) * lda + i] = -Sk[(size_t)i * p + q];
+        base[(size_t)(nd0 + p) * lda + i] = -1.0;
+    }
+    double* aE = base + (size_t)(nd0 + p + 2) * lda;
+    double* eval = base + (size_t)(nd0 + p + 3) * lda;
+    int32_t* erow = reinterpret_cast<int32_t*>(eval + (size_t)nE * LE);
+    int32_t* eidx = erow + (size_t)nE * LE;
+    std::vector<int> fill((size_t)nE, 0);
+    for (int i = 0; i < m; ++i) {
+        int found = -1;
+        for (int e = 0; e < nE; ++e) {
+            const double v = Gk[(size_t)i * n + nd0 + e];
+            if (v == 0.0) continue;
+            if (found >= 0 || fill[(size_t)e] >= LE) return false;
+            found = e;
+            aE[i] = v;
+            eidx[i] = e;
+            eval[(size_t)e * LE + fill[(size_t)e]] = v;
+            erow[(size_t)e * LE + fill[(size_t)e]] = i;
+            fill[(size_t)e]++;
+        }
+    }
+    for (int e = 0; e < nE; ++e)
+        if (fill[(size_t)e] == 0) return false;     // an empty column: Delta_e would be 0
+    return true;
+}
+
+// no eliminated columns: the shared-block kernels read the full image
+static void elim_off(ehm_problem* P) {
+    P->dp.nd0 = P->dp.n;
+    P->dp.LE4 = 0;
+    P->dp.Wc4 = P->dp.Wc2;
+    P->dp.lda4 = P->dp.lda2;
+    P->dp.ncw4 = P->dp.ncw2;
+    P->dp.tot4 = P->dp.ncw2 * P->dp.lda2;
 }
 
 extern "C" {
@@ -772,6 +872,32 @@ int ehm_problem_create(const ehm_problem_desc* d, int device, ehm_problem** out)
         P->dp.Wc2 = P->wc2.as<double>();
         P->dp.lda2 = lda;
         P->dp.ncw2 = ncw;
+        // the same image without the eliminated columns (EHM_SPARSE=0: keep every column)
+        elim_off(P);
+        int nd0 = n, LE = 0;
+        const char* es = getenv("EHM_SPARSE");
+        if (!(es && atoi(es) == 0)) elim_detect(d->G, nd, m, n, p, d->n_u, nd0, LE);
+        if (nd0 < n) {
+            const int nE = n - nd0;
+            const size_t tot4 = elim_tot4(m, p, lda, nd0, nE, LE);
+            std::vector<double> img4((size_t)nd * tot4);
+            bool ok = true;
+            for (int k = 0; k < nd && ok; ++k)
+                ok = elim_image(d->G + (size_t)k * m * n, d->S + (size_t)k * m * p, m, n, p, lda,
+                                nd0, LE, img4.data() + (size_t)k * tot4, tot4);
+            if (ok) {
+                rc = P->wc4.ensure(img4.size() * sizeof(double));
+                if (rc) { delete P; return rc; }
+                HIP_TRY(hipMemcpy(P->wc4.ptr, img4.data(), img4.size() * sizeof(double),
+                                  hipMemcpyHostToDevice), EHM_E_HIP);
+                P->dp.Wc4 = P->wc4.as<double>();
+                P->dp.lda4 = lda;
+                P->dp.ncw4 = nd0 + p + 3;
+                P->dp.tot4 = (int)tot4;
+                P->dp.nd0 = nd0;
+                P->dp.LE4 = LE;
+            }
+        }
     }
     P->dp.Wr3 = nullptr;
     P->dp.mpad3 = 0;
@@ -883,6 +1009,22 @@ int ehm_problem_update_blocks(ehm_problem* P, int32_t first, int32_t count, cons
     if (!img3.empty())
         HIP_TRY(hipMemcpy(P->wr3.as<double>() + (size_t)first * mpad * 64, img3.data(),
                           img3.size() * 8, hipMemcpyHostToDevice), EHM_E_HIP);
+    if (P->dp.nd0 < n) {
+        // the image without the eliminated columns; a block that does not have the shape the
+        // handle was created with (a row with two of those columns) switches the elimination off
+        // for the whole handle -- every kernel then reads the full image again
+        const size_t tot4 = (size_t)P->dp.tot4;
+        std::vector<double> img4((size_t)count * tot4);
+        bool ok = true;
+        for (int k = 0; k < count && ok; ++k)
+            ok = elim_image(G + (size_t)k * m * n, S + (size_t)k * m * p, m, n, p, lda, P->dp.nd0,
+                            P->dp.LE4, img4.data() + (size_t)k * tot4, tot4);
+        if (ok)
+            HIP_TRY(hipMemcpy(P->wc4.as<double>() + (size_t)first * tot4, img4.data(),
+                              img4.size() * 8, hipMemcpyHostToDevice), EHM_E_HIP);
+        else
+            elim_off(P);
+    }
     return EHM_OK;
 }
 
@@ -900,6 +1042,7 @@ int ehm_problem_destroy(ehm_problem* P) {
     P->active_run = nullptr;
     P->consts.release();
     P->wc2.release();
+    P->wc4.release();
     P->wr3.release();
     P->quad.release();
     P->seg.release();
@@ -974,6 +1117,7 @@ int ehm_problem_set_quadratic(ehm_problem* P, const double* H, const double* F, 
     P->dp.c1q = P->dp.Cq + nC;
     P->dp.c0q = P->dp.c1q + n1;
     P->quadratic = true;
+    elim_off(P);        // the Hessian couples the columns: nothing is eliminated
     // shared-block kernels with the quadratic block when an instance holds the largest problem
     // (the suboptimality test), else the one-wavefront kernels
     P->k2q_ok = k2_pick(n + p + 1, lp_slots(P->dp.m, p + 3), true) != nullptr;
@@ -2327,8 +2471,9 @@ static int persistent_run(ehm_tree* T, long long max_pops = 0) {
         int n_d, ne_d, n_e, ne_e;
         kind_dims(P->dp, LP_SLACK, n_d, ne_d);
         kind_dims(P->dp, LP_POINT, n_e, ne_e);
-        const K2Api* ad = k2_pick(n_d, lp_slots(P->dp.m, ne_d), false);
-        const K2Api* ae = k2_pick(n_e, lp_slots(P->dp.m, ne_e), false);
+        const int nE = P->dp.n - P->dp.nd0;
+        const K2Api* ad = k2_pick(n_d - nE, lp_slots(P->dp.m, ne_d), false);
+        const K2Api* ae = k2_pick(n_e - nE, lp_slots(P->dp.m, ne_e), false);
         const int slots = std::max(lp_slots(P->dp.m, ne_d), lp_slots(P->dp.m, ne_e));
         if (ad && ae && ae->np < ad->np) {
             for (kp_getter g : g_kp_getters) {
@@ -2379,9 +2524,10 @@ static int persistent_run(ehm_tree* T, long long max_pops = 0) {
         }
     }
     const long long waves = (long long)cfg.L.grid * (cfg.L.threads / 64);
-    // (+ limit / 2: a node whose midpoint is being solved elsewhere is put back, at most once)
-    const long long n_slots = T->limit + T->limit / 2 + waves + 64;
-    if (n_slots > 0x7fffffffLL || T->limit > 0x7fffffffLL)
+    // (2 x limit: every node is queued once and may be put back once -- its midpoint was being
+    // solved elsewhere; node ids stay below the put-back mark EHM_REQUEUED)
+    const long long n_slots = 2 * T->limit + waves + 64;
+    if (n_slots > 0x7fffffffLL || T->limit >= (long long)EHM_REQUEUED)
         return fail(EHM_E_INVALID, "node pool too large for the persistent engine");
     if ((rc = P->pq_slots.ensure((size_t)n_slots * 4))) return rc;
     if ((rc = P->pq_ctl.ensure(sizeof(PersistCtl)))) return rc;

@@ -23,6 +23,18 @@ struct DevProblem {
     // so that  G z - S psi <= w + S R0  with  psi = theta - R0  (ehm_ipm2.h).
     const double* Wc2;  // [n_delta][ncw2][lda2]
     int lda2, ncw2;
+    // shared-block kernels (ehm_ipm2.h): the LDS image WITHOUT the eliminated z-columns
+    // [nd0, n) -- the trailing range of which every MPC row holds at most one entry (the epigraph
+    // variables of an infinity-norm cost); nd0 = n where there is no such range (and always for
+    // quadratic costs).  Per commutation, column stride lda4:
+    //   [ G_D (nd0) | -S (p) | -1 | 0 | aE ]   (ncw4 = nd0 + p + 3; aE[i] = the entry of row i in
+    //                                           its eliminated column, 0 where it has none)
+    // followed by  eval[nE][LE4] (doubles), erow[nE][LE4], eidx[m] (int32): the rows of every
+    // eliminated column (0-padded) and the eliminated column of every row.  tot4 = doubles per
+    // commutation (even).
+    const double* Wc4;  // [n_delta][tot4]
+    int lda4, ncw4, tot4;
+    int nd0, LE4;
     int wc_lds;         // shared-block kernels: 1 = w and c of the commutation sit behind Wc in LDS,
                         // 0 = they are read from device memory (set per launch: K2Launch::wc_lds)
     // wide kernels (ehm_k3.hip, LPs with more than 32 columns): the same block row-major,

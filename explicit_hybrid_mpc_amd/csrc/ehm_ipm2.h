@@ -19,6 +19,22 @@
 // variables, and Newton's method is affine invariant (checked in oracle/ipm_numpy.py terms:
 // identical iteration counts, optimal values equal to 1e-12).
 //
+// Round 4 -- ELIMINATED COLUMNS (oracle/schur_numpy.py).  The z-columns
+// of an infinity-norm MPC law end with its epigraph variables, and every MPC row holds at most
+// one of them: on that trailing range E the normal matrix of the MPC rows is DIAGONAL.  The
+// solver eliminates E from the Newton system exactly (Schur complement of a positive definite
+// matrix; the dense extra rows are carried along as an augmented unknown, so every term that is
+// added is positive semidefinite) and factorises what is left: 15 instead of 25 columns for the
+// suboptimality-test LP of config 2, 10 instead of 20 for its midpoint LP.  The iterates are the
+// same to rounding (same iteration counts on every LP of the tests).  With the reduced system at
+// <= 16 columns the normal matrix of the MPC rows is ONE 16x16 tile of v_mfma_f64_16x16x4_f64 and
+// the Schur update three more instructions of the same accumulation.
+//   LP columns, INTERNAL order (what W.c / W.x / W.xb / W.t and the extra rows X use):
+//       [ z_D (nd0) | beta (p) | t or tau ]  = the nr columns that are factorised,
+//       [ z_E (nE) ]                           behind them (zcol() maps a z index).
+//   The workgroup's LDS image (DevProblem::Wc4) holds  [G_D | -S | -1 | 0 | aE]  and the tables
+//   of E: aE[i] / eidx[i] = entry and E-column of row i, erow / eval[e][k] = the rows of column e.
+//
 // Reference arithmetic replaced: the `Problem.solve(solver=MOSEK)` call sites of
 // lib/oracle.py:131,134,166,169,203,276,305,350.
 // NO include guard: one inclusion per column capacity (see EHM2_NS below; ehm_kp.hip has two).
@@ -196,19 +212,31 @@ __device__ __forceinline__ double frcp(double x) {
 // are, in device memory (P.wc_lds = 0): the launcher keeps them in LDS unless the 180 doubles
 // they take at config 2 cost the workgroup a wavefront (the persistent frontier kernel's twelfth).
 struct Shared {
-    const double* Wc;   // [ncw][lda]   G | -S | -1 | 0      (LDS)
+    const double* Wc;   // [ncw4][lda]  G_D | -S | -1 | 0 | aE   (LDS), tables behind it
     const double* wv;   // [m]
-    const double* cv;   // [n]
-    int n, m, p, lda, ncw;
+    const double* cv;   // [n]   cost of the z-columns in their ORIGINAL order
+    const double* aE;   // [m]   entry of row i in ITS eliminated column (0: the row has none)
+    const double* eval; // [nE][LE]  entries of eliminated column e (0-padded)
+    const int* erow;    // [nE][LE]  their rows (0-padded)
+    const int* eidx;    // [m]   eliminated column of row i (0 where aE = 0)
+    int n, m, p, lda;
+    int nd0, nE, LE;    // z-columns [0, nd0) stay, [nd0, n) are eliminated (nE = n - nd0)
+    int colS, colOne, colZero;      // image columns of -S, of -1 and of zeros
 };
 __host__ __device__ inline size_t shared_doubles(const DevProblem& P) {
-    return (((size_t)P.ncw2 * P.lda2 + (P.wc_lds ? P.m + P.n : 0)) + 1) & ~(size_t)1;
+    return (((size_t)P.tot4 + (P.wc_lds ? P.m + P.n : 0)) + 1) & ~(size_t)1;
 }
 __device__ inline void carve_shared(Shared& S, double* base, const DevProblem& P) {
-    S.n = P.n; S.m = P.m; S.p = P.p; S.lda = P.lda2; S.ncw = P.ncw2;
+    S.n = P.n; S.m = P.m; S.p = P.p; S.lda = P.lda4;
+    S.nd0 = P.nd0; S.nE = P.n - P.nd0; S.LE = P.LE4;
+    S.colS = P.nd0; S.colOne = P.nd0 + P.p; S.colZero = P.nd0 + P.p + 1;
     S.Wc = base;
+    S.aE = base + (size_t)(P.nd0 + P.p + 2) * P.lda4;
+    S.eval = base + (size_t)P.ncw4 * P.lda4;
+    S.erow = reinterpret_cast<const int*>(S.eval + (size_t)S.nE * S.LE);
+    S.eidx = S.erow + (size_t)S.nE * S.LE;
     if (P.wc_lds) {
-        S.wv = base + (size_t)P.ncw2 * P.lda2;
+        S.wv = base + P.tot4;
         S.cv = S.wv + P.m;
     } else {
         S.wv = P.w;     // commutation 0; use_commutation() after a load_shared of another one
@@ -220,8 +248,8 @@ __device__ inline void use_commutation(Shared& S, const DevProblem& P, int d) {
 }
 // all threads of the workgroup; caller brackets it with __syncthreads()
 __device__ inline void load_shared(const DevProblem& P, int d, double* base, int tid, int nthr) {
-    const int tot = P.ncw2 * P.lda2;
-    const double* src = P.Wc2 + (size_t)d * tot;
+    const int tot = P.tot4;
+    const double* src = P.Wc4 + (size_t)d * tot;
     for (int k = tid; k < tot; k += nthr) base[k] = src[k];
     if (P.wc_lds) {
         const double* wd = P.w + (size_t)d * P.m;
@@ -233,30 +261,39 @@ __device__ inline void load_shared(const DevProblem& P, int d, double* base, int
 // Private to a wavefront.
 struct Wave {
     double* M;      // region A: scratch / NP x LDM normal matrix / packed U (see A_DOUBLES)
-    double* X;      // [n_lp][ldx] extra rows, column-major
+    double* X;      // [n_lp][ldx] extra rows, column-major (columns in the internal order)
     double* vm0;    // MROWS
     double* vm1;    // MROWS
-    double* c;      // NP objective
-    double* x;      // NP iterate
-    double* xb;     // NP best iterate
-    double* t;      // NP scratch
-    double* ub;     // NP pivot-row broadcast
+    double* c;      // n_lp objective           } internal column order:
+    double* x;      // n_lp iterate             }   [0, nr) the factorised columns,
+    double* xb;     // n_lp best iterate        }   [nr, nr + nE) the eliminated ones
+    double* t;      // n_lp scratch / solution of the last Newton system
+    double* ub;     // NP pivot-row broadcast / d of the extra rows
     double* db;     // NP original diagonal, then reciprocal pivots
     double* sc;     // 256 doubles inside A: partial column products while A holds the U factor
     int n_lp, ne, ldx, ldm, xbase;
-    int n_lin;      // LP columns j < n_lin are Wc columns j
-    int spec_col;   // Wc column of LP column n_lin (when n_lin < n_lp)
-    int n_mpc;      // LP columns j < n_mpc have entries in the MPC rows; the rest only in X
+    int nr;         // factorised columns: n_lp - nE
+    int nE;         // eliminated columns (Shared::nE, 0 where the instance has none)
+    int n_lin;      // LP columns j < n_lin are image columns j
+    int spec_col;   // image column of LP column n_lin (when n_lin < nr)
+    int n_mpc;      // LP columns j < n_mpc (<= nr) have entries in the MPC rows; [n_mpc, nr) only in X
     // simplex problems: LP columns [psi0, psi0 + npsi) are the barycentric weights beta; the
     // shared block holds -S, so on the MPC rows they act through psi = E beta
     // (E[r][q] = R[q+1][r] - R[0][r], row-major p x p in LDS).  npsi = 0 for point problems.
     const double* E;
-    double* yv;     // NP: psi-form copy of a vector / hand-off of psi-form column products
+    double* yv;     // NP + 16: psi-form copy of a vector / hand-off of psi-form column products
     int psi0, npsi;
     int nsx;        // extra rows 0..nsx-1 are the simplex rows (-beta_q <= 0, sum beta <= 1):
                     // their normal-matrix terms are added analytically, rows >= nsx densely
     double sign_floor;  // a sign-only stop must establish |optimum| >= this (near-threshold
                         // routing, EHM_ROUTE_TOL): closer calls run to full accuracy
+    // eliminated block (section 3.2b): filled every iteration by form_normal_matrix
+    double* gE;     // [nE][GS]  (A0' D0 A0)_DE, beta-form after the transform
+    double* iD;     // [nE]      1 / Delta_e
+    double* qE;     // [nE]      r_E / Delta of the current right-hand side
+    double* hX;     // [2][nE]   X_E Delta^-1 of the dense extra rows
+    double* xh;     // [2][NP]   the dense extra rows, reduced, in L D L' form
+    double* dn;     // 8: [0] l, [1] 1/delta_1, [2] 1/delta_2 of  Gh = L diag(delta) L'
 #if EHM2_QUAD
     // quadratic block: objective c'x + kap0 V(x), extra rows eq / eq+1 are
     // kap_i V(x) + a_i'x <= bq_i,  V(x) = 1/2 x'Q x + qv'x (+ v0 in the reported objective)
@@ -273,6 +310,7 @@ struct Wave {
 };
 constexpr int LDM = NP + 1;     // odd: row- and column-wise access of the square matrix are both
                                 // bank-conflict free (the factor U is kept packed, see below)
+constexpr int GS = NP + 1;      // row stride of gE: odd for the same reason
 typedef double double2v __attribute__((ext_vector_type(2)));
 
 // Packed upper-triangular factor: row k keeps its columns (k & ~1) .. NP-1 (an even start keeps
@@ -285,46 +323,59 @@ __host__ __device__ constexpr int uoff(int k) { return u_row_start(k) - (k & ~1)
 constexpr int U_SIZE = NP * (NP + 2) / 2;
 // One phase-shared region per wavefront ("A"):
 //   residuals      : lam / d r_p  at vm0 / vm1,  partial column products at A[0..512)
-//   normal matrix  : d at vm0 (read by the row loops), K-slices at A[0..768), then the square
-//                    NP x LDM matrix at A[0..)
+//   normal matrix  : d at vm0 (read by the row loops), K-slices at A[0..768) (form_blocks only,
+//                    i.e. instances with more than 16 columns), then the square NP x LDM matrix
 //   factor + solves: packed U at A[0..U_SIZE), corrector input at vm1, its partials at sc
 // vm0 and sc share [U_SIZE, U_SIZE+256); vm1 follows.  Every overwrite happens after the last
 // read of what it overwrites (same wavefront, program order).
 constexpr size_t A_MIN = (size_t)U_SIZE + 256 + MROWS;
-constexpr size_t A_SQ = ((size_t)NP * LDM < 768) ? 768 : (size_t)NP * LDM;
+constexpr size_t A_KS = (NP > 16) ? 768 : 512;
+constexpr size_t A_SQ = ((size_t)NP * LDM < A_KS) ? A_KS : (size_t)NP * LDM;
 constexpr size_t A_DOUBLES = (A_MIN < A_SQ) ? A_SQ : A_MIN;
-__host__ __device__ inline size_t wave_lp_doubles(int n_lp, int ne) {
+__host__ __device__ inline size_t wave_lp_doubles(int n_lp, int ne, int nE) {
     const size_t ldx = ne ? ((size_t)ne | 1) : 0;
+    const size_t nf = ((size_t)n_lp + 1) & ~(size_t)1;
+    const size_t nEp = ((size_t)nE + 1) & ~(size_t)1;
+    // X | c x xb t | ub db | yv | gE iD qE hX | xh dn
+    size_t tot = A_DOUBLES + (size_t)n_lp * ldx + 4 * nf + 2 * (size_t)NP + ((size_t)NP + 16) +
+                 (size_t)nE * GS + 4 * nEp + 2 * (size_t)NP + 8;
 #if EHM2_QUAD
-    return ((A_DOUBLES + (size_t)n_lp * ldx + 12 * (size_t)NP + (size_t)NP * LDM + 2) + 1) &
-           ~(size_t)1;
-#else
-    return ((A_DOUBLES + (size_t)n_lp * ldx + 7 * (size_t)NP) + 1) & ~(size_t)1;
+    tot += 5 * (size_t)NP + (size_t)NP * LDM + 2;
 #endif
+    return (tot + 1) & ~(size_t)1;
 }
-__device__ inline void carve_wave(Wave& W, double* base, int n_lp, int ne, int m) {
+__device__ inline void carve_wave(Wave& W, double* base, int n_lp, int ne, int m, int nE) {
     W.n_lp = n_lp;
+    W.nE = nE;
+    W.nr = n_lp - nE;
     W.ne = ne;
     W.ldm = LDM;
     W.ldx = ne ? (ne | 1) : 0;
     W.xbase = lp_xbase(m, ne);
     // an instance compiled with more slots than the LP needs keeps the extras in ITS last slot
     if (ne > 0 && W.xbase < 64 * (SLOTS - 1)) W.xbase = 64 * (SLOTS - 1);
+    const int nf = (n_lp + 1) & ~1;
+    const int nEp = (nE + 1) & ~1;
     W.M = base;
     W.vm0 = base + U_SIZE;
     W.sc = base + U_SIZE;
     W.vm1 = base + U_SIZE + 256;
     base += A_DOUBLES;
     W.X = base;   base += (size_t)n_lp * W.ldx;
-    W.c = base;   base += NP;
-    W.x = base;   base += NP;
-    W.xb = base;  base += NP;
-    W.t = base;   base += NP;
+    W.c = base;   base += nf;
+    W.x = base;   base += nf;
+    W.xb = base;  base += nf;
+    W.t = base;   base += nf;
     W.ub = base;  base += NP;
     W.db = base;  base += NP;
-    W.yv = base;
+    W.yv = base;  base += NP + 16;
+    W.gE = base;  base += (size_t)nE * GS;
+    W.iD = base;  base += nEp;
+    W.qE = base;  base += nEp;
+    W.hX = base;  base += 2 * nEp;
+    W.xh = base;  base += 2 * NP;
+    W.dn = base;  base += 8;
 #if EHM2_QUAD
-    base += NP;
     W.qv = base;  base += NP;
     W.a1 = base;  base += NP;
     W.a2 = base;  base += NP;
@@ -336,9 +387,14 @@ __device__ inline void carve_wave(Wave& W, double* base, int n_lp, int ne, int m
     W.kap0 = W.kap1 = W.kap2 = W.v0 = W.bq1 = W.bq2 = 0.0;
 #endif
     W.E = nullptr;
-    W.psi0 = n_lp;
+    W.psi0 = W.nr;
     W.npsi = 0;
     W.nsx = 0;
+}
+// internal index of the z-column with ORIGINAL index j (see the header: eliminated columns
+// sit behind the factorised ones)
+__device__ __forceinline__ int zcol(const Wave& W, const Shared& S, int j) {
+    return (j < S.nd0) ? j : (W.nr + j - S.nd0);
 }
 
 __device__ __forceinline__ int wc_col(const Wave& W, int j) {
@@ -385,11 +441,11 @@ struct RowMap {
 };
 __device__ __forceinline__ void make_rowmap(RowMap& rm, const Shared& S, const Wave& W, int lane) {
     rm.lane = lane;
-    const int zero_off = (S.ncw - 1) * S.lda;
+    const int zero_off = S.colZero * S.lda;
 #pragma unroll
     for (int sl = 0; sl < SLOTS - 1; ++sl) rm.valid[sl] = (lane + 64 * sl) < S.m;
     const int i = lane + 64 * (SLOTS - 1);
-    const bool spec = W.n_lin < W.n_lp;
+    const bool spec = W.n_lin < W.nr;
     rm.last_extra = false;
     if (i < S.m) {
         rm.valid[SLOTS - 1] = true;
@@ -413,7 +469,7 @@ __device__ __forceinline__ void make_rowmap(RowMap& rm, const Shared& S, const W
 // psi-form copy of an LP vector: yv = T v with T = blockdiag(I, E, I)
 __device__ __forceinline__ void to_psi(const Wave& W, const double* v, int lane) {
     if (lane < NP) {
-        double y = (lane < W.n_lp) ? v[lane] : 0.0;
+        double y = (lane < W.nr) ? v[lane] : 0.0;
         const int r = lane - W.psi0;
         if (r >= 0 && r < W.npsi) {
             y = 0.0;
@@ -469,12 +525,31 @@ __device__ __forceinline__ void rows_times(const Shared& S, const Wave& W, int l
         pa += lda;
         pb += str;
     }
-    if (W.n_lin < W.n_lp) {
+    if (W.n_lin < W.nr) {
         const double vj = v[W.n_lin];       // the special column is not a beta column
         const double* ps = S.Wc + (size_t)W.spec_col * lda + rm.lane;
 #pragma unroll
         for (int sl = 0; sl < SLOTS - 1; ++sl) out[sl] = fma(ps[64 * sl], vj, out[sl]);
         out[SLOTS - 1] = fma(*rm.last_spec, vj, out[SLOTS - 1]);
+    }
+    if (W.nE > 0) {
+        // eliminated columns: an MPC row holds at most one of them (gather), the dense extra
+        // rows hold all of them
+        const double* vE = v + W.nr;
+#pragma unroll
+        for (int sl = 0; sl < SLOTS; ++sl) {
+            const int i = rm.lane + 64 * sl;
+            const int ic = (i < S.m) ? i : 0;
+            const double a = (i < S.m) ? S.aE[ic] : 0.0;
+            out[sl] = fma(a, vE[S.eidx[ic]], out[sl]);
+        }
+        const int xe = rm.lane + 64 * (SLOTS - 1) - W.xbase;
+        if (rm.last_extra && xe >= W.nsx) {
+            const double* xr = W.X + (size_t)W.nr * W.ldx + xe;
+            double a = 0.0;
+            for (int e = 0; e < W.nE; ++e) a = fma(xr[(size_t)e * W.ldx], vE[e], a);
+            out[SLOTS - 1] += a;
+        }
     }
 #pragma unroll
     for (int sl = 0; sl < SLOTS; ++sl) out[sl] = rm.valid[sl] ? out[sl] : 0.0;
@@ -484,20 +559,20 @@ __device__ __forceinline__ void rows_times(const Shared& S, const Wave& W, int l
 // columns beyond n_lp point at the zero column.
 __device__ __forceinline__ void block_cols_mpc(const Shared& S, const Wave& W, int cb,
                                                const double* (&pc)[4]) {
-    const double* zero = S.Wc + (size_t)(S.ncw - 1) * S.lda;
+    const double* zero = S.Wc + (size_t)S.colZero * S.lda;
 #pragma unroll
     for (int q = 0; q < 4; ++q) {
         const int j = 4 * cb + q;
-        pc[q] = (j < W.n_lp) ? (S.Wc + (size_t)wc_col(W, j) * S.lda) : zero;
+        pc[q] = (j < W.nr) ? (S.Wc + (size_t)wc_col(W, j) * S.lda) : zero;
     }
 }
 __device__ __forceinline__ void block_cols_ext(const Shared& S, const Wave& W, int cb,
                                                const double* (&px)[4]) {
-    const double* zero = S.Wc + (size_t)(S.ncw - 1) * S.lda;
+    const double* zero = S.Wc + (size_t)S.colZero * S.lda;
 #pragma unroll
     for (int q = 0; q < 4; ++q) {
         const int j = 4 * cb + q;
-        px[q] = (j < W.n_lp && W.ne > 0) ? (W.X + (size_t)j * W.ldx) : zero;
+        px[q] = (j < W.nr && W.ne > 0) ? (W.X + (size_t)j * W.ldx) : zero;
     }
 }
 
@@ -517,6 +592,18 @@ __device__ __forceinline__ void cols_times(const Shared& S, const Wave& W, const
             const double a = xl[e];
             ex0 = fma(a, u0[W.xbase + e], ex0);
             if (TWO) ex1 = fma(a, u1[W.xbase + e], ex1);
+        }
+    }
+    // the eliminated columns: lane nr + e sums over the (few) rows of column e
+    const int ecol = lane - W.nr;
+    const bool elane = W.nE > 0 && ecol >= 0 && ecol < W.nE;
+    if (W.nE > 0) {
+        const int eb = (elane ? ecol : 0) * S.LE;
+        for (int k = 0; k < S.LE; ++k) {
+            const int i = S.erow[eb + k];
+            const double a = S.eval[eb + k];
+            ex0 = elane ? fma(a, u0[i], ex0) : ex0;
+            if (TWO) ex1 = elane ? fma(a, u1[i], ex1) : ex1;
         }
     }
     const int cb = pin(lane % nb);
@@ -599,8 +686,9 @@ __device__ __forceinline__ void cols_times(const Shared& S, const Wave& W, const
         }
         wsync();
     }
-    r0 += ex0;
-    r1 += ex1;
+    // (lanes of eliminated columns hold no block sums: whatever they read above is discarded)
+    r0 = elane ? ex0 : (r0 + ex0);
+    r1 = elane ? ex1 : (r1 + ex1);
 }
 
 // M = A^T diag(dvec) A into W.M (full symmetric), dvec an m-vector in LDS.
@@ -699,35 +787,68 @@ __device__ __forceinline__ void form_blocks(const Shared& S, const Wave& W, cons
 // entries, as 16x16 output tiles of v_mfma_f64_16x16x4_f64 (K = 4 rows per instruction).
 // Operand layout (one f64 per lane): A[i = lane%16][k = lane/16] = d_k W[k][16I + i],
 // B[k = lane/16][j = lane%16] = W[k][16J + j]; result D[(lane>>4) + 4r][lane&15], r = 0..3.
-// Two column panels (<= 32 columns) give the tiles (0,0), (1,0), (1,1); the matrix pipe is
-// otherwise idle in this kernel while the vector pipe and the LDS are the bottleneck, and a
-// K-step needs 3 LDS loads and 2 multiplies instead of 9 loads and 20 vector FMAs per row.
-// FP64 MFMA runs at the vector-FMA rate on MI355X and the tiles compute both triangles: this
-// is an off-load, not a flop saving.
+// With the eliminated columns gone the suboptimality-test LP of config 2 has 14 such columns and
+// its midpoint LP 10: ONE tile, 2 LDS loads + 1 multiply + 1 matrix instruction per 4 rows, where
+// the vector form (form_blocks) issues 9 loads and 20 FMAs per row and lane.  The matrix pipe is
+// otherwise idle in this kernel and works beside the vector instructions of the other wavefronts.
+// Two column panels (<= 32 columns) give the tiles (0,0), (1,0), (1,1); FP64 MFMA runs at the
+// vector-FMA rate on MI355X and those tiles compute both triangles, so beyond 16 columns the
+// vector form is used (measured equal or better there in round 2).
+// The Schur update of the eliminated block rides on the same accumulators:
+//     M <- M - G Delta^-1 G'    =  sum_e (-g_e / Delta_e) g_e'      (K = 4 columns e per instruction)
 typedef double double4v __attribute__((ext_vector_type(4)));
 __device__ __forceinline__ void form_mfma(const Shared& S, const Wave& W, const double* dvec,
                                           int lane, int ncols) {
     const int li = lane & 15, lk = lane >> 4;
-    const bool two = ncols > 16;
-    const double* zero = S.Wc + (size_t)(S.ncw - 1) * S.lda;
+    const bool two = (NP > 16) && ncols > 16;
+    const double* zero = S.Wc + (size_t)S.colZero * S.lda;
     const int j0 = li, j1 = 16 + li;
     const double* p0 = (j0 < ncols) ? (S.Wc + (size_t)wc_col(W, j0) * S.lda) : zero;
     const double* p1 = (j1 < ncols) ? (S.Wc + (size_t)wc_col(W, j1) * S.lda) : zero;
     double4v c00 = {0.0, 0.0, 0.0, 0.0}, c10 = {0.0, 0.0, 0.0, 0.0}, c11 = {0.0, 0.0, 0.0, 0.0};
     const int m = S.m;
-    for (int i0 = 0; i0 < m; i0 += 4) {
-        const int i = i0 + lk;
-        const bool in = i < m;
-        const int ic = in ? i : (m - 1);
-        const double d = in ? lds1(dvec + ic) : 0.0;
-        const double w0 = lds1(p0 + ic);
+    const int m4 = m & ~3;
+    p0 += lk;
+    p1 += lk;
+    const double* pd = dvec + lk;
+    for (int i0 = 0; i0 < m4; i0 += 4) {
+        const double d = lds1(pd + i0);
+        const double w0 = lds1(p0 + i0);
         const double a0 = w0 * d;
         c00 = __builtin_amdgcn_mfma_f64_16x16x4f64(a0, w0, c00, 0, 0, 0);
         if (two) {      // wave-uniform
+            const double w1 = lds1(p1 + i0);
+            const double a1 = w1 * d;
+            c10 = __builtin_amdgcn_mfma_f64_16x16x4f64(a1, w0, c10, 0, 0, 0);
+            c11 = __builtin_amdgcn_mfma_f64_16x16x4f64(a1, w1, c11, 0, 0, 0);
+        }
+    }
+    if (m4 < m) {       // the last 1..3 rows
+        const bool in = m4 + lk < m;
+        const int ic = in ? m4 : (m - 1 - lk);
+        const double d = in ? lds1(pd + ic) : 0.0;
+        const double w0 = lds1(p0 + ic);
+        const double a0 = w0 * d;
+        c00 = __builtin_amdgcn_mfma_f64_16x16x4f64(a0, w0, c00, 0, 0, 0);
+        if (two) {
             const double w1 = lds1(p1 + ic);
             const double a1 = w1 * d;
             c10 = __builtin_amdgcn_mfma_f64_16x16x4f64(a1, w0, c10, 0, 0, 0);
             c11 = __builtin_amdgcn_mfma_f64_16x16x4f64(a1, w1, c11, 0, 0, 0);
+        }
+    }
+    // Schur update of the eliminated block (gE, iD: this iteration's, psi-form)
+    for (int e0 = 0; e0 < W.nE; e0 += 4) {
+        const int e = e0 + lk;
+        const bool in = e < W.nE;
+        const int ec = in ? e : 0;
+        const double id = W.iD[ec];
+        const double g0 = (in && j0 < NP) ? W.gE[ec * GS + (j0 < NP ? j0 : 0)] : 0.0;
+        c00 = __builtin_amdgcn_mfma_f64_16x16x4f64(-g0 * id, g0, c00, 0, 0, 0);
+        if (two) {
+            const double g1 = (in && j1 < NP) ? W.gE[ec * GS + (j1 < NP ? j1 : 0)] : 0.0;
+            c10 = __builtin_amdgcn_mfma_f64_16x16x4f64(-g1 * id, g0, c10, 0, 0, 0);
+            c11 = __builtin_amdgcn_mfma_f64_16x16x4f64(-g1 * id, g1, c11, 0, 0, 0);
         }
     }
     wsync();
@@ -746,35 +867,96 @@ __device__ __forceinline__ void form_mfma(const Shared& S, const Wave& W, const 
     }
 }
 
+// G = (A0' D0 A0)_DE and Delta of the eliminated block, psi-form (before the transform):
+//     g_re = sum_{i in rows(e)} d_i a_ir a_ie ,   Delta_e = sum_{i in rows(e)} d_i a_ie^2 .
+// Task (r, e) = one lane; a column e has at most Shared::LE rows, listed in erow / eval.
+__device__ __forceinline__ void form_eliminated(const Shared& S, const Wave& W, const double* dvec,
+                                                int lane) {
+    constexpr int NPG = (NP > 16) ? 32 : 16;        // tasks per eliminated column
+    const double* zero = S.Wc + (size_t)S.colZero * S.lda;
+    const int ntask = W.nE * NPG;
+    for (int t0 = 0; t0 < ntask; t0 += 64) {
+        const int t = t0 + lane;
+        const int r = t & (NPG - 1);
+        const int e = t / NPG;
+        const bool in = t < ntask;
+        const double* col = (in && r < W.n_mpc) ? (S.Wc + (size_t)wc_col(W, r) * S.lda) : zero;
+        const int eb = (in ? e : 0) * S.LE;
+        double g = 0.0, dl = 0.0;
+        for (int k = 0; k < S.LE; ++k) {
+            const int i = S.erow[eb + k];
+            const double ev = S.eval[eb + k];
+            const double de = lds1(dvec + i) * ev;
+            g = fma(de, lds1(col + i), g);
+            dl = fma(de, ev, dl);
+        }
+        if (in && r < NP) W.gE[e * GS + r] = g;
+        if (in && r == 0) W.iD[e] = frcp(dl);       // Delta_e > 0: d > 0, the column is not empty
+    }
+    wsync();
+}
+
+// M <- M - G Delta^-1 G' on the square matrix in LDS (the vector form's counterpart of the
+// matrix-core accumulation in form_mfma): task = (row j, 4-column block).
+__device__ __forceinline__ void schur_lds(const Wave& W, int lane) {
+    constexpr int nb = NP / 4;
+    for (int t = lane; t < NP * nb; t += 64) {
+        const int j = t / nb, cb = t - j * nb;
+        double acc[4] = {0.0, 0.0, 0.0, 0.0};
+        for (int e = 0; e < W.nE; ++e) {
+            const double gj = W.gE[e * GS + j] * W.iD[e];
+#pragma unroll
+            for (int q = 0; q < 4; ++q) acc[q] = fma(gj, W.gE[e * GS + 4 * cb + q], acc[q]);
+        }
+#pragma unroll
+        for (int q = 0; q < 4; ++q) W.M[j * LDM + 4 * cb + q] -= acc[q];
+    }
+    wsync();
+}
+
+// Sum over the lanes 0..15 (one DPP row), returned to every lane; lanes >= 16 must pass 0 --
+// 14 instructions where the wave reduction takes 22.
+__device__ __forceinline__ double row16_sum(double v) {
+    v += dpp_move<0x111, 0xf>(0.0, v);
+    v += dpp_move<0x112, 0xf>(0.0, v);
+    v += dpp_move<0x114, 0xf>(0.0, v);
+    v += dpp_move<0x118, 0xf>(0.0, v);
+    return readlane_d(v, 15);
+}
+// sum of v over the lanes [0, cnt) (0 elsewhere): one DPP row when they fit, else the wave
+__device__ __forceinline__ double few_sum(double v, int cnt) {
+    return (cnt <= 16) ? row16_sum(v) : wave_sum(v);
+}
+
 // dext[e] = d of extra row e (the square matrix overwrites dvec before the extras are added)
 __device__ inline void form_normal_matrix(const Shared& S, const Wave& W, const double* dvec,
                                           const double* dext, int lane) {
-#if EHM2_FORM_MFMA
-    // columns >= n_mpc are zero columns for the tiles; what they leave in W.M is zero too.
-    // A single panel (n_mpc <= 16) writes rows / columns 0..15 only.
-    const int nbA = (W.n_mpc > 16 || NP <= 16) ? (NP >> 2) : 4;
-    form_mfma(S, W, dvec, lane, W.n_mpc);
-#else
-    const int nbA = (W.n_mpc + 3) >> 2;
-    const int TA = nbA * (nbA + 1) / 2;
-    const int ks = 64 / TA;     // TA <= 36
-    if (ks >= 4) form_blocks<4>(S, W, dvec, lane, nbA, TA);
-    else if (ks == 3) form_blocks<3>(S, W, dvec, lane, nbA, TA);
-    else if (ks == 2) form_blocks<2>(S, W, dvec, lane, nbA, TA);
-    else form_blocks<1>(S, W, dvec, lane, nbA, TA);
-#endif
+    if (W.nE > 0) form_eliminated(S, W, dvec, lane);
+    int nbA;
+    if (NP <= 16 || W.n_mpc <= 16 || EHM2_FORM_MFMA) {
+        // columns >= n_mpc are zero columns for the tiles; what they leave in W.M is zero too.
+        // A single panel (n_mpc <= 16) writes rows / columns 0..15 only.
+        nbA = (W.n_mpc > 16 || NP <= 16) ? (NP >> 2) : 4;
+        form_mfma(S, W, dvec, lane, W.n_mpc);
+    } else {
+        nbA = (W.n_mpc + 3) >> 2;
+        const int TA = nbA * (nbA + 1) / 2;
+        const int ks = 64 / TA;     // TA <= 36
+        if (ks >= 4) form_blocks<4>(S, W, dvec, lane, nbA, TA);
+        else if (ks == 3) form_blocks<3>(S, W, dvec, lane, nbA, TA);
+        else if (ks == 2) form_blocks<2>(S, W, dvec, lane, nbA, TA);
+        else form_blocks<1>(S, W, dvec, lane, nbA, TA);
+    }
     // rows / columns 4*nbA .. NP-1 (no entries in the MPC rows): zero
     const int c0 = 4 * nbA;
     if (c0 < NP) {
         const int nrest = NP - c0;
         for (int k = lane; k < nrest * LDM; k += 64) W.M[c0 * LDM + k] = 0.0;
-        {   // nrest <= 7 (the smallest instance that holds n_lp columns is picked)
-            const int c = lane & 7;
-            if (c < nrest)
-                for (int r = lane >> 3; r < c0; r += 8) W.M[r * LDM + c0 + c] = 0.0;
-        }
+        for (int c = lane & 15; c < nrest; c += 16)
+            for (int r = lane >> 4; r < c0; r += 4) W.M[r * LDM + c0 + c] = 0.0;
     }
     wsync();
+    if (NP > 16 && W.nE > 0 && !(W.n_mpc <= 16 || EHM2_FORM_MFMA)) schur_lds(W, lane);
     // psi-form -> beta-form of the weight block:  M <- T^T M T,  T = blockdiag(I, E, I)
     if (W.npsi > 0) {
         const int np_ = W.npsi, p0 = W.psi0;
@@ -805,6 +987,32 @@ __device__ inline void form_normal_matrix(const Shared& S, const Wave& W, const 
 #pragma unroll
             for (int q = 0; q < 8; ++q)
                 if (q < np_) mc[q * LDM] = tmp[q];
+        }
+        // the eliminated block's rows of the weights:  G_beta = E^T G_psi  (task = (e, q);
+        // nE * npsi <= 256: checked where the problem is created)
+        {
+            const int nt = W.nE * np_;
+            double res[4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const int t = lane + 64 * u;
+                double gq = 0.0;
+                if (t < nt) {
+                    const int e = t / np_, q = t - e * np_;
+                    const double* gr = W.gE + e * GS + p0;
+                    for (int r = 0; r < np_; ++r) gq = fma(W.E[r * np_ + q], gr[r], gq);
+                }
+                res[u] = gq;
+            }
+            wsync();
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const int t = lane + 64 * u;
+                if (t < nt) {
+                    const int e = t / np_, q = t - e * np_;
+                    W.gE[e * GS + p0 + q] = res[u];
+                }
+            }
         }
         wsync();
         // the simplex rows  -beta_q <= 0,  sum beta <= 1  (extra rows 0..npsi): their term
@@ -868,32 +1076,171 @@ __device__ __forceinline__ void lu_factor(double (&row)[NP], const Wave& W, int 
     wsync();
 }
 
-// Solve (LU) x = rhs; lane j passes rhs_j and 1/U[j][j], receives x_j; W.t[0..NP) gets x too.
-// The running right-hand side of a finished lane may turn into garbage: y_k / x_k are taken
-// from the broadcast and parked in LDS by lane 0.
+// bv <- bv - a * s in the lanes of `mask` only (s: wave-uniform, in an SGPR pair).  The two
+// triangular solves below run over the lanes of one register row; the lanes whose component is
+// already final (forward) or not yet needed (backward) must not be touched, and the mask of
+// step k is a compile-time constant: one scalar instruction sets EXEC, none compares lane ids.
+// (s_nop: a VALU result must not be read by v_readlane in the next cycle, and the hazard
+// recogniser does not look into an asm block.)
+__device__ __forceinline__ void masked_fnma(double& bv, double a, double s, unsigned long long mask) {
+    unsigned long long sv;
+    asm volatile("s_and_saveexec_b64 %[sv], %[m]\n\t"
+                 "v_fma_f64 %[bv], -%[a], %[s], %[bv]\n\t"
+                 "s_mov_b64 exec, %[sv]\n\t"
+                 "s_nop 0"
+                 : [bv] "+v"(bv), [sv] "=&s"(sv)
+                 : [a] "v"(a), [s] "s"(s), [m] "s"(mask)
+                 : "scc");
+}
+
+// Solve (LU) x = rhs; lane j passes rhs_j and 1/U[j][j], receives x_j; W.t[0..nr) gets x too.
+// Forward: L (the multipliers row[k], k < lane) with the right-hand side in a register row; step k
+// broadcasts y_k by v_readlane and updates the lanes > k.  Backward: U row `lane` from LDS, step k
+// broadcasts x_k and updates the lanes < k.  No LDS writes, no per-step lane compares: round 3
+// parked every y_k / x_k in LDS through lane 0 (9 instructions a step; 3 now).
 __device__ __forceinline__ double lu_solve(const double (&row)[NP], const Wave& W, double rinv,
                                            double rhs, int lane) {
     double bv = rhs;
 #pragma unroll
-    for (int k = 0; k < NP; ++k) {
+    for (int k = 0; k < NP - 1; ++k) {
         const double yk = readlane_d(bv, k);
-        if (lane == 0) W.ub[k] = yk;
-        bv = fma(-row[k], yk, bv);
-        if ((k & 7) == 7) __builtin_amdgcn_sched_barrier(0);
+        masked_fnma(bv, row[k], yk, ~((2ull << k) - 1ull));
     }
-    wsync();
     const int jl = (lane < NP) ? lane : (NP - 1);
-    bv = W.ub[jl];
     const double* urow = W.M + uoff(jl);
 #pragma unroll
-    for (int k = NP - 1; k >= 0; --k) {
+    for (int k = NP - 1; k >= 1; --k) {
         const double xk = readlane_d(bv * rinv, k);
-        if (lane == 0) W.t[k] = xk;
-        bv = fma(-urow[k], xk, bv);
-        if ((k & 7) == 0) __builtin_amdgcn_sched_barrier(0);
+        masked_fnma(bv, urow[k], xk, (1ull << k) - 1ull);
+    }
+    const double x = bv * rinv;
+    if (lane < W.nr) W.t[lane] = x;
+    wsync();
+    return x;
+}
+
+// The dense extra rows (suboptimality rows, phase-one bound: extra rows nsx .. ne-1, at most two)
+// in the reduced system (header, oracle/schur_numpy.py):
+//     hX = X_E Delta^-1 ,  Xh = X_D - hX G' ,  Gh = diag(1 / d_r) + hX X_E' = L diag(delta) L' ,
+//     xh = L^-1 Xh ,  dn = (l, 1/delta_1, 1/delta_2)
+// after which the factorised matrix is  S0 + sum_r xh_r xh_r' / delta_r.  Without eliminated
+// columns this is the rank-one term d_r x_r x_r' of the dense row itself.
+__device__ __forceinline__ void dense_prep(const Shared& S, const Wave& W, const double* dext,
+                                           int lane) {
+    const int kd = W.ne - W.nsx;
+    if (kd <= 0) return;
+    const int e0 = W.nsx;
+    const int nEp = (W.nE + 1) & ~1;
+    const bool two = kd > 1;
+    double g11 = frcp(dext[e0]);
+    double g22 = two ? frcp(dext[e0 + 1]) : 1.0;
+    double g12 = 0.0;
+    double x0 = 0.0, x1 = 0.0;
+    if (lane < W.nr) {
+        x0 = W.X[(size_t)lane * W.ldx + e0];
+        x1 = two ? W.X[(size_t)lane * W.ldx + e0 + 1] : 0.0;
+    }
+    if (W.nE > 0) {
+        const bool el = lane < W.nE;
+        const double* xr = W.X + (size_t)(W.nr + (el ? lane : 0)) * W.ldx + e0;
+        const double xe0 = el ? xr[0] : 0.0;
+        const double xe1 = (el && two) ? xr[1] : 0.0;
+        const double id = el ? W.iD[el ? lane : 0] : 0.0;
+        const double h0 = xe0 * id, h1 = xe1 * id;
+        if (el) {
+            W.hX[lane] = h0;
+            W.hX[nEp + lane] = h1;
+        }
+        wsync();
+        if (lane < W.nr)
+            for (int e = 0; e < W.nE; ++e) {
+                const double g = W.gE[e * GS + lane];
+                x0 = fma(-W.hX[e], g, x0);
+                x1 = fma(-W.hX[nEp + e], g, x1);
+            }
+        g11 += few_sum(h0 * xe0, W.nE);
+        if (two) {
+            g12 = few_sum(h0 * xe1, W.nE);
+            g22 += few_sum(h1 * xe1, W.nE);
+        }
+    }
+    const double i1 = frcp(g11);
+    const double l = g12 * i1;
+    const double i2 = two ? frcp(fma(-l, g12, g22)) : 0.0;
+    x1 = fma(-l, x0, x1);
+    if (lane < NP) {
+        W.xh[lane] = x0;
+        W.xh[NP + lane] = two ? x1 : 0.0;
+    }
+    if (lane == 0) {
+        W.dn[0] = l;
+        W.dn[1] = i1;
+        W.dn[2] = i2;
     }
     wsync();
-    return W.t[jl];
+}
+
+// The Newton system of one iteration, solved through the reduction: lane j < n_lp passes entry j
+// of the right-hand side (internal column order) and receives entry j of the solution, W.t gets
+// all of it.  `row` / rinv: the factor of the reduced matrix (lu_factor).
+__device__ __forceinline__ double solve_full(const double (&row)[NP], const Shared& S,
+                                             const Wave& W, double rinv, double rhs, int lane) {
+    const int kd = W.ne - W.nsx;
+    const bool two = kd > 1;
+    const int e = lane - W.nr;
+    const bool el = W.nE > 0 && e >= 0 && e < W.nE;
+    const int jl = (lane < NP) ? lane : (NP - 1);
+    double rho0 = 0.0, rho1 = 0.0;
+    double rr = (lane < W.nr) ? rhs : 0.0;
+    if (W.nE > 0) {
+        if (el) W.qE[e] = rhs * W.iD[e];
+        wsync();
+        if (lane < W.nr)
+            for (int e2 = 0; e2 < W.nE; ++e2) rr = fma(-W.gE[e2 * GS + lane], W.qE[e2], rr);
+        if (kd > 0) {       // rho = X_E Delta^-1 r_E
+            const bool l2 = lane < W.nE;
+            const double* xr = W.X + (size_t)(W.nr + (l2 ? lane : 0)) * W.ldx + W.nsx;
+            const double q = l2 ? W.qE[l2 ? lane : 0] : 0.0;
+            rho0 = few_sum(l2 ? xr[0] * q : 0.0, W.nE);
+            if (two) rho1 = few_sum(l2 ? xr[1] * q : 0.0, W.nE);
+        }
+    }
+    double l = 0.0, i1 = 0.0, i2 = 0.0;
+    if (kd > 0) {
+        l = W.dn[0];
+        i1 = W.dn[1];
+        i2 = W.dn[2];
+        rho1 = fma(-l, rho0, rho1);                     // L^-1 rho
+        rr = fma(-W.xh[jl], i1 * rho0, rr);
+        rr = fma(-W.xh[NP + jl], i2 * rho1, rr);
+    }
+    const double xD = lu_solve(row, W, rinv, rr, lane);
+    double y0 = 0.0, y1 = 0.0;
+    if (kd > 0) {
+        const bool lr = lane < W.nr;
+        const double v0 = few_sum(lr ? W.xh[jl] * xD : 0.0, W.nr) + rho0;
+        const double v1 = two ? (few_sum(lr ? W.xh[NP + jl] * xD : 0.0, W.nr) + rho1) : 0.0;
+        y1 = v1 * i2;
+        y0 = fma(-l, y1, v0 * i1);
+    }
+    if (W.nE > 0) {
+        double xE = 0.0;
+        if (el) {
+            double acc = rhs;
+            const double* ge = W.gE + e * GS;
+            for (int j = 0; j < W.nr; ++j) acc = fma(-ge[j], W.t[j], acc);
+            if (kd > 0) {
+                const double* xr = W.X + (size_t)(W.nr + e) * W.ldx + W.nsx;
+                acc = fma(-xr[0], y0, acc);
+                if (two) acc = fma(-xr[1], y1, acc);
+            }
+            xE = acc * W.iD[e];
+            W.t[W.nr + e] = xE;
+        }
+        wsync();
+        return el ? xE : xD;
+    }
+    return xD;
 }
 
 // ---------------------------------------------------------------------------------------
@@ -926,7 +1273,7 @@ __device__ inline IpmResult ipm_solve(const Shared& S, const Wave& W, const doub
     const double cj = (lane < n) ? W.c[lane] : 0.0;
     const double cnorm = uniform_d(1.0 + wave_max(fabs(cj)));
     step_frac = uniform_d(step_frac);
-    if (lane < NP) {
+    if (lane < n) {
         W.x[lane] = 0.0;
         W.xb[lane] = 0.0;
     }
@@ -1046,7 +1393,7 @@ __device__ inline IpmResult ipm_solve(const Shared& S, const Wave& W, const doub
             res.merit = uniform_d(merit);
             res.obj = uniform_d(pobj);
             stall = 0;
-            if (lane < NP) W.xb[lane] = W.x[lane];
+            if (lane < n) W.xb[lane] = W.x[lane];
         } else if (res.merit < const_d(EHM2_STALL_ZONE)) {
             ++stall;
         }
@@ -1067,7 +1414,7 @@ __device__ inline IpmResult ipm_solve(const Shared& S, const Wave& W, const doub
                 res.merit = merit;
                 res.margin = lo;
                 res.status = 0;
-                if (lane < NP) W.xb[lane] = W.x[lane];
+                if (lane < n) W.xb[lane] = W.x[lane];
                 wsync();
                 return res;
             }
@@ -1092,23 +1439,26 @@ __device__ inline IpmResult ipm_solve(const Shared& S, const Wave& W, const doub
         wsync();
         form_normal_matrix(S, W, W.vm0, W.ub, lane);
         lane = pin(lane0);
+        dense_prep(S, W, W.ub, lane);
+        lane = pin(lane0);
         double row[NP];
         {
             // lanes >= NP carry a copy of row NP-1; nothing they compute is ever read
-            const double* mrow = W.M + ((lane < NP) ? lane : (NP - 1)) * LDM;
+            const int jr = (lane < NP) ? lane : (NP - 1);
+            const double* mrow = W.M + jr * LDM;
 #pragma unroll
             for (int q = 0; q < NP; ++q) row[q] = mrow[q];
-            // dense extra rows (suboptimality rows, phase-one bound): rank-one terms; dg follows
-            // the diagonal (original diagonal for the dependent-pivot guard)
-            double dg = mrow[(lane < NP) ? lane : (NP - 1)];
-            for (int e = W.nsx; e < W.ne; ++e) {
-                const double xl = (lane < W.n_lp) ? W.X[(size_t)lane * W.ldx + e] : 0.0;
-                const double ce = W.ub[e] * xl;
+            // dense extra rows (suboptimality rows, phase-one bound), reduced (dense_prep): rank-one
+            // terms; dg follows the diagonal (original diagonal for the dependent-pivot guard)
+            double dg = mrow[jr];
+            for (int r = 0; r < W.ne - W.nsx; ++r) {
+                const double* xh = W.xh + r * NP;
+                const double xl = xh[jr];
+                const double ce = W.dn[1 + r] * xl;
                 dg = fma(ce, xl, dg);
 #pragma unroll
                 for (int q = 0; q < NP; ++q) {
-                    const double xq = (q < W.n_lp) ? W.X[(size_t)q * W.ldx + e] : 0.0;
-                    row[q] = fma(ce, xq, row[q]);
+                    row[q] = fma(ce, xh[q], row[q]);
                     if ((q & 3) == 3) __builtin_amdgcn_sched_barrier(0);   // register budget
                 }
             }
@@ -1138,7 +1488,7 @@ __device__ inline IpmResult ipm_solve(const Shared& S, const Wave& W, const doub
 #else
         const double rhs_aff = (lane < n) ? (-cjj - atdr) : 0.0;
 #endif
-        double dxj = lu_solve(row, W, rinv_l, rhs_aff, lane);
+        double dxj = solve_full(row, S, W, rinv_l, rhs_aff, lane);
         double adx[SLOTS];
         rows_times(S, W, lane, W.t, adx);
         double ds_a[SLOTS], dl_a[SLOTS];
@@ -1179,7 +1529,7 @@ __device__ inline IpmResult ipm_solve(const Shared& S, const Wave& W, const doub
         double atc, dummy;
         cols_times<false>(S, W, W.vm1, W.vm1, W.sc, lane, atc, dummy);
         const double rhs = (lane < n) ? (rhs_aff + atc) : 0.0;
-        dxj = lu_solve(row, W, rinv_l, rhs, lane);
+        dxj = solve_full(row, S, W, rinv_l, rhs, lane);
         rows_times(S, W, lane, W.t, adx);
         double ds[SLOTS], dl[SLOTS];
         rho_p = 0.0;
@@ -1218,7 +1568,7 @@ __device__ inline IpmResult ipm_solve(const Shared& S, const Wave& W, const doub
         // through the convergence test
         const bool conv = (res.status == 0) && (res.merit <= 1.0);
         for (int q = 0; q < S.p; ++q) {
-            const double* col = S.Wc + (size_t)(S.n + q) * S.lda + lane0;
+            const double* col = S.Wc + (size_t)(S.colS + q) * S.lda + lane0;
             double a = 0.0;
 #pragma unroll
             for (int sl = 0; sl < SLOTS; ++sl)

@@ -198,7 +198,7 @@ __global__ __launch_bounds__(EHM_K2_THREADS) void k2_simplex_batch(
                 if (iters) iters[o] = r.iters;
             }
             if (alpha) {
-                const double beta = (lane < p) ? W.xb[P.n + lane] : 0.0;
+                const double beta = (lane < p) ? W.xb[W.psi0 + lane] : 0.0;
                 const double sb = wave_sum(beta);
                 if (lane < p) alpha[o * (p + 1) + lane + 1] = beta;
                 if (lane == 0) alpha[o * (p + 1)] = 1.0 - sb;
@@ -752,14 +752,14 @@ __global__ __launch_bounds__(EHM_K2_THREADS) void k2_persist(
                 // cost of its z, raised by the safety amount (EHM_WIT_REL, ehm_dev.h)
                 const int nz = S.n;
                 double cz = 0.0, sb = 0.0;
-                for (int q = 0; q < nz; ++q) cz = fma(S.cv[q], W.xb[q], cz);
-                for (int q = 0; q < p; ++q) sb += W.xb[nz + q];
+                for (int q = 0; q < nz; ++q) cz = fma(S.cv[q], W.xb[zcol(W, S, q)], cz);
+                for (int q = 0; q < p; ++q) sb += W.xb[W.psi0 + q];
                 wsync();
                 if (lane == 0) {
                     wit[0] = fma(EHM_WIT_REL, margin, cz);
                     wit[1] = 1.0 - sb;
                 }
-                if (lane < p) wit[2 + lane] = W.xb[nz + lane];
+                if (lane < p) wit[2 + lane] = W.xb[W.psi0 + lane];
                 have_wit = true;
                 wsync();
             }
@@ -1180,7 +1180,7 @@ hipError_t set_lds(int bytes) {
 size_t wave_doubles_for(const DevProblem& P, int n_lp, int ne, int persist) {
     // (+ k2_stash_doubles: what the midpoint-first flow of k2_persist parks per node behind the
     // wavefront's workspace; the batch and sweep kernels park nothing)
-    return k2_node_doubles(P.p, P.n_u) + wave_lp_doubles(n_lp, ne) +
+    return k2_node_doubles(P.p, P.n_u) + wave_lp_doubles(n_lp, ne, P.n - P.nd0) +
            ((EHM_PERSIST_MIDFIRST && persist) ? k2_stash_doubles(P.p, P.n_u) : 0);
 }
 size_t shared_doubles_for(const DevProblem& P) { return shared_doubles(P); }

@@ -167,16 +167,19 @@ __device__ inline void quad_grad_add(const Wave& W, const DevProblem& P, int d,
 __device__ inline void assemble_point(const Shared& S, Wave& W, double* lp_base,
                                       const double* theta, bool feas, double (&b)[SLOTS],
                                       int lane, const DevProblem& P, int d) {
-    const int n = S.n, m = S.m, p = S.p;
-    carve_wave(W, lp_base, n + (feas ? 1 : 0), feas ? 1 : 0, m);
-    W.n_lin = n;
-    W.spec_col = n + p;           // the column of -1
-    W.n_mpc = W.n_lp;
+    const int n = S.n, m = S.m, p = S.p, nd0 = S.nd0;
+    carve_wave(W, lp_base, n + (feas ? 1 : 0), feas ? 1 : 0, m, S.nE);
+    // internal column order (ehm_ipm2.h): [z_D | tau] factorised, [z_E] behind them
+    W.n_lin = nd0;
+    W.spec_col = S.colOne;        // the column of -1
+    W.n_mpc = W.nr;
     W.sign_floor = EHM_ROUTE_TOL;     // phase one: the optimum is compared with ~0
-    if (lane < NP) W.c[lane] = feas ? ((lane == n) ? 1.0 : 0.0) : ((lane < n) ? S.cv[lane] : 0.0);
-    if (feas) {
+    if (lane < W.n_lp) {
+        // original z index of internal column `lane` (-1: tau)
+        const int jo = (lane < nd0) ? lane : ((lane >= W.nr) ? (nd0 + lane - W.nr) : -1);
+        W.c[lane] = feas ? ((jo < 0) ? 1.0 : 0.0) : S.cv[jo < 0 ? 0 : jo];
         // extra row 0:  -tau <= 1      (ldx = 1)
-        if (lane <= n) W.X[lane] = (lane == n) ? -1.0 : 0.0;
+        if (feas) W.X[lane] = (jo < 0) ? -1.0 : 0.0;
     }
 #pragma unroll
     for (int sl = 0; sl < SLOTS; ++sl) {
@@ -184,7 +187,8 @@ __device__ inline void assemble_point(const Shared& S, Wave& W, double* lp_base,
         double v = 0.0;
         if (i < m) {
             v = S.wv[i];
-            for (int r = 0; r < p; ++r) v = fma(-S.Wc[(size_t)(n + r) * S.lda + i], theta[r], v);
+            for (int r = 0; r < p; ++r)
+                v = fma(-S.Wc[(size_t)(S.colS + r) * S.lda + i], theta[r], v);
         } else if (feas && i == W.xbase) {
             v = 1.0;
         }
@@ -209,35 +213,38 @@ __device__ inline void assemble_simplex(const Shared& S, Wave& W, const NodeBuf&
                                         const double* R, const double* Vbar, int mode,
                                         double eps_a, double eps_r, double (&b)[SLOTS],
                                         int lane, const DevProblem& P, int d) {
-    const int n = S.n, m = S.m, p = S.p;
+    const int n = S.n, m = S.m, p = S.p, nd0 = S.nd0;
     const bool slack = (mode == SX_SLACK);
     const bool feas = (mode == SX_FEAS);
     const int n_lp = n + p + ((slack || feas) ? 1 : 0);
     const int ne = p + 1 + (slack ? 2 : 0) + (feas ? 1 : 0);
-    carve_wave(W, nb.lp, n_lp, ne, m);
-    W.n_lin = n + p;
-    W.spec_col = slack ? (n + p + 1) : (n + p);   // zeros for t, -1 for tau
-    W.n_mpc = slack ? (n + p) : n_lp;
+    carve_wave(W, nb.lp, n_lp, ne, m, S.nE);
+    // internal column order (ehm_ipm2.h): [z_D | beta | t or tau] factorised, [z_E] behind them;
+    // nb0 = first weight column, nt = the column of t / tau
+    const int nb0 = nd0, nt = nd0 + p;
+    W.n_lin = nd0 + p;
+    W.spec_col = slack ? S.colZero : S.colOne;    // zeros for t, -1 for tau
+    W.n_mpc = slack ? (nd0 + p) : W.nr;
     W.E = nb.F;
-    W.psi0 = n;
+    W.psi0 = nb0;
     W.npsi = p;
     W.nsx = p + 1;
     W.sign_floor = EHM_ROUTE_TOL * (1.0 + (slack ? fabs(Vbar[0]) : 0.0));
     const int ldx = W.ldx;
     for (int k = lane; k < n_lp * ldx; k += 64) W.X[k] = 0.0;
-    if (lane < NP) W.c[lane] = 0.0;
+    if (lane < n_lp) W.c[lane] = 0.0;
     {   // edge matrix
         const int r = lane >> 3, q = lane & 7;
         if (r < p && q < p) nb.F[r * p + q] = R[(q + 1) * p + r] - R[r];
     }
     wsync();
     if (lane < p) {
-        W.X[(n + lane) * ldx + lane] = const_d(-1.0);   // -beta_q <= 0
-        W.X[(n + lane) * ldx + p] = const_d(1.0);       // sum beta <= 1
+        W.X[(nb0 + lane) * ldx + lane] = const_d(-1.0);   // -beta_q <= 0
+        W.X[(nb0 + lane) * ldx + p] = const_d(1.0);       // sum beta <= 1
         if (slack) {
             const double dv = Vbar[lane + 1] - Vbar[0];
-            W.X[(n + lane) * ldx + p + 1] = -dv;
-            W.X[(n + lane) * ldx + p + 2] = -dv;
+            W.X[(nb0 + lane) * ldx + p + 1] = -dv;
+            W.X[(nb0 + lane) * ldx + p + 2] = -dv;
         }
     }
 #if EHM2_QUAD
@@ -247,25 +254,26 @@ __device__ inline void assemble_simplex(const Shared& S, Wave& W, const NodeBuf&
 #endif
     if (slack && quadc) {
         // the two suboptimality rows are quadratic: ipm_solve writes their gradients
-        if (lane == 0) W.c[n + p] = const_d(-1.0);
+        if (lane == 0) W.c[nt] = const_d(-1.0);
     } else if (slack) {
         if (lane < n) {
             const double cj = S.cv[lane];
-            W.X[lane * ldx + p + 1] = cj;
-            W.X[lane * ldx + p + 2] = fma(eps_r, cj, cj);     // (1 + eps_r) c_j
+            const int jc = zcol(W, S, lane);
+            W.X[jc * ldx + p + 1] = cj;
+            W.X[jc * ldx + p + 2] = fma(eps_r, cj, cj);       // (1 + eps_r) c_j
         }
         if (lane == 0) {
-            W.X[(n + p) * ldx + p + 1] = const_d(1.0);
-            W.X[(n + p) * ldx + p + 2] = const_d(1.0);
-            W.c[n + p] = const_d(-1.0);
+            W.X[nt * ldx + p + 1] = const_d(1.0);
+            W.X[nt * ldx + p + 2] = const_d(1.0);
+            W.c[nt] = const_d(-1.0);
         }
     } else if (feas) {
         if (lane == 0) {
-            W.X[(n + p) * ldx + p + 1] = const_d(-1.0);   // -tau <= 1
-            W.c[n + p] = const_d(1.0);
+            W.X[nt * ldx + p + 1] = const_d(-1.0);        // -tau <= 1
+            W.c[nt] = const_d(1.0);
         }
     } else if (lane < n) {
-        W.c[lane] = S.cv[lane];
+        W.c[zcol(W, S, lane)] = S.cv[lane];
     }
 #pragma unroll
     for (int sl = 0; sl < SLOTS; ++sl) {
@@ -273,7 +281,7 @@ __device__ inline void assemble_simplex(const Shared& S, Wave& W, const NodeBuf&
         double v = 0.0;
         if (i < m) {
             v = S.wv[i];
-            for (int r = 0; r < p; ++r) v = fma(-S.Wc[(size_t)(n + r) * S.lda + i], R[r], v);
+            for (int r = 0; r < p; ++r) v = fma(-S.Wc[(size_t)(S.colS + r) * S.lda + i], R[r], v);
         } else {
             const int e = i - W.xbase;
             if (e == p) v = 1.0;
