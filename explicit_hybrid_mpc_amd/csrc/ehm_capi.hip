@@ -741,7 +741,7 @@ static void elim_detect(const double* G, int nd, int m, int n, int p, int n_u, i
         nd0 = n;
         LE = 0;
     }
-    LE = (LE + 1) & ~1;
+    LE = (LE + 3) & ~3;      // the kernels gather the rows of a column four at a time
 }
 
 static size_t elim_tot4(int m, int p, int lda, int nd0, int nE, int LE) {
@@ -2198,6 +2198,16 @@ static int tree_alloc(ehm_tree* T, ehm_problem* P, long long cap) {
 static int read_counters(ehm_problem* P, DevCounters& c) {
     HIP_TRY(hipMemcpyAsync(&c, P->d_cnt, sizeof c, hipMemcpyDeviceToHost, P->stream), EHM_E_HIP);
     HIP_TRY(hipStreamSynchronize(P->stream), EHM_E_HIP);
+    return EHM_OK;
+}
+
+int ehm_solver_phase_ticks(ehm_problem* P, int64_t out[24]) {
+    if (!P || !out) return fail(EHM_E_INVALID, "null argument");
+    HIP_TRY(hipSetDevice(P->device), EHM_E_HIP);
+    DevCounters c;
+    int rc = read_counters(P, c);
+    if (rc) return rc;
+    for (int k = 0; k < 24; ++k) out[k] = (int64_t)c.phase[k];
     return EHM_OK;
 }
 

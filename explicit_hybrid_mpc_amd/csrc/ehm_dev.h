@@ -226,6 +226,9 @@ struct DevCounters {
     // longest edge), [7] child records + queue pushes, [8] nodes put back because their midpoint
     // was being solved elsewhere
     unsigned long long prof[10];
+    // builds with -DEHM2_PROF=1 only (ehm_ipm2.h): shader-clock cycles per phase of ipm_solve,
+    // lane 0 of every wavefront, summed over the solves that ran to their end; [23] = their number
+    unsigned long long phase[24];
     unsigned int ticket;                  // work distribution of the wide sweep kernels: next
     unsigned int ticket_pad;              // frontier position (zeroed before every launch)
 };

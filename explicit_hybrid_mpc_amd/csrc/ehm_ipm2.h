@@ -96,9 +96,34 @@
 #define EHM2_NS EHM2_CAT(ehm2_, EHM_NP, EHM_SLOTS)
 #endif
 
+// -DEHM2_PROF=1 (an experimental build: EHM_BUILD_FLAGS=-DEHM2_PROF=1 EHM_BUILD_TAG=prof): the
+// shader-clock cycles lane 0 of every wavefront spends in each phase of ipm_solve, summed into
+// DevCounters::phase (ehm_solver_phase_ticks; tools/solver_phases.py prints the table).
+#ifndef EHM2_PROF
+#define EHM2_PROF 0
+#endif
+
 namespace EHM2_NS {
 
 using namespace ehm;
+
+#if EHM2_PROF
+#define EHM2_PT(k)                                                                   \
+    {                                                                                \
+        const long long _t = (long long)__builtin_readcyclecounter();               \
+        if (lane0 == 0) W.pf[k] += (unsigned long long)(_t - _tp);                   \
+        _tp = _t;                                                                    \
+    }
+#define EHM2_PDUMP()                                                                 \
+    {                                                                                \
+        wsync();                                                                     \
+        if (S.gprof && lane0 < 24)                                                   \
+            atomicAdd(&S.gprof[lane0], W.pf[lane0] + (lane0 == 23 ? 1ULL : 0ULL));   \
+    }
+#else
+#define EHM2_PT(k)
+#define EHM2_PDUMP()
+#endif
 
 constexpr int NP = EHM_NP;
 constexpr int SLOTS = EHM_SLOTS;
@@ -222,6 +247,9 @@ struct Shared {
     int n, m, p, lda;
     int nd0, nE, LE;    // z-columns [0, nd0) stay, [nd0, n) are eliminated (nE = n - nd0)
     int colS, colOne, colZero;      // image columns of -S, of -1 and of zeros
+#if EHM2_PROF
+    unsigned long long* gprof;      // DevCounters::phase (null: not collected)
+#endif
 };
 __host__ __device__ inline size_t shared_doubles(const DevProblem& P) {
     return (((size_t)P.tot4 + (P.wc_lds ? P.m + P.n : 0)) + 1) & ~(size_t)1;
@@ -230,6 +258,9 @@ __device__ inline void carve_shared(Shared& S, double* base, const DevProblem& P
     S.n = P.n; S.m = P.m; S.p = P.p; S.lda = P.lda4;
     S.nd0 = P.nd0; S.nE = P.n - P.nd0; S.LE = P.LE4;
     S.colS = P.nd0; S.colOne = P.nd0 + P.p; S.colZero = P.nd0 + P.p + 1;
+#if EHM2_PROF
+    S.gprof = nullptr;
+#endif
     S.Wc = base;
     S.aE = base + (size_t)(P.nd0 + P.p + 2) * P.lda4;
     S.eval = base + (size_t)P.ncw4 * P.lda4;
@@ -294,6 +325,9 @@ struct Wave {
     double* hX;     // [2][nE]   X_E Delta^-1 of the dense extra rows
     double* xh;     // [2][NP]   the dense extra rows, reduced, in L D L' form
     double* dn;     // 8: [0] l, [1] 1/delta_1, [2] 1/delta_2 of  Gh = L diag(delta) L'
+#if EHM2_PROF
+    unsigned long long* pf;     // 24 phase accumulators of this wavefront's current solve
+#endif
 #if EHM2_QUAD
     // quadratic block: objective c'x + kap0 V(x), extra rows eq / eq+1 are
     // kap_i V(x) + a_i'x <= bq_i,  V(x) = 1/2 x'Q x + qv'x (+ v0 in the reported objective)
@@ -342,6 +376,9 @@ __host__ __device__ inline size_t wave_lp_doubles(int n_lp, int ne, int nE) {
 #if EHM2_QUAD
     tot += 5 * (size_t)NP + (size_t)NP * LDM + 2;
 #endif
+#if EHM2_PROF
+    tot += 24;
+#endif
     return (tot + 1) & ~(size_t)1;
 }
 __device__ inline void carve_wave(Wave& W, double* base, int n_lp, int ne, int m, int nE) {
@@ -375,6 +412,9 @@ __device__ inline void carve_wave(Wave& W, double* base, int n_lp, int ne, int m
     W.hX = base;  base += 2 * nEp;
     W.xh = base;  base += 2 * NP;
     W.dn = base;  base += 8;
+#if EHM2_PROF
+    W.pf = reinterpret_cast<unsigned long long*>(base);  base += 24;
+#endif
 #if EHM2_QUAD
     W.qv = base;  base += NP;
     W.a1 = base;  base += NP;
@@ -598,13 +638,31 @@ __device__ __forceinline__ void cols_times(const Shared& S, const Wave& W, const
     const int ecol = lane - W.nr;
     const bool elane = W.nE > 0 && ecol >= 0 && ecol < W.nE;
     if (W.nE > 0) {
+        // (LE is a multiple of 4: the gathers of four rows are in flight together, not one dependent
+        // LDS round trip after the other)
         const int eb = (elane ? ecol : 0) * S.LE;
-        for (int k = 0; k < S.LE; ++k) {
-            const int i = S.erow[eb + k];
-            const double a = S.eval[eb + k];
-            ex0 = elane ? fma(a, u0[i], ex0) : ex0;
-            if (TWO) ex1 = elane ? fma(a, u1[i], ex1) : ex1;
+        double s0 = 0.0, s1 = 0.0;
+        for (int k = 0; k < S.LE; k += 4) {
+            int i[4];
+            double a[4], w0[4], w1[4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                i[u] = S.erow[eb + k + u];
+                a[u] = S.eval[eb + k + u];
+            }
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                w0[u] = lds1(u0 + i[u]);
+                w1[u] = TWO ? lds1(u1 + i[u]) : 0.0;
+            }
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                s0 = fma(a[u], w0[u], s0);
+                if (TWO) s1 = fma(a[u], w1[u], s1);
+            }
         }
+        ex0 = elane ? (ex0 + s0) : ex0;
+        if (TWO) ex1 = elane ? (ex1 + s1) : ex1;
     }
     const int cb = pin(lane % nb);
     const int h = pin(lane / nb);
@@ -811,7 +869,27 @@ __device__ __forceinline__ void form_mfma(const Shared& S, const Wave& W, const 
     p0 += lk;
     p1 += lk;
     const double* pd = dvec + lk;
-    for (int i0 = 0; i0 < m4; i0 += 4) {
+    int i0 = 0;
+    if (!two) {
+        // single tile: four K-steps per trip, their eight loads in flight together, two
+        // accumulators so that consecutive matrix instructions do not wait for each other
+        double4v c0b = {0.0, 0.0, 0.0, 0.0};
+        for (; i0 + 16 <= m4; i0 += 16) {
+            double d[4], w[4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                d[u] = lds1(pd + i0 + 4 * u);
+                w[u] = lds1(p0 + i0 + 4 * u);
+            }
+            c00 = __builtin_amdgcn_mfma_f64_16x16x4f64(w[0] * d[0], w[0], c00, 0, 0, 0);
+            c0b = __builtin_amdgcn_mfma_f64_16x16x4f64(w[1] * d[1], w[1], c0b, 0, 0, 0);
+            c00 = __builtin_amdgcn_mfma_f64_16x16x4f64(w[2] * d[2], w[2], c00, 0, 0, 0);
+            c0b = __builtin_amdgcn_mfma_f64_16x16x4f64(w[3] * d[3], w[3], c0b, 0, 0, 0);
+        }
+#pragma unroll
+        for (int r = 0; r < 4; ++r) c00[r] += c0b[r];
+    }
+    for (; i0 < m4; i0 += 4) {
         const double d = lds1(pd + i0);
         const double w0 = lds1(p0 + i0);
         const double a0 = w0 * d;
@@ -883,12 +961,25 @@ __device__ __forceinline__ void form_eliminated(const Shared& S, const Wave& W, 
         const double* col = (in && r < W.n_mpc) ? (S.Wc + (size_t)wc_col(W, r) * S.lda) : zero;
         const int eb = (in ? e : 0) * S.LE;
         double g = 0.0, dl = 0.0;
-        for (int k = 0; k < S.LE; ++k) {
-            const int i = S.erow[eb + k];
-            const double ev = S.eval[eb + k];
-            const double de = lds1(dvec + i) * ev;
-            g = fma(de, lds1(col + i), g);
-            dl = fma(de, ev, dl);
+        for (int k = 0; k < S.LE; k += 4) {         // LE is a multiple of 4
+            int i[4];
+            double ev[4], dv[4], av[4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                i[u] = S.erow[eb + k + u];
+                ev[u] = S.eval[eb + k + u];
+            }
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                dv[u] = lds1(dvec + i[u]);
+                av[u] = lds1(col + i[u]);
+            }
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const double de = dv[u] * ev[u];
+                g = fma(de, av[u], g);
+                dl = fma(de, ev[u], dl);
+            }
         }
         if (in && r < NP) W.gE[e * GS + r] = g;
         if (in && r == 0) W.iD[e] = frcp(dl);       // Delta_e > 0: d > 0, the column is not empty
@@ -930,8 +1021,13 @@ __device__ __forceinline__ double few_sum(double v, int cnt) {
 
 // dext[e] = d of extra row e (the square matrix overwrites dvec before the extras are added)
 __device__ inline void form_normal_matrix(const Shared& S, const Wave& W, const double* dvec,
-                                          const double* dext, int lane) {
+                                          const double* dext, int lane
+#if EHM2_PROF
+                                          , int lane0, long long& _tp
+#endif
+                                          ) {
     if (W.nE > 0) form_eliminated(S, W, dvec, lane);
+    EHM2_PT(2)
     int nbA;
     if (NP <= 16 || W.n_mpc <= 16 || EHM2_FORM_MFMA) {
         // columns >= n_mpc are zero columns for the tiles; what they leave in W.M is zero too.
@@ -956,6 +1052,7 @@ __device__ inline void form_normal_matrix(const Shared& S, const Wave& W, const 
             for (int r = lane >> 4; r < c0; r += 4) W.M[r * LDM + c0 + c] = 0.0;
     }
     wsync();
+    EHM2_PT(3)
     if (NP > 16 && W.nE > 0 && !(W.n_mpc <= 16 || EHM2_FORM_MFMA)) schur_lds(W, lane);
     // psi-form -> beta-form of the weight block:  M <- T^T M T,  T = blockdiag(I, E, I)
     if (W.npsi > 0) {
@@ -1045,9 +1142,11 @@ __device__ __forceinline__ void lu_factor(double (&row)[NP], const Wave& W, int 
     for (int k = 0; k < NP; ++k) {
         const int kk = k & ~1;
         if (lane >= kk && lane < NP) U[uoff(k) + lane] = row[k];
-        wsync();
-        double piv = U[uoff(k) + k];
+        // the pivot itself comes from lane k's register: its reciprocal (v_rcp + two Newton steps)
+        // is under way while the column travels through LDS
+        double piv = readlane_d(row[k], k);
         const double orig = W.db[k];
+        wsync();
         const bool bad = !(piv > const_d(EHM2_PIVOT_REL) * orig) || !(piv > 0.0);
         piv = bad ? const_d(EHM2_PIVOT_BIG) : piv;
         const double rinv = frcp(piv);
@@ -1287,6 +1386,11 @@ __device__ inline IpmResult ipm_solve(const Shared& S, const Wave& W, const doub
     }
     wsync();
 
+#if EHM2_PROF
+    if (lane0 < 24) W.pf[lane0] = 0ULL;
+    wsync();
+    long long _tp = (long long)__builtin_readcyclecounter();
+#endif
     IpmResult res;
     res.obj = 0.0;
     res.merit = const_d(1e300);
@@ -1351,8 +1455,10 @@ __device__ inline IpmResult ipm_solve(const Shared& S, const Wave& W, const doub
             }
         }
         wsync();
+        EHM2_PT(0)
         double atl, atdr;
         cols_times<true>(S, W, W.vm0, W.vm1, W.M, lane, atl, atdr);   // W.M is free here
+        EHM2_PT(1)
         const double cjj = (lane < n) ? W.c[lane] : 0.0;
         const double xjj = (lane < n) ? W.x[lane] : 0.0;
 #if EHM2_QUAD
@@ -1416,11 +1522,14 @@ __device__ inline IpmResult ipm_solve(const Shared& S, const Wave& W, const doub
                 res.status = 0;
                 if (lane < n) W.xb[lane] = W.x[lane];
                 wsync();
+                EHM2_PT(15)
+                EHM2_PDUMP()
                 return res;
             }
         }
         if (stall >= 3 || it == EHM2_MAX_ITER || !(merit == merit)) break;
 
+        EHM2_PT(15)
         // ---- normal matrix and its factorisation ----------------------------------------
         lane = pin(lane0);      // fresh per phase: addresses derived above die here
 #pragma unroll
@@ -1437,9 +1546,15 @@ __device__ inline IpmResult ipm_solve(const Shared& S, const Wave& W, const doub
         }
 #endif
         wsync();
+#if EHM2_PROF
+        form_normal_matrix(S, W, W.vm0, W.ub, lane, lane0, _tp);
+#else
         form_normal_matrix(S, W, W.vm0, W.ub, lane);
+#endif
+        EHM2_PT(4)
         lane = pin(lane0);
         dense_prep(S, W, W.ub, lane);
+        EHM2_PT(5)
         lane = pin(lane0);
         double row[NP];
         {
@@ -1478,7 +1593,9 @@ __device__ inline IpmResult ipm_solve(const Shared& S, const Wave& W, const doub
             if (lane < NP) W.db[lane] = dg;
         }
         wsync();
+        EHM2_PT(6)
         lu_factor(row, W, lane);
+        EHM2_PT(7)
         const double rinv_l = W.db[(lane < NP) ? lane : (NP - 1)];
 
         // ---- predictor ------------------------------------------------------------------
@@ -1489,8 +1606,10 @@ __device__ inline IpmResult ipm_solve(const Shared& S, const Wave& W, const doub
         const double rhs_aff = (lane < n) ? (-cjj - atdr) : 0.0;
 #endif
         double dxj = solve_full(row, S, W, rinv_l, rhs_aff, lane);
+        EHM2_PT(8)
         double adx[SLOTS];
         rows_times(S, W, lane, W.t, adx);
+        EHM2_PT(9)
         double ds_a[SLOTS], dl_a[SLOTS];
         double rho_p = 0.0, rho_d = 0.0;
 #pragma unroll
@@ -1527,10 +1646,14 @@ __device__ inline IpmResult ipm_solve(const Shared& S, const Wave& W, const doub
         }
         wsync();
         double atc, dummy;
+        EHM2_PT(10)
         cols_times<false>(S, W, W.vm1, W.vm1, W.sc, lane, atc, dummy);
+        EHM2_PT(11)
         const double rhs = (lane < n) ? (rhs_aff + atc) : 0.0;
         dxj = solve_full(row, S, W, rinv_l, rhs, lane);
+        EHM2_PT(12)
         rows_times(S, W, lane, W.t, adx);
+        EHM2_PT(13)
         double ds[SLOTS], dl[SLOTS];
         rho_p = 0.0;
         rho_d = 0.0;
@@ -1561,8 +1684,10 @@ __device__ inline IpmResult ipm_solve(const Shared& S, const Wave& W, const doub
             }
         }
         wsync();
+        EHM2_PT(14)
     }
     wsync();
+    EHM2_PDUMP()
     if (gout) {
         // lam is the multiplier of the LAST iterate = the returned one when the loop left
         // through the convergence test

@@ -11,6 +11,11 @@ using namespace ehm;
 
 namespace EHM2_NS {
 
+#if EHM2_PROF
+#define K2_PROF_HOOK(S) S.gprof = cnt ? cnt->phase : nullptr;
+#else
+#define K2_PROF_HOOK(S)
+#endif
 #define K2_PROLOGUE()                                                            \
     double* sm = reinterpret_cast<double*>(k2_smem);                             \
     __shared__ int s_ctr;                                                        \
@@ -19,6 +24,7 @@ namespace EHM2_NS {
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);   /* uniform: SGPR pointers */ \
     Shared S;                                                                    \
     carve_shared(S, sm, P);                                                      \
+    K2_PROF_HOOK(S)                                                              \
     NodeBuf nb;                                                                  \
     carve_node(nb, sm + shared_doubles(P) + (size_t)wave * wave_doubles, P.p, P.n_u)
 

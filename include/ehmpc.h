@@ -457,6 +457,13 @@ int ehm_stats(ehm_problem* prob, ehm_counters* out);
  * sizes it knows; writes at most n of them.  Needs no device. */
 int ehm_abi_sizes(int64_t* sizes, int32_t n);
 
+/* Diagnostics of the shared-block solver (csrc/ehm_ipm2.h): shader-clock cycles spent in each
+ * phase of the interior-point iteration, lane 0 of every wavefront, summed over all solves since
+ * the handle was created; out[23] = the number of solves.  All zero unless the library was built
+ * with -DEHM2_PROF=1 (an experimental build, tools/solver_phases.py).  No reference counterpart:
+ * the reference times whole oracle calls (lib/worker.py:60-116). */
+int ehm_solver_phase_ticks(ehm_problem* prob, int64_t out[24]);
+
 /* Device self test of the wave-level primitives (DPP reductions, reciprocal) of every
  * compiled kernel instance: out[5*k .. 5*k+4] for instance k, expected
  * {1072, 99, 25, 1/3, -1}.  Test hook, not part of the reference's surface. */

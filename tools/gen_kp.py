@@ -27,6 +27,10 @@ sub('''    K2_PROLOGUE();
     kd::carve_shared(S, sm, P);
     ke::Shared Se;
     ke::carve_shared(Se, sm, P);
+#if EHM2_PROF
+    S.gprof = cnt ? cnt->phase : nullptr;
+    Se.gprof = cnt ? cnt->phase : nullptr;
+#endif
     kd::NodeBuf nb;
     kd::carve_node(nb, sm + kd::shared_doubles(P) + (size_t)wave * wave_doubles, P.p, P.n_u);
     ke::NodeBuf nbe;
