@@ -120,6 +120,11 @@ using namespace ehm;
         if (S.gprof && lane0 < 24)                                                   \
             atomicAdd(&S.gprof[lane0], W.pf[lane0] + (lane0 == 23 ? 1ULL : 0ULL));   \
     }
+#elif defined(EHM2_ISA_MARKS)
+// -DEHM2_ISA_MARKS: the same places as comments in the ISA (tools/isa_phases.py counts the
+// instructions of every phase in the compiler's output; phase k ENDS at "@@PHASE k")
+#define EHM2_PT(k) asm volatile("; @@PHASE " #k);
+#define EHM2_PDUMP()
 #else
 #define EHM2_PT(k)
 #define EHM2_PDUMP()
@@ -1019,6 +1024,70 @@ __device__ __forceinline__ double few_sum(double v, int cnt) {
     return (cnt <= 16) ? row16_sum(v) : wave_sum(v);
 }
 
+// psi-form -> beta-form of the weight block of the square matrix in LDS and of the eliminated
+// block's rows:  M <- T^T M T,  G <- G T,  T = blockdiag(I, E, I)  (E: P x P, row-major), then the
+// terms of the simplex rows  -beta_q <= 0,  sum beta <= 1  (extra rows 0..P):
+// sum_e d_e a_e a_e^T = diag(d_q) + d_sum 1 1^T  on the weight block.
+template <int P>
+__device__ __forceinline__ void to_beta_form(const Wave& W, const double* dext, int lane) {
+    const int p0 = W.psi0;
+    const double* Em = W.E;      // P x P, row-major (uniform reads)
+    double tmp[P];
+    if (lane < NP) {            // columns: row `lane` times E
+        double* mr = W.M + lane * LDM + p0;
+        double v[P];
+#pragma unroll
+        for (int r = 0; r < P; ++r) v[r] = mr[r];
+#pragma unroll
+        for (int q = 0; q < P; ++q) {
+            double a = 0.0;
+#pragma unroll
+            for (int r = 0; r < P; ++r) a = fma(v[r], Em[r * P + q], a);
+            tmp[q] = a;
+        }
+#pragma unroll
+        for (int q = 0; q < P; ++q) mr[q] = tmp[q];
+    }
+    // the eliminated block's rows of the weights, same product: task = (column e, 16 at a time)
+    for (int e = lane; e < W.nE; e += 64) {
+        double* gr = W.gE + e * GS + p0;
+        double v[P];
+#pragma unroll
+        for (int r = 0; r < P; ++r) v[r] = gr[r];
+#pragma unroll
+        for (int q = 0; q < P; ++q) {
+            double a = 0.0;
+#pragma unroll
+            for (int r = 0; r < P; ++r) a = fma(v[r], Em[r * P + q], a);
+            gr[q] = a;
+        }
+    }
+    wsync();
+    if (lane < NP) {            // rows: E^T times column `lane`
+        double* mc = W.M + p0 * LDM + lane;
+        double v[P];
+#pragma unroll
+        for (int r = 0; r < P; ++r) v[r] = mc[r * LDM];
+#pragma unroll
+        for (int q = 0; q < P; ++q) {
+            double a = 0.0;
+#pragma unroll
+            for (int r = 0; r < P; ++r) a = fma(Em[r * P + q], v[r], a);
+            tmp[q] = a;
+        }
+#pragma unroll
+        for (int q = 0; q < P; ++q) mc[q * LDM] = tmp[q];
+    }
+    wsync();
+    if (lane < P) {
+        const double dsum = dext[P];
+        double* mr = W.M + (p0 + lane) * LDM + p0;
+#pragma unroll
+        for (int q = 0; q < P; ++q) mr[q] += dsum + ((q == lane) ? dext[lane] : 0.0);
+    }
+    wsync();
+}
+
 // dext[e] = d of extra row e (the square matrix overwrites dvec before the extras are added)
 __device__ inline void form_normal_matrix(const Shared& S, const Wave& W, const double* dvec,
                                           const double* dext, int lane
@@ -1056,70 +1125,16 @@ __device__ inline void form_normal_matrix(const Shared& S, const Wave& W, const 
     if (NP > 16 && W.nE > 0 && !(W.n_mpc <= 16 || EHM2_FORM_MFMA)) schur_lds(W, lane);
     // psi-form -> beta-form of the weight block:  M <- T^T M T,  T = blockdiag(I, E, I)
     if (W.npsi > 0) {
-        const int np_ = W.npsi, p0 = W.psi0;
-        double tmp[8];
-        if (lane < NP) {            // columns: row `lane` times E
-            double* mr = W.M + lane * LDM + p0;
-#pragma unroll
-            for (int q = 0; q < 8; ++q) {
-                double a = 0.0;
-                if (q < np_)
-                    for (int r = 0; r < np_; ++r) a = fma(mr[r], W.E[r * np_ + q], a);
-                tmp[q] = a;
-            }
-#pragma unroll
-            for (int q = 0; q < 8; ++q)
-                if (q < np_) mr[q] = tmp[q];
+        switch (W.npsi) {       // compile-time width: the p x p products live in registers
+            case 1: to_beta_form<1>(W, dext, lane); break;
+            case 2: to_beta_form<2>(W, dext, lane); break;
+            case 3: to_beta_form<3>(W, dext, lane); break;
+            case 4: to_beta_form<4>(W, dext, lane); break;
+            case 5: to_beta_form<5>(W, dext, lane); break;
+            case 6: to_beta_form<6>(W, dext, lane); break;
+            case 7: to_beta_form<7>(W, dext, lane); break;
+            default: to_beta_form<8>(W, dext, lane); break;
         }
-        wsync();
-        if (lane < NP) {            // rows: E^T times column `lane`
-            double* mc = W.M + p0 * LDM + lane;
-#pragma unroll
-            for (int q = 0; q < 8; ++q) {
-                double a = 0.0;
-                if (q < np_)
-                    for (int r = 0; r < np_; ++r) a = fma(W.E[r * np_ + q], mc[r * LDM], a);
-                tmp[q] = a;
-            }
-#pragma unroll
-            for (int q = 0; q < 8; ++q)
-                if (q < np_) mc[q * LDM] = tmp[q];
-        }
-        // the eliminated block's rows of the weights:  G_beta = E^T G_psi  (task = (e, q);
-        // nE * npsi <= 256: checked where the problem is created)
-        {
-            const int nt = W.nE * np_;
-            double res[4];
-#pragma unroll
-            for (int u = 0; u < 4; ++u) {
-                const int t = lane + 64 * u;
-                double gq = 0.0;
-                if (t < nt) {
-                    const int e = t / np_, q = t - e * np_;
-                    const double* gr = W.gE + e * GS + p0;
-                    for (int r = 0; r < np_; ++r) gq = fma(W.E[r * np_ + q], gr[r], gq);
-                }
-                res[u] = gq;
-            }
-            wsync();
-#pragma unroll
-            for (int u = 0; u < 4; ++u) {
-                const int t = lane + 64 * u;
-                if (t < nt) {
-                    const int e = t / np_, q = t - e * np_;
-                    W.gE[e * GS + p0 + q] = res[u];
-                }
-            }
-        }
-        wsync();
-        // the simplex rows  -beta_q <= 0,  sum beta <= 1  (extra rows 0..npsi): their term
-        // sum_e d_e a_e a_e^T  is  diag(d_q) + d_sum 1 1^T  on the weight block
-        if (lane < np_) {
-            const double dsum = dext[np_];
-            double* mr = W.M + (p0 + lane) * LDM + p0;
-            for (int q = 0; q < np_; ++q) mr[q] += dsum + ((q == lane) ? dext[lane] : 0.0);
-        }
-        wsync();
     }
 }
 
@@ -1193,17 +1208,18 @@ __device__ __forceinline__ void masked_fnma(double& bv, double a, double s, unsi
 }
 
 // Solve (LU) x = rhs; lane j passes rhs_j and 1/U[j][j], receives x_j; W.t[0..nr) gets x too.
-// Forward: L (the multipliers row[k], k < lane) with the right-hand side in a register row; step k
-// broadcasts y_k by v_readlane and updates the lanes > k.  Backward: U row `lane` from LDS, step k
+// Forward: L (the multipliers row[k], k < lane, zeros elsewhere) with the right-hand side in a
+// register row; step k broadcasts y_k by v_readlane and every lane subtracts row[k] y_k.  Backward: U row `lane` from LDS, step k
 // broadcasts x_k and updates the lanes < k.  No LDS writes, no per-step lane compares: round 3
 // parked every y_k / x_k in LDS through lane 0 (9 instructions a step; 3 now).
 __device__ __forceinline__ double lu_solve(const double (&row)[NP], const Wave& W, double rinv,
                                            double rhs, int lane) {
     double bv = rhs;
+    // (row[k] = 0 for k >= lane, see ipm_solve: a finished component is not touched again)
 #pragma unroll
     for (int k = 0; k < NP - 1; ++k) {
         const double yk = readlane_d(bv, k);
-        masked_fnma(bv, row[k], yk, ~((2ull << k) - 1ull));
+        bv = fma(-row[k], yk, bv);
     }
     const int jl = (lane < NP) ? lane : (NP - 1);
     const double* urow = W.M + uoff(jl);
@@ -1595,6 +1611,10 @@ __device__ inline IpmResult ipm_solve(const Shared& S, const Wave& W, const doub
         wsync();
         EHM2_PT(6)
         lu_factor(row, W, lane);
+        // what the solves need of the register row are the multipliers of L (row[k], k < lane);
+        // zeros elsewhere make the forward substitutions plain FMAs (lu_solve)
+#pragma unroll
+        for (int k = 0; k < NP; ++k) row[k] = (k < lane) ? row[k] : 0.0;
         EHM2_PT(7)
         const double rinv_l = W.db[(lane < NP) ? lane : (NP - 1)];
 

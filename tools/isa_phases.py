@@ -1,8 +1,10 @@
 """Static instruction census of a kernel's ISA per solver phase.
 
 Usage: python tools/isa_phases.py file.s kernel_substring
-The source marks phases with  asm volatile("; @@PHASE name")  (tools/mark_phases.py inserts them
-into a scratch copy of csrc/ehm_ipm2.h).  For every phase: instruction counts by class, and the
+Compile with -DEHM2_ISA_MARKS: csrc/ehm_ipm2.h then leaves a comment "@@PHASE k" where phase k of
+ipm_solve ENDS (the phase numbers of tools/solver_phases.py), e.g.
+    hipcc --offload-arch=gfx950 -O3 -std=c++17 -DEHM_NP=16 -DEHM_SLOTS=3 -DEHM_PERSIST_MIDFIRST=1 \
+          -DEHM2_ISA_MARKS --cuda-device-only -S explicit_hybrid_mpc_amd/csrc/ehm_k2.hip -o /tmp/k2.s  For every phase: instruction counts by class, and the
 loops found inside it (label, body length, classes) so that trip counts can be applied by hand.
 """
 import re
