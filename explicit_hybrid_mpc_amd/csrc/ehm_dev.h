@@ -192,15 +192,38 @@ __device__ inline double cut_bound(const double* node, const double* g, int p, d
             for (int v = u + 1; v < na; ++v) {
                 const double du = fa[u] - fc[u], dv = fa[v] - fc[v];
                 if (du * dv < 0.0) {                // the edge (u, v) crosses f_a = f_c
-                    const double sx = du / (du - dv);
+                    // (v_rcp_f64 + two Newton steps, not an IEEE division: the crossing point
+                    // enters a bound that is compared with a 1e-6 margin, a few ulp are nothing)
+                    const double den = du - dv;
+                    double rc = __builtin_amdgcn_rcp(den);
+                    rc = fma(rc, fma(-den, rc, 1.0), rc);
+                    rc = fma(rc, fma(-den, rc, 1.0), rc);
+                    const double sx = du * rc;
                     m = fmax(m, fma(sx, fa[v] - fa[u], fa[u]));
                 }
             }
         if (ok) b = fmin(b, m);
     }
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) b = fmin(b, __shfl_xor(b, o, 64));
-    return b;
+    // wave minimum by DPP row shifts / row broadcasts (the reduction of ehm_ipm2.h: 20 instructions
+    // where six ds_bpermute round trips took 60 and their LDS latency)
+#define EHM_DPP_MIN_STEP(CTRL, RMASK)                                                          \
+    {                                                                                          \
+        const int lo = __builtin_amdgcn_update_dpp(__double2loint(1e300), __double2loint(b),   \
+                                                   CTRL, RMASK, 0xf, false);                   \
+        const int hi = __builtin_amdgcn_update_dpp(__double2hiint(1e300), __double2hiint(b),   \
+                                                   CTRL, RMASK, 0xf, false);                   \
+        b = fmin(b, __hiloint2double(hi, lo));                                                 \
+    }
+    EHM_DPP_MIN_STEP(0x111, 0xf)
+    EHM_DPP_MIN_STEP(0x112, 0xf)
+    EHM_DPP_MIN_STEP(0x114, 0xf)
+    EHM_DPP_MIN_STEP(0x118, 0xf)
+    EHM_DPP_MIN_STEP(0x142, 0xa)
+    EHM_DPP_MIN_STEP(0x143, 0xc)
+#undef EHM_DPP_MIN_STEP
+    const int lo = __builtin_amdgcn_readlane(__double2loint(b), 63);
+    const int hi = __builtin_amdgcn_readlane(__double2hiint(b), 63);
+    return __hiloint2double(hi, lo);
 }
 
 struct DevCounters {
@@ -286,6 +309,34 @@ __device__ inline void longest_edge(const double* R, int p, int& bi, int& bj) {
                 bj = j;
             }
         }
+}
+
+// The same decision with one edge per lane (every lane of a 64-wide wavefront calls it; p <= 8,
+// so the (p+1) p / 2 <= 36 edges fit): identical arithmetic per edge, and the FIRST maximal edge in
+// enumeration order is the lowest lane whose length equals the wave maximum.  The serial version
+// costs every lane ten correctly rounded square roots at p = 4; this one costs each lane one.
+__device__ inline void longest_edge_wave(const double* R, int p, int lane, int& bi, int& bj) {
+#pragma clang fp contract(off)
+    const int n_edges = (p + 1) * p / 2;
+    int ea = 0, rem = (lane < n_edges) ? lane : 0;
+    while (rem >= p - ea) {
+        rem -= (p - ea);
+        ++ea;
+    }
+    const int eb = ea + 1 + rem;
+    double s = 0.0;
+    for (int k = 0; k < p; ++k) {
+        const double df = R[ea * p + k] - R[eb * p + k];
+        s = __fma_rn(df, df, s);
+    }
+    const double len = (lane < n_edges) ? __dsqrt_rn(s) : -1.0;
+    double mx = len;
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) mx = fmax(mx, __shfl_xor(mx, o, 64));
+    const unsigned long long hit = __builtin_amdgcn_ballot_w64(len == mx);
+    const int src = hit ? __builtin_ctzll(hit) : 0;     // (NaN vertices: edge 0, like the serial loop)
+    bi = __shfl(ea, src, 64);
+    bj = __shfl(eb, src, 64);
 }
 
 }  // namespace ehm

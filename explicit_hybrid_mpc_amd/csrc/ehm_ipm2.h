@@ -51,12 +51,10 @@
 #ifndef EHM2_UNROLL
 #define EHM2_UNROLL 2
 #endif
-// 1: normal matrix of the MPC rows on the matrix cores (form_mfma), 0: vector FMAs (form_blocks).
-// Measured on the bench tree (MI355X): identical results, decide sweep 59 ms either way, expand
-// sweep 35 ms (MFMA) vs 32 ms (vector) -- v_mfma_f64_16x16x4 issues every 64 cycles, the tiles
-// compute 1024 entries for the 300 (decide) / 210 (expand) distinct ones, and with vector pipe
-// and LDS already shared by three wavefronts the longer per-wavefront chain costs what the
-// off-load frees.  Kept selectable: it is the path for n > 32.
+// Normal matrix of the MPC rows: one tile of the matrix cores when the factorised columns with MPC
+// entries are <= 16 (form_mfma), vector FMAs on 4 x 4 blocks beyond (form_blocks); 1 = matrix
+// cores at every size.  Round 2 measured the two-panel case on the bench tree (25 columns then):
+// identical results, decide sweep 59 ms either way, expand sweep 35 ms (MFMA) vs 32 ms (vector).
 #ifndef EHM2_FORM_MFMA
 #define EHM2_FORM_MFMA 0
 #endif
@@ -297,7 +295,8 @@ __device__ inline void load_shared(const DevProblem& P, int d, double* base, int
 // Private to a wavefront.
 struct Wave {
     double* M;      // region A: scratch / NP x LDM normal matrix / packed U (see A_DOUBLES)
-    double* X;      // [n_lp][ldx] extra rows, column-major (columns in the internal order)
+    double* X;      // [n_lp][ldx] the DENSE extra rows (extra rows nsx .. ne-1), column-major,
+                    // columns in the internal order; the simplex rows 0 .. nsx-1 are not stored
     double* vm0;    // MROWS
     double* vm1;    // MROWS
     double* c;      // n_lp objective           } internal column order:
@@ -351,6 +350,7 @@ constexpr int LDM = NP + 1;     // odd: row- and column-wise access of the squar
                                 // bank-conflict free (the factor U is kept packed, see below)
 constexpr int GS = NP + 1;      // row stride of gE: odd for the same reason
 typedef double double2v __attribute__((ext_vector_type(2)));
+typedef double double4v __attribute__((ext_vector_type(4)));
 
 // Packed upper-triangular factor: row k keeps its columns (k & ~1) .. NP-1 (an even start keeps
 // every row 16-byte aligned); element (k, q) lives at U[uoff(k) + q].
@@ -368,11 +368,15 @@ constexpr int U_SIZE = NP * (NP + 2) / 2;
 // vm0 and sc share [U_SIZE, U_SIZE+256); vm1 follows.  Every overwrite happens after the last
 // read of what it overwrites (same wavefront, program order).
 constexpr size_t A_MIN = (size_t)U_SIZE + 256 + MROWS;
-constexpr size_t A_KS = (NP > 16) ? 768 : 512;
+constexpr size_t A_KS = 512;     // K-slice scratch of form_blocks (in rounds when it needs more)
 constexpr size_t A_SQ = ((size_t)NP * LDM < A_KS) ? A_KS : (size_t)NP * LDM;
 constexpr size_t A_DOUBLES = (A_MIN < A_SQ) ? A_SQ : A_MIN;
-__host__ __device__ inline size_t wave_lp_doubles(int n_lp, int ne, int nE) {
-    const size_t ldx = ne ? ((size_t)ne | 1) : 0;
+// dense extra rows of an LP with ne extra rows: the simplex kinds (ne > p) lead with p + 1 simplex
+// rows, which are never stored
+__host__ __device__ inline int dense_rows(int ne, int p) { return (ne > p) ? ne - (p + 1) : ne; }
+__host__ __device__ inline size_t wave_lp_doubles(int n_lp, int ne, int nE, int p) {
+    const int kd = dense_rows(ne, p);
+    const size_t ldx = kd ? ((size_t)kd | 1) : 0;
     const size_t nf = ((size_t)n_lp + 1) & ~(size_t)1;
     const size_t nEp = ((size_t)nE + 1) & ~(size_t)1;
     // X | c x xb t | ub db | yv | gE iD qE hX | xh dn
@@ -386,13 +390,14 @@ __host__ __device__ inline size_t wave_lp_doubles(int n_lp, int ne, int nE) {
 #endif
     return (tot + 1) & ~(size_t)1;
 }
-__device__ inline void carve_wave(Wave& W, double* base, int n_lp, int ne, int m, int nE) {
+// nsx: the first nsx extra rows are the simplex rows (0 for point problems)
+__device__ inline void carve_wave(Wave& W, double* base, int n_lp, int ne, int m, int nE, int nsx) {
     W.n_lp = n_lp;
     W.nE = nE;
     W.nr = n_lp - nE;
     W.ne = ne;
     W.ldm = LDM;
-    W.ldx = ne ? (ne | 1) : 0;
+    W.ldx = (ne > nsx) ? ((ne - nsx) | 1) : 0;
     W.xbase = lp_xbase(m, ne);
     // an instance compiled with more slots than the LP needs keeps the extras in ITS last slot
     if (ne > 0 && W.xbase < 64 * (SLOTS - 1)) W.xbase = 64 * (SLOTS - 1);
@@ -434,7 +439,7 @@ __device__ inline void carve_wave(Wave& W, double* base, int n_lp, int ne, int m
     W.E = nullptr;
     W.psi0 = W.nr;
     W.npsi = 0;
-    W.nsx = 0;
+    W.nsx = nsx;
 }
 // internal index of the z-column with ORIGINAL index j (see the header: eliminated columns
 // sit behind the factorised ones)
@@ -481,7 +486,8 @@ struct RowMap {
     const double* last_base;   // last slot: address of column 0 for this lane's row
     int last_stride;           // its column stride
     const double* last_spec;   // its address in the special column
-    bool last_extra;           // last slot: this lane's row is an extra row (beta-form vector)
+    bool last_extra;           // last slot: this lane's row is a DENSE extra row (beta-form vector)
+    int last_sx;               // last slot: this lane's row is simplex row last_sx (-1: it is not)
     int lane;
 };
 __device__ __forceinline__ void make_rowmap(RowMap& rm, const Shared& S, const Wave& W, int lane) {
@@ -492,17 +498,25 @@ __device__ __forceinline__ void make_rowmap(RowMap& rm, const Shared& S, const W
     const int i = lane + 64 * (SLOTS - 1);
     const bool spec = W.n_lin < W.nr;
     rm.last_extra = false;
+    rm.last_sx = -1;
     if (i < S.m) {
         rm.valid[SLOTS - 1] = true;
         rm.last_base = S.Wc + i;
         rm.last_stride = S.lda;
         rm.last_spec = S.Wc + (spec ? W.spec_col * S.lda : zero_off) + i;
-    } else if (i >= W.xbase && i < W.xbase + W.ne) {
+    } else if (i >= W.xbase + W.nsx && i < W.xbase + W.ne) {
         rm.valid[SLOTS - 1] = true;
         rm.last_extra = true;
-        rm.last_base = W.X + (i - W.xbase);
+        rm.last_base = W.X + (i - W.xbase - W.nsx);
         rm.last_stride = W.ldx;
-        rm.last_spec = W.X + (size_t)W.n_lin * W.ldx + (i - W.xbase);
+        rm.last_spec = W.X + (size_t)W.n_lin * W.ldx + (i - W.xbase - W.nsx);
+    } else if (i >= W.xbase && i < W.xbase + W.nsx) {
+        // simplex row: -beta_e <= 0 (e < npsi) or sum beta <= 1; nothing stored, see rows_times
+        rm.valid[SLOTS - 1] = true;
+        rm.last_sx = i - W.xbase;
+        rm.last_base = S.Wc + zero_off;
+        rm.last_stride = 0;
+        rm.last_spec = S.Wc + zero_off;
     } else {
         rm.valid[SLOTS - 1] = false;
         rm.last_base = S.Wc + zero_off;
@@ -588,13 +602,21 @@ __device__ __forceinline__ void rows_times(const Shared& S, const Wave& W, int l
             const double a = (i < S.m) ? S.aE[ic] : 0.0;
             out[sl] = fma(a, vE[S.eidx[ic]], out[sl]);
         }
-        const int xe = rm.lane + 64 * (SLOTS - 1) - W.xbase;
-        if (rm.last_extra && xe >= W.nsx) {
+        if (rm.last_extra) {
+            const int xe = rm.lane + 64 * (SLOTS - 1) - W.xbase - W.nsx;
             const double* xr = W.X + (size_t)W.nr * W.ldx + xe;
             double a = 0.0;
             for (int e = 0; e < W.nE; ++e) a = fma(xr[(size_t)e * W.ldx], vE[e], a);
             out[SLOTS - 1] += a;
         }
+    }
+    if (W.nsx > 0) {
+        // the simplex rows: -beta_e, and the sum of the weights for the last one
+        double sb = 0.0;
+        for (int q = 0; q < W.npsi; ++q) sb += v[W.psi0 + q];
+        if (rm.last_sx >= 0)
+            out[SLOTS - 1] = (rm.last_sx < W.npsi) ? -v[W.psi0 + (rm.last_sx < W.npsi ? rm.last_sx : 0)]
+                                                  : sb;
     }
 #pragma unroll
     for (int sl = 0; sl < SLOTS; ++sl) out[sl] = rm.valid[sl] ? out[sl] : 0.0;
@@ -617,7 +639,7 @@ __device__ __forceinline__ void block_cols_ext(const Shared& S, const Wave& W, i
 #pragma unroll
     for (int q = 0; q < 4; ++q) {
         const int j = 4 * cb + q;
-        px[q] = (j < W.nr && W.ne > 0) ? (W.X + (size_t)j * W.ldx) : zero;
+        px[q] = (j < W.nr && W.ldx > 0) ? (W.X + (size_t)j * W.ldx) : zero;
     }
 }
 
@@ -631,12 +653,20 @@ __device__ __forceinline__ void cols_times(const Shared& S, const Wave& W, const
     constexpr int ks = 64 / nb;
     // the extra rows first (beta-form already): u0 / u1 may be overwritten by the partials
     double ex0 = 0.0, ex1 = 0.0;
-    if (lane < W.n_lp && W.ne > 0) {
+    if (lane < W.n_lp && W.ne > W.nsx) {       // the dense extra rows
         const double* xl = W.X + (size_t)lane * W.ldx;
-        for (int e = 0; e < W.ne; ++e) {
+        const int xb0 = W.xbase + W.nsx;
+        for (int e = 0; e < W.ne - W.nsx; ++e) {
             const double a = xl[e];
-            ex0 = fma(a, u0[W.xbase + e], ex0);
-            if (TWO) ex1 = fma(a, u1[W.xbase + e], ex1);
+            ex0 = fma(a, u0[xb0 + e], ex0);
+            if (TWO) ex1 = fma(a, u1[xb0 + e], ex1);
+        }
+    }
+    {   // the simplex rows: column beta_q holds -1 in row q and +1 in the row of the sum
+        const int q = lane - W.psi0;
+        if (W.nsx > 0 && q >= 0 && q < W.npsi) {
+            ex0 += u0[W.xbase + W.npsi] - u0[W.xbase + q];
+            if (TWO) ex1 += u1[W.xbase + W.npsi] - u1[W.xbase + q];
         }
     }
     // the eliminated columns: lane nr + e sums over the (few) rows of column e
@@ -669,6 +699,10 @@ __device__ __forceinline__ void cols_times(const Shared& S, const Wave& W, const
         ex0 = elane ? (ex0 + s0) : ex0;
         if (TWO) ex1 = elane ? (ex1 + s1) : ex1;
     }
+    // (Round 4 tried this product on the matrix cores -- [A^T u0 | A^T u1] = W^T [u0 u1 0 ..] as one
+    // 16 x 16 tile, 2 loads + 1 instruction per 4 rows: 10 % SLOWER end to end.  An FP64
+    // v_mfma_f64_16x16x4 holds the SIMD's double-precision pipe for 64 cycles -- 16 vector FMAs'
+    // worth -- and only 2 of the tile's 16 columns were wanted; profiles/r4/README.md.)
     const int cb = pin(lane % nb);
     const int h = pin(lane / nb);
     const bool active = h < ks;
@@ -761,13 +795,13 @@ __device__ __forceinline__ void cols_times(const Shared& S, const Wave& W, const
 // lane accumulates a 4x4 block over the rows i = h (mod KS) (MPC rows from the shared Wc,
 // extra rows from the private X).  The slices meet in LDS.  Row loop unrolled by 4 so that
 // the 9 loads of a row step use immediate offsets off 9 address registers.
-template <int KS>
+template <int KS, int R>
 __device__ __forceinline__ void form_blocks(const Shared& S, const Wave& W, const double* dvec,
                                             int lane, int nbA, int TA) {
     // lane = h * TA + task without a division by the run-time TA
     int hq = 0;
 #pragma unroll
-    for (int u = 1; u <= 4; ++u) hq += (lane >= u * TA) ? 1 : 0;
+    for (int u = 1; u <= KS; ++u) hq += (lane >= u * TA) ? 1 : 0;
     const int task = pin(lane - hq * TA);
     const int h = pin(hq);
     const bool active = h < KS;
@@ -812,25 +846,61 @@ __device__ __forceinline__ void form_blocks(const Shared& S, const Wave& W, cons
 #endif
         for (; i < m; i += KS) EHM2_FORM_ROW(cj, ck, dvec, i)
 #undef EHM2_FORM_ROW
-    }
-    // slices h > 0 park their blocks in W.M ([slice][entry][pair]: lanes write consecutively)
-    wsync();
-    if (active && h > 0) {
-        double* sc = W.M + (size_t)(h - 1) * 16 * TA + task;
+        // The Schur update of the eliminated block in the same accumulators:
+        //     M <- M - G Delta^-1 G'  =  sum_e (-g_e / Delta_e) g_e' ,
+        // every eliminated column e is one more "row" of weight -1 / Delta_e whose entries are g_e
+        // (form_eliminated; psi-form like the block's columns).  Columns >= NP of G do not exist.
+        for (int e = h; e < W.nE; e += KS) {
+            const double* ge = W.gE + e * GS;
+            const double d = -W.iD[e];
+            double aj[4], ak[4];
 #pragma unroll
-        for (int q = 0; q < 4; ++q)
-#pragma unroll
-            for (int r = 0; r < 4; ++r) sc[(4 * q + r) * TA] = acc[q][r];
-    }
-    wsync();
-    if (h == 0) {
-#pragma unroll
-        for (int hh = 1; hh < KS; ++hh) {
-            const double* sc = W.M + (size_t)(hh - 1) * 16 * TA + task;
+            for (int q = 0; q < 4; ++q) {
+                aj[q] = ge[4 * bj + q] * d;
+                ak[q] = ge[4 * bk + q];
+            }
 #pragma unroll
             for (int q = 0; q < 4; ++q)
 #pragma unroll
-                for (int r = 0; r < 4; ++r) acc[q][r] += sc[(4 * q + r) * TA];
+                for (int r = 0; r < 4; ++r) acc[q][r] = fma(aj[q], ak[r], acc[q][r]);
+        }
+    }
+    // The KS slices meet in W.M: every slice parks EPR of its 16 entries per round
+    // ([slice][entry][pair]: lanes write consecutively), ALL lanes add the slices up -- value v of a
+    // round sits at v, v + EPR TA, v + 2 EPR TA, ... -- and the lanes of slice 0 take the sums back.
+    // Rounds: as many as keep KS x EPR x TA doubles inside the region (A_KS).
+    constexpr int EPR = 16 / R;     // R: chosen by the caller (form_blocks_ks)
+    if (KS > 1) {
+#pragma unroll
+        for (int rd = 0; rd < R; ++rd) {
+            wsync();
+            if (active) {
+                double* sc = W.M + (size_t)h * EPR * TA + task;
+#pragma unroll
+                for (int q = 0; q < 4; ++q)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        const int en = 4 * q + r - rd * EPR;
+                        if (en >= 0 && en < EPR) sc[en * TA] = acc[q][r];
+                    }
+            }
+            wsync();
+            for (int v = lane; v < EPR * TA; v += 64) {
+                double sum = W.M[v];
+#pragma unroll
+                for (int hh = 1; hh < KS; ++hh) sum += W.M[(size_t)hh * EPR * TA + v];
+                W.M[v] = sum;
+            }
+            wsync();
+            if (h == 0) {
+#pragma unroll
+                for (int q = 0; q < 4; ++q)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        const int en = 4 * q + r - rd * EPR;
+                        if (en >= 0 && en < EPR) acc[q][r] = W.M[en * TA + task];
+                    }
+            }
         }
     }
     wsync();
@@ -846,6 +916,16 @@ __device__ __forceinline__ void form_blocks(const Shared& S, const Wave& W, cons
     }
 }
 
+// rounds of the slice exchange: as many as keep KS x (16 / R) x TA doubles inside A_KS
+template <int KS>
+__device__ __forceinline__ void form_blocks_ks(const Shared& S, const Wave& W, const double* dvec,
+                                               int lane, int nbA, int TA) {
+    const int tot1 = KS * 16 * TA;
+    if (tot1 <= (int)A_KS) form_blocks<KS, 1>(S, W, dvec, lane, nbA, TA);
+    else if (tot1 <= 2 * (int)A_KS) form_blocks<KS, 2>(S, W, dvec, lane, nbA, TA);
+    else form_blocks<KS, 4>(S, W, dvec, lane, nbA, TA);
+}
+
 // The same contraction on the matrix cores: M_mpc = W^T diag(d) W over the columns that have MPC
 // entries, as 16x16 output tiles of v_mfma_f64_16x16x4_f64 (K = 4 rows per instruction).
 // Operand layout (one f64 per lane): A[i = lane%16][k = lane/16] = d_k W[k][16I + i],
@@ -859,7 +939,6 @@ __device__ __forceinline__ void form_blocks(const Shared& S, const Wave& W, cons
 // vector form is used (measured equal or better there in round 2).
 // The Schur update of the eliminated block rides on the same accumulators:
 //     M <- M - G Delta^-1 G'    =  sum_e (-g_e / Delta_e) g_e'      (K = 4 columns e per instruction)
-typedef double double4v __attribute__((ext_vector_type(4)));
 __device__ __forceinline__ void form_mfma(const Shared& S, const Wave& W, const double* dvec,
                                           int lane, int ncols) {
     const int li = lane & 15, lk = lane >> 4;
@@ -992,24 +1071,6 @@ __device__ __forceinline__ void form_eliminated(const Shared& S, const Wave& W, 
     wsync();
 }
 
-// M <- M - G Delta^-1 G' on the square matrix in LDS (the vector form's counterpart of the
-// matrix-core accumulation in form_mfma): task = (row j, 4-column block).
-__device__ __forceinline__ void schur_lds(const Wave& W, int lane) {
-    constexpr int nb = NP / 4;
-    for (int t = lane; t < NP * nb; t += 64) {
-        const int j = t / nb, cb = t - j * nb;
-        double acc[4] = {0.0, 0.0, 0.0, 0.0};
-        for (int e = 0; e < W.nE; ++e) {
-            const double gj = W.gE[e * GS + j] * W.iD[e];
-#pragma unroll
-            for (int q = 0; q < 4; ++q) acc[q] = fma(gj, W.gE[e * GS + 4 * cb + q], acc[q]);
-        }
-#pragma unroll
-        for (int q = 0; q < 4; ++q) W.M[j * LDM + 4 * cb + q] -= acc[q];
-    }
-    wsync();
-}
-
 // Sum over the lanes 0..15 (one DPP row), returned to every lane; lanes >= 16 must pass 0 --
 // 14 instructions where the wave reduction takes 22.
 __device__ __forceinline__ double row16_sum(double v) {
@@ -1098,7 +1159,12 @@ __device__ inline void form_normal_matrix(const Shared& S, const Wave& W, const 
     if (W.nE > 0) form_eliminated(S, W, dvec, lane);
     EHM2_PT(2)
     int nbA;
-    if (NP <= 16 || W.n_mpc <= 16 || EHM2_FORM_MFMA) {
+    // One 16 x 16 tile of the matrix cores where the columns fit (measured on the headline tree,
+    // round 4: 29.0 ms per partition against 30.5 with the vector blocks below), the vector blocks
+    // beyond -- three tiles compute 1024 entries for at most 528 distinct ones, and an FP64
+    // v_mfma holds the SIMD's double-precision pipe like 16 vector FMAs (EHM2_FORM_MFMA = 1:
+    // matrix cores at every size).
+    if (EHM2_FORM_MFMA || W.n_mpc <= 16) {
         // columns >= n_mpc are zero columns for the tiles; what they leave in W.M is zero too.
         // A single panel (n_mpc <= 16) writes rows / columns 0..15 only.
         nbA = (W.n_mpc > 16 || NP <= 16) ? (NP >> 2) : 4;
@@ -1107,10 +1173,14 @@ __device__ inline void form_normal_matrix(const Shared& S, const Wave& W, const 
         nbA = (W.n_mpc + 3) >> 2;
         const int TA = nbA * (nbA + 1) / 2;
         const int ks = 64 / TA;     // TA <= 36
-        if (ks >= 4) form_blocks<4>(S, W, dvec, lane, nbA, TA);
-        else if (ks == 3) form_blocks<3>(S, W, dvec, lane, nbA, TA);
-        else if (ks == 2) form_blocks<2>(S, W, dvec, lane, nbA, TA);
-        else form_blocks<1>(S, W, dvec, lane, nbA, TA);
+        // TA = 1, 3, 6, 10, 15, 21, 28, 36 pairs for 1..8 column blocks: 64 / TA slices each
+        // (the instance's column capacity bounds the block count: the rest is not compiled)
+        if (ks >= 8) form_blocks_ks<8>(S, W, dvec, lane, nbA, TA);              // <= 3 blocks
+        else if (NP >= 16 && ks >= 6) form_blocks_ks<6>(S, W, dvec, lane, nbA, TA);     // 4
+        else if (NP >= 20 && ks >= 4) form_blocks_ks<4>(S, W, dvec, lane, nbA, TA);     // 5
+        else if (NP >= 24 && ks == 3) form_blocks_ks<3>(S, W, dvec, lane, nbA, TA);     // 6
+        else if (NP >= 28 && ks == 2) form_blocks_ks<2>(S, W, dvec, lane, nbA, TA);     // 7
+        else if (NP >= 32) form_blocks<1, 1>(S, W, dvec, lane, nbA, TA);                // 8
     }
     // rows / columns 4*nbA .. NP-1 (no entries in the MPC rows): zero
     const int c0 = 4 * nbA;
@@ -1122,7 +1192,6 @@ __device__ inline void form_normal_matrix(const Shared& S, const Wave& W, const 
     }
     wsync();
     EHM2_PT(3)
-    if (NP > 16 && W.nE > 0 && !(W.n_mpc <= 16 || EHM2_FORM_MFMA)) schur_lds(W, lane);
     // psi-form -> beta-form of the weight block:  M <- T^T M T,  T = blockdiag(I, E, I)
     if (W.npsi > 0) {
         switch (W.npsi) {       // compile-time width: the p x p products live in registers
@@ -1244,7 +1313,7 @@ __device__ __forceinline__ void dense_prep(const Shared& S, const Wave& W, const
                                            int lane) {
     const int kd = W.ne - W.nsx;
     if (kd <= 0) return;
-    const int e0 = W.nsx;
+    const int e0 = W.nsx;           // first dense row among the extra rows (dext is indexed by those)
     const int nEp = (W.nE + 1) & ~1;
     const bool two = kd > 1;
     double g11 = frcp(dext[e0]);
@@ -1252,12 +1321,12 @@ __device__ __forceinline__ void dense_prep(const Shared& S, const Wave& W, const
     double g12 = 0.0;
     double x0 = 0.0, x1 = 0.0;
     if (lane < W.nr) {
-        x0 = W.X[(size_t)lane * W.ldx + e0];
-        x1 = two ? W.X[(size_t)lane * W.ldx + e0 + 1] : 0.0;
+        x0 = W.X[(size_t)lane * W.ldx];
+        x1 = two ? W.X[(size_t)lane * W.ldx + 1] : 0.0;
     }
     if (W.nE > 0) {
         const bool el = lane < W.nE;
-        const double* xr = W.X + (size_t)(W.nr + (el ? lane : 0)) * W.ldx + e0;
+        const double* xr = W.X + (size_t)(W.nr + (el ? lane : 0)) * W.ldx;
         const double xe0 = el ? xr[0] : 0.0;
         const double xe1 = (el && two) ? xr[1] : 0.0;
         const double id = el ? W.iD[el ? lane : 0] : 0.0;
@@ -1314,7 +1383,7 @@ __device__ __forceinline__ double solve_full(const double (&row)[NP], const Shar
             for (int e2 = 0; e2 < W.nE; ++e2) rr = fma(-W.gE[e2 * GS + lane], W.qE[e2], rr);
         if (kd > 0) {       // rho = X_E Delta^-1 r_E
             const bool l2 = lane < W.nE;
-            const double* xr = W.X + (size_t)(W.nr + (l2 ? lane : 0)) * W.ldx + W.nsx;
+            const double* xr = W.X + (size_t)(W.nr + (l2 ? lane : 0)) * W.ldx;
             const double q = l2 ? W.qE[l2 ? lane : 0] : 0.0;
             rho0 = few_sum(l2 ? xr[0] * q : 0.0, W.nE);
             if (two) rho1 = few_sum(l2 ? xr[1] * q : 0.0, W.nE);
@@ -1345,7 +1414,7 @@ __device__ __forceinline__ double solve_full(const double (&row)[NP], const Shar
             const double* ge = W.gE + e * GS;
             for (int j = 0; j < W.nr; ++j) acc = fma(-ge[j], W.t[j], acc);
             if (kd > 0) {
-                const double* xr = W.X + (size_t)(W.nr + e) * W.ldx + W.nsx;
+                const double* xr = W.X + (size_t)(W.nr + e) * W.ldx;
                 acc = fma(-xr[0], y0, acc);
                 if (two) acc = fma(-xr[1], y1, acc);
             }
@@ -1438,8 +1507,8 @@ __device__ inline IpmResult ipm_solve(const Shared& S, const Wave& W, const doub
                 const double a1j = (lane < n) ? W.a1[lane] : 0.0;
                 const double a2j = (lane < n) ? W.a2[lane] : 0.0;
                 if (lane < n) {             // current gradients kap_i (Qx+q) + a_i
-                    W.X[(size_t)lane * W.ldx + W.eq] = fma(W.kap1, gvj, a1j);
-                    W.X[(size_t)lane * W.ldx + W.eq + 1] = fma(W.kap2, gvj, a2j);
+                    W.X[(size_t)lane * W.ldx + W.eq - W.nsx] = fma(W.kap1, gvj, a1j);
+                    W.X[(size_t)lane * W.ldx + W.eq - W.nsx + 1] = fma(W.kap2, gvj, a2j);
                 }
                 const double a1x = wave_sum(a1j * xj);
                 const double a2x = wave_sum(a2j * xj);
@@ -1553,7 +1622,8 @@ __device__ inline IpmResult ipm_solve(const Shared& S, const Wave& W, const doub
             if (rm.valid[sl]) W.vm0[lane + 64 * sl] = lam[sl] * rs[sl];
         wsync();
         // d of the extra rows, for the terms added after the MPC part (W.ub is free here)
-        if (rm.last_extra) W.ub[lane + 64 * (SLOTS - 1) - W.xbase] = lam[SLOTS - 1] * rs[SLOTS - 1];
+        if (rm.last_extra || rm.last_sx >= 0)       // d of every extra row, simplex rows included
+            W.ub[lane + 64 * (SLOTS - 1) - W.xbase] = lam[SLOTS - 1] * rs[SLOTS - 1];
 #if EHM2_QUAD
         if (W.quad && W.eq >= 0 && rm.last_extra) {
             const int e = lane + 64 * (SLOTS - 1) - W.xbase;

@@ -13,6 +13,11 @@
 #endif
 
 #define K2_AUG_MIN 32
+// persistent frontier kernel: offset (doubles) into the wavefront's LP workspace where a node's
+// vertex gradients are staged between its load (or its creation as the kept child) and the
+// tangent-plane bound -- behind the bound's own scratch, 2 (p+1)^2 <= 162 doubles, and inside
+// every instance's workspace (>= 512 doubles)
+#define K2_HOT_GRAD 176
 // Near-threshold routing (hard part 1): a node's close / split decision may be
 // taken by a shortcut -- sign-only stop of the suboptimality-test LP, tangent-plane bound,
 // midpoint witness, inherited negative verdict -- only when it establishes |t*| >= this

@@ -316,7 +316,7 @@ __global__ __launch_bounds__(EHM_K2_THREADS) void k2_lcss_expand(
         for (int k = lane; k < nrec; k += 64) node[k] = rec[k];
         wsync();
         int bi, bj;
-        longest_edge(node, p, bi, bj);
+        longest_edge_wave(node, p, lane, bi, bj);
         if (lane < p) {
 #pragma clang fp contract(off)
             mid[lane] = (node[bi * p + lane] + node[bj * p + lane]) / 2.0;
@@ -443,9 +443,17 @@ __global__ __launch_bounds__(EHM_K2_THREADS) void k2_persist(
     if (lane0 == 0) *wmargin = 1e300;
     wsync();
     int keep = -1;          // the child this wavefront goes on with (see "work first" below)
+    // hot: everything the kept child's visit reads first is still in LDS -- its record in nb.rec,
+    // its vertex gradients at nb.lp + K2_HOT_GRAD, its witness in the stash -- and its depth /
+    // commutation in registers: the visit starts without a single global round trip (the sibling's
+    // consumer pays those; round 3 re-read all of it, four dependent loads per kept child)
+    bool hot = false;
+    int hot_dep = 0, hot_d = 0;
     const bool keep_child = deal.keep != 0;
     for (;;) {
         int id = -1;
+        const bool is_hot = hot && keep >= 0;
+        hot = false;
         if (keep >= 0) {
             id = keep;
             keep = -1;
@@ -478,28 +486,49 @@ __global__ __launch_bounds__(EHM_K2_THREADS) void k2_persist(
         const bool came_back = (id & EHM_REQUEUED) != 0;
         id &= ~EHM_REQUEUED;
         const long long t_pre = wall_clock64();
-        // acquire (L1 / non-local L2 invalidate): the record behind the slot is visible
-        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
         const int lane = pin(lane0);
-        const double* rec = T.rec + (size_t)id * T.rec_stride;
         double* node = nb.rec;
-        for (int k = lane; k < nrec; k += 64) node[k] = rec[k];
+        double* hgrad = nb.lp + K2_HOT_GRAD;        // vertex gradients of the node, (p+1) p doubles
+        const int ng = (p + 1) * p;
+        int dep = hot_dep;
+        if (!is_hot) {
+            // acquire (L1 / non-local L2 invalidate): the record behind the slot is visible
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+            const double* rec = T.rec + (size_t)id * T.rec_stride;
+            // record, gradients, witness and depth are independent loads: one wait for all of them
+            const double g_in = (T.grad && lane < ng) ? T.grad[(size_t)id * ng + lane] : 0.0;
+#if EHM_PERSIST_MIDFIRST
+            const double w_in = (T.wit && sign_only && lane < p + 2)
+                ? T.wit[(size_t)id * (p + 2) + lane] : 0.0;
+#endif
+            dep = T.depth[id];
+            for (int k = lane; k < nrec; k += 64) node[k] = rec[k];
+            if (T.grad) {
+                if (lane < ng) hgrad[lane] = g_in;
+                for (int k = lane + 64; k < ng; k += 64) hgrad[k] = T.grad[(size_t)id * ng + k];
+            }
+#if EHM_PERSIST_MIDFIRST
+            if (T.wit && sign_only && lane < p + 2)
+                nb.rec[(size_t)wave_doubles - k2_stash_doubles(p, n_u) + n_u + p + lane] = w_in;
+#endif
+        }
         wsync();
         // ---- suboptimality test --------------------------------------------------------------
         if (T.grad && sign_only) {
             // tangent-plane bound of t* (ehm_dev.h, cut_bound): negative => closed, no LP
-            const double bnd = cut_bound(node, T.grad + (size_t)id * (p + 1) * p, p, P.eps_a,
-                                         P.eps_r, lane, nb.lp);
+            const double bnd = cut_bound(node, hgrad, p, P.eps_a, P.eps_r, lane, nb.lp);
             if (bnd < -EHM_ROUTE_TOL * (1.0 + fabs(node[rec_off_vcost(p)]))) {
                 if (lane == 0) {
-                    const int dep0 = T.depth[id];
+                    const int dep0 = dep;
                     wst[W_CERT] += 1;
                     wst[W_CLOSED] += 1;
                     if (dep0 < deal.depth) wst[W_RCLOSED] += 1;
                     *wmargin = fmin(*wmargin, -bnd);
                     if ((unsigned long long)dep0 > wst[W_DEPTH]) wst[W_DEPTH] = (unsigned long long)dep0;
                     T.tstar[id] = bnd;
-                    T.flags[id] |= 1;
+                    // (a kept child's flags are the ones it was created with a moment ago: 2)
+                    if (is_hot) T.flags[id] = 3;
+                    else T.flags[id] |= 1;
                     atomicSub(&ctl->pending, 1);
                 }
                 wsync();
@@ -516,7 +545,6 @@ __global__ __launch_bounds__(EHM_K2_THREADS) void k2_persist(
         // and t_mid > 0 proves the node open without its suboptimality-test LP (42 % of the open
         // nodes of the bench tree, tools/midpoint_certificate.py).  Otherwise the LP decides as
         // before; a node it closes has paid for a midpoint solve it did not need (3 % of them).
-        const int dep = T.depth[id];
         const bool can_split = !(max_depth > 0 && dep >= max_depth);
         double* mid = nb.th;
         // the last k2_stash_doubles of the wave's LDS: midpoint input, midpoint gradient,
@@ -536,9 +564,7 @@ __global__ __launch_bounds__(EHM_K2_THREADS) void k2_persist(
         bool decided = false;
         if (T.wit && sign_only) {
             // inherited witness: the point that proved an ancestor open, if it lies in this node
-            const double* wv = T.wit + (size_t)id * (p + 2);
-            if (lane < p + 2) wit[lane] = wv[lane];
-            wsync();
+            // (loaded with the record, or left in the stash by the parent's visit)
             const double* Vc = node + rec_off_vcost(p);
             double vbw = 0.0;
             for (int q = 0; q <= p; ++q) vbw = fma(wit[1 + q], Vc[q], vbw);
@@ -554,7 +580,7 @@ __global__ __launch_bounds__(EHM_K2_THREADS) void k2_persist(
             }
         }
         if (can_split) {
-            longest_edge(node, p, bi, bj);
+            longest_edge_wave(node, p, lane, bi, bj);
             if (lane < p) {
 #pragma clang fp contract(off)
                 mid[lane] = (node[bi * p + lane] + node[bj * p + lane]) / 2.0;
@@ -822,6 +848,14 @@ __global__ __launch_bounds__(EHM_K2_THREADS) void k2_persist(
         }
         // ---- children (the midpoint solve is in Jm / stash) --------------------------------------
         const long long t_post = wall_clock64();
+        // the wavefront goes on with child 1 itself (work first, below) unless the children are
+        // dealt over ranks at this depth: then its record, gradients and witness also stay in LDS
+        const bool fast = keep_child && deal.pop_limit <= 0 &&
+                          !(deal.world > 1 && dep + 1 == deal.depth);
+        // the node's own gradients again (the solves have used the workspace they were staged in):
+        // the load is under way while the allocation below makes its round trip
+        const double gv0 = (T.grad && lane < ng) ? T.grad[(size_t)id * ng + lane] : 0.0;
+        const int d = is_hot ? hot_d : T.didx[id];
         int c0 = 0;
         if (lane == 0) c0 = atomicAdd(&ctl->n_nodes, 2);
         c0 = __builtin_amdgcn_readfirstlane(c0);
@@ -832,18 +866,17 @@ __global__ __launch_bounds__(EHM_K2_THREADS) void k2_persist(
             }
             break;
         }
-        const int d = T.didx[id];
         struct { double obj; } r = {Jm};      // the child-record loop below reads r.obj
         if (T.grad) {       // children's vertex gradients, written through like the records
-            const int ng = (p + 1) * p;
             const double* gp_ = T.grad + (size_t)id * ng;
             double* g0 = T.grad + (size_t)c0 * ng;
             for (int k = lane; k < ng; k += 64) {
-                const double gv = gp_[k];
+                const double gv = (k < 64) ? gv0 : gp_[k];
                 const double a0 = (k >= bi * p && k < bi * p + p) ? stash[st_g + k - bi * p] : gv;
                 const double a1 = (k >= bj * p && k < bj * p + p) ? stash[st_g + k - bj * p] : gv;
                 __hip_atomic_store(g0 + k, a0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                 __hip_atomic_store(g0 + ng + k, a1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                if (fast) hgrad[k] = a1;
             }
         }
         if (T.wit && lane < p + 2) {
@@ -859,6 +892,8 @@ __global__ __launch_bounds__(EHM_K2_THREADS) void k2_persist(
             }
             __hip_atomic_store(w0 + lane, v0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             __hip_atomic_store(w0 + (p + 2) + lane, v1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            wsync();                        // every lane has read the parent's witness
+            if (fast) wit[lane] = v1;       // child 1's, for its visit by this wavefront
         }
         if (lane == 0) {
             wst[W_SPLITS] += 1;
@@ -881,7 +916,6 @@ __global__ __launch_bounds__(EHM_K2_THREADS) void k2_persist(
         r.iters = its;
         const double tst = -r.obj;
         const bool open = (tst >= 0.0);
-        const int dep = T.depth[id];
         if (lane == 0) {
             wst[W_SOLVES] += 1;
             if (dep < deal.depth) wst[W_RSOLVES] += 1;
@@ -929,7 +963,7 @@ __global__ __launch_bounds__(EHM_K2_THREADS) void k2_persist(
         }
         double* mid = nb.th;
         int bi, bj;
-        longest_edge(node, p, bi, bj);
+        longest_edge_wave(node, p, lane, bi, bj);
         if (lane < p) {
 #pragma clang fp contract(off)
             mid[lane] = (node[bi * p + lane] + node[bj * p + lane]) / 2.0;
@@ -1001,6 +1035,9 @@ __global__ __launch_bounds__(EHM_K2_THREADS) void k2_persist(
             // dirty copy stays behind that could later clobber the consumer's own writes
             __hip_atomic_store(rec0 + k, v0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             __hip_atomic_store(rec1 + k, v1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+#if EHM_PERSIST_MIDFIRST
+            if (fast) node[k] = v1;         // child 1's record, in place (entry k depends on entry k)
+#endif
         }
         // sharded launch: the children created at the deal depth go to rank (path code % world)
         int own0 = 1, own1 = 1;
@@ -1066,6 +1103,11 @@ __global__ __launch_bounds__(EHM_K2_THREADS) void k2_persist(
             wst[W_TPOST] += (unsigned long long)(wall_clock64() - t_post);
         }
         keep = __builtin_amdgcn_readfirstlane(kept);
+#if EHM_PERSIST_MIDFIRST
+        hot = fast && keep >= 0;
+        hot_dep = dep + 1;
+        hot_d = d;
+#endif
         wsync();
     }
     wsync();
@@ -1186,7 +1228,7 @@ hipError_t set_lds(int bytes) {
 size_t wave_doubles_for(const DevProblem& P, int n_lp, int ne, int persist) {
     // (+ k2_stash_doubles: what the midpoint-first flow of k2_persist parks per node behind the
     // wavefront's workspace; the batch and sweep kernels park nothing)
-    return k2_node_doubles(P.p, P.n_u) + wave_lp_doubles(n_lp, ne, P.n - P.nd0) +
+    return k2_node_doubles(P.p, P.n_u) + wave_lp_doubles(n_lp, ne, P.n - P.nd0, P.p) +
            ((EHM_PERSIST_MIDFIRST && persist) ? k2_stash_doubles(P.p, P.n_u) : 0);
 }
 size_t shared_doubles_for(const DevProblem& P) { return shared_doubles(P); }

@@ -168,7 +168,7 @@ __device__ inline void assemble_point(const Shared& S, Wave& W, double* lp_base,
                                       const double* theta, bool feas, double (&b)[SLOTS],
                                       int lane, const DevProblem& P, int d) {
     const int n = S.n, m = S.m, p = S.p, nd0 = S.nd0;
-    carve_wave(W, lp_base, n + (feas ? 1 : 0), feas ? 1 : 0, m, S.nE);
+    carve_wave(W, lp_base, n + (feas ? 1 : 0), feas ? 1 : 0, m, S.nE, 0);
     // internal column order (ehm_ipm2.h): [z_D | tau] factorised, [z_E] behind them
     W.n_lin = nd0;
     W.spec_col = S.colOne;        // the column of -1
@@ -218,7 +218,7 @@ __device__ inline void assemble_simplex(const Shared& S, Wave& W, const NodeBuf&
     const bool feas = (mode == SX_FEAS);
     const int n_lp = n + p + ((slack || feas) ? 1 : 0);
     const int ne = p + 1 + (slack ? 2 : 0) + (feas ? 1 : 0);
-    carve_wave(W, nb.lp, n_lp, ne, m, S.nE);
+    carve_wave(W, nb.lp, n_lp, ne, m, S.nE, p + 1);
     // internal column order (ehm_ipm2.h): [z_D | beta | t or tau] factorised, [z_E] behind them;
     // nb0 = first weight column, nt = the column of t / tau
     const int nb0 = nd0, nt = nd0 + p;
@@ -228,7 +228,6 @@ __device__ inline void assemble_simplex(const Shared& S, Wave& W, const NodeBuf&
     W.E = nb.F;
     W.psi0 = nb0;
     W.npsi = p;
-    W.nsx = p + 1;
     W.sign_floor = EHM_ROUTE_TOL * (1.0 + (slack ? fabs(Vbar[0]) : 0.0));
     const int ldx = W.ldx;
     for (int k = lane; k < n_lp * ldx; k += 64) W.X[k] = 0.0;
@@ -238,14 +237,12 @@ __device__ inline void assemble_simplex(const Shared& S, Wave& W, const NodeBuf&
         if (r < p && q < p) nb.F[r * p + q] = R[(q + 1) * p + r] - R[r];
     }
     wsync();
-    if (lane < p) {
-        W.X[(nb0 + lane) * ldx + lane] = const_d(-1.0);   // -beta_q <= 0
-        W.X[(nb0 + lane) * ldx + p] = const_d(1.0);       // sum beta <= 1
-        if (slack) {
-            const double dv = Vbar[lane + 1] - Vbar[0];
-            W.X[(nb0 + lane) * ldx + p + 1] = -dv;
-            W.X[(nb0 + lane) * ldx + p + 2] = -dv;
-        }
+    // (the simplex rows -beta_q <= 0, sum beta <= 1 are not stored: the solver knows them;
+    // X holds the dense rows only, row 0 = extra row p + 1)
+    if (lane < p && slack) {
+        const double dv = Vbar[lane + 1] - Vbar[0];
+        W.X[(nb0 + lane) * ldx] = -dv;
+        W.X[(nb0 + lane) * ldx + 1] = -dv;
     }
 #if EHM2_QUAD
     const bool quadc = (P.Hq != nullptr) && !feas;
@@ -259,17 +256,17 @@ __device__ inline void assemble_simplex(const Shared& S, Wave& W, const NodeBuf&
         if (lane < n) {
             const double cj = S.cv[lane];
             const int jc = zcol(W, S, lane);
-            W.X[jc * ldx + p + 1] = cj;
-            W.X[jc * ldx + p + 2] = fma(eps_r, cj, cj);       // (1 + eps_r) c_j
+            W.X[jc * ldx] = cj;
+            W.X[jc * ldx + 1] = fma(eps_r, cj, cj);           // (1 + eps_r) c_j
         }
         if (lane == 0) {
-            W.X[nt * ldx + p + 1] = const_d(1.0);
-            W.X[nt * ldx + p + 2] = const_d(1.0);
+            W.X[nt * ldx] = const_d(1.0);
+            W.X[nt * ldx + 1] = const_d(1.0);
             W.c[nt] = const_d(-1.0);
         }
     } else if (feas) {
         if (lane == 0) {
-            W.X[nt * ldx + p + 1] = const_d(-1.0);        // -tau <= 1
+            W.X[nt * ldx] = const_d(-1.0);                // -tau <= 1
             W.c[nt] = const_d(1.0);
         }
     } else if (lane < n) {

@@ -180,7 +180,7 @@ hipError_t set_lds(int bytes) {
 }
 size_t wave_doubles_for(const DevProblem& P, int n_lp_d, int ne_d, int n_lp_e) {
     const int nE = P.n - P.nd0;
-    const size_t a = kd::wave_lp_doubles(n_lp_d, ne_d, nE), b = ke::wave_lp_doubles(n_lp_e, 0, nE);
+    const size_t a = kd::wave_lp_doubles(n_lp_d, ne_d, nE, P.p), b = ke::wave_lp_doubles(n_lp_e, 0, nE, P.p);
     // (+ k2_stash_doubles: the midpoint-first flow parks the midpoint solve's input and gradient and the
     // node's witness there)
     return k2_node_doubles(P.p, P.n_u) + (a > b ? a : b) + (EHM_PERSIST_MIDFIRST ? k2_stash_doubles(P.p, P.n_u) : 0);
