@@ -36,7 +36,7 @@ EXPORTED = [
     'ehm_explicit_last_error', 'ehm_partition_progress', 'ehm_partition_counts', 'ehm_partition_advance', 'ehm_problem_set_quadratic',
     'ehm_feas_all_batch', 'ehm_lcss_batch', 'ehm_partition_movable',
     'ehm_problem_update_blocks', 'ehm_simplex_idx_batch', 'ehm_point_idx_batch',
-    'ehm_abi_sizes', 'ehm_solver_phase_ticks',
+    'ehm_abi_sizes', 'ehm_solver_phase_ticks', 'ehm_problem_layout',
 ]
 
 
@@ -196,6 +196,7 @@ def load(build_if_missing=True):
     lib.ehm_tree_destroy.argtypes = [vp]
     lib.ehm_stats.argtypes = [vp, ctypes.POINTER(Counters)]
     lib.ehm_solver_phase_ticks.argtypes = [vp, vp]
+    lib.ehm_problem_layout.argtypes = [vp, vp]
     for name in EXPORTED:
         fn = getattr(lib, name)
         if name not in ('ehm_last_error', 'ehm_version', 'ehm_stream',

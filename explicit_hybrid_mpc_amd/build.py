@@ -72,8 +72,11 @@ def _cxx():
     return _hipcc()
 
 
-def _dep_mtime():
-    deps = [os.path.join(SRC_DIR, h) for h in HEADERS] + [__file__]
+def _dep_mtime(public=True):
+    """Newest dependency: the csrc/ headers (every object), the public header (the C-ABI object
+    and the staleness test of the library only: the kernel objects do not include it)."""
+    deps = [os.path.join(SRC_DIR, h) for h in HEADERS if public or not h.startswith('..')]
+    deps += [__file__]
     return max(os.path.getmtime(os.path.normpath(d)) for d in deps)
 
 
@@ -147,8 +150,9 @@ def build(force=False, verbose=False, jobs=None):
     os.makedirs(OBJ_DIR, exist_ok=True)
     _regenerate_kp()
     hipcc = _hipcc()
-    dep_t = _dep_mtime()
-    todo = [(o, s, f) for (o, s, f) in _objects() if force or _stale(o, s, dep_t)]
+    dep_t, dep_k = _dep_mtime(), _dep_mtime(public=False)
+    todo = [(o, s, f) for (o, s, f) in _objects()
+            if force or _stale(o, s, dep_t if os.path.basename(s) == 'ehm_capi.hip' else dep_k)]
 
     def compile_one(item):
         obj, src, extra = item

@@ -2201,6 +2201,15 @@ static int read_counters(ehm_problem* P, DevCounters& c) {
     return EHM_OK;
 }
 
+int ehm_problem_layout(ehm_problem* P, int32_t out[4]) {
+    if (!P || !out) return fail(EHM_E_INVALID, "null argument");
+    out[0] = P->dp.nd0;
+    out[1] = P->dp.n - P->dp.nd0;
+    out[2] = P->dp.LE4;
+    out[3] = P->dp.lda4;
+    return EHM_OK;
+}
+
 int ehm_solver_phase_ticks(ehm_problem* P, int64_t out[24]) {
     if (!P || !out) return fail(EHM_E_INVALID, "null argument");
     HIP_TRY(hipSetDevice(P->device), EHM_E_HIP);

@@ -147,8 +147,11 @@ __device__ __forceinline__ void witness_for_children(const double* wit, const do
 // node = [vertices | vertex costs ...] in LDS, g = the node's (p+1)*p gradients in global memory
 // (NaN = unknown: every function it enters becomes NaN and is skipped), scr = 2(p+1)^2 doubles of
 // LDS scratch.  Every lane returns the bound (+1e300 when nothing is known).
+// thr: a caller that only asks "is the bound below thr?" (the leaf is then closed) gets the
+// one-function bound back as soon as that one answers yes -- 59 % of the closed leaves -- and the
+// 45-pair pass runs for the rest.
 __device__ inline double cut_bound(const double* node, const double* g, int p, double eps_a,
-                                   double eps_r, int lane, double* scr) {
+                                   double eps_r, int lane, double* scr, double thr = -1e301) {
     const int na = p + 1, nr = 2 * na;
     const double* V = node + na * p;
     for (int k = lane; k < na * na; k += 64) {      // f_r at the vertices
@@ -171,6 +174,14 @@ __device__ inline double cut_bound(const double* node, const double* g, int p, d
             m = fmax(m, f);
         }
         if (ok) b = m;
+    }
+    if (thr > -1e300) {
+        double b1 = b;
+#pragma unroll
+        for (int o = 8; o > 0; o >>= 1) b1 = fmin(b1, __shfl_xor(b1, o, 64));    // nr <= 18 lanes
+        const double b1a = __shfl(b1, 0, 64), b1b = __shfl(b1, 16, 64);
+        b1 = fmin(b1a, b1b);
+        if (b1 < thr) return b1;
     }
     const int npairs = nr * (nr - 1) / 2;
     for (int t = lane; t < npairs; t += 64) {       // two at a time

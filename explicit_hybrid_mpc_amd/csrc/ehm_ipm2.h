@@ -1150,7 +1150,7 @@ __device__ __forceinline__ void to_beta_form(const Wave& W, const double* dext, 
 }
 
 // dext[e] = d of extra row e (the square matrix overwrites dvec before the extras are added)
-__device__ inline void form_normal_matrix(const Shared& S, const Wave& W, const double* dvec,
+__device__ __forceinline__ void form_normal_matrix(const Shared& S, const Wave& W, const double* dvec,
                                           const double* dext, int lane
 #if EHM2_PROF
                                           , int lane0, long long& _tp
@@ -1400,7 +1400,7 @@ __device__ __forceinline__ double solve_full(const double (&row)[NP], const Shar
     }
     const double xD = lu_solve(row, W, rinv, rr, lane);
     double y0 = 0.0, y1 = 0.0;
-    if (kd > 0) {
+    if (kd > 0 && W.nE > 0) {       // (without eliminated columns nothing needs y)
         const bool lr = lane < W.nr;
         const double v0 = few_sum(lr ? W.xh[jl] * xD : 0.0, W.nr) + rho0;
         const double v1 = two ? (few_sum(lr ? W.xh[NP + jl] * xD : 0.0, W.nr) + rho1) : 0.0;
@@ -1434,7 +1434,7 @@ __device__ __forceinline__ double solve_full(const double (&row)[NP], const Shar
 // gout (optional, LDS, S.p doubles; point problems of a linear-cost handle): the gradient of the
 // optimal value with respect to the parameter, -S^T lambda = sum_i lambda_i Wc[n+q][i], NaN
 // unless the solve converged to the tolerances (an accepted-inaccurate solve has no usable dual).
-__device__ inline IpmResult ipm_solve(const Shared& S, const Wave& W, const double (&b)[SLOTS],
+__device__ __forceinline__ IpmResult ipm_solve(const Shared& S, const Wave& W, const double (&b)[SLOTS],
                                       int lane0, int sign_only, double step_frac,
                                       double* gout = nullptr) {
     int lane = lane0;

@@ -240,9 +240,10 @@ __global__ __launch_bounds__(EHM_K2_THREADS) void k2_lcss_decide(
         if (T.grad && sign_only) {
             // tangent-plane bound of t* (ehm_dev.h, cut_bound): negative => the leaf is closed,
             // exactly as a negative t* would close it, without solving the LP
+            const double thr = -EHM_ROUTE_TOL * (1.0 + fabs(nb.rec[rec_off_vcost(P.p)]));
             const double bnd = cut_bound(nb.rec, T.grad + (size_t)id * (P.p + 1) * P.p, P.p,
-                                         P.eps_a, P.eps_r, lane, nb.lp);
-            if (bnd < -EHM_ROUTE_TOL * (1.0 + fabs(nb.rec[rec_off_vcost(P.p)]))) {
+                                         P.eps_a, P.eps_r, lane, nb.lp, thr);
+            if (bnd < thr) {
                 if (lane == 0) {
                     atomicAdd(&cnt->cert_closed, 1ULL);
                     T.tstar[id] = bnd;
@@ -514,10 +515,27 @@ __global__ __launch_bounds__(EHM_K2_THREADS) void k2_persist(
         }
         wsync();
         // ---- suboptimality test --------------------------------------------------------------
-        if (T.grad && sign_only) {
+        // the inherited witness first (a dozen instructions): a node it proves open (t* > 0) cannot
+        // be closed by the tangent-plane bound (t* < 0), whose 45 pairs of planes are then skipped
+        bool inh_open = false;
+        double inh_tw = 0.0;
+#if EHM_PERSIST_MIDFIRST
+        if (T.wit && sign_only) {
+            const double* wit_ = nb.rec + (size_t)wave_doubles - k2_stash_doubles(p, n_u) + n_u + p;
+            const double* Vc = node + rec_off_vcost(p);
+            double vbw = 0.0;
+            for (int q = 0; q <= p; ++q) vbw = fma(wit_[1 + q], Vc[q], vbw);
+            const double cw = wit_[0];
+            const double tw = fmin(vbw - cw - P.eps_a, vbw - (1.0 + P.eps_r) * cw);
+            inh_open = tw > EHM_ROUTE_TOL * (1.0 + fabs(vbw));
+            inh_tw = tw;
+        }
+#endif
+        if (T.grad && sign_only && !inh_open) {
             // tangent-plane bound of t* (ehm_dev.h, cut_bound): negative => closed, no LP
-            const double bnd = cut_bound(node, hgrad, p, P.eps_a, P.eps_r, lane, nb.lp);
-            if (bnd < -EHM_ROUTE_TOL * (1.0 + fabs(node[rec_off_vcost(p)]))) {
+            const double thr = -EHM_ROUTE_TOL * (1.0 + fabs(node[rec_off_vcost(p)]));
+            const double bnd = cut_bound(node, hgrad, p, P.eps_a, P.eps_r, lane, nb.lp, thr);
+            if (bnd < thr) {
                 if (lane == 0) {
                     const int dep0 = dep;
                     wst[W_CERT] += 1;
@@ -564,18 +582,13 @@ __global__ __launch_bounds__(EHM_K2_THREADS) void k2_persist(
         bool decided = false;
         if (T.wit && sign_only) {
             // inherited witness: the point that proved an ancestor open, if it lies in this node
-            // (loaded with the record, or left in the stash by the parent's visit)
-            const double* Vc = node + rec_off_vcost(p);
-            double vbw = 0.0;
-            for (int q = 0; q <= p; ++q) vbw = fma(wit[1 + q], Vc[q], vbw);
-            const double cw = wit[0];
-            const double tw = fmin(vbw - cw - P.eps_a, vbw - (1.0 + P.eps_r) * cw);
-            if (tw > EHM_ROUTE_TOL * (1.0 + fabs(vbw))) {
+            // (loaded with the record, or left in the stash by the parent's visit; evaluated above)
+            if (inh_open) {
                 open = true;
                 decided = true;
                 have_wit = true;
-                tst = tw;
-                margin = tw;
+                tst = inh_tw;
+                margin = inh_tw;
                 if (lane == 0) wst[W_INH] += 1;
             }
         }

@@ -393,6 +393,12 @@ class GpuProblem:
         """Resumable partition run (see PartitionRun); same arguments as partition()."""
         return PartitionRun(self, roots, action, init, max_nodes, max_depth, shard, with_volume)
 
+    def layout(self):
+        """ehm_problem_layout: dict(nd0, nE, LE, lda) -- what the solver eliminates (reporting)."""
+        out = (ctypes.c_int32 * 4)()
+        check(self._lib.ehm_problem_layout(self._handle, ctypes.addressof(out)))
+        return dict(nd0=int(out[0]), nE=int(out[1]), LE=int(out[2]), lda=int(out[3]))
+
     def stats(self):
         c = _capi.Counters()
         check(self._lib.ehm_stats(self._handle, ctypes.byref(c)))

@@ -464,6 +464,15 @@ int ehm_abi_sizes(int64_t* sizes, int32_t n);
  * the reference times whole oracle calls (lib/worker.py:60-116). */
 int ehm_solver_phase_ticks(ehm_problem* prob, int64_t out[24]);
 
+/* What the shared-block solver eliminates from the Newton systems of this handle (csrc/ehm_ipm2.h,
+ * DESIGN.md section 3.2b): out = { nd0, nE, LE, lda } -- the z-columns [nd0, nd0 + nE) are the
+ * trailing range of which every MPC row holds at most one entry (the epigraph variables of the
+ * infinity-norm cost, lib/mpc_library.py:530-560), LE = rows per such column (padded), lda = column
+ * stride of the LDS image.  nE = 0: nothing is eliminated (no such range, a quadratic cost, or
+ * EHM_SPARSE=0 in the environment when the handle was created).  Reporting only (bench.py prices
+ * the executed flops with it); no reference counterpart. */
+int ehm_problem_layout(ehm_problem* prob, int32_t out[4]);
+
 /* Device self test of the wave-level primitives (DPP reductions, reciprocal) of every
  * compiled kernel instance: out[5*k .. 5*k+4] for instance k, expected
  * {1072, 99, 25, 1/3, -1}.  Test hook, not part of the reference's surface. */
