@@ -56,16 +56,35 @@ def node_bytes(p, n_u, delta_len):
     return 8 * ((p + 1) * p + (p + 1) + (p + 1) * n_u) + delta_len + 16
 
 
-def flops_executed_per_iteration(n_lp, n_mpc, m, np_cap):
+def flops_executed_per_iteration(n_lp, n_mpc, m, nE=0, LE=0):
     """
-    What the shared-block solver (csrc/ehm_ipm2.h) really executes per iteration, as opposed to
-    the SURVEY formula above: the normal matrix is formed on the lower-triangular 4x4 block pairs
-    of the n_mpc columns that have MPC entries (nb (nb + 1) / 2 pairs x 16 entries x m rows), the
-    elimination runs unsymmetric at the compiled column capacity np_cap and updates both
-    triangles (2 np_cap^3 / 3), matrix-vector products and triangular solves as in the formula.
+    What the shared-block solver (csrc/ehm_ipm2.h, round 4) really executes per iteration, as
+    opposed to the SURVEY formula above.  nE z-columns are eliminated from the Newton system
+    (ehm_problem_layout), nr = n_lp - nE are factorised at the compiled capacity NP:
+      * eliminated block G, Delta: (16 or 32) x nE tasks x LE rows x 2 FMAs;
+      * normal matrix of the MPC rows: ONE 16 x 16 matrix-core tile when the factorised columns
+        with MPC entries are <= 16 (256 FMAs per row, both triangles and the padding included,
+        + the Schur update as ceil(nE / 4) more K-steps), else vector FMAs on the lower-triangular
+        4 x 4 block pairs (nb (nb + 1) / 2 pairs x 16 entries per row, the Schur rows included);
+      * elimination unsymmetric at the capacity NP, both triangles: 2 NP^3 / 3;
+      * four matrix-vector products on the factorised columns + one gathered entry per row for the
+        eliminated ones; two pairs of triangular solves + the eliminated block's products.
     """
-    nb = (n_mpc + 3) // 4
-    return nb * (nb + 1) / 2. * 32. * m + 2. * np_cap ** 3 / 3. + 8. * m * n_lp + 4. * n_lp * n_lp
+    nr = n_lp - nE
+    nm = n_mpc - nE
+    np_cap = np_capacity(nr)
+    f = 0.
+    if nE:
+        f += 2. * 2. * (16 if np_cap <= 16 else 32) * nE * LE
+    if nm <= 16:
+        f += 2. * 256. * (m + 4. * ((nE + 3) // 4))
+    else:
+        nb = (nm + 3) // 4
+        f += nb * (nb + 1) / 2. * 32. * (m + nE)
+    f += 2. * np_cap ** 3 / 3.
+    f += 8. * m * (nr + (1 if nE else 0))
+    f += 4. * np_cap * np_cap + 8. * nE * nr
+    return f
 
 
 def np_capacity(n_lp):
@@ -487,8 +506,9 @@ def measure(args, ctx):
             # sweeps of a single-commutation handle: the decide kernel alone is timed
             kind_iters = [agg['ipm_iters'] - agg['decide_iters'], 0., 0., agg['decide_iters'], 0.]
         f_survey = [kind_iters[q] * flops_per_iteration(dims[q][0], dims[q][2]) for q in range(5)]
+        lay = gp.layout()         # what the solver eliminates (ehm_problem_layout)
         f_exec = [kind_iters[q] * flops_executed_per_iteration(
-            dims[q][0], dims[q][1], dims[q][2], np_capacity(dims[q][0])) for q in range(5)]
+            dims[q][0], dims[q][1], dims[q][2], lay['nE'], lay['LE']) for q in range(5)]
         simplex_kinds, point_kinds = (2, 3, 4), (0, 1)
         B_node = node_bytes(p, can.n_u, can.deltas.shape[1])      # 301 B at config 2
         grad_bytes = 8 * (p + 1) * p if agg['cert_closed'] > 0 else 0
@@ -630,19 +650,26 @@ def measure(args, ctx):
                 'note': ('normal matrix on v_mfma_f64_16x16x4_f64 (57 columns = 4 tiles); peak = '
                          'FP64 matrix = vector peak of MI355X' if wide else
                          'one launch holds the slack LPs (n=%d m=%d) and the midpoint LPs (n=%d '
-                         'm=%d); FP64 vector FMA bound; peak = FP64 vector (= matrix) peak of '
-                         'MI355X' % (n_slack, m_slack, n_pt, m_pt) if persistent else
+                         'm=%d); the solver eliminates %d epigraph columns from the Newton systems '
+                         'and factorises %d / %d; FP64 issue bound (vector FMA + one matrix-core '
+                         'tile for the normal matrix, which holds the same double-precision pipe); '
+                         'peak = FP64 vector (= matrix) peak of MI355X'
+                         % (n_slack, m_slack, n_pt, m_pt, lay['nE'], n_slack - lay['nE'],
+                            n_pt - lay['nE']) if persistent else
                          'FP64 vector FMA bound (no f64 contraction >= 32 wide at n=25); peak = '
                          'FP64 vector (= matrix) peak of MI355X'),
                 'achieved': achieved, 'peak': FP64_PEAK_TFLOPS, 'unit': 'TFLOP/s',
                 'frac': achieved / FP64_PEAK_TFLOPS,
-                # the same launches priced with what the solver really executes (lower-triangular
-                # block pairs of the normal matrix, unsymmetric elimination at the compiled width)
+                # the same launches priced with what the solver really executes
+                # (flops_executed_per_iteration: matrix-core tile incl. its padding, unsymmetric
+                # elimination at the compiled width of the FACTORISED columns)
                 'achieved_executed': flops_x / decide_s / 1e12,
                 'frac_executed': flops_x / decide_s / 1e12 / FP64_PEAK_TFLOPS,
                 'flop_per_ipm_iteration': flops_per_iteration(n_slack, m_slack),
                 'flop_executed_per_ipm_iteration': flops_executed_per_iteration(
-                    n_slack, dims[3][1], m_slack, np_capacity(n_slack)),
+                    n_slack, dims[3][1], m_slack, lay['nE'], lay['LE']),
+                'eliminated_columns': lay['nE'],
+                'factorised_columns': {'slack': n_slack - lay['nE'], 'point': n_pt - lay['nE']},
                 'traffic': traffic,
                 'traffic_unit': 'HBM bytes per launch (rocprofv3 FETCH_SIZE x2 + WRITE_SIZE)',
                 'traffic_source': traffic_src,

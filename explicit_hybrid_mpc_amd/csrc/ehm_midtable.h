@@ -73,6 +73,8 @@ __device__ inline int mt_claim(const MidTable& M, unsigned long long tag, unsign
         unsigned long long s = __hip_atomic_load(&M.state[idx], __ATOMIC_RELAXED,
                                                  __HIP_MEMORY_SCOPE_AGENT);
         if (s == 0ull) {
+            // (relaxed: the claim publishes nothing -- the owner's payload follows with mt_publish,
+            // and a loser re-reads the word it lost to)
             unsigned long long expect = 0ull;
             if (__hip_atomic_compare_exchange_strong(&M.state[idx], &expect, tag | 1ull,
                                                      __ATOMIC_RELAXED, __ATOMIC_RELAXED,
@@ -129,7 +131,13 @@ __device__ inline void mt_publish(const MidTable& M, int slot, unsigned long lon
         else if (lane < 26) v = (grad && lane - 18 < p) ? grad[lane - 18] : 0.0;
         __hip_atomic_store(e + lane, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
-    // the write-through stores have completed (s_waitcnt) before the state word goes out
+    // Payload before state word, in the memory model's terms: the payload stores are agent-scope
+    // (write-through: they reach the device coherence point without an L2 write-back), a
+    // workgroup-scope release fence orders them before the state store for the compiler, and
+    // s_waitcnt(0) holds the wavefront until the hardware has completed them.  A full agent-scope
+    // RELEASE on the state store would say the same and cost a write-back of this XCD's whole L2
+    // (measured in round 2: 47 GB per partition); readers pair it with an agent-scope ACQUIRE fence
+    // (mt_read, the callers of mt_find).
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
     __builtin_amdgcn_s_waitcnt(0);
     if (lane == 0)
