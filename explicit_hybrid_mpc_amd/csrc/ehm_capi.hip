@@ -496,6 +496,9 @@ struct ehm_problem {
     int share_mid = 1;       // 1 = the persistent kernel keeps a table of midpoint optima: the
                              // simplices around an edge solve its midpoint once (DevTree::mt;
                              // option "share_midpoints")
+    int any_admissible = 0;  // multi-commutation engine: seed + 1 = V_R and bar_D return a hashed
+                             // draw among the admissible commutations instead of the canonical
+                             // one (ehm_hybrid.h, hy_draw; option "any_admissible"), 0 = canonical
     int hy_timing = 0;       // 1 = event pairs + counter snapshots around every batch of the
                              // multi-commutation engine (kernel seconds, solves by kind)
     int solver_gen = 2;      // 1 = one wavefront per workgroup (ehm_kernels.h), 2 = ehm_k2.hip
@@ -1198,6 +1201,11 @@ int ehm_problem_set_option(ehm_problem* P, const char* name, double value) {
     }
     if (!strcmp(name, "share_midpoints")) {
         P->share_mid = value != 0.0;
+        return EHM_OK;
+    }
+    if (!strcmp(name, "any_admissible")) {
+        if (value < 0.0 || value > 2e9) return fail(EHM_E_INVALID, "any_admissible: seed + 1, or 0");
+        P->any_admissible = (int)value;
         return EHM_OK;
     }
     return fail(EHM_E_INVALID, "unknown option '%s'", name);

@@ -262,6 +262,26 @@ __global__ void hy_retry_bits(int ns, int nd, int nw, const hy_u64* __restrict__
     retry[t] = r;
 }
 
+// "Any admissible commutation" (option any_admissible = seed + 1): the reference's V_R and bar_D
+// are FEASIBILITY problems -- Minimize(0), lib/oracle.py:201, 347 -- and which admissible
+// commutation comes back is its solver's choice.  The canonical rule below (first feasible / the
+// largest slack) is one such choice; this one draws uniformly by a hash of (seed, oracle, path
+// code of the node), so that a run can be repeated bit for bit and the CPU oracle
+// (oracle/oracle_cpu.py, rule 'hash') takes the same draws.  salt: 1 = V_R, 2 = bar_D.
+// draw >= HY_RULE_BASE: deterministic extremes instead of a draw, for the envelope of what the
+// choice can do to a tree -- bit 0: V_R returns the LAST commutation feasible at every vertex
+// (canonical: the first); bit 1: bar_D returns the admissible commutation with the SMALLEST slack
+// t* >= 0 (canonical: the largest).
+#define HY_RULE_BASE 0x40000000u
+__host__ __device__ inline uint32_t hy_draw(uint32_t draw, uint32_t salt, uint32_t code) {
+    unsigned long long z = ((unsigned long long)((draw - 1u) * 4u + salt) << 32) | code;
+    z += 0x9e3779b97f4a7c15ULL;
+    z = (z ^ (z >> 30)) * 0xbf58476d1ce4e5b9ULL;
+    z = (z ^ (z >> 27)) * 0x94d049bb133111ebULL;
+    z ^= z >> 31;
+    return (uint32_t)(z >> 32);
+}
+
 // One Worker.lcss decision per node (lib/worker.py:368-401 with the oracles of
 // lib/oracle.py:285-394): bar_E from the slacks of every commutation, then bar_D's choice.
 //   act: 0 closed, 1 split with the node's own commutation, 2 better commutation found (its
@@ -275,7 +295,7 @@ __global__ void hy_lcss_decide(DevTree T, const int32_t* __restrict__ frontier, 
                                hy_u64* __restrict__ neg, double* __restrict__ tneg,
                                hy_u64* __restrict__ cand, int32_t* __restrict__ act,
                                int32_t* __restrict__ best_out, double* __restrict__ ths,
-                               HyCtr* ctr) {
+                               HyCtr* ctr, uint32_t draw) {
     const int k = blockIdx.x * blockDim.x + threadIdx.x;
     if (k >= ns) return;
     const int id = frontier[k];
@@ -338,7 +358,45 @@ __global__ void hy_lcss_decide(DevTree T, const int32_t* __restrict__ frontier, 
     }
     atomicAdd(&ctr->ref_solves, 1ULL);
     int best = -1;
-    if (tbm >= 0.0) {
+    if (tbm >= 0.0 && draw) {
+        // any admissible commutation: the r-th of those with t* >= 0 (enumeration order)
+        int cnt = 0;
+        for (int d = 0; d < nd; ++d) {
+            if (!((feas[d >> 6] >> (d & 63)) & 1ULL)) continue;
+            if (!hy_bit(vall + (size_t)k * nw, d) || hy_bit(black + (size_t)id * nw, d)) continue;
+            if (tval[(size_t)k * nd + d] >= 0.0) ++cnt;
+        }
+        if (draw >= HY_RULE_BASE && !(draw & 2u)) {
+            cnt = 0;            // bar_D canonical (bit 1 clear): fall through to the rule below
+        } else if (draw >= HY_RULE_BASE) {
+            double tmin = INFINITY;         // smallest admissible slack, first in enumeration order
+            for (int d = 0; d < nd; ++d) {
+                if (!((feas[d >> 6] >> (d & 63)) & 1ULL)) continue;
+                if (!hy_bit(vall + (size_t)k * nw, d) || hy_bit(black + (size_t)id * nw, d)) continue;
+                const double t = tval[(size_t)k * nd + d];
+                if (t >= 0.0 && t < tmin) {
+                    tmin = t;
+                    best = d;
+                }
+            }
+        } else {
+            int r = (int)(hy_draw(draw, 2u, T.code[id]) % (uint32_t)cnt);
+            for (int d = 0; d < nd && best < 0; ++d) {
+                if (!((feas[d >> 6] >> (d & 63)) & 1ULL)) continue;
+                if (!hy_bit(vall + (size_t)k * nw, d) || hy_bit(black + (size_t)id * nw, d)) continue;
+                if (tval[(size_t)k * nd + d] >= 0.0 && r-- == 0) best = d;
+            }
+        }
+        if (cnt == 0) {
+            const double thr = tbm - tie_tol * (1.0 + fabs(tbm));
+            for (int d = 0; d < nd && best < 0; ++d) {
+                if (!((feas[d >> 6] >> (d & 63)) & 1ULL)) continue;
+                if (!hy_bit(vall + (size_t)k * nw, d) || hy_bit(black + (size_t)id * nw, d)) continue;
+                const double t = tval[(size_t)k * nd + d];
+                if (t >= 0.0 && t >= thr) best = d;
+            }
+        }
+    } else if (tbm >= 0.0) {
         const double thr = tbm - tie_tol * (1.0 + fabs(tbm));
         for (int d = 0; d < nd && best < 0; ++d) {
             if (!((feas[d >> 6] >> (d & 63)) & 1ULL)) continue;
@@ -620,12 +678,37 @@ __global__ void hy_ecc_classify(DevTree T, const int32_t* __restrict__ frontier,
                                 const hy_u64* __restrict__ black, int32_t* __restrict__ act,
                                 int32_t* __restrict__ best, double* __restrict__ ctrs,
                                 hy_u64* __restrict__ cask, long long* __restrict__ coff,
-                                HyCtr* ctr) {
+                                HyCtr* ctr, uint32_t draw) {
     const int k = blockIdx.x * blockDim.x + threadIdx.x;
     if (k >= ns) return;
     const int id = frontier[k];
     const int p = T.p, nv = p + 1;
     int found = -1;
+    if (draw) {
+        // any admissible commutation: the r-th of those feasible at every vertex
+        hy_u64 allw[4] = {0ULL, 0ULL, 0ULL, 0ULL};
+        int cnt = 0;
+        for (int w = 0; w < nw; ++w) {
+            hy_u64 all = hy_valid_word(nd, w) & ~black[(size_t)id * nw + w];
+            for (int v = 0; v < nv; ++v) all &= vf[((size_t)id * nv + v) * nw + w];
+            allw[w] = all;
+            cnt += __popcll(all);
+        }
+        if (cnt > 0) {
+            int r = (draw >= HY_RULE_BASE) ? ((draw & 1u) ? cnt - 1 : 0)
+                                           : (int)(hy_draw(draw, 1u, T.code[id]) % (uint32_t)cnt);
+            for (int w = 0; w < nw && found < 0; ++w) {
+                hy_u64 all = allw[w];
+                const int c = __popcll(all);
+                if (r >= c) {
+                    r -= c;
+                    continue;
+                }
+                while (r-- > 0) all &= all - 1ULL;          // drop the r lowest set bits
+                found = w * 64 + __ffsll((long long)all) - 1;
+            }
+        }
+    } else
     for (int w = 0; w < nw && found < 0; ++w) {
         hy_u64 all = hy_valid_word(nd, w) & ~black[(size_t)id * nw + w];
         for (int v = 0; v < nv; ++v) all &= vf[((size_t)id * nv + v) * nw + w];
@@ -1022,7 +1105,7 @@ static int hy_lcss_chunk(ehm_tree* T, const int32_t* fr, int ns, int32_t* next_l
                        H.tau.as<double>(), H.tval.as<double>(), H.st.as<int32_t>(),
                        H.alpha.as<double>(), EHM_SLIVER_TOL, EHM_TIE_TOL, T->run.max_depth,
                        H.prune, H.neg.as<hy_u64>(), H.tneg.as<double>(), H.cand.as<hy_u64>(), H.act.as<int32_t>(), H.best.as<int32_t>(),
-                       H.ths.as<double>(), ctr);
+                       H.ths.as<double>(), ctr, (uint32_t)P->any_admissible);
     // the nodes with a better commutation: its vertex solves and in_variability_ball
     hipLaunchKernelGGL(hy_delta_entries, HY_GRID(ns), 0, P->stream, T->dt, fr, ns,
                        H.act.as<int32_t>(), H.best.as<int32_t>(), H.dselV.as<int32_t>(),
@@ -1067,7 +1150,8 @@ static int hy_ecc_chunk(ehm_tree* T, const int32_t* fr, int ns, int32_t* next_ec
     hipLaunchKernelGGL(hy_ecc_classify, HY_GRID(ns), 0, P->stream, T->dt, fr, ns, nd, nw,
                        H.vf.as<hy_u64>(), H.black.as<hy_u64>(), H.act.as<int32_t>(),
                        H.best.as<int32_t>(),
-                       H.ths.as<double>(), H.ask.as<hy_u64>(), H.koff.as<long long>(), ctr);
+                       H.ths.as<double>(), H.ask.as<hy_u64>(), H.koff.as<long long>(), ctr,
+                       (uint32_t)P->any_admissible);
     // barycentre check of the nodes without a commutation feasible at every vertex
     hy_build_bits(T, H.ask.as<hy_u64>(), ns, H.koff.as<long long>());
     HY_TRY(hy_run_point(T, H.ths.as<double>(), 1, H.tau.as<double>(), nullptr, nullptr));
@@ -1209,10 +1293,12 @@ static int hy_begin(ehm_tree* T, int64_t n_roots, const ehm_node_init* init) {
     HIP_TRY(hipMemcpyAsync(H.ctr.ptr, &h, sizeof h, hipMemcpyHostToDevice, P->stream), EHM_E_HIP);
     HIP_TRY(hipStreamSynchronize(P->stream), EHM_E_HIP);      // didx / flags / h leave scope
     T->dt.code = nullptr;
-    if (R.shard_world > 1 && R.shard_min >= 0) {
-        if (R.deal_depth <= 0)
+    const bool sharded = R.shard_world > 1 && R.shard_min >= 0;
+    if (sharded || P->any_admissible) {
+        // path codes: the deal of a sharded run and the draws of option any_admissible hash them
+        if (sharded && R.deal_depth <= 0)
             return fail(EHM_E_INVALID, "sharded multi-commutation runs need ehm_run_opts.deal_depth");
-        H.deal = PersistDeal{0, R.deal_depth, R.shard_rank, R.shard_world, 1};
+        if (sharded) H.deal = PersistDeal{0, R.deal_depth, R.shard_rank, R.shard_world, 1};
         if ((rc = T->code.ensure((size_t)T->cap * 4))) return rc;
         T->dt.code = T->code.as<uint32_t>();
         std::vector<uint32_t> codes((size_t)n_roots);

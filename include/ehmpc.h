@@ -138,6 +138,16 @@ int ehm_problem_set_solver(ehm_problem* prob, int generation);
  * (ehm_tree_info.witness_table) and puts a node whose midpoint is being solved elsewhere back
  * into its queue instead of waiting, and the multi-commutation engine shares the results of its
  * point problems by (parameter, commutation, kind);
+ * "any_admissible" (seed + 1, default 0 = off; multi-commutation handles): V_R and bar_D return a
+ * draw among the ADMISSIBLE commutations -- feasible at every vertex; with t* >= 0 -- instead of
+ * the canonical one (first in enumeration order; largest slack).  The reference poses both as
+ * Minimize(0) (lib/oracle.py:201, 347): which admissible commutation comes back is its solver's
+ * choice, and its published cwh_z tree sizes (lib/post_process.py:489, 526) carry that choice.
+ * The draw is a hash of (seed, oracle, path code of the node), so a run repeats bit for bit and
+ * the CPU oracle (oracle/oracle_cpu.py, rule 'hash') takes the same draws; values 2^30 + m are
+ * deterministic extremes instead of draws (m bit 0: V_R returns the LAST commutation feasible at
+ * every vertex, bit 1: bar_D the admissible commutation with the SMALLEST slack): the envelope of
+ * what the choice can do to a tree (tools/cwh_jobs.py);
  * "work_first" (0|1, default 1): a wavefront of the persistent kernel that splits a node goes on
  * with one of the two children itself and queues the other (EHM_NO_WORKFIRST=1 disables);
  * "timing" (0|1, default 0): multi-commutation runs record an event pair and a counter snapshot

@@ -37,6 +37,19 @@ HIGHS_OPTIONS = dict(primal_feasibility_tolerance=1e-10, dual_feasibility_tolera
 TIE_TOL = 1e-6
 
 
+
+def hash_draw(seed, salt, code):
+    """csrc/ehm_hybrid.h::hy_draw with draw = seed + 1: splitmix64 of (4 seed + salt, path code),
+    upper 32 bits.  salt 1 = V_R, 2 = bar_D."""
+    mask = (1 << 64) - 1
+    z = ((((seed * 4 + salt) & 0xffffffff) << 32) | (code & 0xffffffff)) & mask
+    z = (z + 0x9e3779b97f4a7c15) & mask
+    z = ((z ^ (z >> 30)) * 0xbf58476d1ce4e5b9) & mask
+    z = ((z ^ (z >> 27)) * 0x94d049bb133111eb) & mask
+    z ^= z >> 31
+    return z >> 32
+
+
 class SolverError(RuntimeError):
     """Stands in for cvx.SolverError (lib/oracle.py:442)."""
 
@@ -73,6 +86,10 @@ class OracleCPU:
         #   t* >= -tau (1 + |V_0|) on, what a solver that accepts constraint violations of its
         #   feasibility tolerance does
         self.rng = None
+        # rule 'hash': the draw of the device's option "any_admissible" (csrc/ehm_hybrid.h,
+        # hy_draw): hash of (seed, oracle, path code of the node) -- PartitionCPU sets node_code
+        self.hash_seed = 0
+        self.node_code = 0
         self.verdict_tol = 0.
         # a QP solve that stalls is accepted below this residual / gap (the reference accepts
         # OPTIMAL_INACCURATE, lib/oracle.py:440-442); the studies loosen it
@@ -193,10 +210,15 @@ class OracleCPU:
         blacklist = set()                      # lib/oracle.py:198 delta_neq_other_deltas
         while True:
             found = None
-            if self.bar_d_rule == 'random':
+            if self.bar_d_rule in ('random', 'hash'):
                 ok = [d for d in range(len(self.models))
                       if d not in blacklist and self._feasible_on_vertices(R, d)]
-                found = ok[int(self.rng.integers(len(ok)))] if ok else None
+                if not ok:
+                    found = None
+                elif self.bar_d_rule == 'hash':
+                    found = ok[hash_draw(self.hash_seed, 1, self.node_code) % len(ok)]
+                else:
+                    found = ok[int(self.rng.integers(len(ok)))]
             else:
                 for d in range(len(self.models)):
                     if d not in blacklist and self._feasible_on_vertices(R, d):
@@ -257,6 +279,8 @@ class OracleCPU:
                 best = live[0]
             elif self.bar_d_rule == 'random':
                 best = live[int(self.rng.integers(len(live)))]
+            elif self.bar_d_rule == 'hash':
+                best = live[hash_draw(self.hash_seed, 2, self.node_code) % len(live)]
             else:
                 best = next(c for c in live if c[0] >= t_max - TIE_TOL * (1. + abs(t_max)))
             delta_star = self.deltas[best[1]].copy()

@@ -34,6 +34,16 @@ class PartitionCPU:
         self.volume_closed = 0.
         self.min_margin = np.inf
         self.truncated = False
+        # path codes of the nodes (root k: k; children 2 c, 2 c + 1 modulo 2^32 -- DevTree::code of
+        # the device), handed to the oracle before V_R / bar_D for its rule 'hash'
+        self.codes = {}
+
+    def _code(self, loc):
+        c = self.codes.get(loc)
+        if c is None:           # a child: its parent's location is loc[:-1]
+            c = (2 * self._code(loc[:-1]) + int(loc[-1])) & 0xffffffff
+            self.codes[loc] = c
+        return c
 
     # -- one node visit each -------------------------------------------------------------
     def _ecc_visit(self, loc, work):
@@ -41,6 +51,7 @@ class PartitionCPU:
         c_R = np.average(node['vertices'], axis=0)             # lib/worker.py:264
         if not self.oracle.P_theta(theta=c_R, check_feasibility=True):
             raise RuntimeError('STOP, Theta contains infeasible regions')
+        self.oracle.node_code = self._code(loc)
         delta_hat, vx = self.oracle.V_R(node['vertices'])       # lib/worker.py:268
         if delta_hat is None:
             S_1, S_2 = geometry.split_along_longest_edge(node['vertices'])[:2]
@@ -64,6 +75,7 @@ class PartitionCPU:
             node['is_epsilon_suboptimal'] = True
             self.volume_closed += geometry.simplex_volume(node['vertices'])
             return
+        orc.node_code = self._code(loc)
         delta_star, theta_star, new_vx, varies_little = orc.bar_D_delta_R(
             R=node['vertices'], V_delta_R=node['vertex_costs'],
             delta_ref=node['commutation'])
@@ -103,7 +115,8 @@ class PartitionCPU:
         must already carry commutation / vertex costs / vertex inputs).
         """
         work = []
-        for R, loc in zip(roots, locations):
+        for k, (R, loc) in enumerate(zip(roots, locations)):
+            self.codes[loc] = k
             self.nodes[loc] = R if isinstance(R, dict) else _new(R)
             work.append((loc, action))
         work.reverse()

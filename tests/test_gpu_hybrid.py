@@ -135,6 +135,50 @@ def test_blacklist_and_retry_after_a_failed_vertex_solve(monkeypatch):
     assert orc.n_blacklisted > 0
 
 
+def test_any_admissible_commutation_rule_identical_to_cpu_oracle():
+    """
+    Option "any_admissible" (csrc/ehm_hybrid.h, hy_draw): V_R and bar_D return a hashed draw among
+    the admissible commutations -- the reference's Minimize(0) leaves that choice to its solver
+    (lib/oracle.py:201, 347).  The CPU oracle takes the same draws (rule 'hash', path codes from
+    PartitionCPU): identical trees for every seed, and a tree different from the canonical rule's
+    for at least one of them (the rule does something).
+    """
+    from explicit_hybrid_mpc_amd import engine
+    from oracle.oracle_cpu import OracleCPU
+    from oracle.partition_cpu import PartitionCPU
+    from tests.test_gpu_partition import compare_trees
+    mpc = helpers.make_instance('pwa_small', 0)
+    eps_a = helpers.eps_a_rule(mpc, 0.25)
+    roots, locs = helpers.roots_of(mpc)
+    gp = engine.GpuProblem(mpc.compile(), eps_a, 0.2)
+    canonical = gp.partition(np.array(roots), action='ecc')
+    differs = 0
+    for seed in (0, 1, 2):
+        gp.set_option('any_admissible', seed + 1)
+        drawn = gp.partition(np.array(roots), action='ecc')
+        again = gp.partition(np.array(roots), action='ecc')
+        assert drawn.n_nodes == again.n_nodes           # a run repeats itself
+        assert_same_flat(drawn, again, locs)
+        orc = OracleCPU(mpc, eps_a, 0.2)
+        orc.memoize = True
+        orc.bar_d_rule = 'hash'
+        orc.hash_seed = seed
+        cpu = PartitionCPU(orc)
+        cpu.run(roots, locs, 'ecc')
+        for nd in cpu.nodes.values():
+            if nd['vertex_costs'] is None:
+                nd['vertex_costs'] = np.zeros(nd['vertices'].shape[0])
+        compare_trees(drawn, cpu.nodes, locs)
+        if drawn.n_nodes != canonical.n_nodes or \
+                not np.array_equal(np.sort(drawn.delta_idx), np.sort(canonical.delta_idx)):
+            differs += 1
+    gp.set_option('any_admissible', 0)
+    back = gp.partition(np.array(roots), action='ecc')
+    gp.close()
+    assert_same_flat(back, canonical, locs)
+    assert differs > 0
+
+
 def test_config3_subforests_identical_to_cpu_oracle():
     """
     BASELINE.json configs[2] dimensions (n_x = 4, n_u = 2, N = 5: 32 commutations, LPs of
