@@ -299,6 +299,12 @@ def parse_args(argv=None):
                          'cells are grown to completion)')
     ap.add_argument('--cells', type=int, default=0,
                     help='config5: Kuhn cells of the box that are grown (default: one per rank)')
+    ap.add_argument('--cells-at-once', type=int, default=0,
+                    help='config5: grow a rank\'s cells in groups of this many (0 = all of them '
+                         'together, sharing the launches); 1 = one cell after the other, each to '
+                         'completion -- what several host processes per GPU run (EHM_BENCH_BACKEND='
+                         'gloo + torch.distributed.run: the ranks share the GPU, the searches of '
+                         'one overlap the launches of the others)')
     ap.add_argument('--order', choices=['lcss-first', 'fifo', 'deepest'], default='lcss-first',
                     help='config5: visiting order of the search driver (bnb_frontier.grow_frontier; '
                          'the finished tree does not depend on it).  lcss-first (default) '
@@ -826,12 +832,24 @@ def measure_config5(args, ctx):
                     hist=orc.table.by_length.copy(), stalled=orc.table.stalled)
 
     def step():
-        orc.table.forget()
-        trees = [Tree(NodeData(vertices=kuhn_cell(half, c))) for c in my_cells]
-        stats = bnb_frontier.grow_frontier(orc, trees, 'ecc', order=args.order,
-                                           table_backoff=True, round_cap=args.round_cap,
-                                           min_regions=regions, max_visits=args.max_visits)
-        return stats, trees
+        group = args.cells_at_once if args.cells_at_once > 0 else max(len(my_cells), 1)
+        stats, trees = None, []
+        for g0 in range(0, len(my_cells), group):
+            orc.table.forget()
+            part = [Tree(NodeData(vertices=kuhn_cell(half, c))) for c in my_cells[g0:g0 + group]]
+            st = bnb_frontier.grow_frontier(orc, part, 'ecc', order=args.order,
+                                            table_backoff=True, round_cap=args.round_cap,
+                                            min_regions=regions, max_visits=args.max_visits)
+            trees += part
+            if stats is None:
+                stats = dict(st)
+            else:       # counters add up, flags combine
+                for k, v in st.items():
+                    if isinstance(v, bool):
+                        stats[k] = bool(stats.get(k)) or v
+                    elif isinstance(v, (int, float)):
+                        stats[k] = stats.get(k, 0) + v
+        return stats or dict(host_visits=0, handoffs=0, truncated=False), trees
 
     def barrier():
         if world > 1:
@@ -925,7 +943,8 @@ def measure_config5(args, ctx):
             'value': lp / elapsed_max, 'unit': 'LP solves/s',
             'regions_per_s': closed_t / elapsed_max,
             'oracle_calls_answered_per_s': micp / elapsed_max,
-            'n_gpus': world, 'steps': K, 'warmup': args.warmup,
+            'n_gpus': min(world, max(torch.cuda.device_count(), 1)), 'host_processes': world,
+            'steps': K, 'warmup': args.warmup,
             'ms_per_step': 1e3 * elapsed_max / K, 'ms_export': None,
             'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None, 'dtype': 'f64',
             'data': 'synthetic',
@@ -968,8 +987,11 @@ def measure_config5(args, ctx):
                           'fifo': 'level by level', 'deepest': 'deepest first'}[args.order] +
                          '; rounds of %d nodes' % args.round_cap,
                 'stopped_early': bool(any(st['truncated'] for st, _ in runs)),
-                'parallelism': '%d cell(s) over %d GPU(s): cell k on rank k mod world, no '
-                               'data-path collective' % (n_cells, world),
+                'parallelism': '%d cell(s) over %d host process(es) on %d GPU(s): cell k on rank k '
+                               'mod world, %s, no data-path collective' % (
+                                   n_cells, world, min(world, max(torch.cuda.device_count(), 1)),
+                                   'all of a rank\'s cells together' if args.cells_at_once <= 0
+                                   else '%d at a time' % args.cells_at_once),
             },
             'roofline': {
                 'bound': 'mfma' if dom == 'long' else 'valu-fp64',
