@@ -2808,6 +2808,8 @@ int ehm_partition_step(ehm_tree* T, int32_t max_sweeps, int64_t* frontier_size) 
 // Removes the LAST `count` nodes from the live frontier: their records [count][rec_doubles]
 // (vertices | vertex costs | vertex inputs), meta [count][2] = (commutation index, depth) and
 // node ids go to the caller; the nodes are flagged bit2 (owned by another rank).
+// (node_ids / records / meta may be HOST or DEVICE pointers -- hipMemcpyDefault: a multi-GPU
+// driver hands over device-resident blocks, e.g. torch tensors it then sends over xGMI)
 int ehm_partition_take(ehm_tree* T, int64_t count, int32_t* node_ids, double* records,
                        int32_t* meta) {
     if (!T || !T->run.active || !node_ids || !records || !meta || count < 0)
@@ -2829,12 +2831,12 @@ int ehm_partition_take(ehm_tree* T, int64_t count, int32_t* node_ids, double* re
     const int32_t* cur = (R.cur_is_a ? P->fr_a : P->fr_b).as<int32_t>() + (R.nf - count);
     hipLaunchKernelGGL(k_take_nodes, dim3((unsigned)count), dim3(64), 0, P->stream, T->dt, cur,
                        (int)count, nrec, P->out0.as<double>(), P->out2.as<int32_t>());
-    HIP_TRY(hipMemcpyAsync(node_ids, cur, (size_t)count * 4, hipMemcpyDeviceToHost, P->stream),
+    HIP_TRY(hipMemcpyAsync(node_ids, cur, (size_t)count * 4, hipMemcpyDefault, P->stream),
             EHM_E_HIP);
     HIP_TRY(hipMemcpyAsync(records, P->out0.ptr, (size_t)count * nrec * sizeof(double),
-                           hipMemcpyDeviceToHost, P->stream), EHM_E_HIP);
+                           hipMemcpyDefault, P->stream), EHM_E_HIP);
     HIP_TRY(hipMemcpyAsync(meta, P->out2.ptr, (size_t)count * 2 * sizeof(int32_t),
-                           hipMemcpyDeviceToHost, P->stream), EHM_E_HIP);
+                           hipMemcpyDefault, P->stream), EHM_E_HIP);
     HIP_TRY(hipStreamSynchronize(P->stream), EHM_E_HIP);
     R.nf -= count;
     R.given += count;
@@ -2875,9 +2877,9 @@ int ehm_partition_give(ehm_tree* T, int64_t count, const double* records, const 
         bigger.release();
     }
     HIP_TRY(hipMemcpyAsync(P->in0.ptr, records, (size_t)count * nrec * sizeof(double),
-                           hipMemcpyHostToDevice, P->stream), EHM_E_HIP);
+                           hipMemcpyDefault, P->stream), EHM_E_HIP);
     HIP_TRY(hipMemcpyAsync(P->in1.ptr, meta, (size_t)count * 2 * sizeof(int32_t),
-                           hipMemcpyHostToDevice, P->stream), EHM_E_HIP);
+                           hipMemcpyDefault, P->stream), EHM_E_HIP);
     hipLaunchKernelGGL(k_give_nodes, dim3((unsigned)count), dim3(64), 0, P->stream, T->dt,
                        (int)R.n_nodes, (int)count, nrec, P->in0.as<double>(),
                        P->in1.as<int32_t>(), fb.as<int32_t>(), (int)R.nf);

@@ -1458,12 +1458,12 @@ static int hy_take(ehm_tree* T, int64_t count, int32_t* node_ids, double* record
                        (int)count, H.nw, H.vf.as<hy_u64>(), H.cand.as<hy_u64>(),
                        H.neg.as<hy_u64>(), H.black.as<hy_u64>(), H.tneg.as<double>(),
                        P->out0.as<double>(), P->out2.as<int32_t>());
-    HIP_TRY(hipMemcpyAsync(node_ids, cur, (size_t)count * 4, hipMemcpyDeviceToHost, P->stream),
+    HIP_TRY(hipMemcpyAsync(node_ids, cur, (size_t)count * 4, hipMemcpyDefault, P->stream),
             EHM_E_HIP);
     HIP_TRY(hipMemcpyAsync(records, P->out0.ptr, (size_t)count * W * sizeof(double),
-                           hipMemcpyDeviceToHost, P->stream), EHM_E_HIP);
+                           hipMemcpyDefault, P->stream), EHM_E_HIP);
     HIP_TRY(hipMemcpyAsync(meta, P->out2.ptr, (size_t)count * 2 * sizeof(int32_t),
-                           hipMemcpyDeviceToHost, P->stream), EHM_E_HIP);
+                           hipMemcpyDefault, P->stream), EHM_E_HIP);
     HIP_TRY(hipStreamSynchronize(P->stream), EHM_E_HIP);
     H.n_lcss -= count;
     R.nf -= count;
@@ -1498,9 +1498,9 @@ static int hy_give(ehm_tree* T, int64_t count, const double* records, const int3
         bigger.release();
     }
     HIP_TRY(hipMemcpyAsync(P->in0.ptr, records, (size_t)count * W * sizeof(double),
-                           hipMemcpyHostToDevice, P->stream), EHM_E_HIP);
+                           hipMemcpyDefault, P->stream), EHM_E_HIP);
     HIP_TRY(hipMemcpyAsync(P->in1.ptr, meta, (size_t)count * 2 * sizeof(int32_t),
-                           hipMemcpyHostToDevice, P->stream), EHM_E_HIP);
+                           hipMemcpyDefault, P->stream), EHM_E_HIP);
     hipLaunchKernelGGL(hy_give_nodes, dim3((unsigned)count), dim3(64), 0, P->stream, T->dt,
                        (int)R.n_nodes, (int)count, H.nw, P->in0.as<double>(),
                        P->in1.as<int32_t>(), H.vf.as<hy_u64>(), H.cand.as<hy_u64>(),

@@ -152,7 +152,42 @@ def _exchange(run, plan, rank, device, rnd, log):
     import torch.distributed as dist
     nrec = run.nrec
     err = None
+    POISON = -(2 ** 31)         # meta word of a block its donor could not fill
     for donor, receiver, n in plan:
+        if device is not None:
+            # device-resident blocks, peer to peer (ncclSend / ncclRecv over xGMI): the records
+            # and the meta words never visit the host (ehm_partition_take / _give take device
+            # pointers).  Two messages per block: float64 records, int32 (commutation, depth).
+            if rank == donor:
+                rec_t = meta_t = None
+                if err is None:
+                    try:
+                        ids, rec_t, meta_t = run.take_device(n, device)
+                    except Exception as e:
+                        err = e
+                if rec_t is None:
+                    rec_t = torch.zeros((n, nrec), dtype=torch.float64, device=device)
+                    meta_t = torch.full((n, 2), POISON, dtype=torch.int32, device=device)
+                dist.send(rec_t, dst=receiver)
+                dist.send(meta_t, dst=receiver)
+                if err is None:
+                    log.append(dict(kind='give', round=rnd, peer=receiver, ids=ids))
+            elif rank == receiver:
+                rec_t = torch.empty((n, nrec), dtype=torch.float64, device=device)
+                meta_t = torch.empty((n, 2), dtype=torch.int32, device=device)
+                dist.recv(rec_t, src=donor)
+                dist.recv(meta_t, src=donor)
+                if bool((meta_t == POISON).any().item()):
+                    err = err or RuntimeError('rank %d could not hand over the %d nodes planned '
+                                              'for rank %d' % (donor, n, rank))
+                elif err is None:
+                    try:
+                        first = run.give_device(rec_t, meta_t)
+                        log.append(dict(kind='recv', round=rnd, peer=donor, first=first, count=n))
+                    except Exception as e:
+                        err = e
+            continue
+        # host path (gloo: CPU tensors)
         if rank == donor:
             buf = None
             if err is None:
@@ -164,16 +199,13 @@ def _exchange(run, plan, rank, device, rnd, log):
             if buf is None:
                 buf = np.full((n, nrec + 2), np.nan)
             t = torch.from_numpy(np.ascontiguousarray(buf))
-            if device is not None:
-                t = t.to(device)
             dist.send(t, dst=receiver)
             if err is None:
                 log.append(dict(kind='give', round=rnd, peer=receiver, ids=ids))
         elif rank == receiver:
-            t = torch.empty((n, nrec + 2), dtype=torch.float64,
-                            device=device if device is not None else 'cpu')
+            t = torch.empty((n, nrec + 2), dtype=torch.float64)
             dist.recv(t, src=donor)
-            buf = t.cpu().numpy()
+            buf = t.numpy()
             if np.isnan(buf[:, nrec:]).any():
                 err = err or RuntimeError('rank %d could not hand over the %d nodes planned for '
                                           'rank %d' % (donor, n, rank))

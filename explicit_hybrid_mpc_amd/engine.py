@@ -512,6 +512,35 @@ class PartitionRun:
         self.frontier -= count
         return ids, rec, meta
 
+    def take_device(self, count, device):
+        """``take`` into torch tensors on ``device`` (the block stays in device memory: the
+        multi-GPU driver sends it peer to peer).  Returns (node ids [numpy], records, meta)."""
+        import torch
+        count = int(count)
+        ids = np.empty(count, dtype=np.int32)
+        rec = torch.empty((count, self.nrec), dtype=torch.float64, device=device)
+        meta = torch.empty((count, 2), dtype=torch.int32, device=device)
+        check(self._lib.ehm_partition_take(self._tree, count, ptr(ids),
+                                           ctypes.c_void_p(rec.data_ptr()),
+                                           ctypes.c_void_p(meta.data_ptr())))
+        self.frontier -= count
+        return ids, rec, meta
+
+    def give_device(self, records, meta):
+        """``give`` from torch tensors in device memory (float64 (n, nrec), int32 (n, 2))."""
+        import torch
+        assert records.dtype == torch.float64 and meta.dtype == torch.int32
+        records, meta = records.contiguous(), meta.contiguous()
+        if records.is_cuda:
+            torch.cuda.current_stream(records.device).synchronize()    # e.g. a pending recv
+        first = ctypes.c_int32(0)
+        check(self._lib.ehm_partition_give(self._tree, records.shape[0],
+                                           ctypes.c_void_p(records.data_ptr()),
+                                           ctypes.c_void_p(meta.data_ptr()),
+                                           ctypes.addressof(first)))
+        self.frontier += records.shape[0]
+        return int(first.value)
+
     def give(self, records, meta):
         """Adopt nodes another rank took from its frontier; returns the id of the first one."""
         rec = f64(records).reshape(-1, self.nrec)

@@ -305,7 +305,10 @@ int ehm_partition_run(ehm_problem* prob, int64_t n_roots, const double* root_ver
  *            meta [count][2] = (commutation index, depth); the nodes get flag bit2;
  *   give   : appends count nodes produced by another rank's take to the pool (flag bit5)
  *            and to the live frontier; *first_id = node id of the first one;
- *   finish : totals for ehm_tree_info_get / ehm_tree_export (required before either). */
+ *   finish : totals for ehm_tree_info_get / ehm_tree_export (required before either).
+ * The buffers of take (node_ids, records, meta) and give (records, meta) may be HOST or DEVICE
+ * pointers (hipMemcpyDefault): the multi-GPU driver hands device-resident blocks -- torch tensors --
+ * straight to ncclSend / ncclRecv, no staging through the host. */
 int ehm_partition_begin(ehm_problem* prob, int64_t n_roots, const double* root_vertices,
                         const ehm_node_init* init, const ehm_run_opts* opts, ehm_tree** out);
 int ehm_partition_step(ehm_tree* tree, int32_t max_sweeps, int64_t* frontier_size);

@@ -14,7 +14,28 @@ from tests import helpers
 pytestmark = pytest.mark.gpu
 
 
-def test_moved_frontier_nodes_give_the_same_tree():
+@pytest.mark.parametrize('device_blocks', [False, True])
+def test_moved_frontier_nodes_give_the_same_tree(device_blocks):
+    """device_blocks: the hand-over through torch tensors in DEVICE memory (take_device /
+    give_device: what distributed._exchange sends peer to peer under RCCL) instead of numpy."""
+    if device_blocks:
+        # torch brings its own HIP runtime: it has to initialise before libehmpc's does (as in
+        # bench.py, which imports torch first) or it finds no device -- a process of its own
+        import os
+        import subprocess
+        import sys
+        root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+        code = ('import torch; torch.cuda.init(); import sys; sys.path.insert(0, %r); '
+                'from tests.test_gpu_rebalance import _moved_frontier_nodes; '
+                '_moved_frontier_nodes(True); print("DEVICE_BLOCKS_OK")' % root)
+        r = subprocess.run([sys.executable, '-c', code], capture_output=True, text=True, cwd=root)
+        assert r.returncode == 0 and 'DEVICE_BLOCKS_OK' in r.stdout, \
+            r.stdout[-3000:] + r.stderr[-3000:]
+        return
+    _moved_frontier_nodes(False)
+
+
+def _moved_frontier_nodes(device_blocks):
     from explicit_hybrid_mpc_amd import distributed, engine, examples
     from explicit_hybrid_mpc_amd import tools as ehm_tools
     mpc = helpers.make_instance('lin', 0)
@@ -38,9 +59,14 @@ def test_moved_frontier_nodes_give_the_same_tree():
         # make the exchange bite: rank 0 works at half speed in this emulation
         plan = distributed.balance_plan(counts, tolerance=0.02, min_move=4)
         for donor, receiver, n in plan:
-            ids, rec, meta = runs[donor].take(n)
-            assert rec.shape == (n, runs[donor].nrec) and meta.shape == (n, 2)
-            first = runs[receiver].give(rec, meta)
+            if device_blocks:
+                ids, rec, meta = runs[donor].take_device(n, 'cuda:0')
+                assert rec.is_cuda and meta.is_cuda and tuple(rec.shape) == (n, runs[donor].nrec)
+                first = runs[receiver].give_device(rec.clone(), meta.clone())
+            else:
+                ids, rec, meta = runs[donor].take(n)
+                assert rec.shape == (n, runs[donor].nrec) and meta.shape == (n, 2)
+                first = runs[receiver].give(rec, meta)
             logs[donor].append(dict(kind='give', round=rnd, peer=receiver, ids=ids))
             logs[receiver].append(dict(kind='recv', round=rnd, peer=donor, first=first, count=n))
             moved += n
