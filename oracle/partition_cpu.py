@@ -40,8 +40,16 @@ class PartitionCPU:
 
     def _code(self, loc):
         c = self.codes.get(loc)
-        if c is None:           # a child: its parent's location is loc[:-1]
-            c = (2 * self._code(loc[:-1]) + int(loc[-1])) & 0xffffffff
+        if c is None:
+            # a child: the nearest ancestor with a known code, then one bit per turn.  (A run whose
+            # nodes were injected without ``run`` -- bench.py's CPU-baseline workers -- has no root
+            # codes: code 0 at the top; only the rule 'hash' of the oracle reads them.)
+            k = len(loc)
+            while k > 0 and loc[:k] not in self.codes:
+                k -= 1
+            c = self.codes.get(loc[:k], 0)
+            for ch in loc[k:]:
+                c = (2 * c + (1 if ch == '1' else 0)) & 0xffffffff
             self.codes[loc] = c
         return c
 

@@ -379,3 +379,12 @@ def test_a_failing_secondary_workload_does_not_cost_the_headline(monkeypatch):
     assert line['config'] == {'workload': 'w', 'regions_per_step': 7}
     assert line['roofline'] == {'frac': 0.1} and line['cpu_baseline'] == {'value': 5.}
     assert isinstance(args, argparse.Namespace) and args.workload == 'config2'   # untouched
+
+
+def test_cpu_baseline_leg_of_the_bench_runs():
+    """bench.py's ``cpu_baseline`` leg (the oracle port on the host cores) injects nodes into
+    PartitionCPU without ``run``: it must work on a partition whose path codes were never seeded
+    (round 4: a recursion there would have failed the driver's bench run)."""
+    import bench
+    out = bench.cpu_baseline('config2', 0, 0.0216306, 0.01, 1.0)
+    assert out['value'] > 0 and out['kind'] == 'port' and out['cores'] >= 1
