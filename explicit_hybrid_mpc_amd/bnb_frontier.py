@@ -479,7 +479,8 @@ def _hand_off(oracle, nodes, table_max, engine_opts, stats, above=None, costs=No
 
 def grow_frontier(oracle, branch, action='ecc', table_max=256, max_visits=None, handoff=True,
                   engine_opts=None, split_batch=None, round_cap=4096, log=None,
-                  table_backoff=False, order='fifo', min_regions=None, deadline=None):
+                  table_backoff=False, order='fifo', min_regions=None, deadline=None,
+                  created_log=None):
     """
     ``bnb.grow`` with all pending nodes visited together (module docstring).  Same arguments and
     the same tree; ``round_cap`` bounds the nodes of one round, ``split_batch(R (n,p+1,p)) ->
@@ -701,6 +702,11 @@ def grow_frontier(oracle, branch, action='ecc', table_max=256, max_visits=None, 
                                  vertex_inputs=in_1),
                         NodeData(vertices=S2[k].copy(), commutation=delta, vertex_costs=co_2,
                                  vertex_inputs=in_2))
+                if created_log is not None:
+                    # what the children were CREATED with (a later visit of a child may adopt
+                    # another commutation in place, lib/worker.py:396-401): for parity tests
+                    created_log[id(nd.left)] = (np.array(delta, copy=True), co_1.copy())
+                    created_log[id(nd.right)] = (np.array(delta, copy=True), co_2.copy())
                 push(nd.left, 'lcss', down, nd)
                 push(nd.right, 'lcss', down, nd)
             for k, (nd, delta, _, wit, _) in enumerate(to_split):

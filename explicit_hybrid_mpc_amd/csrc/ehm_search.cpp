@@ -752,6 +752,11 @@ int ehm_search_bare_asks(const ehm_search_bare* b, uint64_t* code, int32_t* owne
 int ehm_search_bare_answer(ehm_search_bare* b, const double* t, int64_t* n_active) {
     if (!b || !b->pending || (!b->ask.empty() && !t))
         return fail(EHM_E_INVALID, "ehm_search_bare_answer: no step in flight");
+    // an unknown value must never prune: a slack that is not a number (a solve that failed in a
+    // table which does not raise) is refused, the step stays in flight
+    for (size_t a = 0; a < b->ask.size(); ++a)
+        if (t[a] != t[a])
+            return fail(EHM_E_INVALID, "ehm_search_bare_answer: a slack is not a number");
     try {
         for (size_t a = 0; a < b->ask.size(); ++a) {
             const size_t k = (size_t)b->ask[a];
@@ -767,7 +772,7 @@ int ehm_search_bare_answer(ehm_search_bare* b, const double* t, int64_t* n_activ
                 if (open) continue;                         // (the Python form breaks here)
                 const double tq = b->kid_val[k];
                 if (!(tq >= 0.0)) {
-                    const double a = tq < 0 ? -tq : tq;     // NaN never refutes anything below
+                    const double a = -tq;
                     if (a < b->refuted[(size_t)j]) b->refuted[(size_t)j] = a;
                 } else if (b->kid_len[k] == b->N) {
                     b->state[(size_t)j] = 0;

@@ -160,7 +160,9 @@ class PWAMPC:
     def with_horizon(self, N):
         """The same law over the first ``N`` steps (infinity-norm cost: the stage costs are a plain
         sum, so the relaxation of a mode prefix of at most ``N`` steps -- the undecided steps cost
-        nothing and constrain nothing -- is the same problem in either horizon)."""
+        nothing and constrain nothing PROVIDED u = 0 is admissible, G_u 0 <= g_u, which
+        ``sequences.short_horizon`` checks before it offers the split -- is the same problem in
+        either horizon)."""
         if self.cost_type != 'inf':
             raise ValueError('with_horizon: the quadratic cost has a terminal term')
         return PWAMPC(self.A, self.B, self.w, self.regions, self.Gx, self.gx, self.Gu, self.gu,

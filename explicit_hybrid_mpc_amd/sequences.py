@@ -696,6 +696,13 @@ def short_horizon(mpc, max_cols=32, max_rows=256):
     or if the whole model fits them anyway."""
     if mpc.cost_type != 'inf':
         return 0
+    # The relaxation of a prefix as a block of the FULL model keeps the input rows and the
+    # ||R u|| epigraphs of the undecided steps; they vanish from the optimum -- and the block of
+    # the shorter horizon is the same problem -- exactly when u = 0 is admissible there (it then
+    # costs nothing).  Otherwise the short block's optimum is lower by a constant: still a bound,
+    # but not the same search, so the split is not offered.
+    if mpc.Gu.shape[0] and np.any(mpc.Gu @ np.zeros(mpc.n_u) > np.asarray(mpc.gu).ravel()):
+        return 0
     p = mpc.n_x
     rows_per_step = mpc.Gx.shape[0] + mpc.Gu.shape[0] + 2 * (mpc.Q.shape[0] + mpc.R.shape[0]) + \
         max((0 if r is None else r[0].shape[0]) for r in mpc.regions)
@@ -717,7 +724,8 @@ class SplitPrefixTable(PrefixSearch):
     constrains and prices the first k steps only; as a block of the full model it is a 49 x 379
     LP (config 5) of which k/N is alive, and it runs on the wide kernels.  Here every prefix of
     at most ``short`` steps is solved as a block of the SAME law with horizon ``short``
-    (``PWAMPC.with_horizon``: the same problem, the same optimum, the same first input) -- 29
+    (``PWAMPC.with_horizon``: the same problem, the same optimum, the same first input, given
+    that u = 0 is an admissible input -- ``short_horizon`` checks it) -- 29
     columns x 199 rows at short = 4, a size the shared-block kernels (one wavefront per LP, the
     constant block in LDS) solve an order of magnitude faster.  On config 5 at its stated
     tolerance 94 % of the suboptimality-test problems of the searches are such prefixes

@@ -100,7 +100,9 @@ int ehm_search_descent_result(ehm_search* s, int32_t* sequence, int64_t* steps);
  * seeded by the caller; an inherited upper bound, kept only where it refutes: t < -guard) need no
  * problem, the rest is the ask list of ONE launch.  With the answers: t < 0 refutes a child, a
  * full sequence with t >= 0 proves the node open, any other child is queued; an empty queue
- * closes the node.  Expansion order, ask order and ties are those of heapq on (-t, prefix). */
+ * closes the node.  Expansion order, ask order and ties are those of heapq on (-t, prefix).
+ * An answer holding a NaN is refused (EHM_E_INVALID, the step stays in flight): an unknown value
+ * must never prune. */
 typedef struct ehm_search_bare ehm_search_bare;
 int ehm_search_bare_create(int32_t n, int32_t n_modes, int32_t N, const double* guard,
                            ehm_search_bare** out);

@@ -137,7 +137,12 @@ int ehm_problem_set_solver(ehm_problem* prob, int generation);
  * persistent kernel looks up the midpoints of a node's OTHER edges as witnesses of openness
  * (ehm_tree_info.witness_table) and puts a node whose midpoint is being solved elsewhere back
  * into its queue instead of waiting, and the multi-commutation engine shares the results of its
- * point problems by (parameter, commutation, kind);
+ * point problems by (parameter, commutation, kind).  With the table on, WHICH valid witness a
+ * node records (its own midpoint's, another edge's that a neighbour happened to have published,
+ * an LP's) depends on the order wavefronts reach the table, so ehm_tree_info's solve and witness
+ * counters, min_margin and the stored witnesses vary by a fraction of a percent between runs;
+ * every verdict is taken with the same margin rule, and the tree (structure, vertices, vertex
+ * costs, flags) does not vary.  "share_midpoints" = 0 gives run-to-run identical counters;
  * "any_admissible" (seed + 1, default 0 = off; multi-commutation handles): V_R and bar_D return a
  * draw among the ADMISSIBLE commutations -- feasible at every vertex; with t* >= 0 -- instead of
  * the canonical one (first in enumeration order; largest slack).  The reference poses both as

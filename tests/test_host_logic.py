@@ -345,6 +345,13 @@ def test_config5_helpers_of_the_benchmark():
     assert sequences.short_horizon(big) == 4                  # 29 x 195 fits, 34 columns do not
     assert sequences.short_horizon(examples.pwa4_mpc(N=4)) == 0          # fits as it is
     assert sequences.short_horizon(helpers.make_instance('pwa_small', 0)) == 0
+    # the blocks of the two horizons are the same problem only where u = 0 is admissible (the
+    # undecided steps of the full model then cost nothing): no split otherwise
+    import copy
+    shifted = copy.copy(big)
+    shifted.gu = np.asarray(big.gu, dtype=np.float64).copy()
+    shifted.gu[0] = -0.1
+    assert sequences.short_horizon(shifted) == 0
     four = big.with_horizon(4)
     assert four.N == 4 and four.delta_size == big.delta_size
     G4, _, _ = four.condense_prefix((2, 1))

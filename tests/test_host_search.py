@@ -519,6 +519,13 @@ def test_best_first_queue_protocol_and_its_error_paths():
         assert lib.ehm_search_bare_step(h, 4, ctypes.byref(n_ask), ctypes.byref(left)) != 0   # in flight
         asked += [(int(j), prefix(int(q))) for q, j in zip(c, o)]
         t = np.array([slack(int(j), prefix(int(q))) for q, j in zip(c, o)])
+        if steps == 1:
+            # a slack that is not a number (a failed solve) must not prune: refused, the step
+            # stays in flight and takes the real answers
+            bad = t.copy()
+            bad[0] = np.nan
+            assert lib.ehm_search_bare_answer(h, ptr(bad), ctypes.byref(left)) != 0
+            assert b'not a number' in lib.ehm_search_last_error()
         assert lib.ehm_search_bare_answer(h, ptr(t), ctypes.byref(left)) == 0
     counts = np.zeros(2, dtype=np.int64)
     assert lib.ehm_search_bare_result(h, ptr(closed), ptr(margin), ptr(counts)) == 0
