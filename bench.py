@@ -622,7 +622,9 @@ def measure(args, ctx):
                                 if static else
                                 ': rank 0 owns the roots; budgeted rounds of the persistent '
                                 'kernel (4096 node visits, doubling), after each an all-gather of '
-                                'the frontier sizes and point-to-point node records'
+                                'the frontier sizes and point-to-point node records (every s-th '
+                                'entry of a donor frontier); once a round ends balanced with >= '
+                                '4096 nodes on every rank, one unbudgeted launch per rank'
                                 if (args.engine == 1 and args.solver == 2 and not wide) else
                                 ', rebalanced every %d sweeps (all-gather of frontier sizes + '
                                 'point-to-point node records)' % args.sweeps_per_round),

@@ -2828,6 +2828,27 @@ int ehm_partition_take(ehm_tree* T, int64_t count, int32_t* node_ids, double* re
     int rc;
     if ((rc = P->out0.ensure((size_t)count * nrec * sizeof(double)))) return rc;
     if ((rc = P->out2.ensure((size_t)count * 2 * sizeof(int32_t)))) return rc;
+    // A representative sample of the frontier, not its newest (deepest, smallest) nodes: every
+    // s-th queue entry, s = nf / count.  The frontier is permuted into the other buffer as
+    // [what stays | what goes] by strided device copies.
+    const long long stride = R.nf / count;
+    if (stride >= 2 && !getenv("EHM_TAKE_NEWEST")) {
+        DevBuf& src = R.cur_is_a ? P->fr_a : P->fr_b;
+        DevBuf& dst = R.cur_is_a ? P->fr_b : P->fr_a;
+        if ((rc = dst.ensure((size_t)R.nf * 4 * 2))) return rc;
+        const int32_t* a = src.as<int32_t>();
+        int32_t* b = dst.as<int32_t>();
+        const long long rest = R.nf - count, tail = R.nf - count * stride;
+        HIP_TRY(hipMemcpy2DAsync(b + rest, 4, a, (size_t)stride * 4, 4, (size_t)count,
+                                 hipMemcpyDeviceToDevice, P->stream), EHM_E_HIP);
+        HIP_TRY(hipMemcpy2DAsync(b, (size_t)(stride - 1) * 4, a + 1, (size_t)stride * 4,
+                                 (size_t)(stride - 1) * 4, (size_t)count,
+                                 hipMemcpyDeviceToDevice, P->stream), EHM_E_HIP);
+        if (tail > 0)
+            HIP_TRY(hipMemcpyAsync(b + count * (stride - 1), a + count * stride, (size_t)tail * 4,
+                                   hipMemcpyDeviceToDevice, P->stream), EHM_E_HIP);
+        R.cur_is_a = !R.cur_is_a;
+    }
     const int32_t* cur = (R.cur_is_a ? P->fr_a : P->fr_b).as<int32_t>() + (R.nf - count);
     hipLaunchKernelGGL(k_take_nodes, dim3((unsigned)count), dim3(64), 0, P->stream, T->dt, cur,
                        (int)count, nrec, P->out0.as<double>(), P->out2.as<int32_t>());

@@ -257,7 +257,8 @@ def _publish(status, worker, run, live, device, rank, force=False):
 def run_balanced(gp, roots, action='ecc', init=None, max_nodes=0, min_frontier=1024,
                  sweeps_per_round=3, tolerance=0.1, min_move=16, device=None, export=False,
                  with_volume=False, run_factory=None, status=None, publish_status=False,
-                 engine='sweeps', pops_per_round=4096, pops_max=1 << 17, max_depth=0):
+                 engine='sweeps', pops_per_round=4096, pops_max=1 << 17, max_depth=0,
+                 settle_frontier=4096):
     """
     One partition over all ranks with periodic rebalancing of the live frontiers.
     Returns (FlatTree or info dict of THIS rank's share, transfer log, rounds).
@@ -269,6 +270,16 @@ def run_balanced(gp, roots, action='ecc', init=None, max_nodes=0, min_frontier=1
     (``PartitionRun.advance``: pops_per_round node visits, doubling every round up to pops_max)
     instead of sweeps; rank 0 owns the roots, the other ranks start empty and are fed by the
     first rounds -- nothing is replicated.
+    settle_frontier (persistent engine, > 0): once a round ends with the frontiers balanced (no
+    transfer planned at ``tolerance``) and at least this many nodes on EVERY rank, the ranks --
+    which all hold the same all-gathered counts, so they decide alike -- grow what they hold to
+    completion in ONE unbudgeted launch.  Budgeted launches queue both children of every split
+    (what they leave must be a plain queue slice that ``take`` can cut); the unbudgeted launch
+    is the single-GPU engine at full speed (kept child visited from LDS, nodes put back instead
+    of waited for), so the rounds cost their overhead only while the work is being spread.
+    0 = rebalance to the end (needed where sub-tree sizes under the frontier vary by more than
+    the final imbalance one accepts; ``publish_status`` runs never settle: they report per
+    round).
     """
     import torch.distributed as dist
     rank, _, world = env_rank_world()
@@ -302,11 +313,12 @@ def run_balanced(gp, roots, action='ecc', init=None, max_nodes=0, min_frontier=1
             raise err
         raise RuntimeError('partition run failed on rank(s) %s' % who)
 
+    settled = False
     while True:
         err = None
         try:
             if persistent:
-                n = run.advance(budget if (world > 1 or publish_status) else 0)
+                n = run.advance(budget if ((world > 1 or publish_status) and not settled) else 0)
                 budget = min(2 * budget, int(pops_max))
             else:
                 n = run.step(sweeps_per_round if (world > 1 or publish_status) else 0)
@@ -344,6 +356,12 @@ def run_balanced(gp, roots, action='ecc', init=None, max_nodes=0, min_frontier=1
             if k >= min_move:
                 plan.append((donor, receiver, k))
                 room[receiver] -= k
+        if (persistent and settle_frontier > 0 and not publish_status and not plan and
+                int(counts.min()) >= int(settle_frontier)):
+            settled = True          # every rank sees the same counts: the next launch is the last
+            log.append(dict(kind='settle', round=rnd, counts=[int(c) for c in counts]))
+            rnd += 1
+            continue
         try:
             _exchange(run, plan, rank, device, rnd, log)
         except Exception as e:

@@ -305,7 +305,9 @@ int ehm_partition_run(ehm_problem* prob, int64_t n_roots, const double* root_ver
  *   begin  : uploads the roots (and runs the 'ecc' vertex solves);
  *   step   : up to max_sweeps frontier sweeps (<= 0: until the frontier is empty);
  *            *frontier_size = live frontier nodes afterwards;
- *   take   : removes the LAST count frontier nodes: node_ids [count], records
+ *   take   : removes count frontier nodes -- every s-th entry of the frontier, s = size / count,
+ *            a sample of all its depths (single-commutation runs; the newest count entries if
+ *            s < 2, on multi-commutation runs, or with EHM_TAKE_NEWEST=1): node_ids [count], records
  *            [count][(p+1)p + (p+1) + (p+1)n_u] (vertices | vertex costs | vertex inputs),
  *            meta [count][2] = (commutation index, depth); the nodes get flag bit2;
  *   give   : appends count nodes produced by another rank's take to the pool (flag bit5)

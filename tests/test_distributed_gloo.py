@@ -200,9 +200,11 @@ def _worker_balanced(rank, world, port, out_dir, engine='sweeps'):
     distributed.init_process_group('gloo')
     mpc = helpers.make_instance('di', 0)
     roots, locs = helpers.roots_of(mpc)
+    settle = engine == 'persistent-settle'
     part, log, rounds = distributed.run_balanced(
-        None, roots, min_frontier=6, sweeps_per_round=1, tolerance=0., min_move=1, export=True,
-        engine=engine, pops_per_round=3, pops_max=24,
+        None, roots, min_frontier=6, sweeps_per_round=1, tolerance=0.34 if settle else 0.,
+        min_move=1, export=True, engine='persistent' if settle else engine, pops_per_round=3,
+        pops_max=24, settle_frontier=3 if settle else 0,
         run_factory=lambda shard: CpuRun(mpc, 0.3, 0.02, roots, shard))
     with open(os.path.join(out_dir, 'bal%d.pkl' % rank), 'wb') as f:
         pickle.dump(dict(part=part, log=log, rounds=rounds), f)
@@ -283,12 +285,14 @@ def test_balance_plan_is_deterministic_and_evens_out():
     assert donors.isdisjoint({r for _, r, _ in plan})                 # nobody relays
 
 
-@pytest.mark.parametrize('engine', ['sweeps', 'persistent'])
+@pytest.mark.parametrize('engine', ['sweeps', 'persistent', 'persistent-settle'])
 def test_two_ranks_rebalance_and_merge(tmp_path, engine):
     """
     run_balanced over gloo: frontier nodes really move, and the merged tree is the tree.
     'sweeps': sweep rounds after a deal by position; 'persistent': budgeted rounds of the
-    (emulated) persistent kernel from a single source -- rank 1 starts with nothing.
+    (emulated) persistent kernel from a single source -- rank 1 starts with nothing;
+    'persistent-settle': the same until a round ends balanced with enough nodes on both ranks,
+    then one unbudgeted launch each (run_balanced's settle_frontier).
     """
     import pickle
     from explicit_hybrid_mpc_amd import distributed
@@ -301,6 +305,15 @@ def test_two_ranks_rebalance_and_merge(tmp_path, engine):
     moved = sum(len(e['ids']) for o in outs for e in o['log'] if e['kind'] == 'give')
     got = sum(e['count'] for o in outs for e in o['log'] if e['kind'] == 'recv')
     assert moved == got and moved > 0
+    settles = [[e for e in o['log'] if e['kind'] == 'settle'] for o in outs]
+    if engine == 'persistent-settle':
+        # both ranks took the decision in the same round on the same counts, and the launch
+        # after it was the last
+        assert len(settles[0]) == 1 and settles[0] == settles[1]
+        assert min(settles[0][0]['counts']) >= 3
+        assert outs[0]['rounds'] == outs[1]['rounds'] == settles[0][0]['round'] + 1
+    else:
+        assert not settles[0] and not settles[1]
     mpc = helpers.make_instance('di', 0)
     roots, locs = helpers.roots_of(mpc)
     full = sweep_partition_cpu(mpc, 0.3, 0.02, roots, 0, 1, 0)
