@@ -4,7 +4,7 @@ other: per-rank work and time, speed-up = full run / slowest shard.
   (ehm_run_opts.deal_depth -- what bench.py --gpus N runs);
   mode "sweeps": the round-1 scheme (sweeps until the frontier holds min_frontier nodes, deal by
   position, then one persistent launch per share).
-usage: shard_balance.py [deal|sweeps] [abs_frac] [config2|config4]
+usage: shard_balance.py [deal|sweeps] [abs_frac] [config2|config4] [log2 of the node pool, 24]
   config4 = BASELINE configs[3] (n_x = 6, N = 10: the wide kernels, level-synchronous sweeps, 652
   roots, eps_r 0.25, abs_frac 0.4 as bench.py --workload config4): only the "sweeps" dealing
   exists there."""
@@ -26,7 +26,7 @@ gp = engine.GpuProblem(mpc.compile(), 1., 1.)
 V = examples.box_vertices(examples.theta_box(mpc))
 gp.set_eps(float(np.max(gp.solve_pt(abs_frac * V)[0])), 0.25 if wide else 0.01)
 roots, _ = ehm_tools.delaunay_roots(V)
-cap = 1 << 24
+cap = 1 << (int(sys.argv[4]) if len(sys.argv) > 4 else 24)
 gp.partition(roots, export=False, with_volume=False, max_nodes=cap)
 full = gp.partition(roots, export=False, with_volume=False, max_nodes=cap)
 print('full: nodes', full['n_nodes'], 'LPs', full['lp_solves'], 'ms', 1e3 * full['device_seconds'], flush=True)
@@ -35,7 +35,7 @@ for world in (2, 4, 8):
                   dict(deal_depth=distributed.deal_depth_for(len(roots), world, pr),
                        shard=(None, world, 0))) for pr in (128, 1024, 2048, 4096)]
                 if mode == 'deal' else
-                [('min_frontier %d' % mf, dict(shard=(None, world, mf))) for mf in (64 * world, 1024 * world)])
+                [('min_frontier %d' % mf, dict(shard=(None, world, mf))) for mf in (64 * world, 1024 * world, 4096 * world)])
     for label, kw in variants:
         lp, ms, rep, nodes = [], [], 0, 0
         for r in range(world):
