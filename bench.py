@@ -310,7 +310,7 @@ def parse_args(argv=None):
                          'the finished tree does not depend on it).  lcss-first (default) '
                          'completes subtrees; fifo goes level by level -- with --regions it closes '
                          'the cells that need no refinement first')
-    ap.add_argument('--round-cap', type=int, default=2048,
+    ap.add_argument('--round-cap', type=int, default=4096,
                     help='config5: nodes visited together in one round of the search driver (their '
                          'problems share the launches)')
     ap.add_argument('--max-visits', type=int, default=None,
@@ -1055,7 +1055,7 @@ def secondary_line(args, ctx, workload, steps, warmup):
     a.abs_frac = a.eps_r = a.max_depth = None
     a.cpu_seconds = args.secondary_cpu_seconds
     a.regions = a.cells = 0
-    a.order, a.max_visits, a.round_cap = 'lcss-first', None, 2048
+    a.order, a.max_visits, a.round_cap = 'lcss-first', None, 4096
     a.status_dir = None
     a.engine, a.solver, a.decide_full = 1, 2, False
     a.no_mid_first = a.no_inherit_witness = False

@@ -13,6 +13,7 @@ matter -- a node's fate depends on its own record only (lib/worker.py:241-417).
 
 import ctypes
 import heapq
+import os
 import time
 
 import numpy as np
@@ -110,7 +111,11 @@ def p_theta_many(oracle, thetas):
 
 INHERIT_GUARD = 1e-6     # an inherited bound counts only by more than INHERIT_GUARD (1 + max |V|): ten
                          # times the accuracy the device solver's optima are compared at (1e-7)
-LAUNCH_TARGET = 4096     # problems a best-first step aims at per launch
+# problems a best-first step aims at per launch.  One launch costs about the latency of one LP
+# whatever it holds up to a few thousand problems, so the steps of a round are wide: on config 5
+# 65536 against 4096 takes the cell from 1108 launches / 4.1 s of kernels to 391 / 2.5 s at the
+# same number of LPs (profiles/r4/config5_round_and_launch_sizes.txt)
+LAUNCH_TARGET = int(os.environ.get('EHM_LAUNCH_TARGET', '65536'))
 INHERIT_MAX = 8192       # bounds a node hands down before the non-refuting ones are dropped
 
 
