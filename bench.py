@@ -940,6 +940,8 @@ def measure_config5(args, ctx):
         hbm_alg = n_sx * (12 + 8 * ((p + 1) * p + (p + 1)) + 8 + 8 * (p + 1) + 4)
         dom_s = T['simplex_s']
         achieved = flops / max(dom_s, 1e-12) / 1e12
+        c5_traffic, c5_traffic_src = pmc_traffic(
+            'k3_simplex_batch' if dom == 'long' else 'k2_simplex_batch', 'pmc_summary_config5.json')
         out = {
             'metric': 'oracle LP solves/sec + final regions/sec, 4-state 2-input N=5 hybrid MPC',
             'value': lp / elapsed_max, 'unit': 'LP solves/s',
@@ -1015,7 +1017,9 @@ def measure_config5(args, ctx):
                 'achieved': achieved, 'peak': FP64_PEAK_TFLOPS, 'unit': 'TFLOP/s',
                 'frac': achieved / FP64_PEAK_TFLOPS,
                 'flop_per_ipm_iteration': flops_per_iteration(*dims[4]),
-                'traffic': None, 'traffic_source': 'no PMC profile of this workload',
+                'traffic': c5_traffic, 'traffic_source': c5_traffic_src,
+                'traffic_unit': 'HBM bytes per launch of the kernel, mean over the launches of '
+                                'one cell (rocprofv3 FETCH_SIZE x2 + WRITE_SIZE)',
                 'algorithmic_bytes_per_launch': hbm_alg / max(tot[8], 1.),
                 'kernel_seconds': dom_s, 'launches': tot[8],
                 'point_kernel_seconds': point_s, 'simplex_kernel_seconds_all_tables': simplex_s,

@@ -1,6 +1,6 @@
 """Where the host time of one config-5 cell goes, on the GPU box: bnb_frontier.grow_frontier on
 the whole-box Kuhn cell at the stated tolerances (bench.py --workload config5) under cProfile.
-    python tools/config5_host_profile.py [top=45]
+    python tools/config5_host_profile.py [top=45] [cold|sweep]
 Prints wall seconds, the device's share (ehm_counters.batch_seconds) and the profile sorted by
 own time."""
 import cProfile
@@ -39,15 +39,16 @@ if len(sys.argv) > 2 and sys.argv[2] == 'sweep':
                      orc.table.lp_solves - lp0), flush=True)
     orc.close()
     sys.exit(0)
-for rep in range(2):                                  # second pass: warm tables, profiled
+cold = len(sys.argv) > 2 and sys.argv[2] == 'cold'           # profile the FIRST pass instead
+for rep in range(1 if cold else 2):                   # second pass: warm tables, profiled
     root = Tree(NodeData(vertices=R.copy()))
     pr = cProfile.Profile()
     t0 = time.perf_counter()
-    if rep:
+    if rep or cold:
         pr.enable()
     stats = bnb_frontier.grow_frontier(orc, root, 'ecc', round_cap=2048, order='lcss-first',
                                        table_backoff=True)
-    if rep:
+    if rep or cold:
         pr.disable()
     print('pass %d: %.2f s, %d regions, %d rounds' % (rep, time.perf_counter() - t0,
                                                       stats['regions'], stats['rounds']), flush=True)
