@@ -36,7 +36,14 @@ def first_feasible_many(table, point_sets, excludes=None):
 
 def p_theta_many(oracle, thetas):
     """``PrefixOracle.P_theta`` for many parameters: list of (u0, delta, J) -- (None, None, None)
-    where no sequence is feasible.  Both phases of every parameter's search run in lockstep."""
+    where no sequence is feasible.  Both phases of every parameter's search run in lockstep.
+
+    Phase two (the canonical tie-break: the first sequence in enumeration order whose cost is
+    within TIE_TOL of the optimum) walks prefixes whose children phase one has mostly solved
+    already -- every prefix on the way to the optimum was expanded there.  The values are kept
+    per parameter, and the walk asks the device only for children it has not seen: without ties
+    it needs no problem at all, where it used to re-solve 4 N of them in N dependent launches.
+    Same values, same walk, same answer."""
     table, mpc = oracle.table, oracle.mpc
     n_modes, N = mpc.delta_size, mpc.N
     thetas = np.asarray(thetas, dtype=np.float64).reshape(-1, mpc.n_x)
@@ -47,13 +54,35 @@ def p_theta_many(oracle, thetas):
     best = [np.inf] * n
     limit = [np.inf] * n
     stacks = [None] * n
+    seen = [dict() for _ in range(n)]       # child prefix -> (J, u0) as the device returned them
     out = [(None, None, None)] * n
 
     def cut(j):
         return best[j] - PLATEAU * _rel(best[j]) if np.isfinite(best[j]) else np.inf
+
+    def walk(j):
+        """Phase two of search j as far as the known values carry it: returns the children still
+        to be solved ([] = the search has finished, ``out[j]`` is set)."""
+        known = seen[j]
+        while True:
+            if not stacks[j]:
+                raise SolverError('P_theta: the optimum found in phase one was not reproduced')
+            kids = _kids(stacks[j][-1], n_modes)
+            missing = [k for k in kids if k not in known]
+            if missing:
+                return missing
+            stacks[j].pop()
+            oracle.n_expanded += 1
+            good = [k for k in kids if known[k][0] <= limit[j]]
+            if good and len(good[0]) == N:
+                jk, u = known[good[0]]
+                out[j] = (u.copy(), oracle.delta_of(good[0]), float(jk))
+                return []
+            stacks[j].extend(reversed(good))
     active = list(range(n))
     while active:
         uniq, where, idx, owner, kid_of = [], {}, [], [], {}
+        still = []
         for j in active:
             if phase[j] == 1:
                 batch = []
@@ -62,8 +91,10 @@ def p_theta_many(oracle, thetas):
                 oracle.n_expanded += len(batch)
                 kids = [k for q in batch for k in _kids(q, n_modes)]
             else:
-                oracle.n_expanded += 1
-                kids = _kids(stacks[j].pop(), n_modes)
+                kids = walk(j)
+                if not kids:
+                    continue                        # finished on what phase one had solved
+            still.append(j)
             kid_of[j] = kids
             for k in kids:
                 u = where.get(k)
@@ -72,6 +103,9 @@ def p_theta_many(oracle, thetas):
                     uniq.append(k)
                 idx.append(u)
             owner.extend([j] * len(kids))
+        active = still
+        if not active:
+            break
         J, u0 = table.solve_points_idx(uniq, np.array(idx, dtype=np.int64),
                                        thetas[np.array(owner, dtype=np.int64)])
         pos, still = 0, []
@@ -79,6 +113,9 @@ def p_theta_many(oracle, thetas):
             kids = kid_of[j]
             Jj, uj = J[pos:pos + len(kids)], u0[pos:pos + len(kids)]
             pos += len(kids)
+            known = seen[j]
+            for q, jq, u in zip(kids, Jj, uj):
+                known[q] = (jq, u)
             if phase[j] == 1:
                 for q, jq in zip(kids, Jj):
                     if not np.isfinite(jq):
@@ -93,18 +130,7 @@ def p_theta_many(oracle, thetas):
                     phase[j] = 2
                     limit[j] = best[j] + TIE_TOL * _rel(best[j])
                     stacks[j] = [()]
-                still.append(j)
-            else:
-                good = [(k, jk, u) for k, jk, u in zip(kids, Jj, uj) if jk <= limit[j]]
-                if good and len(good[0][0]) == N:
-                    k, jk, u = good[0]
-                    out[j] = (u.copy(), oracle.delta_of(k), float(jk))
-                    continue
-                stacks[j].extend(k for k, _, _ in reversed(good))
-                if not stacks[j]:
-                    raise SolverError('P_theta: the optimum found in phase one was not '
-                                      'reproduced')
-                still.append(j)
+            still.append(j)
         active = still
     return out
 

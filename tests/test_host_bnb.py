@@ -140,6 +140,18 @@ def test_frontier_wide_searches_equal_the_one_node_searches():
         assert (a[1] is None) == (d is None)
         if d is not None:
             assert np.array_equal(a[1], d) and a[2] == J and np.array_equal(a[0], u)
+    # phase two of the lockstep form walks on the values phase one solved (no second solve of a
+    # child): fewer problems than the one-parameter statement, the same expansions
+    counts = []
+    for many in (True, False):
+        t2 = prefix_bb.CpuPrefixTable(mpc)
+        b2 = bnb.PrefixOracle(mpc, eps_a, 0.2, table=t2)
+        if many:
+            bnb_frontier.p_theta_many(b2, thetas)
+        else:
+            [b2.P_theta(th) for th in thetas]
+        counts.append((t2.lp_solves, b2.n_expanded))
+    assert counts[0][1] == counts[1][1] and counts[0][0] < 0.8 * counts[1][0], counts
     one = [table.first_feasible(R) for R in Rs]
     assert bnb_frontier.first_feasible_many(table, Rs) == one
     assert any(s is not None for s in one)
