@@ -162,6 +162,15 @@ class CpuRun:
         return len(self.frontier)
 
     def take(self, count):
+        # ehm_partition_take: every s-th entry of the frontier, s = size / count (the newest
+        # `count` entries if s < 2); what stays keeps its order
+        nf = len(self.frontier)
+        s = nf // count if count else 0
+        if s >= 2:
+            taken = [self.frontier[i * s] for i in range(count)]
+            keep = [self.frontier[i * s + k] for i in range(count) for k in range(1, s)] + \
+                self.frontier[count * s:]
+            self.frontier = keep + taken
         ids = np.array(self.frontier[len(self.frontier) - count:], dtype=np.int32)
         self.frontier = self.frontier[:len(self.frontier) - count]
         rec = np.array([np.concatenate([self.V[i].ravel(), self.C[i], self.U[i].ravel()])
