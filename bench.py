@@ -298,7 +298,15 @@ def parse_args(argv=None):
                     help='config5: regions to close per rank before a step stops (default: none, the '
                          'cells are grown to completion)')
     ap.add_argument('--cells', type=int, default=0,
-                    help='config5: Kuhn cells of the box that are grown (default: one per rank)')
+                    help='config5: root cells of the box that are grown (default: one per rank)')
+    ap.add_argument('--roots', choices=['delaunay', 'kuhn'], default='delaunay',
+                    help='config5: the root cells.  delaunay (default) = the reference\'s roots, '
+                         'tools.delaunay_roots of the box (lib/tools.py:152-189: Qhull, 34 573 '
+                         'simplices at p = 8) in Qhull order; kuhn = the 8 Kuhn cells of the cyclic '
+                         'coordinate orders (rounds 3-4)')
+    ap.add_argument('--progress-file', default=None,
+                    help='config5: append one JSON line per finished group of cells (a run cut '
+                         'short by a time limit leaves what it measured)')
     ap.add_argument('--cells-at-once', type=int, default=0,
                     help='config5: grow a rank\'s cells in groups of this many (0 = all of them '
                          'together, sharing the launches); 1 = one cell after the other, each to '
@@ -732,7 +740,7 @@ def kuhn_cell(half, k):
 def _cpu5_worker(job):
     """One host core: the search driver on the CPU statement of the table (HiGHS on the
     uncondensed relaxations, oracle/prefix_bb.py) on its own cell, for a bounded wall time."""
-    seed, eps_a, eps_r, cell, seconds = job
+    seed, eps_a, eps_r, cell, seconds = job        # cell: (p+1, p) vertices of the root cell
     from explicit_hybrid_mpc_amd import bnb, bnb_frontier, examples
     from explicit_hybrid_mpc_amd.tree import NodeData, Tree
     from oracle import geometry, prefix_bb
@@ -746,13 +754,13 @@ def _cpu5_worker(job):
             S1.append(a), S2.append(b), ij.append(e)
         return np.array(S1), np.array(S2), np.array(ij)
     t0 = time.perf_counter()
-    tree = Tree(NodeData(vertices=kuhn_cell(examples.theta_box(mpc), cell)))
+    tree = Tree(NodeData(vertices=np.array(cell, dtype=np.float64)))
     stats = bnb_frontier.grow_frontier(orc, tree, 'ecc', handoff=False, split_batch=split_batch,
                                        round_cap=4, order='lcss-first', deadline=t0 + seconds)
     return orc.table.lp_solves, stats['host_visits'], stats['regions'], time.perf_counter() - t0
 
 
-def cpu_baseline_config5(seed, eps_a, eps_r, seconds):
+def cpu_baseline_config5(seed, eps_a, eps_r, seconds, cell_vertices=None):
     """The same search driver (bnb_frontier.grow_frontier on bnb.PrefixOracle) with the CPU
     statement of the table, one process per usable core, each on its own cell of the box."""
     import multiprocessing as mp
@@ -763,7 +771,11 @@ def cpu_baseline_config5(seed, eps_a, eps_r, seconds):
     t1 = time.perf_counter()
     try:
         with mp.get_context('spawn').Pool(cores) as pool:
-            res = pool.map_async(_cpu5_worker, [(seed, eps_a, eps_r, c, seconds)
+            if cell_vertices is None:
+                from explicit_hybrid_mpc_amd import examples
+                half = examples.theta_box(examples.pwa4_mpc(N=CONFIG5['N'], seed=seed))
+                cell_vertices = lambda c: kuhn_cell(half, c)
+            res = pool.map_async(_cpu5_worker, [(seed, eps_a, eps_r, cell_vertices(c), seconds)
                                                 for c in range(cores)]).get(timeout=6 * seconds + 180)
     finally:
         for k, v in saved.items():
@@ -779,7 +791,7 @@ def cpu_baseline_config5(seed, eps_a, eps_r, seconds):
                 node_visits_per_s=sum(r[1] for r in res) / busy,
                 sample='%d processes (one per usable core), each the search driver of the device '
                        'path on the CPU statement of the table (oracle/prefix_bb.py: HiGHS on the '
-                       'uncondensed prefix relaxations) on its own Kuhn cell of the box, %.1f s '
+                       'uncondensed prefix relaxations) on its own root cell of the box, %.1f s '
                        'each (rounds of 4 nodes): %d node visits, %d LP solves, %d regions closed '
                        '(%.1f s wall incl. process start)' %
                        (cores, busy, sum(r[1] for r in res), sum(r[0] for r in res),
@@ -817,7 +829,16 @@ def measure_config5(args, ctx):
     t_eps = time.perf_counter() - t_eps
     orc.eps_a, orc.eps_r = eps_a, eps_r
     orc.table.set_eps(eps_a, eps_r)
+    if args.roots == 'delaunay':
+        from explicit_hybrid_mpc_amd import tools as ehm_tools
+        root_cells, _ = ehm_tools.delaunay_roots(V)
+        n_roots_total = len(root_cells)
+        cell_vertices = lambda c: root_cells[c % n_roots_total].copy()
+    else:
+        n_roots_total = 8
+        cell_vertices = lambda c: kuhn_cell(half, c)
     my_cells = list(range(rank, n_cells, world))
+    cells_log = []
 
     # the device table(s): one, or -- where the full model needs the wide kernels -- a table of the
     # short horizon for the prefixes of few steps next to it (sequences.SplitPrefixTable)
@@ -834,15 +855,31 @@ def measure_config5(args, ctx):
                     hist=orc.table.by_length.copy(), stalled=orc.table.stalled)
 
     def step():
-        group = args.cells_at_once if args.cells_at_once > 0 else max(len(my_cells), 1)
+        # with a target of regions the cells are grown one group after the other, EACH TO
+        # COMPLETION (every leaf eps-suboptimal), until the target is reached
+        group = args.cells_at_once if args.cells_at_once > 0 else (
+            1 if args.regions else max(len(my_cells), 1))
         stats, trees = None, []
         for g0 in range(0, len(my_cells), group):
+            if args.regions and stats is not None and stats.get('regions', 0) >= regions:
+                break
             orc.table.forget()
-            part = [Tree(NodeData(vertices=kuhn_cell(half, c))) for c in my_cells[g0:g0 + group]]
+            part = [Tree(NodeData(vertices=cell_vertices(c))) for c in my_cells[g0:g0 + group]]
+            t_g, lp_g = time.perf_counter(), orc.table.lp_solves
             st = bnb_frontier.grow_frontier(orc, part, 'ecc', order=args.order,
                                             table_backoff=True, round_cap=args.round_cap,
-                                            min_regions=regions, max_visits=args.max_visits)
+                                            min_regions=None if args.regions else regions,
+                                            max_visits=args.max_visits)
             trees += part
+            cells_log.append(dict(cells=my_cells[g0:g0 + group],
+                                  seconds=time.perf_counter() - t_g,
+                                  regions=int(st.get('regions', 0)), rounds=int(st['rounds']),
+                                  visits=int(st['host_visits']),
+                                  lp=int(orc.table.lp_solves - lp_g),
+                                  truncated=bool(st['truncated'])))
+            if args.progress_file and rank == 0:
+                with open(args.progress_file, 'a') as f:
+                    f.write(json.dumps(cells_log[-1]) + '\n')
             if stats is None:
                 stats = dict(st)
             else:       # counters add up, flags combine
@@ -865,6 +902,7 @@ def measure_config5(args, ctx):
     except Exception as e:
         failure = e
     barrier()
+    n_log_warm = len(cells_log)
     s0 = snapshot()
     t0 = time.perf_counter()
     runs = []
@@ -956,10 +994,18 @@ def measure_config5(args, ctx):
                 'workload': 'configs[4] (NOT the headline configuration): n_x=8 n_u=3 N=8 p=8, 4 '
                             'modes = %d mode sequences (searched by branch-and-bound over mode '
                             'prefixes, never enumerated), inf-norm LP oracle (relaxation blocks '
-                            'n=%d m=%d), seed %d, eps_r=%g, eps_a=%.6g (abs_frac=%g), %d Kuhn '
-                            'cell(s) of the box, grown until %d regions are closed per rank' % (
+                            'n=%d m=%d), seed %d, eps_r=%g, eps_a=%.6g (abs_frac=%g), %s, %s' % (
                                 mpc.delta_size ** mpc.N, n, m, args.seed, eps_r, eps_a, abs_frac,
-                                n_cells, regions),
+                                ('the first %d of the %d Delaunay root simplices of the box '
+                                 '(tools.delaunay_roots, Qhull order: the reference\'s roots, '
+                                 'lib/tools.py:152-189)' % (n_cells, n_roots_total))
+                                if args.roots == 'delaunay' else
+                                '%d Kuhn cell(s) of the box' % n_cells,
+                                ('cell after cell, each to completion, until %d regions are closed '
+                                 'per rank' % regions) if args.regions else
+                                'grown to completion'),
+                'cells_grown_per_step': sum(len(c['cells']) for c in cells_log[n_log_warm:]) / K,
+                'cells_log': cells_log[n_log_warm:],
                 'regions_per_step': closed_t / K, 'nodes_per_step': nodes_t / K,
                 'open_leaves_per_step': (leaves - closed) / K if world == 1 else None,
                 'tree_depth': depth,
@@ -1030,7 +1076,8 @@ def measure_config5(args, ctx):
             },
         }
         if world == 1 and not args.no_cpu_baseline:
-            out['cpu_baseline'] = cpu_baseline_config5(args.seed, eps_a, eps_r, args.cpu_seconds)
+            out['cpu_baseline'] = cpu_baseline_config5(args.seed, eps_a, eps_r, args.cpu_seconds,
+                                                       cell_vertices)
         else:
             out['cpu_baseline'] = None
     orc.close()
@@ -1059,6 +1106,7 @@ def secondary_line(args, ctx, workload, steps, warmup):
     a.abs_frac = a.eps_r = a.max_depth = None
     a.cpu_seconds = args.secondary_cpu_seconds
     a.regions = a.cells = 0
+    a.progress_file = None
     a.order, a.max_visits, a.round_cap = 'lcss-first', None, 4096
     a.status_dir = None
     a.engine, a.solver, a.decide_full = 1, 2, False
