@@ -304,6 +304,10 @@ def parse_args(argv=None):
                          'tools.delaunay_roots of the box (lib/tools.py:152-189: Qhull, 34 573 '
                          'simplices at p = 8) in Qhull order; kuhn = the 8 Kuhn cells of the cyclic '
                          'coordinate orders (rounds 3-4)')
+    ap.add_argument('--driver', choices=['native', 'python'], default='native',
+                    help='config5: native = the round loop, the searches\' bookkeeping, the block '
+                         'condensation and the launches in C++ behind ehm_frontier_run '
+                         '(include/ehm_frontier.h); python = bnb_frontier.grow_frontier (rounds 3-4)')
     ap.add_argument('--progress-file', default=None,
                     help='config5: append one JSON line per finished group of cells (a run cut '
                          'short by a time limit leaves what it measured)')
@@ -845,14 +849,62 @@ def measure_config5(args, ctx):
     parts = [('short', orc.table.short), ('long', orc.table.long)] if hasattr(orc.table, 'short') \
         else [('long', orc.table)]
 
+    # the native driver (include/ehm_frontier.h) owns device tables of its own; the Python oracle
+    # above stays for eps_a and for the cells the native driver hands back open
+    native = None
+    if args.driver == 'native':
+        from explicit_hybrid_mpc_amd import frontier
+        native = frontier.NativeFrontier(mpc, eps_a, eps_r, slots=8192, device=device_index)
+    nat_acc = dict(calls=dict(P_theta=0, V_R=0, bar_E=0, bar_D=0), expanded=0, stalled=0,
+                   solver_seconds=0., driver_seconds=0., open_cells=0, launches=0)
+
     def snapshot():
         per = {}
-        for name, tb in parts:
+        nat_tab = native.table_stats() if native else {}
+        nat_hist = native.lp_counts() if native else None
+        for t, (name, tb) in enumerate(parts):
             st = tb.gp.stats()
             per[name] = dict(lp=tb.lp_solves, iters=st['ipm_iters'], secs=list(st['batch_seconds']),
                              launches=list(st['batch_launches']), hist=tb.by_length.copy())
-        return dict(lp=orc.table.lp_solves, per=per, calls=dict(orc.calls), expanded=orc.n_expanded,
-                    hist=orc.table.by_length.copy(), stalled=orc.table.stalled)
+            nt = nat_tab.get(name)
+            if nt:
+                h = nat_hist[0 if name == 'short' else 1]
+                per[name]['lp'] += int(h.sum())
+                per[name]['iters'] += nt['ipm_iters']
+                per[name]['secs'] = [a + b for a, b in zip(per[name]['secs'], nt['batch_seconds'])]
+                per[name]['launches'] = [a + b for a, b in zip(per[name]['launches'],
+                                                               nt['batch_launches'])]
+                per[name]['hist'][:, :h.shape[1]] += h
+        return dict(lp=sum(v['lp'] for v in per.values()), per=per,
+                    calls={k: orc.calls[k] + nat_acc['calls'][k] for k in orc.calls},
+                    expanded=orc.n_expanded + nat_acc['expanded'],
+                    hist=sum(v['hist'] for v in per.values()),
+                    stalled=orc.table.stalled + nat_acc['stalled'])
+
+    def grow_group(part):
+        if native is None:
+            return bnb_frontier.grow_frontier(orc, part, 'ecc', order=args.order,
+                                              table_backoff=True, round_cap=args.round_cap,
+                                              min_regions=None if args.regions else regions,
+                                              max_visits=args.max_visits)
+        orc.table.forget()
+        st = frontier.grow_cells(native, part, slow_oracle=lambda: orc, round_cap=args.round_cap,
+                                 max_visits=args.max_visits or 0,
+                                 min_regions=0 if args.regions or regions >= (1 << 30) else regions,
+                                 slow_opts=dict(order=args.order, table_backoff=True,
+                                                round_cap=args.round_cap))
+        nat_acc['calls']['P_theta'] += st['calls_p_theta']
+        nat_acc['calls']['V_R'] += st['calls_v_r']
+        nat_acc['calls']['bar_E'] += st['calls_bar_e']
+        nat_acc['expanded'] += st['prefixes_expanded']
+        nat_acc['stalled'] += st['stalled']
+        nat_acc['solver_seconds'] += st['seconds_solvers']
+        nat_acc['driver_seconds'] += st['seconds_total']
+        nat_acc['open_cells'] += st['slow_path_cells']
+        nat_acc['launches'] += st['launches']
+        return dict(host_visits=st['visits'] + st['slow_path_visits'], rounds=st['rounds'],
+                    regions=st['regions'], truncated=bool(st['truncated']), handoffs=0,
+                    native_visits=st['visits'], slow_path_cells=st['slow_path_cells'])
 
     def step():
         # with a target of regions the cells are grown one group after the other, EACH TO
@@ -865,17 +917,14 @@ def measure_config5(args, ctx):
                 break
             orc.table.forget()
             part = [Tree(NodeData(vertices=cell_vertices(c))) for c in my_cells[g0:g0 + group]]
-            t_g, lp_g = time.perf_counter(), orc.table.lp_solves
-            st = bnb_frontier.grow_frontier(orc, part, 'ecc', order=args.order,
-                                            table_backoff=True, round_cap=args.round_cap,
-                                            min_regions=None if args.regions else regions,
-                                            max_visits=args.max_visits)
+            t_g, lp_g = time.perf_counter(), snapshot()['lp']
+            st = grow_group(part)
             trees += part
             cells_log.append(dict(cells=my_cells[g0:g0 + group],
                                   seconds=time.perf_counter() - t_g,
                                   regions=int(st.get('regions', 0)), rounds=int(st['rounds']),
                                   visits=int(st['host_visits']),
-                                  lp=int(orc.table.lp_solves - lp_g),
+                                  lp=int(snapshot()['lp'] - lp_g),
                                   truncated=bool(st['truncated'])))
             if args.progress_file and rank == 0:
                 with open(args.progress_file, 'a') as f:
@@ -903,6 +952,7 @@ def measure_config5(args, ctx):
         failure = e
     barrier()
     n_log_warm = len(cells_log)
+    nat_acc.update(solver_seconds=0., driver_seconds=0., open_cells=0, launches=0)
     s0 = snapshot()
     t0 = time.perf_counter()
     runs = []
@@ -1030,9 +1080,19 @@ def measure_config5(args, ctx):
                             if hasattr(orc.table, 'short') else '') +
                            'wide kernels (one workgroup per LP, MFMA normal matrix); both through '
                            'the batched oracles ehm_simplex_idx_batch / ehm_point_idx_batch',
-                'engine': 'host-driven searches (bnb_frontier.grow_frontier: all pending nodes '
-                          'share the launches; native memo of phase-one verdicts, '
-                          'csrc/ehm_search.cpp), LPs on the device',
+                'engine': ('native driver (include/ehm_frontier.h, csrc/ehm_frontier.cpp): round '
+                           'loop, searches, block condensation and launches in C++ behind one '
+                           'call per group of cells; cells bar_E leaves open go back to '
+                           'bnb_frontier (%d of %d visits)' % (
+                               nat_acc['open_cells'], int(tot[9])) if native else
+                           'host-driven searches (bnb_frontier.grow_frontier: all pending nodes '
+                           'share the launches; native memo of phase-one verdicts, '
+                           'csrc/ehm_search.cpp)') + ', LPs on the device',
+                'native_driver': None if not native else {
+                    'seconds_inside_ehm_frontier_run_per_step': nat_acc['driver_seconds'] / K,
+                    'of_them_inside_the_batched_solver_calls': nat_acc['solver_seconds'] / K,
+                    'solver_calls_per_step': nat_acc['launches'] / K,
+                    'cells_handed_back_open_per_step': nat_acc['open_cells'] / K},
                 'order': {'lcss-first': 'cells that hold a commutation first, deepest first',
                           'fifo': 'level by level', 'deepest': 'deepest first'}[args.order] +
                          '; rounds of %d nodes' % args.round_cap,
@@ -1080,6 +1140,8 @@ def measure_config5(args, ctx):
                                                        cell_vertices)
         else:
             out['cpu_baseline'] = None
+    if native:
+        native.close()
     orc.close()
     return out
 
@@ -1107,6 +1169,7 @@ def secondary_line(args, ctx, workload, steps, warmup):
     a.cpu_seconds = args.secondary_cpu_seconds
     a.regions = a.cells = 0
     a.progress_file = None
+    a.driver = 'native'
     a.order, a.max_visits, a.round_cap = 'lcss-first', None, 4096
     a.status_dir = None
     a.engine, a.solver, a.decide_full = 1, 2, False

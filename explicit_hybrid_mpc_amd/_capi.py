@@ -53,6 +53,15 @@ EXPORTED_SEARCH = [
 ]
 
 
+# every symbol include/ehm_frontier.h declares (the native partition driver of configs[4])
+EXPORTED_FRONTIER = [
+    'ehm_frontier_create', 'ehm_frontier_create_custom', 'ehm_frontier_destroy',
+    'ehm_frontier_last_error', 'ehm_frontier_set_eps', 'ehm_frontier_tables',
+    'ehm_frontier_reset', 'ehm_frontier_add_root', 'ehm_frontier_run', 'ehm_frontier_sizes',
+    'ehm_frontier_export', 'ehm_frontier_lp_counts', 'ehm_frontier_condense',
+]
+
+
 class EhmError(RuntimeError):
     def __init__(self, code, message):
         super().__init__('libehmpc error %d: %s' % (code, message))
@@ -106,6 +115,46 @@ class Progress(ctypes.Structure):
                 ('lp_solves', ctypes.c_int64), ('ipm_iters', ctypes.c_int64),
                 ('depth', ctypes.c_int32), ('reserved', ctypes.c_int32),
                 ('volume_closed', ctypes.c_double), ('n_splits', ctypes.c_int64)]
+
+
+class PwaLaw(ctypes.Structure):
+    _fields_ = [('n_x', ctypes.c_int32), ('n_u', ctypes.c_int32), ('n_modes', ctypes.c_int32),
+                ('N', ctypes.c_int32), ('A', c_double_p), ('B', c_double_p), ('w', c_double_p),
+                ('region_rows', c_int32_p), ('Hx', c_double_p), ('hx', c_double_p),
+                ('n_gx', ctypes.c_int32), ('Gx', c_double_p), ('gx', c_double_p),
+                ('n_gu', ctypes.c_int32), ('Gu', c_double_p), ('gu', c_double_p),
+                ('n_q', ctypes.c_int32), ('Q', c_double_p),
+                ('n_r', ctypes.c_int32), ('R', c_double_p)]
+
+
+POINTS_FN = ctypes.CFUNCTYPE(ctypes.c_int, ctypes.c_void_p, ctypes.c_int64, ctypes.c_void_p,
+                             ctypes.c_void_p, ctypes.c_int32, ctypes.c_int32, ctypes.c_void_p,
+                             ctypes.c_void_p)
+SLACK_FN = ctypes.CFUNCTYPE(ctypes.c_int, ctypes.c_void_p, ctypes.c_int64, ctypes.c_void_p,
+                            ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p)
+SPLIT_FN = ctypes.CFUNCTYPE(ctypes.c_int, ctypes.c_void_p, ctypes.c_int64, ctypes.c_void_p,
+                            ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p)
+
+
+class PairSolvers(ctypes.Structure):
+    _fields_ = [('user', ctypes.c_void_p), ('points', POINTS_FN), ('slack', SLACK_FN),
+                ('split', SPLIT_FN)]
+
+
+class FrontierOpts(ctypes.Structure):
+    _fields_ = [('round_cap', ctypes.c_int32), ('launch_target', ctypes.c_int32),
+                ('max_visits', ctypes.c_int64), ('min_regions', ctypes.c_int64),
+                ('speculate', ctypes.c_int32)]
+
+
+class FrontierStats(ctypes.Structure):
+    _fields_ = [(k, ctypes.c_int64) for k in (
+        'rounds', 'visits', 'ecc_visits', 'lcss_visits', 'regions', 'open_cells', 'n_nodes',
+        'calls_v_r', 'calls_p_theta', 'calls_bar_e', 'witness_hits', 'prefixes_expanded',
+        'answered_without_a_problem', 'optima_asked', 'optima_solved', 'lp_solves', 'launches',
+        'blocks_loaded', 'stalled', 'slivers')] + [
+        ('truncated', ctypes.c_int32), ('depth', ctypes.c_int32),
+        ('seconds_solvers', ctypes.c_double), ('seconds_total', ctypes.c_double)]
 
 
 class Counters(ctypes.Structure):
@@ -230,6 +279,27 @@ def load(build_if_missing=True):
     for name in EXPORTED_SEARCH:
         if name != 'ehm_search_last_error':
             getattr(lib, name).restype = i32
+    # include/ehm_frontier.h
+    lib.ehm_frontier_last_error.restype = ctypes.c_char_p
+    lib.ehm_frontier_create.argtypes = [ctypes.POINTER(PwaLaw), i32, i32, ctypes.c_int,
+                                        ctypes.c_double, ctypes.c_double, ctypes.POINTER(vp)]
+    lib.ehm_frontier_create_custom.argtypes = [i32, i32, i32, i32, ctypes.POINTER(PairSolvers),
+                                               ctypes.c_double, ctypes.c_double,
+                                               ctypes.POINTER(vp)]
+    lib.ehm_frontier_destroy.argtypes = [vp]
+    lib.ehm_frontier_set_eps.argtypes = [vp, ctypes.c_double, ctypes.c_double]
+    lib.ehm_frontier_tables.argtypes = [vp, ctypes.POINTER(vp), ctypes.POINTER(vp)]
+    lib.ehm_frontier_reset.argtypes = [vp]
+    lib.ehm_frontier_add_root.argtypes = [vp, vp]
+    lib.ehm_frontier_run.argtypes = [vp, ctypes.POINTER(FrontierOpts),
+                                     ctypes.POINTER(FrontierStats)]
+    lib.ehm_frontier_sizes.argtypes = [vp, ctypes.POINTER(i64), ctypes.POINTER(i64)]
+    lib.ehm_frontier_export.argtypes = [vp, vp, vp, vp, vp, vp, vp, vp]
+    lib.ehm_frontier_lp_counts.argtypes = [vp, vp]
+    lib.ehm_frontier_condense.argtypes = [ctypes.POINTER(PwaLaw), i32, i32, vp, vp, vp, vp, vp]
+    for name in EXPORTED_FRONTIER:
+        if name != 'ehm_frontier_last_error':
+            getattr(lib, name).restype = i32
     _lib = lib
     return lib
 
@@ -242,6 +312,11 @@ def check(rc):
 def check_search(rc):
     if rc != EHM_OK:
         raise EhmError(rc, load().ehm_search_last_error().decode('utf-8', 'replace'))
+
+
+def check_frontier(rc):
+    if rc != EHM_OK:
+        raise EhmError(rc, load().ehm_frontier_last_error().decode('utf-8', 'replace'))
 
 
 def f64(a):

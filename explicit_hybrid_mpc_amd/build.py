@@ -82,8 +82,16 @@ def _dep_mtime(public=True):
 
 SEARCH_SRC = os.path.join(SRC_DIR, 'ehm_search.cpp')      # host C++ only (include/ehm_search.h)
 SEARCH_OBJ = os.path.join(OBJ_DIR, 'ehm_search.o')
+# the native partition driver of configs[4] (include/ehm_frontier.h): host C++ on the public
+# entry points of the library
+FRONTIER_SRC = os.path.join(SRC_DIR, 'ehm_frontier.cpp')
+FRONTIER_OBJ = os.path.join(OBJ_DIR, 'ehm_frontier.o')
 SEARCH_DEPS = [SEARCH_SRC, os.path.normpath(os.path.join(HERE, '..', 'include', 'ehm_search.h')),
                os.path.normpath(os.path.join(HERE, '..', 'include', 'ehmpc.h'))]
+FRONTIER_DEPS = [FRONTIER_SRC,
+                 os.path.normpath(os.path.join(HERE, '..', 'include', 'ehm_frontier.h'))] + \
+    SEARCH_DEPS[1:]
+HOST_OBJECTS = ((SEARCH_OBJ, SEARCH_SRC, SEARCH_DEPS), (FRONTIER_OBJ, FRONTIER_SRC, FRONTIER_DEPS))
 
 
 def _objects():
@@ -140,7 +148,8 @@ def is_stale():
     t = os.path.getmtime(LIB)
     srcs = [os.path.join(SRC_DIR, f)
             for f in ('ehm_capi.hip', 'ehm_k2.hip', 'ehm_k3.hip', 'ehm_kp.hip', 'ehm_explicit.hip')]
-    return max([_dep_mtime()] + [os.path.getmtime(s) for s in srcs + SEARCH_DEPS]) > t
+    return max([_dep_mtime()] + [os.path.getmtime(s)
+                                 for s in srcs + SEARCH_DEPS + FRONTIER_DEPS]) > t
 
 
 def build(force=False, verbose=False, jobs=None):
@@ -152,7 +161,8 @@ def build(force=False, verbose=False, jobs=None):
     hipcc = _hipcc()
     dep_t, dep_k = _dep_mtime(), _dep_mtime(public=False)
     todo = [(o, s, f) for (o, s, f) in _objects()
-            if force or _stale(o, s, dep_t if os.path.basename(s) == 'ehm_capi.hip' else dep_k)]
+            if force or _stale(o, s, dep_t if os.path.basename(s) in (
+                'ehm_capi.hip', 'ehm_explicit.hip') else dep_k)]
 
     def compile_one(item):
         obj, src, extra = item
@@ -164,15 +174,16 @@ def build(force=False, verbose=False, jobs=None):
     jobs = jobs or max(1, (os.cpu_count() or 2))
     with ThreadPoolExecutor(max_workers=jobs) as pool:
         list(pool.map(compile_one, todo))
-    # the searches' host bookkeeping: plain C++, no device code
-    if force or not os.path.exists(SEARCH_OBJ) or \
-            os.path.getmtime(SEARCH_OBJ) < max(os.path.getmtime(d) for d in SEARCH_DEPS):
-        cmd = [_cxx(), '-O2', '-std=c++17', '-fPIC', '-Wall', '-c', SEARCH_SRC, '-o', SEARCH_OBJ]
-        if verbose:
-            print(' '.join(cmd))
-        subprocess.check_call(cmd)
+    # the searches' host bookkeeping and the native driver on top of it: plain C++, no device code
+    for obj, src, deps in HOST_OBJECTS:
+        if force or not os.path.exists(obj) or \
+                os.path.getmtime(obj) < max(os.path.getmtime(d) for d in deps):
+            cmd = [_cxx(), '-O2', '-std=c++17', '-fPIC', '-Wall', '-c', src, '-o', obj]
+            if verbose:
+                print(' '.join(cmd))
+            subprocess.check_call(cmd)
     cmd = [hipcc, '--offload-arch=gfx950', '-shared', '-fPIC'] + [o for (o, _, _) in _objects()]
-    cmd += [SEARCH_OBJ]
+    cmd += [obj for obj, _, _ in HOST_OBJECTS]
     cmd += ['-o', LIB]
     if verbose:
         print(' '.join(cmd))

@@ -1,0 +1,56 @@
+"""
+The native partition driver (include/ehm_frontier.h) on the device, configs[4] (n_x = 8, n_u = 3,
+4 modes, N = 8: 65 536 sequences): one Delaunay root cell of the box grown by
+``frontier.grow_cells`` (C++ round loop, native condensation, two device tables) and by
+``bnb_frontier.grow_frontier`` (rounds 3-4) -- the same tree, cell for cell; the blocks the native
+driver writes are the blocks ``PWAMPC.condense_prefix`` states.
+"""
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+
+def _nodes(t):
+    return {loc: nd for nd, loc in t.walk()}
+
+
+def test_native_driver_grows_the_tree_of_the_python_driver_on_the_device():
+    from explicit_hybrid_mpc_amd import bnb, bnb_frontier, examples, frontier
+    from explicit_hybrid_mpc_amd import tools as ehm_tools
+    from explicit_hybrid_mpc_amd.tree import NodeData, Tree
+    mpc = examples.pwa4_mpc(N=8, seed=0)
+    V = examples.box_vertices(examples.theta_box(mpc))
+    orc = bnb.PrefixOracle(mpc, 1., 1., slots=4096)
+    eps_a = float(np.max([j for _, _, j in bnb_frontier.p_theta_many(orc, 0.2 * V)]))
+    eps_r = 1e-3
+    orc.eps_a, orc.eps_r = eps_a, eps_r
+    orc.table.set_eps(eps_a, eps_r)
+    roots, _ = ehm_tools.delaunay_roots(V)
+    assert len(roots) == 34573                      # the reference's roots at p = 8
+    R = roots[2]                                    # a small cell: ~1.5 k regions
+    ref = Tree(NodeData(vertices=R.copy()))
+    s_ref = bnb_frontier.grow_frontier(orc, ref, 'ecc', order='lcss-first', table_backoff=True)
+    nat = frontier.NativeFrontier(mpc, eps_a, eps_r, slots=4096)
+    got = Tree(NodeData(vertices=R.copy()))
+    orc.table.forget()
+    st = frontier.grow_cells(nat, got, slow_oracle=lambda: orc,
+                             slow_opts=dict(order='lcss-first', table_backoff=True))
+    a, b = _nodes(ref), _nodes(got)
+    assert set(a) == set(b) and len(a) > 1000
+    assert st['regions'] == s_ref['regions'] == sum(nd.is_leaf() for nd in a.values())
+    for loc, x in a.items():
+        y = b[loc]
+        assert np.array_equal(x.data.vertices, y.data.vertices)
+        assert x.is_leaf() == y.is_leaf()
+        assert x.data.is_epsilon_suboptimal == y.data.is_epsilon_suboptimal
+        assert hasattr(x.data, 'commutation') == hasattr(y.data, 'commutation')
+        if hasattr(x.data, 'commutation') and x.is_leaf():
+            assert np.array_equal(x.data.commutation, y.data.commutation)
+            assert np.allclose(x.data.vertex_costs, y.data.vertex_costs, rtol=1e-9, atol=1e-9)
+    # the native share of the work: the interpreter sees only the cells handed back open
+    assert st['slow_path_cells'] <= 0.05 * st['visits']
+    assert st['seconds_solvers'] >= 0.5 * st['seconds_total']
+    nat.close()
+    orc.close()

@@ -1,0 +1,146 @@
+"""
+The native partition driver (include/ehm_frontier.h, csrc/ehm_frontier.cpp) without a device:
+
+* its condensation of prefix relaxations against ``PWAMPC.condense_prefix`` (numpy);
+* the driver on the CPU statement of the table (oracle/prefix_bb.CpuPrefixTable through
+  ``frontier.TableSolvers``) grows the tree ``bnb_frontier.grow_frontier`` grows on the same table
+  -- cell for cell: vertices, verdicts, commutations, vertex costs;
+* the library exports every symbol include/ehm_frontier.h declares.
+"""
+
+import ctypes
+import itertools
+import os
+import re
+
+import numpy as np
+import pytest
+
+from explicit_hybrid_mpc_amd import _capi, bnb, bnb_frontier, examples, frontier
+from explicit_hybrid_mpc_amd.tree import NodeData, Tree
+from oracle import geometry, prefix_bb
+from tests import helpers
+
+
+def _host_split_batch(R):
+    out = [geometry.split_along_longest_edge(r) for r in R]
+    return (np.array([o[0] for o in out]), np.array([o[1] for o in out]),
+            np.array([o[2] for o in out], dtype=np.int32))
+
+
+def test_header_symbols_are_exported():
+    here = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    text = open(os.path.join(here, 'include', 'ehm_frontier.h')).read()
+    declared = set(re.findall(r'\b(ehm_frontier_\w+)\s*\(', text))
+    assert declared == set(_capi.EXPORTED_FRONTIER)
+    lib = ctypes.CDLL(_capi.library_path())
+    for name in declared:
+        assert hasattr(lib, name), name
+
+
+@pytest.mark.parametrize('law', ['pwa4', 'pwa_small', 'pwa'])
+def test_native_condensation_is_condense_prefix(law):
+    mpc = examples.pwa4_mpc(N=5) if law == 'pwa4' else helpers.make_instance(law, 0)
+    rng = np.random.default_rng(0)
+    for horizon in (mpc.N, max(1, mpc.N - 2)):
+        ref = mpc if horizon == mpc.N else mpc.with_horizon(horizon)
+        for _ in range(12):
+            k = int(rng.integers(0, horizon + 1))
+            prefix = tuple(int(i) for i in rng.integers(0, mpc.delta_size, k))
+            G, w, S = frontier.condense_native(mpc, prefix, horizon)
+            G0, w0, S0 = ref.condense_prefix(prefix)
+            assert G.shape == G0.shape and S.shape == S0.shape
+            # (numpy's products go through BLAS: the same sums in another order)
+            assert np.allclose(G, G0, rtol=0, atol=1e-13)
+            assert np.allclose(w, w0, rtol=0, atol=1e-13)
+            assert np.allclose(S, S0, rtol=0, atol=1e-13)
+            assert np.array_equal(G == 0., G0 == 0.) and np.array_equal(S == 0., S0 == 0.)
+
+
+def _same_trees(a, b):
+    na = {loc: nd for nd, loc in a.walk()}
+    nb = {loc: nd for nd, loc in b.walk()}
+    assert set(na) == set(nb)
+    for loc, x in na.items():
+        y = nb[loc]
+        assert np.array_equal(x.data.vertices, y.data.vertices)
+        assert x.is_leaf() == y.is_leaf()
+        assert x.data.is_epsilon_suboptimal == y.data.is_epsilon_suboptimal
+        assert hasattr(x.data, 'commutation') == hasattr(y.data, 'commutation'), loc
+        if hasattr(x.data, 'commutation'):
+            assert np.array_equal(x.data.commutation, y.data.commutation)
+            assert np.allclose(x.data.vertex_costs, y.data.vertex_costs, atol=1e-12)
+            assert np.allclose(x.data.vertex_inputs, y.data.vertex_inputs, atol=1e-9)
+    return len(na)
+
+
+@pytest.mark.parametrize('eps_r', [0.2, 2.0])
+def test_native_driver_grows_the_tree_of_grow_frontier(eps_r):
+    """eps_r 2.0: almost every cell closes on its first lcss visit (the native path to the end);
+    0.2: open cells come back and ``bnb_frontier`` finishes them -- the same tree either way."""
+    mpc = helpers.make_instance('pwa_small', 0)
+    eps_a = helpers.eps_a_rule(mpc, 0.25)
+    roots, _ = helpers.roots_of(mpc)
+    ref_orc = bnb.PrefixOracle(mpc, eps_a, eps_r, table=prefix_bb.CpuPrefixTable(mpc, eps_a, eps_r))
+    ref = [Tree(NodeData(vertices=np.array(R))) for R in roots]
+    bnb_frontier.grow_frontier(ref_orc, ref, 'ecc', handoff=False, split_batch=_host_split_batch,
+                               round_cap=7)
+    table = prefix_bb.CpuPrefixTable(mpc, eps_a, eps_r)
+    solvers = frontier.TableSolvers(table, _host_split_batch)
+    nat = frontier.NativeFrontier(mpc, eps_a, eps_r, solvers=solvers)
+    slow = bnb.PrefixOracle(mpc, eps_a, eps_r, table=prefix_bb.CpuPrefixTable(mpc, eps_a, eps_r))
+    got = [Tree(NodeData(vertices=np.array(R))) for R in roots]
+    st = frontier.grow_cells(nat, got, slow_oracle=lambda: slow, round_cap=5,
+                             slow_opts=dict(handoff=False, split_batch=_host_split_batch))
+    n = sum(_same_trees(a, b) for a, b in zip(ref, got))
+    assert st['n_nodes'] <= n and st['rounds'] > 2 and not st['truncated']
+    closed = sum(1 for t in got for nd, _ in t.walk() if nd.is_leaf())
+    assert st['regions'] == closed
+    if eps_r == 2.0:
+        assert st['slow_path_cells'] <= 0.1 * closed
+    else:
+        assert st['slow_path_cells'] >= 1
+    # a second run on the same handle (reset drops the tree and the memo) gives the same tree
+    again = [Tree(NodeData(vertices=np.array(R))) for R in roots]
+    frontier.grow_cells(nat, again, slow_oracle=lambda: slow, round_cap=64,
+                        slow_opts=dict(handoff=False, split_batch=_host_split_batch))
+    assert sum(_same_trees(a, b) for a, b in zip(ref, again)) == n
+    nat.close()
+
+
+def test_native_driver_respects_a_budget_of_visits():
+    mpc = helpers.make_instance('pwa_small', 0)
+    eps_a = helpers.eps_a_rule(mpc, 0.25)
+    roots, _ = helpers.roots_of(mpc)
+    table = prefix_bb.CpuPrefixTable(mpc, eps_a, 0.2)
+    nat = frontier.NativeFrontier(mpc, eps_a, 0.2,
+                                  solvers=frontier.TableSolvers(table, _host_split_batch))
+    nat.add_roots(roots[:1])
+    st = nat.run(round_cap=2, max_visits=3)
+    assert st['truncated'] and st['visits'] == 3
+    flat = nat.export()
+    leaves = flat['left'] < 0
+    assert np.any(flat['flags'][leaves] & frontier.FR_PENDING)
+    st = nat.run(round_cap=8)                   # ... and goes on where it stopped
+    assert not st['truncated']
+    flat = nat.export()
+    assert not np.any(flat['flags'][flat['left'] < 0] & frontier.FR_PENDING)
+    nat.close()
+
+
+def test_a_failing_solver_surfaces_as_its_own_exception():
+    mpc = helpers.make_instance('pwa_small', 0)
+    table = prefix_bb.CpuPrefixTable(mpc, 1., 1.)
+
+    class Boom(RuntimeError):
+        pass
+
+    def broken(*a, **k):
+        raise Boom('no launch today')
+    table.solve_points = broken
+    nat = frontier.NativeFrontier(mpc, 1., 1.,
+                                  solvers=frontier.TableSolvers(table, _host_split_batch))
+    nat.add_roots(helpers.roots_of(mpc)[0][:1])
+    with pytest.raises(Boom):
+        nat.run()
+    nat.close()

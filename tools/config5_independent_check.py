@@ -49,7 +49,7 @@ ROUTE_TOL = 1e-6
 
 # ---------------------------------------------------------------------------------------------
 def cmd_sample(args):
-    from explicit_hybrid_mpc_amd import bnb, bnb_frontier, examples
+    from explicit_hybrid_mpc_amd import bnb, bnb_frontier, examples, frontier
     from explicit_hybrid_mpc_amd import tools as ehm_tools
     from explicit_hybrid_mpc_amd.tree import NodeData, Tree
     mpc = examples.pwa4_mpc(N=N_STEPS, seed=SEED)
@@ -60,6 +60,8 @@ def cmd_sample(args):
     orc.eps_a, orc.eps_r = eps_a, EPS_R
     orc.table.set_eps(eps_a, EPS_R)
     roots, _ = ehm_tools.delaunay_roots(V)
+    native = frontier.NativeFrontier(mpc, eps_a, EPS_R, slots=8192) if args.driver == 'native' \
+        else None
     rng = np.random.default_rng(args.seed)
     cells = [int(c) for c in args.cell_list.split(',')] if args.cell_list else list(range(args.cells))
     rec = dict(cell=[], loc=[], kind=[], R=[], seq=[], V=[], adopted_here=[], kids_R=[],
@@ -69,8 +71,12 @@ def cmd_sample(args):
         orc.table.forget()
         tree = Tree(NodeData(vertices=roots[c].copy()))
         t0 = time.perf_counter()
-        st = bnb_frontier.grow_frontier(orc, tree, 'ecc', order='lcss-first', table_backoff=True,
-                                        round_cap=4096)
+        if native is not None:          # the product's default driver (bench.py --driver native)
+            st = frontier.grow_cells(native, tree, slow_oracle=lambda: orc, slow_opts=dict(
+                order='lcss-first', table_backoff=True, round_cap=4096))
+        else:
+            st = bnb_frontier.grow_frontier(orc, tree, 'ecc', order='lcss-first',
+                                            table_backoff=True, round_cap=4096)
         nodes = list(tree.walk())
         has = {loc: hasattr(nd.data, 'commutation') for nd, loc in nodes}
         # kinds: 0 = split without a commutation, 1 = closed leaf, 2 = lcss split
@@ -120,6 +126,8 @@ def cmd_sample(args):
                     if hasattr(k.data, 'commutation') else np.full(mpc.N, -1, dtype=np.int32)
                     for k in (nd.left, nd.right)]))
     orc.close()
+    if native is not None:
+        native.close()
     os.makedirs(os.path.dirname(os.path.abspath(args.out)), exist_ok=True)
     np.savez_compressed(args.out, eps_a=eps_a, eps_r=EPS_R, cell=np.array(rec['cell']),
                         loc=np.array(rec['loc']), kind=np.array(rec['kind']),
@@ -307,6 +315,7 @@ def main():
     a.add_argument('--cell-list', default='', help='comma-separated root indices instead')
     a.add_argument('--per-cell', type=int, default=44)
     a.add_argument('--seed', type=int, default=0)
+    a.add_argument('--driver', choices=['native', 'python'], default='native')
     a.add_argument('--out', default='gpurun_out/c5_samples.npz')
     b = sub.add_parser('check')
     b.add_argument('samples')
