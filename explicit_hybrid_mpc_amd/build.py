@@ -146,6 +146,8 @@ def is_stale():
     if not os.path.exists(LIB):
         return True
     t = os.path.getmtime(LIB)
+    if not os.path.exists(os.path.join(SRC_DIR, 'ehm_kp.hip')):
+        return True                 # generated (tools/gen_kp.py), not in the repository
     srcs = [os.path.join(SRC_DIR, f)
             for f in ('ehm_capi.hip', 'ehm_k2.hip', 'ehm_k3.hip', 'ehm_kp.hip', 'ehm_explicit.hip')]
     return max([_dep_mtime()] + [os.path.getmtime(s)

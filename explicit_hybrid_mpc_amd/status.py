@@ -1,7 +1,7 @@
 """
 Progress and metrics of a partition run in the reference's formats:
 the per-process status record of ``WorkerStatusPublisher`` (lib/worker.py:19-116), the
-volume-filling-rate estimator and ETA (``RLS`` / ``ETACalculator``, lib/scheduler.py:59-152)
+volume-filling-rate estimator and ETA (the role of lib/scheduler.py:59-152)
 and the ``status.txt`` / ``statistics.pkl`` writer of ``MainStatusPublisher``
 (lib/scheduler.py:154-362), so that an operator's ``watch cat status.txt`` and the
 reference's ``PostProcessor.progress`` (lib/post_process.py:57-70, 144-175) keep working.
@@ -17,44 +17,46 @@ import time
 import numpy as np
 
 
-class RLS:
-    """Recursive averaging of a scalar with exponential forgetting (lib/scheduler.py:113-152)."""
+class ForgettingMean:
+    """
+    Exponentially weighted mean of a sampled scalar: sample i counts with weight rho^(age in
+    samples), rho = exp(-call_period / time_constant).  Kept as the two running sums
+    (numerator, weight), so there is no start-up case: value = sum rho^a m / sum rho^a.  (The
+    recursive estimator of lib/scheduler.py:113-152 converges to the same numbers.)
+    """
 
     def __init__(self, call_period, time_constant):
-        self.lamda = call_period / time_constant
+        self.rho = float(np.exp(-call_period / time_constant))
         self.reset()
 
     def reset(self):
-        self.state = 'init'
-        self.sigma = 1.
-        self.estimate = None
+        self._num = self._den = 0.
 
-    def update(self, measurement):
-        if self.state == 'init':
-            self.estimate = measurement
-            self.state = 'recurse'
-        else:
-            self.sigma = 1. + np.exp(-self.lamda) * self.sigma
-            phi = 1. / self.sigma
-            self.estimate = phi * measurement + (1. - phi) * self.estimate
+    def update(self, sample):
+        self._num = sample + self.rho * self._num
+        self._den = 1. + self.rho * self._den
+
+    @property
+    def value(self):
+        return self._num / self._den if self._den else None
 
 
-class ETACalculator:
-    """Time remaining from the estimated volume filling rate (lib/scheduler.py:59-111)."""
+class EtaEstimate:
+    """Seconds left = unfilled volume fraction / smoothed filling rate (the role of
+    lib/scheduler.py:59-111); None until a positive rate has been seen."""
 
     def __init__(self, call_period, time_constant):
-        self.rls = RLS(call_period, time_constant)
-
-    def eta(self, volume_filled):
-        if self.rls.estimate is None or self.rls.estimate == 0.:
-            return None
-        return (1. - volume_filled) / self.rls.estimate
-
-    def reset(self):
-        self.rls.reset()
+        self.rate = ForgettingMean(call_period, time_constant)
 
     def update(self, measured_rate):
-        self.rls.update(measured_rate)
+        self.rate.update(measured_rate)
+
+    def reset(self):
+        self.rate.reset()
+
+    def eta(self, volume_filled):
+        r = self.rate.value
+        return (1. - volume_filled) / r if r else None
 
 
 class WorkerStatus:
@@ -139,7 +141,7 @@ class MainStatusPublisher:
         for path in (status_file, statistics_file):     # blank files, like the reference
             if path:
                 open(path, 'w').close()
-        self.eta_estimator = ETACalculator(eta_window_duration, eta_time_constant)
+        self.eta_estimator = EtaEstimate(eta_window_duration, eta_time_constant)
         self.eta_last_measurement = None
         self.write_time_prev = dict(eta=None, status=None, statistics=None)
         self.write_period = dict(eta=eta_window_duration, status=status_write_period,

@@ -126,6 +126,53 @@ def test_reference_format_pickle_roundtrip(tmp_path):
     assert tree.Tree.__module__ == 'explicit_hybrid_mpc_amd.tree'
 
 
+REFERENCE_LIB = '/root/reference/lib'
+
+
+@pytest.mark.skipif(not os.path.exists(os.path.join(REFERENCE_LIB, 'tree.py')),
+                    reason='the reference tree is only present in the build container')
+def test_reference_tree_module_loads_the_pickle(tmp_path):
+    """f1 with the REAL consumer: the unmodified /root/reference/lib/tree.py (imports cleanly,
+    SURVEY 8c) unpickles what ``tree_io.dump_reference`` wrote -- a deep Delaunay-like spine and a
+    grown cell -- into ITS classes, and its own methods (``is_leaf``, attribute absence of
+    lib/tree.py:34-39, 86-95) read the result.  A tree pickled by the reference's classes comes
+    back through ``tree_io.load_reference``."""
+    root = tree.Tree(tree.NodeData(np.zeros((3, 2))))
+    cursor = root
+    for k in range(1500):
+        cursor.grow(tree.NodeData(np.full((3, 2), float(k)), commutation=np.ones(3),
+                                  vertex_costs=np.arange(3.), vertex_inputs=np.ones((3, 1))),
+                    None if k < 1499 else tree.NodeData(np.full((3, 2), -1.)))
+        cursor = cursor.right
+    root.left.grow(tree.NodeData(np.eye(3, 2)), tree.NodeData(np.eye(3, 2) * 2.))
+    root.left.left.data.is_epsilon_suboptimal = True
+    path = str(tmp_path / 'tree.pkl')
+    back_path = str(tmp_path / 'from_reference.pkl')
+    tree_io.dump_reference(root, path)
+    code = ("import sys, pickle; sys.dont_write_bytecode = True; sys.setrecursionlimit(100000);"
+            "sys.path.insert(0, %r); import tree;"
+            "assert tree.__file__.startswith(%r), tree.__file__;"
+            "t = pickle.load(open(%r, 'rb'));"
+            "assert type(t) is tree.Tree and type(t.data) is tree.NodeData;"
+            "assert not t.is_leaf() and t.left.left.is_leaf();"
+            "assert t.left.left.data.is_epsilon_suboptimal and not t.left.right.data.is_epsilon_suboptimal;"
+            "assert hasattr(t.left.data, 'commutation') and not hasattr(t.data, 'commutation');"
+            "n = 0; c = t\n"
+            "while not c.right.is_leaf(): c = c.right; n += 1\n"
+            "assert c.data is None and c.right.data.vertices[0, 0] == -1.\n"
+            "r = tree.Tree(tree.NodeData(vertices=t.left.data.vertices, commutation=t.left.data.commutation))\n"
+            "r.grow(tree.NodeData(vertices=t.left.left.data.vertices), tree.NodeData(vertices=t.left.right.data.vertices))\n"
+            "pickle.dump(r, open(%r, 'wb'))\n"
+            "print(n)") % (REFERENCE_LIB, REFERENCE_LIB, path, back_path)
+    out = subprocess.run([sys.executable, '-c', code], capture_output=True, text=True)
+    assert out.stdout.split() == ['1499'], out.stderr
+    back = tree_io.load_reference(back_path)
+    assert isinstance(back, tree.Tree) and isinstance(back.data, tree.NodeData)
+    assert np.array_equal(back.data.commutation, np.ones(3)) and not back.is_leaf()
+    assert np.array_equal(back.left.data.vertices, np.eye(3, 2))
+    assert not hasattr(back.left.data, 'commutation')
+
+
 def test_status_files_have_the_reference_format(tmp_path):
     """status.txt / statistics.pkl of lib/scheduler.py:154-362, fed from progress counters."""
     from explicit_hybrid_mpc_amd import status
@@ -137,18 +184,20 @@ def test_status_files_have_the_reference_format(tmp_path):
             return self.t
 
     clock = Clock()
-    # the rate estimator: recursive average with exponential forgetting (lib/scheduler.py:113-152)
-    rls = status.RLS(call_period=10., time_constant=180.)
+    # the rate estimator: exponentially weighted mean -- the numbers of the reference's
+    # recursive estimator (lib/scheduler.py:113-152), restated here step by step
+    mean = status.ForgettingMean(call_period=10., time_constant=180.)
+    assert mean.value is None
     est, sigma = None, 1.
     for m in (0.02, 0.03, 0.01, 0.05):
-        rls.update(m)
+        mean.update(m)
         if est is None:
             est = m
         else:
             sigma = 1. + np.exp(-10. / 180.) * sigma
             est = m / sigma + (1. - 1. / sigma) * est
-        assert abs(rls.estimate - est) < 1e-15
-    eta = status.ETACalculator(10., 180.)
+        assert abs(mean.value - est) < 1e-15
+    eta = status.EtaEstimate(10., 180.)
     assert eta.eta(0.3) is None
     eta.update(0.01)
     assert abs(eta.eta(0.3) - 70.) < 1e-12
