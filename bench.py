@@ -874,11 +874,12 @@ def measure_config5(args, ctx):
                 per[name]['secs'] = [a + b for a, b in zip(per[name]['secs'], nt['batch_seconds'])]
                 per[name]['launches'] = [a + b for a, b in zip(per[name]['launches'],
                                                                nt['batch_launches'])]
-                per[name]['hist'][:, :h.shape[1]] += h
+                wdt = min(per[name]['hist'].shape[1], h.shape[1])      # (short table: <= 4 steps)
+                per[name]['hist'][:, :wdt] += h[:, :wdt]
         return dict(lp=sum(v['lp'] for v in per.values()), per=per,
                     calls={k: orc.calls[k] + nat_acc['calls'][k] for k in orc.calls},
                     expanded=orc.n_expanded + nat_acc['expanded'],
-                    hist=sum(v['hist'] for v in per.values()),
+                    hist=orc.table.by_length + (0 if nat_hist is None else nat_hist.sum(axis=0)),
                     stalled=orc.table.stalled + nat_acc['stalled'])
 
     def grow_group(part):

@@ -350,4 +350,21 @@ __device__ inline void longest_edge_wave(const double* R, int p, int lane, int& 
     bj = __shfl(eb, src, 64);
 }
 
+// Status word of a batched solve: 0 = converged / accepted.  Otherwise 1 | (q << 8), q = the decade
+// of the best merit the solve reached (merit <= 10^q; merit 1 = the tolerances of 1e-10): a solve
+// that stalled at merit 10^q holds its optimum to about 10^(q - 10), relative.  Callers that need
+// a SIGN, or that accept what the reference accepts as OPTIMAL_INACCURATE
+// (lib/oracle.py:440-442), read the decade; everybody else sees "nonzero = not converged".
+__device__ inline int ehm_status_word(int status, double merit) {
+    if (status == 0) return 0;
+    int q = 0;
+    if (!(merit == merit)) {
+        q = 99;
+    } else {
+        double m = merit;
+        while (m > 1.0 && q < 99) { m *= 0.1; ++q; }
+    }
+    return 1 | (q << 8);
+}
+
 }  // namespace ehm

@@ -120,7 +120,7 @@ __global__ __launch_bounds__(EHM_K2_THREADS) void k2_point_batch(
             const double Jout = (feas && G.sign_mode) ? copysign(r.margin, r.obj) : r.obj;
             if (lane == 0) {
                 J[o] = Jout;
-                if (status) status[o] = r.status;
+                if (status) status[o] = ehm_status_word(r.status, r.merit);
                 if (iters) iters[o] = r.iters;
             }
             if (u0 && lane < P.n_u) u0[o * P.n_u + lane] = W.xb[lane];
@@ -200,7 +200,7 @@ __global__ __launch_bounds__(EHM_K2_THREADS) void k2_simplex_batch(
             if (lane == 0) {
                 const double val = (G.sign_mode && mode != SX_MIN) ? copysign(r.margin, r.obj) : r.obj;
                 obj[o] = (mode == SX_SLACK) ? -val : val;         // t* = -(min -t)
-                if (status) status[o] = r.status;
+                if (status) status[o] = ehm_status_word(r.status, r.merit);
                 if (iters) iters[o] = r.iters;
             }
             if (alpha) {

@@ -193,7 +193,7 @@ EHM3_KERNEL void k3_point_batch(
         count_solve(cnt, r, tid);
         if (tid == 0) {
             J[o] = r.obj;
-            if (status) status[o] = r.status;
+            if (status) status[o] = ehm_status_word(r.status, r.merit);
             if (iters) iters[o] = r.iters;
         }
         if (u0 && tid < P.n_u) u0[o * P.n_u + tid] = L.xb[tid];
@@ -245,7 +245,7 @@ EHM3_KERNEL void k3_simplex_batch(
         count_solve(cnt, r, tid);
         if (tid == 0) {
             obj[o] = (mode == SX_SLACK) ? -r.obj : r.obj;     // t* = -(min -t)
-            if (status) status[o] = r.status;
+            if (status) status[o] = ehm_status_word(r.status, r.merit);
             if (iters) iters[o] = r.iters;
         }
         if (alpha && B.wave == 0) {
