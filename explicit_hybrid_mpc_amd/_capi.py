@@ -37,6 +37,7 @@ EXPORTED = [
     'ehm_feas_all_batch', 'ehm_lcss_batch', 'ehm_partition_movable',
     'ehm_problem_update_blocks', 'ehm_simplex_idx_batch', 'ehm_point_idx_batch',
     'ehm_abi_sizes', 'ehm_solver_phase_ticks', 'ehm_problem_layout',
+    'ehm_host_alloc', 'ehm_host_free',
 ]
 
 
@@ -242,6 +243,8 @@ def load(build_if_missing=True):
     lib.ehm_explicit_last_error.restype = ctypes.c_char_p
     lib.ehm_tree_info_get.argtypes = [vp, ctypes.POINTER(TreeInfo)]
     lib.ehm_tree_export.argtypes = [vp, vp, vp, vp, vp, vp, vp, vp, vp]
+    lib.ehm_host_alloc.argtypes = [ctypes.c_size_t, ctypes.POINTER(vp)]
+    lib.ehm_host_free.argtypes = [vp]
     lib.ehm_tree_destroy.argtypes = [vp]
     lib.ehm_stats.argtypes = [vp, ctypes.POINTER(Counters)]
     lib.ehm_solver_phase_ticks.argtypes = [vp, vp]

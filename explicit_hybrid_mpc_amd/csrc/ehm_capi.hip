@@ -514,6 +514,7 @@ struct ehm_problem {
     DevBuf fr_a, fr_b, open_flag, open_list, d_count;
     DevBuf pq_slots, pq_ctl;   // persistent engine: queue slots, control block
     DevBuf in0, in1, in2, out0, out1, out2, out3;
+    DevBuf ex_stage, ex_tmp;      // ehm_tree_export: staging of the gathered records, scan scratch
     DevCounters* d_cnt = nullptr;
     struct ehm_tree* active_run = nullptr;   // the partition run that owns the scratch above
     // every tree made from this handle that is still alive: ehm_problem_destroy detaches them, so
@@ -548,7 +549,8 @@ struct ehm_tree {
     bool unordered = false;
     bool keep_ids = false;   // runs that exchanged nodes with other ranks: the transfer logs name
                              // device ids, the export must not renumber
-    std::vector<int32_t> perm;
+    DevBuf d_perm, d_inv;    // the numbering, once computed (k_bfs_*)
+    bool have_perm = false;
     // state of a run in progress (ehm_partition_begin .. ehm_partition_finish)
     struct Run {
         bool active = false;
@@ -1056,6 +1058,7 @@ int ehm_problem_destroy(ehm_problem* P) {
     P->d_count.release();
     P->pq_slots.release(); P->pq_ctl.release();
     P->in0.release(); P->in1.release(); P->in2.release();
+    P->ex_stage.release(); P->ex_tmp.release();
     P->out0.release(); P->out1.release(); P->out2.release(); P->out3.release();
     if (P->d_cnt) (void)hipFree(P->d_cnt);
     for (hipEvent_t e : P->bev)
@@ -1205,6 +1208,9 @@ int ehm_problem_set_option(ehm_problem* P, const char* name, double value) {
     }
     if (!strcmp(name, "any_admissible")) {
         if (value < 0.0 || value > 2e9) return fail(EHM_E_INVALID, "any_admissible: seed + 1, or 0");
+        // the path codes the hashed draws read are allocated when a run begins (hy_begin)
+        if (P->active_run)
+            return fail(EHM_E_INVALID, "any_admissible: not while a partition run is active");
         P->any_admissible = (int)value;
         return EHM_OK;
     }
@@ -2138,6 +2144,7 @@ int ehm_tree_destroy(ehm_tree* T) {
     T->rec.release(); T->left.release(); T->didx.release(); T->depth.release();
     T->flags.release(); T->tstar.release(); T->grad.release(); T->code.release();
     T->wit.release(); T->mt_state.release(); T->mt_data.release();
+    T->d_perm.release(); T->d_inv.release();
     delete T;
     return EHM_OK;
 }
@@ -2261,6 +2268,95 @@ __global__ void k_export_gather(DevTree T, const int32_t* __restrict__ perm,
         out_d[k] = T.didx[id];
         out_f[k] = T.flags[id];
     }
+}
+
+// ---- breadth-first numbering on the device (ehm_tree_export of the persistent engine) -----------
+// The persistent kernel allocates node ids in the order its wavefronts split; the export
+// renumbers them breadth first (roots in order, then per level the two children of every split
+// node in parent order: the numbering of the level-synchronous engine).  Level by level:
+// perm[lo..hi) holds level d in its final order; an exclusive scan of "was split" over it gives
+// every parent the place of its children in level d + 1.  Three small launches per level with
+// the bounds in device memory (no host round trip): count per block, scan of the block sums,
+// write.  bounds[2 * parity] = lo, [2 * parity + 1] = hi.
+#define BFS_BLOCKS 256
+#define BFS_THREADS 256
+__global__ void k_bfs_roots(int32_t* __restrict__ perm, int32_t* __restrict__ bounds, int n_roots) {
+    const int t = blockIdx.x * blockDim.x + threadIdx.x;
+    if (t < n_roots) perm[t] = t;
+    if (t == 0) { bounds[0] = 0; bounds[1] = n_roots; bounds[2] = n_roots; bounds[3] = n_roots; }
+}
+__global__ void k_bfs_count(const int32_t* __restrict__ left, const int32_t* __restrict__ perm,
+                            const int32_t* __restrict__ bounds, int parity,
+                            int32_t* __restrict__ bsum) {
+    const int lo = bounds[2 * parity], hi = bounds[2 * parity + 1];
+    const int per = (hi - lo + (int)gridDim.x - 1) / (int)gridDim.x;
+    const int b0 = lo + (int)blockIdx.x * per, b1 = min(hi, b0 + per);
+    int c = 0;
+    for (int i = b0 + (int)threadIdx.x; i < b1; i += (int)blockDim.x) c += left[perm[i]] >= 0;
+    __shared__ int sh[BFS_THREADS / 64];
+    for (int o = 32; o > 0; o >>= 1) c += __shfl_xor(c, o, 64);
+    if ((threadIdx.x & 63) == 0) sh[threadIdx.x >> 6] = c;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        int tot = 0;
+        for (int w = 0; w < BFS_THREADS / 64; ++w) tot += sh[w];
+        bsum[blockIdx.x] = tot;
+    }
+}
+__global__ void k_bfs_scan(int32_t* __restrict__ bsum, int32_t* __restrict__ bounds, int parity) {
+    __shared__ int sh[BFS_BLOCKS];
+    const int t = threadIdx.x;
+    sh[t] = bsum[t];
+    __syncthreads();
+    for (int o = 1; o < BFS_BLOCKS; o <<= 1) {          // inclusive scan, BFS_BLOCKS threads
+        const int v = (t >= o) ? sh[t - o] : 0;
+        __syncthreads();
+        sh[t] += v;
+        __syncthreads();
+    }
+    bsum[t] = t ? sh[t - 1] : 0;
+    if (t == 0) {
+        const int hi = bounds[2 * parity + 1];
+        bounds[2 * (parity ^ 1)] = hi;
+        bounds[2 * (parity ^ 1) + 1] = hi + 2 * sh[BFS_BLOCKS - 1];
+    }
+}
+__global__ void k_bfs_write(const int32_t* __restrict__ left, int32_t* __restrict__ perm,
+                            const int32_t* __restrict__ bounds, int parity,
+                            const int32_t* __restrict__ boff) {
+    const int lo = bounds[2 * parity], hi = bounds[2 * parity + 1];
+    const int per = (hi - lo + (int)gridDim.x - 1) / (int)gridDim.x;
+    const int b0 = lo + (int)blockIdx.x * per, b1 = min(hi, b0 + per);
+    __shared__ int woff[BFS_THREADS / 64];
+    __shared__ int s_run;
+    if (threadIdx.x == 0) s_run = boff[blockIdx.x];
+    __syncthreads();
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    for (int base = b0; base < b1; base += (int)blockDim.x) {
+        const int i = base + (int)threadIdx.x;
+        const int c = (i < b1) ? left[perm[i]] : -1;
+        const unsigned long long m = __builtin_amdgcn_ballot_w64(c >= 0);
+        const int before = __builtin_popcountll(m & ((1ull << lane) - 1ull));
+        if (lane == 0) woff[wave] = __builtin_popcountll(m);
+        __syncthreads();
+        int off = s_run;
+        for (int w = 0; w < wave; ++w) off += woff[w];
+        if (c >= 0) {
+            perm[hi + 2 * (off + before)] = c;
+            perm[hi + 2 * (off + before) + 1] = c + 1;
+        }
+        __syncthreads();
+        if (threadIdx.x == 0) {
+            int tot = 0;
+            for (int w = 0; w < BFS_THREADS / 64; ++w) tot += woff[w];
+            s_run += tot;
+        }
+        __syncthreads();
+    }
+}
+__global__ void k_bfs_invert(const int32_t* __restrict__ perm, int32_t* __restrict__ inv, long long n) {
+    const long long k = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (k < n) inv[perm[k]] = (int32_t)k;
 }
 
 // gather / scatter of node records for the frontier hand-over
@@ -3127,56 +3223,54 @@ int ehm_tree_export(const ehm_tree* Tc, double* vertices, int32_t* left, int32_t
     ehm_problem* P = T->prob;
     HIP_TRY(hipSetDevice(P->device), EHM_E_HIP);
     const long long n = T->info.n_nodes;
-    const int p = P->dp.p, n_u = P->dp.n_u, stride = T->dt.rec_stride;
+    if (n <= 0) return EHM_OK;
+    const int p = P->dp.p, n_u = P->dp.n_u;
     const int nR = (p + 1) * p;
-    std::vector<int32_t> inv;
     const bool relabel = T->unordered && !T->keep_ids;
-    if (relabel) {
-        // breadth-first relabelling = the numbering of the level-synchronous engine: roots in
-        // order, then per level the two children of every split node in parent order
-        std::vector<int32_t> l((size_t)n);
-        HIP_TRY(hipMemcpy(l.data(), T->dt.left, (size_t)n * 4, hipMemcpyDeviceToHost), EHM_E_HIP);
-        if (T->perm.empty()) {
-            T->perm.reserve((size_t)n);
-            for (int32_t k = 0; k < (int32_t)T->info.n_roots; ++k) T->perm.push_back(k);
-            for (size_t h = 0; h < T->perm.size(); ++h) {
-                const int32_t c = l[(size_t)T->perm[h]];
-                if (c >= 0) {
-                    T->perm.push_back(c);
-                    T->perm.push_back(c + 1);
-                }
-            }
-            if ((long long)T->perm.size() != n)
-                return fail(EHM_E_HIP, "tree structure inconsistent (%zu of %lld nodes reachable)",
-                            T->perm.size(), n);
-        }
-        inv.assign((size_t)n, -1);
-        for (long long k = 0; k < n; ++k) inv[(size_t)T->perm[(size_t)k]] = (int32_t)k;
-    }
-    // The records are gathered ON THE DEVICE into the caller's layout and numbering (one pass
-    // over a chunk of nodes, coalesced writes), then copied out slice by slice: no host-side
-    // staging copy of the whole pool, no per-node memcpy.
-    DevBuf d_perm, d_inv, stage;
     int rc = EHM_OK;
-    if (relabel) {
-        if ((rc = d_perm.ensure((size_t)n * 4)) || (rc = d_inv.ensure((size_t)n * 4))) return rc;
-        HIP_TRY(hipMemcpyAsync(d_perm.ptr, T->perm.data(), (size_t)n * 4, hipMemcpyHostToDevice,
-                               P->stream), EHM_E_HIP);
-        HIP_TRY(hipMemcpyAsync(d_inv.ptr, inv.data(), (size_t)n * 4, hipMemcpyHostToDevice,
-                               P->stream), EHM_E_HIP);
+    if (relabel && !T->have_perm) {
+        // breadth-first numbering, level by level ON THE DEVICE (k_bfs_*): no copy of the
+        // structure to the host, no host loop over the nodes
+        if ((rc = T->d_perm.ensure((size_t)n * 4)) || (rc = T->d_inv.ensure((size_t)n * 4))) return rc;
+        if ((rc = P->ex_tmp.ensure((size_t)(BFS_BLOCKS + 8) * 4))) return rc;
+        int32_t* bsum = P->ex_tmp.as<int32_t>();
+        int32_t* bounds = bsum + BFS_BLOCKS;
+        int32_t* perm = T->d_perm.as<int32_t>();
+        const int n_roots = (int)T->info.n_roots;
+        hipLaunchKernelGGL(k_bfs_roots, dim3((unsigned)((n_roots + 255) / 256)), dim3(256), 0, P->stream,
+                           perm, bounds, n_roots);
+        const int levels = T->info.max_depth + 2;       // (the last ones are empty)
+        for (int d = 0; d < levels; ++d) {
+            const int par = d & 1;
+            hipLaunchKernelGGL(k_bfs_count, dim3(BFS_BLOCKS), dim3(BFS_THREADS), 0, P->stream,
+                               T->dt.left, perm, bounds, par, bsum);
+            hipLaunchKernelGGL(k_bfs_scan, dim3(1), dim3(BFS_BLOCKS), 0, P->stream, bsum, bounds, par);
+            hipLaunchKernelGGL(k_bfs_write, dim3(BFS_BLOCKS), dim3(BFS_THREADS), 0, P->stream,
+                               T->dt.left, perm, bounds, par, bsum);
+        }
+        int32_t hb[4] = {0, 0, 0, 0};
+        HIP_TRY(hipMemcpyAsync(hb, bounds, sizeof hb, hipMemcpyDeviceToHost, P->stream), EHM_E_HIP);
+        HIP_TRY(hipStreamSynchronize(P->stream), EHM_E_HIP);
+        const int reached = hb[2 * (levels & 1) + 1];
+        if (reached != n || hb[2 * (levels & 1)] != reached)
+            return fail(EHM_E_HIP, "tree structure inconsistent (%d of %lld nodes numbered in %d levels)",
+                        reached, n, levels);
+        hipLaunchKernelGGL(k_bfs_invert, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, P->stream,
+                           perm, T->d_inv.as<int32_t>(), n);
+        T->have_perm = true;
     }
+    // The records are gathered ON THE DEVICE into the caller's layout and numbering -- ONE pass
+    // over all nodes into a staging buffer that lives with the problem handle (no allocation per
+    // export) -- and copied out array by array with ONE wait at the end.  Callers that hand over
+    // pinned memory (ehm_host_alloc) get the copies at the speed of the host link.
     const int nc = p + 1, nu = (p + 1) * n_u, nrec = nR + nc + nu;
-    const long long chunk = std::min<long long>(n, 1LL << 18);
-    // staging per chunk: records (nrec doubles) | tstar | left | right | didx | flags
     const size_t per_node = (size_t)nrec * 8 + 8 + 4 + 4 + 4 + 1;
-    if ((rc = stage.ensure((size_t)chunk * per_node + 64))) {
-        d_perm.release(); d_inv.release();
-        return rc;
-    }
-    auto cleanup = [&]() { d_perm.release(); d_inv.release(); stage.release(); };
+    // (a pool too large for one staging buffer goes in parts of 2^22 nodes, one wait each)
+    const long long chunk = std::min<long long>(n, 1LL << 22);
+    if ((rc = P->ex_stage.ensure((size_t)chunk * per_node + 64))) return rc;
     for (long long k0 = 0; k0 < n; k0 += chunk) {
         const long long nk = std::min(chunk, n - k0);
-        double* s_v = stage.as<double>();
+        double* s_v = P->ex_stage.as<double>();
         double* s_c = s_v + (size_t)nk * nR;
         double* s_u = s_c + (size_t)nk * nc;
         double* s_t = s_u + (size_t)nk * nu;
@@ -3185,8 +3279,8 @@ int ehm_tree_export(const ehm_tree* Tc, double* vertices, int32_t* left, int32_t
         int32_t* s_d = s_r + nk;
         uint8_t* s_f = reinterpret_cast<uint8_t*>(s_d + nk);
         hipLaunchKernelGGL(k_export_gather, dim3((unsigned)((nk * nrec + 255) / 256)), dim3(256), 0,
-                           P->stream, T->dt, relabel ? d_perm.as<int32_t>() : (const int32_t*)nullptr,
-                           relabel ? d_inv.as<int32_t>() : (const int32_t*)nullptr, k0, nk, n_u, s_v,
+                           P->stream, T->dt, relabel ? T->d_perm.as<int32_t>() : (const int32_t*)nullptr,
+                           relabel ? T->d_inv.as<int32_t>() : (const int32_t*)nullptr, k0, nk, n_u, s_v,
                            s_c, s_u, s_t, s_l, s_r, s_d, s_f);
         hipError_t e = hipGetLastError();
 #define EXP_COPY(dst, srcp, bytes)                                                         \
@@ -3201,13 +3295,25 @@ int ehm_tree_export(const ehm_tree* Tc, double* vertices, int32_t* left, int32_t
         EXP_COPY(delta_idx ? delta_idx + k0 : nullptr, s_d, (size_t)nk * 4);
         EXP_COPY(flags ? flags + k0 : nullptr, s_f, (size_t)nk);
 #undef EXP_COPY
-        if (e == hipSuccess) e = hipStreamSynchronize(P->stream);   // the stage is reused
-        if (e != hipSuccess) {
-            cleanup();
-            return fail(EHM_E_HIP, "tree export failed: %s", hipGetErrorString(e));
-        }
+        if (e == hipSuccess) e = hipStreamSynchronize(P->stream);
+        if (e != hipSuccess) return fail(EHM_E_HIP, "tree export failed: %s", hipGetErrorString(e));
     }
-    cleanup();
+    return EHM_OK;
+}
+
+// Page-locked host memory for the arrays ehm_tree_export fills: copies into it run at the speed
+// of the host link (into pageable memory they are staged by the runtime, several times slower).
+int ehm_host_alloc(size_t bytes, void** out) {
+    if (!out) return fail(EHM_E_INVALID, "ehm_host_alloc: out is NULL");
+    *out = nullptr;
+    void* q = nullptr;
+    if (hipHostMalloc(&q, bytes ? bytes : 1, hipHostMallocDefault) != hipSuccess)
+        return fail(EHM_E_CAPACITY, "ehm_host_alloc: %zu bytes of page-locked memory refused", bytes);
+    *out = q;
+    return EHM_OK;
+}
+int ehm_host_free(void* q) {
+    if (q && hipHostFree(q) != hipSuccess) return fail(EHM_E_HIP, "ehm_host_free failed");
     return EHM_OK;
 }
 

@@ -863,8 +863,7 @@ __global__ __launch_bounds__(EHM_K2_THREADS) void k2_persist(
         const long long t_post = wall_clock64();
         // the wavefront goes on with child 1 itself (work first, below) unless the children are
         // dealt over ranks at this depth: then its record, gradients and witness also stay in LDS
-        const bool fast = keep_child && deal.pop_limit <= 0 &&
-                          !(deal.world > 1 && dep + 1 == deal.depth);
+        const bool fast = keep_child && !(deal.world > 1 && dep + 1 == deal.depth);
         // the node's own gradients again (the solves have used the workspace they were staged in):
         // the load is under way while the allocation below makes its round trip
         const double gv0 = (T.grad && lane < ng) ? T.grad[(size_t)id * ng + lane] : 0.0;
@@ -1089,11 +1088,13 @@ __global__ __launch_bounds__(EHM_K2_THREADS) void k2_persist(
             // Work first: the wavefront goes on with ONE of the children itself (its record is
             // hot, no queue round trip, and the deep chains that end a partition are followed at
             // once instead of waiting behind the whole frontier at every level); the other child
-            // feeds the queue.  Budgeted launches (pop_limit) queue both: what they leave must be
-            // the contiguous slice behind the pop limit.
+            // feeds the queue.  Budgeted launches (pop_limit) do the same since round 5: a kept
+            // child never enters the queue -- its wavefront follows the chain to its end, at most
+            // one visit per tree level --, so what the launch leaves is still the contiguous slice
+            // behind the pop limit (rounds 3-4 queued both children there and paid 40 % more LPs).
             const int nown = own0 + own1;
             int push0 = own0, push1 = own1;
-            if (deal.pop_limit <= 0 && keep_child) {
+            if (keep_child) {
                 if (own1) { kept = c0 + 1; push1 = 0; }
                 else if (own0) { kept = c0; push0 = 0; }
             }

@@ -351,12 +351,15 @@ def run_balanced(gp, roots, action='ecc', init=None, max_nodes=0, min_frontier=1
         room = [int(v) for v in info[:, 1]]
         plan = []
         # planned on what can move (multi-commutation runs: nodes that carry data)
-        for donor, receiver, k in balance_plan(info[:, 2], tolerance, min_move):
+        wanted = balance_plan(info[:, 2], tolerance, min_move)
+        for donor, receiver, k in wanted:
             k = min(k, max(0, room[receiver] - 2 * int(counts[receiver]) - 64))
             if k >= min_move:
                 plan.append((donor, receiver, k))
                 room[receiver] -= k
-        if (persistent and settle_frontier > 0 and not publish_status and not plan and
+        # settling is decided on the plan BEFORE the receivers' room clips it: a round whose
+        # transfers were all dropped for lack of room is not a balanced one
+        if (persistent and settle_frontier > 0 and not publish_status and not wanted and
                 int(counts.min()) >= int(settle_frontier)):
             settled = True          # every rank sees the same counts: the next launch is the last
             log.append(dict(kind='settle', round=rnd, counts=[int(c) for c in counts]))

@@ -16,6 +16,46 @@ from . import _capi
 from ._capi import f64, u8, ptr, check
 
 
+# -- page-locked arrays for the flat export ------------------------------------------------------
+# ehm_tree_export copies straight into the caller's arrays; into page-locked memory
+# (ehm_host_alloc) those copies run at the speed of the host link.  Blocks are recycled by size: a
+# FlatTree that is garbage-collected hands its blocks to the next export of the same shape
+# (pinning half a gigabyte costs more than copying it).
+_PINNED_FREE = {}           # nbytes -> [address, ...]
+_PINNED_CACHE_LIMIT = 4 << 30
+_pinned_cached = [0]
+
+
+def _pinned_release(addr, nbytes):
+    if _pinned_cached[0] + nbytes <= _PINNED_CACHE_LIMIT:
+        _PINNED_FREE.setdefault(nbytes, []).append(addr)
+        _pinned_cached[0] += nbytes
+    else:
+        try:
+            _capi.load().ehm_host_free(ctypes.c_void_p(addr))
+        except Exception:
+            pass
+
+
+def pinned_empty(shape, dtype=np.float64):
+    """An uninitialised numpy array in page-locked host memory (freed / recycled when the last
+    view of it is dropped)."""
+    import weakref
+    dtype = np.dtype(dtype)
+    nbytes = max(int(np.prod(shape)) * dtype.itemsize, 1)
+    free = _PINNED_FREE.get(nbytes)
+    if free:
+        addr = free.pop()
+        _pinned_cached[0] -= nbytes
+    else:
+        out = ctypes.c_void_p()
+        check(_capi.load().ehm_host_alloc(nbytes, ctypes.byref(out)))
+        addr = out.value
+    buf = (ctypes.c_char * nbytes).from_address(addr)
+    weakref.finalize(buf, _pinned_release, addr, nbytes)
+    return np.frombuffer(buf, dtype=dtype, count=int(np.prod(shape))).reshape(shape)
+
+
 def _info_dict(info):
     """ehm_tree_info as a dict (array members as lists)."""
     out = {}
@@ -372,14 +412,14 @@ class GpuProblem:
                 return info_d
             K = info.n_nodes
             p, n_u = self.can.p, self.can.n_u
-            vertices = np.empty((K, p + 1, p))
-            left = np.empty(K, dtype=np.int32)
-            right = np.empty(K, dtype=np.int32)
-            didx = np.empty(K, dtype=np.int32)
-            vcost = np.empty((K, p + 1))
-            vinput = np.empty((K, p + 1, n_u))
-            flags = np.empty(K, dtype=np.uint8)
-            tstar = np.empty(K)
+            vertices = pinned_empty((K, p + 1, p))
+            left = pinned_empty(K, np.int32)
+            right = pinned_empty(K, np.int32)
+            didx = pinned_empty(K, np.int32)
+            vcost = pinned_empty((K, p + 1))
+            vinput = pinned_empty((K, p + 1, n_u))
+            flags = pinned_empty(K, np.uint8)
+            tstar = pinned_empty(K)
             check(self._lib.ehm_tree_export(tree, ptr(vertices), ptr(left), ptr(right),
                                             ptr(didx), ptr(vcost), ptr(vinput), ptr(flags),
                                             ptr(tstar)))

@@ -23,6 +23,7 @@
 #ifndef EHMPC_H
 #define EHMPC_H
 
+#include <stddef.h>
 #include <stdint.h>
 
 #ifdef __cplusplus
@@ -431,6 +432,12 @@ int ehm_tree_export(const ehm_tree* tree, double* vertices, int32_t* left, int32
                     int32_t* delta_idx, double* vcost, double* vinput, uint8_t* flags,
                     double* tstar);
 int ehm_tree_destroy(ehm_tree* tree);
+/* Page-locked host memory for the arrays ehm_tree_export fills (the export then runs at the speed
+ * of the host link; the branch is the worker's output, lib/worker.py:456-458).  Free with
+ * ehm_host_free. */
+int ehm_host_alloc(size_t bytes, void** out);
+int ehm_host_free(void* ptr);
+
 
 /* ---- batched evaluation of the explicit control law (the partition's consumer) --------- */
 
