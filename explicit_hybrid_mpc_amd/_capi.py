@@ -132,14 +132,17 @@ POINTS_FN = ctypes.CFUNCTYPE(ctypes.c_int, ctypes.c_void_p, ctypes.c_int64, ctyp
                              ctypes.c_void_p, ctypes.c_int32, ctypes.c_int32, ctypes.c_void_p,
                              ctypes.c_void_p)
 SLACK_FN = ctypes.CFUNCTYPE(ctypes.c_int, ctypes.c_void_p, ctypes.c_int64, ctypes.c_void_p,
-                            ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p)
+                            ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p,
+                            ctypes.c_void_p)
+MIN_FN = ctypes.CFUNCTYPE(ctypes.c_int, ctypes.c_void_p, ctypes.c_int64, ctypes.c_void_p,
+                          ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p)
 SPLIT_FN = ctypes.CFUNCTYPE(ctypes.c_int, ctypes.c_void_p, ctypes.c_int64, ctypes.c_void_p,
                             ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p)
 
 
 class PairSolvers(ctypes.Structure):
     _fields_ = [('user', ctypes.c_void_p), ('points', POINTS_FN), ('slack', SLACK_FN),
-                ('split', SPLIT_FN)]
+                ('min', MIN_FN), ('split', SPLIT_FN)]
 
 
 class FrontierOpts(ctypes.Structure):
@@ -151,7 +154,7 @@ class FrontierOpts(ctypes.Structure):
 class FrontierStats(ctypes.Structure):
     _fields_ = [(k, ctypes.c_int64) for k in (
         'rounds', 'visits', 'ecc_visits', 'lcss_visits', 'regions', 'open_cells', 'n_nodes',
-        'calls_v_r', 'calls_p_theta', 'calls_bar_e', 'witness_hits', 'prefixes_expanded',
+        'calls_v_r', 'calls_p_theta', 'calls_bar_e', 'calls_bar_d', 'swaps', 'witness_hits', 'prefixes_expanded',
         'answered_without_a_problem', 'optima_asked', 'optima_solved', 'lp_solves', 'launches',
         'blocks_loaded', 'stalled', 'slivers')] + [
         ('truncated', ctypes.c_int32), ('depth', ctypes.c_int32),

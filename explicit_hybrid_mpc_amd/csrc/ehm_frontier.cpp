@@ -414,8 +414,9 @@ struct DeviceSolver {
 
     // sequences.PrefixTable.slack_by_prefix_index (+ _settle_stalled)
     void slack(int64_t n_pairs, const uint64_t* code, const double* R, const double* Vbar,
-               const uint8_t* known, double* t_out) {
+               const uint8_t* known, double* t_out, double* alpha_out) {
         for (int64_t k = 0; k < n_pairs; ++k) t_out[k] = -INF;
+        if (alpha_out) std::fill(alpha_out, alpha_out + (size_t)n_pairs * nv, 0.0);
         std::vector<int64_t> sel[2];
         split_tables(n_pairs, code, sel);
         const size_t sx = (size_t)nv * p;
@@ -504,7 +505,91 @@ struct DeviceSolver {
                         raise(EHM_E_NUMERIC, "%lld suboptimality-test problem(s) of full mode "
                               "sequences did not converge on the device", (long long)full_err);
                 }
-                for (size_t g = 0; g < good.size(); ++g) t_out[part[good[g]]] = tk[g];
+                for (size_t g = 0; g < good.size(); ++g) {
+                    t_out[part[good[g]]] = tk[g];
+                    if (alpha_out)
+                        std::memcpy(alpha_out + (size_t)part[good[g]] * nv, &al[g * nv], 8 * (size_t)nv);
+                }
+            });
+        }
+    }
+
+    // sequences.PrefixTable.solve_min for pairs KNOWN to be feasible on their simplex (the node's
+    // own commutation): +inf infeasible (an interior-free sliver), -inf a solve that stalled
+    void minimum(int64_t n_pairs, const uint64_t* code, const double* R, const uint8_t* known,
+                 double* J_out) {
+        for (int64_t k = 0; k < n_pairs; ++k) J_out[k] = INF;
+        std::vector<int64_t> sel[2];
+        split_tables(n_pairs, code, sel);
+        const size_t sx = (size_t)nv * p;
+        std::vector<double> Rb, tau, al, Jk;
+        std::vector<int32_t> st, sl;
+        std::vector<uint8_t> ok, v;
+        for (int tt = 0; tt < 2; ++tt) {
+            if (sel[tt].empty()) continue;
+            Table& T = tab[tt];
+            chunks(T, code, sel[tt], [&](const std::vector<int64_t>& part, const std::vector<int32_t>& slot) {
+                const size_t cnt = part.size();
+                ok.assign(cnt, 1);
+                std::vector<size_t> todo;
+                for (size_t k = 0; k < cnt; ++k)
+                    if (!(known && known[part[k]])) todo.push_back(k);
+                if (!todo.empty()) {
+                    Rb.resize(todo.size() * sx); sl.resize(todo.size());
+                    for (size_t q = 0; q < todo.size(); ++q) {
+                        std::memcpy(&Rb[q * sx], R + (size_t)part[todo[q]] * sx, 8 * sx);
+                        sl[q] = slot[todo[q]];
+                    }
+                    tau.resize(todo.size()); al.resize(todo.size() * nv); st.resize(todo.size());
+                    chk_dev(ehm_simplex_idx_batch(T.P, (int64_t)todo.size(), Rb.data(), nullptr, sl.data(),
+                                                  2, tau.data(), al.data(), st.data()),
+                            "ehm_simplex_idx_batch");
+                    ++launches;
+                    T.lp += (int64_t)todo.size();
+                    tally(T, 2, sl);
+                    verdicts(tau, st, v);
+                    for (size_t q = 0; q < todo.size(); ++q) ok[todo[q]] = v[q];
+                }
+                std::vector<size_t> good;
+                for (size_t k = 0; k < cnt; ++k)
+                    if (ok[k]) good.push_back(k);
+                if (good.empty()) return;
+                Rb.resize(good.size() * sx); sl.resize(good.size());
+                for (size_t g = 0; g < good.size(); ++g) {
+                    std::memcpy(&Rb[g * sx], R + (size_t)part[good[g]] * sx, 8 * sx);
+                    sl[g] = slot[good[g]];
+                }
+                Jk.resize(good.size()); al.resize(good.size() * nv); st.resize(good.size());
+                chk_dev(ehm_simplex_idx_batch(T.P, (int64_t)good.size(), Rb.data(), nullptr, sl.data(), 0,
+                                              Jk.data(), al.data(), st.data()), "ehm_simplex_idx_batch");
+                ++launches;
+                T.lp += (int64_t)good.size();
+                tally(T, 3, sl);
+                std::vector<size_t> bad;
+                for (size_t g = 0; g < good.size(); ++g)
+                    if (st[g] != 0) bad.push_back(g);
+                if (!bad.empty()) {
+                    stalled += (int64_t)bad.size();
+                    std::vector<double> R2(bad.size() * sx), tau2(bad.size()), al2(bad.size() * nv);
+                    std::vector<int32_t> sl2(bad.size()), st2(bad.size());
+                    for (size_t q = 0; q < bad.size(); ++q) {
+                        std::memcpy(&R2[q * sx], &Rb[bad[q] * sx], 8 * sx);
+                        sl2[q] = sl[bad[q]];
+                    }
+                    chk_dev(ehm_simplex_idx_batch(T.P, (int64_t)bad.size(), R2.data(), nullptr, sl2.data(),
+                                                  2, tau2.data(), al2.data(), st2.data()),
+                            "ehm_simplex_idx_batch");
+                    ++launches;
+                    T.lp += (int64_t)bad.size();
+                    for (size_t q = 0; q < bad.size(); ++q) {
+                        const bool sliver = st2[q] == 0 && tau2[q] >= -SLIVER_TOL;
+                        const bool feasible = !sliver && (tau2[q] <= FEAS_TOL || st2[q] != 0);
+                        slivers += sliver;
+                        Jk[bad[q]] = feasible ? -INF : INF;     // (a minimum is a pruning bound)
+                        stalled_relax += feasible;
+                    }
+                }
+                for (size_t g = 0; g < good.size(); ++g) J_out[part[good[g]]] = Jk[g];
             });
         }
     }
@@ -520,9 +605,18 @@ int dev_points(void* user, int64_t n, const uint64_t* code, const double* theta,
     return EHM_OK;
 }
 int dev_slack(void* user, int64_t n, const uint64_t* code, const double* R, const double* V,
-              const uint8_t* known, double* t) {
+              const uint8_t* known, double* t, double* alpha) {
     try {
-        static_cast<DeviceSolver*>(user)->slack(n, code, R, V, known, t);
+        static_cast<DeviceSolver*>(user)->slack(n, code, R, V, known, t, alpha);
+    } catch (const Fail& e) {
+        return fail(e.code, "%s", e.msg.c_str());
+    }
+    return EHM_OK;
+}
+int dev_min(void* user, int64_t n, const uint64_t* code, const double* R, const uint8_t* known,
+            double* J) {
+    try {
+        static_cast<DeviceSolver*>(user)->minimum(n, code, R, known, J);
     } catch (const Fail& e) {
         return fail(e.code, "%s", e.msg.c_str());
     }
@@ -552,6 +646,7 @@ struct ehm_frontier {
     std::vector<int64_t> pids;
     std::vector<int32_t> left, right, depth;
     std::vector<int64_t> seq, witness;          // code of the full sequence held / of the witness
+    std::vector<int64_t> incumbent;             // lcss: the parent's best-slack sequence (-1: none)
     std::vector<uint8_t> flags;
     int64_t n_roots = 0;
     std::vector<int32_t> ecc_work, lcss_work;
@@ -574,7 +669,7 @@ struct ehm_frontier {
         inputs.insert(inputs.end(), (size_t)nv * n_u, NAN);
         pids.insert(pids.end(), (size_t)nv, -1);
         left.push_back(-1); right.push_back(-1); depth.push_back(d);
-        seq.push_back(-1); witness.push_back(-1);
+        seq.push_back(-1); witness.push_back(-1); incumbent.push_back(-1);
         flags.push_back(EHM_FR_PENDING);
         return k;
     }
@@ -586,11 +681,18 @@ struct ehm_frontier {
         if (rc) raise(rc, "%s", dev ? g_err : "the caller's point solver failed");
     }
     void solver_slack(int64_t n, const uint64_t* code, const double* R, const double* V,
-                      const uint8_t* known, double* t) {
+                      const uint8_t* known, double* t, double* alpha) {
         const double t0 = now();
-        int rc = sol.slack(sol.user, n, code, R, V, known, t);
+        int rc = sol.slack(sol.user, n, code, R, V, known, t, alpha);
         st.seconds_solvers += now() - t0;
         if (rc) raise(rc, "%s", dev ? g_err : "the caller's slack solver failed");
+    }
+    void solver_min(int64_t n, const uint64_t* code, const double* R, const uint8_t* known,
+                    double* J) {
+        const double t0 = now();
+        int rc = sol.min(sol.user, n, code, R, known, J);
+        st.seconds_solvers += now() - t0;
+        if (rc) raise(rc, "%s", dev ? g_err : "the caller's minimum solver failed");
     }
     void forget_if_full() {
         if (feas_n > FEAS_MEMO_LIMIT) {
@@ -656,12 +758,200 @@ struct ehm_frontier {
             if (sq[(size_t)j * N] >= 0) result[(size_t)j] = (int64_t)seq_code(&sq[(size_t)j * N]);
     }
 
-    void ecc_round(const std::vector<int32_t>& E);
-    void lcss_round(const std::vector<int32_t>& Lc, int launch_target);
+    // what one lcss visit has solved on its cell: prefix code -> (t, index of its maximiser or -1)
+    struct Known { double t; int64_t alpha; };
+    typedef std::unordered_map<uint64_t, Known> Learned;
+    std::vector<double> alpha_pool;             // maximisers of the round, nv doubles each
+    struct Split { int32_t node; int64_t code; std::vector<double> c, u; int64_t star; };
+
+    void feasible_somewhere(const std::vector<uint64_t>& codes, const std::vector<int32_t>& node_of,
+                            std::vector<uint8_t>& known);
+    void slack_pairs(const std::vector<uint64_t>& codes, const std::vector<int32_t>& node_of,
+                     std::vector<double>& t, std::vector<double>* alpha);
+    void optima(const std::vector<uint64_t>& code, const std::vector<int64_t>& pid,
+                const std::vector<double>& pts, std::vector<double>& J, std::vector<double>& u);
+    void bisect(std::vector<Split>& todo);
+    void bar_d(const std::vector<int32_t>& O, std::vector<Learned>& learned, int launch_target,
+               std::vector<Split>& to_split);
+    void ecc_round(const std::vector<int32_t>& E, std::vector<Split>& to_split);
+    void lcss_round(const std::vector<int32_t>& Lc, int launch_target, std::vector<Split>& to_split);
     void run(const ehm_frontier_opts& o);
 };
 
-void ehm_frontier::ecc_round(const std::vector<int32_t>& E) {
+// sequences.PrefixSearch.feasible_somewhere_codes: a relaxation known to be feasible at a vertex of
+// the cell is feasible on the cell; where nothing is held the first vertex without a verdict is
+// asked (one point problem, remembered: the neighbours that ask about the same prefix get it free)
+void ehm_frontier::feasible_somewhere(const std::vector<uint64_t>& codes,
+                                      const std::vector<int32_t>& node_of,
+                                      std::vector<uint8_t>& known) {
+    const int64_t n = (int64_t)codes.size();
+    known.assign((size_t)n, 0);
+    if (!n) return;
+    std::vector<uint64_t> rep((size_t)n * nv);
+    std::vector<int64_t> pp((size_t)n * nv);
+    std::vector<int8_t> ver((size_t)n * nv);
+    for (int64_t a = 0; a < n; ++a)
+        for (int v = 0; v < nv; ++v) {
+            rep[(size_t)a * nv + v] = codes[(size_t)a];
+            pp[(size_t)a * nv + v] = pids[(size_t)node_of[(size_t)a] * nv + v];
+        }
+    chk_search(ehm_search_peek(S, n * nv, rep.data(), pp.data(), ver.data()), "ehm_search_peek");
+    std::vector<uint64_t> qc;
+    std::vector<int64_t> qb(1, 0), qp, qa;
+    for (int64_t a = 0; a < n; ++a) {
+        int first_unknown = -1;
+        for (int v = 0; v < nv; ++v) {
+            const int8_t r = ver[(size_t)a * nv + v];
+            if (r == 1) known[(size_t)a] = 1;
+            if (r == -1 && first_unknown < 0) first_unknown = v;
+        }
+        if (!known[(size_t)a] && first_unknown >= 0) {
+            qc.push_back(codes[(size_t)a]);
+            qp.push_back(pp[(size_t)a * nv + first_unknown]);
+            qb.push_back((int64_t)qp.size());
+            qa.push_back(a);
+        }
+    }
+    if (!qc.empty()) {
+        std::vector<uint8_t> fl;
+        feasible_sets(qc, qb, qp, fl);
+        for (size_t q = 0; q < qa.size(); ++q) known[(size_t)qa[q]] = fl[q];
+    }
+}
+
+// suboptimality-test optima of (prefix, cell) pairs: t (and the maximisers, nv doubles per pair)
+void ehm_frontier::slack_pairs(const std::vector<uint64_t>& codes, const std::vector<int32_t>& node_of,
+                               std::vector<double>& t, std::vector<double>* alpha) {
+    const size_t n = codes.size(), sx = (size_t)nv * p;
+    t.assign(n, -INF);
+    if (alpha) alpha->assign(n * nv, 0.0);
+    if (!n) return;
+    std::vector<uint8_t> known;
+    feasible_somewhere(codes, node_of, known);
+    std::vector<double> Rp(n * sx), Vp(n * nv);
+    for (size_t a = 0; a < n; ++a) {
+        std::memcpy(&Rp[a * sx], &verts[(size_t)node_of[a] * sx], 8 * sx);
+        std::memcpy(&Vp[a * nv], &costs[(size_t)node_of[a] * nv], 8 * (size_t)nv);
+    }
+    solver_slack((int64_t)n, codes.data(), Rp.data(), Vp.data(), known.data(), t.data(),
+                 alpha ? alpha->data() : nullptr);
+}
+
+// sequences.PrefixSearch.optima_at: optimal cost and first input of full sequence code[k] at point
+// k (id pid[k]) for pairs the caller KNOWS to be feasible; computed once per (sequence, point)
+void ehm_frontier::optima(const std::vector<uint64_t>& code, const std::vector<int64_t>& pid,
+                          const std::vector<double>& pts, std::vector<double>& J,
+                          std::vector<double>& u) {
+    const size_t n = code.size();
+    J.resize(n); u.resize(n * n_u);
+    if (!n) return;
+    if (opt_of.size() > OPTIMA_MEMO_LIMIT) { opt_of.clear(); opt_J.clear(); opt_u.clear(); }
+    std::vector<uint64_t> mcode, mkey;
+    std::vector<double> mth;
+    for (size_t k = 0; k < n; ++k) {
+        const uint64_t key = (code[k] << PID_BITS) | (uint64_t)pid[k];
+        if (opt_of.count(key)) continue;
+        opt_of[key] = -1 - (int64_t)mkey.size();            // claimed by this launch
+        mkey.push_back(key);
+        mcode.push_back(code[k]);
+        mth.insert(mth.end(), &pts[k * p], &pts[k * p] + p);
+    }
+    st.optima_asked += (int64_t)n;
+    st.optima_solved += (int64_t)mkey.size();
+    if (!mkey.empty()) {
+        std::vector<double> Jm(mkey.size()), um(mkey.size() * n_u);
+        solver_points((int64_t)mkey.size(), mcode.data(), mth.data(), 0, 1, Jm.data(), um.data());
+        for (size_t a = 0; a < mkey.size(); ++a) {
+            opt_of[mkey[a]] = (int64_t)opt_J.size();
+            opt_J.push_back(Jm[a]);
+            opt_u.insert(opt_u.end(), &um[a * n_u], &um[a * n_u] + n_u);
+        }
+    }
+    for (size_t k = 0; k < n; ++k) {
+        const int64_t at = opt_of[(code[k] << PID_BITS) | (uint64_t)pid[k]];
+        J[k] = opt_J[(size_t)at];
+        std::memcpy(&u[k * n_u], &opt_u[(size_t)at * n_u], 8 * (size_t)n_u);
+    }
+}
+
+// Longest-edge bisection of the cells in `todo` (lib/worker.py:277-291, 403-417): children of a cell
+// without a commutation look for one (ecc); children of a cell that holds one inherit its vertex
+// costs and inputs with the new vertex's slot replaced by the optimum at the midpoint
+// (lib/worker.py:356-365) and go on with lcss.
+void ehm_frontier::bisect(std::vector<Split>& todo) {
+    const size_t n = todo.size(), sx = (size_t)nv * p;
+    if (!n) return;
+    std::vector<double> Rs(n * sx), S1(n * sx), S2(n * sx);
+    std::vector<int32_t> ij(n * 2);
+    for (size_t i = 0; i < n; ++i) std::memcpy(&Rs[i * sx], &verts[(size_t)todo[i].node * sx], 8 * sx);
+    {
+        const double t0 = now();
+        int rc = sol.split(sol.user, (int64_t)n, Rs.data(), S1.data(), S2.data(), ij.data());
+        st.seconds_solvers += now() - t0;
+        if (rc) raise(rc, "%s", dev ? g_err : "the caller's bisection failed");
+    }
+    std::vector<double> mids(n * p);
+    for (size_t i = 0; i < n; ++i) std::memcpy(&mids[i * p], &S1[i * sx + (size_t)ij[2 * i] * p], 8 * (size_t)p);
+    std::vector<int64_t> mid_id(n), a_id(n), b_id(n);
+    chk_search(ehm_search_point_ids(S, (int64_t)n, mids.data(), mid_id.data()), "ehm_search_point_ids");
+    for (size_t i = 0; i < n; ++i) {
+        a_id[i] = pids[(size_t)todo[i].node * nv + ij[2 * i]];
+        b_id[i] = pids[(size_t)todo[i].node * nv + ij[2 * i + 1]];
+    }
+    chk_search(ehm_search_register_midpoints(S, (int64_t)n, mid_id.data(), a_id.data(), b_id.data()),
+               "ehm_search_register_midpoints");
+    // the adopted commutation is feasible at both ends of the edge, so at its midpoint: no phase
+    // one; the cells around an edge that hold the same commutation share the optimum
+    std::vector<size_t> with;
+    std::vector<uint64_t> mc;
+    std::vector<int64_t> mp;
+    std::vector<double> mpt, Jm, um;
+    for (size_t i = 0; i < n; ++i)
+        if (todo[i].code >= 0) {
+            with.push_back(i);
+            mc.push_back((uint64_t)todo[i].code);
+            mp.push_back(mid_id[i]);
+            mpt.insert(mpt.end(), &mids[i * p], &mids[i * p] + p);
+        }
+    optima(mc, mp, mpt, Jm, um);
+    for (size_t w = 0; w < with.size(); ++w)
+        if (!std::isfinite(Jm[w]))
+            raise(EHM_E_NUMERIC, "midpoint solve of the adopted commutation failed");
+    size_t w = 0;
+    for (size_t i = 0; i < n; ++i) {
+        const int32_t nd = todo[i].node;
+        const int32_t l = new_node(&S1[i * sx], depth[nd] + 1);
+        const int32_t r = new_node(&S2[i * sx], depth[nd] + 1);
+        left[nd] = l; right[nd] = r;
+        flags[nd] &= (uint8_t)EHM_FR_HAS_RECORD;
+        for (int v = 0; v < nv; ++v) pids[(size_t)l * nv + v] = pids[(size_t)r * nv + v] = pids[(size_t)nd * nv + v];
+        const int vi = ij[2 * i], vj = ij[2 * i + 1];
+        pids[(size_t)l * nv + vi] = mid_id[i];
+        pids[(size_t)r * nv + vj] = mid_id[i];
+        st.depth = std::max(st.depth, depth[nd] + 1);
+        if (todo[i].code < 0) {
+            witness[l] = witness[r] = witness[nd];
+            ecc_work.push_back(l);
+            ecc_work.push_back(r);
+            continue;
+        }
+        for (int32_t ch : {l, r}) {
+            std::memcpy(&costs[(size_t)ch * nv], todo[i].c.data(), 8 * (size_t)nv);
+            std::memcpy(&inputs[(size_t)ch * nv * n_u], todo[i].u.data(), 8 * (size_t)nv * n_u);
+            seq[ch] = todo[i].code;
+            incumbent[ch] = todo[i].star;
+            flags[ch] = EHM_FR_HAS_RECORD | EHM_FR_PENDING;
+            lcss_work.push_back(ch);
+        }
+        costs[(size_t)l * nv + vi] = Jm[w];
+        costs[(size_t)r * nv + vj] = Jm[w];
+        std::memcpy(&inputs[((size_t)l * nv + vi) * n_u], &um[w * n_u], 8 * (size_t)n_u);
+        std::memcpy(&inputs[((size_t)r * nv + vj) * n_u], &um[w * n_u], 8 * (size_t)n_u);
+        ++w;
+    }
+}
+
+void ehm_frontier::ecc_round(const std::vector<int32_t>& E, std::vector<Split>& to_split) {
     const size_t ne = E.size();
     if (!ne) return;
     st.calls_v_r += (int64_t)ne;
@@ -684,9 +974,9 @@ void ehm_frontier::ecc_round(const std::vector<int32_t>& E) {
         for (size_t i = 0; i < none.size(); ++i) {
             const double* R = &verts[(size_t)E[none[i]] * nv * p];
             for (int c = 0; c < p; ++c) {
-                double s = R[c];
-                for (int v = 1; v < nv; ++v) s += R[(size_t)v * p + c];
-                centre[i * p + c] = s / (double)nv;
+                double sum = R[c];
+                for (int v = 1; v < nv; ++v) sum += R[(size_t)v * p + c];
+                centre[i * p + c] = sum / (double)nv;
             }
         }
         std::vector<int64_t> cid(none.size());
@@ -730,41 +1020,26 @@ void ehm_frontier::ecc_round(const std::vector<int32_t>& E) {
     for (size_t k = 0; k < ne; ++k)
         if (found[k] >= 0) have.push_back(k);
     if (!have.empty()) {
-        if (opt_of.size() > OPTIMA_MEMO_LIMIT) { opt_of.clear(); opt_J.clear(); opt_u.clear(); }
-        std::vector<uint64_t> mcode;
-        std::vector<double> mth;
-        std::vector<uint64_t> mkey;
+        std::vector<uint64_t> oc;
+        std::vector<int64_t> op;
+        std::vector<double> opt_pts, J, u;
         for (size_t h = 0; h < have.size(); ++h) {
             const int32_t nd = E[have[h]];
             for (int v = 0; v < nv; ++v) {
-                const uint64_t key = ((uint64_t)found[have[h]] << PID_BITS) | (uint64_t)pids[(size_t)nd * nv + v];
-                if (opt_of.count(key)) continue;
-                opt_of[key] = -1 - (int64_t)mkey.size();        // claimed by this launch
-                mkey.push_back(key);
-                mcode.push_back((uint64_t)found[have[h]]);
-                mth.insert(mth.end(), &verts[((size_t)nd * nv + v) * p], &verts[((size_t)nd * nv + v) * p] + p);
+                oc.push_back((uint64_t)found[have[h]]);
+                op.push_back(pids[(size_t)nd * nv + v]);
+                opt_pts.insert(opt_pts.end(), &verts[((size_t)nd * nv + v) * p],
+                               &verts[((size_t)nd * nv + v) * p] + p);
             }
         }
-        st.optima_asked += (int64_t)have.size() * nv;
-        st.optima_solved += (int64_t)mkey.size();
-        if (!mkey.empty()) {
-            std::vector<double> J(mkey.size()), u(mkey.size() * n_u);
-            solver_points((int64_t)mkey.size(), mcode.data(), mth.data(), 0, 1, J.data(), u.data());
-            for (size_t a = 0; a < mkey.size(); ++a) {
-                opt_of[mkey[a]] = (int64_t)opt_J.size();
-                opt_J.push_back(J[a]);
-                opt_u.insert(opt_u.end(), &u[a * n_u], &u[a * n_u] + n_u);
-            }
-        }
+        optima(oc, op, opt_pts, J, u);
         for (size_t h = 0; h < have.size(); ++h) {
             const int32_t nd = E[have[h]];
             bool finite = true;
             for (int v = 0; v < nv; ++v) {
-                const uint64_t key = ((uint64_t)found[have[h]] << PID_BITS) | (uint64_t)pids[(size_t)nd * nv + v];
-                const int64_t at = opt_of[key];
-                costs[(size_t)nd * nv + v] = opt_J[(size_t)at];
-                std::memcpy(&inputs[((size_t)nd * nv + v) * n_u], &opt_u[(size_t)at * n_u], 8 * (size_t)n_u);
-                finite = finite && std::isfinite(opt_J[(size_t)at]);
+                costs[(size_t)nd * nv + v] = J[h * nv + v];
+                std::memcpy(&inputs[((size_t)nd * nv + v) * n_u], &u[(h * nv + v) * n_u], 8 * (size_t)n_u);
+                finite = finite && std::isfinite(J[h * nv + v]);
             }
             if (!finite) {
                 // lib/oracle.py:214-218: a failed vertex solve blacklists the commutation and V_R is
@@ -778,54 +1053,323 @@ void ehm_frontier::ecc_round(const std::vector<int32_t>& E) {
             lcss_work.push_back(nd);
         }
     }
-    // the cells without a commutation: bisect, the children look again
-    if (!none.empty()) {
-        const size_t sx = (size_t)nv * p;
-        std::vector<double> Rs(none.size() * sx), S1(none.size() * sx), S2(none.size() * sx);
-        std::vector<int32_t> ij(none.size() * 2);
-        for (size_t i = 0; i < none.size(); ++i)
-            std::memcpy(&Rs[i * sx], &verts[(size_t)E[none[i]] * sx], 8 * sx);
+    for (size_t i : none) to_split.push_back(Split{E[i], -1, {}, {}, -1});
+}
+
+namespace {
+// heapq on (-t, prefix tuple): larger t first; ties by the tuples' lexicographic order (digit by
+// digit from step 0; a prefix sorts before its extensions) -- ehm_search.cpp, BareItem
+struct HeapItem { double t; uint64_t code; int32_t len; };
+struct PrefixHeap {
+    uint64_t base = 1;
+    std::vector<HeapItem> h;
+    bool before(const HeapItem& a, const HeapItem& b) const {
+        if (a.t != b.t) return a.t > b.t;
+        uint64_t ca = a.code, cb = b.code;
+        const int32_t m = a.len < b.len ? a.len : b.len;
+        for (int32_t i = 0; i < m; ++i) {
+            const uint64_t da = ca % base, db = cb % base;
+            if (da != db) return da < db;
+            ca /= base; cb /= base;
+        }
+        return a.len < b.len;
+    }
+    void push(const HeapItem& it) {
+        h.push_back(it);
+        size_t c = h.size() - 1;
+        while (c > 0) {
+            const size_t q = (c - 1) / 2;
+            if (!before(h[c], h[q])) break;
+            std::swap(h[c], h[q]);
+            c = q;
+        }
+    }
+    HeapItem pop() {
+        HeapItem top = h.front();
+        h.front() = h.back();
+        h.pop_back();
+        size_t q = 0;
+        const size_t n_ = h.size();
+        for (;;) {
+            size_t l = 2 * q + 1, r = l + 1, b = q;
+            if (l < n_ && before(h[l], h[b])) b = l;
+            if (r < n_ && before(h[r], h[b])) b = r;
+            if (b == q) break;
+            std::swap(h[q], h[b]);
+            q = b;
+        }
+        return top;
+    }
+};
+constexpr double TIE_TOL = 1e-6;               // sequences.TIE_TOL
+constexpr double PLATEAU = 1e-7;               // bnb.PLATEAU
+inline double rel(double x) { return 1.0 + std::fabs(x); }
+}  // namespace
+
+// bnb_frontier.bar_d_many (lib/oracle.py:311-414 as a search): for every open cell the commutation
+// with the LARGEST slack among those feasible at every vertex with t* >= 0 (ties: first in
+// enumeration order) -- best-first for the value, a lexicographic walk for the sequence --, then
+// the winners' vertex optima and variability test (lib/oracle.py:220-283), and the cell's fate
+// (lib/worker.py:377-417): adopt in place and look again, or bisect.
+void ehm_frontier::bar_d(const std::vector<int32_t>& O, std::vector<Learned>& learned,
+                         int launch_target, std::vector<Split>& to_split) {
+    const size_t n = O.size();
+    if (!n) return;
+    st.calls_bar_d += (int64_t)n;
+    struct Search {
+        int phase = 1;
+        PrefixHeap heap;
+        double best = -INF, limit = 0.0;
+        std::vector<HeapItem> stack;
+        int star = 0;                           // 0 searching, 1 found, -1 there is none
+        uint64_t star_code = 0;
+        int64_t star_alpha = -1;
+        // the step in flight
+        std::vector<uint64_t> kid;
+        std::vector<int32_t> klen;
+        std::vector<double> kt;
+        std::vector<int64_t> kalpha;
+        std::vector<uint8_t> kdead;
+    };
+    std::vector<Search> sr(n);
+    auto floor_of = [](const Search& q) {
+        return std::isfinite(q.best) ? std::max(0.0, q.best + PLATEAU * rel(q.best)) : 0.0;
+    };
+    for (size_t j = 0; j < n; ++j) {
+        sr[j].heap.base = base;
+        sr[j].heap.push(HeapItem{INF, 0, 0});
+    }
+    // warm start: the parent's best-slack sequence, evaluated on the cell by bar_E's seeding
+    {
+        std::vector<uint64_t> wc;
+        std::vector<int64_t> wb(1, 0), wp;
+        std::vector<size_t> wj;
+        for (size_t j = 0; j < n; ++j) {
+            const int64_t inc = incumbent[O[j]];
+            if (inc < 0) continue;
+            auto it = learned[j].find((uint64_t)inc);
+            if (it == learned[j].end() || !(it->second.t >= 0.0)) continue;
+            wc.push_back((uint64_t)inc);
+            for (int v = 0; v < nv; ++v) wp.push_back(pids[(size_t)O[j] * nv + v]);
+            wb.push_back((int64_t)wp.size());
+            wj.push_back(j);
+        }
+        if (!wc.empty()) {
+            std::vector<uint8_t> fl;
+            feasible_sets(wc, wb, wp, fl);
+            for (size_t q = 0; q < wj.size(); ++q)
+                if (fl[q]) sr[wj[q]].best = learned[wj[q]][wc[q]].t;
+        }
+    }
+    std::vector<size_t> active(n);
+    for (size_t j = 0; j < n; ++j) active[j] = j;
+    while (!active.empty()) {
+        const int width = (int)std::max<int64_t>(1, std::min<int64_t>(
+            BATCH, launch_target / std::max<int64_t>(1, (int64_t)active.size() * n_modes)));
+        std::vector<uint64_t> ask_code;
+        std::vector<int32_t> ask_node;
+        std::vector<std::pair<size_t, size_t>> ask_at;          // (search, kid index)
+        for (size_t j : active) {
+            Search& q = sr[j];
+            q.kid.clear(); q.klen.clear(); q.kt.clear(); q.kalpha.clear(); q.kdead.clear();
+            std::vector<HeapItem> batch;
+            if (q.phase == 1) {
+                const double fl = floor_of(q);
+                while (!q.heap.h.empty() && (int)batch.size() < width && q.heap.h.front().t >= fl)
+                    batch.push_back(q.heap.pop());
+            } else {
+                batch.push_back(q.stack.back());
+                q.stack.pop_back();
+            }
+            st.prefixes_expanded += (int64_t)batch.size();
+            for (const HeapItem& b : batch)
+                for (int i = 0; i < n_modes; ++i) {
+                    const uint64_t c = b.code + (uint64_t)(i + 1) * pw[(size_t)b.len];
+                    const int32_t len = b.len + 1;
+                    double t = 0.0;
+                    int64_t al = -1;
+                    bool have = false;
+                    auto it = learned[j].find(c);
+                    if (it != learned[j].end() &&
+                        (it->second.t < 0.0 || len < N || it->second.alpha >= 0)) {
+                        t = it->second.t; al = it->second.alpha; have = true;
+                        ++st.answered_without_a_problem;
+                    }
+                    if (!have) {
+                        ask_at.emplace_back(j, q.kid.size());
+                        ask_code.push_back(c);
+                        ask_node.push_back(O[j]);
+                    }
+                    q.kid.push_back(c); q.klen.push_back(len); q.kt.push_back(t);
+                    q.kalpha.push_back(al); q.kdead.push_back(0);
+                }
+        }
+        if (!ask_code.empty()) {
+            std::vector<double> t, al;
+            slack_pairs(ask_code, ask_node, t, &al);
+            for (size_t a = 0; a < ask_code.size(); ++a) {
+                Search& q = sr[ask_at[a].first];
+                const size_t k = ask_at[a].second;
+                int64_t at = -1;
+                if (q.klen[k] == N) {
+                    at = (int64_t)(alpha_pool.size() / nv);
+                    alpha_pool.insert(alpha_pool.end(), &al[a * nv], &al[a * nv] + nv);
+                }
+                q.kt[k] = t[a];
+                q.kalpha[k] = at;
+                learned[ask_at[a].first][ask_code[a]] = Known{t[a], at};
+            }
+        }
+        // feasibility at every vertex, for the prefixes whose slack bound is not negative
         {
-            const double t0 = now();
-            int rc = sol.split(sol.user, (int64_t)none.size(), Rs.data(), S1.data(), S2.data(), ij.data());
-            st.seconds_solvers += now() - t0;
-            if (rc) raise(rc, "%s", dev ? g_err : "the caller's bisection failed");
+            std::vector<uint64_t> lc;
+            std::vector<int64_t> lb(1, 0), lp;
+            std::vector<std::pair<size_t, size_t>> lat;
+            for (size_t j : active) {
+                Search& q = sr[j];
+                for (size_t k = 0; k < q.kid.size(); ++k)
+                    if (q.kt[k] >= 0.0) {
+                        lc.push_back(q.kid[k]);
+                        for (int v = 0; v < nv; ++v) lp.push_back(pids[(size_t)O[j] * nv + v]);
+                        lb.push_back((int64_t)lp.size());
+                        lat.emplace_back(j, k);
+                    }
+            }
+            if (!lc.empty()) {
+                std::vector<uint8_t> fl;
+                feasible_sets(lc, lb, lp, fl);
+                for (size_t a = 0; a < lat.size(); ++a)
+                    if (!fl[a]) sr[lat[a].first].kdead[lat[a].second] = 1;
+            }
         }
-        std::vector<double> mids(none.size() * p);
-        for (size_t i = 0; i < none.size(); ++i)
-            std::memcpy(&mids[i * p], &S1[i * sx + (size_t)ij[2 * i] * p], 8 * (size_t)p);
-        std::vector<int64_t> mid_id(none.size()), a_id(none.size()), b_id(none.size());
-        chk_search(ehm_search_point_ids(S, (int64_t)none.size(), mids.data(), mid_id.data()),
-                   "ehm_search_point_ids");
-        for (size_t i = 0; i < none.size(); ++i) {
-            a_id[i] = pids[(size_t)E[none[i]] * nv + ij[2 * i]];
-            b_id[i] = pids[(size_t)E[none[i]] * nv + ij[2 * i + 1]];
+        std::vector<size_t> still;
+        for (size_t j : active) {
+            Search& q = sr[j];
+            const size_t nk = q.kid.size();
+            if (q.phase == 1) {
+                for (size_t k = 0; k < nk; ++k) {
+                    const double tq = q.kdead[k] ? -INF : q.kt[k];
+                    if (!(tq >= 0.0)) continue;
+                    if (q.klen[k] == N) q.best = std::max(q.best, tq);
+                    else q.heap.push(HeapItem{tq, q.kid[k], q.klen[k]});
+                }
+                if (!(!q.heap.h.empty() && q.heap.h.front().t >= floor_of(q))) {
+                    if (!std::isfinite(q.best)) {
+                        q.star = -1;
+                        continue;
+                    }
+                    q.phase = 2;
+                    q.limit = std::max(0.0, q.best - TIE_TOL * rel(q.best));
+                    q.stack.assign(1, HeapItem{0.0, 0, 0});
+                }
+                still.push_back(j);
+            } else {
+                std::vector<size_t> good;
+                for (size_t k = 0; k < nk; ++k) {
+                    const double tk = q.kdead[k] ? -INF : q.kt[k];
+                    if (tk >= q.limit) good.push_back(k);
+                }
+                if (!good.empty() && q.klen[good[0]] == N) {
+                    q.star = 1;
+                    q.star_code = q.kid[good[0]];
+                    q.star_alpha = q.kalpha[good[0]];
+                    continue;
+                }
+                for (size_t g = good.size(); g-- > 0;)
+                    q.stack.push_back(HeapItem{0.0, q.kid[good[g]], q.klen[good[g]]});
+                if (q.stack.empty())
+                    raise(EHM_E_NUMERIC, "bar_D: the slack found in phase one was not reproduced");
+                still.push_back(j);
+            }
         }
-        chk_search(ehm_search_register_midpoints(S, (int64_t)none.size(), mid_id.data(), a_id.data(),
-                                                 b_id.data()), "ehm_search_register_midpoints");
-        for (size_t i = 0; i < none.size(); ++i) {
-            const int32_t nd = E[none[i]];
-            const int32_t l = new_node(&S1[i * sx], depth[nd] + 1);
-            const int32_t r = new_node(&S2[i * sx], depth[nd] + 1);
-            left[nd] = l; right[nd] = r;
-            flags[nd] = 0;
-            for (int v = 0; v < nv; ++v) pids[(size_t)l * nv + v] = pids[(size_t)r * nv + v] = pids[(size_t)nd * nv + v];
-            pids[(size_t)l * nv + ij[2 * i]] = mid_id[i];
-            pids[(size_t)r * nv + ij[2 * i + 1]] = mid_id[i];
-            witness[l] = witness[r] = witness[nd];
-            ecc_work.push_back(l);
-            ecc_work.push_back(r);
-            st.depth = std::max(st.depth, depth[nd] + 1);
+        active.swap(still);
+    }
+    // the winners' vertex solves and variability checks, one call each
+    std::vector<size_t> win;
+    for (size_t j = 0; j < n; ++j)
+        if (sr[j].star == 1 && (int64_t)sr[j].star_code != seq[O[j]]) win.push_back(j);
+    std::vector<double> Jv, uv, thetas, Jmin, Jth;
+    if (!win.empty()) {
+        const size_t nw = win.size(), sx = (size_t)nv * p;
+        std::vector<uint64_t> vc(nw * nv), rc(nw), sc(nw);
+        std::vector<double> vpts(nw * sx), Rw(nw * sx), uth(nw * n_u);
+        std::vector<uint8_t> ones(nw, 1);
+        thetas.assign(nw * p, 0.0);
+        for (size_t w = 0; w < nw; ++w) {
+            const int32_t nd = O[win[w]];
+            for (int v = 0; v < nv; ++v) vc[w * nv + v] = sr[win[w]].star_code;
+            std::memcpy(&vpts[w * sx], &verts[(size_t)nd * sx], 8 * sx);
+            std::memcpy(&Rw[w * sx], &verts[(size_t)nd * sx], 8 * sx);
+            rc[w] = (uint64_t)seq[nd];
+            sc[w] = sr[win[w]].star_code;
+            if (sr[win[w]].star_alpha < 0) raise(EHM_E_NUMERIC, "bar_D: a winner without its maximiser");
+            const double* al = &alpha_pool[(size_t)sr[win[w]].star_alpha * nv];
+            for (int c = 0; c < p; ++c) {
+                double acc = 0.0;
+                for (int v = 0; v < nv; ++v) acc += al[v] * verts[((size_t)nd * nv + v) * p + c];
+                thetas[w * p + c] = acc;
+            }
         }
+        Jv.resize(nw * nv); uv.resize(nw * nv * n_u); Jmin.resize(nw); Jth.resize(nw);
+        solver_points((int64_t)(nw * nv), vc.data(), vpts.data(), 0, 0, Jv.data(), uv.data());
+        // (the cell's own commutation is feasible at every vertex: no phase one over the simplex)
+        solver_min((int64_t)nw, rc.data(), Rw.data(), ones.data(), Jmin.data());
+        solver_points((int64_t)nw, sc.data(), thetas.data(), 0, 0, Jth.data(), uth.data());
+    }
+    size_t w = 0;
+    for (size_t j = 0; j < n; ++j) {
+        const int32_t nd = O[j];
+        const int64_t star = sr[j].star == 1 ? (int64_t)sr[j].star_code : -1;
+        const bool winner = w < win.size() && win[w] == j;
+        if (!winner) {                          // no better commutation: bisect with the cell's own
+            to_split.push_back(Split{nd, seq[nd],
+                                     std::vector<double>(&costs[(size_t)nd * nv], &costs[(size_t)nd * nv] + nv),
+                                     std::vector<double>(&inputs[(size_t)nd * nv * n_u],
+                                                         &inputs[(size_t)nd * nv * n_u] + (size_t)nv * n_u),
+                                     star});
+            continue;
+        }
+        bool finite = std::isfinite(Jmin[w]) && std::isfinite(Jth[w]);
+        for (int v = 0; v < nv; ++v) finite = finite && std::isfinite(Jv[w * nv + v]);
+        if (!finite) {
+            // a failed solve: the blacklist-and-retry path of the one-cell oracle
+            // (lib/oracle.py:406-414) -- the caller's driver has it
+            flags[nd] = EHM_FR_HAS_RECORD | EHM_FR_OPEN;
+            ++st.open_cells;
+            ++w;
+            continue;
+        }
+        std::vector<double> nc(&Jv[w * nv], &Jv[w * nv] + nv);
+        std::vector<double> nu(&uv[w * nv * n_u], &uv[w * nv * n_u] + (size_t)nv * n_u);
+        double vmax = -INF;
+        for (int v = 0; v < nv; ++v) vmax = std::max(vmax, costs[(size_t)nd * nv + v]);
+        const double rhs = std::max(eps_a, eps_r * Jth[w]);
+        const bool small = vmax - Jmin[w] < rhs;
+        if (small) {                            // lib/worker.py:396-401: adopt in place, look again
+            seq[nd] = (int64_t)sr[j].star_code;
+            std::memcpy(&costs[(size_t)nd * nv], nc.data(), 8 * (size_t)nv);
+            std::memcpy(&inputs[(size_t)nd * nv * n_u], nu.data(), 8 * (size_t)nv * n_u);
+            incumbent[nd] = star;
+            flags[nd] = EHM_FR_HAS_RECORD | EHM_FR_PENDING;
+            lcss_work.push_back(nd);
+            ++st.swaps;
+        } else {
+            to_split.push_back(Split{nd, (int64_t)sr[j].star_code, nc, nu, star});
+        }
+        ++w;
     }
 }
 
-// bnb_frontier.bar_e_many for cells on their first lcss visit (nothing inherited, no incumbent)
-void ehm_frontier::lcss_round(const std::vector<int32_t>& Lc, int launch_target) {
+// lib/worker.py:340-417 for the cells that hold a commutation: bar_E by best-first search over
+// prefixes (bnb_frontier.bar_e_many: native queues, the parent's best-slack sequence tried first),
+// closed cells are leaves, open ones go through bar_D.
+void ehm_frontier::lcss_round(const std::vector<int32_t>& Lc, int launch_target,
+                              std::vector<Split>& to_split) {
     const size_t n = Lc.size();
     if (!n) return;
     st.calls_bar_e += (int64_t)n;
     st.lcss_visits += (int64_t)n;
+    alpha_pool.clear();
     std::vector<double> guard(n);
     for (size_t j = 0; j < n; ++j) {
         double mx = 0.0;
@@ -835,58 +1379,46 @@ void ehm_frontier::lcss_round(const std::vector<int32_t>& Lc, int launch_target)
     ehm_search_bare* Bq = nullptr;
     chk_search(ehm_search_bare_create((int32_t)n, n_modes, N, guard.data(), &Bq), "ehm_search_bare_create");
     struct Guard { ehm_search_bare* b; ~Guard() { ehm_search_bare_destroy(b); } } g{Bq};
-    const size_t sx = (size_t)nv * p;
+    std::vector<Learned> learned(n);
     int64_t n_ask = 0, left_n = (int64_t)n;
-    std::vector<uint64_t> codes, rep;
-    std::vector<int32_t> owner;
-    std::vector<int64_t> pp;
-    std::vector<int8_t> ver;
-    std::vector<uint8_t> known;
-    std::vector<double> Rp, Vp, t;
+    // the parent's best-slack sequence first: where its slack is not negative the cell is open and
+    // the search is not run
+    {
+        std::vector<uint64_t> ic;
+        std::vector<int32_t> in;
+        std::vector<size_t> ij;
+        for (size_t j = 0; j < n; ++j)
+            if (incumbent[Lc[j]] >= 0) {
+                ic.push_back((uint64_t)incumbent[Lc[j]]);
+                in.push_back(Lc[j]);
+                ij.push_back(j);
+            }
+        if (!ic.empty()) {
+            std::vector<double> t, al;
+            slack_pairs(ic, in, t, &al);
+            for (size_t q = 0; q < ic.size(); ++q) {
+                const int64_t at = (int64_t)(alpha_pool.size() / nv);
+                alpha_pool.insert(alpha_pool.end(), &al[q * nv], &al[q * nv] + nv);
+                learned[ij[q]][ic[q]] = Known{t[q], at};
+                const int open = t[q] >= 0.0;
+                left_n -= open;
+                chk_search(ehm_search_bare_seed(Bq, (int32_t)ij[q], ic[q], t[q], open),
+                           "ehm_search_bare_seed");
+            }
+        }
+    }
+    std::vector<uint64_t> codes;
+    std::vector<int32_t> owner, node_of;
+    std::vector<double> t;
     while (left_n > 0) {
         const int width = (int)std::max<int64_t>(1, std::min<int64_t>(BATCH, launch_target /
                                                                      std::max<int64_t>(1, left_n * n_modes)));
         chk_search(ehm_search_bare_step(Bq, width, &n_ask, &left_n), "ehm_search_bare_step");
         if (!n_ask) break;
-        codes.resize((size_t)n_ask); owner.resize((size_t)n_ask);
+        codes.resize((size_t)n_ask); owner.resize((size_t)n_ask); node_of.resize((size_t)n_ask);
         chk_search(ehm_search_bare_asks(Bq, codes.data(), owner.data()), "ehm_search_bare_asks");
-        // feasible_somewhere_codes: a relaxation known to be feasible at a vertex is feasible on the
-        // simplex; where nothing is held the first vertex without a verdict is asked (remembered)
-        rep.resize((size_t)n_ask * nv); pp.resize((size_t)n_ask * nv); ver.resize((size_t)n_ask * nv);
-        for (int64_t a = 0; a < n_ask; ++a)
-            for (int v = 0; v < nv; ++v) {
-                rep[(size_t)a * nv + v] = codes[(size_t)a];
-                pp[(size_t)a * nv + v] = pids[(size_t)Lc[owner[(size_t)a]] * nv + v];
-            }
-        chk_search(ehm_search_peek(S, n_ask * nv, rep.data(), pp.data(), ver.data()), "ehm_search_peek");
-        known.assign((size_t)n_ask, 0);
-        std::vector<uint64_t> qc;
-        std::vector<int64_t> qb(1, 0), qp, qa;
-        for (int64_t a = 0; a < n_ask; ++a) {
-            int first_unknown = -1;
-            for (int v = 0; v < nv; ++v) {
-                const int8_t r = ver[(size_t)a * nv + v];
-                if (r == 1) known[(size_t)a] = 1;
-                if (r == -1 && first_unknown < 0) first_unknown = v;
-            }
-            if (!known[(size_t)a] && first_unknown >= 0) {
-                qc.push_back(codes[(size_t)a]);
-                qp.push_back(pp[(size_t)a * nv + first_unknown]);
-                qb.push_back((int64_t)qp.size());
-                qa.push_back(a);
-            }
-        }
-        if (!qc.empty()) {
-            std::vector<uint8_t> fl;
-            feasible_sets(qc, qb, qp, fl);
-            for (size_t q = 0; q < qa.size(); ++q) known[(size_t)qa[q]] = fl[q];
-        }
-        Rp.resize((size_t)n_ask * sx); Vp.resize((size_t)n_ask * nv); t.resize((size_t)n_ask);
-        for (int64_t a = 0; a < n_ask; ++a) {
-            std::memcpy(&Rp[(size_t)a * sx], &verts[(size_t)Lc[owner[(size_t)a]] * sx], 8 * sx);
-            std::memcpy(&Vp[(size_t)a * nv], &costs[(size_t)Lc[owner[(size_t)a]] * nv], 8 * (size_t)nv);
-        }
-        solver_slack(n_ask, codes.data(), Rp.data(), Vp.data(), known.data(), t.data());
+        for (int64_t a = 0; a < n_ask; ++a) node_of[(size_t)a] = Lc[owner[(size_t)a]];
+        slack_pairs(codes, node_of, t, nullptr);
         chk_search(ehm_search_bare_answer(Bq, t.data(), &left_n), "ehm_search_bare_answer");
     }
     std::vector<int8_t> closed(n);
@@ -895,16 +1427,30 @@ void ehm_frontier::lcss_round(const std::vector<int32_t>& Lc, int launch_target)
     chk_search(ehm_search_bare_result(Bq, closed.data(), margin.data(), counts), "ehm_search_bare_result");
     st.prefixes_expanded += counts[0];
     st.answered_without_a_problem += counts[1];
+    std::vector<int32_t> O;
+    std::vector<Learned> lo;
+    std::vector<uint64_t> lc;
+    std::vector<double> lt;
     for (size_t j = 0; j < n; ++j) {
         const int32_t nd = Lc[j];
         if (closed[j]) {
             flags[nd] = EHM_FR_HAS_RECORD | EHM_FR_CLOSED;
             ++st.regions;
-        } else {
-            flags[nd] = EHM_FR_HAS_RECORD | EHM_FR_OPEN;
-            ++st.open_cells;
+            continue;
         }
+        // what bar_E solved on the cell: the same problems bar_D asks about
+        int64_t cnt = 0;
+        chk_search(ehm_search_bare_learned(Bq, (int32_t)j, &cnt, nullptr, nullptr), "ehm_search_bare_learned");
+        if (cnt) {
+            lc.resize((size_t)cnt); lt.resize((size_t)cnt);
+            chk_search(ehm_search_bare_learned(Bq, (int32_t)j, &cnt, lc.data(), lt.data()),
+                       "ehm_search_bare_learned");
+            for (int64_t q = 0; q < cnt; ++q) learned[j][lc[(size_t)q]] = Known{lt[(size_t)q], -1};
+        }
+        O.push_back(nd);
+        lo.push_back(std::move(learned[j]));
     }
+    bar_d(O, lo, launch_target, to_split);
 }
 
 void ehm_frontier::run(const ehm_frontier_opts& o) {
@@ -937,8 +1483,10 @@ void ehm_frontier::run(const ehm_frontier_opts& o) {
         ecc_work.erase(ecc_work.begin(), ecc_work.begin() + ne);
         ++st.rounds;
         st.visits += (int64_t)(nl + ne);
-        ecc_round(E);
-        lcss_round(Lc, target);
+        std::vector<Split> to_split;
+        ecc_round(E, to_split);
+        lcss_round(Lc, target, to_split);
+        bisect(to_split);
     }
     st.n_nodes = n_nodes();
     st.seconds_total += now() - t0;
@@ -971,7 +1519,8 @@ static int init_common(ehm_frontier* f, int n_x, int n_u, int n_modes, int N, do
 int ehm_frontier_create_custom(int32_t n_x, int32_t n_u, int32_t n_modes, int32_t N,
                                const ehm_pair_solvers* solvers, double eps_a, double eps_r,
                                ehm_frontier** out) {
-    if (!out || !solvers || !solvers->points || !solvers->slack || !solvers->split || n_x < 1 ||
+    if (!out || !solvers || !solvers->points || !solvers->slack || !solvers->min ||
+        !solvers->split || n_x < 1 ||
         n_u < 1 || n_modes < 1 || N < 1)
         return fail(EHM_E_INVALID, "ehm_frontier_create_custom: bad argument");
     ehm_frontier* f = new (std::nothrow) ehm_frontier();
@@ -1049,7 +1598,8 @@ int ehm_frontier_create(const ehm_pwa_law* law, int32_t short_len, int32_t long_
     if (!rc) {
         f->dev = D;
         f->sol.user = D;
-        f->sol.points = dev_points; f->sol.slack = dev_slack; f->sol.split = dev_split;
+        f->sol.points = dev_points; f->sol.slack = dev_slack; f->sol.min = dev_min;
+        f->sol.split = dev_split;
         rc = init_common(f, D->law.n_x, D->law.n_u, D->law.n_modes, D->law.N, eps_a, eps_r);
     }
     if (rc) {
@@ -1103,6 +1653,7 @@ int ehm_frontier_reset(ehm_frontier* f) {
     f->feas_n = 0;
     f->verts.clear(); f->costs.clear(); f->inputs.clear(); f->pids.clear();
     f->left.clear(); f->right.clear(); f->depth.clear(); f->seq.clear(); f->witness.clear();
+    f->incumbent.clear();
     f->flags.clear(); f->n_roots = 0;
     f->ecc_work.clear(); f->lcss_work.clear();
     f->opt_of.clear(); f->opt_J.clear(); f->opt_u.clear();

@@ -8,10 +8,10 @@ profiles/r4/config5_host_profile*.txt).  Here ONE call grows the cells: the roun
 searches' bookkeeping, the condensation and the launches are C++ behind ``ehm_frontier_run``;
 Python states the law once (``ehm_pwa_law``), adds the roots and reads the flat tree back.
 
-What stays with ``bnb_frontier``: the cells bar_E leaves OPEN on their first lcss visit (bar_D, the
-hand-off to the enumerating engine, everything below them) -- they come back flagged and are
-finished by ``grow_frontier`` on a ``bnb.PrefixOracle`` of their own (on configs[4] at its stated
-tolerances: 0.3 % of the node visits).
+What stays with ``bnb_frontier``: a cell whose vertex solves fail (the blacklist-and-retry paths
+of lib/oracle.py:214-218, 406-414) comes back flagged and is finished by ``grow_frontier`` on a
+``bnb.PrefixOracle`` -- none on configs[4] so far.  The hand-off of small regions to the
+enumerating engine (``bnb_frontier._hand_off``) is not taken by the native driver.
 
 Per-cell semantics: lib/worker.py:241-417; canonical answers of the oracles: bnb.py.
 """
@@ -105,12 +105,20 @@ class TableSolvers:
             if u0:
                 _as(u0, (n, n_u), np.float64)[:] = uv
 
-        def slack(user, n, code, R, V, known, t):
+        def slack(user, n, code, R, V, known, t, alpha):
             pre = [table._prefix(int(c)) for c in _as(code, (n,), np.uint64)]
             kn = _as(known, (n,), np.uint8).astype(bool) if known else None
-            tv, _ = table.solve_slack(pre, _as(R, (n, nv, p), np.float64).copy(),
-                                      _as(V, (n, nv), np.float64).copy(), kn)
+            tv, av = table.solve_slack(pre, _as(R, (n, nv, p), np.float64).copy(),
+                                       _as(V, (n, nv), np.float64).copy(), kn)
             _as(t, (n,), np.float64)[:] = tv
+            if alpha:
+                _as(alpha, (n, nv), np.float64)[:] = av
+
+        def minimum(user, n, code, R, known, J):
+            pre = [table._prefix(int(c)) for c in _as(code, (n,), np.uint64)]
+            kn = _as(known, (n,), np.uint8).astype(bool) if known else None
+            _as(J, (n,), np.float64)[:] = table.solve_min(
+                pre, _as(R, (n, nv, p), np.float64).copy(), kn)
 
         def split(user, n, R, S1, S2, ij):
             a, b, e = self.split_batch(_as(R, (n, nv, p), np.float64).copy())
@@ -118,9 +126,9 @@ class TableSolvers:
             _as(S2, (n, nv, p), np.float64)[:] = b
             _as(ij, (n, 2), np.int32)[:] = e
         self._fns = (_capi.POINTS_FN(guard(points)), _capi.SLACK_FN(guard(slack)),
-                     _capi.SPLIT_FN(guard(split)))
+                     _capi.MIN_FN(guard(minimum)), _capi.SPLIT_FN(guard(split)))
         self.struct = _capi.PairSolvers(user=None, points=self._fns[0], slack=self._fns[1],
-                                        split=self._fns[2])
+                                        min=self._fns[2], split=self._fns[3])
 
 
 class NativeFrontier:

@@ -17,12 +17,17 @@
  *        vertex (ehm_search.h descents) -> vertex optima -> the cell holds a commutation;
  *        none: feasibility at the barycentre (lib/worker.py:264-266), longest-edge bisection
  *        (ehm_split_batch), two ecc children
- *   lcss (lib/worker.py:293-417), first visit: bar_E by best-first search over prefixes
- *        (ehm_search_bare_*): closed -> an epsilon-suboptimal leaf.  A cell bar_E leaves OPEN is
- *        handed back to the caller with its record (flag EHM_FR_OPEN): bar_D, the hand-off to the
- *        enumerating engine and everything below such a cell stay with the caller's driver
- *        (explicit_hybrid_mpc_amd/bnb_frontier.py) -- on configs[4] at its stated tolerances
- *        that is 0.3 % of the node visits.
+ *   lcss (lib/worker.py:293-417)  bar_E by best-first search over prefixes (ehm_search_bare_*;
+ *        the parent's best-slack sequence is tried first): closed -> an epsilon-suboptimal leaf.
+ *        Open: bar_D = the sequence of LARGEST slack among those feasible at every vertex
+ *        (best-first for the value, a lexicographic walk for the first sequence that attains it),
+ *        its vertex optima and the variability test (lib/oracle.py:220-283); the cell adopts it
+ *        in place and is looked at again (lib/worker.py:396-401) or is bisected, the children
+ *        inheriting the vertex costs with the midpoint's optimum in the new slot
+ *        (lib/worker.py:356-365).
+ *   Only a cell whose vertex solves FAIL (lib/oracle.py:214-218, 406-414: blacklist and retry)
+ *   is handed back to the caller with its record (flag EHM_FR_OPEN); the caller's one-cell
+ *   oracles (explicit_hybrid_mpc_amd/bnb.py) have that path.
  *
  * Every function returns 0 or a negative EHM_E_* code of ehmpc.h; message:
  * ehm_frontier_last_error() (thread-local).  A handle is not thread-safe.
@@ -70,7 +75,11 @@ typedef struct ehm_pair_solvers {
      * vertex costs Vbar[k] (-inf: infeasible on it; +inf: a relaxation whose solve stalled --
      * "no information").  known[k]: feasible somewhere on the simplex, no phase one. */
     int (*slack)(void* user, int64_t n, const uint64_t* code, const double* R, const double* Vbar,
-                 const uint8_t* known, double* t);
+                 const uint8_t* known, double* t, double* alpha /* [n][p+1] maximiser, or NULL */);
+    /* J [n]: minimum over simplex R[k] of the optimal cost of the prefix's relaxation (+inf:
+     * infeasible on it; -inf: a solve that stalled -- as a bound it prunes nothing). */
+    int (*min)(void* user, int64_t n, const uint64_t* code, const double* R, const uint8_t* known,
+               double* J);
     /* tools.split_along_longest_edge for a batch (ehm_split_batch). */
     int (*split)(void* user, int64_t n, const double* R, double* S1, double* S2, int32_t* ij);
 } ehm_pair_solvers;
@@ -112,7 +121,8 @@ typedef struct ehm_frontier_stats {
     int64_t regions;          /* closed leaves                                                 */
     int64_t open_cells;       /* cells handed back to the caller (EHM_FR_OPEN)                 */
     int64_t n_nodes;
-    int64_t calls_v_r, calls_p_theta, calls_bar_e;
+    int64_t calls_v_r, calls_p_theta, calls_bar_e, calls_bar_d;
+    int64_t swaps;            /* cells that adopted bar_D's commutation in place (lib/worker.py:396-401) */
     int64_t witness_hits;
     int64_t prefixes_expanded, answered_without_a_problem;
     int64_t optima_asked, optima_solved;
