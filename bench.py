@@ -308,6 +308,10 @@ def parse_args(argv=None):
                     help='config5: native = the round loop, the searches\' bookkeeping, the block '
                          'condensation and the launches in C++ behind ehm_frontier_run '
                          '(include/ehm_frontier.h); python = bnb_frontier.grow_frontier (rounds 3-4)')
+    ap.add_argument('--seconds', type=float, default=0.,
+                    help='config5 with --regions: soft limit of a step; the cell in progress is cut '
+                         'short (its pending leaves stay open and are reported) and no further cell '
+                         'is started')
     ap.add_argument('--progress-file', default=None,
                     help='config5: append one JSON line per finished group of cells (a run cut '
                          'short by a time limit leaves what it measured)')
@@ -863,38 +867,46 @@ def measure_config5(args, ctx):
     # short horizon for the prefixes of few steps next to it (sequences.SplitPrefixTable)
     parts = [('short', orc.table.short), ('long', orc.table.long)] if hasattr(orc.table, 'short') \
         else [('long', orc.table)]
+    # accounting by table = by horizon: 'h4' ... 'h8'; (n, m, p) of the table's blocks
+    hname = lambda tb: 'h%d' % tb.mpc.N
+    table_dims = {hname(tb): (tb.gp.can.n, tb.gp.can.m, tb.gp.can.p) for _, tb in parts}
 
     # the native driver (include/ehm_frontier.h) owns device tables of its own; the Python oracle
     # above stays for eps_a and for the cells the native driver hands back open
     native = None
     if args.driver == 'native':
         from explicit_hybrid_mpc_amd import frontier
-        native = frontier.NativeFrontier(mpc, eps_a, eps_r, slots=8192, device=device_index)
+        native = frontier.NativeFrontier(mpc, eps_a, eps_r, slots=16384, device=device_index)
+        for hz in native.horizons:
+            if 'h%d' % hz not in table_dims:
+                G_h = frontier.condense_native(mpc, (), hz)[0]
+                table_dims['h%d' % hz] = (G_h.shape[1], G_h.shape[0], mpc.n_x)
     nat_acc = dict(calls=dict(P_theta=0, V_R=0, bar_E=0, bar_D=0), expanded=0, stalled=0,
                    solver_seconds=0., driver_seconds=0., open_cells=0, launches=0)
 
     def snapshot():
-        per = {}
-        nat_tab = native.table_stats() if native else {}
-        nat_hist = native.lp_counts() if native else None
-        for t, (name, tb) in enumerate(parts):
-            st = tb.gp.stats()
-            per[name] = dict(lp=tb.lp_solves, iters=st['ipm_iters'], secs=list(st['batch_seconds']),
-                             launches=list(st['batch_launches']), hist=tb.by_length.copy())
-            nt = nat_tab.get(name)
-            if nt:
-                h = nat_hist[0 if name == 'short' else 1]
-                per[name]['lp'] += int(h.sum())
-                per[name]['iters'] += nt['ipm_iters']
-                per[name]['secs'] = [a + b for a, b in zip(per[name]['secs'], nt['batch_seconds'])]
-                per[name]['launches'] = [a + b for a, b in zip(per[name]['launches'],
-                                                               nt['batch_launches'])]
-                wdt = min(per[name]['hist'].shape[1], h.shape[1])      # (short table: <= 4 steps)
-                per[name]['hist'][:, :wdt] += h[:, :wdt]
+        per = {name: dict(lp=0, iters=0, secs=[0., 0.], launches=[0, 0],
+                          hist=np.zeros((5, mpc.N + 1), dtype=np.int64)) for name in table_dims}
+        for _, tb in parts:             # the Python oracle's tables (eps_a, cells handed back)
+            st, e = tb.gp.stats(), per[hname(tb)]
+            e['lp'] += tb.lp_solves
+            e['iters'] += st['ipm_iters']
+            e['secs'] = [a + b for a, b in zip(e['secs'], st['batch_seconds'])]
+            e['launches'] = [a + b for a, b in zip(e['launches'], st['batch_launches'])]
+            e['hist'][:, :tb.by_length.shape[1]] += tb.by_length
+        if native:
+            counts = native.lp_counts()
+            for t, nt in enumerate(native.table_stats()):
+                e = per['h%d' % nt['horizon']]
+                e['lp'] += int(counts[t].sum())
+                e['iters'] += nt['ipm_iters']
+                e['secs'] = [a + b for a, b in zip(e['secs'], nt['batch_seconds'])]
+                e['launches'] = [a + b for a, b in zip(e['launches'], nt['batch_launches'])]
+                e['hist'] += counts[t]
         return dict(lp=sum(v['lp'] for v in per.values()), per=per,
                     calls={k: orc.calls[k] + nat_acc['calls'][k] for k in orc.calls},
                     expanded=orc.n_expanded + nat_acc['expanded'],
-                    hist=orc.table.by_length + (0 if nat_hist is None else nat_hist.sum(axis=0)),
+                    hist=sum(v['hist'] for v in per.values()),
                     stalled=orc.table.stalled + nat_acc['stalled'])
 
     def grow_group(part):
@@ -905,13 +917,14 @@ def measure_config5(args, ctx):
                                               max_visits=args.max_visits)
         orc.table.forget()
         st = frontier.grow_cells(native, part, slow_oracle=lambda: orc, round_cap=args.round_cap,
-                                 max_visits=args.max_visits or 0,
+                                 max_visits=args.max_visits or 0, deadline=step_deadline[0],
                                  min_regions=0 if args.regions or regions >= (1 << 30) else regions,
                                  slow_opts=dict(order=args.order, table_backoff=True,
                                                 round_cap=args.round_cap))
         nat_acc['calls']['P_theta'] += st['calls_p_theta']
         nat_acc['calls']['V_R'] += st['calls_v_r']
         nat_acc['calls']['bar_E'] += st['calls_bar_e']
+        nat_acc['calls']['bar_D'] += st['calls_bar_d']
         nat_acc['expanded'] += st['prefixes_expanded']
         nat_acc['stalled'] += st['stalled']
         nat_acc['solver_seconds'] += st['seconds_solvers']
@@ -922,7 +935,10 @@ def measure_config5(args, ctx):
                     regions=st['regions'], truncated=bool(st['truncated']), handoffs=0,
                     native_visits=st['visits'], slow_path_cells=st['slow_path_cells'])
 
+    step_deadline = [None]
+
     def step():
+        step_deadline[0] = time.perf_counter() + args.seconds if args.seconds > 0 else None
         # with a target of regions the cells are grown one group after the other, EACH TO
         # COMPLETION (every leaf eps-suboptimal), until the target is reached
         group = args.cells_at_once if args.cells_at_once > 0 else (
@@ -930,6 +946,8 @@ def measure_config5(args, ctx):
         stats, trees = None, []
         for g0 in range(0, len(my_cells), group):
             if args.regions and stats is not None and stats.get('regions', 0) >= regions:
+                break
+            if step_deadline[0] is not None and time.perf_counter() >= step_deadline[0]:
                 break
             orc.table.forget()
             part = [Tree(NodeData(vertices=cell_vertices(c))) for c in my_cells[g0:g0 + group]]
@@ -1002,15 +1020,13 @@ def measure_config5(args, ctx):
     # per table: LPs, iterations, kernel seconds (HIP events around every batched launch) and the
     # SURVEY 8(d) flops of its problems over a simplex, priced at the table's own dimensions
     tables = {}
-    for name, tb in parts:
+    for name, (n_t, m_t, p_t) in table_dims.items():
         a0, a1 = s0['per'][name], s1['per'][name]
-        can_t = tb.gp.can
         d_lp, d_it = a1['lp'] - a0['lp'], a1['iters'] - a0['iters']
         mean_it_t = d_it / max(d_lp, 1.)
         h = a1['hist'] - a0['hist']
-        dims_t = {2: (can_t.n + can_t.p + 1, can_t.m + can_t.p + 2),
-                  3: (can_t.n + can_t.p, can_t.m + can_t.p + 1),
-                  4: (can_t.n + can_t.p + 1, can_t.m + can_t.p + 3)}
+        dims_t = {2: (n_t + p_t + 1, m_t + p_t + 2), 3: (n_t + p_t, m_t + p_t + 1),
+                  4: (n_t + p_t + 1, m_t + p_t + 3)}
         tables[name] = dict(
             lp=float(d_lp), iters=float(d_it), mean_it=mean_it_t, dims=dims_t,
             point_s=a1['secs'][0] - a0['secs'][0], simplex_s=a1['secs'][1] - a0['secs'][1],
@@ -1019,6 +1035,10 @@ def measure_config5(args, ctx):
             flops=sum(float(h[k].sum()) * mean_it_t * flops_per_iteration(*dims_t[k])
                       for k in dims_t))
     dom = max(tables, key=lambda k: tables[k]['simplex_s'])
+    # the dominant table runs on the wide kernels unless its blocks fit the shared-block ones
+    # (columns n + p + 1 <= 32 and rows m + p + 3 <= 256: csrc/ehm_capi.hip)
+    dom_wide = table_dims[dom][0] + table_dims[dom][2] + 1 > 32 or \
+        table_dims[dom][1] + table_dims[dom][2] + 3 > 256
     local = [float(s1['lp'] - s0['lp']), float(sum(t['iters'] for t in tables.values())),
              float(nodes), float(closed), float(sum(calls.values())), elapsed,
              sum(t['point_s'] for t in tables.values()),
@@ -1045,7 +1065,7 @@ def measure_config5(args, ctx):
         dom_s = T['simplex_s']
         achieved = flops / max(dom_s, 1e-12) / 1e12
         c5_traffic, c5_traffic_src = pmc_traffic(
-            'k3_simplex_batch' if dom == 'long' else 'k2_simplex_batch', 'pmc_summary_config5.json')
+            'k3_simplex_batch' if dom_wide else 'k2_simplex_batch', 'pmc_summary_config5.json')
         out = {
             'metric': 'oracle LP solves/sec + final regions/sec, 4-state 2-input N=5 hybrid MPC',
             'value': lp / elapsed_max, 'unit': 'LP solves/s',
@@ -1120,15 +1140,15 @@ def measure_config5(args, ctx):
                                    else '%d at a time' % args.cells_at_once),
             },
             'roofline': {
-                'bound': 'mfma' if dom == 'long' else 'valu-fp64',
-                'kernel': 'k3_simplex_batch' if dom == 'long' else 'k2_simplex_batch',
+                'bound': 'mfma' if dom_wide else 'valu-fp64',
+                'kernel': 'k3_simplex_batch' if dom_wide else 'k2_simplex_batch',
                 'note': 'LPs over a simplex of the %s table (slack n=%d m=%d) on the %s; flops = '
                         'its LPs by kind x the MEAN iteration count of its LPs x SURVEY 8(d) '
                         'flops per iteration; kernel seconds by HIP events around every launch '
                         '(ehm_counters.batch_seconds)' % (
                             dom, dims[4][0], dims[4][1],
                             'wide kernels (normal matrix on v_mfma_f64_16x16x4_f64)'
-                            if dom == 'long' else
+                            if dom_wide else
                             'shared-block kernels (one wavefront per LP, FP64 vector FMA)'),
                 'tables': {name: {'lp_solves': t['lp'] / K, 'mean_ipm_iterations': t['mean_it'],
                                   'simplex_kernel_seconds': t['simplex_s'],
@@ -1185,6 +1205,7 @@ def secondary_line(args, ctx, workload, steps, warmup):
     a.cpu_seconds = args.secondary_cpu_seconds
     a.regions = a.cells = 0
     a.progress_file = None
+    a.seconds = 0.
     a.driver = 'native'
     a.order, a.max_visits, a.round_cap = 'lcss-first', None, 4096
     a.status_dir = None

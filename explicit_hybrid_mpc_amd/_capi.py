@@ -57,7 +57,7 @@ EXPORTED_SEARCH = [
 # every symbol include/ehm_frontier.h declares (the native partition driver of configs[4])
 EXPORTED_FRONTIER = [
     'ehm_frontier_create', 'ehm_frontier_create_custom', 'ehm_frontier_destroy',
-    'ehm_frontier_last_error', 'ehm_frontier_set_eps', 'ehm_frontier_tables',
+    'ehm_frontier_last_error', 'ehm_frontier_set_eps', 'ehm_frontier_table',
     'ehm_frontier_reset', 'ehm_frontier_add_root', 'ehm_frontier_run', 'ehm_frontier_sizes',
     'ehm_frontier_export', 'ehm_frontier_lp_counts', 'ehm_frontier_condense',
 ]
@@ -287,14 +287,15 @@ def load(build_if_missing=True):
             getattr(lib, name).restype = i32
     # include/ehm_frontier.h
     lib.ehm_frontier_last_error.restype = ctypes.c_char_p
-    lib.ehm_frontier_create.argtypes = [ctypes.POINTER(PwaLaw), i32, i32, ctypes.c_int,
+    lib.ehm_frontier_create.argtypes = [ctypes.POINTER(PwaLaw), i32, vp, vp, ctypes.c_int,
                                         ctypes.c_double, ctypes.c_double, ctypes.POINTER(vp)]
     lib.ehm_frontier_create_custom.argtypes = [i32, i32, i32, i32, ctypes.POINTER(PairSolvers),
                                                ctypes.c_double, ctypes.c_double,
                                                ctypes.POINTER(vp)]
     lib.ehm_frontier_destroy.argtypes = [vp]
     lib.ehm_frontier_set_eps.argtypes = [vp, ctypes.c_double, ctypes.c_double]
-    lib.ehm_frontier_tables.argtypes = [vp, ctypes.POINTER(vp), ctypes.POINTER(vp)]
+    lib.ehm_frontier_table.argtypes = [vp, i32, ctypes.POINTER(vp), ctypes.POINTER(i32),
+                                       ctypes.POINTER(i32), ctypes.POINTER(i64)]
     lib.ehm_frontier_reset.argtypes = [vp]
     lib.ehm_frontier_add_root.argtypes = [vp, vp]
     lib.ehm_frontier_run.argtypes = [vp, ctypes.POINTER(FrontierOpts),

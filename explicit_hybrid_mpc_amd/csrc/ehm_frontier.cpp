@@ -233,6 +233,9 @@ struct Table {
     int slots = 0, horizon = 0, n = 0, m = 0, full_length = -1;
     std::unordered_map<uint64_t, int> slot_of;
     std::vector<int> slot_len;
+    std::vector<uint64_t> slot_code;           // what a slot holds (for eviction)
+    std::vector<int64_t> slot_stamp;           // the launch that used it last
+    int64_t stamp = 0, evicted = 0;
     Condenser cond;
     std::vector<int64_t> counts;               // [5][N + 1]
     int64_t lp = 0, loaded = 0;
@@ -242,7 +245,14 @@ struct DeviceSolver {
     Law law;
     int device = 0, short_len = 0, p = 0, nv = 0, n_u = 0, N = 0;
     uint64_t base = 1;
-    Table tab[2];                              // 0 short, 1 long
+    // one table per horizon, ascending; tab_of_len[k] = the table of the prefixes of k steps (the
+    // smallest horizon that holds them: the relaxation of a prefix constrains and prices its own
+    // steps only, so as a block of the law with a shorter horizon it is the same problem in
+    // fewer columns and rows -- PWAMPC.with_horizon)
+    std::vector<Table> tab;
+    std::vector<int> tab_of_len;
+    int64_t total_lp() const { int64_t a = 0; for (const Table& T : tab) a += T.lp; return a; }
+    int64_t total_loaded() const { int64_t a = 0; for (const Table& T : tab) a += T.loaded; return a; }
     int64_t stalled = 0, slivers = 0, stalled_relax = 0, launches = 0, accepted_inaccurate = 0;
     // sequences.decisive_inaccurate: status word 1 | (decade << 8) of a stalled solve (ehm_dev.h)
     static bool decisive(int32_t status, double value) {
@@ -266,34 +276,64 @@ struct DeviceSolver {
     void tally(Table& T, int kind, const std::vector<int32_t>& slot) {
         for (int32_t s : slot) ++T.counts[(size_t)kind * (N + 1) + T.slot_len[s]];
     }
-    // slots of the distinct prefixes `uniq` (at most T.slots of them), loading what is missing
+    // slots of the distinct prefixes `uniq` (at most T.slots of them), loading what is missing; a
+    // full table gives up the blocks that have gone unused the longest (never one of `uniq`)
     void ensure(Table& T, const std::vector<uint64_t>& uniq, std::vector<int32_t>& slot_u) {
+        ++T.stamp;
         std::vector<uint64_t> missing;
-        for (uint64_t c : uniq)
-            if (!T.slot_of.count(c)) missing.push_back(c);
-        if (!missing.empty() && (int64_t)T.slot_of.size() + (int64_t)missing.size() > T.slots) {
-            T.slot_of.clear();
-            missing = uniq;
+        for (uint64_t c : uniq) {
+            auto it = T.slot_of.find(c);
+            if (it == T.slot_of.end()) missing.push_back(c);
+            else T.slot_stamp[(size_t)it->second] = T.stamp;
         }
         if (!missing.empty()) {
-            const int first = (int)T.slot_of.size();
+            std::vector<int> place(missing.size());
+            const int64_t n_free = (int64_t)T.slots - (int64_t)T.slot_of.size();
+            size_t k = 0;
+            int next_free = (int)T.slot_of.size();       // slots fill up from 0 before any eviction
+            for (; k < missing.size() && (int64_t)k < n_free; ++k) place[k] = next_free++;
+            if (k < missing.size()) {
+                std::vector<int> victims;
+                victims.reserve((size_t)T.slots);
+                for (int sl = 0; sl < T.slots; ++sl)
+                    if (T.slot_stamp[(size_t)sl] != T.stamp) victims.push_back(sl);
+                const size_t need = missing.size() - k;
+                if (victims.size() < need) raise(EHM_E_CAPACITY, "a launch names more prefixes than the table holds");
+                std::partial_sort(victims.begin(), victims.begin() + (long)need, victims.end(),
+                                  [&](int x, int y) { return T.slot_stamp[(size_t)x] < T.slot_stamp[(size_t)y]; });
+                for (size_t v = 0; k < missing.size(); ++k, ++v) {
+                    place[k] = victims[v];
+                    T.slot_of.erase(T.slot_code[(size_t)victims[v]]);
+                    ++T.evicted;
+                }
+            }
+            // contiguous runs of slots go up together (the staging buffers stay small)
+            std::vector<size_t> order(missing.size());
+            for (size_t q = 0; q < order.size(); ++q) order[q] = q;
+            std::sort(order.begin(), order.end(), [&](size_t x, size_t y) { return place[x] < place[y]; });
             const size_t nG = (size_t)T.m * T.n, nS = (size_t)T.m * p;
-            // blocks go up in groups: the staging buffers stay small whatever a launch names
             const size_t group = 256;
             int pre[64];
-            for (size_t g0 = 0; g0 < missing.size(); g0 += group) {
-                const size_t cnt = std::min(group, missing.size() - g0);
+            for (size_t g0 = 0; g0 < order.size();) {
+                size_t cnt = 1;
+                while (g0 + cnt < order.size() && cnt < group &&
+                       place[order[g0 + cnt]] == place[order[g0]] + (int)cnt)
+                    ++cnt;
                 bG.resize(cnt * nG); bw.resize(cnt * T.m); bS.resize(cnt * nS);
-                for (size_t k = 0; k < cnt; ++k) {
-                    const uint64_t c = missing[g0 + k];
+                for (size_t q = 0; q < cnt; ++q) {
+                    const uint64_t c = missing[order[g0 + q]];
                     const int len = len_of(c);
                     digits(c, pre);
-                    T.cond.block(pre, len, &bG[k * nG], &bw[k * T.m], &bS[k * nS]);
-                    T.slot_of[c] = first + (int)(g0 + k);
-                    T.slot_len[first + g0 + k] = len;
+                    T.cond.block(pre, len, &bG[q * nG], &bw[q * T.m], &bS[q * nS]);
+                    const int sl = place[order[g0 + q]];
+                    T.slot_of[c] = sl;
+                    T.slot_len[(size_t)sl] = len;
+                    T.slot_code[(size_t)sl] = c;
+                    T.slot_stamp[(size_t)sl] = T.stamp;
                 }
-                chk_dev(ehm_problem_update_blocks(T.P, first + (int)g0, (int)cnt, bG.data(), bw.data(),
+                chk_dev(ehm_problem_update_blocks(T.P, place[order[g0]], (int)cnt, bG.data(), bw.data(),
                                                   bS.data()), "ehm_problem_update_blocks");
+                g0 += cnt;
             }
             T.loaded += (int64_t)missing.size();
         }
@@ -330,10 +370,9 @@ struct DeviceSolver {
             if (!part.empty()) f(part, slot);
         }
     }
-    void split_tables(int64_t n_pairs, const uint64_t* code, std::vector<int64_t> sel[2]) const {
-        sel[0].clear(); sel[1].clear();
-        for (int64_t k = 0; k < n_pairs; ++k)
-            sel[(short_len > 0 && len_of(code[k]) <= short_len) ? 0 : 1].push_back(k);
+    void split_tables(int64_t n_pairs, const uint64_t* code, std::vector<std::vector<int64_t>>& sel) const {
+        sel.assign(tab.size(), std::vector<int64_t>());
+        for (int64_t k = 0; k < n_pairs; ++k) sel[(size_t)tab_of_len[(size_t)len_of(code[k])]].push_back(k);
     }
     // sequences.PrefixTable._phase_one_verdict
     void verdicts(const std::vector<double>& tau, const std::vector<int32_t>& st,
@@ -357,12 +396,12 @@ struct DeviceSolver {
                 int known_feasible, double* J, double* u0) {
         for (int64_t k = 0; k < n_pairs; ++k) J[k] = INF;
         if (u0) std::fill(u0, u0 + (size_t)n_pairs * n_u, 0.0);
-        std::vector<int64_t> sel[2];
+        std::vector<std::vector<int64_t>> sel;
         split_tables(n_pairs, code, sel);
         std::vector<double> th, tau, uu, Jk;
         std::vector<int32_t> st, slot2;
         std::vector<uint8_t> ok;
-        for (int t = 0; t < 2; ++t) {
+        for (size_t t = 0; t < tab.size(); ++t) {
             if (sel[t].empty()) continue;
             Table& T = tab[t];
             chunks(T, code, sel[t], [&](const std::vector<int64_t>& part, const std::vector<int32_t>& slot) {
@@ -417,13 +456,13 @@ struct DeviceSolver {
                const uint8_t* known, double* t_out, double* alpha_out) {
         for (int64_t k = 0; k < n_pairs; ++k) t_out[k] = -INF;
         if (alpha_out) std::fill(alpha_out, alpha_out + (size_t)n_pairs * nv, 0.0);
-        std::vector<int64_t> sel[2];
+        std::vector<std::vector<int64_t>> sel;
         split_tables(n_pairs, code, sel);
         const size_t sx = (size_t)nv * p;
         std::vector<double> Rb, Vb, tau, al, tk;
         std::vector<int32_t> st, sl;
         std::vector<uint8_t> ok, v;
-        for (int tt = 0; tt < 2; ++tt) {
+        for (size_t tt = 0; tt < tab.size(); ++tt) {
             if (sel[tt].empty()) continue;
             Table& T = tab[tt];
             chunks(T, code, sel[tt], [&](const std::vector<int64_t>& part, const std::vector<int32_t>& slot) {
@@ -519,13 +558,13 @@ struct DeviceSolver {
     void minimum(int64_t n_pairs, const uint64_t* code, const double* R, const uint8_t* known,
                  double* J_out) {
         for (int64_t k = 0; k < n_pairs; ++k) J_out[k] = INF;
-        std::vector<int64_t> sel[2];
+        std::vector<std::vector<int64_t>> sel;
         split_tables(n_pairs, code, sel);
         const size_t sx = (size_t)nv * p;
         std::vector<double> Rb, tau, al, Jk;
         std::vector<int32_t> st, sl;
         std::vector<uint8_t> ok, v;
-        for (int tt = 0; tt < 2; ++tt) {
+        for (size_t tt = 0; tt < tab.size(); ++tt) {
             if (sel[tt].empty()) continue;
             Table& T = tab[tt];
             chunks(T, code, sel[tt], [&](const std::vector<int64_t>& part, const std::vector<int32_t>& slot) {
@@ -1491,9 +1530,9 @@ void ehm_frontier::run(const ehm_frontier_opts& o) {
     st.n_nodes = n_nodes();
     st.seconds_total += now() - t0;
     if (dev) {                                  // since the last reset
-        st.lp_solves = dev->tab[0].lp + dev->tab[1].lp - base_ctr[0];
+        st.lp_solves = dev->total_lp() - base_ctr[0];
         st.launches = dev->launches - base_ctr[1];
-        st.blocks_loaded = dev->tab[0].loaded + dev->tab[1].loaded - base_ctr[2];
+        st.blocks_loaded = dev->total_loaded() - base_ctr[2];
         st.stalled = dev->stalled - base_ctr[3];
         st.slivers = dev->slivers - base_ctr[4];
     }
@@ -1538,6 +1577,8 @@ static int make_table(DeviceSolver* D, Table& T, int horizon, int slots, int ful
     T.cond.init(&D->law, horizon);
     T.n = T.cond.n; T.m = T.cond.m;
     T.slot_len.assign((size_t)slots, 0);
+    T.slot_code.assign((size_t)slots, 0);
+    T.slot_stamp.assign((size_t)slots, 0);
     T.counts.assign((size_t)5 * (D->N + 1), 0);
     // every slot starts as the block of the sequence 0 .. 0 (as sequences.PrefixTable creates its
     // handle: ehm_problem_create derives the eliminated columns from FULL blocks); problem data is
@@ -1573,26 +1614,43 @@ static int make_table(DeviceSolver* D, Table& T, int horizon, int slots, int ful
     return EHM_OK;
 }
 
-int ehm_frontier_create(const ehm_pwa_law* law, int32_t short_len, int32_t long_slots, int device,
-                        double eps_a, double eps_r, ehm_frontier** out) {
+int ehm_frontier_create(const ehm_pwa_law* law, int32_t n_tables, const int32_t* horizons,
+                        const int32_t* slots, int device, double eps_a, double eps_r,
+                        ehm_frontier** out) {
     if (!out) return fail(EHM_E_INVALID, "ehm_frontier_create: out is NULL");
     DeviceSolver* D = new (std::nothrow) DeviceSolver();
     if (!D) return fail(EHM_E_CAPACITY, "ehm_frontier_create: out of memory");
     int rc = copy_law(law, D->law);
     if (rc) { delete D; return rc; }
-    if (short_len < 0 || short_len >= D->law.N || long_slots < 16 || D->law.N > 60) {
+    const int N = D->law.N;
+    bool ok = n_tables >= 1 && n_tables <= 16 && horizons && slots && N <= 60 &&
+              horizons[n_tables - 1] == N;
+    for (int t = 0; ok && t < n_tables; ++t)
+        ok = horizons[t] >= 1 && (t == 0 || horizons[t] > horizons[t - 1]) && slots[t] >= 0;
+    if (!ok) {
         delete D;
-        return fail(EHM_E_INVALID, "ehm_frontier_create: short_len %d, long_slots %d", short_len, long_slots);
+        return fail(EHM_E_INVALID, "ehm_frontier_create: horizons must ascend to N, slots >= 0");
     }
-    D->device = device; D->short_len = short_len;
-    D->p = D->law.n_x; D->nv = D->p + 1; D->n_u = D->law.n_u; D->N = D->law.N;
+    D->device = device; D->short_len = n_tables > 1 ? horizons[0] : 0;
+    D->p = D->law.n_x; D->nv = D->p + 1; D->n_u = D->law.n_u; D->N = N;
     D->base = (uint64_t)D->law.n_modes + 1;
-    if (short_len > 0) {
-        int n_short = 0, pwr = 1;
-        for (int k = 0; k <= short_len; ++k) { n_short += pwr; pwr *= D->law.n_modes; }
-        rc = make_table(D, D->tab[0], short_len, std::max(16, n_short), -1, eps_a, eps_r);
+    D->tab.resize((size_t)n_tables);
+    D->tab_of_len.assign((size_t)N + 1, n_tables - 1);
+    int lo = 0;
+    for (int t = 0; !rc && t < n_tables; ++t) {
+        // the prefixes this table holds: lo .. horizons[t] steps (the first one from the empty prefix)
+        double count = 0.0, pwr = 1.0;
+        for (int k = 0; k <= horizons[t]; ++k) {
+            if (k >= lo) count += pwr;
+            pwr *= D->law.n_modes;
+        }
+        for (int k = lo; k <= horizons[t]; ++k) D->tab_of_len[(size_t)k] = t;
+        int want = slots[t];
+        if (want == 0 || (double)want > count) want = (int)std::min(count, 1e6);   // one slot each
+        want = std::max(want, 16);
+        rc = make_table(D, D->tab[(size_t)t], horizons[t], want, horizons[t] == N ? N : -1, eps_a, eps_r);
+        lo = horizons[t] + 1;
     }
-    if (!rc) rc = make_table(D, D->tab[1], D->law.N, long_slots, D->law.N, eps_a, eps_r);
     ehm_frontier* f = rc ? nullptr : new (std::nothrow) ehm_frontier();
     if (!rc && !f) rc = fail(EHM_E_CAPACITY, "ehm_frontier_create: out of memory");
     if (!rc) {
@@ -1637,10 +1695,19 @@ int ehm_frontier_set_eps(ehm_frontier* f, double eps_a, double eps_r) {
     return EHM_OK;
 }
 
-int ehm_frontier_tables(ehm_frontier* f, ehm_problem** short_table, ehm_problem** long_table) {
-    if (!f) return fail(EHM_E_INVALID, "ehm_frontier_tables: NULL handle");
-    if (short_table) *short_table = f->dev ? f->dev->tab[0].P : nullptr;
-    if (long_table) *long_table = f->dev ? f->dev->tab[1].P : nullptr;
+int ehm_frontier_table(ehm_frontier* f, int32_t index, ehm_problem** table, int32_t* horizon,
+                       int32_t* slots, int64_t* evicted) {
+    if (!f) return fail(EHM_E_INVALID, "ehm_frontier_table: NULL handle");
+    const int32_t n = f->dev ? (int32_t)f->dev->tab.size() : 0;
+    if (index < 0 || index >= n) {
+        if (table) *table = nullptr;
+        return index == n ? EHM_OK : fail(EHM_E_INVALID, "ehm_frontier_table: index %d of %d", index, n);
+    }
+    const Table& T = f->dev->tab[(size_t)index];
+    if (table) *table = T.P;
+    if (horizon) *horizon = T.horizon;
+    if (slots) *slots = T.slots;
+    if (evicted) *evicted = T.evicted;
     return EHM_OK;
 }
 
@@ -1659,9 +1726,9 @@ int ehm_frontier_reset(ehm_frontier* f) {
     f->opt_of.clear(); f->opt_J.clear(); f->opt_u.clear();
     f->st = ehm_frontier_stats{};
     if (f->dev) {
-        f->base_ctr[0] = f->dev->tab[0].lp + f->dev->tab[1].lp;
+        f->base_ctr[0] = f->dev->total_lp();
         f->base_ctr[1] = f->dev->launches;
-        f->base_ctr[2] = f->dev->tab[0].loaded + f->dev->tab[1].loaded;
+        f->base_ctr[2] = f->dev->total_loaded();
         f->base_ctr[3] = f->dev->stalled;
         f->base_ctr[4] = f->dev->slivers;
     }
@@ -1733,11 +1800,9 @@ int ehm_frontier_export(const ehm_frontier* f, double* vertices, int32_t* left, 
 int ehm_frontier_lp_counts(const ehm_frontier* f, int64_t* out) {
     if (!f || !out) return fail(EHM_E_INVALID, "ehm_frontier_lp_counts: bad argument");
     const size_t per = (size_t)5 * (f->N + 1);
-    std::fill(out, out + 2 * per, 0);
     if (f->dev)
-        for (int t = 0; t < 2; ++t)
-            if (!f->dev->tab[t].counts.empty())
-                std::memcpy(out + t * per, f->dev->tab[t].counts.data(), per * 8);
+        for (size_t t = 0; t < f->dev->tab.size(); ++t)
+            std::memcpy(out + t * per, f->dev->tab[t].counts.data(), per * 8);
     return EHM_OK;
 }
 

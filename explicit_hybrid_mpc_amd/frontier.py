@@ -131,12 +131,26 @@ class TableSolvers:
                                         min=self._fns[2], split=self._fns[3])
 
 
-class NativeFrontier:
-    """One native driver handle: two device tables (or the caller's solvers), the searches'
-    memory, the flat tree.  ``short_len`` None = ``sequences.short_horizon`` decides."""
+def default_horizons(mpc):
+    """Horizons of the device tables of a law: the short horizon whose blocks fit the shared-block
+    kernels with every column kept (``sequences.short_horizon``), then one table per longer horizon
+    up to N -- the relaxation of a prefix of k steps runs at the size of the law with horizon k,
+    not of the full model (include/ehm_frontier.h).  ``[N]`` where the split is not admissible."""
+    from . import sequences
+    k = sequences.short_horizon(mpc)
+    if k < 1:
+        return [mpc.N]
+    return [k] + list(range(k + 1, mpc.N + 1))
 
-    def __init__(self, mpc, eps_a, eps_r, slots=8192, device=0, short_len=None, solvers=None):
-        from . import sequences
+
+class NativeFrontier:
+    """One native driver handle: its device tables (or the caller's solvers), the searches'
+    memory, the flat tree.  ``horizons``: ascending horizons of the tables (None =
+    ``default_horizons``); ``slots``: blocks resident in the tables that do not hold every
+    prefix of their lengths at once."""
+
+    def __init__(self, mpc, eps_a, eps_r, slots=16384, device=0, horizons=None, solvers=None,
+                 short_len=None):
         self.mpc = mpc
         self._lib = _capi.load()
         self._solvers = solvers
@@ -145,14 +159,26 @@ class NativeFrontier:
             _capi.check_frontier(self._lib.ehm_frontier_create_custom(
                 mpc.n_x, mpc.n_u, mpc.delta_size, mpc.N, ctypes.byref(solvers.struct),
                 float(eps_a), float(eps_r), ctypes.byref(h)))
-            self.short_len = 0
+            self.horizons = []
         else:
-            self.short_len = sequences.short_horizon(mpc) if short_len is None else int(short_len)
+            if horizons is None and short_len is not None:      # two tables: short_len and N
+                horizons = [int(short_len), mpc.N] if 0 < int(short_len) < mpc.N else [mpc.N]
+            self.horizons = [int(x) for x in (default_horizons(mpc) if horizons is None
+                                              else horizons)]
+            hz = np.array(self.horizons, dtype=np.int32)
+            # a table whose prefixes all fit gets a slot each (0); the others share `slots`
+            count, lo, sl = 0, 0, []
+            for hh in self.horizons:
+                count = sum(mpc.delta_size ** k for k in range(lo, hh + 1))
+                sl.append(0 if count <= int(slots) else int(slots))
+                lo = hh + 1
+            sl = np.array(sl, dtype=np.int32)
             law, keep = _law_struct(mpc)
             _capi.check_frontier(self._lib.ehm_frontier_create(
-                ctypes.byref(law), self.short_len, int(slots), int(device), float(eps_a),
+                ctypes.byref(law), hz.size, ptr(hz), ptr(sl), int(device), float(eps_a),
                 float(eps_r), ctypes.byref(h)))
             del keep
+        self.short_len = self.horizons[0] if len(self.horizons) > 1 else 0
         self._h = h
         self.eps_a, self.eps_r = float(eps_a), float(eps_r)
         self.last_stats = None
@@ -197,25 +223,27 @@ class NativeFrontier:
         return self.last_stats
 
     def table_stats(self):
-        """ehm_stats of the two device tables: dict short / long -> counters (None: no table)."""
-        a, b = ctypes.c_void_p(), ctypes.c_void_p()
-        self._check(self._lib.ehm_frontier_tables(self._h, ctypes.byref(a), ctypes.byref(b)))
-        out = {}
-        for name, h in (('short', a), ('long', b)):
+        """ehm_stats of the device tables: list of dicts (horizon, slots, evicted, counters)."""
+        out = []
+        k = 0
+        while True:
+            h, hz, sl, ev = ctypes.c_void_p(), ctypes.c_int32(), ctypes.c_int32(), ctypes.c_int64()
+            self._check(self._lib.ehm_frontier_table(self._h, k, ctypes.byref(h), ctypes.byref(hz),
+                                                     ctypes.byref(sl), ctypes.byref(ev)))
             if not h:
-                out[name] = None
-                continue
+                return out
             c = _capi.Counters()
             _capi.check(self._lib.ehm_stats(h, ctypes.byref(c)))
-            out[name] = dict(lp_solves=c.lp_solves, ipm_iters=c.ipm_iters,
-                             kernel_launches=c.kernel_launches, stalled=c.stalled,
-                             batch_seconds=list(c.batch_seconds),
-                             batch_launches=list(c.batch_launches))
-        return out
+            out.append(dict(horizon=hz.value, slots=sl.value, evicted=ev.value,
+                            lp_solves=c.lp_solves, ipm_iters=c.ipm_iters,
+                            kernel_launches=c.kernel_launches, stalled=c.stalled,
+                            batch_seconds=list(c.batch_seconds),
+                            batch_launches=list(c.batch_launches)))
+            k += 1
 
     def lp_counts(self):
-        """Problems solved by (table 0 short / 1 long, kind, prefix length): (2, 5, N+1)."""
-        out = np.zeros((2, 5, self.mpc.N + 1), dtype=np.int64)
+        """Problems solved by (table, kind, prefix length): (n_tables, 5, N+1)."""
+        out = np.zeros((max(len(self.horizons), 1), 5, self.mpc.N + 1), dtype=np.int64)
         self._check(self._lib.ehm_frontier_lp_counts(self._h, ptr(out)))
         return out
 
@@ -270,19 +298,36 @@ def graft(flat, mpc, targets):
 
 
 def grow_cells(native, branches, slow_oracle=None, round_cap=4096, launch_target=65536,
-               max_visits=0, min_regions=0, speculate=0, slow_opts=None):
+               max_visits=0, min_regions=0, speculate=0, slow_opts=None, deadline=None,
+               slice_visits=100000):
     """
     ``bnb_frontier.grow_frontier(oracle, branches, 'ecc')`` on the native driver: ``branches`` (a
     ``Tree`` or a list of them, data = the root simplices) are grown in place.  ``slow_oracle``: a
     callable returning the ``bnb.PrefixOracle`` that finishes the cells handed back open (created
-    on first need -- most cells of configs[4] never need it).  Returns a dict of counts.
+    on first need -- most cells of configs[4] never need it).  ``deadline``: a
+    ``time.perf_counter()`` value; the run is then made in slices of ``slice_visits`` cell visits
+    and stops (truncated: pending cells stay open leaves) at the first slice that ends after it.
+    Returns a dict of counts.
     """
+    import time
     from . import bnb_frontier
     branches = list(branches) if isinstance(branches, (list, tuple)) else [branches]
     native.reset()
     native.add_roots([np.asarray(b.data.vertices, dtype=np.float64) for b in branches])
-    st = dict(native.run(round_cap=round_cap, launch_target=launch_target, max_visits=max_visits,
-                         min_regions=min_regions, speculate=speculate))
+    if deadline is None:
+        st = dict(native.run(round_cap=round_cap, launch_target=launch_target,
+                             max_visits=max_visits, min_regions=min_regions, speculate=speculate))
+    else:
+        budget = 0
+        while True:
+            budget += int(slice_visits)
+            cap = min(budget, int(max_visits)) if max_visits else budget
+            st = dict(native.run(round_cap=round_cap, launch_target=launch_target, max_visits=cap,
+                                 min_regions=min_regions, speculate=speculate))
+            if not st['truncated'] or time.perf_counter() >= deadline or \
+                    (max_visits and st['visits'] >= max_visits) or \
+                    (min_regions and st['regions'] >= min_regions):
+                break
     back = graft(native.export(), native.mpc, branches)
     st['slow_path_cells'] = len(back)
     st['slow_path_regions'] = st['slow_path_visits'] = 0

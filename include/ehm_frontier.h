@@ -84,12 +84,17 @@ typedef struct ehm_pair_solvers {
     int (*split)(void* user, int64_t n, const double* R, double* S1, double* S2, int32_t* ij);
 } ehm_pair_solvers;
 
-/* Device form: two commutation tables on GPU `device` -- prefixes of at most short_len steps as
- * blocks of the law with THAT horizon (shared-block kernels; 0 = no such table), longer ones
- * and full sequences as blocks of the full model with long_slots slots (written on demand,
- * dropped together when full). */
-int ehm_frontier_create(const ehm_pwa_law* law, int32_t short_len, int32_t long_slots, int device,
-                        double eps_a, double eps_r, ehm_frontier** out);
+/* Device form: n_tables commutation tables on GPU `device`, one per horizon (ascending, the last
+ * one N).  The relaxation of a prefix constrains and prices its own steps only, so as a block of
+ * the law with a SHORTER horizon it is the same problem in fewer columns and rows
+ * (PWAMPC.with_horizon; it requires u = 0 to be admissible, which the caller checks): table t holds
+ * the prefixes of horizons[t-1]+1 .. horizons[t] steps -- short ones on the shared-block kernels,
+ * the rest on the wide kernels at THEIR size -- and full sequences live in the last one.
+ * slots[t]: blocks resident in table t, written on demand, the longest-unused ones replaced when
+ * it is full (0 = one slot per prefix, nothing is ever replaced). */
+int ehm_frontier_create(const ehm_pwa_law* law, int32_t n_tables, const int32_t* horizons,
+                        const int32_t* slots, int device, double eps_a, double eps_r,
+                        ehm_frontier** out);
 /* The same driver on the caller's solvers (n_x, n_u, n_modes, N of the law). */
 int ehm_frontier_create_custom(int32_t n_x, int32_t n_u, int32_t n_modes, int32_t N,
                                const ehm_pair_solvers* solvers, double eps_a, double eps_r,
@@ -97,9 +102,10 @@ int ehm_frontier_create_custom(int32_t n_x, int32_t n_u, int32_t n_modes, int32_
 int ehm_frontier_destroy(ehm_frontier* f);
 const char* ehm_frontier_last_error(void);
 int ehm_frontier_set_eps(ehm_frontier* f, double eps_a, double eps_r);
-/* The device tables (NULL where there is none): for ehm_stats. */
-int ehm_frontier_tables(ehm_frontier* f, struct ehm_problem** short_table,
-                        struct ehm_problem** long_table);
+/* Device table `index` (for ehm_stats), its horizon, slots and blocks replaced so far; index ==
+ * number of tables returns *table = NULL. */
+int ehm_frontier_table(ehm_frontier* f, int32_t index, struct ehm_problem** table, int32_t* horizon,
+                       int32_t* slots, int64_t* evicted);
 
 /* Drops the tree and everything the searches remember (point ids, phase-one verdicts, vertex
  * optima); the blocks loaded in the device tables are problem data and stay. */
@@ -155,7 +161,7 @@ int ehm_frontier_sizes(const ehm_frontier* f, int64_t* n_nodes, int64_t* n_roots
 int ehm_frontier_export(const ehm_frontier* f, double* vertices, int32_t* left, int32_t* right,
                         int32_t* sequence, double* vertex_costs, double* vertex_inputs,
                         uint8_t* flags);
-/* Problems solved by (table: 0 short / 1 long, kind, prefix length): out [2][5][N+1]; kinds
+/* Problems solved by (table, kind, prefix length): out [n_tables][5][N+1]; kinds
  * 0 point phase one, 1 point optimum, 2 simplex phase one, 3 minimum over a simplex, 4 slack. */
 int ehm_frontier_lp_counts(const ehm_frontier* f, int64_t* out);
 /* The relaxation block of a prefix as the device tables hold it (tests: against

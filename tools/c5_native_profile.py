@@ -25,6 +25,9 @@ def main():
     ap.add_argument('--round-cap', type=int, default=4096)
     ap.add_argument('--launch-target', type=int, default=65536)
     ap.add_argument('--speculate', type=int, default=0)
+    ap.add_argument('--horizons', default='', help='e.g. 4,8 or 4,5,6,7,8 (default: one per '
+                                                   'horizon above the short one)')
+    ap.add_argument('--slots', type=int, default=16384)
     ap.add_argument('--out', default='')
     args = ap.parse_args()
     from explicit_hybrid_mpc_amd import bnb, bnb_frontier, examples, frontier
@@ -35,7 +38,9 @@ def main():
     eps_a = float(np.max([j for _, _, j in bnb_frontier.p_theta_many(orc, 0.2 * V)]))
     orc.close()
     roots, _ = ehm_tools.delaunay_roots(V)
-    nat = frontier.NativeFrontier(mpc, eps_a, 1e-3, slots=8192)
+    horizons = [int(x) for x in args.horizons.split(',')] if args.horizons else None
+    nat = frontier.NativeFrontier(mpc, eps_a, 1e-3, slots=args.slots, horizons=horizons)
+    print('tables of horizons %s' % nat.horizons, flush=True)
     out = []
     for c in [int(x) for x in args.cells.split(',')]:
         nat.reset()
@@ -56,10 +61,12 @@ def main():
             if not st['truncated'] or el > args.seconds:
                 break
         tab1 = nat.table_stats()
-        kern = {k: [b - a for a, b in zip(tab0[k]['batch_seconds'], tab1[k]['batch_seconds'])]
-                for k in tab1 if tab1[k]}
-        launches = {k: [b - a for a, b in zip(tab0[k]['batch_launches'], tab1[k]['batch_launches'])]
-                    for k in tab1 if tab1[k]}
+        kern = {'h%d' % b['horizon']: [y - x for x, y in zip(a['batch_seconds'], b['batch_seconds'])]
+                for a, b in zip(tab0, tab1)}
+        launches = {'h%d' % b['horizon']: [y - x for x, y in zip(a['batch_launches'],
+                                                                  b['batch_launches'])]
+                    for a, b in zip(tab0, tab1)}
+        kern['evicted'] = {'h%d' % b['horizon']: b['evicted'] for b in tab1}
         rec = dict(cell=c, wall=el, finished=not st['truncated'], stats=st,
                    kernel_seconds_point_simplex=kern, kernel_launches_point_simplex=launches,
                    lp_by_table_kind_length=nat.lp_counts().tolist())
