@@ -148,13 +148,14 @@ class PairSolvers(ctypes.Structure):
 class FrontierOpts(ctypes.Structure):
     _fields_ = [('round_cap', ctypes.c_int32), ('launch_target', ctypes.c_int32),
                 ('max_visits', ctypes.c_int64), ('min_regions', ctypes.c_int64),
-                ('speculate', ctypes.c_int32)]
+                ('speculate', ctypes.c_int32), ('max_depth', ctypes.c_int32)]
 
 
 class FrontierStats(ctypes.Structure):
     _fields_ = [(k, ctypes.c_int64) for k in (
         'rounds', 'visits', 'ecc_visits', 'lcss_visits', 'regions', 'open_cells', 'n_nodes',
-        'calls_v_r', 'calls_p_theta', 'calls_bar_e', 'calls_bar_d', 'swaps', 'witness_hits', 'prefixes_expanded',
+        'calls_v_r', 'calls_p_theta', 'calls_bar_e', 'calls_bar_d', 'depth_limited', 'swaps',
+        'witness_hits', 'prefixes_expanded',
         'answered_without_a_problem', 'optima_asked', 'optima_solved', 'lp_solves', 'launches',
         'blocks_loaded', 'stalled', 'slivers')] + [
         ('truncated', ctypes.c_int32), ('depth', ctypes.c_int32),

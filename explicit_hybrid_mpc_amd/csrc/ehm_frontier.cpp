@@ -22,6 +22,7 @@
 #include <cstdio>
 #include <cstring>
 #include <limits>
+#include <memory>
 #include <new>
 #include <stdexcept>
 #include <string>
@@ -64,6 +65,7 @@ constexpr double SLIVER_TOL = 1e-7;            // EHM_SLIVER_TOL
 constexpr double INHERIT_GUARD = 1e-6;         // bnb_frontier.INHERIT_GUARD
 constexpr int BATCH = 16;                      // bnb.BATCH
 constexpr int PID_BITS = 38;
+constexpr size_t INHERIT_MAX = 8192;           // bnb_frontier.INHERIT_MAX
 constexpr int64_t FEAS_MEMO_LIMIT = 3000000;   // sequences.PrefixSearch.FEAS_MEMO_LIMIT
 constexpr size_t OPTIMA_MEMO_LIMIT = 2000000;
 const double INF = std::numeric_limits<double>::infinity();
@@ -693,6 +695,7 @@ struct ehm_frontier {
     std::unordered_map<uint64_t, int64_t> opt_of;
     std::vector<double> opt_J, opt_u;
     ehm_frontier_stats st{};
+    int32_t max_depth = 0;                      // of the run in progress (0 = none)
     int64_t base_ctr[5] = {0, 0, 0, 0, 0};      // the device solver's counters at the last reset
 
     int64_t n_nodes() const { return (int64_t)left.size(); }
@@ -709,6 +712,7 @@ struct ehm_frontier {
         pids.insert(pids.end(), (size_t)nv, -1);
         left.push_back(-1); right.push_back(-1); depth.push_back(d);
         seq.push_back(-1); witness.push_back(-1); incumbent.push_back(-1);
+        node_bounds.emplace_back();
         flags.push_back(EHM_FR_PENDING);
         return k;
     }
@@ -801,7 +805,16 @@ struct ehm_frontier {
     struct Known { double t; int64_t alpha; };
     typedef std::unordered_map<uint64_t, Known> Learned;
     std::vector<double> alpha_pool;             // maximisers of the round, nv doubles each
-    struct Split { int32_t node; int64_t code; std::vector<double> c, u; int64_t star; };
+    // upper bounds of the suboptimality-test optimum per prefix, proven on a cell's ancestors: a
+    // child lies inside its parent and the optimal cost of a commutation is convex, so the
+    // interpolant of its vertex costs lies below the parent's and t*(child) <= t*(parent) for
+    // every prefix (+ the largest increase of a vertex cost where a commutation with larger costs
+    // is adopted) -- bounds that refute, or stay below what a search still accepts, without a solve
+    // (bnb_frontier.grow_frontier)
+    typedef std::unordered_map<uint64_t, double> BoundMap;
+    std::vector<std::shared_ptr<BoundMap>> node_bounds;     // per node, null = nothing inherited
+    struct Split { int32_t node; int64_t code; std::vector<double> c, u; int64_t star;
+                   std::shared_ptr<BoundMap> down; };
 
     void feasible_somewhere(const std::vector<uint64_t>& codes, const std::vector<int32_t>& node_of,
                             std::vector<uint8_t>& known);
@@ -917,7 +930,18 @@ void ehm_frontier::optima(const std::vector<uint64_t>& code, const std::vector<i
 // without a commutation look for one (ecc); children of a cell that holds one inherit its vertex
 // costs and inputs with the new vertex's slot replaced by the optimum at the midpoint
 // (lib/worker.py:356-365) and go on with lcss.
-void ehm_frontier::bisect(std::vector<Split>& todo) {
+void ehm_frontier::bisect(std::vector<Split>& todo_all) {
+    // a cell at the depth limit is not bisected: it stays an open leaf (EHM_FR_DEPTH)
+    std::vector<Split> todo;
+    for (Split& sp : todo_all) {
+        if (max_depth > 0 && depth[sp.node] >= max_depth) {
+            flags[sp.node] = (uint8_t)((flags[sp.node] & EHM_FR_HAS_RECORD) | EHM_FR_DEPTH);
+            node_bounds[(size_t)sp.node].reset();
+            ++st.depth_limited;
+            continue;
+        }
+        todo.push_back(std::move(sp));
+    }
     const size_t n = todo.size(), sx = (size_t)nv * p;
     if (!n) return;
     std::vector<double> Rs(n * sx), S1(n * sx), S2(n * sx);
@@ -963,6 +987,7 @@ void ehm_frontier::bisect(std::vector<Split>& todo) {
         const int32_t r = new_node(&S2[i * sx], depth[nd] + 1);
         left[nd] = l; right[nd] = r;
         flags[nd] &= (uint8_t)EHM_FR_HAS_RECORD;
+        node_bounds[(size_t)nd].reset();
         for (int v = 0; v < nv; ++v) pids[(size_t)l * nv + v] = pids[(size_t)r * nv + v] = pids[(size_t)nd * nv + v];
         const int vi = ij[2 * i], vj = ij[2 * i + 1];
         pids[(size_t)l * nv + vi] = mid_id[i];
@@ -979,6 +1004,7 @@ void ehm_frontier::bisect(std::vector<Split>& todo) {
             std::memcpy(&inputs[(size_t)ch * nv * n_u], todo[i].u.data(), 8 * (size_t)nv * n_u);
             seq[ch] = todo[i].code;
             incumbent[ch] = todo[i].star;
+            node_bounds[(size_t)ch] = todo[i].down;
             flags[ch] = EHM_FR_HAS_RECORD | EHM_FR_PENDING;
             lcss_work.push_back(ch);
         }
@@ -1092,7 +1118,7 @@ void ehm_frontier::ecc_round(const std::vector<int32_t>& E, std::vector<Split>& 
             lcss_work.push_back(nd);
         }
     }
-    for (size_t i : none) to_split.push_back(Split{E[i], -1, {}, {}, -1});
+    for (size_t i : none) to_split.push_back(Split{E[i], -1, {}, {}, -1, nullptr});
 }
 
 namespace {
@@ -1171,6 +1197,12 @@ void ehm_frontier::bar_d(const std::vector<int32_t>& O, std::vector<Learned>& le
         std::vector<uint8_t> kdead;
     };
     std::vector<Search> sr(n);
+    std::vector<double> guard(n);
+    for (size_t j = 0; j < n; ++j) {
+        double mx = 0.0;
+        for (int v = 0; v < nv; ++v) mx = std::max(mx, std::fabs(costs[(size_t)O[j] * nv + v]));
+        guard[j] = INHERIT_GUARD * (1.0 + mx);
+    }
     auto floor_of = [](const Search& q) {
         return std::isfinite(q.best) ? std::max(0.0, q.best + PLATEAU * rel(q.best)) : 0.0;
     };
@@ -1212,8 +1244,10 @@ void ehm_frontier::bar_d(const std::vector<int32_t>& O, std::vector<Learned>& le
             Search& q = sr[j];
             q.kid.clear(); q.klen.clear(); q.kt.clear(); q.kalpha.clear(); q.kdead.clear();
             std::vector<HeapItem> batch;
+            double need = q.limit;
             if (q.phase == 1) {
                 const double fl = floor_of(q);
+                need = fl;
                 while (!q.heap.h.empty() && (int)batch.size() < width && q.heap.h.front().t >= fl)
                     batch.push_back(q.heap.pop());
             } else {
@@ -1233,6 +1267,15 @@ void ehm_frontier::bar_d(const std::vector<int32_t>& O, std::vector<Learned>& le
                         (it->second.t < 0.0 || len < N || it->second.alpha >= 0)) {
                         t = it->second.t; al = it->second.alpha; have = true;
                         ++st.answered_without_a_problem;
+                    } else if (const BoundMap* bm = node_bounds[(size_t)O[j]].get()) {
+                        // an inherited upper bound that refutes, or that lies below what this
+                        // phase still accepts: never solved
+                        auto bt = bm->find(c);
+                        if (bt != bm->end()) {
+                            if (bt->second < -guard[j]) { t = bt->second; have = true; }
+                            else if (bt->second < need - guard[j]) { t = -INF; have = true; }
+                            if (have) ++st.answered_without_a_problem;
+                        }
                     }
                     if (!have) {
                         ask_at.emplace_back(j, q.kid.size());
@@ -1360,12 +1403,21 @@ void ehm_frontier::bar_d(const std::vector<int32_t>& O, std::vector<Learned>& le
         const int32_t nd = O[j];
         const int64_t star = sr[j].star == 1 ? (int64_t)sr[j].star_code : -1;
         const bool winner = w < win.size() && win[w] == j;
+        // what the children inherit: the optima solved on this cell bound theirs from above, on
+        // top of what the cell inherited itself
+        std::shared_ptr<BoundMap> down = std::make_shared<BoundMap>();
+        if (node_bounds[(size_t)nd]) *down = *node_bounds[(size_t)nd];
+        for (const auto& kv : learned[j]) (*down)[kv.first] = kv.second.t;
+        if (down->size() > INHERIT_MAX) {       // keep what refutes; the rest only orders bar_D
+            for (auto it = down->begin(); it != down->end();)
+                if (it->second < 0.0) ++it; else it = down->erase(it);
+        }
         if (!winner) {                          // no better commutation: bisect with the cell's own
             to_split.push_back(Split{nd, seq[nd],
                                      std::vector<double>(&costs[(size_t)nd * nv], &costs[(size_t)nd * nv] + nv),
                                      std::vector<double>(&inputs[(size_t)nd * nv * n_u],
                                                          &inputs[(size_t)nd * nv * n_u] + (size_t)nv * n_u),
-                                     star});
+                                     star, down});
             continue;
         }
         bool finite = std::isfinite(Jmin[w]) && std::isfinite(Jth[w]);
@@ -1380,8 +1432,15 @@ void ehm_frontier::bar_d(const std::vector<int32_t>& O, std::vector<Learned>& le
         }
         std::vector<double> nc(&Jv[w * nv], &Jv[w * nv] + nv);
         std::vector<double> nu(&uv[w * nv * n_u], &uv[w * nv * n_u] + (size_t)nv * n_u);
-        double vmax = -INF;
-        for (int v = 0; v < nv; ++v) vmax = std::max(vmax, costs[(size_t)nd * nv + v]);
+        double vmax = -INF, rise = -INF;
+        for (int v = 0; v < nv; ++v) {
+            vmax = std::max(vmax, costs[(size_t)nd * nv + v]);
+            rise = std::max(rise, nc[(size_t)v] - costs[(size_t)nd * nv + v]);
+        }
+        // the bounds were proven against the interpolation of the OLD vertex costs; where the
+        // adopted commutation's are larger the interpolant rises by at most the largest increase
+        if (rise > 0.0)
+            for (auto& kv : *down) kv.second += rise;
         const double rhs = std::max(eps_a, eps_r * Jth[w]);
         const bool small = vmax - Jmin[w] < rhs;
         if (small) {                            // lib/worker.py:396-401: adopt in place, look again
@@ -1389,11 +1448,12 @@ void ehm_frontier::bar_d(const std::vector<int32_t>& O, std::vector<Learned>& le
             std::memcpy(&costs[(size_t)nd * nv], nc.data(), 8 * (size_t)nv);
             std::memcpy(&inputs[(size_t)nd * nv * n_u], nu.data(), 8 * (size_t)nv * n_u);
             incumbent[nd] = star;
+            node_bounds[(size_t)nd] = down;
             flags[nd] = EHM_FR_HAS_RECORD | EHM_FR_PENDING;
             lcss_work.push_back(nd);
             ++st.swaps;
         } else {
-            to_split.push_back(Split{nd, (int64_t)sr[j].star_code, nc, nu, star});
+            to_split.push_back(Split{nd, (int64_t)sr[j].star_code, nc, nu, star, down});
         }
         ++w;
     }
@@ -1420,6 +1480,18 @@ void ehm_frontier::lcss_round(const std::vector<int32_t>& Lc, int launch_target,
     struct Guard { ehm_search_bare* b; ~Guard() { ehm_search_bare_destroy(b); } } g{Bq};
     std::vector<Learned> learned(n);
     int64_t n_ask = 0, left_n = (int64_t)n;
+    {   // inherited bounds (the queues keep the refuting ones)
+        std::vector<uint64_t> bc;
+        std::vector<double> bt;
+        for (size_t j = 0; j < n; ++j) {
+            const BoundMap* bm = node_bounds[(size_t)Lc[j]].get();
+            if (!bm || bm->empty()) continue;
+            bc.clear(); bt.clear();
+            for (const auto& kv : *bm) { bc.push_back(kv.first); bt.push_back(kv.second); }
+            chk_search(ehm_search_bare_bounds(Bq, (int32_t)j, (int64_t)bc.size(), bc.data(), bt.data()),
+                       "ehm_search_bare_bounds");
+        }
+    }
     // the parent's best-slack sequence first: where its slack is not negative the cell is open and
     // the search is not run
     {
@@ -1490,10 +1562,15 @@ void ehm_frontier::lcss_round(const std::vector<int32_t>& Lc, int launch_target,
         lo.push_back(std::move(learned[j]));
     }
     bar_d(O, lo, launch_target, to_split);
+    // (a cell that adopted a commutation in place holds its new bounds; everything else has
+    // handed them on or is a leaf)
+    for (size_t j = 0; j < n; ++j)
+        if (!(flags[Lc[j]] & EHM_FR_PENDING)) node_bounds[(size_t)Lc[j]].reset();
 }
 
 void ehm_frontier::run(const ehm_frontier_opts& o) {
     const int cap = o.round_cap > 0 ? o.round_cap : 4096;
+    max_depth = o.max_depth;
     const int target = o.launch_target > 0 ? o.launch_target : 65536;
     const double t0 = now();
     st.truncated = 0;
@@ -1720,7 +1797,7 @@ int ehm_frontier_reset(ehm_frontier* f) {
     f->feas_n = 0;
     f->verts.clear(); f->costs.clear(); f->inputs.clear(); f->pids.clear();
     f->left.clear(); f->right.clear(); f->depth.clear(); f->seq.clear(); f->witness.clear();
-    f->incumbent.clear();
+    f->incumbent.clear(); f->node_bounds.clear();
     f->flags.clear(); f->n_roots = 0;
     f->ecc_work.clear(); f->lcss_work.clear();
     f->opt_of.clear(); f->opt_J.clear(); f->opt_u.clear();

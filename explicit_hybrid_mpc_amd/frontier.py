@@ -24,7 +24,7 @@ from . import _capi
 from ._capi import ptr
 from .tree import NodeData, Tree
 
-FR_CLOSED, FR_HAS_RECORD, FR_OPEN, FR_PENDING, FR_NEEDS_ECC = 1, 2, 4, 8, 16
+FR_CLOSED, FR_HAS_RECORD, FR_OPEN, FR_PENDING, FR_NEEDS_ECC, FR_DEPTH = 1, 2, 4, 8, 16, 32
 
 
 def _law_struct(mpc):
@@ -213,10 +213,12 @@ class NativeFrontier:
             R = np.ascontiguousarray(R)
             self._check(self._lib.ehm_frontier_add_root(self._h, ptr(R)))
 
-    def run(self, round_cap=4096, launch_target=65536, max_visits=0, min_regions=0, speculate=0):
+    def run(self, round_cap=4096, launch_target=65536, max_visits=0, min_regions=0, speculate=0,
+            max_depth=0):
         opts = _capi.FrontierOpts(round_cap=int(round_cap), launch_target=int(launch_target),
                                   max_visits=int(max_visits or 0),
-                                  min_regions=int(min_regions or 0), speculate=int(speculate))
+                                  min_regions=int(min_regions or 0), speculate=int(speculate),
+                                  max_depth=int(max_depth or 0))
         st = _capi.FrontierStats()
         self._check(self._lib.ehm_frontier_run(self._h, ctypes.byref(opts), ctypes.byref(st)))
         self.last_stats = {k: getattr(st, k) for k, _ in st._fields_}
@@ -299,7 +301,7 @@ def graft(flat, mpc, targets):
 
 def grow_cells(native, branches, slow_oracle=None, round_cap=4096, launch_target=65536,
                max_visits=0, min_regions=0, speculate=0, slow_opts=None, deadline=None,
-               slice_visits=100000):
+               slice_visits=100000, max_depth=0):
     """
     ``bnb_frontier.grow_frontier(oracle, branches, 'ecc')`` on the native driver: ``branches`` (a
     ``Tree`` or a list of them, data = the root simplices) are grown in place.  ``slow_oracle``: a
@@ -316,14 +318,16 @@ def grow_cells(native, branches, slow_oracle=None, round_cap=4096, launch_target
     native.add_roots([np.asarray(b.data.vertices, dtype=np.float64) for b in branches])
     if deadline is None:
         st = dict(native.run(round_cap=round_cap, launch_target=launch_target,
-                             max_visits=max_visits, min_regions=min_regions, speculate=speculate))
+                             max_visits=max_visits, min_regions=min_regions, speculate=speculate,
+                             max_depth=max_depth))
     else:
         budget = 0
         while True:
             budget += int(slice_visits)
             cap = min(budget, int(max_visits)) if max_visits else budget
             st = dict(native.run(round_cap=round_cap, launch_target=launch_target, max_visits=cap,
-                                 min_regions=min_regions, speculate=speculate))
+                                 min_regions=min_regions, speculate=speculate,
+                                 max_depth=max_depth))
             if not st['truncated'] or time.perf_counter() >= deadline or \
                     (max_visits and st['visits'] >= max_visits) or \
                     (min_regions and st['regions'] >= min_regions):

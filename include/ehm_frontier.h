@@ -118,8 +118,11 @@ typedef struct ehm_frontier_opts {
     int32_t launch_target;    /* problems a best-first step aims at per launch (0 = 65536)     */
     int64_t max_visits;       /* stop after that many cell visits (0 = none): open cells stay  */
     int64_t min_regions;      /* stop once that many leaves are closed (0 = run to completion) */
-    int32_t speculate;        /* 1 = a descent asks about the next level's candidates in the
-                               * same launch (fewer dependent launches, more problems)        */
+    int32_t speculate;        /* reserved (0)                                                  */
+    int32_t max_depth;        /* cells at this depth (roots: 0) are not bisected: they stay
+                               * open leaves flagged EHM_FR_DEPTH (0 = no limit).  A law whose
+                               * optimal cost jumps across a mode boundary is refined without
+                               * end along that boundary (so is the reference's partition)      */
 } ehm_frontier_opts;
 
 typedef struct ehm_frontier_stats {
@@ -128,6 +131,7 @@ typedef struct ehm_frontier_stats {
     int64_t open_cells;       /* cells handed back to the caller (EHM_FR_OPEN)                 */
     int64_t n_nodes;
     int64_t calls_v_r, calls_p_theta, calls_bar_e, calls_bar_d;
+    int64_t depth_limited;    /* open leaves left at max_depth                                 */
     int64_t swaps;            /* cells that adopted bar_D's commutation in place (lib/worker.py:396-401) */
     int64_t witness_hits;
     int64_t prefixes_expanded, answered_without_a_problem;
@@ -153,6 +157,7 @@ int ehm_frontier_run(ehm_frontier* f, const ehm_frontier_opts* opts, ehm_frontie
                                * caller), or a vertex solve failed (lib/oracle.py:214-218)     */
 #define EHM_FR_PENDING    8   /* leaf not visited yet (a truncated run)                        */
 #define EHM_FR_NEEDS_ECC 16   /* with EHM_FR_OPEN: the cell has no record, the caller runs ecc */
+#define EHM_FR_DEPTH     32   /* open leaf: not bisected, the run's depth limit                */
 
 int ehm_frontier_sizes(const ehm_frontier* f, int64_t* n_nodes, int64_t* n_roots);
 /* vertices [n][p+1][p], left / right [n] (-1: leaf; the roots are nodes 0 .. n_roots-1, children

@@ -28,6 +28,7 @@ def main():
     ap.add_argument('--horizons', default='', help='e.g. 4,8 or 4,5,6,7,8 (default: one per '
                                                    'horizon above the short one)')
     ap.add_argument('--slots', type=int, default=16384)
+    ap.add_argument('--max-depth', type=int, default=0)
     ap.add_argument('--out', default='')
     args = ap.parse_args()
     from explicit_hybrid_mpc_amd import bnb, bnb_frontier, examples, frontier
@@ -51,11 +52,11 @@ def main():
         while True:
             visits += args.slice
             st = nat.run(round_cap=args.round_cap, launch_target=args.launch_target,
-                         max_visits=visits, speculate=args.speculate)
+                         max_visits=visits, speculate=args.speculate, max_depth=args.max_depth)
             el = time.perf_counter() - t0
-            print('cell %d: %6.1f s  visits %8d  nodes %8d  regions %8d  open %6d  depth %2d  LPs '
+            print('cell %d: %6.1f s  visits %8d  nodes %8d  regions %8d  at depth limit %6d  depth %2d  LPs '
                   '%9d  solver calls %6d  in solvers %.1f s' % (
-                      c, el, st['visits'], st['n_nodes'], st['regions'], st['open_cells'],
+                      c, el, st['visits'], st['n_nodes'], st['regions'], st['depth_limited'],
                       st['depth'], st['lp_solves'], st['launches'], st['seconds_solvers']),
                   flush=True)
             if not st['truncated'] or el > args.seconds:
