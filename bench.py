@@ -918,6 +918,7 @@ def measure_config5(args, ctx):
         orc.table.forget()
         st = frontier.grow_cells(native, part, slow_oracle=lambda: orc, round_cap=args.round_cap,
                                  max_visits=args.max_visits or 0, deadline=step_deadline[0],
+                                 max_depth=args.max_depth or 0,
                                  min_regions=0 if args.regions or regions >= (1 << 30) else regions,
                                  slow_opts=dict(order=args.order, table_backoff=True,
                                                 round_cap=args.round_cap))
@@ -1094,6 +1095,7 @@ def measure_config5(args, ctx):
                 'cells_log': cells_log[n_log_warm:],
                 'regions_per_step': closed_t / K, 'nodes_per_step': nodes_t / K,
                 'open_leaves_per_step': (leaves - closed) / K if world == 1 else None,
+                'depth_limit': args.max_depth or None,
                 'tree_depth': depth,
                 'node_visits_per_step': tot[9] / K,
                 'lp_solves_per_step': lp / K,

@@ -65,7 +65,9 @@ constexpr double SLIVER_TOL = 1e-7;            // EHM_SLIVER_TOL
 constexpr double INHERIT_GUARD = 1e-6;         // bnb_frontier.INHERIT_GUARD
 constexpr int BATCH = 16;                      // bnb.BATCH
 constexpr int PID_BITS = 38;
-constexpr size_t INHERIT_MAX = 8192;           // bnb_frontier.INHERIT_MAX
+constexpr size_t INHERIT_MAX = 2048;           // bounds handed down before the non-refuting ones are
+                                               // dropped (bnb_frontier.INHERIT_MAX: 8192; the copies cost
+                                               // more than the few problems the rest saves)
 constexpr int64_t FEAS_MEMO_LIMIT = 3000000;   // sequences.PrefixSearch.FEAS_MEMO_LIMIT
 constexpr size_t OPTIMA_MEMO_LIMIT = 2000000;
 const double INF = std::numeric_limits<double>::infinity();
@@ -1406,6 +1408,7 @@ void ehm_frontier::bar_d(const std::vector<int32_t>& O, std::vector<Learned>& le
         // what the children inherit: the optima solved on this cell bound theirs from above, on
         // top of what the cell inherited itself
         std::shared_ptr<BoundMap> down = std::make_shared<BoundMap>();
+        down->reserve((node_bounds[(size_t)nd] ? node_bounds[(size_t)nd]->size() : 0) + learned[j].size());
         if (node_bounds[(size_t)nd]) *down = *node_bounds[(size_t)nd];
         for (const auto& kv : learned[j]) (*down)[kv.first] = kv.second.t;
         if (down->size() > INHERIT_MAX) {       // keep what refutes; the rest only orders bar_D
@@ -1487,7 +1490,9 @@ void ehm_frontier::lcss_round(const std::vector<int32_t>& Lc, int launch_target,
             const BoundMap* bm = node_bounds[(size_t)Lc[j]].get();
             if (!bm || bm->empty()) continue;
             bc.clear(); bt.clear();
-            for (const auto& kv : *bm) { bc.push_back(kv.first); bt.push_back(kv.second); }
+            for (const auto& kv : *bm)              // (the queues keep the refuting ones only)
+                if (kv.second < -guard[j]) { bc.push_back(kv.first); bt.push_back(kv.second); }
+            if (bc.empty()) continue;
             chk_search(ehm_search_bare_bounds(Bq, (int32_t)j, (int64_t)bc.size(), bc.data(), bt.data()),
                        "ehm_search_bare_bounds");
         }

@@ -144,3 +144,27 @@ def test_a_failing_solver_surfaces_as_its_own_exception():
     with pytest.raises(Boom):
         nat.run()
     nat.close()
+
+
+def test_depth_limit_leaves_open_cells_flagged():
+    """``max_depth``: a cell at the limit is not bisected -- it stays an open leaf flagged
+    EHM_FR_DEPTH (a law whose optimal cost jumps across a mode boundary is refined without end
+    along it; so is the reference's partition, lib/worker.py:403-417 has no limit either)."""
+    mpc = helpers.make_instance('pwa_small', 0)
+    eps_a = helpers.eps_a_rule(mpc, 0.25)
+    roots, _ = helpers.roots_of(mpc)
+    table = prefix_bb.CpuPrefixTable(mpc, eps_a, 0.2)
+    nat = frontier.NativeFrontier(mpc, eps_a, 0.2,
+                                  solvers=frontier.TableSolvers(table, _host_split_batch))
+    nat.add_roots(roots)
+    st = nat.run(max_depth=3)
+    flat = nat.export()
+    leaves = flat['left'] < 0
+    limited = (flat['flags'] & frontier.FR_DEPTH) != 0
+    assert st['depth_limited'] == int(limited.sum()) > 0 and st['depth'] == 3
+    assert not np.any(limited & ~leaves)
+    assert not np.any(flat['flags'][leaves] & frontier.FR_PENDING)
+    # every leaf is closed or at the limit
+    closed = (flat['flags'] & frontier.FR_CLOSED) != 0
+    assert np.all(closed[leaves] | limited[leaves]) and st['regions'] == int(closed.sum())
+    nat.close()

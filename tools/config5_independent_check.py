@@ -73,7 +73,9 @@ def cmd_sample(args):
         t0 = time.perf_counter()
         if native is not None:          # the product's default driver (bench.py --driver native)
             st = frontier.grow_cells(native, tree, slow_oracle=lambda: orc, slow_opts=dict(
-                order='lcss-first', table_backoff=True, round_cap=4096))
+                order='lcss-first', table_backoff=True, round_cap=4096),
+                max_depth=args.max_depth, deadline=time.perf_counter() + args.cell_seconds,
+                slice_visits=20000)
         else:
             st = bnb_frontier.grow_frontier(orc, tree, 'ecc', order='lcss-first',
                                             table_backoff=True, round_cap=4096)
@@ -83,8 +85,9 @@ def cmd_sample(args):
         kinds = {}
         for nd, loc in nodes:
             if nd.is_leaf():
-                assert nd.data.is_epsilon_suboptimal, 'an open leaf in a finished cell'
-                kinds[loc] = 1
+                # (open leaves: the depth limit, or a cell cut short by --cell-seconds -- undecided,
+                # nothing to check)
+                kinds[loc] = 1 if nd.data.is_epsilon_suboptimal else -1
             else:
                 kinds[loc] = 2 if has[loc] else 0
         by_kind = {k: [i for i, (nd, loc) in enumerate(nodes) if kinds[loc] == k] for k in (0, 1, 2)}
@@ -316,6 +319,8 @@ def main():
     a.add_argument('--per-cell', type=int, default=44)
     a.add_argument('--seed', type=int, default=0)
     a.add_argument('--driver', choices=['native', 'python'], default='native')
+    a.add_argument('--max-depth', type=int, default=28)
+    a.add_argument('--cell-seconds', type=float, default=30.)
     a.add_argument('--out', default='gpurun_out/c5_samples.npz')
     b = sub.add_parser('check')
     b.add_argument('samples')
