@@ -272,9 +272,24 @@ def cmd_check(args):
     os.environ.update(OMP_NUM_THREADS='1', OPENBLAS_NUM_THREADS='1', MKL_NUM_THREADS='1')
     t0 = time.perf_counter()
     res = []
-    with mp.get_context('spawn').Pool(args.procs) as pool:
+    # every finished node is appended to <out>.jsonl at once: a run that is stopped keeps what it
+    # has, and the next one goes on with the nodes that are missing
+    log = (args.out or args.samples) + '.jsonl'
+    if os.path.exists(log):
+        res = [json.loads(line) for line in open(log) if line.strip()]
+        done = {r['idx'] for r in res}
+        jobs = [j for j in jobs if j[0] not in done]
+        print('%d nodes already checked (%s), %d to go' % (len(res), log, len(jobs)), flush=True)
+    # the cheap kinds first (one MILP per split without a commutation), so that all cells are
+    # covered early
+    jobs.sort(key=lambda j: (j[1] != 0, j[0]))
+    if args.summary_only:
+        jobs = []
+    with mp.get_context('spawn').Pool(args.procs) as pool, open(log, 'a') as lf:
         for r in pool.imap_unordered(_check_one, jobs):
             res.append(r)
+            lf.write(json.dumps(r) + '\n')
+            lf.flush()
             if len(res) % 20 == 0:
                 print('  %d / %d nodes, %d failed, %.0f s' % (
                     len(res), len(jobs), sum(not x['ok'] for x in res), time.perf_counter() - t0),
@@ -287,7 +302,8 @@ def cmd_check(args):
              'device tables), re-decided by one MILP per oracle call (oracle/milp_check.py, HiGHS '
              'branch-and-bound on the big-M statement of the law) and uncondensed fixed-sequence '
              'LPs; no code of the product\'s search takes part',
-        eps_a=eps_a, eps_r=eps_r, nodes=len(res), cells=sorted(set(int(c) for c in z['cell'])),
+        eps_a=eps_a, eps_r=eps_r, nodes=len(res), nodes_sampled=int(n),
+        cells=sorted(set(int(z['cell'][r['idx']]) for r in res)),
         by_kind={kinds[k]: dict(nodes=sum(r['kind'] == k for r in res),
                                 agree=sum(r['kind'] == k and r['ok'] and not r['routed']
                                           for r in res),
@@ -326,6 +342,8 @@ def main():
     b.add_argument('samples')
     b.add_argument('--procs', type=int, default=8)
     b.add_argument('--limit', type=int, default=0)
+    b.add_argument('--summary-only', action='store_true',
+                   help='no new checks: the summary of what <out>.jsonl holds')
     b.add_argument('--out', default='')
     args = ap.parse_args()
     return cmd_sample(args) if args.cmd == 'sample' else cmd_check(args)
