@@ -115,7 +115,7 @@ def pmc_traffic(kernel, summary):
     the kernel sources it was measured on (tools/pmc_summary.py); a profile of OTHER code is not
     quoted: returns (None, reason).
     """
-    for rnd in ('r4', 'r3', 'r2', 'r1'):
+    for rnd in ('r5', 'r4', 'r3', 'r2', 'r1'):
         path = os.path.join(ROOT, 'profiles', rnd, summary)
         if os.path.exists(path):
             break

@@ -47,7 +47,7 @@ EXPORTED_SEARCH = [
     'ehm_search_register_midpoints', 'ehm_search_forget', 'ehm_search_counts',
     'ehm_search_query', 'ehm_search_asks', 'ehm_search_answer', 'ehm_search_descent_begin',
     'ehm_search_descent_step', 'ehm_search_descent_result', 'ehm_search_peek',
-    'ehm_search_abandon',
+    'ehm_search_abandon', 'ehm_search_peek_any',
     'ehm_search_bare_create', 'ehm_search_bare_destroy', 'ehm_search_bare_seed',
     'ehm_search_bare_bounds', 'ehm_search_bare_step', 'ehm_search_bare_asks',
     'ehm_search_bare_answer', 'ehm_search_bare_result', 'ehm_search_bare_learned',
@@ -274,6 +274,7 @@ def load(build_if_missing=True):
     lib.ehm_search_descent_begin.argtypes = [vp, i64, vp, vp, vp, vp]
     lib.ehm_search_descent_step.argtypes = [vp, vp, ctypes.POINTER(i64), ctypes.POINTER(i64)]
     lib.ehm_search_descent_result.argtypes = [vp, vp, ctypes.POINTER(i64)]
+    lib.ehm_search_peek_any.argtypes = [vp, i64, vp, vp, vp, vp, vp]
     lib.ehm_search_bare_create.argtypes = [i32, i32, i32, vp, ctypes.POINTER(vp)]
     lib.ehm_search_bare_destroy.argtypes = [vp]
     lib.ehm_search_bare_seed.argtypes = [vp, i32, ctypes.c_uint64, ctypes.c_double, i32]

@@ -491,6 +491,7 @@ struct ehm_problem {
     int mid_first = 1;       // 1 = persistent kernel with the midpoint solve first (default)
     int inherit_wit = 1;     // 1 = open nodes hand the point that proved them open to the child
                              // that contains it (DevTree::wit; option "inherit_witness")
+    bool budget_keep = false;   // budgeted launches keep one child too (option "budget_keep")
     int work_first = 1;      // 1 = a wavefront of the persistent kernel that splits a node goes on
                              // with one child itself and queues the other (option "work_first")
     int share_mid = 1;       // 1 = the persistent kernel keeps a table of midpoint optima: the
@@ -1200,6 +1201,10 @@ int ehm_problem_set_option(ehm_problem* P, const char* name, double value) {
     }
     if (!strcmp(name, "work_first")) {
         P->work_first = value != 0.0;
+        return EHM_OK;
+    }
+    if (!strcmp(name, "budget_keep")) {
+        P->budget_keep = value != 0.0;
         return EHM_OK;
     }
     if (!strcmp(name, "share_midpoints")) {
@@ -2676,6 +2681,12 @@ static int persistent_run(ehm_tree* T, long long max_pops = 0) {
     // budgeted launch (ehm_partition_advance): queue positions >= pop_limit stay unprocessed
     if (max_pops > 0 && max_pops < n_slots) deal.pop_limit = (int)max_pops;
     deal.keep = (P->work_first && !getenv("EHM_NO_WORKFIRST")) ? 1 : 0;
+    // budgeted launches queue both children unless option "budget_keep" is set: a wavefront that
+    // keeps a child follows its chain depth first, what the launch leaves behind the pop limit is
+    // then a frontier of deep small cells, and the rebalancing rounds move 4 x the nodes for 8 %
+    // more LPs (two gloo ranks on one GPU: 38.2 against 33.4 ms per partition,
+    // profiles/r5/bench_2_gloo_ranks_dynamic_budget_keep.json)
+    if (deal.pop_limit > 0 && !P->budget_keep) deal.keep = 0;
     PersistCtl h{};
     h.head = 0;
     h.tail = (int)R.nf;

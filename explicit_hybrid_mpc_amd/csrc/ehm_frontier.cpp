@@ -813,7 +813,18 @@ struct ehm_frontier {
     // every prefix (+ the largest increase of a vertex cost where a commutation with larger costs
     // is adopted) -- bounds that refute, or stay below what a search still accepts, without a solve
     // (bnb_frontier.grow_frontier)
-    typedef std::unordered_map<uint64_t, double> BoundMap;
+    // (flat and sorted by prefix code: handing bounds down is a merge and two memcpy, a look-up a
+    // binary search -- a hash map per open cell cost the driver more than the solves it saved)
+    struct BoundMap {
+        std::vector<uint64_t> code;
+        std::vector<double> t;
+        size_t size() const { return code.size(); }
+        bool empty() const { return code.empty(); }
+        const double* find(uint64_t c) const {
+            auto it = std::lower_bound(code.begin(), code.end(), c);
+            return (it != code.end() && *it == c) ? &t[(size_t)(it - code.begin())] : nullptr;
+        }
+    };
     std::vector<std::shared_ptr<BoundMap>> node_bounds;     // per node, null = nothing inherited
     struct Split { int32_t node; int64_t code; std::vector<double> c, u; int64_t star;
                    std::shared_ptr<BoundMap> down; };
@@ -841,31 +852,24 @@ void ehm_frontier::feasible_somewhere(const std::vector<uint64_t>& codes,
     const int64_t n = (int64_t)codes.size();
     known.assign((size_t)n, 0);
     if (!n) return;
-    std::vector<uint64_t> rep((size_t)n * nv);
-    std::vector<int64_t> pp((size_t)n * nv);
-    std::vector<int8_t> ver((size_t)n * nv);
-    for (int64_t a = 0; a < n; ++a)
-        for (int v = 0; v < nv; ++v) {
-            rep[(size_t)a * nv + v] = codes[(size_t)a];
-            pp[(size_t)a * nv + v] = pids[(size_t)node_of[(size_t)a] * nv + v];
-        }
-    chk_search(ehm_search_peek(S, n * nv, rep.data(), pp.data(), ver.data()), "ehm_search_peek");
+    std::vector<int64_t> pp((size_t)n * nv), pb((size_t)n + 1);
+    std::vector<int32_t> first((size_t)n);
+    for (int64_t a = 0; a < n; ++a) {
+        pb[(size_t)a] = a * nv;
+        std::memcpy(&pp[(size_t)a * nv], &pids[(size_t)node_of[(size_t)a] * nv], 8 * (size_t)nv);
+    }
+    pb[(size_t)n] = n * nv;
+    chk_search(ehm_search_peek_any(S, n, codes.data(), pb.data(), pp.data(), known.data(), first.data()),
+               "ehm_search_peek_any");
     std::vector<uint64_t> qc;
     std::vector<int64_t> qb(1, 0), qp, qa;
-    for (int64_t a = 0; a < n; ++a) {
-        int first_unknown = -1;
-        for (int v = 0; v < nv; ++v) {
-            const int8_t r = ver[(size_t)a * nv + v];
-            if (r == 1) known[(size_t)a] = 1;
-            if (r == -1 && first_unknown < 0) first_unknown = v;
-        }
-        if (!known[(size_t)a] && first_unknown >= 0) {
+    for (int64_t a = 0; a < n; ++a)
+        if (!known[(size_t)a] && first[(size_t)a] >= 0) {
             qc.push_back(codes[(size_t)a]);
-            qp.push_back(pp[(size_t)a * nv + first_unknown]);
+            qp.push_back(pp[(size_t)a * nv + first[(size_t)a]]);
             qb.push_back((int64_t)qp.size());
             qa.push_back(a);
         }
-    }
     if (!qc.empty()) {
         std::vector<uint8_t> fl;
         feasible_sets(qc, qb, qp, fl);
@@ -1272,10 +1276,9 @@ void ehm_frontier::bar_d(const std::vector<int32_t>& O, std::vector<Learned>& le
                     } else if (const BoundMap* bm = node_bounds[(size_t)O[j]].get()) {
                         // an inherited upper bound that refutes, or that lies below what this
                         // phase still accepts: never solved
-                        auto bt = bm->find(c);
-                        if (bt != bm->end()) {
-                            if (bt->second < -guard[j]) { t = bt->second; have = true; }
-                            else if (bt->second < need - guard[j]) { t = -INF; have = true; }
+                        if (const double* bt = bm->find(c)) {
+                            if (*bt < -guard[j]) { t = *bt; have = true; }
+                            else if (*bt < need - guard[j]) { t = -INF; have = true; }
                             if (have) ++st.answered_without_a_problem;
                         }
                     }
@@ -1408,12 +1411,30 @@ void ehm_frontier::bar_d(const std::vector<int32_t>& O, std::vector<Learned>& le
         // what the children inherit: the optima solved on this cell bound theirs from above, on
         // top of what the cell inherited itself
         std::shared_ptr<BoundMap> down = std::make_shared<BoundMap>();
-        down->reserve((node_bounds[(size_t)nd] ? node_bounds[(size_t)nd]->size() : 0) + learned[j].size());
-        if (node_bounds[(size_t)nd]) *down = *node_bounds[(size_t)nd];
-        for (const auto& kv : learned[j]) (*down)[kv.first] = kv.second.t;
-        if (down->size() > INHERIT_MAX) {       // keep what refutes; the rest only orders bar_D
-            for (auto it = down->begin(); it != down->end();)
-                if (it->second < 0.0) ++it; else it = down->erase(it);
+        {
+            std::vector<std::pair<uint64_t, double>> own;
+            own.reserve(learned[j].size());
+            for (const auto& kv : learned[j]) own.emplace_back(kv.first, kv.second.t);
+            std::sort(own.begin(), own.end());
+            const BoundMap* inh = node_bounds[(size_t)nd].get();
+            const size_t ni = inh ? inh->size() : 0;
+            down->code.reserve(ni + own.size());
+            down->t.reserve(ni + own.size());
+            size_t a = 0, b = 0;                // merge; what was solved HERE overrides what was inherited
+            while (a < ni || b < own.size()) {
+                if (b == own.size() || (a < ni && inh->code[a] < own[b].first)) {
+                    down->code.push_back(inh->code[a]); down->t.push_back(inh->t[a]); ++a;
+                } else {
+                    if (a < ni && inh->code[a] == own[b].first) ++a;
+                    down->code.push_back(own[b].first); down->t.push_back(own[b].second); ++b;
+                }
+            }
+            if (down->size() > INHERIT_MAX) {   // keep what refutes; the rest only orders bar_D
+                size_t w2 = 0;
+                for (size_t q = 0; q < down->code.size(); ++q)
+                    if (down->t[q] < 0.0) { down->code[w2] = down->code[q]; down->t[w2] = down->t[q]; ++w2; }
+                down->code.resize(w2); down->t.resize(w2);
+            }
         }
         if (!winner) {                          // no better commutation: bisect with the cell's own
             to_split.push_back(Split{nd, seq[nd],
@@ -1443,7 +1464,7 @@ void ehm_frontier::bar_d(const std::vector<int32_t>& O, std::vector<Learned>& le
         // the bounds were proven against the interpolation of the OLD vertex costs; where the
         // adopted commutation's are larger the interpolant rises by at most the largest increase
         if (rise > 0.0)
-            for (auto& kv : *down) kv.second += rise;
+            for (double& tb : down->t) tb += rise;
         const double rhs = std::max(eps_a, eps_r * Jth[w]);
         const bool small = vmax - Jmin[w] < rhs;
         if (small) {                            // lib/worker.py:396-401: adopt in place, look again
@@ -1490,8 +1511,8 @@ void ehm_frontier::lcss_round(const std::vector<int32_t>& Lc, int launch_target,
             const BoundMap* bm = node_bounds[(size_t)Lc[j]].get();
             if (!bm || bm->empty()) continue;
             bc.clear(); bt.clear();
-            for (const auto& kv : *bm)              // (the queues keep the refuting ones only)
-                if (kv.second < -guard[j]) { bc.push_back(kv.first); bt.push_back(kv.second); }
+            for (size_t q = 0; q < bm->code.size(); ++q)    // (the queues keep the refuting ones only)
+                if (bm->t[q] < -guard[j]) { bc.push_back(bm->code[q]); bt.push_back(bm->t[q]); }
             if (bc.empty()) continue;
             chk_search(ehm_search_bare_bounds(Bq, (int32_t)j, (int64_t)bc.size(), bc.data(), bt.data()),
                        "ehm_search_bare_bounds");

@@ -394,6 +394,44 @@ int ehm_search_peek(ehm_search* s, int64_t n, const uint64_t* code, const int64_
     return EHM_OK;
 }
 
+// For n_sets (prefix, point set) questions "is the relaxation KNOWN to be feasible at one of the
+// points?": known[k] = 1 at the first point with a held verdict 1 (the scan stops there: a cell
+// shares all but one of its vertices with its parent, so the answer is usually the first look-up),
+// else 0 and first_unknown[k] = the position (within the set) of the first point nothing is held
+// about, -1 if every point is known to be infeasible.
+int ehm_search_peek_any(ehm_search* s, int64_t n_sets, const uint64_t* code, const int64_t* set_begin,
+                        const int64_t* point_id, uint8_t* known, int32_t* first_unknown) {
+    if (!s || n_sets < 0 || (n_sets && (!code || !set_begin || !point_id || !known || !first_unknown)))
+        return fail(EHM_E_INVALID, "ehm_search_peek_any: bad argument");
+    const int64_t np_ = (int64_t)s->mid_a.size();
+    const uint64_t top = s->pw[s->N];
+    try {
+        for (int64_t k = 0; k < n_sets; ++k) {
+            if (code[k] >= top) return fail(EHM_E_INVALID, "ehm_search_peek_any: prefix code out of range");
+            known[k] = 0;
+            first_unknown[k] = -1;
+            for (int64_t t = set_begin[k]; t < set_begin[k + 1]; ++t) {
+                const int64_t v = point_id[t];
+                if (v < 0 || v >= np_) return fail(EHM_E_INVALID, "ehm_search_peek_any: unknown point id");
+                int32_t r = s->memo.get(s->key_of(code[k], v));
+                if (r < 0) {
+                    const int64_t a = s->mid_a[v];
+                    if (a >= 0 && s->memo.get(s->key_of(code[k], a)) == 1 &&
+                        s->memo.get(s->key_of(code[k], s->mid_b[v])) == 1) {
+                        s->memo.put(s->key_of(code[k], v), 1);
+                        r = 1;
+                    }
+                }
+                if (r == 1) { known[k] = 1; break; }
+                if (r != 0 && first_unknown[k] < 0) first_unknown[k] = (int32_t)(t - set_begin[k]);
+            }
+        }
+    } catch (const std::bad_alloc&) {
+        return fail(EHM_E_CAPACITY, "ehm_search_peek_any: out of memory");
+    }
+    return EHM_OK;
+}
+
 int ehm_search_query(ehm_search* s, int64_t n_sets, const uint64_t* code, const int64_t* set_begin,
                      const int64_t* point_id, uint8_t* flags, int64_t* n_ask, int64_t* n_prefix) {
     if (!s || n_sets < 0 || !set_begin || !n_ask || !n_prefix || (n_sets && (!code || !flags)))

@@ -65,6 +65,14 @@ int ehm_search_counts(const ehm_search* s, int64_t counts[4]);
 int ehm_search_peek(ehm_search* s, int64_t n, const uint64_t* code, const int64_t* point_id,
                     int8_t* verdict);
 
+/* n_sets questions "is the relaxation of prefix code[k] KNOWN to be feasible at one of the points
+ * point_id[set_begin[k] .. set_begin[k+1])?" (then it is feasible on their convex hull): known[k]
+ * = 1 at the first held verdict 1 -- the scan of the set stops there --, else 0 and
+ * first_unknown[k] = position within the set of the first point nothing is held about (-1: every
+ * point is known to be infeasible). */
+int ehm_search_peek_any(ehm_search* s, int64_t n_sets, const uint64_t* code, const int64_t* set_begin,
+                        const int64_t* point_id, uint8_t* known, int32_t* first_unknown);
+
 /* n_sets questions "is the relaxation of prefix code[k] feasible at EVERY point
  * point_id[set_begin[k] .. set_begin[k+1])?".  flags[k] = 0 where a held verdict already says
  * no; the pairs that need a problem are pending afterwards (*n_ask of them over *n_prefix

@@ -154,6 +154,9 @@ int ehm_problem_set_solver(ehm_problem* prob, int generation);
  * deterministic extremes instead of draws (m bit 0: V_R returns the LAST commutation feasible at
  * every vertex, bit 1: bar_D the admissible commutation with the SMALLEST slack): the envelope of
  * what the choice can do to a tree (tools/cwh_jobs.py);
+ * "budget_keep" (0|1, default 0): budgeted launches (ehm_partition_advance) let a wavefront keep
+ * one child like unbudgeted ones.  Off by default: measured, the frontier such a launch leaves
+ * costs the rebalancing rounds more than the kept children save.
  * "work_first" (0|1, default 1): a wavefront of the persistent kernel that splits a node goes on
  * with one of the two children itself and queues the other (EHM_NO_WORKFIRST=1 disables);
  * "timing" (0|1, default 0): multi-commutation runs record an event pair and a counter snapshot
