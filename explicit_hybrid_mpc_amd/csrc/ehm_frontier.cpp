@@ -26,6 +26,8 @@
 #include <new>
 #include <stdexcept>
 #include <string>
+#include <atomic>
+#include <thread>
 #include <unordered_map>
 #include <vector>
 
@@ -242,6 +244,7 @@ struct Table {
     int64_t stamp = 0, evicted = 0;
     Condenser cond;
     std::vector<int64_t> counts;               // [5][N + 1]
+    std::vector<double> bG, bw, bS;            // staging of the blocks that go up
     int64_t lp = 0, loaded = 0;
 };
 
@@ -257,7 +260,9 @@ struct DeviceSolver {
     std::vector<int> tab_of_len;
     int64_t total_lp() const { int64_t a = 0; for (const Table& T : tab) a += T.lp; return a; }
     int64_t total_loaded() const { int64_t a = 0; for (const Table& T : tab) a += T.loaded; return a; }
-    int64_t stalled = 0, slivers = 0, stalled_relax = 0, launches = 0, accepted_inaccurate = 0;
+    // (the tables of one solver call run on threads of their own: shared tallies are atomic)
+    std::atomic<int64_t> stalled{0}, slivers{0}, stalled_relax{0}, launches{0}, accepted_inaccurate{0};
+    bool parallel_tables = true;
     // sequences.decisive_inaccurate: status word 1 | (decade << 8) of a stalled solve (ehm_dev.h)
     static bool decisive(int32_t status, double value) {
         const int dec = (status >> 8) & 0xff;
@@ -265,8 +270,6 @@ struct DeviceSolver {
         const double err = 100.0 * std::pow(10.0, dec - 10) * (1.0 + std::fabs(value));
         return std::fabs(value) > err;
     }
-    // scratch
-    std::vector<double> bG, bw, bS;
 
     int len_of(uint64_t code) const {
         int k = 0;
@@ -323,20 +326,20 @@ struct DeviceSolver {
                 while (g0 + cnt < order.size() && cnt < group &&
                        place[order[g0 + cnt]] == place[order[g0]] + (int)cnt)
                     ++cnt;
-                bG.resize(cnt * nG); bw.resize(cnt * T.m); bS.resize(cnt * nS);
+                T.bG.resize(cnt * nG); T.bw.resize(cnt * T.m); T.bS.resize(cnt * nS);
                 for (size_t q = 0; q < cnt; ++q) {
                     const uint64_t c = missing[order[g0 + q]];
                     const int len = len_of(c);
                     digits(c, pre);
-                    T.cond.block(pre, len, &bG[q * nG], &bw[q * T.m], &bS[q * nS]);
+                    T.cond.block(pre, len, &T.bG[q * nG], &T.bw[q * T.m], &T.bS[q * nS]);
                     const int sl = place[order[g0 + q]];
                     T.slot_of[c] = sl;
                     T.slot_len[(size_t)sl] = len;
                     T.slot_code[(size_t)sl] = c;
                     T.slot_stamp[(size_t)sl] = T.stamp;
                 }
-                chk_dev(ehm_problem_update_blocks(T.P, place[order[g0]], (int)cnt, bG.data(), bw.data(),
-                                                  bS.data()), "ehm_problem_update_blocks");
+                chk_dev(ehm_problem_update_blocks(T.P, place[order[g0]], (int)cnt, T.bG.data(), T.bw.data(),
+                                                  T.bS.data()), "ehm_problem_update_blocks");
                 g0 += cnt;
             }
             T.loaded += (int64_t)missing.size();
@@ -374,6 +377,33 @@ struct DeviceSolver {
             if (!part.empty()) f(part, slot);
         }
     }
+    // body(t) does table t's share of one solver call.  Every table is a problem handle with a
+    // stream of its own: the tables that have work run on threads of their own, so their kernels
+    // share the device and their host sides (pair gathers, block condensation, copies) the cores.
+    template <class Body>
+    void per_table(const std::vector<std::vector<int64_t>>& sel, Body body) {
+        std::vector<size_t> busy;
+        for (size_t t = 0; t < sel.size(); ++t)
+            if (!sel[t].empty()) busy.push_back(t);
+        if (busy.size() <= 1 || !parallel_tables) {
+            for (size_t t : busy) body(t);
+            return;
+        }
+        std::vector<Fail> errs(busy.size(), Fail{0, ""});
+        std::vector<std::thread> pool;
+        for (size_t i = 1; i < busy.size(); ++i)
+            pool.emplace_back([&, i] {
+                try { body(busy[i]); }
+                catch (const Fail& e) { errs[i] = e; }
+                catch (const std::exception& e) { errs[i] = Fail{EHM_E_CAPACITY, e.what()}; }
+            });
+        try { body(busy[0]); }
+        catch (const Fail& e) { errs[0] = e; }
+        catch (const std::exception& e) { errs[0] = Fail{EHM_E_CAPACITY, e.what()}; }
+        for (std::thread& th : pool) th.join();
+        for (const Fail& e : errs)
+            if (e.code) throw e;
+    }
     void split_tables(int64_t n_pairs, const uint64_t* code, std::vector<std::vector<int64_t>>& sel) const {
         sel.assign(tab.size(), std::vector<int64_t>());
         for (int64_t k = 0; k < n_pairs; ++k) sel[(size_t)tab_of_len[(size_t)len_of(code[k])]].push_back(k);
@@ -402,12 +432,11 @@ struct DeviceSolver {
         if (u0) std::fill(u0, u0 + (size_t)n_pairs * n_u, 0.0);
         std::vector<std::vector<int64_t>> sel;
         split_tables(n_pairs, code, sel);
-        std::vector<double> th, tau, uu, Jk;
-        std::vector<int32_t> st, slot2;
-        std::vector<uint8_t> ok;
-        for (size_t t = 0; t < tab.size(); ++t) {
-            if (sel[t].empty()) continue;
+        per_table(sel, [&](size_t t) {
             Table& T = tab[t];
+            std::vector<double> th, tau, uu, Jk;
+            std::vector<int32_t> st, slot2;
+            std::vector<uint8_t> ok;
             chunks(T, code, sel[t], [&](const std::vector<int64_t>& part, const std::vector<int32_t>& slot) {
                 const size_t cnt = part.size();
                 th.resize(cnt * p);
@@ -452,7 +481,7 @@ struct DeviceSolver {
                     if (u0) std::memcpy(u0 + (size_t)k * n_u, &uu[g * n_u], 8 * (size_t)n_u);
                 }
             });
-        }
+        });
     }
 
     // sequences.PrefixTable.slack_by_prefix_index (+ _settle_stalled)
@@ -463,12 +492,11 @@ struct DeviceSolver {
         std::vector<std::vector<int64_t>> sel;
         split_tables(n_pairs, code, sel);
         const size_t sx = (size_t)nv * p;
-        std::vector<double> Rb, Vb, tau, al, tk;
-        std::vector<int32_t> st, sl;
-        std::vector<uint8_t> ok, v;
-        for (size_t tt = 0; tt < tab.size(); ++tt) {
-            if (sel[tt].empty()) continue;
+        per_table(sel, [&](size_t tt) {
             Table& T = tab[tt];
+            std::vector<double> Rb, Vb, tau, al, tk;
+            std::vector<int32_t> st, sl;
+            std::vector<uint8_t> ok, v;
             chunks(T, code, sel[tt], [&](const std::vector<int64_t>& part, const std::vector<int32_t>& slot) {
                 const size_t cnt = part.size();
                 ok.assign(cnt, 1);
@@ -554,7 +582,7 @@ struct DeviceSolver {
                         std::memcpy(alpha_out + (size_t)part[good[g]] * nv, &al[g * nv], 8 * (size_t)nv);
                 }
             });
-        }
+        });
     }
 
     // sequences.PrefixTable.solve_min for pairs KNOWN to be feasible on their simplex (the node's
@@ -565,12 +593,11 @@ struct DeviceSolver {
         std::vector<std::vector<int64_t>> sel;
         split_tables(n_pairs, code, sel);
         const size_t sx = (size_t)nv * p;
-        std::vector<double> Rb, tau, al, Jk;
-        std::vector<int32_t> st, sl;
-        std::vector<uint8_t> ok, v;
-        for (size_t tt = 0; tt < tab.size(); ++tt) {
-            if (sel[tt].empty()) continue;
+        per_table(sel, [&](size_t tt) {
             Table& T = tab[tt];
+            std::vector<double> Rb, tau, al, Jk;
+            std::vector<int32_t> st, sl;
+            std::vector<uint8_t> ok, v;
             chunks(T, code, sel[tt], [&](const std::vector<int64_t>& part, const std::vector<int32_t>& slot) {
                 const size_t cnt = part.size();
                 ok.assign(cnt, 1);
@@ -634,7 +661,7 @@ struct DeviceSolver {
                 }
                 for (size_t g = 0; g < good.size(); ++g) J_out[part[good[g]]] = Jk[g];
             });
-        }
+        });
     }
 };
 
@@ -1735,6 +1762,7 @@ int ehm_frontier_create(const ehm_pwa_law* law, int32_t n_tables, const int32_t*
         return fail(EHM_E_INVALID, "ehm_frontier_create: horizons must ascend to N, slots >= 0");
     }
     D->device = device; D->short_len = n_tables > 1 ? horizons[0] : 0;
+    if (const char* e = getenv("EHM_FRONTIER_THREADS")) D->parallel_tables = atoi(e) != 0;
     D->p = D->law.n_x; D->nv = D->p + 1; D->n_u = D->law.n_u; D->N = N;
     D->base = (uint64_t)D->law.n_modes + 1;
     D->tab.resize((size_t)n_tables);
