@@ -2924,6 +2924,12 @@ int ehm_partition_take(ehm_tree* T, int64_t count, int32_t* node_ids, double* re
     ehm_problem* P = T->prob;
     auto& R = T->run;
     if (T->hy) {
+        // the hashed draws of option "any_admissible" read the path code of a node, and the
+        // hand-over does not carry it: a moved subtree would draw as if it started at code 0 and
+        // the run would no longer repeat the single-GPU one (nor the CPU oracle's rule 'hash')
+        if (P->any_admissible && count > 0)
+            return fail(EHM_E_INVALID, "nodes cannot be handed over under option any_admissible "
+                                       "(its draws are reproducible only without rebalancing)");
         HIP_TRY(hipSetDevice(P->device), EHM_E_HIP);
         return hy_take(T, count, node_ids, records, meta);
     }
@@ -2980,6 +2986,9 @@ int ehm_partition_give(ehm_tree* T, int64_t count, const double* records, const 
     ehm_problem* P = T->prob;
     auto& R = T->run;
     if (T->hy) {
+        if (P->any_admissible && count > 0)
+            return fail(EHM_E_INVALID, "nodes cannot be handed over under option any_admissible "
+                                       "(its draws are reproducible only without rebalancing)");
         HIP_TRY(hipSetDevice(P->device), EHM_E_HIP);
         return hy_give(T, count, records, meta, first_id);
     }

@@ -268,6 +268,17 @@ class NativeFrontier:
 def graft(flat, mpc, targets):
     """Writes the flat tree of ``NativeFrontier.export`` into ``targets`` (one ``Tree`` per root,
     grown in place).  Returns the list of (Tree node, flags) of the cells handed back open."""
+    import gc
+    was_on = gc.isenabled()
+    gc.disable()            # (millions of small objects, nothing cyclic among them)
+    try:
+        return _graft(flat, mpc, targets)
+    finally:
+        if was_on:
+            gc.enable()
+
+
+def _graft(flat, mpc, targets):
     n = flat['n_nodes']
     nodes = [None] * n
     for r, t in enumerate(targets):

@@ -47,18 +47,62 @@ def node_data_from_flat(flat, k):
 def graft_flat(flat, targets):
     """
     Write the subtree below flat root r into ``targets[r]`` (existing ``Tree`` nodes, grown
-    in place), iteratively.
+    in place), iteratively.  One bulk copy of every array (the export's arrays are page-locked
+    and recycled: the tree must not hold on to them), then the nodes are ROW VIEWS of those copies
+    and their payloads are filled through ``__dict__`` with the cyclic collector paused.  What is
+    left is the interpreter allocating ~8 objects per node (about 4 microseconds: 1.6 M nodes take
+    seconds either way; the flat arrays are what ``explicit.ExplicitMPC`` and ``tree_io`` read, the
+    object tree is for consumers written against lib/tree.py).
     """
-    nodes = [None] * flat.n_nodes
+    import gc
+    import time
+    n = flat.n_nodes
+    # (millions of small objects: the cyclic collector would rescan the growing tree again and
+    # again -- it is paused for the loop, there is nothing cyclic to find in it)
+    was_on = gc.isenabled()
+    gc.disable()
+    try:
+        return _graft_flat(flat, targets, n, time.time())
+    finally:
+        if was_on:
+            gc.enable()
+
+
+def _graft_flat(flat, targets, n, stamp):
+    V = list(np.array(flat.vertices))          # list of (p+1, p) views into ONE private copy
+    C = list(np.array(flat.vertex_costs))
+    U = list(np.array(flat.vertex_inputs))
+    left, right = flat.left.tolist(), flat.right.tolist()
+    flags = flat.flags.tolist()
+    didx = flat.delta_idx.tolist()
+    # one array per distinct commutation, shared by the nodes that hold it -- as the reference's
+    # children share their parent's delta_star object (lib/worker.py:356-365)
+    deltas = [np.array(d) for d in flat.deltas]
+    new_data, new_tree = NodeData.__new__, Tree.__new__
+    nodes = [None] * n
     for r, t in enumerate(targets):
         nodes[r] = t
-    for k in range(flat.n_nodes):                  # parents precede children
+    for k in range(n):                          # parents precede children
         node = nodes[k]
-        node.data = node_data_from_flat(flat, k)
-        if flat.left[k] >= 0:
-            node.grow(None, None)
-            nodes[flat.left[k]] = node.left
-            nodes[flat.right[k]] = node.right
+        f = flags[k]
+        data = new_data(NodeData)
+        if f & 2:                               # attribute-absence semantics of lib/tree.py:34-39
+            data.__dict__ = {'timestamp': stamp, 'vertices': V[k],
+                             'is_epsilon_suboptimal': bool(f & 1),
+                             'commutation': deltas[didx[k]], 'vertex_costs': C[k],
+                             'vertex_inputs': U[k]}
+        else:
+            data.__dict__ = {'timestamp': stamp, 'vertices': V[k],
+                             'is_epsilon_suboptimal': bool(f & 1)}
+        node.data = data
+        lk = left[k]
+        if lk >= 0:
+            a, b = new_tree(Tree), new_tree(Tree)
+            a.__dict__ = {'data': None, 'top': False}
+            b.__dict__ = {'data': None, 'top': False}
+            node.left, node.right = a, b
+            nodes[lk] = a
+            nodes[right[k]] = b
     return targets
 
 

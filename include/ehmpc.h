@@ -153,7 +153,9 @@ int ehm_problem_set_solver(ehm_problem* prob, int generation);
  * the CPU oracle (oracle/oracle_cpu.py, rule 'hash') takes the same draws; values 2^30 + m are
  * deterministic extremes instead of draws (m bit 0: V_R returns the LAST commutation feasible at
  * every vertex, bit 1: bar_D the admissible commutation with the SMALLEST slack): the envelope of
- * what the choice can do to a tree (tools/cwh_jobs.py);
+ * what the choice can do to a tree (tools/cwh_jobs.py).  Not to be set while a run is active, and
+ * ehm_partition_take / _give refuse to move nodes of a multi-commutation run under it (the
+ * hand-over does not carry the path codes the draws read);
  * "budget_keep" (0|1, default 0): budgeted launches (ehm_partition_advance) let a wavefront keep
  * one child like unbudgeted ones.  Off by default: measured, the frontier such a launch leaves
  * costs the rebalancing rounds more than the kept children save.
