@@ -168,3 +168,60 @@ def test_depth_limit_leaves_open_cells_flagged():
     closed = (flat['flags'] & frontier.FR_CLOSED) != 0
     assert np.all(closed[leaves] | limited[leaves]) and st['regions'] == int(closed.sum())
     nat.close()
+
+
+def test_peek_any_is_the_early_exit_form_of_peek():
+    """``ehm_search_peek_any`` (known at a vertex => known on the cell; first vertex nothing is
+    held about) against the per-pair ``ehm_search_peek`` it replaces in the native driver,
+    including the midpoint inference (feasible at both ends of a bisected edge)."""
+    lib = _capi.load()
+    p, n_modes, N = 3, 2, 4
+    h = ctypes.c_void_p()
+    _capi.check_search(lib.ehm_search_create(p, n_modes, N, ctypes.byref(h)))
+    rng = np.random.default_rng(3)
+    pts = rng.standard_normal((40, p))
+    pts[30:] = 0.5 * (pts[0:10] + pts[10:20])           # midpoints of (k, k + 10)
+    ids = np.empty(40, dtype=np.int64)
+    _capi.check_search(lib.ehm_search_point_ids(h, 40, _capi.ptr(pts), _capi.ptr(ids)))
+    mid, ea, eb = ids[30:].copy(), ids[0:10].copy(), ids[10:20].copy()   # (kept alive: raw pointers)
+    _capi.check_search(lib.ehm_search_register_midpoints(h, 10, _capi.ptr(mid), _capi.ptr(ea),
+                                                         _capi.ptr(eb)))
+    codes = np.array([1, 2, 1 + 3 * 1, 2 + 3 * 2, 1 + 3 * 2 + 9 * 1], dtype=np.uint64)
+    # verdicts for a random subset of (prefix, point) pairs among the first 30 points
+    n_sets = 200
+    qc = rng.choice(codes, n_sets)
+    sets = [rng.choice(30, size=rng.integers(1, 5), replace=False) for _ in range(n_sets)]
+    begin = np.zeros(n_sets + 1, dtype=np.int64)
+    np.cumsum([len(s) for s in sets], out=begin[1:])
+    flat = np.concatenate(sets).astype(np.int64)
+    flags = np.ones(n_sets, dtype=np.uint8)
+    n_ask, n_pre = ctypes.c_int64(), ctypes.c_int64()
+    qp = ids[flat].copy()
+    _capi.check_search(lib.ehm_search_query(h, n_sets, _capi.ptr(qc), _capi.ptr(begin),
+                                            _capi.ptr(qp), _capi.ptr(flags),
+                                            ctypes.byref(n_ask), ctypes.byref(n_pre)))
+    ok = (rng.random(n_ask.value) < 0.6).astype(np.uint8)
+    _capi.check_search(lib.ehm_search_answer(h, _capi.ptr(ok), _capi.ptr(flags)))
+    # questions over sets that mix known, unknown and midpoint points
+    m = 300
+    c2 = rng.choice(codes, m)
+    sets2 = [rng.choice(40, size=4, replace=False) for _ in range(m)]
+    b2 = np.arange(0, 4 * m + 1, 4, dtype=np.int64)
+    f2 = ids[np.concatenate(sets2)].copy()
+    ver = np.empty(4 * m, dtype=np.int8)
+    # (peek first on a COPY of the questions' order: both calls may store inferred midpoints,
+    # which changes nothing either of them reports)
+    known = np.empty(m, dtype=np.uint8)
+    first = np.empty(m, dtype=np.int32)
+    _capi.check_search(lib.ehm_search_peek_any(h, m, _capi.ptr(c2), _capi.ptr(b2), _capi.ptr(f2),
+                                               _capi.ptr(known), _capi.ptr(first)))
+    rep = np.repeat(c2, 4)
+    _capi.check_search(lib.ehm_search_peek(h, 4 * m, _capi.ptr(rep), _capi.ptr(f2), _capi.ptr(ver)))
+    ver = ver.reshape(m, 4)
+    assert np.array_equal(known.astype(bool), (ver == 1).any(axis=1))
+    open_q = ~known.astype(bool)
+    has_unknown = (ver == -1).any(axis=1)
+    assert np.array_equal(first[open_q & has_unknown], (ver == -1).argmax(axis=1)[open_q & has_unknown])
+    assert np.all(first[open_q & ~has_unknown] == -1)
+    assert known.any() and open_q.any() and (ver[:, :] == 1).any()
+    lib.ehm_search_destroy(h)
