@@ -226,9 +226,24 @@ def _check_one(job):
                 if not swapped:
                     fail('first feasible sequence by the MILP %s, the product holds %s' %
                          (first, seq))
+        # bar_E in decision form: max t.  HiGHS' branch-and-bound on a big-M model is itself a
+        # numerical method (one of the first 160 nodes came back "optimal" at -0.0057 with M = 50
+        # and at +0.0016 with M = 10 and M = 200): every run returns a FEASIBLE point of the
+        # reference's problem, so the largest t over several M is a certified lower bound of the
+        # maximum -- t >= 0 from any run proves the cell open; a closed leaf must come out
+        # negative for every M tried
         out['milps'] += 1
         t, s_e = milp_check.bar_e_milp(mpc, R, V, eps_a, eps_r)
+        tried = {50.: float(t)}
+        more = (10.,) if kind == 1 else ((10., 200.) if (kind == 2 and not t >= 0.) else ())
+        for big_m in more:
+            out['milps'] += 1
+            t2, s2 = milp_check.bar_e_milp(mpc, R, V, eps_a, eps_r, big_m=big_m)
+            tried[big_m] = float(t2)
+            if t2 > t:
+                t, s_e = t2, s2
         out['t_max'] = float(t)
+        out['t_max_by_big_m'] = tried
         near = abs(t) < ROUTE_TOL * (1. + float(np.max(np.abs(V))))
         if kind == 1 and not t < 0.:
             if near:
