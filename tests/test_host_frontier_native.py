@@ -225,3 +225,33 @@ def test_peek_any_is_the_early_exit_form_of_peek():
     assert np.all(first[open_q & ~has_unknown] == -1)
     assert known.any() and open_q.any() and (ver[:, :] == 1).any()
     lib.ehm_search_destroy(h)
+
+
+def test_native_driver_on_a_cell_across_a_mode_boundary_32_sequences():
+    """n_x = 4, n_u = 2, N = 5, two modes (32 sequences), a cell across the boundary x_1 = 0 at
+    tolerances that make lcss do most of the work (342 bar_E and 156 bar_D searches, inherited
+    bounds and best-slack sequences at every level): the native driver grows the tree of
+    ``bnb_frontier.grow_frontier`` with the same visits and -- every search step asking for the
+    same problems -- the same number of LPs."""
+    mpc = helpers.make_instance('pwa', 0)
+    half = examples.theta_box(mpc)
+    eps_a, eps_r = helpers.eps_a_rule(mpc, 0.03), 0.02
+    rng = np.random.default_rng(4)
+    centre = np.array([0.0, 0.3, -0.2, 0.1]) * half
+    R = np.clip(centre + 0.8 * half * rng.uniform(-1, 1, (5, 4)), -half, half)
+    ref_table = prefix_bb.CpuPrefixTable(mpc, eps_a, eps_r)
+    ref_orc = bnb.PrefixOracle(mpc, eps_a, eps_r, table=ref_table)
+    ref = Tree(NodeData(vertices=R.copy()))
+    s_ref = bnb_frontier.grow_frontier(ref_orc, ref, 'ecc', handoff=False,
+                                       split_batch=_host_split_batch, round_cap=16)
+    table = prefix_bb.CpuPrefixTable(mpc, eps_a, eps_r)
+    nat = frontier.NativeFrontier(mpc, eps_a, eps_r,
+                                  solvers=frontier.TableSolvers(table, _host_split_batch))
+    got = Tree(NodeData(vertices=R.copy()))
+    st = frontier.grow_cells(nat, got, round_cap=16)
+    assert _same_trees(ref, got) > 300
+    assert st['slow_path_cells'] == 0 and st['visits'] == s_ref['host_visits']
+    assert st['calls_bar_d'] == ref_orc.calls['bar_D'] > 100
+    assert st['regions'] == s_ref['regions']
+    assert table.lp_solves == ref_table.lp_solves
+    nat.close()
