@@ -62,7 +62,7 @@ typedef struct ehm_pwa_law {
     int32_t n_r;  const double* R;      /* [n_r][n_u] */
 } ehm_pwa_law;
 
-/* The three batched solvers the driver stands on, over (prefix code, point / simplex) PAIRS
+/* The batched solvers the driver stands on, over (prefix code, point / simplex) PAIRS
  * (prefix codes: ehm_search.h).  The device form is built by ehm_frontier_create; a caller may
  * bring its own (tests: the CPU statement of the table, oracle/prefix_bb.py). */
 typedef struct ehm_pair_solvers {

@@ -264,10 +264,32 @@ def _check_one(job):
             allowed = {seq} | ({s_d} if s_d is not None and td >= 0. else set())
             for k in range(2):
                 ks = tuple(int(i) for i in kids_seq[k])
-                if ks not in allowed:
-                    # a tie within the canonical tolerance: another sequence of the same slack
-                    fail('child %d holds %s; the node %s, bar_D\'s MILP optimum %s (t = %g)' %
-                         (k, ks, seq, s_d, td))
+                if ks in allowed:
+                    continue
+                # bar_D's optimum is often attained by several sequences (modes that are
+                # interchangeable in the overlap band, or at the last step): the canonical rule
+                # takes the first in enumeration order, the MILP returns any.  The child's
+                # sequence is accepted where it is one of them -- feasible at every vertex and its
+                # own slack (a fixed-sequence LP, oracle/prefix_bb.py) within the canonical tie
+                # tolerance of the MILP's maximum
+                from oracle import prefix_bb
+                t_child = prefix_bb.prefix_slack(mpc, ks, R, V, eps_a, eps_r)
+                out['lps'] += 1
+                mk = FixedCommutationModel(mpc, ks)
+                feas = True
+                for v in R:
+                    lp = mk.lp_point(v)
+                    rk = linprog(lp['c'], A_ub=lp['A_ub'], b_ub=lp['b_ub'], A_eq=lp['A_eq'],
+                                 b_eq=lp['b_eq'], bounds=(None, None), method='highs')
+                    out['lps'] += 1
+                    feas = feas and rk.status == 0
+                tie = feas and t_child >= td - 1e-6 * (1. + abs(td)) and t_child >= 0.
+                if tie:
+                    out['notes'].append('child %d: %s ties with the MILP optimum %s (t %.9g / %.9g)'
+                                        % (k, ks, s_d, t_child, td))
+                    break               # (both children hold the same commutation)
+                fail('child %d holds %s (t = %g, feasible at every vertex: %s); the node %s, '
+                     'bar_D\'s MILP optimum %s (t = %g)' % (k, ks, t_child, feas, seq, s_d, td))
     if kind == 0:
         S1, S2, _ = geometry.split_along_longest_edge(R)
         if not (np.array_equal(S1, kids_R[0]) and np.array_equal(S2, kids_R[1])):

@@ -11,10 +11,12 @@ O=$R/gpurun_out/round
 mkdir -p $O
 python $R/bench.py > $O/bench_default.json 2> $O/bench_default.err
 tail -1 $O/bench_default.err
-BENCH_ARGS="" bash $R/tools/profile.sh r4_bench
-BENCH_ARGS="--workload config4" bash $R/tools/profile.sh r4_wide
-BENCH_ARGS="--workload config3" bash $R/tools/profile.sh r4_config3
-BENCH_ARGS="--workload config2q" bash $R/tools/profile.sh r4_quad
+RND=${RND:-r5}
+BENCH_ARGS="" bash $R/tools/profile.sh ${RND}_bench
+BENCH_ARGS="--workload config4" bash $R/tools/profile.sh ${RND}_wide
+BENCH_ARGS="--workload config3" bash $R/tools/profile.sh ${RND}_config3
+BENCH_ARGS="--workload config2q" bash $R/tools/profile.sh ${RND}_quad
+BENCH_ARGS="--workload config5" bash $R/tools/profile.sh ${RND}_config5
 cd $R
 timeout 200 python tools/shard_balance.py deal > $O/shard_balance_deal_1p6M_nodes.txt 2>&1
 tail -4 $O/shard_balance_deal_1p6M_nodes.txt
