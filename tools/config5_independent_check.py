@@ -283,6 +283,11 @@ def _check_one(job):
                                  b_eq=lp['b_eq'], bounds=(None, None), method='highs')
                     out['lps'] += 1
                     feas = feas and rk.status == 0
+                # (the MILP's objective carries its feasibility tolerance -- 4.6e-6 at one of the
+                # first 240 nodes --: its SEQUENCE is re-priced by the same fixed-sequence LP)
+                td_lp = prefix_bb.prefix_slack(mpc, s_d, R, V, eps_a, eps_r) if s_d else td
+                out['lps'] += 1
+                td = min(td, td_lp)
                 tie = feas and t_child >= td - 1e-6 * (1. + abs(td)) and t_child >= 0.
                 if tie:
                     out['notes'].append('child %d: %s ties with the MILP optimum %s (t %.9g / %.9g)'
