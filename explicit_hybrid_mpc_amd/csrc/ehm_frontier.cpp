@@ -865,6 +865,7 @@ struct ehm_frontier {
     void bisect(std::vector<Split>& todo);
     void bar_d(const std::vector<int32_t>& O, std::vector<Learned>& learned, int launch_target,
                std::vector<Split>& to_split);
+    void p_theta(int64_t n, const double* theta, double* J, double* u0, int32_t* sequence);
     void ecc_round(const std::vector<int32_t>& E, std::vector<Split>& to_split);
     void lcss_round(const std::vector<int32_t>& Lc, int launch_target, std::vector<Split>& to_split);
     void run(const ehm_frontier_opts& o);
@@ -1203,6 +1204,137 @@ constexpr double TIE_TOL = 1e-6;               // sequences.TIE_TOL
 constexpr double PLATEAU = 1e-7;               // bnb.PLATEAU
 inline double rel(double x) { return 1.0 + std::fabs(x); }
 }  // namespace
+
+// bnb_frontier.p_theta_many (lib/oracle.py:104-139 as a search): P_theta at n parameters in
+// lockstep.  Phase one: best-first on the relaxations' optimal costs (a prefix's cost is a lower
+// bound of each completion's) for the optimal VALUE; phase two: the first sequence, in enumeration
+// order, within the tie tolerance of it -- a walk over prefixes whose children phase one has
+// mostly solved already (their values are kept per parameter: without ties the walk needs no
+// problem at all).
+void ehm_frontier::p_theta(int64_t n, const double* theta, double* J_out, double* u_out,
+                           int32_t* seq_out) {
+    struct Search {
+        int phase = 1;
+        PrefixHeap heap;                        // keyed by -J: the cheapest relaxation first
+        double best = INF, limit = INF;
+        std::vector<HeapItem> stack;
+        std::unordered_map<uint64_t, std::pair<double, int64_t>> seen;   // code -> (J, index of u0)
+        bool done = false;
+    };
+    std::vector<Search> sr((size_t)n);
+    std::vector<double> upool;                  // first inputs of every solved (prefix, parameter)
+    for (int64_t j = 0; j < n; ++j) {
+        sr[(size_t)j].heap.base = base;
+        sr[(size_t)j].heap.push(HeapItem{-0.0, 0, 0});
+        J_out[j] = INF;
+        if (u_out) std::fill(u_out + (size_t)j * n_u, u_out + (size_t)(j + 1) * n_u, NAN);
+        if (seq_out) std::fill(seq_out + (size_t)j * N, seq_out + (size_t)(j + 1) * N, -1);
+    }
+    auto cut_of = [](const Search& q) {
+        return std::isfinite(q.best) ? q.best - PLATEAU * rel(q.best) : INF;
+    };
+    std::vector<int64_t> active((size_t)n);
+    for (int64_t j = 0; j < n; ++j) active[(size_t)j] = j;
+    std::vector<uint64_t> ask_code;
+    std::vector<double> ask_th, Ja, ua;
+    std::vector<std::pair<int64_t, uint64_t>> ask_at;
+    while (!active.empty()) {
+        ask_code.clear(); ask_th.clear(); ask_at.clear();
+        std::vector<int64_t> still;
+        std::vector<std::vector<HeapItem>> kids_of(active.size());
+        for (size_t a = 0; a < active.size(); ++a) {
+            const int64_t j = active[a];
+            Search& q = sr[(size_t)j];
+            std::vector<HeapItem>& kids = kids_of[a];
+            if (q.phase == 1) {
+                const double cut = cut_of(q);
+                int taken = 0;
+                while (!q.heap.h.empty() && taken < BATCH && -q.heap.h.front().t < cut) {
+                    const HeapItem b = q.heap.pop();
+                    ++taken;
+                    ++st.prefixes_expanded;
+                    for (int i = 0; i < n_modes; ++i)
+                        kids.push_back(HeapItem{0.0, b.code + (uint64_t)(i + 1) * pw[(size_t)b.len], b.len + 1});
+                }
+            } else {
+                // walk as far as the known values carry it
+                for (;;) {
+                    if (q.stack.empty())
+                        raise(EHM_E_NUMERIC, "P_theta: the optimum found in phase one was not reproduced");
+                    const HeapItem top = q.stack.back();
+                    std::vector<HeapItem> ch;
+                    bool missing = false;
+                    for (int i = 0; i < n_modes; ++i) {
+                        const uint64_t c = top.code + (uint64_t)(i + 1) * pw[(size_t)top.len];
+                        ch.push_back(HeapItem{0.0, c, top.len + 1});
+                        if (!q.seen.count(c)) { missing = true; kids.push_back(ch.back()); }
+                    }
+                    if (missing) break;
+                    q.stack.pop_back();
+                    ++st.prefixes_expanded;
+                    std::vector<HeapItem> good;
+                    for (const HeapItem& c : ch)
+                        if (q.seen[c.code].first <= q.limit) good.push_back(c);
+                    if (!good.empty() && good[0].len == N) {
+                        const auto& hit = q.seen[good[0].code];
+                        J_out[j] = hit.first;
+                        if (u_out) std::memcpy(u_out + (size_t)j * n_u, &upool[(size_t)hit.second * n_u], 8 * (size_t)n_u);
+                        if (seq_out) {
+                            uint64_t c = good[0].code;
+                            for (int i = 0; i < N; ++i) { seq_out[(size_t)j * N + i] = (int32_t)(c % base) - 1; c /= base; }
+                        }
+                        q.done = true;
+                        kids.clear();
+                        break;
+                    }
+                    for (size_t g = good.size(); g-- > 0;) q.stack.push_back(good[g]);
+                }
+                if (q.done) continue;
+            }
+            still.push_back(j);
+            for (const HeapItem& k : kids) {
+                ask_at.emplace_back(j, k.code);
+                ask_code.push_back(k.code);
+                ask_th.insert(ask_th.end(), theta + (size_t)j * p, theta + (size_t)(j + 1) * p);
+            }
+        }
+        // (kids_of is indexed like `active`; keep the pairing while the answers come in)
+        std::vector<int64_t> act_before = active;
+        active.swap(still);
+        if (active.empty()) break;
+        Ja.resize(ask_code.size()); ua.resize(ask_code.size() * n_u);
+        if (!ask_code.empty())
+            solver_points((int64_t)ask_code.size(), ask_code.data(), ask_th.data(), 0, 0, Ja.data(), ua.data());
+        for (size_t a = 0; a < ask_code.size(); ++a) {
+            Search& q = sr[(size_t)ask_at[a].first];
+            const int64_t ui = (int64_t)(upool.size() / n_u);
+            upool.insert(upool.end(), &ua[a * n_u], &ua[a * n_u] + n_u);
+            q.seen[ask_at[a].second] = std::make_pair(Ja[a], ui);
+        }
+        std::vector<int64_t> next;
+        for (size_t a = 0; a < act_before.size(); ++a) {
+            const int64_t j = act_before[a];
+            Search& q = sr[(size_t)j];
+            if (q.done) continue;
+            if (q.phase == 1) {
+                for (const HeapItem& k : kids_of[a]) {
+                    const double jq = q.seen[k.code].first;
+                    if (!std::isfinite(jq)) continue;
+                    if (k.len == N) q.best = std::min(q.best, jq);
+                    else q.heap.push(HeapItem{-jq, k.code, k.len});
+                }
+                if (!(!q.heap.h.empty() && -q.heap.h.front().t < cut_of(q))) {
+                    if (!std::isfinite(q.best)) { q.done = true; continue; }     // infeasible parameter
+                    q.phase = 2;
+                    q.limit = q.best + TIE_TOL * rel(q.best);
+                    q.stack.assign(1, HeapItem{0.0, 0, 0});
+                }
+            }
+            next.push_back(j);
+        }
+        active.swap(next);
+    }
+}
 
 // bnb_frontier.bar_d_many (lib/oracle.py:311-414 as a search): for every open cell the commutation
 // with the LARGEST slack among those feasible at every vertex with t* >= 0 (ties: first in
@@ -1894,6 +2026,19 @@ int ehm_frontier_run(ehm_frontier* f, const ehm_frontier_opts* opts, ehm_frontie
         return fail(EHM_E_CAPACITY, "ehm_frontier_run: out of memory");
     }
     if (stats) *stats = f->st;
+    return EHM_OK;
+}
+
+int ehm_frontier_p_theta(ehm_frontier* f, int64_t n, const double* theta, double* J, double* u0,
+                         int32_t* sequence) {
+    if (!f || n < 0 || (n && (!theta || !J))) return fail(EHM_E_INVALID, "ehm_frontier_p_theta: bad argument");
+    try {
+        f->p_theta(n, theta, J, u0, sequence);
+    } catch (const Fail& e) {
+        return fail(e.code, "%s", e.msg.c_str());
+    } catch (const std::bad_alloc&) {
+        return fail(EHM_E_CAPACITY, "ehm_frontier_p_theta: out of memory");
+    }
     return EHM_OK;
 }
 

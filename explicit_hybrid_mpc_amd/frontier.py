@@ -224,6 +224,18 @@ class NativeFrontier:
         self.last_stats = {k: getattr(st, k) for k, _ in st._fields_}
         return self.last_stats
 
+    def p_theta(self, thetas):
+        """``Oracle.P_theta`` for many parameters (``bnb_frontier.p_theta_many``): list of
+        (u0, delta, J), (None, None, None) where no mode sequence is feasible."""
+        th = np.ascontiguousarray(thetas, dtype=np.float64).reshape(-1, self.mpc.n_x)
+        n = th.shape[0]
+        J = np.empty(n)
+        u0 = np.empty((n, self.mpc.n_u))
+        seq = np.empty((n, self.mpc.N), dtype=np.int32)
+        self._check(self._lib.ehm_frontier_p_theta(self._h, n, ptr(th), ptr(J), ptr(u0), ptr(seq)))
+        return [(u0[k].copy(), self.mpc.sequence_to_delta(tuple(int(i) for i in seq[k])),
+                 float(J[k])) if np.isfinite(J[k]) else (None, None, None) for k in range(n)]
+
     def table_stats(self):
         """ehm_stats of the device tables: list of dicts (horizon, slots, evicted, counters)."""
         out = []

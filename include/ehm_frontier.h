@@ -150,6 +150,14 @@ typedef struct ehm_frontier_stats {
  * pending) until nothing is pending or a limit of `opts` is reached. */
 int ehm_frontier_run(ehm_frontier* f, const ehm_frontier_opts* opts, ehm_frontier_stats* stats);
 
+/* Oracle.P_theta (lib/oracle.py:104-139) at n parameters ([n][p]) in lockstep: J [n] (+inf: no mode
+ * sequence is feasible there), u0 [n][n_u], sequence [n][N] (modes; -1 where infeasible) -- the
+ * canonical answer, the first sequence in enumeration order within the tie tolerance of the
+ * optimum.  What examples.create_oracle's eps_a rule (lib/examples.py:42-46) and a batched
+ * ImplicitMPC (lib/mpc_library.py:659) call.  u0 / sequence may be NULL. */
+int ehm_frontier_p_theta(ehm_frontier* f, int64_t n, const double* theta, double* J, double* u0,
+                         int32_t* sequence);
+
 /* Node flags of the export. */
 #define EHM_FR_CLOSED     1   /* epsilon-suboptimal leaf                                       */
 #define EHM_FR_HAS_RECORD 2   /* holds a commutation, vertex costs and vertex inputs           */

@@ -29,6 +29,16 @@ def test_native_driver_grows_the_tree_of_the_python_driver_on_the_device():
     orc.table.set_eps(eps_a, eps_r)
     roots, _ = ehm_tools.delaunay_roots(V)
     assert len(roots) > 30000                       # Qhull's triangulation of the 8-cube
+    # the eps_a rule (lib/examples.py:42-46: 2^p P_theta searches) on the native driver: the
+    # optima and canonical sequences of bnb_frontier.p_theta_many
+    ref_pt = bnb_frontier.p_theta_many(orc, 0.2 * V)
+    nat0 = frontier.NativeFrontier(mpc, 1., 1., slots=4096)
+    got_pt = nat0.p_theta(0.2 * V)
+    nat0.close()
+    for (u_r, d_r, J_r), (u_g, d_g, J_g) in zip(ref_pt, got_pt):
+        assert d_g is not None and np.array_equal(d_g, d_r)
+        assert abs(J_g - J_r) <= 1e-9 * (1. + abs(J_r)) and np.allclose(u_g, u_r, atol=1e-7)
+    assert abs(max(j for _, _, j in got_pt) - eps_a) <= 1e-9
     R = roots[2]                                    # a small cell: ~1.5 k regions
     ref = Tree(NodeData(vertices=R.copy()))
     s_ref = bnb_frontier.grow_frontier(orc, ref, 'ecc', order='lcss-first', table_backoff=True)

@@ -255,3 +255,35 @@ def test_native_driver_on_a_cell_across_a_mode_boundary_32_sequences():
     assert st['regions'] == s_ref['regions']
     assert table.lp_solves == ref_table.lp_solves
     nat.close()
+
+
+@pytest.mark.parametrize('law', ['pwa_small', 'pwa'])
+def test_native_p_theta_is_p_theta_many(law):
+    """``ehm_frontier_p_theta`` (best-first for the optimal value, lexicographic walk for the
+    first sequence that attains it) against ``bnb_frontier.p_theta_many`` on the same CPU table:
+    the same optimum, the same canonical sequence, the same first input -- also where the
+    parameter is infeasible for every sequence."""
+    mpc = helpers.make_instance(law, 0)
+    half = examples.theta_box(mpc)
+    rng = np.random.default_rng(7)
+    n = 14 if law == 'pwa' else 24
+    thetas = rng.uniform(-1, 1, (n, mpc.n_x)) * half
+    thetas[-1] = 3. * half                                   # outside the feasible set
+    thetas[0] = 0.                                           # ties: every mode is admissible at 0
+    ref_table = prefix_bb.CpuPrefixTable(mpc)
+    ref = bnb_frontier.p_theta_many(bnb.PrefixOracle(mpc, 1., 1., table=ref_table), thetas)
+    table = prefix_bb.CpuPrefixTable(mpc)
+    nat = frontier.NativeFrontier(mpc, 1., 1.,
+                                  solvers=frontier.TableSolvers(table, _host_split_batch))
+    got = nat.p_theta(thetas)
+    nat.close()
+    assert ref[-1] == (None, None, None) and got[-1] == (None, None, None)
+    feasible = 0
+    for (u_r, d_r, J_r), (u_g, d_g, J_g) in zip(ref, got):
+        assert (d_r is None) == (d_g is None)
+        if d_r is None:
+            continue
+        feasible += 1
+        assert J_g == J_r and np.array_equal(d_g, d_r) and np.array_equal(u_g, u_r)
+    assert feasible >= n - 3
+    assert table.lp_solves == ref_table.lp_solves           # the same problems, step for step
