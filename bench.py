@@ -846,12 +846,21 @@ def measure_config5(args, ctx):
     half = examples.theta_box(mpc)
     V = examples.box_vertices(half)
     orc = bnb.PrefixOracle(mpc, 1., 1., slots=8192, device=device_index)
+    # the native driver (include/ehm_frontier.h) owns device tables of its own; the Python oracle
+    # stays for the cells the native driver hands back (failed vertex solves: none so far)
+    native = None
+    if args.driver == 'native':
+        from explicit_hybrid_mpc_amd import frontier
+        native = frontier.NativeFrontier(mpc, 1., 1., slots=16384, device=device_index)
     t_eps = time.perf_counter()
     # eps_a by the reference's rule (lib/examples.py:42-46): 2^p P_theta searches in lockstep
-    eps_a = float(np.max([j for _, _, j in bnb_frontier.p_theta_many(orc, abs_frac * V)]))
+    eps_a = float(np.max([j for _, _, j in (native.p_theta(abs_frac * V) if native else
+                                            bnb_frontier.p_theta_many(orc, abs_frac * V))]))
     t_eps = time.perf_counter() - t_eps
     orc.eps_a, orc.eps_r = eps_a, eps_r
     orc.table.set_eps(eps_a, eps_r)
+    if native:
+        native.set_eps(eps_a, eps_r)
     if args.roots == 'delaunay':
         from explicit_hybrid_mpc_amd import tools as ehm_tools
         root_cells, _ = ehm_tools.delaunay_roots(V)
@@ -871,12 +880,7 @@ def measure_config5(args, ctx):
     hname = lambda tb: 'h%d' % tb.mpc.N
     table_dims = {hname(tb): (tb.gp.can.n, tb.gp.can.m, tb.gp.can.p) for _, tb in parts}
 
-    # the native driver (include/ehm_frontier.h) owns device tables of its own; the Python oracle
-    # above stays for eps_a and for the cells the native driver hands back open
-    native = None
-    if args.driver == 'native':
-        from explicit_hybrid_mpc_amd import frontier
-        native = frontier.NativeFrontier(mpc, eps_a, eps_r, slots=16384, device=device_index)
+    if native:
         for hz in native.horizons:
             if 'h%d' % hz not in table_dims:
                 G_h = frontier.condense_native(mpc, (), hz)[0]
