@@ -48,7 +48,10 @@ K3_RS = (2, 4)
 # the single-width persistent kernel of ehm_k2.hip (quadratic handles, unlisted width pairs) runs
 # the midpoint-first flow, like the ehm_kpm objects
 MIDFIRST = '-DEHM_PERSIST_MIDFIRST=1'
-FLAGS = ['--offload-arch=gfx950', '-O3', '-std=c++17', '-fPIC', '-Wno-unused-result']
+# -fvisibility=hidden: the library exports what include/*.h declare (a visibility pragma there)
+# and nothing else -- not the dispatch tables the objects hand each other (ehm_k2_api_* ...)
+FLAGS = ['--offload-arch=gfx950', '-O3', '-std=c++17', '-fPIC', '-Wno-unused-result',
+         '-fvisibility=hidden']
 # experiments: extra -D flags and an alternative output name, e.g.
 #   EHM_BUILD_FLAGS="-DEHM2_UNROLL=2" EHM_BUILD_TAG=u2 python -m explicit_hybrid_mpc_amd.build
 FLAGS += os.environ.get('EHM_BUILD_FLAGS', '').split()
@@ -123,6 +126,8 @@ def _objects():
                      os.path.join(SRC_DIR, 'ehm_k3.hip'),
                      # the 64-step elimination is unrolled completely (rows live in registers)
                      ['-DEHM3_RS=%d' % rs, '-mllvm', '-pragma-unroll-threshold=200000']))
+    # the LDS-resident wide family (ehm_ipm4.h): one object, both tile counts inside
+    objs.append((os.path.join(OBJ_DIR, 'ehm_k4.o'), os.path.join(SRC_DIR, 'ehm_k4.hip'), []))
     return objs
 
 
@@ -149,7 +154,8 @@ def is_stale():
     if not os.path.exists(os.path.join(SRC_DIR, 'ehm_kp.hip')):
         return True                 # generated (tools/gen_kp.py), not in the repository
     srcs = [os.path.join(SRC_DIR, f)
-            for f in ('ehm_capi.hip', 'ehm_k2.hip', 'ehm_k3.hip', 'ehm_kp.hip', 'ehm_explicit.hip')]
+            for f in ('ehm_capi.hip', 'ehm_k2.hip', 'ehm_k3.hip', 'ehm_k4.hip', 'ehm_kp.hip',
+                      'ehm_explicit.hip')]
     return max([_dep_mtime()] + [os.path.getmtime(s)
                                  for s in srcs + SEARCH_DEPS + FRONTIER_DEPS]) > t
 
@@ -180,7 +186,8 @@ def build(force=False, verbose=False, jobs=None):
     for obj, src, deps in HOST_OBJECTS:
         if force or not os.path.exists(obj) or \
                 os.path.getmtime(obj) < max(os.path.getmtime(d) for d in deps):
-            cmd = [_cxx(), '-O2', '-std=c++17', '-fPIC', '-Wall', '-c', src, '-o', obj]
+            cmd = [_cxx(), '-O2', '-std=c++17', '-fPIC', '-Wall', '-fvisibility=hidden', '-c', src, '-o',
+                   obj]
             if verbose:
                 print(' '.join(cmd))
             subprocess.check_call(cmd)

@@ -29,8 +29,12 @@ EHM_K2_ALL(EHM_K2_DECL)
 // wide instances (ehm_k3.hip compiled per row capacity): LPs with 33..64 columns or > 256 rows
 extern "C" const ehm::K2Api* ehm_k3_api_2();
 extern "C" const ehm::K2Api* ehm_k3_api_4();
+// the LDS-resident wide family (ehm_k4.hip): taken instead of ehm_k3 where the reduced block fits
+extern "C" const ehm::K2Api* ehm_k4_api();
+#define EHM_LDS_BUDGET (160 * 1024 - 256)   // dynamic LDS a workgroup may ask for
 typedef const ehm::K2Api* (*k2_getter)();
-static const k2_getter g_k2_getters[] = {EHM_K2_ALL(EHM_K2_ENTRY) ehm_k3_api_2, ehm_k3_api_4};
+static const k2_getter g_k2_getters[] = {EHM_K2_ALL(EHM_K2_ENTRY) ehm_k3_api_2, ehm_k3_api_4,
+                                         ehm_k4_api};
 // instances of ehm_k2.hip with the quadratic block (-DEHM2_QUAD=1): convex QP / QCQP
 #define EHM_K2Q_NPS(X, S) X(8, S) X(16, S) X(24, S) X(32, S)
 #define EHM_K2Q_ALL(X) EHM_K2Q_NPS(X, 1) EHM_K2Q_NPS(X, 2) EHM_K2Q_NPS(X, 3) EHM_K2Q_NPS(X, 4)
@@ -104,7 +108,7 @@ __global__ __launch_bounds__(64) void k_point_batch(DevProblem P, long long n_in
         count_solve(cnt, r, lane);
         if (lane == 0) {
             J[inst] = r.obj;
-            if (status) status[inst] = r.status;
+            if (status) status[inst] = ehm_status_word(r.status, r.merit);     // decade of the merit: ehm_dev.h
             if (iters) iters[inst] = r.iters;
         }
         if (u0 && lane < P.n_u) u0[inst * P.n_u + lane] = w.xb[lane];
@@ -144,7 +148,7 @@ __global__ __launch_bounds__(64) void k_simplex_batch(DevProblem P, long long n_
         count_solve(cnt, r, lane);
         if (lane == 0) {
             obj[inst] = (slack == SX_SLACK) ? -r.obj : r.obj;     // t* = -(min -t)
-            if (status) status[inst] = r.status;
+            if (status) status[inst] = ehm_status_word(r.status, r.merit);     // decade of the merit: ehm_dev.h
             if (iters) iters[inst] = r.iters;
         }
         if (alpha) {
@@ -607,7 +611,6 @@ static int grid_for(ehm_problem* P, long long n) {
 }
 
 // ---- second-generation launch configuration --------------------------------------------------
-#define EHM_LDS_BUDGET (160 * 1024 - 256)   // dynamic LDS a workgroup may ask for
 
 static void kind_dims(const DevProblem& dp, int kind, int& n_lp, int& ne) {
     switch (kind) {
@@ -619,11 +622,17 @@ static void kind_dims(const DevProblem& dp, int kind, int& n_lp, int& ne) {
     }
 }
 
-// smallest compiled instance that holds n_lp columns and `slots` row slots
-static const K2Api* k2_pick(int n_lp, int slots, bool quad) {
+// smallest compiled instance that holds n_lp columns and `slots` row slots (dp: the problem, for
+// families that do not take every problem of their class -- K2Api::fits; null = those are skipped)
+static const K2Api* k2_pick(int n_lp, int slots, bool quad, const DevProblem* dp = nullptr) {
     const K2Api* best = nullptr;
+    static const int no_k4 = [] {       // EHM_K4=0: the streaming wide kernels everywhere (A/B runs)
+        const char* e = getenv("EHM_K4");
+        return (e && atoi(e) == 0) ? 1 : 0;
+    }();
     auto consider = [&](const K2Api* a) {
         if (a->np < n_lp || a->slots < slots) return;
+        if (a->fits && (no_k4 || !dp || !a->fits(*dp, EHM_LDS_BUDGET))) return;
         if (!best || a->np < best->np || (a->np == best->np && a->slots < best->slots)) best = a;
     };
     if (quad) {
@@ -649,7 +658,7 @@ static int k2_config(ehm_problem* P, int kind_a, int kind_b, long long n_items, 
     n_lp = std::max(n_lp, n_lp2);
     ne = std::max(ne, ne2);
     // (the instances are sized by the FACTORISED columns: ehm_ipm2.h eliminates [nd0, n))
-    const K2Api* api = k2_pick(n_lp - (P->dp.n - P->dp.nd0), slots, P->quadratic);
+    const K2Api* api = k2_pick(n_lp - (P->dp.n - P->dp.nd0), slots, P->quadratic, &P->dp);
     if (!api)
         return fail(EHM_E_INVALID, "no kernel instance for an LP with %d columns, %d row slots",
                     n_lp, slots);
@@ -672,7 +681,7 @@ static int k2_config(ehm_problem* P, int kind_a, int kind_b, long long n_items, 
     const long long nw0 = std::min<long long>(max_w, (long long)((budget - shared0) / wave));
     const int wc_lds = (nw1 >= nw0 && nw1 >= 1) ? 1 : 0;
     const size_t shared = wc_lds ? shared1 : shared0;
-    if (api->threads_per_lp > 64 && !P->dp.Wr3)
+    if (api->threads_per_lp > 64 && !api->fits && !P->dp.Wr3)
         return fail(EHM_E_INVALID, "wide kernels selected but their constant image is missing");
     // LPs per workgroup: as many wavefronts as fit (wave-local kernels); exactly one (wide)
     long long nw = wc_lds ? nw1 : nw0;
@@ -684,7 +693,8 @@ static int k2_config(ehm_problem* P, int kind_a, int kind_b, long long n_items, 
     }
     // residency: LDS, and the wavefronts per CU the instances' register budget admits
     // (wide kernels: 256 threads with up to 256 VGPRs -> two workgroups per CU)
-    const long long reg_wg = (api->threads_per_lp > 64) ? 2 : (api->max_threads / 64) / nw;
+    const long long reg_wg = (api->threads_per_lp > 256) ? 1
+        : (api->threads_per_lp > 64) ? 2 : (api->max_threads / 64) / nw;
     long long wg_per_cu = std::max<long long>(1, std::min<long long>(EHM_LDS_BUDGET / lds, reg_wg));
     long long grid = std::min<long long>((long long)P->num_cu * wg_per_cu, (n_items + nw - 1) / nw);
     cfg.api = api;

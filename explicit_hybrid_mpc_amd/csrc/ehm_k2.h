@@ -125,8 +125,10 @@ struct K2Launch {
 };
 
 // One compiled kernel family: the wave-local instances of ehm_k2.hip (threads_per_lp = 64,
-// several LPs per workgroup around one LDS copy of the constant block) or the wide instances
-// of ehm_k3.hip (threads_per_lp = 256, one LP per workgroup, constant block from L2).
+// several LPs per workgroup around one LDS copy of the constant block), the wide instances of
+// ehm_k3.hip (threads_per_lp = 256, one LP per workgroup, constant block streamed from L2) or the
+// LDS-resident wide family of ehm_k4.hip (threads_per_lp = 512, one LP per workgroup and CU, the
+// reduced block of the commutation in LDS).
 struct K2Api {
     int np, slots, max_threads, threads_per_lp;
     hipError_t (*set_lds)(int bytes);
@@ -150,6 +152,9 @@ struct K2Api {
     void (*persist)(const K2Launch&, DevProblem, DevTree, int32_t* slots, int n_slots,
                     PersistCtl* ctl, int node_cap, DevCounters*, int sign_only, int max_depth,
                     PersistDeal);
+    // families that cannot take every problem of their (np, slots) class say which they take
+    // (ehm_k4.hip: the reduced block must fit in LDS); null = all of them
+    int (*fits)(const DevProblem& P, int lds_budget_bytes);
 };
 
 // The persistent frontier kernel compiled at two solver widths (ehm_kp.hip).

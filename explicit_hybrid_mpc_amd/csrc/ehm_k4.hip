@@ -1,63 +1,76 @@
-// Wide-LP kernels of libehmpc (gfx950): one workgroup of 256 threads per LP, the
-// commutation's constant block read from global memory / L2, the normal matrix formed on the
-// matrix cores (ehm_ipm3.h).  Used when an LP has more than 32 columns (BASELINE.json
-// configs 4 and 5).  Same entry points and node semantics as ehm_k2.hip; compiled once per
-// row capacity (EHM3_RS row slots per thread).
+// Wide-LP kernels of libehmpc (gfx950) with the constant block RESIDENT IN LDS: one workgroup of
+// 512 threads per LP and CU, the reduced block [G_D | -S] of the commutation copied into LDS once
+// per workgroup and commutation, eliminated epigraph columns, the normal matrix AND the trailing
+// updates of the blocked factorisation on the matrix cores (ehm_ipm4.h).  Taken instead of the
+// streaming kernels of ehm_k3.hip whenever the reduced block fits in LDS (BASELINE.json configs
+// 4 and 5: it does).  Same entry points and node semantics as ehm_k2.hip / ehm_k3.hip.
 #include <hip/hip_runtime.h>
 
 #include "ehm_k2.h"
-#include "ehm_ipm3.h"
+#include "ehm_ipm4.h"
 
 using namespace ehm;
 
-extern __shared__ __attribute__((aligned(16))) char k3_smem[];
+extern __shared__ __attribute__((aligned(16))) char k4_smem[];
 
-namespace EHM3_NS {
+namespace ehm4 {
 
 struct NodeBuf {
     double* rec;    // node record / simplex vertices (+ vertex costs)
     double* th;     // p doubles (parameter / midpoint)
+    double* red;    // workgroup reductions
     double* g;      // p doubles: gradient of the optimal cost from a point solve
 };
+__host__ __device__ inline size_t node_doubles(int p, int n_u) {
+    return (size_t)((rec_doubles(p, n_u) + 7) & ~7) + 8 + 2 * NWV * 8 + 8;
+}
 __device__ __forceinline__ void carve_node(NodeBuf& nb, double* base, int p, int n_u) {
     const int nrec = (rec_doubles(p, n_u) + 7) & ~7;
     nb.rec = base;
     nb.th = base + nrec;
-    nb.g = nb.th + 8 + 64;
+    nb.red = nb.th + 8;
+    nb.g = nb.red + 2 * NWV * 8;
 }
-__host__ __device__ inline size_t node_doubles(int p, int n_u) {
-    // + parameter + reduction scratch + gradient
-    return (size_t)((rec_doubles(p, n_u) + 7) & ~7) + 8 + 64 + 8;
+
+__device__ __forceinline__ unsigned long long low_bits(int k) {
+    return (k < 64) ? ((1ULL << k) - 1ULL) : ~0ULL;
 }
 
 // P_theta_delta at one parameter value (lib/oracle.py:141-173) or its phase-one form
 //   min tau  s.t.  G z - tau <= w + S theta,  tau >= -1.
-__device__ __forceinline__ void assemble_point(Lp& L, const double* theta, bool feas, double (&b)[RS],
-                                      int tid) {
-    const int n = L.n, m = L.m, p = L.p;
-    L.ne = feas ? 1 : 0;
-    L.m_lp = m + L.ne;
+// Returns the right-hand side of this thread's row.  Ends with a workgroup barrier.
+__device__ __forceinline__ double assemble_point(const Blk& S, Lp& L, const double* theta, bool feas,
+                                                 int tid) {
+    const int n = S.n, m = S.m, p = S.p, nd0 = S.nd0;
+    L.nsx = 0;
+    L.kd = feas ? 1 : 0;
     L.has_beta = 0;
     L.sign_floor = EHM_ROUTE_TOL;
     L.spec_mpc = feas ? 1 : 0;
-    L.act = ((n < 64) ? ((1ULL << n) - 1ULL) : ~0ULL) | (feas ? (1ULL << (n + p)) : 0ULL);
-    if (tid < NW) {
-        L.c[tid] = feas ? ((tid == n + p) ? 1.0 : 0.0) : ((tid < n) ? L.cv[tid] : 0.0);
-        if (feas) L.X[tid] = (tid == n + p) ? -1.0 : 0.0;      // extra row 0:  -tau <= 1
-    }
-#pragma unroll
-    for (int sl = 0; sl < RS; ++sl) {
-        const int i = tid + NT * sl;
-        double v = 0.0;
-        if (i < m) {
-            v = L.wv[i];
-            for (int r = 0; r < p; ++r) v = fma(-L.Wcm[(size_t)(n + r) * L.ldc + i], theta[r], v);
-        } else if (feas && i == m) {
-            v = 1.0;
-        }
-        b[sl] = v;
+    L.act = low_bits(nd0) | (feas ? (1ULL << (nd0 + p)) : 0ULL);
+    if (tid < NC) {
+        L.c[tid] = 0.0;
+        L.X[tid] = 0.0;
+        L.X[NC + tid] = 0.0;
     }
     __syncthreads();
+    if (feas) {
+        if (tid == 0) {
+            L.c[nd0 + p] = 1.0;
+            L.X[nd0 + p] = -1.0;            // dense row 0:  -tau <= 1
+        }
+    } else if (tid < n) {
+        L.c[zcol(S, tid)] = S.cv[tid];
+    }
+    double v = 0.0;
+    if (tid < m) {
+        v = S.wv[tid];
+        for (int r = 0; r < p; ++r) v = fma(-S.Wb[(size_t)(nd0 + r) * S.ld + tid], theta[r], v);
+    } else if (feas && tid == S.m4) {
+        v = 1.0;
+    }
+    __syncthreads();
+    return v;
 }
 
 // Problems over a simplex R (rows = vertices, in LDS) in the variables (z, beta[, t]) with
@@ -66,71 +79,69 @@ __device__ __forceinline__ void assemble_point(Lp& L, const double* theta, bool 
 //   SX_SLACK : max t  s.t.  Vbar0 + dV^T beta - V - eps_a >= t,
 //                           Vbar0 + dV^T beta - (1+eps_r) V >= t   (lib/oracle.py:89-97)
 //   SX_FEAS  : min tau s.t. MPC rows relaxed by tau, tau >= -1
-// Extra rows: e < p facets -beta_e <= 0, e = p sum beta <= 1, then the dense ones.
-__device__ __forceinline__ void assemble_simplex(Lp& L, const double* R, const double* Vbar, int mode,
-                                        double eps_a, double eps_r, double (&b)[RS], int tid) {
-    const int n = L.n, m = L.m, p = L.p;
+// Extra rows: the simplex rows -beta_e <= 0 (e < p), sum beta <= 1 (analytic), then the dense ones.
+__device__ __forceinline__ double assemble_simplex(const Blk& S, Lp& L, const double* R,
+                                                   const double* Vbar, int mode, double eps_a,
+                                                   double eps_r, int tid) {
+    const int n = S.n, m = S.m, p = S.p, nd0 = S.nd0;
     const bool slack = (mode == SX_SLACK);
     const bool feas = (mode == SX_FEAS);
-    L.ne = p + 1 + (slack ? 2 : 0) + (feas ? 1 : 0);
-    L.m_lp = m + L.ne;
+    L.nsx = p + 1;
+    L.kd = slack ? 2 : (feas ? 1 : 0);
     L.has_beta = 1;
-    L.sign_floor = EHM_ROUTE_TOL * (1.0 + ((mode == SX_SLACK) ? fabs(Vbar[0]) : 0.0));
+    L.sign_floor = EHM_ROUTE_TOL * (1.0 + (slack ? fabs(Vbar[0]) : 0.0));
     L.spec_mpc = feas ? 1 : 0;
-    const int n_lp = n + p + ((slack || feas) ? 1 : 0);
-    L.act = (n_lp < 64) ? ((1ULL << n_lp) - 1ULL) : ~0ULL;
-    for (int k = tid; k < L.ne * NW; k += NT) L.X[k] = 0.0;
-    if (tid < NW) L.c[tid] = 0.0;
-    if (tid < p * p) {
-        const int r = tid / p, q = tid - r * p;
-        L.E[tid] = R[(q + 1) * p + r] - R[r];
+    L.act = low_bits(nd0 + p + ((slack || feas) ? 1 : 0));
+    if (tid < NC) {
+        L.c[tid] = 0.0;
+        L.X[tid] = 0.0;
+        L.X[NC + tid] = 0.0;
+    }
+    if (tid >= 64 && tid < 64 + p * p) {
+        const int k = tid - 64;
+        const int r = k / p, q = k - r * p;
+        L.E[k] = R[(q + 1) * p + r] - R[r];
     }
     __syncthreads();
-    if (tid < p) {
-        L.X[tid * NW + n + tid] = -1.0;     // -beta_q <= 0
-        L.X[p * NW + n + tid] = 1.0;        // sum beta <= 1
-        if (slack) {
-            const double dv = Vbar[tid + 1] - Vbar[0];
-            L.X[(p + 1) * NW + n + tid] = -dv;
-            L.X[(p + 2) * NW + n + tid] = -dv;
-        }
-    }
     if (slack) {
         if (tid < n) {
-            const double cj = L.cv[tid];
-            L.X[(p + 1) * NW + tid] = cj;
-            L.X[(p + 2) * NW + tid] = fma(eps_r, cj, cj);     // (1 + eps_r) c_j
+            const double cj = S.cv[tid];
+            const int zc = zcol(S, tid);
+            L.X[zc] = cj;
+            L.X[NC + zc] = fma(eps_r, cj, cj);      // (1 + eps_r) c_j
         }
-        if (tid == 0) {
-            L.X[(p + 1) * NW + n + p] = 1.0;
-            L.X[(p + 2) * NW + n + p] = 1.0;
-            L.c[n + p] = -1.0;
+        if (tid >= 64 && tid < 64 + p) {
+            const int q = tid - 64;
+            const double dv = Vbar[q + 1] - Vbar[0];
+            L.X[nd0 + q] = -dv;
+            L.X[NC + nd0 + q] = -dv;
+        }
+        if (tid == 128) {
+            L.X[nd0 + p] = 1.0;
+            L.X[NC + nd0 + p] = 1.0;
+            L.c[nd0 + p] = -1.0;
         }
     } else if (feas) {
         if (tid == 0) {
-            L.X[(p + 1) * NW + n + p] = -1.0;       // -tau <= 1
-            L.c[n + p] = 1.0;
+            L.X[nd0 + p] = -1.0;            // -tau <= 1
+            L.c[nd0 + p] = 1.0;
         }
     } else if (tid < n) {
-        L.c[tid] = L.cv[tid];
+        L.c[zcol(S, tid)] = S.cv[tid];
     }
-#pragma unroll
-    for (int sl = 0; sl < RS; ++sl) {
-        const int i = tid + NT * sl;
-        double v = 0.0;
-        if (i < m) {
-            v = L.wv[i];
-            for (int r = 0; r < p; ++r) v = fma(-L.Wcm[(size_t)(n + r) * L.ldc + i], R[r], v);
-        } else {
-            const int e = i - m;
-            if (e == p) v = 1.0;
-            else if (feas && e == p + 1) v = 1.0;
-            else if (slack && e == p + 1) v = Vbar[0] - eps_a;
-            else if (slack && e == p + 2) v = Vbar[0];
-        }
-        b[sl] = v;
+    double v = 0.0;
+    if (tid < m) {
+        v = S.wv[tid];
+        for (int r = 0; r < p; ++r) v = fma(-S.Wb[(size_t)(nd0 + r) * S.ld + tid], R[r], v);
+    } else if (tid >= S.m4) {
+        const int e = tid - S.m4;
+        if (e == p) v = 1.0;
+        else if (feas && e == p + 1) v = 1.0;
+        else if (slack && e == p + 1) v = Vbar[0] - eps_a;
+        else if (slack && e == p + 2) v = Vbar[0];
     }
     __syncthreads();
+    return v;
 }
 
 __device__ __forceinline__ void count_solve(DevCounters* cnt, const IpmResult& r, int tid) {
@@ -141,32 +152,45 @@ __device__ __forceinline__ void count_solve(DevCounters* cnt, const IpmResult& r
     }
 }
 
-#define K3_PROLOGUE(D)                                                           \
-    double* sm = reinterpret_cast<double*>(k3_smem);                             \
+#define K4_PROLOGUE()                                                            \
+    double* sm = reinterpret_cast<double*>(k4_smem);                             \
     const int tid0 = threadIdx.x;                                                \
     int tid = tid0;                                                              \
-    Block B;                                                                     \
+    Ctx B;                                                                       \
     B.tid = tid0;                                                                \
     B.lane = tid0 & 63;                                                          \
     B.wave = __builtin_amdgcn_readfirstlane(tid0 >> 6);                          \
     B.flip = 0;                                                                  \
     NodeBuf nb;                                                                  \
     carve_node(nb, sm, P.p, P.n_u);                                              \
-    B.red = nb.th + 8;                                                           \
+    B.red = nb.red;                                                              \
+    Blk S;                                                                       \
+    carve_blk(S, sm + node_doubles(P.p, P.n_u), P);                              \
     Lp L;                                                                        \
-    carve_lp(L, sm + node_doubles(P.p, P.n_u), P, (D))
+    carve_lp(L, sm + node_doubles(P.p, P.n_u) +                                  \
+                 blk_doubles(P.m, P.p, P.nd0, P.n - P.nd0, P.LE4), S)
+
+// the block of commutation d into LDS (all threads; barriers on both sides)
+#define K4_USE_BLOCK(D)                                                          \
+    {                                                                            \
+        __syncthreads();                                                         \
+        load_blk(S, P, (D), tid0);                                               \
+        S.wv = P.w + (size_t)(D) * P.m;                                          \
+        __syncthreads();                                                         \
+    }
 
 // ---- a2: P_theta_delta batch / its feasibility form; instances sorted by commutation -----
-EHM3_KERNEL void k3_point_batch(
+template <int NTILE>
+EHM4_KERNEL void k4_point_batch(
     DevProblem P, long long n_inst, const double* __restrict__ theta,
     const int32_t* __restrict__ seg, int feas, double* __restrict__ J, double* __restrict__ u0,
     int32_t* __restrict__ status, int32_t* __restrict__ iters, DevCounters* cnt, K2Gather G) {
-    K3_PROLOGUE(0);
+    K4_PROLOGUE();
     if (G.n_dev) n_inst = *G.n_dev;
-    // instances are drawn from a ticket (DevCounters::ticket, zeroed by the launcher; see
-    // k3_lcss_decide): phase-one problems end after 4 iterations, ranked ones after 10
+    // instances are drawn from a ticket (DevCounters::ticket, zeroed by the launcher): they are
+    // sorted by commutation, so a workgroup reloads its block only when the segment changes
     __shared__ unsigned int s_ticket;
-    int d = 0;
+    int d = 0, d_loaded = -1;
     for (;;) {
         __syncthreads();
         if (tid0 == 0) s_ticket = atomicAdd(&cnt->ticket, 1u);
@@ -175,17 +199,19 @@ EHM3_KERNEL void k3_point_batch(
         if (inst >= n_inst) break;
         tid = pin(tid0);
         while (d + 1 < P.n_delta && seg[d + 1] <= inst) ++d;
-        carve_lp(L, sm + node_doubles(P.p, P.n_u), P, d);
+        if (d != d_loaded) {
+            K4_USE_BLOCK(d)
+            d_loaded = d;
+        }
         const double* tsrc = G.src ? theta + G.src[inst] : theta + inst * P.p;
         const long long o = G.dst ? (long long)G.dst[inst] : inst;
         if (tid < P.p) nb.th[tid] = tsrc[tid];
         __syncthreads();
         IpmResult r;
         int its = 0;
-        for (int attempt = 0; attempt < EHM3_ATTEMPTS; ++attempt) {     // see EHM3_STEP_FRAC
-            double b[RS];
-            assemble_point(L, nb.th, feas != 0, b, pin(tid));
-            r = ipm_solve(L, B, b, false, step_fraction(attempt));
+        for (int attempt = 0; attempt < EHM4_ATTEMPTS; ++attempt) {     // see EHM4_STEP_FRAC
+            const double b = assemble_point(S, L, nb.th, feas != 0, pin(tid));
+            r = ipm_solve<NTILE>(S, L, B, b, false, step_fraction(attempt));
             its += r.iters;
             if (r.status == 0) break;
         }
@@ -202,19 +228,18 @@ EHM3_KERNEL void k3_point_batch(
 }
 
 // ---- a5 / a7': problems over a simplex, one commutation per instance (sorted) -------------
-EHM3_KERNEL void k3_simplex_batch(
+template <int NTILE>
+EHM4_KERNEL void k4_simplex_batch(
     DevProblem P, long long n_inst, const double* __restrict__ R,
     const double* __restrict__ Vbar, const int32_t* __restrict__ seg, int mode,
     double* __restrict__ obj, double* __restrict__ alpha, int32_t* __restrict__ status,
     int32_t* __restrict__ iters, DevCounters* cnt, K2Gather G) {
-    K3_PROLOGUE(0);
+    K4_PROLOGUE();
     const int p = P.p;
     const int nR = (p + 1) * p;
     if (G.n_dev) n_inst = *G.n_dev;
-    // instances are drawn from a ticket (DevCounters::ticket, zeroed by the launcher; see
-    // k3_lcss_decide): phase-one problems end after 4 iterations, ranked ones after 10
     __shared__ unsigned int s_ticket;
-    int d = 0;
+    int d = 0, d_loaded = -1;
     for (;;) {
         __syncthreads();
         if (tid0 == 0) s_ticket = atomicAdd(&cnt->ticket, 1u);
@@ -223,7 +248,10 @@ EHM3_KERNEL void k3_simplex_batch(
         if (inst >= n_inst) break;
         tid = pin(tid0);
         while (d + 1 < P.n_delta && seg[d + 1] <= inst) ++d;
-        carve_lp(L, sm + node_doubles(P.p, P.n_u), P, d);
+        if (d != d_loaded) {
+            K4_USE_BLOCK(d)
+            d_loaded = d;
+        }
         double* Rl = nb.rec;
         double* Vl = nb.rec + nR;
         const double* Rsrc = G.src ? R + G.src[inst] : R + inst * nR;
@@ -234,10 +262,9 @@ EHM3_KERNEL void k3_simplex_batch(
         __syncthreads();
         IpmResult r;
         int its = 0;
-        for (int attempt = 0; attempt < EHM3_ATTEMPTS; ++attempt) {
-            double b[RS];
-            assemble_simplex(L, Rl, Vl, mode, P.eps_a, P.eps_r, b, pin(tid));
-            r = ipm_solve(L, B, b, false, step_fraction(attempt));
+        for (int attempt = 0; attempt < EHM4_ATTEMPTS; ++attempt) {
+            const double b = assemble_simplex(S, L, Rl, Vl, mode, P.eps_a, P.eps_r, pin(tid));
+            r = ipm_solve<NTILE>(S, L, B, b, false, step_fraction(attempt));
             its += r.iters;
             if (r.status == 0) break;
         }
@@ -249,7 +276,7 @@ EHM3_KERNEL void k3_simplex_batch(
             if (iters) iters[o] = r.iters;
         }
         if (alpha && B.wave == 0) {
-            const double beta = (tid < p) ? L.xb[P.n + tid] : 0.0;
+            const double beta = (tid < p) ? L.xb[S.nd0 + tid] : 0.0;
             const double sb = wave_sum(beta);
             if (tid < p) alpha[o * (p + 1) + tid + 1] = beta;
             if (tid == 0) alpha[o * (p + 1)] = 1.0 - sb;
@@ -260,16 +287,17 @@ EHM3_KERNEL void k3_simplex_batch(
 
 // ---- frontier sweep (single commutation): epsilon-suboptimality decision per node --------
 // (lib/worker.py:368-375)
-EHM3_KERNEL void k3_lcss_decide(
+template <int NTILE>
+EHM4_KERNEL void k4_lcss_decide(
     DevProblem P, DevTree T, const int32_t* __restrict__ frontier, int nf,
     int32_t* __restrict__ open_flag, DevCounters* cnt, int sign_only) {
-    K3_PROLOGUE(0);
+    K4_PROLOGUE();
     const int nrec = rec_doubles(P.p, P.n_u);
-    // Workgroups draw frontier positions from a ticket (DevCounters::ticket, zeroed by the
-    // launcher): a node costs anything between a tangent-plane bound and a 20-iteration LP, and
-    // neighbours in the frontier are siblings with alike costs -- contiguous shares per
-    // workgroup took 29 % longer on config 4, interleaved ones 8 %.
+    K4_USE_BLOCK(0)
+    // Workgroups draw frontier positions from a ticket (see ehm_k3.hip): a node costs anything
+    // between a tangent-plane bound and a 20-iteration LP.
     __shared__ int s_ticket;
+    __shared__ double s_bnd;
     for (;;) {
         __syncthreads();
         if (tid0 == 0) s_ticket = (int)atomicAdd(&cnt->ticket, 1u);
@@ -282,15 +310,15 @@ EHM3_KERNEL void k3_lcss_decide(
         for (int k = tid; k < nrec; k += NT) nb.rec[k] = rec[k];
         __syncthreads();
         if (T.grad && sign_only) {
-            // tangent-plane bound of t* (ehm_dev.h, cut_bound), evaluated
-            // by the first wavefront in the LP workspace that is still free: negative => closed
+            // tangent-plane bound of t* (ehm_dev.h, cut_bound), evaluated by the first wavefront in
+            // the LP workspace that is still free: negative => closed
             if (B.wave == 0) {
                 const double bnd0 = cut_bound(nb.rec, T.grad + (size_t)id * (P.p + 1) * P.p, P.p,
                                               P.eps_a, P.eps_r, B.lane, L.M);
-                if (B.lane == 0) L.M[4000] = bnd0;
+                if (B.lane == 0) s_bnd = bnd0;
             }
             __syncthreads();
-            const double bnd = L.M[4000];
+            const double bnd = s_bnd;
             __syncthreads();
             if (bnd < -EHM_ROUTE_TOL * (1.0 + fabs(nb.rec[rec_off_vcost(P.p)]))) {
                 if (tid == 0) {
@@ -306,8 +334,8 @@ EHM3_KERNEL void k3_lcss_decide(
             }
         }
         if (T.wit && sign_only) {
-            // inherited witness (DevTree::wit): the point that proved an
-            // ancestor open, if this node contains it and it still beats the interpolated cost
+            // inherited witness (DevTree::wit): the point that proved an ancestor open, if this
+            // node contains it and it still beats the interpolated cost
             const double* wv = T.wit + (size_t)id * (P.p + 2);
             const double* Vc = nb.rec + rec_off_vcost(P.p);
             double vbw = 0.0;
@@ -328,25 +356,24 @@ EHM3_KERNEL void k3_lcss_decide(
         }
         IpmResult r;
         int its = 0;
-        for (int attempt = 0; attempt < EHM3_ATTEMPTS; ++attempt) {
-            double b[RS];
-            assemble_simplex(L, nb.rec, nb.rec + rec_off_vcost(P.p), SX_SLACK, P.eps_a, P.eps_r,
-                             b, pin(tid));
-            r = ipm_solve(L, B, b, sign_only != 0, step_fraction(attempt));
+        for (int attempt = 0; attempt < EHM4_ATTEMPTS; ++attempt) {
+            const double b = assemble_simplex(S, L, nb.rec, nb.rec + rec_off_vcost(P.p), SX_SLACK,
+                                              P.eps_a, P.eps_r, pin(tid));
+            r = ipm_solve<NTILE>(S, L, B, b, sign_only != 0, step_fraction(attempt));
             its += r.iters;
             if (r.status == 0) break;
         }
         r.iters = its;
         count_solve(cnt, r, tid);
         if (T.wit && B.wave == 0) {
-            // this node's own witness: the accepted iterate's parameter (barycentric) and the
-            // cost of its z, raised by the safety amount (EHM_WIT_REL); none after a failed solve
+            // this node's own witness: the accepted iterate's parameter (barycentric) and the cost
+            // of its z, raised by the safety amount (EHM_WIT_REL); none after a failed solve
             const bool ok = sign_only && r.status == 0 && -r.obj >= 0.0;
             double* wv = T.wit + (size_t)id * (P.p + 2);
             double cz = 0.0;
-            for (int q = B.lane; q < P.n; q += 64) cz = fma(L.cv[q], L.xb[q], cz);
+            for (int q = B.lane; q < P.n; q += 64) cz = fma(S.cv[q], L.xb[zcol(S, q)], cz);
             cz = wave_sum(cz);
-            const double beta = (B.lane < P.p) ? L.xb[P.n + B.lane] : 0.0;
+            const double beta = (B.lane < P.p) ? L.xb[S.nd0 + B.lane] : 0.0;
             const double sb = wave_sum(beta);
             if (B.lane < P.p) wv[2 + B.lane] = ok ? beta : 0.0;
             if (B.lane == 0) {
@@ -376,12 +403,14 @@ EHM3_KERNEL void k3_lcss_decide(
 
 // ---- split every open node, solve P_theta_delta at the midpoint, write the children -------
 // (lib/worker.py:403-414, 354-365)
-EHM3_KERNEL void k3_lcss_expand(
+template <int NTILE>
+EHM4_KERNEL void k4_lcss_expand(
     DevProblem P, DevTree T, const int32_t* __restrict__ open_list, int n_open, int child_base,
     int32_t* __restrict__ next_frontier, DevCounters* cnt) {
-    K3_PROLOGUE(0);
+    K4_PROLOGUE();
     const int p = P.p, n_u = P.n_u;
     const int nrec = rec_doubles(p, n_u);
+    K4_USE_BLOCK(0)
     __shared__ int s_ticket;
     __shared__ int s_mt[3];
     __shared__ double s_mtv[2];
@@ -410,10 +439,9 @@ EHM3_KERNEL void k3_lcss_expand(
         IpmResult r;
         r.obj = 0.0;
         r.status = 0;
-        // the simplices around an edge all ask for this midpoint (12.5 splits per distinct one on
-        // the config-4 instance): the table of midpoint optima of the persistent kernel
-        // (ehm_midtable.h) serves the sweeps as well -- within a sweep (the owner of a claimed
-        // slot is a workgroup that is running its solve) and from one sweep to the next
+        r.merit = 0.0;
+        // the table of midpoint optima (ehm_midtable.h) serves the sweeps: the simplices around an
+        // edge all ask for this midpoint (see ehm_k3.hip)
         int mt_res = MT_NONE, mt_slot = 0;
         unsigned long long mt_tg = 0ull;
         if (T.mt.state) {
@@ -448,10 +476,10 @@ EHM3_KERNEL void k3_lcss_expand(
         }
         if (mt_res != MT_HIT) {
             int its = 0;
-            for (int attempt = 0; attempt < EHM3_ATTEMPTS; ++attempt) {
-                double b[RS];
-                assemble_point(L, mid, false, b, pin(tid));
-                r = ipm_solve(L, B, b, false, step_fraction(attempt), T.grad ? nb.g : nullptr);
+            for (int attempt = 0; attempt < EHM4_ATTEMPTS; ++attempt) {
+                const double b = assemble_point(S, L, mid, false, pin(tid));
+                r = ipm_solve<NTILE>(S, L, B, b, false, step_fraction(attempt),
+                                     T.grad ? nb.g : nullptr);
                 its += r.iters;
                 if (r.status == 0) break;
             }
@@ -469,6 +497,7 @@ EHM3_KERNEL void k3_lcss_expand(
             atomicAdd(&cnt->errors, 1ULL);
             T.flags[id] |= 16;
         }
+        __syncthreads();
         const int c0 = child_base + 2 * f;
         if (T.grad) {       // the children inherit the vertex gradients, the midpoint's is new
             const int ng = (p + 1) * p;
@@ -531,10 +560,12 @@ EHM3_KERNEL void k3_lcss_expand(
 }
 
 // ---- vertex solves that seed a node's costs / inputs (lib/oracle.py:416-443) ---------------
-EHM3_KERNEL void k3_vertex_solve(
+template <int NTILE>
+EHM4_KERNEL void k4_vertex_solve(
     DevProblem P, DevTree T, const int32_t* __restrict__ nodes, int n_nodes, DevCounters* cnt) {
-    K3_PROLOGUE(0);
+    K4_PROLOGUE();
     const int p = P.p, n_u = P.n_u;
+    K4_USE_BLOCK(0)
     const int total = n_nodes * (p + 1);
     const int per = (total + gridDim.x - 1) / gridDim.x;
     const int lo = blockIdx.x * per;
@@ -548,10 +579,10 @@ EHM3_KERNEL void k3_vertex_solve(
         __syncthreads();
         IpmResult r;
         int its = 0;
-        for (int attempt = 0; attempt < EHM3_ATTEMPTS; ++attempt) {
-            double b[RS];
-            assemble_point(L, nb.th, false, b, pin(tid));
-            r = ipm_solve(L, B, b, false, step_fraction(attempt), T.grad ? nb.g : nullptr);
+        for (int attempt = 0; attempt < EHM4_ATTEMPTS; ++attempt) {
+            const double b = assemble_point(S, L, nb.th, false, pin(tid));
+            r = ipm_solve<NTILE>(S, L, B, b, false, step_fraction(attempt),
+                                 T.grad ? nb.g : nullptr);
             its += r.iters;
             if (r.status == 0) break;
         }
@@ -565,17 +596,17 @@ EHM3_KERNEL void k3_vertex_solve(
     }
 }
 
-// ---- self test: workgroup reductions and one 16x16x4 tile product --------------------------
-__global__ __launch_bounds__(EHM3_THREADS) void k3_selftest(double* out) {
-    __shared__ double red[64];
-    Block B;
+// ---- self test: workgroup reductions, the quad sum and one 16x16x4 tile product -----------
+__global__ __launch_bounds__(EHM4_THREADS) void k4_selftest(double* out) {
+    __shared__ double red[2 * NWV * 8];
+    Ctx B;
     B.tid = threadIdx.x;
     B.lane = threadIdx.x & 63;
     B.wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     B.flip = 0;
     B.red = red;
     const int tid = B.tid;
-    // 256 threads: sum(1 + 0.5 k, k < 64) = 1072 from the first wavefront only
+    // sum(1 + 0.5 k, k < 64) = 1072 from the first wavefront only
     double mx[2] = {(tid == 137) ? 99.0 : -(double)tid, -1.0 - tid};
     double sm[4] = {(tid < 64) ? 1.0 + 0.5 * tid : 0.0, (tid < 25) ? 1.0 : 0.0, 0.0, 0.0};
     block_reduce(B, mx, sm);
@@ -588,28 +619,35 @@ __global__ __launch_bounds__(EHM3_THREADS) void k3_selftest(double* out) {
     for (int r = 0; r < 4; ++r)
         if (lk + 4 * r == li) tr += C[r];
     tr = wave_sum(tr);
+    // quad sums: lanes 4q .. 4q+3 hold q + 1 each -> 4 (q + 1); checked on quad 5
+    const double qs = quad_sum((double)((B.lane >> 2) + 1));
+    const double q5 = readlane_d(qs, 21);
     if (tid == 0) {
         out[0] = sm[0];
         out[1] = mx[0];
         out[2] = sm[1];
-        out[3] = frcp(3.0) + (tr / 16.0 - 8.5);
+        out[3] = frcp(3.0) + (tr / 16.0 - 8.5) + (q5 - 24.0);
         out[4] = mx[1];
     }
 }
 
-}  // namespace EHM3_NS
+}  // namespace ehm4
 
 // ---------------------------------------------------------------------------------------
 // host-side launchers
 // ---------------------------------------------------------------------------------------
 namespace {
 
-using namespace EHM3_NS;
+using namespace ehm4;
+
+int ntile_of(const DevProblem& P) { return (P.nd0 + P.p + 1 > 32) ? 3 : 2; }
 
 hipError_t set_lds(int bytes) {
-    const void* ks[] = {(const void*)k3_point_batch, (const void*)k3_simplex_batch,
-                        (const void*)k3_lcss_decide, (const void*)k3_lcss_expand,
-                        (const void*)k3_vertex_solve};
+    const void* ks[] = {(const void*)k4_point_batch<2>,   (const void*)k4_point_batch<3>,
+                        (const void*)k4_simplex_batch<2>, (const void*)k4_simplex_batch<3>,
+                        (const void*)k4_lcss_decide<2>,   (const void*)k4_lcss_decide<3>,
+                        (const void*)k4_lcss_expand<2>,   (const void*)k4_lcss_expand<3>,
+                        (const void*)k4_vertex_solve<2>,  (const void*)k4_vertex_solve<3>};
     for (const void* k : ks) {
         hipError_t e = hipFuncSetAttribute(k, hipFuncAttributeMaxDynamicSharedMemorySize, bytes);
         if (e != hipSuccess) return e;
@@ -617,73 +655,85 @@ hipError_t set_lds(int bytes) {
     return hipSuccess;
 }
 
+// LDS doubles of the LP in flight (+ the node buffer); the block is the "shared" part
 size_t unit_doubles_for(const DevProblem& P, int /*n_lp*/, int /*ne*/, int /*persist*/) {
-    return (node_doubles(P.p, P.n_u) + lp_doubles(P.m) + 1) & ~(size_t)1;
+    return (node_doubles(P.p, P.n_u) + lp_doubles(P.m, P.p, P.nd0, P.n - P.nd0) + 1) & ~(size_t)1;
 }
-size_t shared_doubles_for(const DevProblem&) { return 0; }
+size_t shared_doubles_for(const DevProblem& P) {
+    return blk_doubles(P.m, P.p, P.nd0, P.n - P.nd0, P.LE4);
+}
+// the family takes a problem when its factorised columns, its rows and its eliminated block fit
+int fits(const DevProblem& P, int lds_budget_bytes) {
+    const int nE = P.n - P.nd0;
+    if (P.nd0 + P.p + 1 > NF || nE > MAXNE) return 0;
+    if (((P.m + 3) & ~3) + P.p + 3 > NT) return 0;
+    if (P.n_u > P.nd0 || P.p * P.p + 64 > NT) return 0;
+    const size_t need = (shared_doubles_for(P) + unit_doubles_for(P, 0, 0, 0)) * sizeof(double);
+    return need <= (size_t)lds_budget_bytes ? 1 : 0;
+}
 
 void l_point(const K2Launch& L, DevProblem P, long long n_inst, const double* theta,
              const int32_t* seg, int feas, double* J, double* u0, int32_t* status,
              int32_t* iters, DevCounters* cnt, K2Gather G) {
     (void)hipMemsetAsync(&cnt->ticket, 0, sizeof(unsigned int), L.stream);
-    hipLaunchKernelGGL(k3_point_batch, dim3(L.grid), dim3(L.threads), L.lds_bytes, L.stream, P,
-                       n_inst, theta, seg, feas, J, u0, status, iters, cnt, G);
+    if (ntile_of(P) == 3)
+        hipLaunchKernelGGL(k4_point_batch<3>, dim3(L.grid), dim3(L.threads), L.lds_bytes, L.stream,
+                           P, n_inst, theta, seg, feas, J, u0, status, iters, cnt, G);
+    else
+        hipLaunchKernelGGL(k4_point_batch<2>, dim3(L.grid), dim3(L.threads), L.lds_bytes, L.stream,
+                           P, n_inst, theta, seg, feas, J, u0, status, iters, cnt, G);
 }
 void l_simplex(const K2Launch& L, DevProblem P, long long n_inst, const double* R,
                const double* Vbar, const int32_t* seg, int mode, double* obj, double* alpha,
                int32_t* status, int32_t* iters, DevCounters* cnt, K2Gather G) {
     (void)hipMemsetAsync(&cnt->ticket, 0, sizeof(unsigned int), L.stream);
-    hipLaunchKernelGGL(k3_simplex_batch, dim3(L.grid), dim3(L.threads), L.lds_bytes, L.stream,
-                       P, n_inst, R, Vbar, seg, mode, obj, alpha, status, iters, cnt, G);
+    if (ntile_of(P) == 3)
+        hipLaunchKernelGGL(k4_simplex_batch<3>, dim3(L.grid), dim3(L.threads), L.lds_bytes,
+                           L.stream, P, n_inst, R, Vbar, seg, mode, obj, alpha, status, iters, cnt,
+                           G);
+    else
+        hipLaunchKernelGGL(k4_simplex_batch<2>, dim3(L.grid), dim3(L.threads), L.lds_bytes,
+                           L.stream, P, n_inst, R, Vbar, seg, mode, obj, alpha, status, iters, cnt,
+                           G);
 }
 void l_decide(const K2Launch& L, DevProblem P, DevTree T, const int32_t* frontier, int nf,
               int32_t* open_flag, DevCounters* cnt, int sign_only) {
     (void)hipMemsetAsync(&cnt->ticket, 0, sizeof(unsigned int), L.stream);
-    hipLaunchKernelGGL(k3_lcss_decide, dim3(L.grid), dim3(L.threads), L.lds_bytes, L.stream, P,
-                       T, frontier, nf, open_flag, cnt, sign_only);
+    if (ntile_of(P) == 3)
+        hipLaunchKernelGGL(k4_lcss_decide<3>, dim3(L.grid), dim3(L.threads), L.lds_bytes, L.stream,
+                           P, T, frontier, nf, open_flag, cnt, sign_only);
+    else
+        hipLaunchKernelGGL(k4_lcss_decide<2>, dim3(L.grid), dim3(L.threads), L.lds_bytes, L.stream,
+                           P, T, frontier, nf, open_flag, cnt, sign_only);
 }
 void l_expand(const K2Launch& L, DevProblem P, DevTree T, const int32_t* open_list, int n_open,
               int child_base, int32_t* next_frontier, DevCounters* cnt) {
     (void)hipMemsetAsync(&cnt->ticket, 0, sizeof(unsigned int), L.stream);
-    hipLaunchKernelGGL(k3_lcss_expand, dim3(L.grid), dim3(L.threads), L.lds_bytes, L.stream, P,
-                       T, open_list, n_open, child_base, next_frontier, cnt);
+    if (ntile_of(P) == 3)
+        hipLaunchKernelGGL(k4_lcss_expand<3>, dim3(L.grid), dim3(L.threads), L.lds_bytes, L.stream,
+                           P, T, open_list, n_open, child_base, next_frontier, cnt);
+    else
+        hipLaunchKernelGGL(k4_lcss_expand<2>, dim3(L.grid), dim3(L.threads), L.lds_bytes, L.stream,
+                           P, T, open_list, n_open, child_base, next_frontier, cnt);
 }
 void l_vertex(const K2Launch& L, DevProblem P, DevTree T, const int32_t* nodes, int n_nodes,
               DevCounters* cnt) {
-    hipLaunchKernelGGL(k3_vertex_solve, dim3(L.grid), dim3(L.threads), L.lds_bytes, L.stream, P,
-                       T, nodes, n_nodes, cnt);
+    if (ntile_of(P) == 3)
+        hipLaunchKernelGGL(k4_vertex_solve<3>, dim3(L.grid), dim3(L.threads), L.lds_bytes, L.stream,
+                           P, T, nodes, n_nodes, cnt);
+    else
+        hipLaunchKernelGGL(k4_vertex_solve<2>, dim3(L.grid), dim3(L.threads), L.lds_bytes, L.stream,
+                           P, T, nodes, n_nodes, cnt);
 }
 void l_selftest(hipStream_t stream, double* out) {
-    hipLaunchKernelGGL(k3_selftest, dim3(1), dim3(EHM3_THREADS), 0, stream, out);
+    hipLaunchKernelGGL(k4_selftest, dim3(1), dim3(EHM4_THREADS), 0, stream, out);
 }
 
-// np = 64 columns; slots in units of 64 rows; one LP per workgroup of 256 threads
-const K2Api g_api = {NW,      4 * EHM3_RS, EHM3_THREADS, EHM3_THREADS, set_lds,  unit_doubles_for,
-                     shared_doubles_for, l_point,   l_simplex,    l_decide,     l_expand,
-                     l_vertex, l_selftest, nullptr};
+// np = 48 factorised columns; slots in units of 64 rows; one LP per workgroup of 512 threads
+const K2Api g_api = {NF,       EHM4_THREADS / 64, EHM4_THREADS, EHM4_THREADS, set_lds,
+                     unit_doubles_for, shared_doubles_for, l_point, l_simplex, l_decide,
+                     l_expand, l_vertex, l_selftest, nullptr, fits};
 
 }  // namespace
 
-// phase timers of an experimental build (-DEHM3_PROFILE); zeros otherwise
-#define K3P_CAT2(a, b) a##b
-#define K3P_CAT(a, b) K3P_CAT2(a, b)
-// (a diagnostic hook outside include/*.h: exported by hand, the library is built with
-// -fvisibility=hidden)
-extern "C" __attribute__((visibility("default"))) int K3P_CAT(ehm_k3_profile_, EHM3_RS)(
-    unsigned long long* out, int reset) {
-#ifdef EHM3_PROFILE
-    unsigned long long zero[32] = {0};
-    if (hipMemcpyFromSymbol(out, HIP_SYMBOL(EHM3_NS::g_prof3), sizeof zero) != hipSuccess) return -1;
-    if (reset && hipMemcpyToSymbol(HIP_SYMBOL(EHM3_NS::g_prof3), zero, sizeof zero) != hipSuccess)
-        return -1;
-    return 1;
-#else
-    for (int k = 0; k < 32; ++k) out[k] = 0;
-    (void)reset;
-    return 0;
-#endif
-}
-
-#define K3_CAT2(a, b) a##b
-#define K3_CAT(a, b) K3_CAT2(a, b)
-extern "C" const ehm::K2Api* K3_CAT(ehm_k3_api_, EHM3_RS)() { return &g_api; }
+extern "C" const ehm::K2Api* ehm_k4_api() { return &g_api; }

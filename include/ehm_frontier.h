@@ -40,6 +40,11 @@
 #ifdef __cplusplus
 extern "C" {
 #endif
+/* libehmpc.so is built with -fvisibility=hidden: the entry points declared in this header (and
+ * in the other two public headers) are its whole exported surface. */
+#if defined(__GNUC__)
+#pragma GCC visibility push(default)
+#endif
 
 typedef struct ehm_frontier ehm_frontier;
 struct ehm_problem;
@@ -183,6 +188,9 @@ int ehm_frontier_lp_counts(const ehm_frontier* f, int64_t* out);
 int ehm_frontier_condense(const ehm_pwa_law* law, int32_t horizon, int32_t len,
                           const int32_t* prefix, int32_t dims[2], double* G, double* w, double* S);
 
+#if defined(__GNUC__)
+#pragma GCC visibility pop
+#endif
 #ifdef __cplusplus
 }
 #endif

@@ -38,6 +38,11 @@
 #ifdef __cplusplus
 extern "C" {
 #endif
+/* libehmpc.so is built with -fvisibility=hidden: the entry points declared in this header (and
+ * in the other two public headers) are its whole exported surface. */
+#if defined(__GNUC__)
+#pragma GCC visibility push(default)
+#endif
 
 typedef struct ehm_search ehm_search;
 
@@ -126,6 +131,9 @@ int ehm_search_bare_result(const ehm_search_bare* b, int8_t* closed, double* mar
 int ehm_search_bare_learned(const ehm_search_bare* b, int32_t j, int64_t* count, uint64_t* code,
                             double* t);
 
+#if defined(__GNUC__)
+#pragma GCC visibility pop
+#endif
 #ifdef __cplusplus
 }
 #endif

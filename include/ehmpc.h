@@ -29,6 +29,11 @@
 #ifdef __cplusplus
 extern "C" {
 #endif
+/* libehmpc.so is built with -fvisibility=hidden: the entry points declared in this header (and
+ * in the other two public headers) are its whole exported surface. */
+#if defined(__GNUC__)
+#pragma GCC visibility push(default)
+#endif
 
 #define EHM_OK              0
 #define EHM_E_INVALID      -1   /* bad argument / unsupported dimension */
@@ -513,6 +518,9 @@ int ehm_selftest(int device, double* out, int32_t max_instances, int32_t* n_inst
 const char* ehm_last_error(void);
 const char* ehm_version(void);
 
+#if defined(__GNUC__)
+#pragma GCC visibility pop
+#endif
 #ifdef __cplusplus
 }
 #endif

@@ -33,7 +33,7 @@ def both(gp, fn):
 def test_wave_primitives_of_every_instance():
     from explicit_hybrid_mpc_amd import engine
     out = engine.selftest()
-    assert out.shape[0] == 30     # 28 wave-local + 2 wide instances
+    assert out.shape[0] == 31     # 28 wave-local + 2 streaming wide + the LDS-resident wide family
     assert np.abs(out - np.array([1072., 99., 25., 1. / 3., -1.])).max() < 1e-13
 
 

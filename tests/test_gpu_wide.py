@@ -34,7 +34,7 @@ def wide(request):
 def test_selftest_covers_the_wide_instances():
     from explicit_hybrid_mpc_amd import engine
     out = engine.selftest()
-    assert out.shape[0] == 30
+    assert out.shape[0] == 31
     assert np.abs(out - np.array([1072., 99., 25., 1. / 3., -1.])).max() < 1e-13
 
 
