@@ -51,7 +51,7 @@ MIDFIRST = '-DEHM_PERSIST_MIDFIRST=1'
 # -fvisibility=hidden: the library exports what include/*.h declare (a visibility pragma there)
 # and nothing else -- not the dispatch tables the objects hand each other (ehm_k2_api_* ...)
 FLAGS = ['--offload-arch=gfx950', '-O3', '-std=c++17', '-fPIC', '-Wno-unused-result',
-         '-fvisibility=hidden']
+         '-fvisibility=hidden', '-fvisibility-inlines-hidden']
 # experiments: extra -D flags and an alternative output name, e.g.
 #   EHM_BUILD_FLAGS="-DEHM2_UNROLL=2" EHM_BUILD_TAG=u2 python -m explicit_hybrid_mpc_amd.build
 FLAGS += os.environ.get('EHM_BUILD_FLAGS', '').split()
@@ -75,12 +75,38 @@ def _cxx():
     return _hipcc()
 
 
-def _dep_mtime(public=True):
-    """Newest dependency: the csrc/ headers (every object), the public header (the C-ABI object
-    and the staleness test of the library only: the kernel objects do not include it)."""
-    deps = [os.path.join(SRC_DIR, h) for h in HEADERS if public or not h.startswith('..')]
+_INC_CACHE = {}
+
+
+def _includes(path):
+    """The quoted #include files of a source, transitively (paths normalised)."""
+    path = os.path.normpath(path)
+    if path in _INC_CACHE:
+        return _INC_CACHE[path]
+    _INC_CACHE[path] = found = set()
+    try:
+        text = open(path).read()
+    except OSError:
+        return found
+    import re
+    for inc in re.findall(r'^\s*#\s*include\s+"([^"]+)"', text, flags=re.M):
+        dep = os.path.normpath(os.path.join(os.path.dirname(path), inc))
+        if os.path.exists(dep):
+            found.add(dep)
+            found |= _includes(dep)
+    return found
+
+
+def _dep_mtime(src=None):
+    """Newest dependency of an object: the headers its source includes (transitively; derived
+    from the #include lines, so none can be forgotten) and this file.  src=None: every header
+    (the staleness test of the library)."""
+    if src is None:
+        deps = [os.path.normpath(os.path.join(SRC_DIR, h)) for h in HEADERS]
+    else:
+        deps = list(_includes(src))
     deps += [__file__]
-    return max(os.path.getmtime(os.path.normpath(d)) for d in deps)
+    return max(os.path.getmtime(d) for d in deps)
 
 
 SEARCH_SRC = os.path.join(SRC_DIR, 'ehm_search.cpp')      # host C++ only (include/ehm_search.h)
@@ -167,10 +193,7 @@ def build(force=False, verbose=False, jobs=None):
     os.makedirs(OBJ_DIR, exist_ok=True)
     _regenerate_kp()
     hipcc = _hipcc()
-    dep_t, dep_k = _dep_mtime(), _dep_mtime(public=False)
-    todo = [(o, s, f) for (o, s, f) in _objects()
-            if force or _stale(o, s, dep_t if os.path.basename(s) in (
-                'ehm_capi.hip', 'ehm_explicit.hip') else dep_k)]
+    todo = [(o, s, f) for (o, s, f) in _objects() if force or _stale(o, s, _dep_mtime(s))]
 
     def compile_one(item):
         obj, src, extra = item
@@ -186,8 +209,8 @@ def build(force=False, verbose=False, jobs=None):
     for obj, src, deps in HOST_OBJECTS:
         if force or not os.path.exists(obj) or \
                 os.path.getmtime(obj) < max(os.path.getmtime(d) for d in deps):
-            cmd = [_cxx(), '-O2', '-std=c++17', '-fPIC', '-Wall', '-fvisibility=hidden', '-c', src, '-o',
-                   obj]
+            cmd = [_cxx(), '-O2', '-std=c++17', '-fPIC', '-Wall', '-fvisibility=hidden', '-fvisibility-inlines-hidden',
+                   '-c', src, '-o', obj]
             if verbose:
                 print(' '.join(cmd))
             subprocess.check_call(cmd)

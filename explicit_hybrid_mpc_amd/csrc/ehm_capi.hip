@@ -639,6 +639,18 @@ static const K2Api* k2_pick(int n_lp, int slots, bool quad, const DevProblem* dp
         for (k2_getter g : g_k2q_getters) consider(g());
     } else {
         for (k2_getter g : g_k2_getters) consider(g());
+        // Where both fit, the LDS-resident wide family takes the LPs at the upper end of the
+        // shared-block instances: at >= EHM_K4_MIN_NP factorised columns and 4 row slots one
+        // wavefront per LP keeps its rows in 4 x 10 register pairs and the forced-inline solver
+        // spills (configs[4], horizon-5 table: 3.0 us per LP against the wide family's 1.7).
+        static const int k4_min_np = [] {
+            const char* e = getenv("EHM_K4_MIN_NP");
+            return e ? atoi(e) : 24;
+        }();
+        const K2Api* k4 = ehm_k4_api();
+        if (best && best != k4 && best->threads_per_lp == 64 && n_lp >= k4_min_np && slots >= 4 &&
+            !no_k4 && dp && k4->np >= n_lp && k4->slots >= slots && k4->fits(*dp, EHM_LDS_BUDGET))
+            best = k4;
     }
     return best;
 }

@@ -702,7 +702,9 @@ int dev_split(void* user, int64_t n, const double* R, double* S1, double* S2, in
 }  // namespace
 
 // ---- the driver -------------------------------------------------------------------------------
-struct ehm_frontier {
+// (hidden: the header forward-declares the handle type inside its visibility pragma, which would
+// otherwise export every member function)
+struct __attribute__((visibility("hidden"))) ehm_frontier {
     int p = 0, nv = 0, n_u = 0, n_modes = 0, N = 0;
     uint64_t base = 1;
     std::vector<uint64_t> pw;

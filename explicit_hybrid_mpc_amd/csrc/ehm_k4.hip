@@ -11,25 +11,18 @@
 
 using namespace ehm;
 
-extern __shared__ __attribute__((aligned(16))) char k4_smem[];
-
 namespace ehm4 {
 
+// node record / parameter / gradient buffers: fixed offsets of the workgroup's LDS (ehm_ipm4.h)
 struct NodeBuf {
     double* rec;    // node record / simplex vertices (+ vertex costs)
     double* th;     // p doubles (parameter / midpoint)
-    double* red;    // workgroup reductions
     double* g;      // p doubles: gradient of the optimal cost from a point solve
 };
-__host__ __device__ inline size_t node_doubles(int p, int n_u) {
-    return (size_t)((rec_doubles(p, n_u) + 7) & ~7) + 8 + 2 * NWV * 8 + 8;
-}
-__device__ __forceinline__ void carve_node(NodeBuf& nb, double* base, int p, int n_u) {
-    const int nrec = (rec_doubles(p, n_u) + 7) & ~7;
-    nb.rec = base;
-    nb.th = base + nrec;
-    nb.red = nb.th + 8;
-    nb.g = nb.red + 2 * NWV * 8;
+__device__ __forceinline__ void carve_node(NodeBuf& nb) {
+    nb.rec = lds_at(O_REC);
+    nb.th = lds_at(O_TH);
+    nb.g = lds_at(O_G);
 }
 
 __device__ __forceinline__ unsigned long long low_bits(int k) {
@@ -49,18 +42,18 @@ __device__ __forceinline__ double assemble_point(const Blk& S, Lp& L, const doub
     L.spec_mpc = feas ? 1 : 0;
     L.act = low_bits(nd0) | (feas ? (1ULL << (nd0 + p)) : 0ULL);
     if (tid < NC) {
-        L.c[tid] = 0.0;
-        L.X[tid] = 0.0;
-        L.X[NC + tid] = 0.0;
+        L.c()[tid] = 0.0;
+        L.X()[tid] = 0.0;
+        L.X()[NC + tid] = 0.0;
     }
     __syncthreads();
     if (feas) {
         if (tid == 0) {
-            L.c[nd0 + p] = 1.0;
-            L.X[nd0 + p] = -1.0;            // dense row 0:  -tau <= 1
+            L.c()[nd0 + p] = 1.0;
+            L.X()[nd0 + p] = -1.0;            // dense row 0:  -tau <= 1
         }
     } else if (tid < n) {
-        L.c[zcol(S, tid)] = S.cv[tid];
+        L.c()[zcol(S, tid)] = S.cv[tid];
     }
     double v = 0.0;
     if (tid < m) {
@@ -93,41 +86,41 @@ __device__ __forceinline__ double assemble_simplex(const Blk& S, Lp& L, const do
     L.spec_mpc = feas ? 1 : 0;
     L.act = low_bits(nd0 + p + ((slack || feas) ? 1 : 0));
     if (tid < NC) {
-        L.c[tid] = 0.0;
-        L.X[tid] = 0.0;
-        L.X[NC + tid] = 0.0;
+        L.c()[tid] = 0.0;
+        L.X()[tid] = 0.0;
+        L.X()[NC + tid] = 0.0;
     }
     if (tid >= 64 && tid < 64 + p * p) {
         const int k = tid - 64;
         const int r = k / p, q = k - r * p;
-        L.E[k] = R[(q + 1) * p + r] - R[r];
+        L.E()[k] = R[(q + 1) * p + r] - R[r];
     }
     __syncthreads();
     if (slack) {
         if (tid < n) {
             const double cj = S.cv[tid];
             const int zc = zcol(S, tid);
-            L.X[zc] = cj;
-            L.X[NC + zc] = fma(eps_r, cj, cj);      // (1 + eps_r) c_j
+            L.X()[zc] = cj;
+            L.X()[NC + zc] = fma(eps_r, cj, cj);      // (1 + eps_r) c_j
         }
         if (tid >= 64 && tid < 64 + p) {
             const int q = tid - 64;
             const double dv = Vbar[q + 1] - Vbar[0];
-            L.X[nd0 + q] = -dv;
-            L.X[NC + nd0 + q] = -dv;
+            L.X()[nd0 + q] = -dv;
+            L.X()[NC + nd0 + q] = -dv;
         }
         if (tid == 128) {
-            L.X[nd0 + p] = 1.0;
-            L.X[NC + nd0 + p] = 1.0;
-            L.c[nd0 + p] = -1.0;
+            L.X()[nd0 + p] = 1.0;
+            L.X()[NC + nd0 + p] = 1.0;
+            L.c()[nd0 + p] = -1.0;
         }
     } else if (feas) {
         if (tid == 0) {
-            L.X[nd0 + p] = -1.0;            // -tau <= 1
-            L.c[nd0 + p] = 1.0;
+            L.X()[nd0 + p] = -1.0;            // -tau <= 1
+            L.c()[nd0 + p] = 1.0;
         }
     } else if (tid < n) {
-        L.c[zcol(S, tid)] = S.cv[tid];
+        L.c()[zcol(S, tid)] = S.cv[tid];
     }
     double v = 0.0;
     if (tid < m) {
@@ -162,13 +155,11 @@ __device__ __forceinline__ void count_solve(DevCounters* cnt, const IpmResult& r
     B.wave = __builtin_amdgcn_readfirstlane(tid0 >> 6);                          \
     B.flip = 0;                                                                  \
     NodeBuf nb;                                                                  \
-    carve_node(nb, sm, P.p, P.n_u);                                              \
-    B.red = nb.red;                                                              \
+    carve_node(nb);                                                              \
     Blk S;                                                                       \
-    carve_blk(S, sm + node_doubles(P.p, P.n_u), P);                              \
+    carve_blk(S, sm + O_VAR + lp_doubles(P.m, P.p, P.nd0, P.n - P.nd0), P);      \
     Lp L;                                                                        \
-    carve_lp(L, sm + node_doubles(P.p, P.n_u) +                                  \
-                 blk_doubles(P.m, P.p, P.nd0, P.n - P.nd0, P.LE4), S)
+    carve_lp(L, sm + O_VAR, S)
 
 // the block of commutation d into LDS (all threads; barriers on both sides)
 #define K4_USE_BLOCK(D)                                                          \
@@ -222,7 +213,7 @@ EHM4_KERNEL void k4_point_batch(
             if (status) status[o] = ehm_status_word(r.status, r.merit);
             if (iters) iters[o] = r.iters;
         }
-        if (u0 && tid < P.n_u) u0[o * P.n_u + tid] = L.xb[tid];
+        if (u0 && tid < P.n_u) u0[o * P.n_u + tid] = L.xb()[tid];
         __syncthreads();
     }
 }
@@ -276,7 +267,7 @@ EHM4_KERNEL void k4_simplex_batch(
             if (iters) iters[o] = r.iters;
         }
         if (alpha && B.wave == 0) {
-            const double beta = (tid < p) ? L.xb[S.nd0 + tid] : 0.0;
+            const double beta = (tid < p) ? L.xb()[S.nd0 + tid] : 0.0;
             const double sb = wave_sum(beta);
             if (tid < p) alpha[o * (p + 1) + tid + 1] = beta;
             if (tid == 0) alpha[o * (p + 1)] = 1.0 - sb;
@@ -371,9 +362,9 @@ EHM4_KERNEL void k4_lcss_decide(
             const bool ok = sign_only && r.status == 0 && -r.obj >= 0.0;
             double* wv = T.wit + (size_t)id * (P.p + 2);
             double cz = 0.0;
-            for (int q = B.lane; q < P.n; q += 64) cz = fma(S.cv[q], L.xb[zcol(S, q)], cz);
+            for (int q = B.lane; q < P.n; q += 64) cz = fma(S.cv[q], L.xb()[zcol(S, q)], cz);
             cz = wave_sum(cz);
-            const double beta = (B.lane < P.p) ? L.xb[S.nd0 + B.lane] : 0.0;
+            const double beta = (B.lane < P.p) ? L.xb()[S.nd0 + B.lane] : 0.0;
             const double sb = wave_sum(beta);
             if (B.lane < P.p) wv[2 + B.lane] = ok ? beta : 0.0;
             if (B.lane == 0) {
@@ -461,7 +452,7 @@ EHM4_KERNEL void k4_lcss_expand(
                     const double ev = mt_read(T.mt, mt_slot, B.lane, mid, p, &same);
                     if (B.lane == 8) s_mtv[0] = ev;
                     if (B.lane == 9) s_mtv[1] = ev;
-                    if (B.lane >= 10 && B.lane < 10 + n_u) L.xb[B.lane - 10] = ev;
+                    if (B.lane >= 10 && B.lane < 10 + n_u) L.xb()[B.lane - 10] = ev;
                     if (T.grad && B.lane >= 18 && B.lane < 18 + p) nb.g[B.lane - 18] = ev;
                     if (B.lane == 0) s_mt[2] = same ? 1 : 0;
                 }
@@ -489,7 +480,7 @@ EHM4_KERNEL void k4_lcss_expand(
                 __syncthreads();
                 if (B.wave == 0)
                     mt_publish(T.mt, mt_slot, mt_tg, B.lane, mid, p, r.obj, r.status,
-                               (r.status == 0 && r.merit <= 1.0) ? 1 : 0, its, L.xb, n_u,
+                               (r.status == 0 && r.merit <= 1.0) ? 1 : 0, its, L.xb(), n_u,
                                T.grad ? nb.g : nullptr);
             }
         }
@@ -533,8 +524,8 @@ EHM4_KERNEL void k4_lcss_expand(
                 if (k - ov == bj) v1 = r.obj;
             } else {                            // vertex inputs
                 const int q = k - ou;
-                if (q >= bi * n_u && q < bi * n_u + n_u) v0 = L.xb[q - bi * n_u];
-                if (q >= bj * n_u && q < bj * n_u + n_u) v1 = L.xb[q - bj * n_u];
+                if (q >= bi * n_u && q < bi * n_u + n_u) v0 = L.xb()[q - bi * n_u];
+                if (q >= bj * n_u && q < bj * n_u + n_u) v1 = L.xb()[q - bj * n_u];
             }
             rec0[k] = v0;
             rec1[k] = v1;
@@ -591,25 +582,23 @@ EHM4_KERNEL void k4_vertex_solve(
         if (r.status != 0 && tid == 0) atomicAdd(&cnt->errors, 1ULL);
         if (T.grad && tid < p) T.grad[((size_t)id * (p + 1) + v) * p + tid] = nb.g[tid];
         if (tid == 0) rec[rec_off_vcost(p) + v] = r.obj;
-        if (tid < n_u) rec[rec_off_vinput(p) + v * n_u + tid] = L.xb[tid];
+        if (tid < n_u) rec[rec_off_vinput(p) + v * n_u + tid] = L.xb()[tid];
         __syncthreads();
     }
 }
 
 // ---- self test: workgroup reductions, the quad sum and one 16x16x4 tile product -----------
 __global__ __launch_bounds__(EHM4_THREADS) void k4_selftest(double* out) {
-    __shared__ double red[2 * NWV * 8];
     Ctx B;
     B.tid = threadIdx.x;
     B.lane = threadIdx.x & 63;
     B.wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     B.flip = 0;
-    B.red = red;
     const int tid = B.tid;
     // sum(1 + 0.5 k, k < 64) = 1072 from the first wavefront only
     double mx[2] = {(tid == 137) ? 99.0 : -(double)tid, -1.0 - tid};
     double sm[4] = {(tid < 64) ? 1.0 + 0.5 * tid : 0.0, (tid < 25) ? 1.0 : 0.0, 0.0, 0.0};
-    block_reduce(B, mx, sm);
+    block_reduce<2, 4>(B, mx, sm);
     // D = A B with A[i][k] = i + 1, B[k][j] = (k == 0): D[i][j] = i + 1; trace / 16 = 8.5
     const int li = B.lane & 15, lk = B.lane >> 4;
     double4v C = {0.0, 0.0, 0.0, 0.0};
@@ -657,7 +646,7 @@ hipError_t set_lds(int bytes) {
 
 // LDS doubles of the LP in flight (+ the node buffer); the block is the "shared" part
 size_t unit_doubles_for(const DevProblem& P, int /*n_lp*/, int /*ne*/, int /*persist*/) {
-    return (node_doubles(P.p, P.n_u) + lp_doubles(P.m, P.p, P.nd0, P.n - P.nd0) + 1) & ~(size_t)1;
+    return ((size_t)O_VAR + lp_doubles(P.m, P.p, P.nd0, P.n - P.nd0) + 1) & ~(size_t)1;
 }
 size_t shared_doubles_for(const DevProblem& P) {
     return blk_doubles(P.m, P.p, P.nd0, P.n - P.nd0, P.LE4);
@@ -667,7 +656,7 @@ int fits(const DevProblem& P, int lds_budget_bytes) {
     const int nE = P.n - P.nd0;
     if (P.nd0 + P.p + 1 > NF || nE > MAXNE) return 0;
     if (((P.m + 3) & ~3) + P.p + 3 > NT) return 0;
-    if (P.n_u > P.nd0 || P.p * P.p + 64 > NT) return 0;
+    if (P.n_u > P.nd0 || P.p * P.p + 64 > NT || rec_doubles(P.p, P.n_u) > 160) return 0;
     const size_t need = (shared_doubles_for(P) + unit_doubles_for(P, 0, 0, 0)) * sizeof(double);
     return need <= (size_t)lds_budget_bytes ? 1 : 0;
 }
@@ -726,7 +715,8 @@ void l_vertex(const K2Launch& L, DevProblem P, DevTree T, const int32_t* nodes, 
                            P, T, nodes, n_nodes, cnt);
 }
 void l_selftest(hipStream_t stream, double* out) {
-    hipLaunchKernelGGL(k4_selftest, dim3(1), dim3(EHM4_THREADS), 0, stream, out);
+    hipLaunchKernelGGL(k4_selftest, dim3(1), dim3(EHM4_THREADS), O_VAR * sizeof(double), stream,
+                       out);
 }
 
 // np = 48 factorised columns; slots in units of 64 rows; one LP per workgroup of 512 threads
@@ -737,3 +727,20 @@ const K2Api g_api = {NF,       EHM4_THREADS / 64, EHM4_THREADS, EHM4_THREADS, se
 }  // namespace
 
 extern "C" const ehm::K2Api* ehm_k4_api() { return &g_api; }
+
+// phase timers of an experimental build (-DEHM4_PROFILE; a diagnostic hook outside include/*.h,
+// exported by hand); zeros otherwise
+extern "C" __attribute__((visibility("default"))) int ehm_k4_profile(unsigned long long* out,
+                                                                     int reset) {
+#ifdef EHM4_PROFILE
+    unsigned long long zero[40] = {0};
+    if (hipMemcpyFromSymbol(out, HIP_SYMBOL(ehm4::g_prof4), sizeof zero) != hipSuccess) return -1;
+    if (reset && hipMemcpyToSymbol(HIP_SYMBOL(ehm4::g_prof4), zero, sizeof zero) != hipSuccess)
+        return -1;
+    return 1;
+#else
+    for (int k = 0; k < 40; ++k) out[k] = 0;
+    (void)reset;
+    return 0;
+#endif
+}

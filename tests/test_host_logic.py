@@ -39,6 +39,16 @@ def test_library_exports_every_declared_symbol():
     for name in declared:
         assert hasattr(lib, name), name
         assert re.search(r'\bT %s\b' % name, out), name
+    # ... and NOTHING else: the library is built with -fvisibility=hidden, its exported functions
+    # are what the three public headers declare plus the profile hooks of experimental builds
+    every = set()
+    for h in ('ehmpc.h', 'ehm_search.h', 'ehm_frontier.h'):
+        text = open(os.path.join(ROOT, 'include', h)).read()
+        every |= set(re.findall(r'\b(ehm_[a-z0-9_]+)\s*\(', text))
+    every -= {'ehm_problem_desc', 'ehm_run_opts'}
+    exported = set(re.findall(r'\bT (\S+)', out))
+    hooks = {'ehm_k3_profile_2', 'ehm_k3_profile_4', 'ehm_k4_profile'}
+    assert exported - hooks == every, sorted((exported - hooks) ^ every)
 
 
 def test_no_cpu_fallback_without_a_gpu():
