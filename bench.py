@@ -255,7 +255,8 @@ def parse_args(argv=None):
     ap.add_argument('--steps', type=int, default=3)
     ap.add_argument('--warmup', type=int, default=1)
     ap.add_argument('--seed', type=int, default=0)
-    ap.add_argument('--workload', choices=['config2', 'config3', 'config4', 'config2q', 'config5'],
+    ap.add_argument('--workload', choices=['config2', 'config3', 'config4', 'config2q', 'config5',
+                                           'explicit'],
                     default='config2',
                     help='config2 = the BASELINE.json metric (default); config3 = the 2-mode PWA '
                          'hybrid instance (32 commutations, mixed-integer oracles on the device '
@@ -289,6 +290,8 @@ def parse_args(argv=None):
                          'progress read-back (and, N > 1, one all-gather) per round -- off by '
                          'default, the headline number is measured without it')
     ap.add_argument('--cpu-seconds', type=float, default=15.)
+    ap.add_argument('--queries', type=int, default=1 << 21,
+                    help='explicit: states evaluated per step')
     ap.add_argument('--secondary-cpu-seconds', type=float, default=6.,
                     help='CPU-baseline time of each entry of the "secondary" list')
     ap.add_argument('--no-secondary', action='store_true',
@@ -1192,6 +1195,127 @@ def measure_config5(args, ctx):
 
 
 # what the default invocation measures after the headline: (workload, steps, warmup)
+# ---- f2: batched evaluation of the explicit law ---------------------------
+def _explicit_cpu_worker(job):
+    """cpu_baseline leg of --workload explicit (test infrastructure: oracle/explicit_cpu.py)."""
+    path, seconds, seed = job
+    from oracle.explicit_cpu import ExplicitFlatCPU
+    d = np.load(path)
+    cpu = ExplicitFlatCPU(d['vertices'], d['vinput'], d['left'], d['right'], int(d['n_roots']))
+    X = d['X']
+    rng = np.random.default_rng(seed)
+    t0 = time.perf_counter()
+    n = 0
+    while time.perf_counter() - t0 < seconds:
+        cpu(X[rng.integers(X.shape[0])])
+        n += 1
+    return n, time.perf_counter() - t0
+
+
+def measure_explicit(args, ctx):
+    """
+    Evaluations per second of the explicit law (csrc/ehm_explicit.hip; the reference's
+    ExplicitMPC.__call__, lib/mpc_library.py:737-792, whose evaluation time is the headline of the
+    reference's README): the partition of the headline workload (1.6 M nodes, 22 roots, p = 4),
+    and the root location over the 34 871 Delaunay roots of a p = 8 box (the spine of configs[4]).
+    """
+    import tempfile
+    from explicit_hybrid_mpc_amd import engine, examples, explicit
+    from explicit_hybrid_mpc_amd import tools as ehm_tools
+    device_index = ctx['device_index']
+    out_cases = []
+    n_q = args.queries
+    rng = np.random.default_rng(args.seed)
+
+    def run_case(name, flat, half, note):
+        ex = explicit.ExplicitMPC(flat, device=device_index)
+        X = rng.uniform(-1, 1, (n_q, half.size)) * half
+        ex.evaluate(X[:1024])                                   # warm-up
+        secs, walls, visited = [], [], None
+        for _ in range(max(1, args.steps)):
+            t0 = time.perf_counter()
+            u, leaf, visited, ks = ex.evaluate(X, return_info=True)
+            walls.append(time.perf_counter() - t0)
+            secs.append(ks)
+        ks = float(np.mean(secs))
+        p, n_u = ex.p, ex.n_u
+        rec_bytes = 8 * (((p + p * p + 7) // 8) * 8)
+        # algorithmic bytes: one record per containment test, the child pair per level, the leaf's
+        # record + vertex inputs, the query in and the input out
+        tests = float(np.sum(visited))
+        alg = tests * (rec_bytes + 8) + n_q * (rec_bytes + 8 * (p + 1) * n_u + 8 * p + 8 * n_u)
+        case = {
+            'name': name, 'note': note, 'queries': n_q, 'nodes': int(flat.n_nodes),
+            'roots': int(flat.info['n_roots']), 'p': p, 'n_u': n_u,
+            'evaluations_per_s': n_q / ks, 'kernel_ms': ks * 1e3,
+            'evaluations_per_s_with_host_copies': n_q / float(np.mean(walls)),
+            'containment_tests_per_query': tests / n_q,
+            'roofline': {'bound': 'hbm', 'kernel': 'k_explicit_eval' +
+                         (' + k_explicit_locate' if flat.info['n_roots'] >= 128 else ''),
+                         'achieved': alg / ks / 1e9, 'peak': 8000.0, 'unit': 'GB/s',
+                         'frac': alg / ks / 8e12, 'traffic': None,
+                         'algorithmic_bytes_per_launch': alg,
+                         'note': 'a walk reads one 64-byte-aligned record per test: latency-bound '
+                                 'pointer chasing through L2 / MALL, not a stream'}}
+        if not args.no_cpu_baseline:
+            import multiprocessing as mp
+            cores = usable_cores()
+            with tempfile.TemporaryDirectory() as td:
+                path = os.path.join(td, 'tree.npz')
+                np.savez(path, vertices=flat.vertices, vinput=flat.vertex_inputs, left=flat.left,
+                         right=flat.right, n_roots=flat.info['n_roots'], X=X[:4096])
+                with mp.get_context('spawn').Pool(cores) as pool:
+                    res = pool.map(_explicit_cpu_worker,
+                                   [(path, args.cpu_seconds, args.seed + k) for k in range(cores)])
+            case['cpu_baseline'] = {
+                'value': sum(r[0] for r in res) / max(r[1] for r in res), 'unit': 'evaluations/s',
+                'cores': cores, 'kind': 'port',
+                'sample': '%d processes, each the walk of lib/mpc_library.py:737-792 restated on '
+                          'the flat arrays (oracle/explicit_cpu.ExplicitFlatCPU, numpy) for %.0f s '
+                          'over queries drawn from the same batch' % (cores, args.cpu_seconds)}
+        ex.close()
+        return case
+
+    # (a) the headline partition
+    mpc = make_mpc('config2', args.seed)
+    gp = engine.GpuProblem(mpc.compile(), 1., 1., device=device_index)
+    half = examples.theta_box(mpc)
+    V = examples.box_vertices(half)
+    J_abs, _, _ = gp.solve_pt(0.02 * V)
+    gp.set_eps(float(np.max(J_abs)), 1e-2)
+    roots, _ = ehm_tools.delaunay_roots(V)
+    flat = gp.partition(roots, action='ecc', export=True, with_volume=False)
+    gp.close()
+    out_cases.append(run_case('headline_tree', flat, half,
+                              'partition of configs[1] (eps_r 0.01, abs_frac 0.02), uniform states'))
+    # (b) root location over the spine of a p = 8 box (the roots of configs[4], none grown: what is
+    # measured is the walk over the right spine, lib/mpc_library.py:760-766)
+    mpc8 = examples.pwa4_mpc(N=CONFIG5['N'], seed=args.seed)
+    half8 = examples.theta_box(mpc8)
+    roots8, _ = ehm_tools.delaunay_roots(examples.box_vertices(half8))
+    roots8 = np.asarray(roots8, dtype=np.float64)
+    K, p8 = roots8.shape[0], roots8.shape[2]
+    n_u8 = mpc8.n_u if hasattr(mpc8, 'n_u') else 3
+    leafs = -np.ones(K, dtype=np.int32)
+    flat8 = engine.FlatTree(roots8, leafs, leafs.copy(), np.zeros(K, dtype=np.int32),
+                            np.zeros((K, p8 + 1)), np.zeros((K, p8 + 1, n_u8)),
+                            np.zeros(K, dtype=np.uint8), np.zeros(K), {'n_roots': K}, None)
+    out_cases.append(run_case('p8_spine', flat8, half8,
+                              'the %d Delaunay roots of the p = 8 box of configs[4] as leaves: root '
+                              'location only (one wavefront per query, 64 roots per step)' % K))
+    head = out_cases[0]
+    return {
+        'metric': 'explicit-law evaluations/s (SURVEY 8 f2; NOT the headline metric of BASELINE.json)',
+        'value': head['evaluations_per_s'], 'unit': 'evaluations/s', 'n_gpus': 1,
+        'steps': max(1, args.steps), 'warmup': 1, 'ms_per_step': head['kernel_ms'],
+        'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None, 'dtype': 'f64',
+        'data': 'synthetic',
+        'config': {'workload': 'explicit: %d uniform states per step through the partition of '
+                               'configs[1] (%d nodes)' % (n_q, head['nodes'])},
+        'roofline': head['roofline'], 'cpu_baseline': head.get('cpu_baseline'),
+        'cases': out_cases}
+
+
 SECONDARY = (('config3', 2, 1), ('config4', 2, 1), ('config2q', 5, 2), ('config5', 1, 0))
 SECONDARY_KEYS = ('value', 'unit', 'ms_per_step', 'regions_per_s', 'oracle_calls_answered_per_s',
                   'steps', 'warmup', 'roofline', 'cpu_baseline')
@@ -1250,7 +1374,8 @@ def main():
     ctx = dict(backend=backend, rank=rank, world=world, device_index=device_index)
     rc = 0
     try:
-        out = (measure_config5 if args.workload == 'config5' else measure)(args, ctx)
+        out = (measure_config5 if args.workload == 'config5' else
+               measure_explicit if args.workload == 'explicit' else measure)(args, ctx)
         if (rank == 0 and world == 1 and args.workload == 'config2' and not args.no_secondary
                 and not args.status_dir):
             out['secondary'] = [secondary_line(args, ctx, *w) for w in SECONDARY]

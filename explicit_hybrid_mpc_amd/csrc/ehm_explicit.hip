@@ -20,13 +20,17 @@
 
 #include <cstdarg>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
+#include <algorithm>
 #include <string>
+#include <unordered_map>
 #include <vector>
 
 #include "../../include/ehmpc.h"
 
 #define EHM_XP 8   // max parameter dimension (EHM_MAX_P)
+#define EHM_X_LOCATE_MIN 128     // spines at least this long get the root locator
 
 namespace {
 
@@ -105,23 +109,96 @@ __device__ __forceinline__ bool weights(const DevExplicit& E, long long k, const
     return in && (alpha0 >= -eps) && (alpha0 <= 1.0 + eps);
 }
 
+// Containment only, the coordinates tested one after the other and the test left at the first
+// weight outside [-eps, 1+eps]: the SAME sums in the same order as `weights`, so the verdict is
+// bit-identical -- but a root that does not hold x is usually dismissed after one or two rows of
+// Minv instead of p (the spine walk reads 3p instead of p + p^2 doubles per dismissed root).
+__device__ __forceinline__ bool contains(const DevExplicit& E, long long k, const double* x) {
+    const double* r = E.rec + (size_t)k * E.rec_stride;
+    const int p = E.p;
+    const double eps = 2.220446049250313e-16;
+    double d[EHM_XP];
+    for (int c = 0; c < p; ++c) d[c] = x[c] - r[c];
+    double s = 0.0;
+    for (int q = 0; q < p; ++q) {
+        double a = 0.0;
+        for (int c = 0; c < p; ++c) a += r[p + q * p + c] * d[c];
+        if (!((a >= -eps) && (a <= 1.0 + eps))) return false;
+        s += a;
+    }
+    const double a0 = 1.0 - s;
+    return (a0 >= -eps) && (a0 <= 1.0 + eps);
+}
+
+// Root locator for long spines (tools.delaunay of a p = 8 box: 34 871 roots).  The reference walks
+// the right spine and takes the FIRST root, in spine order, that contains x
+// (lib/mpc_library.py:737-767): 17 000 containment tests per state on that spine, and one
+// wavefront per query testing 64 roots at a time costs the same lane-steps (measured: 0.85 M
+// against 0.95 M states/s).  The roots are a triangulation, so a state in the INTERIOR of a root
+// (every barycentric weight > EHM_X_STRICT) is in no other root and the first one in spine order
+// is that one -- found by a visibility walk over the face adjacency of the roots (built at
+// set-up): from the current root cross the face opposite its most negative weight.  A state
+// within EHM_X_STRICT of a face, a walk that leaves the hull or does not end in EHM_X_STEPS steps
+// gets root = -1 and the reference's serial walk (k_explicit_eval): same leaf in every case.
+#define EHM_X_STRICT 1e-9
+#define EHM_X_STEPS 96
+__global__ void k_explicit_locate(DevExplicit E, long long n, const double* __restrict__ X,
+                                  const int32_t* __restrict__ nbr, int32_t* __restrict__ root) {
+#pragma clang fp contract(off)
+    const long long q = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (q >= n) return;
+    const int p = E.p;
+    double x[EHM_XP], alpha[EHM_XP], a0;
+    for (int c = 0; c < p; ++c) x[c] = X[q * p + c];
+    int k = (int)(q % E.n_roots);           // any start: the walk is short from everywhere
+    int found = -1, steps = 0;
+    for (int step = 0; step < EHM_X_STEPS; ++step) {
+        ++steps;
+        (void)weights(E, k, x, alpha, a0);
+        double lo = a0;
+        int at = 0;
+        for (int i = 0; i < p; ++i)
+            if (alpha[i] < lo) {
+                lo = alpha[i];
+                at = i + 1;
+            }
+        if (lo > EHM_X_STRICT) {            // strictly inside: the only root that holds x
+            found = k;
+            break;
+        }
+        if (lo >= -EHM_X_STRICT) break;     // on a face: the serial walk decides
+        const int k2 = nbr[(size_t)k * (p + 1) + at];
+        if (k2 < 0) break;                  // left the hull (x outside the set, or rounding)
+        k = k2;
+    }
+    // (the containment tests made ride in the upper bits: `visited` reports the device's work)
+    root[q] = (found < 0) ? -1 : (found | (steps << 20));
+}
+
 __global__ void k_explicit_eval(DevExplicit E, long long n, const double* __restrict__ X,
                                 double* __restrict__ U, int32_t* __restrict__ leaf,
-                                int32_t* __restrict__ depth_out) {
+                                int32_t* __restrict__ depth_out,
+                                const int32_t* __restrict__ root) {
 #pragma clang fp contract(off)
     const long long q = (long long)blockIdx.x * blockDim.x + threadIdx.x;
     if (q >= n) return;
     const int p = E.p, n_u = E.n_u;
     double x[EHM_XP], alpha[EHM_XP], a0;
     for (int c = 0; c < p; ++c) x[c] = X[q * p + c];
-    // spine: first root that contains x, the last one without a test
+    // spine: first root that contains x, the last one without a test (found by k_explicit_locate
+    // where the spine is long; `visited` counts the tests the reference's walk makes)
     long long k = E.n_roots - 1;
     int visited = 0;
-    for (int r = 0; r + 1 < E.n_roots; ++r) {
-        ++visited;
-        if (weights(E, r, x, alpha, a0)) {
-            k = r;
-            break;
+    if (root && root[q] >= 0) {
+        k = root[q] & 0xfffff;
+        visited = root[q] >> 20;
+    } else {
+        for (int r = 0; r + 1 < E.n_roots; ++r) {
+            ++visited;
+            if (contains(E, r, x)) {
+                k = r;
+                break;
+            }
         }
     }
     // partition subtree: left iff inside the left child
@@ -129,7 +206,7 @@ __global__ void k_explicit_eval(DevExplicit E, long long n, const double* __rest
         const int2 ch = E.child[k];
         if (ch.x < 0) break;
         ++visited;
-        k = weights(E, ch.x, x, alpha, a0) ? ch.x : ch.y;
+        k = contains(E, ch.x, x) ? ch.x : ch.y;
     }
     (void)weights(E, k, x, alpha, a0);
     const double* vi = E.vinput + (size_t)k * (p + 1) * n_u;
@@ -159,7 +236,8 @@ struct ehm_explicit {
     int device = 0;
     DevExplicit d{};
     void *rec = nullptr, *child = nullptr, *vinput = nullptr;
-    void *x = nullptr, *u = nullptr, *leaf = nullptr, *depth = nullptr;
+    void *x = nullptr, *u = nullptr, *leaf = nullptr, *depth = nullptr, *root = nullptr;
+    void* nbr = nullptr;        // [n_roots][p+1] root across the face opposite vertex i (-1: hull)
     size_t cap = 0;
     hipStream_t stream = nullptr;
 };
@@ -171,7 +249,7 @@ const char* ehm_explicit_last_error(void) { return x_err.c_str(); }
 int ehm_explicit_destroy(ehm_explicit* E) {
     if (!E) return EHM_OK;
     (void)hipSetDevice(E->device);
-    for (void* p : {E->rec, E->child, E->vinput, E->x, E->u, E->leaf, E->depth})
+    for (void* p : {E->rec, E->child, E->vinput, E->x, E->u, E->leaf, E->depth, E->root, E->nbr})
         if (p) (void)hipFree(p);
     if (E->stream) (void)hipStreamDestroy(E->stream);
     delete E;
@@ -228,6 +306,40 @@ int ehm_explicit_create(int device, int64_t n_nodes, int32_t n_roots, int32_t p,
         ehm_explicit_destroy(E);
         return xfail(EHM_E_NUMERIC, "%d degenerate simplices in the partition", (int)sing);
     }
+    if (n_roots >= EHM_X_LOCATE_MIN && n_roots < (1 << 20)) {
+        // face adjacency of the roots: vertices by value, faces by their sorted vertex ids
+        std::unordered_map<std::string, int32_t> vid;
+        std::vector<int32_t> ids((size_t)n_roots * (p + 1));
+        for (int64_t r = 0; r < n_roots; ++r)
+            for (int i = 0; i <= p; ++i) {
+                std::string key((const char*)(vertices + ((size_t)r * (p + 1) + i) * p),
+                                sizeof(double) * p);
+                auto it = vid.find(key);
+                if (it == vid.end()) it = vid.emplace(std::move(key), (int32_t)vid.size()).first;
+                ids[(size_t)r * (p + 1) + i] = it->second;
+            }
+        std::vector<int32_t> nbr((size_t)n_roots * (p + 1), -1);
+        std::unordered_map<std::string, int64_t> face;      // key -> root * (p+1) + i of the first owner
+        std::vector<int32_t> f((size_t)p);
+        for (int64_t r = 0; r < n_roots; ++r)
+            for (int i = 0; i <= p; ++i) {
+                int w = 0;
+                for (int j = 0; j <= p; ++j)
+                    if (j != i) f[(size_t)w++] = ids[(size_t)r * (p + 1) + j];
+                std::sort(f.begin(), f.end());
+                std::string key((const char*)f.data(), sizeof(int32_t) * p);
+                auto it = face.find(key);
+                if (it == face.end()) {
+                    face.emplace(std::move(key), r * (p + 1) + i);
+                } else {
+                    const int64_t o = it->second;
+                    nbr[(size_t)r * (p + 1) + i] = (int32_t)(o / (p + 1));
+                    nbr[(size_t)o] = (int32_t)r;
+                }
+            }
+        X_TRY(hipMalloc(&E->nbr, nbr.size() * sizeof(int32_t)));
+        X_TRY(hipMemcpy(E->nbr, nbr.data(), nbr.size() * sizeof(int32_t), hipMemcpyHostToDevice));
+    }
     E->d.rec = (const double*)E->rec;
     E->d.child = (const int2*)E->child;
     E->d.vinput = (const double*)E->vinput;
@@ -248,7 +360,7 @@ int ehm_explicit_eval_batch(ehm_explicit* E, int64_t n, const double* x, double*
     if (e != hipSuccess) return xfail(EHM_E_HIP, "hipSetDevice: %s", hipGetErrorString(e));
     const int p = E->d.p, n_u = E->d.n_u;
     if ((size_t)n > E->cap) {
-        for (void** q : {&E->x, &E->u, &E->leaf, &E->depth}) {
+        for (void** q : {&E->x, &E->u, &E->leaf, &E->depth, &E->root}) {
             if (*q) (void)hipFree(*q);
             *q = nullptr;
         }
@@ -256,7 +368,8 @@ int ehm_explicit_eval_batch(ehm_explicit* E, int64_t n, const double* x, double*
         if (hipMalloc(&E->x, (size_t)n * p * sizeof(double)) != hipSuccess ||
             hipMalloc(&E->u, (size_t)n * n_u * sizeof(double)) != hipSuccess ||
             hipMalloc(&E->leaf, (size_t)n * sizeof(int32_t)) != hipSuccess ||
-            hipMalloc(&E->depth, (size_t)n * sizeof(int32_t)) != hipSuccess)
+            hipMalloc(&E->depth, (size_t)n * sizeof(int32_t)) != hipSuccess ||
+            hipMalloc(&E->root, (size_t)n * sizeof(int32_t)) != hipSuccess)
             return xfail(EHM_E_HIP, "out of device memory for %lld queries", (long long)n);
         E->cap = (size_t)n;
     }
@@ -272,9 +385,21 @@ int ehm_explicit_eval_batch(ehm_explicit* E, int64_t n, const double* x, double*
     Y_TRY(hipMemcpyAsync(E->x, x, (size_t)n * p * sizeof(double), hipMemcpyHostToDevice,
                          E->stream));
     (void)hipEventRecord(e0, E->stream);
+    // long spines: the visibility walk over the roots finds the root first (EHM_EXPLICIT_LOCATE=0:
+    // the reference's serial walk for every state)
+    static const int locate_off = [] {
+        const char* e = getenv("EHM_EXPLICIT_LOCATE");
+        return (e && atoi(e) == 0) ? 1 : 0;
+    }();
+    const bool locate = E->nbr && !locate_off;
+    if (locate)
+        hipLaunchKernelGGL(k_explicit_locate, dim3((unsigned)((n + 255) / 256)), dim3(256), 0,
+                           E->stream, E->d, (long long)n, (const double*)E->x,
+                           (const int32_t*)E->nbr, (int32_t*)E->root);
     hipLaunchKernelGGL(k_explicit_eval, dim3((unsigned)((n + 255) / 256)), dim3(256), 0,
                        E->stream, E->d, (long long)n, (const double*)E->x, (double*)E->u,
-                       (int32_t*)E->leaf, (int32_t*)E->depth);
+                       (int32_t*)E->leaf, (int32_t*)E->depth,
+                       locate ? (const int32_t*)E->root : (const int32_t*)nullptr);
     (void)hipEventRecord(e1, E->stream);
     Y_TRY(hipGetLastError());
     Y_TRY(hipMemcpyAsync(u, E->u, (size_t)n * n_u * sizeof(double), hipMemcpyDeviceToHost,

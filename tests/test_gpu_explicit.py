@@ -62,6 +62,51 @@ def test_explicit_evaluation_matches_reference_walk():
     forest.close()
 
 
+def test_long_spine_goes_through_the_root_locator():
+    """
+    652 Delaunay roots (the p = 6 box of config 4): the root is found by k_explicit_locate (a
+    visibility walk over the face adjacency of the roots; states within 1e-9 of a face fall back to
+    the serial walk) and must be the one the reference's serial walk over the right spine ends in
+    -- the flat restatement of that walk on the CPU is the checker.
+    """
+    from explicit_hybrid_mpc_amd import engine, examples, explicit
+    from explicit_hybrid_mpc_amd import tools as ehm_tools
+    from oracle.explicit_cpu import ExplicitFlatCPU
+    mpc = helpers.make_instance('chain', 0)
+    gp = engine.GpuProblem(mpc.compile(), 1., 1.)
+    half = examples.theta_box(mpc)
+    V = examples.box_vertices(half)
+    J, _, _ = gp.solve_pt(0.5 * V)
+    gp.set_eps(float(np.max(J)), 1.0)
+    roots, _ = ehm_tools.delaunay_roots(V)
+    assert len(roots) >= 128
+    flat = gp.partition(np.array(roots), action='ecc')
+    gp.close()
+    ex = explicit.ExplicitMPC(flat)
+    rng = np.random.default_rng(3)
+    X = rng.uniform(-1, 1, (3000, half.size)) * half
+    # states ON faces of the roots (midpoints of root edges, pulled 1e-12 towards a vertex): the
+    # locator must hand them to the serial walk
+    R0 = np.array(roots)
+    X[:40] = 0.5 * (R0[:40, 0] + R0[:40, 1]) * (1 - 1e-12)
+    u, leaf, visited, _ = ex.evaluate(X, return_info=True)
+    cpu = ExplicitFlatCPU(flat.vertices, flat.vertex_inputs, flat.left, flat.right,
+                          flat.info['n_roots'])
+    same = 0
+    for k in range(300):
+        u_ref, k_ref = cpu(X[k])
+        if k_ref == leaf[k]:
+            same += 1
+            assert np.allclose(u[k], u_ref, rtol=1e-9, atol=1e-11)
+        else:       # within rounding of a shared face: the neighbour must contain the state too
+            R = flat.vertices[leaf[k]]
+            a = np.linalg.solve(np.column_stack([v - R[0] for v in R[1:]]), X[k] - R[0])
+            assert min(a.min(), 1 - a.sum()) > -1e-9
+    assert same >= 290
+    assert (visited >= 1).all() and flat.is_leaf(leaf[0])
+    ex.close()
+
+
 def _interpolated_cost(flat, leaf, X):
     """sum_i alpha_i V_i at X in the leaves `leaf` of a FlatTree (barycentric weights)."""
     R = flat.vertices[leaf]                                  # (n, p+1, p)
