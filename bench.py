@@ -157,7 +157,9 @@ def _cpu_worker(job):
     while part._work and time.perf_counter() - t0 < seconds:
         part.max_nodes = part.visits + 5
         part.resume()
-    return orc.n_solves, part.visits, time.perf_counter() - t0
+    closed = sum(1 for nd in part.nodes.values()
+                 if nd.get('leaf') and nd.get('is_epsilon_suboptimal'))
+    return orc.n_solves, part.visits, time.perf_counter() - t0, closed
 
 
 def usable_cores():
@@ -238,8 +240,13 @@ def cpu_baseline(workload, seed, eps_a, eps_r, seconds):
     solves = sum(r[0] for r in res)
     visits = sum(r[1] for r in res)
     busy = max(r[2] for r in res)
+    closed = sum(r[3] for r in res)
+    # the same work in the units of the device line next to it: every node visit is one
+    # epsilon-suboptimality decision (the oracle call the device answers with or without an LP),
+    # a closed leaf is a region
     return dict(value=solves / busy, unit='LP solves/s', cores=n_proc, host_cores=host_cores,
                 usable_cores=cores,
+                regions_per_s=closed / busy, oracle_calls_answered_per_s=visits / busy,
                 kind='port',
                 sample='%d processes (one per usable core: affinity / cgroup quota; the top of the partition, %d node visits / '
                        '%d LP solves in %.1f s on one core, produced %d tasks, dealt round-robin), '
@@ -290,6 +297,8 @@ def parse_args(argv=None):
                          'progress read-back (and, N > 1, one all-gather) per round -- off by '
                          'default, the headline number is measured without it')
     ap.add_argument('--cpu-seconds', type=float, default=15.)
+    ap.add_argument('--scale-seconds', type=float, default=480.,
+                    help='soft time limit of the config5_scale entry of "secondary" (0 = skip it)')
     ap.add_argument('--queries', type=int, default=1 << 21,
                     help='explicit: states evaluated per step')
     ap.add_argument('--secondary-cpu-seconds', type=float, default=6.,
@@ -941,7 +950,10 @@ def measure_config5(args, ctx):
         nat_acc['launches'] += st['launches']
         return dict(host_visits=st['visits'] + st['slow_path_visits'], rounds=st['rounds'],
                     regions=st['regions'], truncated=bool(st['truncated']), handoffs=0,
-                    native_visits=st['visits'], slow_path_cells=st['slow_path_cells'])
+                    native_visits=st['visits'], slow_path_cells=st['slow_path_cells'],
+                    depth_limited_leaves=int(st.get('depth_limited_leaves', 0)),
+                    depth_limited_without_commutation=int(
+                        st.get('depth_limited_without_commutation', 0)))
 
     step_deadline = [None]
 
@@ -1103,6 +1115,12 @@ def measure_config5(args, ctx):
                 'regions_per_step': closed_t / K, 'nodes_per_step': nodes_t / K,
                 'open_leaves_per_step': (leaves - closed) / K if world == 1 else None,
                 'depth_limit': args.max_depth or None,
+                # open leaves the depth limit left unbisected (flag EHM_FR_DEPTH; the rest of the
+                # open leaves were pending when a time / region limit cut the step)
+                'depth_limited_leaves_per_step':
+                    sum(st.get('depth_limited_leaves', 0) for st, _ in runs) / K,
+                'depth_limited_leaves_without_a_commutation_per_step':
+                    sum(st.get('depth_limited_without_commutation', 0) for st, _ in runs) / K,
                 'tree_depth': depth,
                 'node_visits_per_step': tot[9] / K,
                 'lp_solves_per_step': lp / K,
@@ -1316,11 +1334,14 @@ def measure_explicit(args, ctx):
         'cases': out_cases}
 
 
-SECONDARY = (('config3', 2, 1), ('config4', 2, 1), ('config2q', 5, 2), ('config5', 1, 0))
+SECONDARY = (('config3', 2, 1), ('config4', 2, 1), ('config2q', 5, 2), ('config5', 1, 0),
+             ('config5_scale', 1, 0))
 SECONDARY_KEYS = ('value', 'unit', 'ms_per_step', 'regions_per_s', 'oracle_calls_answered_per_s',
                   'steps', 'warmup', 'roofline', 'cpu_baseline')
 SECONDARY_CONFIG_KEYS = ('workload', 'regions_per_step', 'nodes_per_step', 'lp_solves_per_step',
                          'open_leaves_at_max_depth_per_step', 'open_leaves_per_step',
+                         'depth_limit', 'depth_limited_leaves_per_step', 'cells_grown_per_step',
+                         'depth_limited_leaves_without_a_commutation_per_step', 'cells_log',
                          'tree_depth', 'mean_ipm_iterations',
                          'midpoint_optima_taken_from_the_table_per_step',
                          'lp_solves_per_mixed_integer_oracle_call',
@@ -1339,6 +1360,14 @@ def secondary_line(args, ctx, workload, steps, warmup):
     a.regions = a.cells = 0
     a.progress_file = None
     a.seconds = 0.
+    if workload == 'config5_scale':
+        # configs[4] towards its stated size: the Delaunay roots in Qhull order, each to completion
+        # under a depth limit, until 1e6 regions are closed or the soft time limit cuts the root in
+        # progress (its pending cells stay open leaves and are reported as such)
+        if args.scale_seconds <= 0:
+            return {'name': workload, 'skipped': '--scale-seconds 0'}
+        a.workload, a.regions, a.cells = 'config5', 10 ** 6, 400
+        a.seconds, a.max_depth = float(args.scale_seconds), 26
     a.driver = 'native'
     a.order, a.max_visits, a.round_cap = 'lcss-first', None, 4096
     a.status_dir = None
@@ -1351,6 +1380,9 @@ def secondary_line(args, ctx, workload, steps, warmup):
         return {'workload': workload, 'error': '%s: %s' % (type(e).__name__, e)}
     line = {k: full.get(k) for k in SECONDARY_KEYS}
     line['name'] = workload
+    if workload == 'config5_scale':
+        line['limits'] = {'soft_seconds': a.seconds, 'regions_target': a.regions,
+                          'max_depth': a.max_depth, 'roots_offered': a.cells}
     line['workload'] = full['config']['workload']
     line['config'] = {k: full['config'][k] for k in SECONDARY_CONFIG_KEYS if k in full['config']}
     line['wall_seconds'] = time.perf_counter() - t0

@@ -496,6 +496,7 @@ struct ehm_problem {
     int inherit_wit = 1;     // 1 = open nodes hand the point that proved them open to the child
                              // that contains it (DevTree::wit; option "inherit_witness")
     bool budget_keep = false;   // budgeted launches keep one child too (option "budget_keep")
+    bool check_witness = false; // PersistDeal::check (option "check_witness")
     int work_first = 1;      // 1 = a wavefront of the persistent kernel that splits a node goes on
                              // with one child itself and queues the other (option "work_first")
     int share_mid = 1;       // 1 = the persistent kernel keeps a table of midpoint optima: the
@@ -907,11 +908,26 @@ int ehm_problem_create(const ehm_problem_desc* d, int device, ehm_problem** out)
         if (!(es && atoi(es) == 0)) elim_detect(d->G, nd, m, n, p, d->n_u, nd0, LE);
         if (nd0 < n) {
             const int nE = n - nd0;
-            const size_t tot4 = elim_tot4(m, p, lda, nd0, nE, LE);
+            // Column stride of the reduced image: = 2 (mod 8) doubles.  The LDS serves a
+            // ds_read_b64 in two groups of 32 lanes over 32 bank pairs (MI355X_MICROARCH.md):
+            // the matrix-core operands (lane -> column l & 15, row l >> 4) and the column
+            // products (lane -> column block, K-slice) both need (column stride) x (small integer)
+            // to spread over the bank pairs, which an ODD stride (round 1: m | 1) does not do --
+            // 18 % of the LDS-active cycles of the headline kernel were bank conflicts.  The row
+            // products (lane = row) are conflict free at any stride.  EHM_LDA4=odd: the old stride.
+            int lda4 = lda;
+            {
+                const char* e = getenv("EHM_LDA4");
+                if (!(e && !strcmp(e, "odd"))) {
+                    lda4 = m;
+                    while ((lda4 & 7) != 2) ++lda4;
+                }
+            }
+            const size_t tot4 = elim_tot4(m, p, lda4, nd0, nE, LE);
             std::vector<double> img4((size_t)nd * tot4);
             bool ok = true;
             for (int k = 0; k < nd && ok; ++k)
-                ok = elim_image(d->G + (size_t)k * m * n, d->S + (size_t)k * m * p, m, n, p, lda,
+                ok = elim_image(d->G + (size_t)k * m * n, d->S + (size_t)k * m * p, m, n, p, lda4,
                                 nd0, LE, img4.data() + (size_t)k * tot4, tot4);
             if (ok) {
                 rc = P->wc4.ensure(img4.size() * sizeof(double));
@@ -919,7 +935,7 @@ int ehm_problem_create(const ehm_problem_desc* d, int device, ehm_problem** out)
                 HIP_TRY(hipMemcpy(P->wc4.ptr, img4.data(), img4.size() * sizeof(double),
                                   hipMemcpyHostToDevice), EHM_E_HIP);
                 P->dp.Wc4 = P->wc4.as<double>();
-                P->dp.lda4 = lda;
+                P->dp.lda4 = lda4;
                 P->dp.ncw4 = nd0 + p + 3;
                 P->dp.tot4 = (int)tot4;
                 P->dp.nd0 = nd0;
@@ -1045,7 +1061,7 @@ int ehm_problem_update_blocks(ehm_problem* P, int32_t first, int32_t count, cons
         std::vector<double> img4((size_t)count * tot4);
         bool ok = true;
         for (int k = 0; k < count && ok; ++k)
-            ok = elim_image(G + (size_t)k * m * n, S + (size_t)k * m * p, m, n, p, lda, P->dp.nd0,
+            ok = elim_image(G + (size_t)k * m * n, S + (size_t)k * m * p, m, n, p, P->dp.lda4, P->dp.nd0,
                             P->dp.LE4, img4.data() + (size_t)k * tot4, tot4);
         if (ok)
             HIP_TRY(hipMemcpy(P->wc4.as<double>() + (size_t)first * tot4, img4.data(),
@@ -1223,6 +1239,10 @@ int ehm_problem_set_option(ehm_problem* P, const char* name, double value) {
     }
     if (!strcmp(name, "work_first")) {
         P->work_first = value != 0.0;
+        return EHM_OK;
+    }
+    if (!strcmp(name, "check_witness")) {
+        P->check_witness = value != 0.0;
         return EHM_OK;
     }
     if (!strcmp(name, "budget_keep")) {
@@ -2686,12 +2706,13 @@ static int persistent_run(ehm_tree* T, long long max_pops = 0) {
     const int32_t* cur = (R.cur_is_a ? P->fr_a : P->fr_b).as<int32_t>();
     HIP_TRY(hipMemcpyAsync(slots, cur, (size_t)R.nf * 4, hipMemcpyDeviceToDevice, P->stream),
             EHM_E_HIP);
-    PersistDeal deal{0, 0, 0, 1, 0};
+    PersistDeal deal{0, 0, 0, 1, 0, 0};
+    deal.check = P->check_witness ? 1 : 0;
     T->dt.code = nullptr;
     if (R.deal_depth > 0 && R.shard_world > 1 && R.sweeps == 0) {
         // one launch from the roots, dealt over the ranks at a tree depth (PersistDeal)
         deal = PersistDeal{0, R.deal_depth, R.shard_rank, R.shard_world,
-                           getenv("EHM_DEAL_LOW_BITS") ? 0 : 1};
+                           getenv("EHM_DEAL_LOW_BITS") ? 0 : 1, 0, P->check_witness ? 1 : 0};
         if ((rc = T->code.ensure((size_t)T->cap * 4))) return rc;
         T->dt.code = T->code.as<uint32_t>();
         std::vector<uint32_t> codes((size_t)R.n_roots);
@@ -3307,8 +3328,11 @@ int ehm_tree_export(const ehm_tree* Tc, double* vertices, int32_t* left, int32_t
     // pinned memory (ehm_host_alloc) get the copies at the speed of the host link.
     const int nc = p + 1, nu = (p + 1) * n_u, nrec = nR + nc + nu;
     const size_t per_node = (size_t)nrec * 8 + 8 + 4 + 4 + 4 + 1;
-    // (a pool too large for one staging buffer goes in parts of 2^22 nodes, one wait each)
-    const long long chunk = std::min<long long>(n, 1LL << 22);
+    // (a pool too large for one staging buffer goes in parts, one wait each; the buffer stays with
+    // the handle, so it is capped by BYTES -- 768 MB: the headline tree, 483 MB, still goes in one
+    // piece -- not by nodes: at ~1 KB per node of a p = 8 law 2^22 nodes were 4 GB held for good)
+    const long long cap_nodes = std::max<long long>(1, (768LL << 20) / (long long)per_node);
+    const long long chunk = std::min<long long>(n, std::min<long long>(1LL << 22, cap_nodes));
     if ((rc = P->ex_stage.ensure((size_t)chunk * per_node + 64))) return rc;
     for (long long k0 = 0; k0 < n; k0 += chunk) {
         const long long nk = std::min(chunk, n - k0);

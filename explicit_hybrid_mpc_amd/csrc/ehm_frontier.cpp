@@ -720,6 +720,10 @@ struct __attribute__((visibility("hidden"))) ehm_frontier {
     std::vector<int64_t> seq, witness;          // code of the full sequence held / of the witness
     std::vector<int64_t> incumbent;             // lcss: the parent's best-slack sequence (-1: none)
     std::vector<uint8_t> flags;
+    // a failure inside run() / p_theta() leaves cells flagged PENDING in no work list and memo
+    // entries claimed by a launch that never answered: the handle then refuses everything but
+    // ehm_frontier_reset (and destroy) instead of handing out a silently incomplete tree
+    bool poisoned = false;
     int64_t n_roots = 0;
     std::vector<int32_t> ecc_work, lcss_work;
     // vertex optima by (sequence, point id)
@@ -1989,6 +1993,7 @@ int ehm_frontier_reset(ehm_frontier* f) {
     f->flags.clear(); f->n_roots = 0;
     f->ecc_work.clear(); f->lcss_work.clear();
     f->opt_of.clear(); f->opt_J.clear(); f->opt_u.clear();
+    f->poisoned = false;
     f->st = ehm_frontier_stats{};
     if (f->dev) {
         f->base_ctr[0] = f->dev->total_lp();
@@ -2002,6 +2007,9 @@ int ehm_frontier_reset(ehm_frontier* f) {
 
 int ehm_frontier_add_root(ehm_frontier* f, const double* vertices) {
     if (!f || !vertices) return fail(EHM_E_INVALID, "ehm_frontier_add_root: bad argument");
+    if (f->poisoned)
+        return fail(EHM_E_INVALID, "ehm_frontier_add_root: an earlier call failed inside a round; "
+                                   "ehm_frontier_reset first");
     if (f->n_roots != f->n_nodes())
         return fail(EHM_E_INVALID, "ehm_frontier_add_root: the tree has been grown already (reset first)");
     try {
@@ -2018,13 +2026,20 @@ int ehm_frontier_add_root(ehm_frontier* f, const double* vertices) {
 
 int ehm_frontier_run(ehm_frontier* f, const ehm_frontier_opts* opts, ehm_frontier_stats* stats) {
     if (!f) return fail(EHM_E_INVALID, "ehm_frontier_run: NULL handle");
+    if (f->poisoned)
+        return fail(EHM_E_INVALID, "ehm_frontier_run: an earlier call failed inside a round -- the "
+                                   "tree is incomplete; ehm_frontier_reset first");
     ehm_frontier_opts o{};
     if (opts) o = *opts;
     try {
         f->run(o);
     } catch (const Fail& e) {
+        f->poisoned = true;
+        if (f->S) (void)ehm_search_abandon(f->S);
         return fail(e.code, "%s", e.msg.c_str());
     } catch (const std::bad_alloc&) {
+        f->poisoned = true;
+        if (f->S) (void)ehm_search_abandon(f->S);
         return fail(EHM_E_CAPACITY, "ehm_frontier_run: out of memory");
     }
     if (stats) *stats = f->st;
@@ -2034,11 +2049,16 @@ int ehm_frontier_run(ehm_frontier* f, const ehm_frontier_opts* opts, ehm_frontie
 int ehm_frontier_p_theta(ehm_frontier* f, int64_t n, const double* theta, double* J, double* u0,
                          int32_t* sequence) {
     if (!f || n < 0 || (n && (!theta || !J))) return fail(EHM_E_INVALID, "ehm_frontier_p_theta: bad argument");
+    if (f->poisoned)
+        return fail(EHM_E_INVALID, "ehm_frontier_p_theta: an earlier call failed inside a round; "
+                                   "ehm_frontier_reset first");
     try {
         f->p_theta(n, theta, J, u0, sequence);
     } catch (const Fail& e) {
+        f->poisoned = true;
         return fail(e.code, "%s", e.msg.c_str());
     } catch (const std::bad_alloc&) {
+        f->poisoned = true;
         return fail(EHM_E_CAPACITY, "ehm_frontier_p_theta: out of memory");
     }
     return EHM_OK;
@@ -2055,6 +2075,9 @@ int ehm_frontier_export(const ehm_frontier* f, double* vertices, int32_t* left, 
                         int32_t* sequence, double* vertex_costs, double* vertex_inputs,
                         uint8_t* flags) {
     if (!f) return fail(EHM_E_INVALID, "ehm_frontier_export: NULL handle");
+    if (f->poisoned)
+        return fail(EHM_E_INVALID, "ehm_frontier_export: an earlier call failed inside a round -- "
+                                   "the tree is incomplete; ehm_frontier_reset first");
     const size_t n = (size_t)f->n_nodes();
     if (vertices) std::memcpy(vertices, f->verts.data(), f->verts.size() * 8);
     if (left) std::memcpy(left, f->left.data(), n * 4);

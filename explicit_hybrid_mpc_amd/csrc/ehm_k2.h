@@ -96,6 +96,11 @@ struct PersistDeal {
                     // the last turns of the path (measured: 12 % imbalance at 8 ranks against 5 %)
     int keep;       // 1 = work first: a wavefront that splits a node goes on with one of the
                     // children itself and queues only the other (option "work_first")
+    int check;      // 1 = cross-check of the two LP-free verdicts (option "check_witness"): the
+                    // tangent-plane bound is evaluated ALSO for nodes the inherited witness proves
+                    // open; a node it would close at the same time (t* > 0 and t* < 0 cannot both
+                    // hold) is counted in ehm_tree_info.errors.  Test builds of a run, not the default:
+                    // it costs the bound for half a million nodes of the headline tree.
 };
 
 // Optional indirection of the batched oracle kernels: the hybrid partition engine

@@ -531,6 +531,13 @@ __global__ __launch_bounds__(EHM_K2_THREADS) void k2_persist(
             inh_tw = tw;
         }
 #endif
+        if (T.grad && sign_only && inh_open && deal.check) {
+            // option "check_witness": the witness says open -- the bound must not say closed
+            const double thr = -EHM_ROUTE_TOL * (1.0 + fabs(node[rec_off_vcost(p)]));
+            const double bnd = cut_bound(node, hgrad, p, P.eps_a, P.eps_r, lane, nb.lp, thr);
+            if (bnd < thr && lane == 0) wst[W_ERRORS] += 1;
+            wsync();
+        }
         if (T.grad && sign_only && !inh_open) {
             // tangent-plane bound of t* (ehm_dev.h, cut_bound): negative => closed, no LP
             const double thr = -EHM_ROUTE_TOL * (1.0 + fabs(node[rec_off_vcost(p)]));
@@ -1088,10 +1095,13 @@ __global__ __launch_bounds__(EHM_K2_THREADS) void k2_persist(
             // Work first: the wavefront goes on with ONE of the children itself (its record is
             // hot, no queue round trip, and the deep chains that end a partition are followed at
             // once instead of waiting behind the whole frontier at every level); the other child
-            // feeds the queue.  Budgeted launches (pop_limit) do the same since round 5: a kept
-            // child never enters the queue -- its wavefront follows the chain to its end, at most
-            // one visit per tree level --, so what the launch leaves is still the contiguous slice
-            // behind the pop limit (rounds 3-4 queued both children there and paid 40 % more LPs).
+            // feeds the queue.  Budgeted launches (pop_limit) queue BOTH children by default
+            // (PersistDeal::keep = 0: persistent_run sets it unless option "budget_keep" is on):
+            // keeping one there was built and measured in round 5 -- the kept chains run depth
+            // first, what the launch leaves behind the pop limit is then made of deep small cells
+            // and the rebalancing rounds move 4x the nodes (38.2 against 33.4 ms for two ranks) --
+            // and stays off; with budget_keep = 1 a kept child never enters the queue, so what the
+            // launch leaves is still the contiguous slice behind the pop limit.
             const int nown = own0 + own1;
             int push0 = own0, push1 = own1;
             if (keep_child) {

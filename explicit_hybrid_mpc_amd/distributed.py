@@ -465,28 +465,98 @@ def merge_flat(parts, root_locations=None, received=None):
                     take('vertex_inputs'), flags, take('tstar'), info, parts[0].deltas)
 
 
-def grow_roots_sharded(oracle, roots, action='ecc', device=None, **kw):
+def claim_roots(n_roots, batch=1, key='ehm_root_ticket', store=None):
     """
-    The search-oracle driver (``bnb_frontier.grow_frontier``: problems whose mode sequences
-    cannot be enumerated) over the ranks: root ``k`` of the list -- the Delaunay roots of the
-    set -- belongs to rank ``k % world``; the roots of a rank share their visit rounds.  The
-    subtrees are independent, so the data path has no collective (weak scaling over the
-    roots); the counts are all-gathered at the end.
-    Returns (the list of roots with THIS rank's roots grown in place, stats of this rank,
-    (world, 3) array of every rank's [host visits, leaves, roots]).  ``device``: where the final
-    all-gather's tensors live ('cuda:k' under the nccl = RCCL backend, which cannot move host
-    tensors; default: the oracle table's device there, the host under gloo).
+    Dynamic deal of independent roots over the ranks (the reference's task queue,
+    lib/scheduler.py:498-599, without a scheduler process): a shared counter in the
+    ``torch.distributed`` store of the process group -- ``store.add`` is atomic -- hands out the
+    next ``batch`` root indices to whoever asks.  Generator of lists of indices; exhausted when the
+    counter has passed ``n_roots``.  No process group: this process takes every root, in order.
+    ``key`` must be fresh per deal (the counter is never reset).
+    """
+    import torch.distributed as dist
+    if store is None and dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1:
+        store = dist.distributed_c10d._get_default_store()
+    if store is None:
+        for k0 in range(0, n_roots, batch):
+            yield list(range(k0, min(n_roots, k0 + batch)))
+        return
+    while True:
+        hi = int(store.add(key, int(batch)))
+        lo = hi - int(batch)
+        if lo >= n_roots:
+            return
+        yield list(range(lo, min(hi, n_roots)))
+
+
+def emulate_claims(seconds, world):
+    """Makespan of ``claim_roots`` over roots that take ``seconds[k]`` each (every rank asks for
+    the next root the moment it is free): (per-rank busy seconds, max / mean)."""
+    import heapq
+    free = [(0.0, r) for r in range(world)]
+    heapq.heapify(free)
+    busy = [0.0] * world
+    for t in seconds:
+        at, r = heapq.heappop(free)
+        busy[r] = at + float(t)
+        heapq.heappush(free, (busy[r], r))
+    mean = sum(busy) / max(world, 1)
+    return busy, (max(busy) / mean if mean > 0 else 1.0)
+
+
+def grow_roots_sharded(oracle, roots, action='ecc', device=None, deal='static', native=None,
+                       claim_key='ehm_root_ticket', batch=1, native_opts=None, **kw):
+    """
+    The search-oracle driver (problems whose mode sequences cannot be enumerated) over the ranks;
+    the subtrees of the roots -- the Delaunay roots of the set -- are independent, so the data path
+    has no collective (weak scaling over the roots) and the counts are all-gathered at the end.
+
+    deal='static':  root ``k`` belongs to rank ``k % world``; a rank's roots share their rounds.
+    deal='dynamic': the ranks CLAIM roots from a shared counter (``claim_roots``), ``batch`` at a
+                    time, each group grown to completion before the next claim -- the roots of
+                    configs[4] cost anything between 2 s and 8 min each, and a static deal leaves
+                    most ranks idle behind the slow ones.
+    ``native``: a ``frontier.NativeFrontier`` -- the roots are then grown by the native driver
+    (``frontier.grow_cells``, ``oracle`` only finishes cells it hands back open; ``native_opts``:
+    its keyword arguments), otherwise by ``bnb_frontier.grow_frontier(oracle, ...)``.
+    Returns (the list of roots with THIS rank's roots grown in place, stats of this rank with
+    ``stats['mine']`` = the indices it grew, (world, 3) array of every rank's [host visits,
+    leaves, roots]).  ``device``: where the final all-gather's tensors live ('cuda:k' under the
+    nccl = RCCL backend, which cannot move host tensors; default: the oracle table's device there,
+    the host under gloo).
     """
     import torch.distributed as dist
     from . import bnb_frontier
     rank, _, world = env_rank_world()
     if not (dist.is_available() and dist.is_initialized()):
         world, rank = 1, 0
-    mine = [r for k, r in enumerate(roots) if k % world == rank]
-    stats = bnb_frontier.grow_frontier(oracle, mine, action, **kw) if mine else \
-        dict(host_visits=0, rounds=0, truncated=False)
-    leaves = sum(1 for r in mine for _ in r.leaves())
+
+    def grow(part):
+        if native is not None:
+            from . import frontier
+            st = frontier.grow_cells(native, part, slow_oracle=lambda: oracle,
+                                     slow_opts=kw or None, **(native_opts or {}))
+            return dict(host_visits=st['visits'] + st['slow_path_visits'], rounds=st['rounds'],
+                        truncated=bool(st['truncated']), regions=st['regions'])
+        return bnb_frontier.grow_frontier(oracle, part, action, **kw)
+
+    stats = dict(host_visits=0, rounds=0, truncated=False, regions=0)
+    if deal == 'dynamic':
+        mine = []
+        for ks in claim_roots(len(roots), batch=batch, key=claim_key):
+            st = grow([roots[k] for k in ks])
+            mine += ks
+            stats['host_visits'] += st['host_visits']
+            stats['rounds'] += st['rounds']
+            stats['truncated'] = stats['truncated'] or bool(st['truncated'])
+            stats['regions'] += int(st.get('regions', 0))
+    else:
+        mine = [k for k in range(len(roots)) if k % world == rank]
+        if mine:
+            stats = dict(grow([roots[k] for k in mine]))
+    stats['mine'] = mine
+    leaves = sum(1 for k in mine for _ in roots[k].leaves())
     if device is None and world > 1 and dist.get_backend() == 'nccl':
-        device = 'cuda:%d' % int(getattr(oracle.table, 'device', 0))
+        device = 'cuda:%d' % int(getattr(getattr(oracle, 'table', None), 'device', 0))
     counts = allgather_counts([stats['host_visits'], leaves, len(mine)], device=device)
     return roots, stats, counts

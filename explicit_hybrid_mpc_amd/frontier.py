@@ -301,6 +301,7 @@ def _graft(flat, mpc, targets):
     has = (flags & FR_HAS_RECORD) != 0
     deltas = {}
     handed_back = []
+    depth_limited = _graft.depth_limited = []
     for k in range(n):
         node = nodes[k]
         if has[k]:
@@ -319,6 +320,12 @@ def _graft(flat, mpc, targets):
             nodes[right[k]] = node.right
         elif flags[k] & FR_OPEN:
             handed_back.append((node, int(flags[k])))
+        elif flags[k] & FR_DEPTH:
+            # an open leaf the run's depth limit left unbisected: NOT epsilon-suboptimal, and --
+            # where the limit met it before a commutation was found -- without a record.  Marked,
+            # so that consumers written against lib/tree.py can tell it from a closed region.
+            node.data.depth_limited = True
+            depth_limited.append(node)
     return handed_back
 
 
@@ -356,6 +363,13 @@ def grow_cells(native, branches, slow_oracle=None, round_cap=4096, launch_target
                     (min_regions and st['regions'] >= min_regions):
                 break
     back = graft(native.export(), native.mpc, branches)
+    # leaves the depth limit left open (flag FR_DEPTH): neither regions nor handed back -- reported,
+    # and marked in the tree (NodeData.depth_limited); those without a commutation have no vertex
+    # inputs either, so a tree that holds any must not be given to ExplicitMPC as it is
+    limited = getattr(_graft, 'depth_limited', [])
+    st['depth_limited_leaves'] = len(limited)
+    st['depth_limited_without_commutation'] = sum(1 for nd in limited
+                                                  if not hasattr(nd.data, 'commutation'))
     st['slow_path_cells'] = len(back)
     st['slow_path_regions'] = st['slow_path_visits'] = 0
     if back and not st['truncated']:

@@ -152,7 +152,11 @@ typedef struct ehm_frontier_stats {
 } ehm_frontier_stats;
 
 /* Grows every pending cell (the roots added since the last reset, or what an earlier call left
- * pending) until nothing is pending or a limit of `opts` is reached. */
+ * pending) until nothing is pending or a limit of `opts` is reached.
+ * A call that FAILS inside a round (a solver error, EHM_E_NUMERIC, out of memory) leaves the handle
+ * poisoned: the cells of that round are in no work list any more, so run / p_theta / add_root /
+ * export answer EHM_E_INVALID ("reset first") until ehm_frontier_reset -- never a silently
+ * incomplete tree. */
 int ehm_frontier_run(ehm_frontier* f, const ehm_frontier_opts* opts, ehm_frontier_stats* stats);
 
 /* Oracle.P_theta (lib/oracle.py:104-139) at n parameters ([n][p]) in lockstep: J [n] (+inf: no mode

@@ -164,6 +164,10 @@ int ehm_problem_set_solver(ehm_problem* prob, int generation);
  * "budget_keep" (0|1, default 0): budgeted launches (ehm_partition_advance) let a wavefront keep
  * one child like unbudgeted ones.  Off by default: measured, the frontier such a launch leaves
  * costs the rebalancing rounds more than the kept children save.
+ * "check_witness" (0|1, default 0): cross-check of the persistent kernel's two LP-free verdicts --
+ * the tangent-plane bound is evaluated also for the nodes the inherited witness proves open; a
+ * node it would close at the same time counts in ehm_tree_info.errors (a test option: it costs
+ * the bound for every such node);
  * "work_first" (0|1, default 1): a wavefront of the persistent kernel that splits a node goes on
  * with one of the two children itself and queues the other (EHM_NO_WORKFIRST=1 disables);
  * "timing" (0|1, default 0): multi-commutation runs record an event pair and a counter snapshot

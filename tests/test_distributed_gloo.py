@@ -497,3 +497,78 @@ def test_two_ranks_share_the_roots_of_the_search_driver(tmp_path):
     assert counts[:, 1].sum() == sum(1 for nd in cpu.nodes.values() if nd['leaf'])
     assert np.array_equal(outs[0]['counts'], outs[1]['counts'])
     assert all(c > 0 for c in counts[:, 0])
+
+
+def _worker_roots_dynamic(rank, world, port, out_dir):
+    os.environ.update(RANK=str(rank), LOCAL_RANK=str(rank), WORLD_SIZE=str(world),
+                      MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port))
+    import pickle
+    import torch.distributed as dist
+    from explicit_hybrid_mpc_amd import bnb, distributed, frontier
+    from explicit_hybrid_mpc_amd.tree import Tree, NodeData
+    from oracle import prefix_bb, geometry
+    distributed.init_process_group('gloo')
+    mpc = helpers.make_instance('pwa_small', 0)
+    eps_a = helpers.eps_a_rule(mpc, 0.25)
+    roots, locs = helpers.roots_of(mpc)
+    trees = [Tree(NodeData(vertices=np.array(R))) for R in roots]
+
+    def split_batch(R):
+        out = [geometry.split_along_longest_edge(r) for r in R]
+        return (np.array([o[0] for o in out]), np.array([o[1] for o in out]),
+                np.array([o[2] for o in out], dtype=np.int32))
+    # the native driver on the CPU statement of the table (no device in this test)
+    solvers = frontier.TableSolvers(prefix_bb.CpuPrefixTable(mpc, eps_a, 0.2), split_batch)
+    nat = frontier.NativeFrontier(mpc, eps_a, 0.2, solvers=solvers)
+    slow = bnb.PrefixOracle(mpc, eps_a, 0.2, table=prefix_bb.CpuPrefixTable(mpc, eps_a, 0.2))
+    trees, stats, counts = distributed.grow_roots_sharded(
+        slow, trees, 'ecc', deal='dynamic', native=nat, native_opts=dict(round_cap=16),
+        handoff=False, split_batch=split_batch)
+    mine = {k: [(loc, nd.is_leaf(), nd.data.is_epsilon_suboptimal)
+                for nd, loc in trees[k].walk(locs[k])] for k in stats['mine']}
+    with open(os.path.join(out_dir, 'dyn%d.pkl' % rank), 'wb') as f:
+        pickle.dump(dict(mine=mine, counts=counts, owned=stats['mine']), f)
+    nat.close()
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_two_ranks_claim_the_roots_of_the_native_driver_dynamically(tmp_path):
+    """deal='dynamic': the ranks claim roots from a counter in the process group's store and grow
+    them with the NATIVE driver; every root is grown exactly once and the union is the enumerating
+    CPU partition (= the one-rank tree)."""
+    import pickle
+    from oracle.oracle_cpu import OracleCPU
+    from oracle.partition_cpu import PartitionCPU
+    s = socket.socket()
+    s.bind(('127.0.0.1', 0))
+    port = s.getsockname()[1]
+    s.close()
+    mp.spawn(_worker_roots_dynamic, args=(2, port, str(tmp_path)), nprocs=2, join=True)
+    outs = [pickle.load(open(str(tmp_path / ('dyn%d.pkl' % r)), 'rb')) for r in range(2)]
+    mpc = helpers.make_instance('pwa_small', 0)
+    roots, locs = helpers.roots_of(mpc)
+    owned = sorted(outs[0]['owned'] + outs[1]['owned'])
+    assert owned == list(range(len(roots)))              # each root claimed exactly once
+    cpu = PartitionCPU(OracleCPU(mpc, helpers.eps_a_rule(mpc, 0.25), 0.2))
+    cpu.run(roots, locs, 'ecc')
+    got = {}
+    for o in outs:
+        for k, nodes in o['mine'].items():
+            for loc, leaf, closed in nodes:
+                got[loc] = (leaf, closed)
+    assert set(got) == set(cpu.nodes)
+    for loc, nd in cpu.nodes.items():
+        assert got[loc] == (nd['leaf'], nd['is_epsilon_suboptimal'])
+    counts = outs[0]['counts']
+    assert counts[:, 2].sum() == len(roots)
+    assert counts[:, 1].sum() == sum(1 for nd in cpu.nodes.values() if nd['leaf'])
+
+
+def test_claims_emulated_over_measured_root_times():
+    from explicit_hybrid_mpc_amd import distributed
+    busy, ratio = distributed.emulate_claims([1.0] * 64, 8)
+    assert abs(ratio - 1.0) < 1e-12 and len(busy) == 8
+    # one slow root among many: whoever claims it keeps it, the others take the rest
+    busy, ratio = distributed.emulate_claims([100.0] + [1.0] * 700, 8)
+    assert max(busy) == 100.0 and ratio < 1.01

@@ -125,8 +125,14 @@ def test_bench_tree_subforests_identical_to_cpu_oracle():
     eps_r = 1e-2
     gp.set_eps(eps_a, eps_r)
     roots, _ = ehm_tools.delaunay_roots(V)
+    # option check_witness: the tangent-plane bound is evaluated ALSO for the 489 k nodes the
+    # inherited witness proves open -- the two LP-free verdicts must never contradict each other
+    # (a conflict counts as a device error and the run fails with EHM_E_NUMERIC); the tree is the
+    # default run's either way
+    gp.set_option('check_witness', 1)
     flat = gp.partition(roots, action='ecc', max_nodes=1 << 22)     # the bench's default engine
     gp.close()
+    assert flat.info['witness_inherited'] > 400000
     assert flat.n_nodes == 1610186 and flat.info['n_closed'] == 805104
     left = flat.left
     depth = _depths(flat)

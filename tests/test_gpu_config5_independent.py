@@ -9,7 +9,12 @@ law, oracle/milp_check.py):
 * cells split without a commutation: V_R's MILP (a trajectory copy per vertex, shared mode
   indicators) is infeasible;
 * closed leaves: vertex costs = the uncondensed fixed-sequence LP; where the commutation was
-  adopted at the cell it is the lexicographic minimum of V_R's MILP; bar_E's MILP has max t < 0.
+  adopted at the cell it is the lexicographic minimum of V_R's MILP; bar_E's MILP has max t < 0;
+* lcss splits (round 6): bar_E's MILP has max t >= 0 (the largest over big-M 50 / 10 / 200 -- any
+  run's point is feasible for the reference's problem, so that is a certified lower bound), the
+  children are the longest-edge bisection and hold the node's commutation or bar_D's optimum --
+  compared tie-aware: a child's sequence is also accepted where it is feasible at every vertex
+  and its own fixed-sequence slack is within the canonical tie tolerance of the MILP's maximum.
 """
 
 import os
@@ -46,21 +51,31 @@ def test_nodes_of_a_native_tree_against_one_milp_per_oracle_call():
     ecc_splits = [i for i, (nd, loc) in enumerate(nodes) if not nd.is_leaf() and not has[loc]]
     own_leaves = [i for i, (nd, loc) in enumerate(nodes) if nd.is_leaf() and
                   (loc == '' or not has[loc[:-1]])]
+    lcss_splits = [i for i, (nd, loc) in enumerate(nodes) if not nd.is_leaf() and has[loc]]
+    assert len(lcss_splits) >= 2
     picks = list(rng.choice(ecc_splits, 3, replace=False)) + \
-        list(rng.choice(own_leaves, 2, replace=False))
+        list(rng.choice(own_leaves, 2, replace=False)) + \
+        list(rng.choice(lcss_splits, 2, replace=False))
     seq_of = lambda d: tuple(int(i) for i in np.asarray(d).reshape(mpc.N, mpc.delta_size).argmax(1))
     nv, p = roots.shape[1], roots.shape[2]
     for k, i in enumerate(picks):
         nd, loc = nodes[i]
         d = nd.data
         leaf = nd.is_leaf()
-        job = (k, 1 if leaf else 0, np.asarray(d.vertices, dtype=np.float64),
-               np.array(seq_of(d.commutation) if leaf else [-1] * mpc.N),
-               np.asarray(d.vertex_costs) if leaf else np.full(nv, np.nan), bool(leaf),
+        kind = 1 if leaf else (2 if has[loc] else 0)
+        kids_seq = np.full((2, mpc.N), -1)
+        if kind == 2:
+            kids_seq = np.array([seq_of(c.data.commutation) for c in (nd.left, nd.right)])
+        job = (k, kind, np.asarray(d.vertices, dtype=np.float64),
+               np.array(seq_of(d.commutation) if has[loc] else [-1] * mpc.N),
+               np.asarray(d.vertex_costs) if has[loc] else np.full(nv, np.nan),
+               bool(has[loc] and (loc == '' or not has[loc[:-1]])),
                np.full((2, nv, p), np.nan) if leaf else
                np.array([np.asarray(c.data.vertices) for c in (nd.left, nd.right)]),
-               np.full((2, mpc.N), -1), eps_a, c5.EPS_R)
+               kids_seq, eps_a, c5.EPS_R)
         res = c5._check_one(job)
-        assert res['ok'] and not res['routed'], (loc, res['notes'])
+        assert res['ok'] and not res['routed'], (loc, kind, res['notes'])
         if leaf:
             assert res['t_max'] < 0. and res['max_cost_diff'] <= 1e-7
+        if kind == 2:
+            assert res['t_max'] >= 0. and res['max_cost_diff'] <= 1e-7

@@ -287,3 +287,45 @@ def test_native_p_theta_is_p_theta_many(law):
         assert J_g == J_r and np.array_equal(d_g, d_r) and np.array_equal(u_g, u_r)
     assert feasible >= n - 3
     assert table.lp_solves == ref_table.lp_solves           # the same problems, step for step
+
+
+def test_a_failed_round_poisons_the_handle_until_reset():
+    """
+    A solver call that fails inside a round leaves cells flagged PENDING in no work list: the
+    handle must refuse run / export (EHM_E_INVALID, "reset first") instead of returning a silently
+    incomplete tree, and give the reference tree again after ehm_frontier_reset.
+    """
+    mpc = helpers.make_instance('pwa_small', 0)
+    eps_a, eps_r = helpers.eps_a_rule(mpc, 0.25), 0.2
+    roots, _ = helpers.roots_of(mpc)
+    table = prefix_bb.CpuPrefixTable(mpc, eps_a, eps_r)
+    calls = {'n': 0, 'fail_at': 3}
+    real = table.solve_slack
+
+    def flaky(*a, **kw):
+        calls['n'] += 1
+        if calls['n'] == calls['fail_at']:
+            raise RuntimeError('injected solver failure')
+        return real(*a, **kw)
+    table.solve_slack = flaky
+    solvers = frontier.TableSolvers(table, _host_split_batch)
+    nat = frontier.NativeFrontier(mpc, eps_a, eps_r, solvers=solvers)
+    nat.add_roots(np.array(roots))
+    with pytest.raises(RuntimeError, match='injected'):
+        nat.run(round_cap=5)
+    for call in (lambda: nat.run(round_cap=5), nat.export):
+        with pytest.raises(_capi.EhmError) as err:
+            call()
+        assert err.value.code == _capi.EHM_E_INVALID and 'reset' in str(err.value)
+    # after a reset the same handle grows the whole tree (the failure does not repeat)
+    calls['fail_at'] = -1
+    slow = bnb.PrefixOracle(mpc, eps_a, eps_r, table=prefix_bb.CpuPrefixTable(mpc, eps_a, eps_r))
+    got = [Tree(NodeData(vertices=np.array(R))) for R in roots]
+    frontier.grow_cells(nat, got, slow_oracle=lambda: slow, round_cap=64,
+                        slow_opts=dict(handoff=False, split_batch=_host_split_batch))
+    ref_orc = bnb.PrefixOracle(mpc, eps_a, eps_r, table=prefix_bb.CpuPrefixTable(mpc, eps_a, eps_r))
+    ref = [Tree(NodeData(vertices=np.array(R))) for R in roots]
+    bnb_frontier.grow_frontier(ref_orc, ref, 'ecc', handoff=False, split_batch=_host_split_batch,
+                               round_cap=7)
+    assert sum(_same_trees(a, b) for a, b in zip(ref, got)) > 10
+    nat.close()

@@ -1,6 +1,8 @@
 """
 Whole-tree identity of the HEADLINE partition (bench.py default: configs[1], 22 Delaunay roots,
-eps_r 1e-2, abs_frac 0.02 -- 1 610 186 nodes) against the CPU oracle, node by node.
+eps_r 1e-2, abs_frac 0.02 -- 1 610 186 nodes) or of bench.py --workload config4 (--workload
+config4: configs[3], 652 roots, 325 080 nodes on the wide kernels) against the CPU oracle, node by
+node.
 
 Every node of the exported device tree is decided AGAIN by the CPU restatement of
 lib/worker.py:293-417 (oracle/partition_cpu.py on oracle/oracle_cpu.py: HiGHS on the uncondensed
@@ -42,10 +44,16 @@ def usable_cores():
         return os.cpu_count() or 1
 
 
-def _init(seed, eps_a, eps_r, arrays):
+def _mpc_of(workload, seed):
     from explicit_hybrid_mpc_amd import examples
+    if workload == 'config4':       # configs[3]: the wide LPs (ehm_k4.hip / ehm_k3.hip)
+        return examples.integrator_chain_mpc()
+    return examples.linear_mpc(seed)
+
+
+def _init(seed, eps_a, eps_r, arrays, workload='config2'):
     from oracle.oracle_cpu import OracleCPU
-    mpc = examples.linear_mpc(seed)
+    mpc = _mpc_of(workload, seed)
     orc = OracleCPU(mpc, eps_a, eps_r)
     orc.memoize = True
     _G.update(orc=orc, **arrays)
@@ -124,8 +132,11 @@ def _check_block(block):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument('--seed', type=int, default=0)
-    ap.add_argument('--abs-frac', type=float, default=0.02)
-    ap.add_argument('--eps-r', type=float, default=1e-2)
+    ap.add_argument('--workload', choices=['config2', 'config4'], default='config2',
+                    help='config2 = the headline; config4 = bench.py --workload config4 (n_x=6, '
+                         'N=10: 325 080 nodes on the wide kernels, abs_frac 0.4, eps_r 0.25)')
+    ap.add_argument('--abs-frac', type=float, default=None)
+    ap.add_argument('--eps-r', type=float, default=None)
     ap.add_argument('--limit', type=int, default=0, help='check only the first N nodes (0 = all)')
     ap.add_argument('--stride', type=int, default=1, help='check every s-th block of nodes')
     ap.add_argument('--cores', type=int, default=0)
@@ -133,7 +144,11 @@ def main():
     args = ap.parse_args()
     from explicit_hybrid_mpc_amd import engine, examples
     from explicit_hybrid_mpc_amd import tools as ehm_tools
-    mpc = examples.linear_mpc(args.seed)
+    if args.abs_frac is None:
+        args.abs_frac = 0.4 if args.workload == 'config4' else 0.02
+    if args.eps_r is None:
+        args.eps_r = 0.25 if args.workload == 'config4' else 1e-2
+    mpc = _mpc_of(args.workload, args.seed)
     gp = engine.GpuProblem(mpc.compile(), 1., 1.)
     Vb = examples.box_vertices(examples.theta_box(mpc))
     eps_a = float(np.max(gp.solve_pt(args.abs_frac * Vb)[0]))
@@ -163,7 +178,8 @@ def main():
                max_input_diff=0., lp=0, bad=[])
     t0 = time.perf_counter()
     with mp.get_context('fork').Pool(cores, initializer=_init,
-                                     initargs=(args.seed, eps_a, args.eps_r, arrays)) as pool:
+                                     initargs=(args.seed, eps_a, args.eps_r, arrays,
+                                               args.workload)) as pool:
         for i, r in enumerate(pool.imap_unordered(_check_block, blocks)):
             for k, v in r.items():
                 if k.startswith('max_'):
@@ -176,8 +192,10 @@ def main():
                     time.perf_counter() - t0), flush=True)
     wall = time.perf_counter() - t0
     near = int(np.sum(np.abs(flat.tstar) < ROUTE_TOL * (1. + np.abs(flat.vertex_costs[:, 0]))))
-    rec = dict(workload='bench.py headline: linear_mpc seed %d, abs_frac %g, eps_r %g, %d Delaunay '
-                        'roots' % (args.seed, args.abs_frac, args.eps_r, len(roots)),
+    rec = dict(workload='bench.py %s: %s seed %d, abs_frac %g, eps_r %g, %d Delaunay '
+                        'roots' % ('headline' if args.workload == 'config2' else
+                                   '--workload config4', mpc.name, args.seed, args.abs_frac,
+                                   args.eps_r, len(roots)),
                eps_a=eps_a, device_nodes=int(n), device_regions=int(flat.info['n_closed']),
                nodes_checked=tot['nodes'], closed_leaves_equal=tot['closed'],
                splits_equal=tot['splits'], routed_disagreements=tot['routed'],
