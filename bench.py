@@ -106,6 +106,12 @@ def kernel_source_hash():
     return h.hexdigest()[:16]
 
 
+def wide_kernel(what):
+    """Name of the wide-LP kernel the library launches: the LDS-resident family (ehm_k4.hip) unless
+    EHM_K4=0 selects the streaming one (ehm_k3.hip)."""
+    return ('k3_' if os.environ.get('EHM_K4') == '0' else 'k4_') + what
+
+
 def pmc_traffic(kernel, summary):
     """
     HBM bytes per launch of `kernel` from the committed rocprofv3 --pmc passes of THIS workload
@@ -115,7 +121,7 @@ def pmc_traffic(kernel, summary):
     the kernel sources it was measured on (tools/pmc_summary.py); a profile of OTHER code is not
     quoted: returns (None, reason).
     """
-    for rnd in ('r5', 'r4', 'r3', 'r2', 'r1'):
+    for rnd in ('r6', 'r5', 'r4', 'r3', 'r2', 'r1'):
         path = os.path.join(ROOT, 'profiles', rnd, summary)
         if os.path.exists(path):
             break
@@ -400,7 +406,7 @@ def measure(args, ctx):
                   not args.status_dir)
     # (the persistent kernel exists at one solver width, k2_persist, and -- where a pair of
     # instances is compiled, as for this workload -- at two, kp_persist; the library picks)
-    kname = 'k3_lcss_decide' if wide else 'k2_simplex_batch' if hybrid else (
+    kname = wide_kernel('lcss_decide') if wide else 'k2_simplex_batch' if hybrid else (
         ('kp_persist' if not quad else 'k2_persist') if persistent else
         'k2_lcss_decide' if args.solver == 2 else 'k_lcss_decide')
     pmc_file = {'config4': 'pmc_summary_wide.json', 'config3': 'pmc_summary_config3.json',
@@ -1085,7 +1091,8 @@ def measure_config5(args, ctx):
         dom_s = T['simplex_s']
         achieved = flops / max(dom_s, 1e-12) / 1e12
         c5_traffic, c5_traffic_src = pmc_traffic(
-            'k3_simplex_batch' if dom_wide else 'k2_simplex_batch', 'pmc_summary_config5.json')
+            wide_kernel('simplex_batch') if dom_wide else 'k2_simplex_batch',
+            'pmc_summary_config5.json')
         out = {
             'metric': 'oracle LP solves/sec + final regions/sec, 4-state 2-input N=5 hybrid MPC',
             'value': lp / elapsed_max, 'unit': 'LP solves/s',
@@ -1168,7 +1175,7 @@ def measure_config5(args, ctx):
             },
             'roofline': {
                 'bound': 'mfma' if dom_wide else 'valu-fp64',
-                'kernel': 'k3_simplex_batch' if dom_wide else 'k2_simplex_batch',
+                'kernel': wide_kernel('simplex_batch') if dom_wide else 'k2_simplex_batch',
                 'note': 'LPs over a simplex of the %s table (slack n=%d m=%d) on the %s; flops = '
                         'its LPs by kind x the MEAN iteration count of its LPs x SURVEY 8(d) '
                         'flops per iteration; kernel seconds by HIP events around every launch '

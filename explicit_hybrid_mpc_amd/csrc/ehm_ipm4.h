@@ -1083,28 +1083,47 @@ __device__ __forceinline__ void factor_panel(const Lp& L, int lane, int nrows) {
     }
     const double orig_l = L.db()[(lane < NF) ? lane : (NF - 1)];
     double piv_own = 0.0, rinv_own = 0.0;
+    // the reciprocal of pivot k+1 (v_rcp_f64 + two Newton steps: five dependent double-precision
+    // instructions) is started as soon as entry k+1 of the pivot row is updated, so that it runs
+    // beside the rest of step k's row update instead of heading step k+1
+    double piv, rinv;
+    {
+        piv = readlane_d(a[0], c0);
+        const double orig = readlane_d(orig_l, c0);
+        const bool bad = !(piv > EHM4_PIVOT_REL * orig) || !(piv > 0.0);
+        piv = bad ? EHM4_PIVOT_BIG : piv;
+        rinv = frcp(piv);
+    }
 #pragma unroll
     for (int k = 0; k < 16; ++k) {
-        double piv = readlane_d(a[k], c0 + k);
-        const double orig = readlane_d(orig_l, c0 + k);
         double u[16];
 #pragma unroll
         for (int q = k + 1; q < 16; ++q) u[q] = readlane_d(a[q], c0 + k);
-        const bool bad = !(piv > EHM4_PIVOT_REL * orig) || !(piv > 0.0);
-        piv = bad ? EHM4_PIVOT_BIG : piv;
-        const double rinv = frcp(piv);
         piv_own = (lane == c0 + k) ? piv : piv_own;
         rinv_own = (lane == c0 + k) ? rinv : rinv_own;
         const double l = a[k] * rinv;
         a[k] = l;
+        if (k + 1 < 16) {
+            a[k + 1] = fma(-l, u[k + 1], a[k + 1]);
+            piv = readlane_d(a[k + 1], c0 + k + 1);
+            const double orig = readlane_d(orig_l, c0 + k + 1);
+            const bool bad = !(piv > EHM4_PIVOT_REL * orig) || !(piv > 0.0);
+            piv = bad ? EHM4_PIVOT_BIG : piv;
+            rinv = frcp(piv);
+        }
 #pragma unroll
-        for (int q = k + 1; q < 16; ++q) a[q] = fma(-l, u[q], a[q]);
+        for (int q = k + 2; q < 16; ++q) a[q] = fma(-l, u[q], a[q]);
     }
     if (lane >= c0 && lane < nrows) {
         double* mrow = L.M + lane * SQ + c0;
 #pragma unroll
         for (int q = 0; q < 16; ++q)
-            if (c0 + q < lane) mrow[q] = a[q];      // strictly lower: the multipliers
+            if (c0 + q < lane) {
+                mrow[q] = a[q];                     // strictly lower: the multipliers
+                // ... and their transpose in the upper triangle (free once the panel is in
+                // registers): the backward solve then reads ROWS, like the forward one
+                L.M[(c0 + q) * SQ + lane] = a[q];
+            }
         if (lane < c0 + 16) {
             L.pv()[lane] = piv_own;
             L.rinv()[lane] = rinv_own;
@@ -1219,16 +1238,15 @@ __device__ __forceinline__ double ldl_solve(const Blk& S, const Lp& L, const Ctx
     }
     EHM4_TICK(23);
     bv = dl ? bv * rinv : 0.0;      // z = D^-1 y
-    const double* lcol = L.M + jr;
 #pragma unroll
     for (int k0 = NR - 16; k0 >= 0; k0 -= 16) {
         double lv[16];
 #pragma unroll
-        for (int u = 0; u < 16; ++u) lv[u] = lcol[(k0 + u) * SQ];
+        for (int u = 0; u < 16; ++u) lv[u] = lrow[k0 + u];      // row `lane` of L' (upper triangle)
 #pragma unroll
         for (int u = 0; u < 16; ++u) {
-            // column `lane` of L below the diagonal, rows < nrf (nrf is wave-uniform: rows beyond
-            // the matrix are discarded by the select, whatever the region holds there)
+            // entries (lane, k), lane < k < nrf (nrf is wave-uniform); everything else the row
+            // holds -- the diagonal, the lower triangle, columns beyond the matrix -- is discarded
             const bool take = (k0 + u < nrf) && (lane < k0 + u);
             lv[u] = take ? lv[u] : 0.0;
         }
@@ -1376,9 +1394,10 @@ __device__ __forceinline__ IpmResult ipm_solve(const Blk& S, const Lp& L, Ctx& B
     }
     double mx[2] = {fabs(v), fabs(cj)}, sm[4] = {0.0, 0.0, 0.0, 0.0};
     block_reduce<2, 0>(B, mx, sm);
-    const double bnorm = 1.0 + mx[0];
-    const double cnorm = 1.0 + mx[1];
-    const double inv_m = 1.0 / (double)m_lp;
+    // (reciprocals once per solve: an f64 division is a dozen dependent instructions, ~150 ticks)
+    const double inv_bnorm = frcp(1.0 + mx[0]);
+    const double inv_cnorm = frcp(1.0 + mx[1]);
+    const double inv_m = frcp((double)m_lp);
 
     IpmResult res;
     res.obj = 0.0;
@@ -1411,7 +1430,7 @@ __device__ __forceinline__ IpmResult ipm_solve(const Blk& S, const Lp& L, Ctx& B
         }
         const bool colon = (tid < n_lp) && (tid >= nrf || ((L.act >> tid) & 1ULL));
         const double r_d = colon ? (atl + cj) : 0.0;
-        mx[0] = fmax(fabs(r_p) / bnorm, fabs(r_d) / cnorm);
+        mx[0] = fmax(fabs(r_p) * inv_bnorm, fabs(r_d) * inv_cnorm);
         mx[1] = 0.0;
         sm[0] = s * lam;
         sm[1] = v * lam + xj * atl;        // b' lam = v' lam + x' (A' lam)
@@ -1423,8 +1442,8 @@ __device__ __forceinline__ IpmResult ipm_solve(const Blk& S, const Lp& L, Ctx& B
         const double mu = sm[0] * inv_m;
         const double dobj = -sm[1];
         const double pobj = sm[2];
-        const double e_g = fabs(pobj - dobj) / (1.0 + fabs(pobj));
-        const double merit = fmax(emax / EHM4_TOL_RES, e_g / EHM4_TOL_GAP);
+        const double e_g = fabs(pobj - dobj) * frcp(1.0 + fabs(pobj));
+        const double merit = fmax(emax * (1.0 / EHM4_TOL_RES), e_g * (1.0 / EHM4_TOL_GAP));
         // fmax drops NaNs: a non-finite input would pass as "converged" (see ehm_ipm2.h)
         if (!(mu == mu) || !(pobj == pobj) || fabs(pobj) > 1e300) {
             res.merit = 1e300;
@@ -1494,13 +1513,13 @@ __device__ __forceinline__ IpmResult ipm_solve(const Blk& S, const Lp& L, Ctx& B
         mx[1] = valid ? fma(ds_a, rs, 1.0) : 0.0;
         sm[0] = sm[1] = sm[2] = sm[3] = 0.0;
         block_reduce<2, 0>(B, mx, sm);
-        double ap = (mx[0] > 1.0) ? 1.0 / mx[0] : 1.0;
-        double ad = (mx[1] > 1.0) ? 1.0 / mx[1] : 1.0;
+        double ap = (mx[0] > 1.0) ? frcp(mx[0]) : 1.0;
+        double ad = (mx[1] > 1.0) ? frcp(mx[1]) : 1.0;
         mx[0] = mx[1] = 0.0;
         sm[0] = valid ? (s + ap * ds_a) * (lam + ad * dl_a) : 0.0;
         block_reduce<0, 1>(B, mx, sm);
         const double mu_aff = sm[0] * inv_m;
-        const double ratio = mu_aff / mu;
+        const double ratio = mu_aff * frcp(mu);
         const double sigma = ratio * ratio * ratio;
         const double smu = sigma * mu;
 
@@ -1534,8 +1553,8 @@ __device__ __forceinline__ IpmResult ipm_solve(const Blk& S, const Lp& L, Ctx& B
         mx[1] = -dl * rl;
         sm[0] = 0.0;
         block_reduce<2, 0>(B, mx, sm);
-        ap = (mx[0] > step_frac) ? step_frac / mx[0] : 1.0;
-        ad = (mx[1] > step_frac) ? step_frac / mx[1] : 1.0;
+        ap = (mx[0] > step_frac) ? step_frac * frcp(mx[0]) : 1.0;
+        ad = (mx[1] > step_frac) ? step_frac * frcp(mx[1]) : 1.0;
         if (tid < n_lp) L.x()[tid] = fma(ap, L.t()[tid], xj);
         if (valid) {
             s = fma(ap, ds, s);

@@ -14,7 +14,7 @@ import sys
 
 
 def short(name):
-    m = re.search(r'(k[23p]?_[a-z_]+|hy_[a-z_0-9]+)', name)
+    m = re.search(r'(k[234p]?_[a-z_]+|hy_[a-z_0-9]+)', name)
     return m.group(1) if m else name.split('(')[0]
 
 
