@@ -402,11 +402,17 @@ def measure(args, ctx):
     static = args.balance == 'static' and not args.status_dir
     # both balancing modes run the persistent frontier kernel: static = one launch per rank,
     # dynamic = budgeted rounds of it
+    # (wide LPs: the LDS-resident family has a persistent kernel of its own, single rank only --
+    # csrc/ehm_k4.hip, k4_persist; EHM_K4=0 / EHM_K4_PERSIST=0 select the streaming kernels / the
+    # level-synchronous sweeps)
+    wide_persist = (wide and world == 1 and args.engine == 1 and not args.status_dir and
+                    os.environ.get('EHM_K4') != '0' and os.environ.get('EHM_K4_PERSIST') != '0')
     persistent = (args.engine == 1 and args.solver == 2 and not wide and not hybrid and
-                  not args.status_dir)
+                  not args.status_dir) or wide_persist
     # (the persistent kernel exists at one solver width, k2_persist, and -- where a pair of
     # instances is compiled, as for this workload -- at two, kp_persist; the library picks)
-    kname = wide_kernel('lcss_decide') if wide else 'k2_simplex_batch' if hybrid else (
+    kname = (wide_kernel('persist') if wide_persist else wide_kernel('lcss_decide')) if wide else \
+        'k2_simplex_batch' if hybrid else (
         ('kp_persist' if not quad else 'k2_persist') if persistent else
         'k2_lcss_decide' if args.solver == 2 else 'k_lcss_decide')
     pmc_file = {'config4': 'pmc_summary_wide.json', 'config3': 'pmc_summary_config3.json',
@@ -704,8 +710,10 @@ def measure(args, ctx):
                 # "hbm" | "mfma": the wide kernels form their normal matrix on the matrix cores,
                 # the shared-block kernels execute no MFMA at all -- FP64 vector FMA issue
                 'bound': 'mfma' if wide else 'valu-fp64', 'kernel': kname,
-                'note': ('normal matrix on v_mfma_f64_16x16x4_f64 (57 columns = 4 tiles); peak = '
-                         'FP64 matrix = vector peak of MI355X' if wide else
+                'note': ('LDS-resident reduced block (57 -> 37 factorised columns), normal matrix '
+                         'and the trailing updates of the blocked factorisation on '
+                         'v_mfma_f64_16x16x4_f64 (csrc/ehm_ipm4.h); peak = FP64 matrix = vector '
+                         'peak of MI355X' if wide else
                          'one launch holds the slack LPs (n=%d m=%d) and the midpoint LPs (n=%d '
                          'm=%d); the solver eliminates %d epigraph columns from the Newton systems '
                          'and factorises %d / %d; FP64 issue bound (vector FMA + one matrix-core '
@@ -1382,7 +1390,7 @@ def secondary_line(args, ctx, workload, steps, warmup):
     a.no_mid_first = a.no_inherit_witness = False
     t0 = time.perf_counter()
     try:
-        full = (measure_config5 if workload == 'config5' else measure)(a, ctx)
+        full = (measure_config5 if a.workload == 'config5' else measure)(a, ctx)
     except (Exception, SystemExit) as e:       # a failing secondary workload must not cost the headline
         return {'workload': workload, 'error': '%s: %s' % (type(e).__name__, e)}
     line = {k: full.get(k) for k in SECONDARY_KEYS}

@@ -2827,8 +2827,21 @@ int ehm_partition_step(ehm_tree* T, int32_t max_sweeps, int64_t* frontier_size) 
     // persistent frontier kernel: a run that goes to completion in this call.  A sharded run
     // first sweeps until the frontier has been dealt over the ranks, then grows its share in
     // one launch (static dealing: no rebalancing rounds, see distributed.py)
+    // (wide LPs: the LDS-resident family has a persistent kernel of its own -- single rank only,
+    // it does not deal nodes over ranks; EHM_K4_PERSIST=0 keeps the level-synchronous sweeps)
+    bool wide_persist = false;
+    if (P->dp.Wr3 && R.engine == 1 && P->solver_gen == 2 && max_sweeps <= 0 &&
+        R.shard_world == 1 && R.deal_depth <= 0) {
+        static const int off = [] {
+            const char* e = getenv("EHM_K4_PERSIST");
+            return (e && atoi(e) == 0) ? 1 : 0;
+        }();
+        K2Cfg pc;
+        wide_persist = !off && k2_config(P, LP_SLACK, LP_POINT, 1LL << 40, pc, true) == EHM_OK &&
+                       pc.api->persist != nullptr;
+    }
     const bool want_persist = R.engine == 1 && P->solver_gen == 2 && max_sweeps <= 0 &&
-                              !P->dp.Wr3;
+                              (!P->dp.Wr3 || wide_persist);
     if (want_persist && R.nf > 0 && (R.shard_world == 1 || R.sharded || R.deal_depth > 0)) {
         int rc = persistent_run(T);
         if (frontier_size) *frontier_size = 0;

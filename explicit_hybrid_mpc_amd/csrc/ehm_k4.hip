@@ -550,6 +550,329 @@ EHM4_KERNEL void k4_lcss_expand(
     }
 }
 
+
+// ---- persistent frontier kernel of the wide family (round 6) --------------------------------
+// One launch per partition, one workgroup per CU: the workgroup draws a node from the device queue
+// of ehm_k2.hip's persistent kernel (same slot array and control block: PersistCtl), decides it
+// exactly as k4_lcss_decide does (tangent-plane bound, inherited witness, suboptimality-test LP),
+// and -- if it stays open -- bisects it as k4_lcss_expand does (midpoint optimum from the table or
+// by its own LP) and queues both children.  What a consumer on another XCD reads of a child --
+// record, gradients, witness, structure words -- is written THROUGH (agent-scope atomic stores),
+// the stores are waited for, then the queue slots go out; the consumer reads its slot with an
+// agent-scope load and invalidates before it reads the record (the protocol of ehm_k2.hip:
+// no L2 write-back anywhere).  Same tree as the sweeps: a node's fate depends on its record only.
+// Single rank, unbudgeted (PersistDeal: world <= 1, pop_limit = 0); anything else runs the sweeps.
+#define K4_WT(ptr, val) __hip_atomic_store((ptr), (val), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)
+template <int NTILE>
+EHM4_KERNEL void k4_persist(
+    DevProblem P, DevTree T, int32_t* slots, int n_slots, PersistCtl* ctl, int node_cap,
+    DevCounters* cnt, int sign_only, int max_depth, PersistDeal deal) {
+    K4_PROLOGUE();
+    const int p = P.p, n_u = P.n_u;
+    const int nrec = rec_doubles(p, n_u);
+    K4_USE_BLOCK(0)
+    __shared__ int s_id, s_c0, s_open;
+    __shared__ int s_mt[3];
+    __shared__ double s_mtv[2];
+    __shared__ double s_bnd;
+    const long long t_start = wall_clock64();
+    unsigned long long n_closed = 0, n_splits = 0;      // thread 0's, added to ctl when it leaves
+    int depth_seen = 0, trunc = 0;
+    for (;;) {
+        __syncthreads();
+        if (tid0 == 0) {
+            int id = -1;
+            const int idx = atomicAdd(&ctl->head, 1);
+            if (idx < n_slots) {
+                for (;;) {
+                    id = __hip_atomic_load(&slots[idx], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    if (id >= 0) break;
+                    if (__hip_atomic_load(&ctl->pending, __ATOMIC_RELAXED,
+                                          __HIP_MEMORY_SCOPE_AGENT) <= 0 ||
+                        __hip_atomic_load(&ctl->abort, __ATOMIC_RELAXED,
+                                          __HIP_MEMORY_SCOPE_AGENT) != 0)
+                        break;
+                    if (wall_clock64() - t_start > 60LL * 100000000LL) {
+                        atomicMax(&ctl->abort, 3);
+                        break;
+                    }
+                    __builtin_amdgcn_s_sleep(64);
+                }
+            }
+            s_id = id;
+        }
+        __syncthreads();
+        const int id = s_id & ~EHM_REQUEUED;
+        if (s_id < 0) break;
+        tid = pin(tid0);
+        // acquire (L1 / non-local L2 invalidate): the record behind the slot is visible
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+        const double* rec = T.rec + (size_t)id * T.rec_stride;
+        for (int k = tid; k < nrec; k += NT) nb.rec[k] = rec[k];
+        const int dep = T.depth[id];
+        __syncthreads();
+        // ---- the decision (k4_lcss_decide) --------------------------------------------------
+        bool open = false, decided = false;
+        if (T.grad && sign_only) {
+            if (B.wave == 0) {
+                const double bnd0 = cut_bound(nb.rec, T.grad + (size_t)id * (p + 1) * p, p, P.eps_a,
+                                              P.eps_r, B.lane, L.M);
+                if (B.lane == 0) s_bnd = bnd0;
+            }
+            __syncthreads();
+            const double bnd = s_bnd;
+            __syncthreads();
+            if (bnd < -EHM_ROUTE_TOL * (1.0 + fabs(nb.rec[rec_off_vcost(p)]))) {
+                if (tid == 0) {
+                    atomicAdd(&cnt->cert_closed, 1ULL);
+                    T.tstar[id] = bnd;
+                    T.flags[id] |= 1;
+                    atomicMin(&cnt->min_margin_bits,
+                              (unsigned long long)__double_as_longlong(-bnd));
+                }
+                decided = true;
+            }
+        }
+        if (!decided && T.wit && sign_only) {
+            const double* wv = T.wit + (size_t)id * (p + 2);
+            const double* Vc = nb.rec + rec_off_vcost(p);
+            double vbw = 0.0;
+            for (int q = 0; q <= p; ++q) vbw = fma(wv[1 + q], Vc[q], vbw);
+            const double cw = wv[0];
+            const double tw = fmin(vbw - cw - P.eps_a, vbw - (1.0 + P.eps_r) * cw);
+            if (tw > EHM_ROUTE_TOL * (1.0 + fabs(vbw))) {
+                if (tid == 0) {
+                    atomicAdd(&cnt->wit_inherited, 1ULL);
+                    T.tstar[id] = tw;
+                    atomicMin(&cnt->min_margin_bits,
+                              (unsigned long long)__double_as_longlong(tw));
+                }
+                decided = true;
+                open = true;
+            }
+        }
+        if (!decided) {
+            IpmResult r;
+            int its = 0;
+            for (int attempt = 0; attempt < EHM4_ATTEMPTS; ++attempt) {
+                const double b = assemble_simplex(S, L, nb.rec, nb.rec + rec_off_vcost(p), SX_SLACK,
+                                                  P.eps_a, P.eps_r, pin(tid));
+                r = ipm_solve<NTILE>(S, L, B, b, sign_only != 0, step_fraction(attempt));
+                its += r.iters;
+                if (r.status == 0) break;
+            }
+            r.iters = its;
+            count_solve(cnt, r, tid);
+            if (T.wit && B.wave == 0) {
+                // this node's own witness (see k4_lcss_decide); its children read it below
+                const bool ok = sign_only && r.status == 0 && -r.obj >= 0.0;
+                double* wv = T.wit + (size_t)id * (p + 2);
+                double cz = 0.0;
+                for (int q = B.lane; q < P.n; q += 64) cz = fma(S.cv[q], L.xb()[zcol(S, q)], cz);
+                cz = wave_sum(cz);
+                const double beta = (B.lane < p) ? L.xb()[S.nd0 + B.lane] : 0.0;
+                const double sb = wave_sum(beta);
+                if (B.lane < p) wv[2 + B.lane] = ok ? beta : 0.0;
+                if (B.lane == 0) {
+                    wv[0] = ok ? fma(EHM_WIT_REL, r.margin, cz) : 0.0;
+                    wv[1] = ok ? 1.0 - sb : 0.0;
+                }
+            }
+            const double t = -r.obj;
+            open = (t >= 0.0);
+            if (tid == 0) {
+                if (r.status != 0) {
+                    atomicAdd(&cnt->errors, 1ULL);
+                    T.flags[id] |= 8;
+                }
+                atomicAdd(&cnt->slack_solves, 1ULL);
+                atomicAdd(&cnt->slack_iters, (unsigned long long)r.iters);
+                T.tstar[id] = t;
+                if (!open) T.flags[id] |= 1;
+                atomicMin(&cnt->min_margin_bits, (unsigned long long)__double_as_longlong(r.margin));
+                if (r.margin < EHM_ROUTE_TOL * (1.0 + fabs(nb.rec[rec_off_vcost(p)])))
+                    atomicAdd(&cnt->routed, 1ULL);
+            }
+        }
+        if (tid == 0) {
+            depth_seen = (dep > depth_seen) ? dep : depth_seen;
+            s_open = open ? 1 : 0;
+        }
+        __syncthreads();
+        if (!open) {
+            if (tid == 0) {
+                ++n_closed;
+                atomicSub(&ctl->pending, 1);
+            }
+            continue;
+        }
+        if (max_depth > 0 && dep >= max_depth) {
+            if (tid == 0) {
+                trunc = 1;
+                atomicSub(&ctl->pending, 1);
+            }
+            continue;
+        }
+        // ---- bisection, midpoint optimum, children (k4_lcss_expand) ----------------------------
+        if (tid == 0) s_c0 = atomicAdd(&ctl->n_nodes, 2);
+        double* node = nb.rec;
+        double* mid = nb.th;
+        int bi, bj;
+        longest_edge(node, p, bi, bj);
+        if (tid < p) {
+#pragma clang fp contract(off)
+            mid[tid] = (node[bi * p + tid] + node[bj * p + tid]) / 2.0;
+        }
+        __syncthreads();
+        const int c0 = s_c0;
+        if (c0 + 2 > node_cap) {
+            if (tid == 0) {
+                atomicMax(&ctl->abort, 1);
+                atomicSub(&ctl->pending, 1);
+            }
+            break;
+        }
+        const int d = T.didx[id];
+        IpmResult r;
+        r.obj = 0.0;
+        r.status = 0;
+        r.merit = 0.0;
+        int mt_res = MT_NONE, mt_slot = 0;
+        unsigned long long mt_tg = 0ull;
+        if (T.mt.state) {
+            unsigned int mt_i = 0u;
+            mt_tg = mt_tag(mid, p, T.mt.mask, &mt_i);
+            if (tid == 0) {
+                int sl = 0;
+                s_mt[0] = mt_claim(T.mt, mt_tg, mt_i, t_start, 60LL * 100000000LL, &sl);
+                s_mt[1] = sl;
+            }
+            __syncthreads();
+            mt_res = s_mt[0];
+            mt_slot = s_mt[1];
+            if (mt_res == MT_HIT) {
+                if (B.wave == 0) {      // entry layout: ehm_midtable.h
+                    bool same = false;
+                    const double ev = mt_read(T.mt, mt_slot, B.lane, mid, p, &same);
+                    if (B.lane == 8) s_mtv[0] = ev;
+                    if (B.lane == 9) s_mtv[1] = ev;
+                    if (B.lane >= 10 && B.lane < 10 + n_u) L.xb()[B.lane - 10] = ev;
+                    if (T.grad && B.lane >= 18 && B.lane < 18 + p) nb.g[B.lane - 18] = ev;
+                    if (B.lane == 0) s_mt[2] = same ? 1 : 0;
+                }
+                __syncthreads();
+                if (!s_mt[2]) mt_res = MT_NONE;         // another midpoint with this tag
+                else {
+                    r.obj = s_mtv[0];
+                    r.status = ((int)s_mtv[1]) & 0xff;
+                    if (tid == 0) atomicAdd(&cnt->mid_shared, 1ULL);
+                }
+            }
+        }
+        if (mt_res != MT_HIT) {
+            int its = 0;
+            for (int attempt = 0; attempt < EHM4_ATTEMPTS; ++attempt) {
+                const double b = assemble_point(S, L, mid, false, pin(tid));
+                r = ipm_solve<NTILE>(S, L, B, b, false, step_fraction(attempt),
+                                     T.grad ? nb.g : nullptr);
+                its += r.iters;
+                if (r.status == 0) break;
+            }
+            r.iters = its;
+            count_solve(cnt, r, tid);
+            if (mt_res == MT_OWN) {
+                __syncthreads();
+                if (B.wave == 0)
+                    mt_publish(T.mt, mt_slot, mt_tg, B.lane, mid, p, r.obj, r.status,
+                               (r.status == 0 && r.merit <= 1.0) ? 1 : 0, its, L.xb(), n_u,
+                               T.grad ? nb.g : nullptr);
+            }
+        }
+        if (r.status != 0 && tid == 0) {
+            atomicAdd(&cnt->errors, 1ULL);
+            T.flags[id] |= 16;
+        }
+        __syncthreads();
+        if (T.grad) {       // the children inherit the vertex gradients, the midpoint's is new
+            const int ng = (p + 1) * p;
+            const double* gp_ = T.grad + (size_t)id * ng;
+            double* g0 = T.grad + (size_t)c0 * ng;
+            for (int k = tid; k < ng; k += NT) {
+                const double gv = gp_[k];
+                K4_WT(g0 + k, (k >= bi * p && k < bi * p + p) ? nb.g[k - bi * p] : gv);
+                K4_WT(g0 + ng + k, (k >= bj * p && k < bj * p + p) ? nb.g[k - bj * p] : gv);
+            }
+        }
+        if (T.wit && tid < p + 2) {
+            const double* wv = T.wit + (size_t)id * (p + 2);
+            double* w0 = T.wit + (size_t)c0 * (p + 2);
+            double v0, v1;
+            witness_for_children(wv, node + rec_off_vcost(p), bi, bj, tid, v0, v1);
+            const bool none = wv[0] == 0.0 && wv[1 + bi] == 0.0 && wv[1 + bj] == 0.0;
+            K4_WT(w0 + tid, none ? 0.0 : v0);
+            K4_WT(w0 + (p + 2) + tid, none ? 0.0 : v1);
+        }
+        double* rec0 = T.rec + (size_t)c0 * T.rec_stride;
+        double* rec1 = rec0 + T.rec_stride;
+        const int ov = rec_off_vcost(p), ou = rec_off_vinput(p);
+        for (int k = tid; k < nrec; k += NT) {
+            double v0 = node[k], v1 = node[k];
+            if (k < ov) {                       // vertices: row bi / bj replaced
+                if (k >= bi * p && k < bi * p + p) v0 = mid[k - bi * p];
+                if (k >= bj * p && k < bj * p + p) v1 = mid[k - bj * p];
+            } else if (k < ou) {                // vertex costs
+                if (k - ov == bi) v0 = r.obj;
+                if (k - ov == bj) v1 = r.obj;
+            } else {                            // vertex inputs
+                const int q = k - ou;
+                if (q >= bi * n_u && q < bi * n_u + n_u) v0 = L.xb()[q - bi * n_u];
+                if (q >= bj * n_u && q < bj * n_u + n_u) v1 = L.xb()[q - bj * n_u];
+            }
+            K4_WT(rec0 + k, v0);
+            K4_WT(rec1 + k, v1);
+        }
+        if (tid == 0) {
+            T.left[id] = c0;
+            K4_WT(&T.left[c0], -1);
+            K4_WT(&T.left[c0 + 1], -1);
+            K4_WT(&T.didx[c0], d);
+            K4_WT(&T.didx[c0 + 1], d);
+            K4_WT(&T.depth[c0], dep + 1);
+            K4_WT(&T.depth[c0 + 1], dep + 1);
+            K4_WT(&T.flags[c0], (uint8_t)2);
+            K4_WT(&T.flags[c0 + 1], (uint8_t)2);
+            K4_WT(&T.tstar[c0], 0.0);
+            K4_WT(&T.tstar[c0 + 1], 0.0);
+        }
+        // every thread's write-through stores have completed before the slots go out
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+        __builtin_amdgcn_s_waitcnt(0);
+        __syncthreads();
+        if (tid == 0) {
+            ++n_splits;
+            const int t = atomicAdd(&ctl->tail, 2);
+            if (t + 2 <= n_slots) {
+                __hip_atomic_store(&slots[t], c0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                __hip_atomic_store(&slots[t + 1], c0 + 1, __ATOMIC_RELAXED,
+                                   __HIP_MEMORY_SCOPE_AGENT);
+                atomicAdd(&ctl->pending, 1);        // -1 (this node) + 2 children
+            } else {
+                atomicMax(&ctl->abort, 1);
+                atomicSub(&ctl->pending, 1);
+            }
+        }
+    }
+    if (tid0 == 0) {
+        atomicAdd(&ctl->closed, n_closed);
+        atomicAdd(&ctl->splits, n_splits);
+        atomicMax(&ctl->max_depth_seen, depth_seen);
+        if (trunc) atomicMax(&ctl->truncated, 1);
+        atomicAdd(&cnt->prof[0], (unsigned long long)(wall_clock64() - t_start));
+    }
+    (void)deal;
+}
+#undef K4_WT
+
 // ---- vertex solves that seed a node's costs / inputs (lib/oracle.py:416-443) ---------------
 template <int NTILE>
 EHM4_KERNEL void k4_vertex_solve(
@@ -636,7 +959,8 @@ hipError_t set_lds(int bytes) {
                         (const void*)k4_simplex_batch<2>, (const void*)k4_simplex_batch<3>,
                         (const void*)k4_lcss_decide<2>,   (const void*)k4_lcss_decide<3>,
                         (const void*)k4_lcss_expand<2>,   (const void*)k4_lcss_expand<3>,
-                        (const void*)k4_vertex_solve<2>,  (const void*)k4_vertex_solve<3>};
+                        (const void*)k4_vertex_solve<2>,  (const void*)k4_vertex_solve<3>,
+                        (const void*)k4_persist<2>,       (const void*)k4_persist<3>};
     for (const void* k : ks) {
         hipError_t e = hipFuncSetAttribute(k, hipFuncAttributeMaxDynamicSharedMemorySize, bytes);
         if (e != hipSuccess) return e;
@@ -714,6 +1038,16 @@ void l_vertex(const K2Launch& L, DevProblem P, DevTree T, const int32_t* nodes, 
         hipLaunchKernelGGL(k4_vertex_solve<2>, dim3(L.grid), dim3(L.threads), L.lds_bytes, L.stream,
                            P, T, nodes, n_nodes, cnt);
 }
+void l_persist(const K2Launch& L, DevProblem P, DevTree T, int32_t* slots, int n_slots,
+               PersistCtl* ctl, int node_cap, DevCounters* cnt, int sign_only, int max_depth,
+               PersistDeal deal) {
+    if (ntile_of(P) == 3)
+        hipLaunchKernelGGL(k4_persist<3>, dim3(L.grid), dim3(L.threads), L.lds_bytes, L.stream, P, T,
+                           slots, n_slots, ctl, node_cap, cnt, sign_only, max_depth, deal);
+    else
+        hipLaunchKernelGGL(k4_persist<2>, dim3(L.grid), dim3(L.threads), L.lds_bytes, L.stream, P, T,
+                           slots, n_slots, ctl, node_cap, cnt, sign_only, max_depth, deal);
+}
 void l_selftest(hipStream_t stream, double* out) {
     hipLaunchKernelGGL(k4_selftest, dim3(1), dim3(EHM4_THREADS), O_VAR * sizeof(double), stream,
                        out);
@@ -722,7 +1056,7 @@ void l_selftest(hipStream_t stream, double* out) {
 // np = 48 factorised columns; slots in units of 64 rows; one LP per workgroup of 512 threads
 const K2Api g_api = {NF,       EHM4_THREADS / 64, EHM4_THREADS, EHM4_THREADS, set_lds,
                      unit_doubles_for, shared_doubles_for, l_point, l_simplex, l_decide,
-                     l_expand, l_vertex, l_selftest, nullptr, fits};
+                     l_expand, l_vertex, l_selftest, l_persist, fits};
 
 }  // namespace
 

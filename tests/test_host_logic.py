@@ -445,6 +445,22 @@ def test_a_failing_secondary_workload_does_not_cost_the_headline(monkeypatch):
     assert line['config'] == {'workload': 'w', 'regions_per_step': 7}
     assert line['roofline'] == {'frac': 0.1} and line['cpu_baseline'] == {'value': 5.}
     assert isinstance(args, argparse.Namespace) and args.workload == 'config2'   # untouched
+    # the time-boxed configs[4] entry: the config5 driver with a region target, the Delaunay roots
+    # in order, a soft time limit and the depth limit -- and skippable
+    seen = {}
+
+    def c5(a, ctx):
+        seen.update(workload=a.workload, regions=a.regions, cells=a.cells, seconds=a.seconds,
+                    max_depth=a.max_depth)
+        return dict(value=1., unit='LP solves/s', ms_per_step=2., regions_per_s=3., steps=1,
+                    warmup=0, roofline={}, cpu_baseline=None, config={'workload': 'c5'})
+    monkeypatch.setattr(bench, 'measure_config5', c5)
+    line = bench.secondary_line(args, {}, 'config5_scale', 1, 0)
+    assert seen == dict(workload='config5', regions=10 ** 6, cells=400,
+                        seconds=args.scale_seconds, max_depth=26)
+    assert line['name'] == 'config5_scale' and line['limits']['soft_seconds'] == args.scale_seconds
+    args.scale_seconds = 0.
+    assert 'skipped' in bench.secondary_line(args, {}, 'config5_scale', 1, 0)
 
 
 def test_cpu_baseline_leg_of_the_bench_runs():
