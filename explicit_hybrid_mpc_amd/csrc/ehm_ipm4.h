@@ -80,7 +80,9 @@ constexpr int O_REC = 0;                    // node record (rec_doubles <= 160)
 constexpr int O_TH = O_REC + 160;           // parameter / midpoint (8)
 constexpr int O_RED = O_TH + 8;             // [2][NWV][8] workgroup reductions
 constexpr int O_G = O_RED + 2 * NWV * 8;    // gradient of a point solve (8)
-constexpr int O_X = O_G + 8;                // [2][NC] dense extra rows, internal column order
+constexpr int O_STASH = O_G + 8;            // first input of a midpoint solve kept across the
+                                            // suboptimality-test LP (k4_persist, 8)
+constexpr int O_X = O_STASH + 8;            // [2][NC] dense extra rows, internal column order
 constexpr int O_XH = O_X + 2 * NC;          // [2][NF] the same, reduced
 constexpr int O_HX = O_XH + 2 * NF;         // [2][MAXNE]  X_E Delta^-1
 constexpr int O_ID = O_HX + 2 * MAXNE;      // [MAXNE] 1 / Delta_e

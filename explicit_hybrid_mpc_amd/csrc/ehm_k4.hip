@@ -611,8 +611,15 @@ EHM4_KERNEL void k4_persist(
         for (int k = tid; k < nrec; k += NT) nb.rec[k] = rec[k];
         const int dep = T.depth[id];
         __syncthreads();
-        // ---- the decision (k4_lcss_decide) --------------------------------------------------
+        // ---- the decision --------------------------------------------------------------------
+        // tangent-plane bound, inherited witness (k4_lcss_decide); then -- the midpoint-first flow
+        // of the shared-block persistent kernel -- the midpoint optimum BEFORE the
+        // suboptimality-test LP: a node that is not closed by the bound is almost always open and
+        // needs that optimum anyway, and at theta = mid the interpolated cost is (V_bi + V_bj) / 2,
+        // so  t_mid = min(Vbar - J_mid - eps_a, Vbar - (1 + eps_r) J_mid) <= t*  and t_mid > 0
+        // proves the node open without its LP; otherwise the LP decides as before.
         bool open = false, decided = false;
+        bool hand_on = false;           // T.wit[id] is a witness worth handing to the children
         if (T.grad && sign_only) {
             if (B.wave == 0) {
                 const double bnd0 = cut_bound(nb.rec, T.grad + (size_t)id * (p + 1) * p, p, P.eps_a,
@@ -649,6 +656,97 @@ EHM4_KERNEL void k4_persist(
                 }
                 decided = true;
                 open = true;
+                hand_on = true;
+            }
+        }
+        const bool can_split = !(max_depth > 0 && dep >= max_depth);
+        double* node = nb.rec;
+        double* mid = nb.th;
+        double* xmid = lds_at(O_STASH);     // first input of the midpoint optimum
+        int bi = 0, bj = 1;
+        double Jm = 0.0;
+        int mid_status = 0;
+        if ((!decided || open) && can_split) {
+            // ---- midpoint optimum: from the table of the simplices around the edge, or by an LP
+            longest_edge(node, p, bi, bj);
+            if (tid < p) {
+#pragma clang fp contract(off)
+                mid[tid] = (node[bi * p + tid] + node[bj * p + tid]) / 2.0;
+            }
+            __syncthreads();
+            bool mid_conv = false;
+            int mt_res = MT_NONE, mt_slot = 0;
+            unsigned long long mt_tg = 0ull;
+            if (T.mt.state) {
+                unsigned int mt_i = 0u;
+                mt_tg = mt_tag(mid, p, T.mt.mask, &mt_i);
+                if (tid == 0) {
+                    int sl = 0;
+                    s_mt[0] = mt_claim(T.mt, mt_tg, mt_i, t_start, 60LL * 100000000LL, &sl);
+                    s_mt[1] = sl;
+                }
+                __syncthreads();
+                mt_res = s_mt[0];
+                mt_slot = s_mt[1];
+                if (mt_res == MT_HIT) {
+                    if (B.wave == 0) {      // entry layout: ehm_midtable.h
+                        bool same = false;
+                        const double ev = mt_read(T.mt, mt_slot, B.lane, mid, p, &same);
+                        if (B.lane == 8) s_mtv[0] = ev;
+                        if (B.lane == 9) s_mtv[1] = ev;
+                        if (B.lane >= 10 && B.lane < 10 + n_u) xmid[B.lane - 10] = ev;
+                        if (T.grad && B.lane >= 18 && B.lane < 18 + p) nb.g[B.lane - 18] = ev;
+                        if (B.lane == 0) s_mt[2] = same ? 1 : 0;
+                    }
+                    __syncthreads();
+                    if (!s_mt[2]) mt_res = MT_NONE;         // another midpoint with this tag
+                    else {
+                        const int word = (int)s_mtv[1];
+                        Jm = s_mtv[0];
+                        mid_status = word & 0xff;
+                        mid_conv = ((word >> 8) & 1) != 0;
+                        if (tid == 0) atomicAdd(&cnt->mid_shared, 1ULL);
+                    }
+                }
+            }
+            if (mt_res != MT_HIT) {
+                IpmResult r;
+                int its = 0;
+                for (int attempt = 0; attempt < EHM4_ATTEMPTS; ++attempt) {
+                    const double b = assemble_point(S, L, mid, false, pin(tid));
+                    r = ipm_solve<NTILE>(S, L, B, b, false, step_fraction(attempt),
+                                         T.grad ? nb.g : nullptr);
+                    its += r.iters;
+                    if (r.status == 0) break;
+                }
+                r.iters = its;
+                count_solve(cnt, r, tid);
+                Jm = r.obj;
+                mid_status = r.status;
+                mid_conv = (r.status == 0) && (r.merit <= 1.0);     // not merely "accepted"
+                if (tid < n_u) xmid[tid] = L.xb()[tid];
+                if (mt_res == MT_OWN) {
+                    __syncthreads();
+                    if (B.wave == 0)
+                        mt_publish(T.mt, mt_slot, mt_tg, B.lane, mid, p, Jm, mid_status,
+                                   mid_conv ? 1 : 0, its, L.xb(), n_u, T.grad ? nb.g : nullptr);
+                }
+            }
+            __syncthreads();
+            if (sign_only && mid_conv && !decided) {
+                const double* Vc = node + rec_off_vcost(p);
+                const double vb = 0.5 * (Vc[bi] + Vc[bj]);
+                const double tw = fmin(vb - Jm - P.eps_a, vb - (1.0 + P.eps_r) * Jm);
+                if (tw > EHM_ROUTE_TOL * (1.0 + fabs(vb))) {
+                    open = true;
+                    decided = true;
+                    if (tid == 0) {
+                        atomicAdd(&cnt->wit_open, 1ULL);
+                        T.tstar[id] = tw;
+                        atomicMin(&cnt->min_margin_bits,
+                                  (unsigned long long)__double_as_longlong(tw));
+                    }
+                }
             }
         }
         if (!decided) {
@@ -678,6 +776,7 @@ EHM4_KERNEL void k4_persist(
                     wv[1] = ok ? 1.0 - sb : 0.0;
                 }
             }
+            hand_on = true;             // (zeros after a failed or negative solve: "none")
             const double t = -r.obj;
             open = (t >= 0.0);
             if (tid == 0) {
@@ -694,10 +793,7 @@ EHM4_KERNEL void k4_persist(
                     atomicAdd(&cnt->routed, 1ULL);
             }
         }
-        if (tid == 0) {
-            depth_seen = (dep > depth_seen) ? dep : depth_seen;
-            s_open = open ? 1 : 0;
-        }
+        if (tid == 0) depth_seen = (dep > depth_seen) ? dep : depth_seen;
         __syncthreads();
         if (!open) {
             if (tid == 0) {
@@ -706,23 +802,19 @@ EHM4_KERNEL void k4_persist(
             }
             continue;
         }
-        if (max_depth > 0 && dep >= max_depth) {
+        if (!can_split) {
             if (tid == 0) {
                 trunc = 1;
                 atomicSub(&ctl->pending, 1);
             }
             continue;
         }
-        // ---- bisection, midpoint optimum, children (k4_lcss_expand) ----------------------------
-        if (tid == 0) s_c0 = atomicAdd(&ctl->n_nodes, 2);
-        double* node = nb.rec;
-        double* mid = nb.th;
-        int bi, bj;
-        longest_edge(node, p, bi, bj);
-        if (tid < p) {
-#pragma clang fp contract(off)
-            mid[tid] = (node[bi * p + tid] + node[bj * p + tid]) / 2.0;
+        // ---- children (the midpoint optimum is in Jm / xmid / nb.g) -----------------------------
+        if (mid_status != 0 && tid == 0) {
+            atomicAdd(&cnt->errors, 1ULL);
+            T.flags[id] |= 16;
         }
+        if (tid == 0) s_c0 = atomicAdd(&ctl->n_nodes, 2);
         __syncthreads();
         const int c0 = s_c0;
         if (c0 + 2 > node_cap) {
@@ -733,66 +825,7 @@ EHM4_KERNEL void k4_persist(
             break;
         }
         const int d = T.didx[id];
-        IpmResult r;
-        r.obj = 0.0;
-        r.status = 0;
-        r.merit = 0.0;
-        int mt_res = MT_NONE, mt_slot = 0;
-        unsigned long long mt_tg = 0ull;
-        if (T.mt.state) {
-            unsigned int mt_i = 0u;
-            mt_tg = mt_tag(mid, p, T.mt.mask, &mt_i);
-            if (tid == 0) {
-                int sl = 0;
-                s_mt[0] = mt_claim(T.mt, mt_tg, mt_i, t_start, 60LL * 100000000LL, &sl);
-                s_mt[1] = sl;
-            }
-            __syncthreads();
-            mt_res = s_mt[0];
-            mt_slot = s_mt[1];
-            if (mt_res == MT_HIT) {
-                if (B.wave == 0) {      // entry layout: ehm_midtable.h
-                    bool same = false;
-                    const double ev = mt_read(T.mt, mt_slot, B.lane, mid, p, &same);
-                    if (B.lane == 8) s_mtv[0] = ev;
-                    if (B.lane == 9) s_mtv[1] = ev;
-                    if (B.lane >= 10 && B.lane < 10 + n_u) L.xb()[B.lane - 10] = ev;
-                    if (T.grad && B.lane >= 18 && B.lane < 18 + p) nb.g[B.lane - 18] = ev;
-                    if (B.lane == 0) s_mt[2] = same ? 1 : 0;
-                }
-                __syncthreads();
-                if (!s_mt[2]) mt_res = MT_NONE;         // another midpoint with this tag
-                else {
-                    r.obj = s_mtv[0];
-                    r.status = ((int)s_mtv[1]) & 0xff;
-                    if (tid == 0) atomicAdd(&cnt->mid_shared, 1ULL);
-                }
-            }
-        }
-        if (mt_res != MT_HIT) {
-            int its = 0;
-            for (int attempt = 0; attempt < EHM4_ATTEMPTS; ++attempt) {
-                const double b = assemble_point(S, L, mid, false, pin(tid));
-                r = ipm_solve<NTILE>(S, L, B, b, false, step_fraction(attempt),
-                                     T.grad ? nb.g : nullptr);
-                its += r.iters;
-                if (r.status == 0) break;
-            }
-            r.iters = its;
-            count_solve(cnt, r, tid);
-            if (mt_res == MT_OWN) {
-                __syncthreads();
-                if (B.wave == 0)
-                    mt_publish(T.mt, mt_slot, mt_tg, B.lane, mid, p, r.obj, r.status,
-                               (r.status == 0 && r.merit <= 1.0) ? 1 : 0, its, L.xb(), n_u,
-                               T.grad ? nb.g : nullptr);
-            }
-        }
-        if (r.status != 0 && tid == 0) {
-            atomicAdd(&cnt->errors, 1ULL);
-            T.flags[id] |= 16;
-        }
-        __syncthreads();
+        struct { double obj; } r = {Jm};
         if (T.grad) {       // the children inherit the vertex gradients, the midpoint's is new
             const int ng = (p + 1) * p;
             const double* gp_ = T.grad + (size_t)id * ng;
@@ -808,7 +841,7 @@ EHM4_KERNEL void k4_persist(
             double* w0 = T.wit + (size_t)c0 * (p + 2);
             double v0, v1;
             witness_for_children(wv, node + rec_off_vcost(p), bi, bj, tid, v0, v1);
-            const bool none = wv[0] == 0.0 && wv[1 + bi] == 0.0 && wv[1 + bj] == 0.0;
+            const bool none = !hand_on || (wv[0] == 0.0 && wv[1 + bi] == 0.0 && wv[1 + bj] == 0.0);
             K4_WT(w0 + tid, none ? 0.0 : v0);
             K4_WT(w0 + (p + 2) + tid, none ? 0.0 : v1);
         }
@@ -825,8 +858,8 @@ EHM4_KERNEL void k4_persist(
                 if (k - ov == bj) v1 = r.obj;
             } else {                            // vertex inputs
                 const int q = k - ou;
-                if (q >= bi * n_u && q < bi * n_u + n_u) v0 = L.xb()[q - bi * n_u];
-                if (q >= bj * n_u && q < bj * n_u + n_u) v1 = L.xb()[q - bj * n_u];
+                if (q >= bi * n_u && q < bi * n_u + n_u) v0 = xmid[q - bi * n_u];
+                if (q >= bj * n_u && q < bj * n_u + n_u) v1 = xmid[q - bj * n_u];
             }
             K4_WT(rec0 + k, v0);
             K4_WT(rec1 + k, v1);

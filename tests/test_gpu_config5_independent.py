@@ -10,7 +10,7 @@ law, oracle/milp_check.py):
   indicators) is infeasible;
 * closed leaves: vertex costs = the uncondensed fixed-sequence LP; where the commutation was
   adopted at the cell it is the lexicographic minimum of V_R's MILP; bar_E's MILP has max t < 0;
-* lcss splits (round 6): bar_E's MILP has max t >= 0 (the largest over big-M 50 / 10 / 200 -- any
+* an lcss split (round 6): bar_E's MILP has max t >= 0 (the largest over big-M 50 / 10 / 200 -- any
   run's point is feasible for the reference's problem, so that is a certified lower bound), the
   children are the longest-edge bisection and hold the node's commutation or bar_D's optimum --
   compared tie-aware: a child's sequence is also accepted where it is feasible at every vertex
@@ -55,7 +55,7 @@ def test_nodes_of_a_native_tree_against_one_milp_per_oracle_call():
     assert len(lcss_splits) >= 2
     picks = list(rng.choice(ecc_splits, 3, replace=False)) + \
         list(rng.choice(own_leaves, 2, replace=False)) + \
-        list(rng.choice(lcss_splits, 2, replace=False))
+        list(rng.choice(lcss_splits, 1, replace=False))     # (~3 min of HiGHS per lcss split)
     seq_of = lambda d: tuple(int(i) for i in np.asarray(d).reshape(mpc.N, mpc.delta_size).argmax(1))
     nv, p = roots.shape[1], roots.shape[2]
     for k, i in enumerate(picks):
