@@ -1037,13 +1037,16 @@ __device__ __forceinline__ void form_normal_matrix(const Blk& S, const Lp& L, co
         const int r = tid >> 3, c0 = 6 * (tid & 7);
         if (r < nrf) {
             const bool ron = (L.act >> r) & 1ULL;
-            const double x0 = ce0 * L.xh()[r], x1 = ce1 * L.xh()[NF + r];
+            // (the reduced dense rows exist only where kd > 0: L.xh is NOT written otherwise, and
+            // 0 x whatever-LDS-held is NaN as soon as that is a NaN pattern -- selects, not products)
+            const double x0 = (L.kd > 0) ? ce0 * L.xh()[r] : 0.0;
+            const double x1 = (L.kd > 1) ? ce1 * L.xh()[NF + r] : 0.0;
             double v[6], h0[6], h1[6];
 #pragma unroll
             for (int k = 0; k < 6; ++k) {
                 v[k] = L.M[r * SQ + c0 + k];
-                h0[k] = L.xh()[c0 + k];
-                h1[k] = L.xh()[NF + c0 + k];
+                h0[k] = (L.kd > 0) ? L.xh()[c0 + k] : 0.0;
+                h1[k] = (L.kd > 1) ? L.xh()[NF + c0 + k] : 0.0;
             }
 #pragma unroll
             for (int k = 0; k < 6; ++k) {

@@ -159,7 +159,13 @@ __device__ __forceinline__ void count_solve(DevCounters* cnt, const IpmResult& r
     Blk S;                                                                       \
     carve_blk(S, sm + O_VAR + lp_doubles(P.m, P.p, P.nd0, P.n - P.nd0), P);      \
     Lp L;                                                                        \
-    carve_lp(L, sm + O_VAR, S)
+    carve_lp(L, sm + O_VAR, S);                                                  \
+    /* the workspace starts as numbers: LDS is not cleared between kernels, and  \
+       several phases multiply exact zeros with entries they never wrote */      \
+    for (int k_ = tid0;                                                          \
+         k_ < O_VAR + (int)lp_doubles(P.m, P.p, P.nd0, P.n - P.nd0); k_ += NT)   \
+        sm[k_] = 0.0;                                                            \
+    __syncthreads()
 
 // the block of commutation d into LDS (all threads; barriers on both sides)
 #define K4_USE_BLOCK(D)                                                          \
@@ -748,6 +754,81 @@ EHM4_KERNEL void k4_persist(
                     }
                 }
             }
+        }
+        if (!decided && T.mt.state && sign_only) {
+            // The OTHER edges' midpoints (the headline kernel's W_WITT): a neighbour that has
+            // bisected one of this simplex's edges left the optimal cost at that edge's midpoint in
+            // the table -- a candidate witness like the node's own midpoint (V*(mid') known,
+            // interpolated cost (V_a + V_b) / 2) and, unlike it, a point the children inherit.
+            // Wavefront 0: lane e looks edge e up (read-only, nobody waits).
+            if (B.wave == 0) {
+                const int lane = B.lane;
+                const double* Vc = node + rec_off_vcost(p);
+                double tw_l = -1e300, J_l = 0.0;
+                int ea = 0, eb = 1, slot_l = -1;
+                const int n_edges = (p + 1) * p / 2;
+                double* em = L.M + 8 * (lane < n_edges ? lane : 0);     // lane e's midpoint
+                if (lane < n_edges) {
+                    int rem = lane;
+                    while (rem >= p - ea) { rem -= (p - ea); ++ea; }
+                    eb = ea + 1 + rem;
+                    if (!(ea == bi && eb == bj && can_split)) {
+                        {
+#pragma clang fp contract(off)
+                            for (int k = 0; k < p; ++k)
+                                em[k] = (node[ea * p + k] + node[eb * p + k]) / 2.0;
+                        }
+                        unsigned int e_i = 0u;
+                        const unsigned long long e_tg = mt_tag(em, p, T.mt.mask, &e_i);
+                        slot_l = mt_find(T.mt, e_tg, e_i);
+                    }
+                }
+                if (__builtin_amdgcn_ballot_w64(slot_l >= 0) != 0ull) {
+                    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+                    if (slot_l >= 0) {
+                        const double* e = T.mt.data + (size_t)slot_l * MT_DOUBLES;
+                        bool same = true;
+                        for (int k = 0; k < p; ++k)
+                            same = same && __double_as_longlong(e[k]) == __double_as_longlong(em[k]);
+                        const int word = (int)e[9];
+                        if (same && (word & 0xff) == 0 && ((word >> 8) & 1)) {   // converged optimum
+                            J_l = e[8];
+                            const double vb = 0.5 * (Vc[ea] + Vc[eb]);
+                            const double tw = fmin(vb - J_l - P.eps_a, vb - (1.0 + P.eps_r) * J_l);
+                            if (tw > EHM_ROUTE_TOL * (1.0 + fabs(vb))) tw_l = tw;
+                        }
+                    }
+                }
+                const unsigned long long won = __builtin_amdgcn_ballot_w64(tw_l > -1e299);
+                if (lane == 0) s_mt[0] = 0;
+                if (won != 0ull) {
+                    // first edge (enumeration order) whose midpoint proves the node open
+                    const int src = __builtin_ctzll(won);
+                    const double tw = __shfl(tw_l, src);
+                    const double Jw = __shfl(J_l, src);
+                    const int wa = __shfl(ea, src), wb = __shfl(eb, src);
+                    if (T.wit) {
+                        double* wv = T.wit + (size_t)id * (p + 2);
+                        if (lane == 0) wv[0] = Jw;
+                        if (lane <= p) wv[1 + lane] = (lane == wa || lane == wb) ? 0.5 : 0.0;
+                    }
+                    if (lane == 0) {
+                        s_mt[0] = 1;
+                        s_mtv[0] = tw;
+                        atomicAdd(&cnt->wit_table, 1ULL);
+                        T.tstar[id] = tw;
+                        atomicMin(&cnt->min_margin_bits,
+                                  (unsigned long long)__double_as_longlong(tw));
+                    }
+                }
+            }
+            __syncthreads();
+            if (s_mt[0]) {
+                open = true;
+                decided = true;
+                hand_on = T.wit != nullptr;
+            }
+            __syncthreads();
         }
         if (!decided) {
             IpmResult r;
