@@ -303,6 +303,9 @@ def parse_args(argv=None):
                          'progress read-back (and, N > 1, one all-gather) per round -- off by '
                          'default, the headline number is measured without it')
     ap.add_argument('--cpu-seconds', type=float, default=15.)
+    ap.add_argument('--host-streams', type=int, default=1,
+                    help='config5, native driver: driver handles that grow different roots at the '
+                         'same time from as many interpreter threads (the scale entry uses 2)')
     ap.add_argument('--scale-seconds', type=float, default=480.,
                     help='soft time limit of the config5_scale entry of "secondary" (0 = skip it)')
     ap.add_argument('--queries', type=int, default=1 << 21,
@@ -875,9 +878,16 @@ def measure_config5(args, ctx):
     # the native driver (include/ehm_frontier.h) owns device tables of its own; the Python oracle
     # stays for the cells the native driver hands back (failed vertex solves: none so far)
     native = None
+    natives = []
     if args.driver == 'native':
         from explicit_hybrid_mpc_amd import frontier
-        native = frontier.NativeFrontier(mpc, 1., 1., slots=16384, device=device_index)
+        # --host-streams S: S driver handles (own device tables, streams and host threads each) grow
+        # different roots at the same time from S interpreter threads -- the native calls release
+        # the GIL --, so that one handle's host bookkeeping between its solver calls (a quarter of a
+        # deep root's time) and the tails of its launches are filled with the other's kernels
+        natives = [frontier.NativeFrontier(mpc, 1., 1., slots=16384, device=device_index)
+                   for _ in range(max(1, args.host_streams))]
+        native = natives[0]
     t_eps = time.perf_counter()
     # eps_a by the reference's rule (lib/examples.py:42-46): 2^p P_theta searches in lockstep
     eps_a = float(np.max([j for _, _, j in (native.p_theta(abs_frac * V) if native else
@@ -885,8 +895,8 @@ def measure_config5(args, ctx):
     t_eps = time.perf_counter() - t_eps
     orc.eps_a, orc.eps_r = eps_a, eps_r
     orc.table.set_eps(eps_a, eps_r)
-    if native:
-        native.set_eps(eps_a, eps_r)
+    for nat in natives:
+        nat.set_eps(eps_a, eps_r)
     if args.roots == 'delaunay':
         from explicit_hybrid_mpc_amd import tools as ehm_tools
         root_cells, _ = ehm_tools.delaunay_roots(V)
@@ -924,9 +934,9 @@ def measure_config5(args, ctx):
             e['secs'] = [a + b for a, b in zip(e['secs'], st['batch_seconds'])]
             e['launches'] = [a + b for a, b in zip(e['launches'], st['batch_launches'])]
             e['hist'][:, :tb.by_length.shape[1]] += tb.by_length
-        if native:
-            counts = native.lp_counts()
-            for t, nt in enumerate(native.table_stats()):
+        for nat in natives:
+            counts = nat.lp_counts()
+            for t, nt in enumerate(nat.table_stats()):
                 e = per['h%d' % nt['horizon']]
                 e['lp'] += int(counts[t].sum())
                 e['iters'] += nt['ipm_iters']
@@ -939,29 +949,35 @@ def measure_config5(args, ctx):
                     hist=sum(v['hist'] for v in per.values()),
                     stalled=orc.table.stalled + nat_acc['stalled'])
 
-    def grow_group(part):
+    import threading
+    acc_lock = threading.Lock()
+
+    def grow_group(part, nat=None):
+        nat = nat or native
         if native is None:
             return bnb_frontier.grow_frontier(orc, part, 'ecc', order=args.order,
                                               table_backoff=True, round_cap=args.round_cap,
                                               min_regions=None if args.regions else regions,
                                               max_visits=args.max_visits)
-        orc.table.forget()
-        st = frontier.grow_cells(native, part, slow_oracle=lambda: orc, round_cap=args.round_cap,
+        if len(natives) == 1:
+            orc.table.forget()
+        st = frontier.grow_cells(nat, part, slow_oracle=lambda: orc, round_cap=args.round_cap,
                                  max_visits=args.max_visits or 0, deadline=step_deadline[0],
                                  max_depth=args.max_depth or 0,
                                  min_regions=0 if args.regions or regions >= (1 << 30) else regions,
                                  slow_opts=dict(order=args.order, table_backoff=True,
                                                 round_cap=args.round_cap))
-        nat_acc['calls']['P_theta'] += st['calls_p_theta']
-        nat_acc['calls']['V_R'] += st['calls_v_r']
-        nat_acc['calls']['bar_E'] += st['calls_bar_e']
-        nat_acc['calls']['bar_D'] += st['calls_bar_d']
-        nat_acc['expanded'] += st['prefixes_expanded']
-        nat_acc['stalled'] += st['stalled']
-        nat_acc['solver_seconds'] += st['seconds_solvers']
-        nat_acc['driver_seconds'] += st['seconds_total']
-        nat_acc['open_cells'] += st['slow_path_cells']
-        nat_acc['launches'] += st['launches']
+        with acc_lock:
+            nat_acc['calls']['P_theta'] += st['calls_p_theta']
+            nat_acc['calls']['V_R'] += st['calls_v_r']
+            nat_acc['calls']['bar_E'] += st['calls_bar_e']
+            nat_acc['calls']['bar_D'] += st['calls_bar_d']
+            nat_acc['expanded'] += st['prefixes_expanded']
+            nat_acc['stalled'] += st['stalled']
+            nat_acc['solver_seconds'] += st['seconds_solvers']
+            nat_acc['driver_seconds'] += st['seconds_total']
+            nat_acc['open_cells'] += st['slow_path_cells']
+            nat_acc['launches'] += st['launches']
         return dict(host_visits=st['visits'] + st['slow_path_visits'], rounds=st['rounds'],
                     regions=st['regions'], truncated=bool(st['truncated']), handoffs=0,
                     native_visits=st['visits'], slow_path_cells=st['slow_path_cells'],
@@ -971,12 +987,73 @@ def measure_config5(args, ctx):
 
     step_deadline = [None]
 
+    def merge(stats, st):
+        if stats is None:
+            return dict(st)
+        for k, v in st.items():         # counters add up, flags combine
+            if isinstance(v, bool):
+                stats[k] = bool(stats.get(k)) or v
+            elif isinstance(v, (int, float)):
+                stats[k] = stats.get(k, 0) + v
+        return stats
+
     def step():
         step_deadline[0] = time.perf_counter() + args.seconds if args.seconds > 0 else None
         # with a target of regions the cells are grown one group after the other, EACH TO
         # COMPLETION (every leaf eps-suboptimal), until the target is reached
         group = args.cells_at_once if args.cells_at_once > 0 else (
             1 if args.regions else max(len(my_cells), 1))
+        box = dict(stats=None, trees=[], next=0, error=None)
+
+        def claim():
+            """Next group of this rank's cells, or None when a limit is reached (under the lock)."""
+            with acc_lock:
+                if box['error'] is not None or box['next'] >= len(my_cells):
+                    return None
+                if args.regions and box['stats'] is not None and \
+                        box['stats'].get('regions', 0) >= regions:
+                    return None
+                if step_deadline[0] is not None and time.perf_counter() >= step_deadline[0]:
+                    return None
+                g0 = box['next']
+                box['next'] += group
+                return g0
+
+        def work(nat):
+            try:
+                while True:
+                    g0 = claim()
+                    if g0 is None:
+                        return
+                    part = [Tree(NodeData(vertices=cell_vertices(c)))
+                            for c in my_cells[g0:g0 + group]]
+                    t_g = time.perf_counter()
+                    st = grow_group(part, nat)
+                    with acc_lock:
+                        box['trees'] += part
+                        cells_log.append(dict(cells=my_cells[g0:g0 + group],
+                                              seconds=time.perf_counter() - t_g,
+                                              regions=int(st.get('regions', 0)),
+                                              rounds=int(st['rounds']),
+                                              visits=int(st['host_visits']),
+                                              truncated=bool(st['truncated'])))
+                        if args.progress_file and rank == 0:
+                            with open(args.progress_file, 'a') as f:
+                                f.write(json.dumps(cells_log[-1]) + '\n')
+                        box['stats'] = merge(box['stats'], st)
+            except BaseException as e:      # a worker's failure ends the step
+                with acc_lock:
+                    box['error'] = e
+
+        if len(natives) > 1:
+            threads = [threading.Thread(target=work, args=(nat,)) for nat in natives]
+            for t in threads:
+                t.start()
+            for t in threads:
+                t.join()
+            if box['error'] is not None:
+                raise box['error']
+            return box['stats'] or dict(host_visits=0, handoffs=0, truncated=False), box['trees']
         stats, trees = None, []
         for g0 in range(0, len(my_cells), group):
             if args.regions and stats is not None and stats.get('regions', 0) >= regions:
@@ -997,14 +1074,7 @@ def measure_config5(args, ctx):
             if args.progress_file and rank == 0:
                 with open(args.progress_file, 'a') as f:
                     f.write(json.dumps(cells_log[-1]) + '\n')
-            if stats is None:
-                stats = dict(st)
-            else:       # counters add up, flags combine
-                for k, v in st.items():
-                    if isinstance(v, bool):
-                        stats[k] = bool(stats.get(k)) or v
-                    elif isinstance(v, (int, float)):
-                        stats[k] = stats.get(k, 0) + v
+            stats = merge(stats, st)
         return stats or dict(host_visits=0, handoffs=0, truncated=False), trees
 
     def barrier():
@@ -1179,7 +1249,10 @@ def measure_config5(args, ctx):
                                'mod world, %s, no data-path collective' % (
                                    n_cells, world, min(world, max(torch.cuda.device_count(), 1)),
                                    'all of a rank\'s cells together' if args.cells_at_once <= 0
-                                   else '%d at a time' % args.cells_at_once),
+                                   else '%d at a time' % args.cells_at_once) + (
+                    '; %d driver handles per process grow different cells at the same time '
+                    '(--host-streams)' % len(natives) if len(natives) > 1 else ''),
+                'host_streams': max(1, len(natives)),
             },
             'roofline': {
                 'bound': 'mfma' if dom_wide else 'valu-fp64',
@@ -1221,8 +1294,8 @@ def measure_config5(args, ctx):
                                                        cell_vertices)
         else:
             out['cpu_baseline'] = None
-    if native:
-        native.close()
+    for nat in natives:
+        nat.close()
     orc.close()
     return out
 
@@ -1357,6 +1430,7 @@ SECONDARY_CONFIG_KEYS = ('workload', 'regions_per_step', 'nodes_per_step', 'lp_s
                          'open_leaves_at_max_depth_per_step', 'open_leaves_per_step',
                          'depth_limit', 'depth_limited_leaves_per_step', 'cells_grown_per_step',
                          'depth_limited_leaves_without_a_commutation_per_step', 'cells_log',
+                         'host_streams', 'parallelism',
                          'tree_depth', 'mean_ipm_iterations',
                          'midpoint_optima_taken_from_the_table_per_step',
                          'lp_solves_per_mixed_integer_oracle_call',
@@ -1383,6 +1457,7 @@ def secondary_line(args, ctx, workload, steps, warmup):
             return {'name': workload, 'skipped': '--scale-seconds 0'}
         a.workload, a.regions, a.cells = 'config5', 10 ** 6, 400
         a.seconds, a.max_depth = float(args.scale_seconds), 26
+        a.host_streams = max(2, args.host_streams)
     a.driver = 'native'
     a.order, a.max_visits, a.round_cap = 'lcss-first', None, 4096
     a.status_dir = None

@@ -277,20 +277,21 @@ class NativeFrontier:
         return out
 
 
-def graft(flat, mpc, targets):
+def graft(flat, mpc, targets, depth_limited=None):
     """Writes the flat tree of ``NativeFrontier.export`` into ``targets`` (one ``Tree`` per root,
-    grown in place).  Returns the list of (Tree node, flags) of the cells handed back open."""
+    grown in place).  Returns the list of (Tree node, flags) of the cells handed back open;
+    ``depth_limited``: a list that receives the leaves a depth limit left unbisected."""
     import gc
     was_on = gc.isenabled()
     gc.disable()            # (millions of small objects, nothing cyclic among them)
     try:
-        return _graft(flat, mpc, targets)
+        return _graft(flat, mpc, targets, depth_limited if depth_limited is not None else [])
     finally:
         if was_on:
             gc.enable()
 
 
-def _graft(flat, mpc, targets):
+def _graft(flat, mpc, targets, depth_limited):
     n = flat['n_nodes']
     nodes = [None] * n
     for r, t in enumerate(targets):
@@ -301,7 +302,6 @@ def _graft(flat, mpc, targets):
     has = (flags & FR_HAS_RECORD) != 0
     deltas = {}
     handed_back = []
-    depth_limited = _graft.depth_limited = []
     for k in range(n):
         node = nodes[k]
         if has[k]:
@@ -362,11 +362,11 @@ def grow_cells(native, branches, slow_oracle=None, round_cap=4096, launch_target
                     (max_visits and st['visits'] >= max_visits) or \
                     (min_regions and st['regions'] >= min_regions):
                 break
-    back = graft(native.export(), native.mpc, branches)
+    limited = []
+    back = graft(native.export(), native.mpc, branches, limited)
     # leaves the depth limit left open (flag FR_DEPTH): neither regions nor handed back -- reported,
     # and marked in the tree (NodeData.depth_limited); those without a commutation have no vertex
     # inputs either, so a tree that holds any must not be given to ExplicitMPC as it is
-    limited = getattr(_graft, 'depth_limited', [])
     st['depth_limited_leaves'] = len(limited)
     st['depth_limited_without_commutation'] = sum(1 for nd in limited
                                                   if not hasattr(nd.data, 'commutation'))

@@ -65,3 +65,54 @@ def test_native_driver_grows_the_tree_of_the_python_driver_on_the_device():
     assert st['seconds_solvers'] >= 0.5 * st['seconds_total']
     nat.close()
     orc.close()
+
+
+def test_two_handles_grow_different_roots_at_the_same_time():
+    """
+    bench.py --host-streams: two driver handles (own device tables, streams and host threads) grow
+    different Delaunay roots from two interpreter threads at the same time -- the native calls
+    release the GIL.  Each tree must be the one the same handle grows alone.
+    """
+    import threading
+    from explicit_hybrid_mpc_amd import examples, frontier
+    from explicit_hybrid_mpc_amd import tools as ehm_tools
+    from explicit_hybrid_mpc_amd.tree import NodeData, Tree
+    mpc = examples.pwa4_mpc(N=8, seed=0)
+    V = examples.box_vertices(examples.theta_box(mpc))
+    nats = [frontier.NativeFrontier(mpc, 1., 1., slots=4096) for _ in range(2)]
+    eps_a = max(j for _, _, j in nats[0].p_theta(0.2 * V))
+    for nat in nats:
+        nat.set_eps(eps_a, 1e-3)
+    roots, _ = ehm_tools.delaunay_roots(V)
+    cells = (2, 1)                      # 1.5 k and 22.6 k regions
+    alone = []
+    for nat, c in zip(nats, cells):
+        t = Tree(NodeData(vertices=roots[c].copy()))
+        st = frontier.grow_cells(nat, t)
+        assert st['slow_path_cells'] == 0
+        alone.append((t, st['regions']))
+    both, errs = [None, None], []
+
+    def work(k):
+        try:
+            t = Tree(NodeData(vertices=roots[cells[k]].copy()))
+            st = frontier.grow_cells(nats[k], t)
+            both[k] = (t, st['regions'])
+        except BaseException as e:
+            errs.append(e)
+    threads = [threading.Thread(target=work, args=(k,)) for k in range(2)]
+    for t in threads:
+        t.start()
+    for t in threads:
+        t.join()
+    assert not errs, errs
+    for (ta, ra), (tb, rb) in zip(alone, both):
+        a, b = _nodes(ta), _nodes(tb)
+        assert ra == rb and set(a) == set(b)
+        for loc, x in a.items():
+            y = b[loc]
+            assert np.array_equal(x.data.vertices, y.data.vertices)
+            assert x.is_leaf() == y.is_leaf()
+            assert x.data.is_epsilon_suboptimal == y.data.is_epsilon_suboptimal
+    for nat in nats:
+        nat.close()
