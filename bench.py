@@ -305,8 +305,8 @@ def parse_args(argv=None):
     ap.add_argument('--cpu-seconds', type=float, default=15.)
     ap.add_argument('--host-streams', type=int, default=1,
                     help='config5, native driver: driver handles that grow different roots at the '
-                         'same time from as many interpreter threads (the scale entry uses 2)')
-    ap.add_argument('--scale-seconds', type=float, default=480.,
+                         'same time from as many interpreter threads (the scale entry uses 6)')
+    ap.add_argument('--scale-seconds', type=float, default=600.,
                     help='soft time limit of the config5_scale entry of "secondary" (0 = skip it)')
     ap.add_argument('--queries', type=int, default=1 << 21,
                     help='explicit: states evaluated per step')
@@ -1457,7 +1457,9 @@ def secondary_line(args, ctx, workload, steps, warmup):
             return {'name': workload, 'skipped': '--scale-seconds 0'}
         a.workload, a.regions, a.cells = 'config5', 10 ** 6, 400
         a.seconds, a.max_depth = float(args.scale_seconds), 26
-        a.host_streams = max(2, args.host_streams)
+        # (measured, 480-s box: 1 / 2 / 3 / 4 / 6 handles -> 462 / 611 / 675 / 703 / 721 k LP/s,
+        # 446 / 578 / 649 / 724 / 850 k regions: profiles/r6/c5_scale_host_streams.txt)
+        a.host_streams = max(6, args.host_streams)
     a.driver = 'native'
     a.order, a.max_visits, a.round_cap = 'lcss-first', None, 4096
     a.status_dir = None
@@ -1472,7 +1474,8 @@ def secondary_line(args, ctx, workload, steps, warmup):
     line['name'] = workload
     if workload == 'config5_scale':
         line['limits'] = {'soft_seconds': a.seconds, 'regions_target': a.regions,
-                          'max_depth': a.max_depth, 'roots_offered': a.cells}
+                          'max_depth': a.max_depth, 'roots_offered': a.cells,
+                          'host_streams': a.host_streams}
     line['workload'] = full['config']['workload']
     line['config'] = {k: full['config'][k] for k in SECONDARY_CONFIG_KEYS if k in full['config']}
     line['wall_seconds'] = time.perf_counter() - t0
