@@ -963,6 +963,8 @@ def measure_config5(args, ctx):
             orc.table.forget()
         st = frontier.grow_cells(nat, part, slow_oracle=lambda: orc, round_cap=args.round_cap,
                                  max_visits=args.max_visits or 0, deadline=step_deadline[0],
+                                 # (a soft limit is honoured at the end of a slice of visits)
+                                 slice_visits=40000 if len(natives) > 1 else 100000,
                                  max_depth=args.max_depth or 0,
                                  min_regions=0 if args.regions or regions >= (1 << 30) else regions,
                                  slow_opts=dict(order=args.order, table_backoff=True,
