@@ -1020,6 +1020,10 @@ def measure_config5(args, ctx):
                 g0 = box['next']
                 box['next'] += group
                 return g0
+        # (N > 1 with --regions: the cells of a rank are the static deal k mod world; the dynamic
+        # deal over ranks -- distributed.claim_roots, a counter in the process group's store -- is
+        # what distributed.grow_roots_sharded(deal='dynamic') does and tests/test_distributed_gloo.py
+        # covers; the handles of ONE rank claim from its list here)
 
         def work(nat):
             try:

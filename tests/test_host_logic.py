@@ -289,7 +289,7 @@ def test_bench_helpers_quote_only_profiles_of_this_code(tmp_path, monkeypatch):
     assert len(sha) == 16 and sha == bench.kernel_source_hash()
     # the committed summaries of the four workloads name the kernel sources they belong to
     for summary, kernel in (('pmc_summary_bench.json', 'kp_persist'),
-                            ('pmc_summary_wide.json', 'k3_lcss_decide'),
+                            ('pmc_summary_wide.json', bench.wide_kernel('persist')),
                             ('pmc_summary_config3.json', 'k2_simplex_batch'),
                             ('pmc_summary_quad.json', 'k2_persist')):
         traffic, source = bench.pmc_traffic(kernel, summary)
