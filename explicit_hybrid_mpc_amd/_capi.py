@@ -21,6 +21,7 @@ EHM_E_HIP = -3
 EHM_E_CAPACITY = -4
 EHM_E_INFEASIBLE = -5
 EHM_E_NUMERIC = -6
+EHM_MAX_P = 8           # include/ehmpc.h
 
 # every symbol include/ehmpc.h declares
 EXPORTED = [

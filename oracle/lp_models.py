@@ -108,6 +108,26 @@ class FixedCommutationModel:
             lp['P'] = self.P
         return lp
 
+    def lp_point_lexicographic(self, theta, j, V_cap, u_caps):
+        """
+        Stage 1+j of the lexicographic tie-break of the first input (no counterpart in the
+        reference, which stores the vertex its solver stops at, lib/worker.py:356-365; the
+        device form is explicit_hybrid_mpc_amd/lexicographic.py): min u_0[j] over the rows of
+        P_theta_delta with V <= V_cap and u_0[i] <= u_caps[i] for i < j.
+        """
+        lp = self.lp_point(theta)
+        rows = [self.cost[None, :]]
+        rhs = [float(V_cap)]
+        for i in range(j):
+            r = np.zeros((1, self.nv))
+            r[0, self.ou + i] = 1.
+            rows.append(r)
+            rhs.append(float(u_caps[i]))
+        c = np.zeros(self.nv)
+        c[self.ou + j] = 1.
+        return dict(c=c, A_ub=np.vstack([lp['A_ub']] + rows),
+                    b_ub=np.concatenate([lp['b_ub'], rhs]), A_eq=lp['A_eq'], b_eq=lp['b_eq'])
+
     # -- problems over a simplex (lib/oracle.py:70-79, 89-97) -------------------------
     def _simplex_blocks(self, R, extra_cols):
         """x_0 = sum_i alpha_i R[i], sum alpha = 1, alpha >= 0 (as bounds)."""

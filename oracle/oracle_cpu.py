@@ -190,6 +190,29 @@ class OracleCPU:
         return u, J, time.time() - t0
 
     # -- lib/oracle.py:416-443 -----------------------------------------------------------
+    def lexicographic_u0(self, theta, delta, tol=1e-6):
+        """
+        The lexicographically smallest first input over the tol-optimal face of P_theta_delta
+        (oracle/lp_models.py: lp_point_lexicographic; the rule of
+        explicit_hybrid_mpc_amd/lexicographic.py restated on the uncondensed model with HiGHS).
+        """
+        d = self.delta_index(delta)
+        model = self.models[d]
+        if model.quadratic:
+            raise ValueError('quadratic cost: the optimum is a point')
+        ok, _, J = self._point(theta, d)
+        if not ok:
+            raise SolverError('P_theta_delta infeasible')
+        V_cap = J + tol * (1. + abs(J))
+        caps, u = [], []
+        for j in range(model.n_u):
+            res = self._solve(model.lp_point_lexicographic(theta, j, V_cap, caps))
+            if res.status != 0:
+                raise SolverError('lexicographic stage %d failed' % (1 + j))
+            u.append(float(res.fun))
+            caps.append(u[-1] + tol * (1. + abs(u[-1])))
+        return np.array(u)
+
     def _compute_vx_inputs_and_costs(self, R, delta):
         out = []
         if (self.fail_vertex_solves_of is not None and

@@ -19,8 +19,10 @@ def compare_trees(flat, nodes_cpu, locs, inputs_tol=None):
     (lib/mpc_library.py:786-789).  The first input of an LP optimum is a function of the
     parameter only where the optimal face is a point in u_0: so it is on the random dense
     instances ('lin': checked on the CPU over the bench instance, face width <= 1e-6 at every
-    sampled parameter, HiGHS' vertex and the interior-point limit agree to 1e-10), not on the
-    double integrator, whose infinity-norm cost leaves u_0 free on a face."""
+    sampled parameter, HiGHS' vertex and the interior-point limit agree to 1e-10).  On the
+    double integrator the infinity-norm cost leaves u_0 free on a face, so the RAW inputs of two
+    solvers differ there; its inputs are compared after the lexicographic second stage
+    (tests/test_gpu_lexicographic.py: every vertex of every node, device against oracle)."""
     loc = flat.locations(locs)
     assert len(loc) == len(nodes_cpu)
     assert set(loc) == set(nodes_cpu.keys())

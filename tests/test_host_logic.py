@@ -470,3 +470,47 @@ def test_cpu_baseline_leg_of_the_bench_runs():
     import bench
     out = bench.cpu_baseline('config2', 0, 0.0216306, 0.01, 1.0)
     assert out['value'] > 0 and out['kind'] == 'port' and out['cores'] >= 1
+
+
+def test_lexicographic_stage_problems_and_the_oracles_rule():
+    """explicit_hybrid_mpc_amd/lexicographic.py builds stage 1+j as a canonical LP with 1+j more
+    rows and parameters; the oracle's statement of the rule (HiGHS, uncondensed model) returns an
+    OPTIMAL first input that is lexicographically no larger than the solver's own vertex."""
+    from explicit_hybrid_mpc_amd import examples, lexicographic
+    from oracle.oracle_cpu import OracleCPU
+    mpc = examples.double_integrator(3)
+    can = mpc.compile()
+    for j in range(can.n_u):
+        st = lexicographic.stage_problem(can, j)
+        assert (st.m, st.p, st.n, st.n_delta) == (can.m + 1 + j, can.p + 1 + j, can.n, can.n_delta)
+        assert np.array_equal(st.G[:, :can.m], can.G) and np.array_equal(st.G[0, can.m], can.c)
+        assert st.c[j] == 1. and st.c.sum() == 1.
+        assert np.array_equal(st.S[0, can.m:, can.p:], np.eye(1 + j))
+    wide = examples.integrator_chain_mpc().compile()                # p = 6, n_u = 3
+    with pytest.raises(ValueError, match='EHM_MAX_P'):
+        lexicographic.LexicographicInputs(wide)
+    with pytest.raises(ValueError, match='strictly convex'):
+        lexicographic.LexicographicInputs(examples.double_integrator(3, cost='quadratic').compile())
+    orc = OracleCPU(mpc, 0.1, 0.1)
+    half = examples.theta_box(mpc)
+    rng = np.random.default_rng(0)
+    wider = 0
+    for _ in range(40):
+        theta = (rng.random(2) * 2 - 1) * half * 0.8
+        ok, u, J = orc._point(theta, 0)
+        if not ok:
+            continue
+        ul = orc.lexicographic_u0(theta, orc.deltas[0], tol=1e-7)
+        assert ul[0] <= u[0] + 1e-7
+        wider += ul[0] < u[0] - 1e-3
+        # still optimal: fixing u_0 at the returned input costs no more than the tolerance
+        m = orc.models[0]
+        lp = m.lp_point(theta)
+        row = np.zeros((1, m.nv))
+        row[0, m.ou] = 1.
+        from scipy.optimize import linprog
+        res = linprog(lp['c'], A_ub=lp['A_ub'], b_ub=lp['b_ub'],
+                      A_eq=np.vstack([lp['A_eq'], row]), b_eq=np.concatenate([lp['b_eq'], ul[:1]]),
+                      bounds=(None, None), method='highs')
+        assert res.status == 0 and res.fun <= J + 2e-7 * (1. + abs(J))
+    assert wider >= 2           # the optimal face of the double integrator is wide at some
