@@ -303,6 +303,17 @@ def parse_args(argv=None):
                          'progress read-back (and, N > 1, one all-gather) per round -- off by '
                          'default, the headline number is measured without it')
     ap.add_argument('--cpu-seconds', type=float, default=15.)
+    ap.add_argument('--steal-slice', type=int, default=2048,
+                    help='config5 with several --host-streams: cell visits between two looks at '
+                         'the requests of idle handles (also the largest round)')
+    ap.add_argument('--steal', action='store_true',
+                    help='config5 with several --host-streams: a handle that finds no root left '
+                         'takes pending cells from the busy ones (frontier.LocalExchange on '
+                         'ehm_frontier_take / _give).  Off by default: the handles of ONE process '
+                         'share one GPU, and a single root shared by them costs 17-35 %% more LPs '
+                         '(no shared memo) for no gain in wall time '
+                         '(profiles/r6/take_give_one_root.txt); between RANKS it is what evens out '
+                         'an expensive root (distributed.grow_roots_sharded(steal=True))')
     ap.add_argument('--host-streams', type=int, default=1,
                     help='config5, native driver: driver handles that grow different roots at the '
                          'same time from as many interpreter threads (the scale entry uses 6)')
@@ -952,7 +963,12 @@ def measure_config5(args, ctx):
     import threading
     acc_lock = threading.Lock()
 
-    def grow_group(part, nat=None):
+    # several handles: a worker that finds no root left takes pending cells from one that is in the
+    # middle of a root (frontier.LocalExchange on ehm_frontier_take / _give), so ONE expensive
+    # root is shared by all handles; the sub-trees are attached to the owner's tree after the step
+    exchange = [None]
+
+    def grow_group(part, nat=None, cells=None):
         nat = nat or native
         if native is None:
             return bnb_frontier.grow_frontier(orc, part, 'ecc', order=args.order,
@@ -963,8 +979,14 @@ def measure_config5(args, ctx):
             orc.table.forget()
         st = frontier.grow_cells(nat, part, slow_oracle=lambda: orc, round_cap=args.round_cap,
                                  max_visits=args.max_visits or 0, deadline=step_deadline[0],
-                                 # (a soft limit is honoured at the end of a slice of visits)
-                                 slice_visits=40000 if len(natives) > 1 else 100000,
+                                 # (a soft limit is honoured, and a request for cells answered,
+                                 # at the end of a slice of visits)
+                                 slice_visits=(args.steal_slice
+                                               if exchange[0] is not None else
+                                               40000 if len(natives) > 1 else 100000),
+                                 cells=cells,
+                                 between_slices=exchange[0].serve if exchange[0] is not None
+                                 else None,
                                  max_depth=args.max_depth or 0,
                                  min_regions=0 if args.regions or regions >= (1 << 30) else regions,
                                  slow_opts=dict(order=args.order, table_backoff=True,
@@ -982,6 +1004,8 @@ def measure_config5(args, ctx):
             nat_acc['launches'] += st['launches']
         return dict(host_visits=st['visits'] + st['slow_path_visits'], rounds=st['rounds'],
                     regions=st['regions'], truncated=bool(st['truncated']), handoffs=0,
+                    given=[(pc['id'], leaves) for pc, leaves in st['given_away']],
+                    cells_given_away=sum(len(pc['node']) for pc, _ in st['given_away']),
                     native_visits=st['visits'], slow_path_cells=st['slow_path_cells'],
                     depth_limited_leaves=int(st.get('depth_limited_leaves', 0)),
                     depth_limited_without_commutation=int(
@@ -1005,7 +1029,18 @@ def measure_config5(args, ctx):
         # COMPLETION (every leaf eps-suboptimal), until the target is reached
         group = args.cells_at_once if args.cells_at_once > 0 else (
             1 if args.regions else max(len(my_cells), 1))
-        box = dict(stats=None, trees=[], next=0, error=None)
+        box = dict(stats=None, trees=[], next=0, error=None, given=[], adopted={})
+        exchange[0] = frontier.LocalExchange(len(natives)) \
+            if len(natives) > 1 and args.steal else None
+
+        def over():
+            """No more work is started: a limit of the step is reached (under no lock)."""
+            if box['error'] is not None:
+                return True
+            if args.regions and box['stats'] is not None and \
+                    box['stats'].get('regions', 0) >= regions:
+                return True
+            return step_deadline[0] is not None and time.perf_counter() >= step_deadline[0]
 
         def claim():
             """Next group of this rank's cells, or None when a limit is reached (under the lock)."""
@@ -1030,12 +1065,13 @@ def measure_config5(args, ctx):
                 while True:
                     g0 = claim()
                     if g0 is None:
-                        return
+                        break
                     part = [Tree(NodeData(vertices=cell_vertices(c)))
                             for c in my_cells[g0:g0 + group]]
                     t_g = time.perf_counter()
                     st = grow_group(part, nat)
                     with acc_lock:
+                        box['given'] += st['given']
                         box['trees'] += part
                         cells_log.append(dict(cells=my_cells[g0:g0 + group],
                                               seconds=time.perf_counter() - t_g,
@@ -1046,6 +1082,17 @@ def measure_config5(args, ctx):
                         if args.progress_file and rank == 0:
                             with open(args.progress_file, 'a') as f:
                                 f.write(json.dumps(cells_log[-1]) + '\n')
+                        box['stats'] = merge(box['stats'], st)
+                # no root left: cells of the roots the other handles are still growing
+                while exchange[0] is not None:
+                    parcel = exchange[0].wait_for_work(stop=over)
+                    if parcel is None:
+                        break
+                    sub = [Tree(NodeData(vertices=R.copy())) for R in parcel['vertices']]
+                    st = grow_group(sub, nat, cells=parcel)
+                    with acc_lock:
+                        box['adopted'][parcel['id']] = dict(trees=sub, given=st['given'])
+                        st['cells_adopted'] = len(sub)
                         box['stats'] = merge(box['stats'], st)
             except BaseException as e:      # a worker's failure ends the step
                 with acc_lock:
@@ -1059,6 +1106,11 @@ def measure_config5(args, ctx):
                 t.join()
             if box['error'] is not None:
                 raise box['error']
+            if box['stats'] is not None:
+                waiting = []
+                box['stats']['subtrees_attached'] = frontier.attach_adopted(
+                    box['given'], box['adopted'], waiting)
+                box['stats']['cells_taken_and_never_grown'] = len(waiting)
             return box['stats'] or dict(host_visits=0, handoffs=0, truncated=False), box['trees']
         stats, trees = None, []
         for g0 in range(0, len(my_cells), group):
@@ -1259,6 +1311,12 @@ def measure_config5(args, ctx):
                     '; %d driver handles per process grow different cells at the same time '
                     '(--host-streams)' % len(natives) if len(natives) > 1 else ''),
                 'host_streams': max(1, len(natives)),
+                'cells_moved_between_handles_per_step': sum(
+                    st.get('cells_given_away', 0) for st, _ in runs) / K,
+                'subtrees_attached_per_step': sum(
+                    st.get('subtrees_attached', 0) for st, _ in runs) / K,
+                'cells_taken_and_never_grown_per_step': sum(
+                    st.get('cells_taken_and_never_grown', 0) for st, _ in runs) / K,
             },
             'roofline': {
                 'bound': 'mfma' if dom_wide else 'valu-fp64',
@@ -1436,7 +1494,8 @@ SECONDARY_CONFIG_KEYS = ('workload', 'regions_per_step', 'nodes_per_step', 'lp_s
                          'open_leaves_at_max_depth_per_step', 'open_leaves_per_step',
                          'depth_limit', 'depth_limited_leaves_per_step', 'cells_grown_per_step',
                          'depth_limited_leaves_without_a_commutation_per_step', 'cells_log',
-                         'host_streams', 'parallelism',
+                         'host_streams', 'parallelism', 'cells_moved_between_handles_per_step',
+                         'subtrees_attached_per_step', 'cells_taken_and_never_grown_per_step',
                          'tree_depth', 'mean_ipm_iterations',
                          'midpoint_optima_taken_from_the_table_per_step',
                          'lp_solves_per_mixed_integer_oracle_call',

@@ -61,7 +61,7 @@ EXPORTED_FRONTIER = [
     'ehm_frontier_last_error', 'ehm_frontier_set_eps', 'ehm_frontier_table',
     'ehm_frontier_reset', 'ehm_frontier_add_root', 'ehm_frontier_run', 'ehm_frontier_sizes',
     'ehm_frontier_export', 'ehm_frontier_lp_counts', 'ehm_frontier_condense',
-    'ehm_frontier_p_theta',
+    'ehm_frontier_p_theta', 'ehm_frontier_pending', 'ehm_frontier_take', 'ehm_frontier_give',
 ]
 
 
@@ -308,6 +308,9 @@ def load(build_if_missing=True):
     lib.ehm_frontier_export.argtypes = [vp, vp, vp, vp, vp, vp, vp, vp]
     lib.ehm_frontier_lp_counts.argtypes = [vp, vp]
     lib.ehm_frontier_p_theta.argtypes = [vp, i64, vp, vp, vp, vp]
+    lib.ehm_frontier_pending.argtypes = [vp, ctypes.POINTER(i64)]
+    lib.ehm_frontier_take.argtypes = [vp, i64, ctypes.POINTER(i64), vp, vp, vp, vp, vp, vp]
+    lib.ehm_frontier_give.argtypes = [vp, i64, vp, vp, vp, vp, vp]
     lib.ehm_frontier_condense.argtypes = [ctypes.POINTER(PwaLaw), i32, i32, vp, vp, vp, vp, vp]
     for name in EXPORTED_FRONTIER:
         if name != 'ehm_frontier_last_error':

@@ -2024,6 +2024,120 @@ int ehm_frontier_add_root(ehm_frontier* f, const double* vertices) {
     return EHM_OK;
 }
 
+int ehm_frontier_pending(const ehm_frontier* f, int64_t* n_pending) {
+    if (!f || !n_pending) return fail(EHM_E_INVALID, "ehm_frontier_pending: bad argument");
+    *n_pending = (int64_t)(f->ecc_work.size() + f->lcss_work.size());
+    return EHM_OK;
+}
+
+// Work leaves this handle: the shallowest pending cells (the largest sub-trees still to grow) come
+// out with their records; here they stay leaves flagged EHM_FR_REMOTE.
+int ehm_frontier_take(ehm_frontier* f, int64_t max_cells, int64_t* n_taken, int32_t* node,
+                      double* vertices, int32_t* sequence, double* vertex_costs,
+                      double* vertex_inputs, int32_t* depth) {
+    if (!f || !n_taken || max_cells < 0 || (max_cells && (!node || !vertices || !sequence ||
+                                                          !vertex_costs || !vertex_inputs || !depth)))
+        return fail(EHM_E_INVALID, "ehm_frontier_take: bad argument");
+    if (f->poisoned)
+        return fail(EHM_E_INVALID, "ehm_frontier_take: an earlier call failed inside a round; "
+                                   "ehm_frontier_reset first");
+    *n_taken = 0;
+    try {
+        // (work list, position) of every pending cell, shallowest first; ties: cells that hold a
+        // commutation first, then the order of the lists -- a fixed rule, so a run that is repeated
+        // hands over the same cells
+        struct Pick { int32_t depth; int list; size_t at; };
+        std::vector<Pick> all;
+        for (size_t a = 0; a < f->lcss_work.size(); ++a) all.push_back({f->depth[f->lcss_work[a]], 0, a});
+        for (size_t a = 0; a < f->ecc_work.size(); ++a) all.push_back({f->depth[f->ecc_work[a]], 1, a});
+        std::stable_sort(all.begin(), all.end(), [](const Pick& x, const Pick& y) { return x.depth < y.depth; });
+        const size_t n = (size_t)std::min<int64_t>(max_cells, (int64_t)all.size());
+        const size_t sx = (size_t)f->nv * f->p;
+        std::vector<uint8_t> gone_l(f->lcss_work.size(), 0), gone_e(f->ecc_work.size(), 0);
+        for (size_t i = 0; i < n; ++i) {
+            const int32_t k = all[i].list ? f->ecc_work[all[i].at] : f->lcss_work[all[i].at];
+            (all[i].list ? gone_e : gone_l)[all[i].at] = 1;
+            node[i] = k;
+            depth[i] = f->depth[k];
+            std::memcpy(vertices + i * sx, &f->verts[(size_t)k * sx], 8 * sx);
+            std::memcpy(vertex_costs + i * f->nv, &f->costs[(size_t)k * f->nv], 8 * (size_t)f->nv);
+            std::memcpy(vertex_inputs + i * f->nv * f->n_u, &f->inputs[(size_t)k * f->nv * f->n_u],
+                        8 * (size_t)f->nv * f->n_u);
+            int32_t* sq = sequence + i * f->N;
+            if (f->seq[k] < 0) {
+                for (int j = 0; j < f->N; ++j) sq[j] = -1;
+            } else {
+                uint64_t c = (uint64_t)f->seq[k];
+                for (int j = 0; j < f->N; ++j) { sq[j] = (int32_t)(c % f->base) - 1; c /= f->base; }
+            }
+            f->flags[k] = (uint8_t)((f->flags[k] & EHM_FR_HAS_RECORD) | EHM_FR_REMOTE);
+            f->node_bounds[(size_t)k].reset();
+        }
+        auto compact = [](std::vector<int32_t>& w, const std::vector<uint8_t>& gone) {
+            size_t o = 0;
+            for (size_t a = 0; a < w.size(); ++a)
+                if (!gone[a]) w[o++] = w[a];
+            w.resize(o);
+        };
+        compact(f->lcss_work, gone_l);
+        compact(f->ecc_work, gone_e);
+        *n_taken = (int64_t)n;
+    } catch (const std::bad_alloc&) {
+        return fail(EHM_E_CAPACITY, "ehm_frontier_take: out of memory");
+    }
+    return EHM_OK;
+}
+
+// Work arrives: cells another handle gave up become roots of this handle's forest (a cell that
+// holds a commutation goes on with lcss from its record, lib/scheduler.py:633-639; one without
+// looks for one with ecc).  Depths are kept, so a depth limit means the same in both handles.
+int ehm_frontier_give(ehm_frontier* f, int64_t n, const double* vertices, const int32_t* sequence,
+                      const double* vertex_costs, const double* vertex_inputs, const int32_t* depth) {
+    if (!f || n < 0 || (n && (!vertices || !sequence || !vertex_costs || !vertex_inputs)))
+        return fail(EHM_E_INVALID, "ehm_frontier_give: bad argument");
+    if (f->poisoned)
+        return fail(EHM_E_INVALID, "ehm_frontier_give: an earlier call failed inside a round; "
+                                   "ehm_frontier_reset first");
+    if (f->n_roots != f->n_nodes())
+        return fail(EHM_E_INVALID, "ehm_frontier_give: the tree has been grown already (reset first)");
+    const size_t sx = (size_t)f->nv * f->p;
+    for (int64_t i = 0; i < n; ++i) {
+        const int32_t* sq = sequence + (size_t)i * f->N;
+        const bool has = sq[0] >= 0;
+        for (int j = 0; j < f->N; ++j)
+            if ((sq[j] >= 0) != has || sq[j] >= f->n_modes)
+                return fail(EHM_E_INVALID, "ehm_frontier_give: cell %lld: bad mode sequence", (long long)i);
+        if (has)
+            for (int v = 0; v < f->nv; ++v)
+                if (!std::isfinite(vertex_costs[(size_t)i * f->nv + v]))
+                    return fail(EHM_E_INVALID, "ehm_frontier_give: cell %lld holds a commutation but no "
+                                               "vertex costs", (long long)i);
+    }
+    try {
+        for (int64_t i = 0; i < n; ++i) {
+            const int32_t k = f->new_node(vertices + (size_t)i * sx, depth ? depth[i] : 0);
+            int rc = ehm_search_point_ids(f->S, f->nv, vertices + (size_t)i * sx, &f->pids[(size_t)k * f->nv]);
+            if (rc) return fail(rc, "ehm_search_point_ids: %s", ehm_search_last_error());
+            ++f->n_roots;
+            const int32_t* sq = sequence + (size_t)i * f->N;
+            if (sq[0] < 0) {
+                f->ecc_work.push_back(k);
+                continue;
+            }
+            f->seq[k] = (int64_t)f->seq_code(sq);
+            std::memcpy(&f->costs[(size_t)k * f->nv], vertex_costs + (size_t)i * f->nv, 8 * (size_t)f->nv);
+            std::memcpy(&f->inputs[(size_t)k * f->nv * f->n_u], vertex_inputs + (size_t)i * f->nv * f->n_u,
+                        8 * (size_t)f->nv * f->n_u);
+            f->flags[k] = EHM_FR_HAS_RECORD | EHM_FR_PENDING;
+            f->lcss_work.push_back(k);
+            f->st.depth = std::max(f->st.depth, f->depth[k]);
+        }
+    } catch (const std::bad_alloc&) {
+        return fail(EHM_E_CAPACITY, "ehm_frontier_give: out of memory");
+    }
+    return EHM_OK;
+}
+
 int ehm_frontier_run(ehm_frontier* f, const ehm_frontier_opts* opts, ehm_frontier_stats* stats) {
     if (!f) return fail(EHM_E_INVALID, "ehm_frontier_run: NULL handle");
     if (f->poisoned)

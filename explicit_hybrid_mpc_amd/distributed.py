@@ -504,8 +504,91 @@ def emulate_claims(seconds, world):
     return busy, (max(busy) / mean if mean > 0 else 1.0)
 
 
+class CellExchange:
+    """
+    Take / give of pending cells between the ranks, through the process group's store (the
+    reference's scheduler hands any leaf to any idle worker, lib/scheduler.py:498-599, 633-639;
+    here there is no scheduler process: a rank that ran out of roots ASKS the others in turn, a
+    rank that still holds work answers between two slices of its run with the shallowest half of
+    its pending cells -- ``NativeFrontier.take`` -- and everybody stops once all ranks are idle
+    with nothing on its way).
+
+    Keys under ``key`` (fresh per deal -- counters are never reset):
+      idle             counter: ranks that are idle AND have no parcel on its way to them
+      req/<v>          counter: requests addressed to rank v;  req/<v>/<t> = b"<requester>:<n>"
+      box/<r>/<n>      the answer to rank r's n-th request: a pickled parcel, or None
+    A giver lowers ``idle`` on the taker's behalf BEFORE it posts a non-empty parcel, so
+    ``idle == world`` can only be seen when no work exists anywhere.
+    """
+
+    def __init__(self, store, rank, world, key='ehm_cells', poll=0.002):
+        self.store, self.rank, self.world = store, int(rank), int(world)
+        self.key, self.poll = key, float(poll)
+        self.answered = 0           # requests addressed to this rank that it has answered
+        self.asked = 0              # requests this rank has made
+        self.given = 0              # parcels this rank gave away
+        self._victim = self.rank
+
+    def _k(self, *parts):
+        return '/'.join([self.key] + [str(x) for x in parts])
+
+    def serve(self, take):
+        """Answers every request addressed to this rank: ``take()`` -> a parcel (dict of arrays,
+        ``NativeFrontier.take``) or None.  Returns the parcels given away, each stamped with
+        ``parcel['id']`` = (this rank, running number)."""
+        import pickle
+        out = []
+        pending = int(self.store.add(self._k('req', self.rank), 0))
+        while self.answered < pending:
+            self.answered += 1
+            who, n = self.store.get(self._k('req', self.rank, self.answered)).decode().split(':')
+            parcel = take()
+            if parcel is not None and len(parcel['node']):
+                self.given += 1
+                parcel['id'] = (self.rank, self.given)
+                self.store.add(self._k('idle'), -1)         # it is on its way: `who` is busy again
+                out.append(parcel)
+            else:
+                parcel = None
+            self.store.set(self._k('box', who, n), pickle.dumps(parcel))
+        return out
+
+    def _ask(self):
+        self._victim = (self._victim + 1) % self.world
+        if self._victim == self.rank:
+            self._victim = (self._victim + 1) % self.world
+        self.asked += 1
+        t = int(self.store.add(self._k('req', self._victim), 1))
+        self.store.set(self._k('req', self._victim, t), '%d:%d' % (self.rank, self.asked))
+        return self._k('box', self.rank, self.asked)
+
+    def wait_for_work(self):
+        """This rank is idle: asks the others in turn (answering their requests with None
+        meanwhile) until one gives it a parcel -- returned -- or every rank is idle: None."""
+        import pickle
+        import time
+        self.store.add(self._k('idle'), 1)
+        box, empty = None, 0
+        while True:
+            self.serve(lambda: None)
+            if box is None:
+                box = self._ask()
+            if self.store.check([box]):
+                parcel = pickle.loads(self.store.get(box))
+                box = None
+                if parcel is not None:
+                    return parcel
+                empty += 1
+                if empty % (self.world - 1):
+                    continue            # the next rank may still hold work: ask at once
+            if int(self.store.add(self._k('idle'), 0)) >= self.world:
+                return None
+            time.sleep(self.poll)
+
+
 def grow_roots_sharded(oracle, roots, action='ecc', device=None, deal='static', native=None,
-                       claim_key='ehm_root_ticket', batch=1, native_opts=None, **kw):
+                       claim_key='ehm_root_ticket', batch=1, native_opts=None, steal=False,
+                       steal_slice=2000, **kw):
     """
     The search-oracle driver (problems whose mode sequences cannot be enumerated) over the ranks;
     the subtrees of the roots -- the Delaunay roots of the set -- are independent, so the data path
@@ -516,6 +599,11 @@ def grow_roots_sharded(oracle, roots, action='ecc', device=None, deal='static', 
                     time, each group grown to completion before the next claim -- the roots of
                     configs[4] cost anything between 2 s and 8 min each, and a static deal leaves
                     most ranks idle behind the slow ones.
+    ``steal`` (with deal='dynamic' and ``native``): a rank that finds no root left asks the others
+                    for pending CELLS (``CellExchange``: take / give between driver handles), so one
+                    expensive root is shared; the sub-trees return to the rank that owns the root
+                    (all-gather of the adopted trees at the end) and are attached there.  A busy
+                    rank looks for requests every ``steal_slice`` cell visits.
     ``native``: a ``frontier.NativeFrontier`` -- the roots are then grown by the native driver
     (``frontier.grow_cells``, ``oracle`` only finishes cells it hands back open; ``native_opts``:
     its keyword arguments), otherwise by ``bnb_frontier.grow_frontier(oracle, ...)``.
@@ -531,14 +619,34 @@ def grow_roots_sharded(oracle, roots, action='ecc', device=None, deal='static', 
     if not (dist.is_available() and dist.is_initialized()):
         world, rank = 1, 0
 
-    def grow(part):
+    exchange = None
+    if steal and deal == 'dynamic' and native is not None and world > 1:
+        exchange = CellExchange(dist.distributed_c10d._get_default_store(), rank, world,
+                                key=claim_key + '/cells')
+    given = []              # [(parcel id, [leaf per cell])]: cells of this rank's runs grown elsewhere
+
+    def serve(nat, st):     # between two slices of a run: requests of idle ranks
+        return exchange.serve(lambda: nat.take(nat.pending() // 2) if nat.pending() >= 2 else None)
+
+    def grow(part, cells=None):
         if native is not None:
             from . import frontier
+            opts = dict(native_opts or {})
+            if exchange is not None:
+                opts.update(between_slices=serve, slice_visits=int(steal_slice))
             st = frontier.grow_cells(native, part, slow_oracle=lambda: oracle,
-                                     slow_opts=kw or None, **(native_opts or {}))
-            return dict(host_visits=st['visits'] + st['slow_path_visits'], rounds=st['rounds'],
-                        truncated=bool(st['truncated']), regions=st['regions'])
+                                     slow_opts=kw or None, cells=cells, **opts)
+            out = dict(host_visits=st['visits'] + st['slow_path_visits'], rounds=st['rounds'],
+                       truncated=bool(st['truncated']), regions=st['regions'])
+            out['given'] = [(pc['id'], leaves) for pc, leaves in st['given_away']]
+            return out
         return bnb_frontier.grow_frontier(oracle, part, action, **kw)
+
+    def tally(st):
+        stats['host_visits'] += st['host_visits']
+        stats['rounds'] += st['rounds']
+        stats['truncated'] = stats['truncated'] or bool(st['truncated'])
+        stats['regions'] += int(st.get('regions', 0))
 
     stats = dict(host_visits=0, rounds=0, truncated=False, regions=0)
     if deal == 'dynamic':
@@ -546,10 +654,26 @@ def grow_roots_sharded(oracle, roots, action='ecc', device=None, deal='static', 
         for ks in claim_roots(len(roots), batch=batch, key=claim_key):
             st = grow([roots[k] for k in ks])
             mine += ks
-            stats['host_visits'] += st['host_visits']
-            stats['rounds'] += st['rounds']
-            stats['truncated'] = stats['truncated'] or bool(st['truncated'])
-            stats['regions'] += int(st.get('regions', 0))
+            tally(st)
+            given += st.get('given', [])
+        if exchange is not None:
+            from .tree import NodeData, Tree
+            adopted = []
+            while True:
+                parcel = exchange.wait_for_work()
+                if parcel is None:
+                    break
+                trees = [Tree(NodeData(vertices=V.copy())) for V in parcel['vertices']]
+                st = grow(trees, cells=parcel)
+                tally(st)
+                adopted.append(dict(id=parcel['id'], trees=trees, given=st['given']))
+            stats['cells_adopted'] = sum(len(a['trees']) for a in adopted)
+            stats['parcels_given'] = exchange.given
+            everybody = [None] * world
+            dist.all_gather_object(everybody, adopted)
+            by_id = {a['id']: a for part in everybody for a in part}
+            from . import frontier
+            stats['subtrees_attached'] = frontier.attach_adopted(given, by_id)
     else:
         mine = [k for k in range(len(roots)) if k % world == rank]
         if mine:

@@ -24,7 +24,7 @@ from . import _capi
 from ._capi import ptr
 from .tree import NodeData, Tree
 
-FR_CLOSED, FR_HAS_RECORD, FR_OPEN, FR_PENDING, FR_NEEDS_ECC, FR_DEPTH = 1, 2, 4, 8, 16, 32
+FR_CLOSED, FR_HAS_RECORD, FR_OPEN, FR_PENDING, FR_NEEDS_ECC, FR_DEPTH, FR_REMOTE = 1, 2, 4, 8, 16, 32, 64
 
 
 def _law_struct(mpc):
@@ -224,6 +224,43 @@ class NativeFrontier:
         self.last_stats = {k: getattr(st, k) for k, _ in st._fields_}
         return self.last_stats
 
+    def pending(self):
+        """Cells in the handle's work lists (a truncated run's, or the roots before the first)."""
+        n = ctypes.c_int64()
+        self._check(self._lib.ehm_frontier_pending(self._h, ctypes.byref(n)))
+        return n.value
+
+    def take(self, max_cells):
+        """
+        ``ehm_frontier_take``: up to ``max_cells`` pending cells leave this handle, shallowest
+        first; here they stay leaves flagged ``FR_REMOTE``.  Returns their records as a dict of
+        arrays (``node`` = index in this handle's tree) -- what ``give`` of another handle takes,
+        picklable, so it can travel between ranks (distributed.CellExchange).
+        """
+        m = int(min(max_cells, self.pending()))
+        p, nv, nu, N = self.mpc.n_x, self.mpc.n_x + 1, self.mpc.n_u, self.mpc.N
+        out = dict(node=np.empty(m, dtype=np.int32), vertices=np.empty((m, nv, p)),
+                   sequence=np.empty((m, N), dtype=np.int32), vertex_costs=np.empty((m, nv)),
+                   vertex_inputs=np.empty((m, nv, nu)), depth=np.empty(m, dtype=np.int32))
+        n = ctypes.c_int64()
+        self._check(self._lib.ehm_frontier_take(
+            self._h, m, ctypes.byref(n), ptr(out['node']), ptr(out['vertices']),
+            ptr(out['sequence']), ptr(out['vertex_costs']), ptr(out['vertex_inputs']),
+            ptr(out['depth'])))
+        assert n.value == m
+        return out
+
+    def give(self, cells):
+        """``ehm_frontier_give``: the cells of another handle's ``take`` become roots of this
+        handle's forest (only before it has grown: after ``reset``)."""
+        m = int(len(cells['node']))
+        V = np.ascontiguousarray(cells['vertices'], dtype=np.float64)
+        S = np.ascontiguousarray(cells['sequence'], dtype=np.int32)
+        C = np.ascontiguousarray(cells['vertex_costs'], dtype=np.float64)
+        U = np.ascontiguousarray(cells['vertex_inputs'], dtype=np.float64)
+        D = np.ascontiguousarray(cells['depth'], dtype=np.int32)
+        self._check(self._lib.ehm_frontier_give(self._h, m, ptr(V), ptr(S), ptr(C), ptr(U), ptr(D)))
+
     def p_theta(self, thetas):
         """``Oracle.P_theta`` for many parameters (``bnb_frontier.p_theta_many``): list of
         (u0, delta, J), (None, None, None) where no mode sequence is feasible."""
@@ -277,21 +314,150 @@ class NativeFrontier:
         return out
 
 
-def graft(flat, mpc, targets, depth_limited=None):
+def merge_taken(giver, cells, taker):
+    """
+    One flat tree out of two: ``giver`` = export of the handle that gave ``cells`` away (they are
+    its ``FR_REMOTE`` leaves ``cells['node']``), ``taker`` = export of the handle that grew them
+    (its roots, in the same order).  The taker's sub-trees are appended behind the giver's nodes
+    (children still follow their parents) and each taken leaf gets its root's final record and
+    children.  The result is what ``graft`` and ``NativeFrontier.export`` consumers expect.
+    """
+    m = len(cells['node'])
+    if taker['n_roots'] != m:
+        raise ValueError('the taker holds %d roots for %d taken cells' % (taker['n_roots'], m))
+    ng, nt = giver['n_nodes'], taker['n_nodes']
+    where = np.empty(nt, dtype=np.int64)
+    where[:m] = cells['node']
+    where[m:] = ng + np.arange(nt - m)
+    out = dict(n_nodes=ng + nt - m, n_roots=giver['n_roots'])
+    for key in ('vertices', 'sequence', 'vertex_costs', 'vertex_inputs', 'flags', 'left', 'right'):
+        out[key] = np.concatenate([giver[key], taker[key][m:]])
+    for side in ('left', 'right'):
+        kids = taker[side].astype(np.int64)
+        mapped = np.where(kids >= 0, where[np.maximum(kids, 0)], -1).astype(np.int32)
+        out[side][ng:] = mapped[m:]
+        out[side][cells['node']] = mapped[:m]
+    for k, g in enumerate(cells['node']):
+        if not giver['flags'][g] & FR_REMOTE:
+            raise ValueError('node %d of the giver is not a taken leaf' % g)
+        if not np.array_equal(giver['vertices'][g], taker['vertices'][k]):
+            raise ValueError('taken cell %d: the two handles disagree on its vertices' % k)
+    for key in ('sequence', 'vertex_costs', 'vertex_inputs', 'flags'):
+        out[key][cells['node']] = taker[key][:m]
+    return out
+
+
+def graft(flat, mpc, targets, depth_limited=None, remote=None):
     """Writes the flat tree of ``NativeFrontier.export`` into ``targets`` (one ``Tree`` per root,
     grown in place).  Returns the list of (Tree node, flags) of the cells handed back open;
-    ``depth_limited``: a list that receives the leaves a depth limit left unbisected."""
+    ``depth_limited``: a list that receives the leaves a depth limit left unbisected;
+    ``remote``: a dict that receives {node index: Tree node} of the leaves ``take`` gave away
+    (another handle grows them; ``NodeData.remote`` marks them until their sub-tree is attached)."""
     import gc
     was_on = gc.isenabled()
     gc.disable()            # (millions of small objects, nothing cyclic among them)
     try:
-        return _graft(flat, mpc, targets, depth_limited if depth_limited is not None else [])
+        return _graft(flat, mpc, targets, depth_limited if depth_limited is not None else [],
+                      remote if remote is not None else {})
     finally:
         if was_on:
             gc.enable()
 
 
-def _graft(flat, mpc, targets, depth_limited):
+def attach(leaf, grown):
+    """The sub-tree another handle grew from a cell ``take`` gave away (``grown``: its root) takes
+    the place of the ``remote`` leaf it was taken as."""
+    if not np.array_equal(leaf.data.vertices, grown.data.vertices):
+        raise ValueError('the sub-tree does not belong to this leaf')
+    leaf.data = grown.data              # (the taker's final record: it may have swapped in place)
+    if not grown.is_leaf():
+        leaf.left, leaf.right = grown.left, grown.right
+    return leaf
+
+
+def attach_adopted(given, adopted_by_id, never_grown=None):
+    """Attaches the sub-trees other handles grew to the leaves they were taken as: ``given`` =
+    [(parcel id, [leaf per cell])] of the runs that gave cells away, ``adopted_by_id`` = {parcel
+    id: dict(trees, given)} of everybody who took some (a taker may have given cells of its
+    parcel away in turn: those are attached first).  Returns the number of sub-trees attached.
+    ``never_grown``: a list that receives the leaves of parcels nobody adopted (a run that a time
+    limit ended while a parcel was waiting; they stay open leaves marked ``remote``) -- without
+    it such a parcel is an error."""
+    n = 0
+    for pid, leaves in given:
+        entry = adopted_by_id.get(pid)
+        if entry is None:
+            if never_grown is None:
+                raise KeyError('parcel %r was given away and never grown' % (pid,))
+            never_grown += leaves
+            continue
+        n += attach_adopted(entry['given'], adopted_by_id, never_grown)
+        for leaf, grown in zip(leaves, entry['trees']):
+            attach(leaf, grown)
+            n += 1
+    return n
+
+
+class LocalExchange:
+    """
+    Take / give between the driver handles of ONE process (one interpreter thread each; the native
+    calls release the GIL): a worker that finds no root left waits here, a worker in the middle
+    of a run answers between two slices (``grow_cells(between_slices=exchange.serve)``) with the
+    shallowest half of its pending cells.  The rank-to-rank form of the same protocol is
+    ``distributed.CellExchange``.
+    """
+
+    def __init__(self, n_workers, poll=0.001):
+        import collections
+        import threading
+        self.n = int(n_workers)
+        self.poll = float(poll)
+        self.lock = threading.Lock()
+        self.hungry = 0         # waiting workers nobody has taken cells for yet
+        self.idle = 0           # workers inside wait_for_work
+        self.parcels = collections.deque()
+        self.given = 0
+
+    def serve(self, native, stats=None):
+        """Every waiting worker gets an equal share: with k of them, k / (k + 1) of the pending
+        cells leave, dealt in stripes of the shallowest-first order (a stripe each)."""
+        pending = native.pending()
+        with self.lock:
+            k = min(self.hungry, pending - 1)
+            if k <= 0:
+                return None
+            self.hungry -= k
+            first = self.given
+            self.given += k
+        taken = native.take(max(k, pending * k // (k + 1)))
+        parcels = []
+        for i in range(k):
+            part = {key: np.ascontiguousarray(v[i::k]) for key, v in taken.items()}
+            part['id'] = first + 1 + i
+            parcels.append(part)
+        with self.lock:
+            self.parcels.extend(parcels)
+        return parcels
+
+    def wait_for_work(self, stop=None):
+        """A parcel, or None once every worker is idle (or ``stop()`` says the run is over)."""
+        import time
+        with self.lock:
+            self.hungry += 1
+            self.idle += 1
+        while True:
+            with self.lock:
+                if self.parcels:
+                    self.idle -= 1
+                    return self.parcels.popleft()
+                # (a parcel being taken for somebody keeps its giver out of `idle`)
+                if self.idle >= self.n or (stop is not None and stop()):
+                    self.hungry = max(0, self.hungry - 1)
+                    return None
+            time.sleep(self.poll)
+
+
+def _graft(flat, mpc, targets, depth_limited, remote):
     n = flat['n_nodes']
     nodes = [None] * n
     for r, t in enumerate(targets):
@@ -326,12 +492,15 @@ def _graft(flat, mpc, targets, depth_limited):
             # so that consumers written against lib/tree.py can tell it from a closed region.
             node.data.depth_limited = True
             depth_limited.append(node)
+        elif flags[k] & FR_REMOTE:
+            node.data.remote = True
+            remote[k] = node
     return handed_back
 
 
 def grow_cells(native, branches, slow_oracle=None, round_cap=4096, launch_target=65536,
                max_visits=0, min_regions=0, speculate=0, slow_opts=None, deadline=None,
-               slice_visits=100000, max_depth=0):
+               slice_visits=100000, max_depth=0, cells=None, between_slices=None):
     """
     ``bnb_frontier.grow_frontier(oracle, branches, 'ecc')`` on the native driver: ``branches`` (a
     ``Tree`` or a list of them, data = the root simplices) are grown in place.  ``slow_oracle``: a
@@ -339,14 +508,27 @@ def grow_cells(native, branches, slow_oracle=None, round_cap=4096, launch_target
     on first need -- most cells of configs[4] never need it).  ``deadline``: a
     ``time.perf_counter()`` value; the run is then made in slices of ``slice_visits`` cell visits
     and stops (truncated: pending cells stay open leaves) at the first slice that ends after it.
+
+    Take / give (include/ehm_frontier.h): ``cells`` = a parcel another handle's ``take`` produced
+    -- the handle is given those instead of bare roots and ``branches`` are the trees they grow
+    into (one per cell).  ``between_slices(native, stats)``: called after every slice that left
+    work pending (the run is sliced by ``slice_visits`` then, deadline or not); it may ``take``
+    cells away and returns the parcels it took (or None).  The leaves given away are reported as
+    ``given_away`` = [(parcel, [Tree leaf per cell])], for ``attach`` when their sub-trees return.
     Returns a dict of counts.
     """
     import time
     from . import bnb_frontier
     branches = list(branches) if isinstance(branches, (list, tuple)) else [branches]
     native.reset()
-    native.add_roots([np.asarray(b.data.vertices, dtype=np.float64) for b in branches])
-    if deadline is None:
+    if cells is not None:
+        if len(cells['node']) != len(branches):
+            raise ValueError('one tree per given cell')
+        native.give(cells)
+    else:
+        native.add_roots([np.asarray(b.data.vertices, dtype=np.float64) for b in branches])
+    parcels = []
+    if deadline is None and between_slices is None:
         st = dict(native.run(round_cap=round_cap, launch_target=launch_target,
                              max_visits=max_visits, min_regions=min_regions, speculate=speculate,
                              max_depth=max_depth))
@@ -358,12 +540,15 @@ def grow_cells(native, branches, slow_oracle=None, round_cap=4096, launch_target
             st = dict(native.run(round_cap=round_cap, launch_target=launch_target, max_visits=cap,
                                  min_regions=min_regions, speculate=speculate,
                                  max_depth=max_depth))
-            if not st['truncated'] or time.perf_counter() >= deadline or \
-                    (max_visits and st['visits'] >= max_visits) or \
+            if not st['truncated'] or (deadline is not None and time.perf_counter() >= deadline) \
+                    or (max_visits and st['visits'] >= max_visits) or \
                     (min_regions and st['regions'] >= min_regions):
                 break
-    limited = []
-    back = graft(native.export(), native.mpc, branches, limited)
+            if between_slices is not None:
+                parcels += [pc for pc in (between_slices(native, st) or []) if len(pc['node'])]
+    limited, remote = [], {}
+    back = graft(native.export(), native.mpc, branches, limited, remote)
+    st['given_away'] = [(pc, [remote[int(k)] for k in pc['node']]) for pc in parcels]
     # leaves the depth limit left open (flag FR_DEPTH): neither regions nor handed back -- reported,
     # and marked in the tree (NodeData.depth_limited); those without a commutation have no vertex
     # inputs either, so a tree that holds any must not be given to ExplicitMPC as it is

@@ -167,6 +167,29 @@ int ehm_frontier_run(ehm_frontier* f, const ehm_frontier_opts* opts, ehm_frontie
 int ehm_frontier_p_theta(ehm_frontier* f, int64_t n, const double* theta, double* J, double* u0,
                          int32_t* sequence);
 
+/* Take / give of pending cells between handles (the reference's task queue hands any leaf to any
+ * worker, lib/scheduler.py:498-599, 633-639; here a handle that runs dry -- its rank's roots are
+ * finished -- is fed from one that still holds work, e.g. one configs[4] root that costs minutes).
+ *
+ * ehm_frontier_pending: cells in this handle's work lists (after a run that max_visits /
+ * min_regions truncated, or before the first run).
+ * ehm_frontier_take: removes up to max_cells of them, the SHALLOWEST first (the largest sub-trees
+ * still to grow; a fixed order, so a repeated run hands over the same cells), and writes their
+ * records: node [max_cells] (index in this handle's tree, where the cell stays a leaf flagged
+ * EHM_FR_REMOTE), vertices [.][p+1][p], sequence [.][N] (-1: the cell holds no commutation yet),
+ * vertex_costs [.][p+1], vertex_inputs [.][p+1][n_u], depth [.].
+ * ehm_frontier_give: the cells become ROOTS of this handle's forest (only before it has grown:
+ * after create / reset / add_root), with their depths, so ehm_frontier_opts.max_depth cuts the same
+ * cells in either handle; a cell with a sequence goes on with lcss from its record, one without
+ * starts with ecc.  The taker's tree, grafted onto the giver's EHM_FR_REMOTE leaves in the order
+ * of `node`, is the tree one handle would have grown (tests/test_gpu_frontier_native.py). */
+int ehm_frontier_pending(const ehm_frontier* f, int64_t* n_pending);
+int ehm_frontier_take(ehm_frontier* f, int64_t max_cells, int64_t* n_taken, int32_t* node,
+                      double* vertices, int32_t* sequence, double* vertex_costs,
+                      double* vertex_inputs, int32_t* depth);
+int ehm_frontier_give(ehm_frontier* f, int64_t n, const double* vertices, const int32_t* sequence,
+                      const double* vertex_costs, const double* vertex_inputs, const int32_t* depth);
+
 /* Node flags of the export. */
 #define EHM_FR_CLOSED     1   /* epsilon-suboptimal leaf                                       */
 #define EHM_FR_HAS_RECORD 2   /* holds a commutation, vertex costs and vertex inputs           */
@@ -175,6 +198,7 @@ int ehm_frontier_p_theta(ehm_frontier* f, int64_t n, const double* theta, double
 #define EHM_FR_PENDING    8   /* leaf not visited yet (a truncated run)                        */
 #define EHM_FR_NEEDS_ECC 16   /* with EHM_FR_OPEN: the cell has no record, the caller runs ecc */
 #define EHM_FR_DEPTH     32   /* open leaf: not bisected, the run's depth limit                */
+#define EHM_FR_REMOTE    64   /* leaf taken out by ehm_frontier_take: another handle grows it  */
 
 int ehm_frontier_sizes(const ehm_frontier* f, int64_t* n_nodes, int64_t* n_roots);
 /* vertices [n][p+1][p], left / right [n] (-1: leaf; the roots are nodes 0 .. n_roots-1, children

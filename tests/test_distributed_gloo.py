@@ -572,3 +572,79 @@ def test_claims_emulated_over_measured_root_times():
     # one slow root among many: whoever claims it keeps it, the others take the rest
     busy, ratio = distributed.emulate_claims([100.0] + [1.0] * 700, 8)
     assert max(busy) == 100.0 and ratio < 1.01
+
+
+def _worker_roots_stealing(rank, world, port, out_dir):
+    os.environ.update(RANK=str(rank), LOCAL_RANK=str(rank), WORLD_SIZE=str(world),
+                      MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port))
+    import pickle
+    import time
+    import torch.distributed as dist
+    from explicit_hybrid_mpc_amd import bnb, distributed, frontier
+    from explicit_hybrid_mpc_amd.tree import Tree, NodeData
+    from oracle import prefix_bb, geometry
+    distributed.init_process_group('gloo')
+    mpc = helpers.make_instance('pwa_small', 0)
+    eps_a = helpers.eps_a_rule(mpc, 0.25)
+    roots, locs = helpers.roots_of(mpc)
+    trees = [Tree(NodeData(vertices=np.array(R))) for R in roots]
+
+    def split_batch(R):
+        out = [geometry.split_along_longest_edge(r) for r in R]
+        return (np.array([o[0] for o in out]), np.array([o[1] for o in out]),
+                np.array([o[2] for o in out], dtype=np.int32))
+    solvers = frontier.TableSolvers(prefix_bb.CpuPrefixTable(mpc, eps_a, 0.2), split_batch)
+    nat = frontier.NativeFrontier(mpc, eps_a, 0.2, solvers=solvers)
+    slow = bnb.PrefixOracle(mpc, eps_a, 0.2, table=prefix_bb.CpuPrefixTable(mpc, eps_a, 0.2))
+    if rank == 1:
+        time.sleep(1.0)         # rank 0 claims the one batch that holds every root
+    trees, stats, counts = distributed.grow_roots_sharded(
+        slow, trees, 'ecc', deal='dynamic', native=nat, batch=len(roots), steal=True,
+        steal_slice=3, native_opts=dict(round_cap=2), handoff=False, split_batch=split_batch)
+    mine = {k: [(loc, nd.is_leaf(), nd.data.is_epsilon_suboptimal,
+                 getattr(nd.data, 'remote', False))
+                for nd, loc in trees[k].walk(locs[k])] for k in stats['mine']}
+    with open(os.path.join(out_dir, 'steal%d.pkl' % rank), 'wb') as f:
+        pickle.dump(dict(mine=mine, counts=counts, owned=stats['mine'],
+                         stats={k: v for k, v in stats.items() if k != 'mine'}), f)
+    nat.close()
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_an_idle_rank_takes_cells_from_a_busy_one(tmp_path):
+    """
+    deal='dynamic', steal=True (distributed.CellExchange on ehm_frontier_take / _give): rank 0
+    claims EVERY root in one batch, rank 1 finds none and asks; rank 0 answers between two slices
+    of its run with half of its pending cells, more than once; the sub-trees rank 1 grows return
+    and are attached to rank 0's trees, which must be the enumerating CPU partition -- no leaf
+    still marked remote, every leaf counted once over the two ranks.
+    """
+    import pickle
+    from oracle.oracle_cpu import OracleCPU
+    from oracle.partition_cpu import PartitionCPU
+    s = socket.socket()
+    s.bind(('127.0.0.1', 0))
+    port = s.getsockname()[1]
+    s.close()
+    mp.spawn(_worker_roots_stealing, args=(2, port, str(tmp_path)), nprocs=2, join=True)
+    outs = [pickle.load(open(str(tmp_path / ('steal%d.pkl' % r)), 'rb')) for r in range(2)]
+    mpc = helpers.make_instance('pwa_small', 0)
+    roots, locs = helpers.roots_of(mpc)
+    assert outs[0]['owned'] == list(range(len(roots))) and outs[1]['owned'] == []
+    s0, s1 = outs[0]['stats'], outs[1]['stats']
+    assert s0['parcels_given'] >= 2 and s1['cells_adopted'] >= 2
+    assert s0['subtrees_attached'] == s1['cells_adopted'] + s0['cells_adopted']
+    assert s1['regions'] > 0 and s0['regions'] > 0
+    cpu = PartitionCPU(OracleCPU(mpc, helpers.eps_a_rule(mpc, 0.25), 0.2))
+    cpu.run(roots, locs, 'ecc')
+    got = {}
+    for k, nodes in outs[0]['mine'].items():
+        for loc, leaf, closed, remote in nodes:
+            assert not remote, loc
+            got[loc] = (leaf, closed)
+    assert set(got) == set(cpu.nodes)
+    for loc, nd in cpu.nodes.items():
+        assert got[loc] == (nd['leaf'], nd['is_epsilon_suboptimal'])
+    closed = sum(1 for nd in cpu.nodes.values() if nd['leaf'] and nd['is_epsilon_suboptimal'])
+    assert s0['regions'] + s1['regions'] == closed

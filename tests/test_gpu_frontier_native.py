@@ -116,3 +116,72 @@ def test_two_handles_grow_different_roots_at_the_same_time():
             assert x.data.is_epsilon_suboptimal == y.data.is_epsilon_suboptimal
     for nat in nats:
         nat.close()
+
+
+def test_cells_move_between_two_device_handles():
+    """
+    ehm_frontier_take / ehm_frontier_give on the device tables: a handle that grows a configs[4]
+    Delaunay root is stopped after 3 000 visits, the shallowest half of its pending cells moves to
+    a second handle (own tables, own stream), the two finish AT THE SAME TIME from two threads, and
+    the merged tree (frontier.merge_taken) is the tree one handle grows alone.
+    """
+    import threading
+    from explicit_hybrid_mpc_amd import examples, frontier
+    from explicit_hybrid_mpc_amd import tools as ehm_tools
+    mpc = examples.pwa4_mpc(N=8, seed=0)
+    V = examples.box_vertices(examples.theta_box(mpc))
+    nats = [frontier.NativeFrontier(mpc, 1., 1., slots=4096) for _ in range(2)]
+    eps_a = max(j for _, _, j in nats[0].p_theta(0.2 * V))
+    for nat in nats:
+        nat.set_eps(eps_a, 1e-3)
+    roots, _ = ehm_tools.delaunay_roots(V)
+    a, b = nats
+    a.add_roots(roots[1:2])                      # 22.6 k regions
+    st0 = a.run()
+    ref = a.export()
+    a.reset()
+    a.add_roots(roots[1:2])
+    st = a.run(max_visits=3000)
+    assert st['truncated'] and a.pending() >= 4
+    cells = a.take(a.pending() // 2)
+    assert len(cells['node']) >= 2 and np.all(np.diff(cells['depth']) >= 0)
+    b.give(cells)
+    out, errs = {}, []
+
+    def work(name, nat):
+        try:
+            out[name] = nat.run()
+        except BaseException as e:
+            errs.append(e)
+    threads = [threading.Thread(target=work, args=(n, h)) for n, h in (('a', a), ('b', b))]
+    for t in threads:
+        t.start()
+    for t in threads:
+        t.join()
+    assert not errs, errs
+    assert out['a']['regions'] + out['b']['regions'] == st0['regions']
+    assert out['b']['regions'] > 0 and out['a']['open_cells'] == out['b']['open_cells'] == 0
+    merged = frontier.merge_taken(a.export(), cells, b.export())
+    assert merged['n_nodes'] == ref['n_nodes']
+
+    def by_location(flat):
+        loc, stack = {}, [(0, '')]
+        while stack:
+            k, name = stack.pop()
+            loc[name] = k
+            if flat['left'][k] >= 0:
+                stack.append((int(flat['left'][k]), name + '0'))
+                stack.append((int(flat['right'][k]), name + '1'))
+        return loc
+    lr, lm = by_location(ref), by_location(merged)
+    assert set(lr) == set(lm)
+    for name, k in lr.items():
+        j = lm[name]
+        assert np.array_equal(ref['vertices'][k], merged['vertices'][j]), name
+        assert ref['flags'][k] == merged['flags'][j], name
+        assert np.array_equal(ref['sequence'][k], merged['sequence'][j]), name
+        if ref['flags'][k] & frontier.FR_HAS_RECORD:
+            assert np.allclose(ref['vertex_costs'][k], merged['vertex_costs'][j],
+                               rtol=1e-7, atol=1e-7), name
+    for nat in nats:
+        nat.close()

@@ -329,3 +329,162 @@ def test_a_failed_round_poisons_the_handle_until_reset():
                                round_cap=7)
     assert sum(_same_trees(a, b) for a, b in zip(ref, got)) > 10
     nat.close()
+
+
+def _flat_nodes(flat):
+    """{location: node index} of a flat export (roots: their index as the first letter)."""
+    loc = {}
+    stack = [(r, 'r%d.' % r) for r in range(flat['n_roots'])]
+    while stack:
+        k, name = stack.pop()
+        loc[name] = k
+        if flat['left'][k] >= 0:
+            stack.append((int(flat['left'][k]), name + '0'))
+            stack.append((int(flat['right'][k]), name + '1'))
+    return loc
+
+
+@pytest.mark.parametrize('stop_after,share', [(4, 0.5), (9, 1.0), (1, 0.34)])
+def test_cells_taken_from_one_handle_and_given_to_another_grow_the_same_tree(stop_after, share):
+    """
+    ehm_frontier_take / ehm_frontier_give (lib/scheduler.py:498-599, 633-639: any worker grows any
+    leaf): a handle is stopped after a few visits, the shallowest of its pending cells -- some
+    hold a commutation, some still look for one -- move to a second handle, both run to the end,
+    and the two trees merged (frontier.merge_taken) are the tree one handle grows alone: same
+    nodes, same verdicts, same commutations and vertex costs.
+    """
+    mpc = helpers.make_instance('pwa_small', 0)
+    eps_a, eps_r = helpers.eps_a_rule(mpc, 0.25), 0.2
+    roots, _ = helpers.roots_of(mpc)
+
+    def handle():
+        table = prefix_bb.CpuPrefixTable(mpc, eps_a, eps_r)
+        return frontier.NativeFrontier(mpc, eps_a, eps_r,
+                                       solvers=frontier.TableSolvers(table, _host_split_batch))
+    alone = handle()
+    alone.add_roots(np.array(roots))
+    st0 = alone.run(round_cap=5)
+    ref = alone.export()
+    alone.close()
+
+    a, b = handle(), handle()
+    a.add_roots(np.array(roots))
+    st = a.run(round_cap=3, max_visits=stop_after)
+    assert st['truncated']
+    pending = a.pending()
+    assert pending >= 2
+    cells = a.take(max(1, int(round(share * pending))))
+    m = len(cells['node'])
+    assert a.pending() == pending - m
+    # shallowest first, and the giver keeps them as leaves flagged REMOTE
+    assert np.all(np.diff(cells['depth']) >= 0)
+    mid = a.export()
+    assert np.all(mid['flags'][cells['node']] & frontier.FR_REMOTE)
+    assert np.all(mid['left'][cells['node']] < 0)
+    # the records travel as plain arrays (what goes through the store between two ranks)
+    import pickle
+    cells = pickle.loads(pickle.dumps(cells))
+    b.give(cells)
+    assert b.pending() == m
+    st_a = a.run(round_cap=5)
+    st_b = b.run(round_cap=5)
+    assert not st_a['truncated'] and not st_b['truncated']
+    assert st_a['regions'] + st_b['regions'] == st0['regions']
+    fa, fb = a.export(), b.export()
+    assert np.all(fa['flags'][cells['node']] & frontier.FR_REMOTE)      # still leaves over there
+    merged = frontier.merge_taken(fa, cells, fb)
+    assert merged['n_nodes'] == ref['n_nodes'] and merged['n_roots'] == ref['n_roots']
+    lm, lr = _flat_nodes(merged), _flat_nodes(ref)
+    assert set(lm) == set(lr)
+    for name, k in lr.items():
+        j = lm[name]
+        assert np.array_equal(ref['vertices'][k], merged['vertices'][j]), name
+        assert (ref['left'][k] < 0) == (merged['left'][j] < 0), name
+        assert ref['flags'][k] == merged['flags'][j], name
+        assert np.array_equal(ref['sequence'][k], merged['sequence'][j]), name
+        if ref['flags'][k] & frontier.FR_HAS_RECORD:
+            assert np.allclose(ref['vertex_costs'][k], merged['vertex_costs'][j], atol=1e-12), name
+            assert np.allclose(ref['vertex_inputs'][k], merged['vertex_inputs'][j], atol=1e-9), name
+    # ... and it grafts into the reference's tree objects like any export
+    got = [Tree(NodeData(vertices=np.array(R))) for R in roots]
+    assert frontier.graft(merged, mpc, got) == []
+    assert sum(1 for t in got for nd, _ in t.walk() if nd.is_leaf() and
+               nd.data.is_epsilon_suboptimal) == st0['regions']
+    # a handle that has grown refuses cells; a cell with half a record is refused too
+    with pytest.raises(_capi.EhmError, match='grown already'):
+        a.give(cells)
+    b.reset()
+    bad = {k: v.copy() for k, v in cells.items()}
+    bad['sequence'][0, -1] = -1 if bad['sequence'][0, 0] >= 0 else 0
+    with pytest.raises(_capi.EhmError, match='bad mode sequence'):
+        b.give(bad)
+    a.close()
+    b.close()
+
+
+def test_handles_of_one_process_share_a_root_through_the_local_exchange():
+    """frontier.LocalExchange (bench.py --host-streams): three workers, ONE group of roots -- the
+    worker that claims it answers the other two between its slices; the attached tree is the tree
+    one handle grows."""
+    import threading
+    mpc = helpers.make_instance('pwa_small', 0)
+    eps_a, eps_r = helpers.eps_a_rule(mpc, 0.25), 0.2
+    roots, _ = helpers.roots_of(mpc)
+
+    def handle():
+        table = prefix_bb.CpuPrefixTable(mpc, eps_a, eps_r)
+        return frontier.NativeFrontier(mpc, eps_a, eps_r,
+                                       solvers=frontier.TableSolvers(table, _host_split_batch))
+    ref_nat = handle()
+    ref = [Tree(NodeData(vertices=np.array(R))) for R in roots]
+    st0 = frontier.grow_cells(ref_nat, ref, round_cap=4)
+    ref_nat.close()
+    nats = [handle() for _ in range(3)]
+    ex = frontier.LocalExchange(len(nats))
+    todo = [[Tree(NodeData(vertices=np.array(R))) for R in roots]]     # one group: one owner
+    lock = threading.Lock()
+    box = dict(given=[], adopted={}, regions=0, errors=[], owner=[])
+
+    def work(i):
+        try:
+            with lock:
+                part = todo.pop() if todo else None
+            if part is not None:
+                st = frontier.grow_cells(nats[i], part, round_cap=2, slice_visits=3,
+                                         between_slices=ex.serve)
+                with lock:
+                    box['owner'].append((i, part))
+                    box['given'] += [(pc['id'], leaves) for pc, leaves in st['given_away']]
+                    box['regions'] += st['regions']
+            while True:
+                parcel = ex.wait_for_work()
+                if parcel is None:
+                    return
+                sub = [Tree(NodeData(vertices=R.copy())) for R in parcel['vertices']]
+                st = frontier.grow_cells(nats[i], sub, cells=parcel, round_cap=2, slice_visits=3,
+                                         between_slices=ex.serve)
+                with lock:
+                    box['adopted'][parcel['id']] = dict(
+                        trees=sub, given=[(pc['id'], lv) for pc, lv in st['given_away']])
+                    box['regions'] += st['regions']
+        except BaseException as e:
+            box['errors'].append(e)
+    threads = [threading.Thread(target=work, args=(i,)) for i in range(3)]
+    for t in threads:
+        t.start()
+    for t in threads:
+        t.join()
+    assert not box['errors'], box['errors']
+    assert len(box['adopted']) >= 2 and box['regions'] == st0['regions']
+    n = frontier.attach_adopted(box['given'], box['adopted'])
+    assert n == sum(len(a['trees']) for a in box['adopted'].values())
+    got = box['owner'][0][1]
+    assert sum(_same_trees(a, b) for a, b in zip(ref, got)) == st0['n_nodes']
+    assert not any(getattr(nd.data, 'remote', False) for t in got for nd, _ in t.walk())
+    # a parcel nobody grew is an error unless the caller asks for the list
+    with pytest.raises(KeyError):
+        frontier.attach_adopted([(999, [])], {})
+    left = []
+    assert frontier.attach_adopted([(999, [got[0]])], {}, left) == 0 and left == [got[0]]
+    for nat in nats:
+        nat.close()
