@@ -648,3 +648,54 @@ def test_an_idle_rank_takes_cells_from_a_busy_one(tmp_path):
         assert got[loc] == (nd['leaf'], nd['is_epsilon_suboptimal'])
     closed = sum(1 for nd in cpu.nodes.values() if nd['leaf'] and nd['is_epsilon_suboptimal'])
     assert s0['regions'] + s1['regions'] == closed
+
+
+def test_cell_exchange_protocol_over_a_store():
+    """distributed.CellExchange on a HashStore, three 'ranks' as threads: rank 0 holds 40 units of
+    work and serves between units; ranks 1 and 2 start idle and ask.  Every unit is done exactly
+    once, takers serve each other too, and everybody leaves once all are idle with nothing on its
+    way."""
+    import threading
+    import time
+    import torch.distributed as dist
+    from explicit_hybrid_mpc_amd import distributed
+    store = dist.HashStore()
+    world = 3
+    done, errors = [], []
+    lock = threading.Lock()
+
+    def rank_main(rank):
+        try:
+            ex = distributed.CellExchange(store, rank, world, key='t/cells', poll=0.0005)
+            work = list(range(40)) if rank == 0 else []
+
+            def take():
+                if len(work) < 2:
+                    return None
+                half = [work.pop() for _ in range(len(work) // 2)]
+                return dict(node=np.array(half))
+
+            while True:
+                while work:
+                    unit = work.pop()
+                    time.sleep(0.002)
+                    with lock:
+                        done.append((rank, unit))
+                    ex.serve(take)
+                parcel = ex.wait_for_work()
+                if parcel is None:
+                    return
+                assert parcel['id'][0] != rank
+                work.extend(int(u) for u in parcel['node'])
+        except BaseException as e:
+            errors.append(e)
+    threads = [threading.Thread(target=rank_main, args=(r,)) for r in range(world)]
+    for t in threads:
+        t.start()
+    for t in threads:
+        t.join(timeout=60)
+    assert not errors, errors
+    assert not any(t.is_alive() for t in threads)
+    assert sorted(u for _, u in done) == list(range(40))
+    assert {r for r, _ in done} == {0, 1, 2}              # everybody got some
+    assert int(store.add('t/cells/idle', 0)) == world
