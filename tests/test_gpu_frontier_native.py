@@ -185,3 +185,74 @@ def test_cells_move_between_two_device_handles():
                                rtol=1e-7, atol=1e-7), name
     for nat in nats:
         nat.close()
+
+
+def _rank_shares_a_device_root(rank, world, port, out_dir):
+    import os
+    import pickle
+    import time
+    os.environ.update(RANK=str(rank), LOCAL_RANK=str(rank), WORLD_SIZE=str(world),
+                      MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port))
+    import torch.distributed as dist
+    from explicit_hybrid_mpc_amd import distributed, examples, frontier
+    from explicit_hybrid_mpc_amd import tools as ehm_tools
+    from explicit_hybrid_mpc_amd.tree import NodeData, Tree
+    distributed.init_process_group('gloo')          # both ranks on the one GPU of the box
+    mpc = examples.pwa4_mpc(N=8, seed=0)
+    V = examples.box_vertices(examples.theta_box(mpc))
+    nat = frontier.NativeFrontier(mpc, 1., 1., slots=4096)
+    eps_a = max(j for _, _, j in nat.p_theta(0.2 * V))
+    nat.set_eps(eps_a, 1e-3)
+    roots, _ = ehm_tools.delaunay_roots(V)
+    alone = None
+    if rank == 0:
+        t = Tree(NodeData(vertices=roots[2].copy()))
+        frontier.grow_cells(nat, t)
+        alone = [(loc, nd.is_leaf(), bool(nd.data.is_epsilon_suboptimal)) for nd, loc in t.walk()]
+    dist.barrier()
+    if rank == 1:
+        time.sleep(0.5)             # rank 0 claims the only root
+    trees = [Tree(NodeData(vertices=roots[2].copy()))]
+    trees, stats, counts = distributed.grow_roots_sharded(
+        None, trees, 'ecc', deal='dynamic', native=nat, steal=True, steal_slice=256,
+        claim_key='share_one_root')
+    got = [(loc, nd.is_leaf(), bool(nd.data.is_epsilon_suboptimal),
+            bool(getattr(nd.data, 'remote', False))) for nd, loc in trees[0].walk()] \
+        if stats['mine'] else None
+    with open(os.path.join(out_dir, 'share%d.pkl' % rank), 'wb') as f:
+        pickle.dump(dict(alone=alone, got=got, counts=counts,
+                         stats={k: v for k, v in stats.items() if k != 'mine'},
+                         mine=stats['mine']), f)
+    nat.close()
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_two_ranks_share_one_root_on_the_device(tmp_path):
+    """
+    distributed.grow_roots_sharded(deal='dynamic', steal=True) with DEVICE handles: two processes
+    (gloo; they share the box's one GPU), ONE configs[4] root.  Rank 0 claims it, rank 1 asks for
+    cells through the store, grows them on its own tables and sends the sub-trees back; rank 0's
+    tree is the tree it grows alone.
+    """
+    import pickle
+    import socket
+    import torch.multiprocessing as mp
+    s = socket.socket()
+    s.bind(('127.0.0.1', 0))
+    port = s.getsockname()[1]
+    s.close()
+    mp.spawn(_rank_shares_a_device_root, args=(2, port, str(tmp_path)), nprocs=2, join=True)
+    outs = [pickle.load(open(str(tmp_path / ('share%d.pkl' % r)), 'rb')) for r in range(2)]
+    assert outs[0]['mine'] == [0] and outs[1]['mine'] == []
+    s0, s1 = outs[0]['stats'], outs[1]['stats']
+    assert s0['parcels_given'] >= 1 and s1['cells_adopted'] >= 1 and s1['regions'] > 0
+    assert s0['subtrees_attached'] == s1['cells_adopted'] + s0['cells_adopted']
+    alone = {loc: (leaf, closed) for loc, leaf, closed in outs[0]['alone']}
+    got = {}
+    for loc, leaf, closed, remote in outs[0]['got']:
+        assert not remote, loc
+        got[loc] = (leaf, closed)
+    assert got == alone
+    assert s0['regions'] + s1['regions'] == sum(1 for leaf, closed in alone.values()
+                                                if leaf and closed)
