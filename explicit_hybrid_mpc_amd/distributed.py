@@ -517,6 +517,7 @@ class CellExchange:
       idle             counter: ranks that are idle AND have no parcel on its way to them
       req/<v>          counter: requests addressed to rank v;  req/<v>/<t> = b"<requester>:<n>"
       box/<r>/<n>      the answer to rank r's n-th request: a pickled parcel, or None
+      failed           counter: ranks whose driver raised (``fail``); a waiting rank raises too
     A giver lowers ``idle`` on the taker's behalf BEFORE it posts a non-empty parcel, so
     ``idle == world`` can only be seen when no work exists anywhere.
     """
@@ -553,6 +554,11 @@ class CellExchange:
             self.store.set(self._k('box', who, n), pickle.dumps(parcel))
         return out
 
+    def fail(self):
+        """This rank gives up (its driver raised): the others must not wait for it."""
+        self.store.add(self._k('failed'), 1)
+        self.serve(lambda: None)
+
     def _ask(self):
         self._victim = (self._victim + 1) % self.world
         if self._victim == self.rank:
@@ -581,6 +587,8 @@ class CellExchange:
                 empty += 1
                 if empty % (self.world - 1):
                     continue            # the next rank may still hold work: ask at once
+            if int(self.store.add(self._k('failed'), 0)) > 0:
+                raise RuntimeError('another rank failed while this one was waiting for cells')
             if int(self.store.add(self._k('idle'), 0)) >= self.world:
                 return None
             time.sleep(self.poll)
@@ -651,15 +659,15 @@ def grow_roots_sharded(oracle, roots, action='ecc', device=None, deal='static', 
     stats = dict(host_visits=0, rounds=0, truncated=False, regions=0)
     if deal == 'dynamic':
         mine = []
-        for ks in claim_roots(len(roots), batch=batch, key=claim_key):
-            st = grow([roots[k] for k in ks])
-            mine += ks
-            tally(st)
-            given += st.get('given', [])
-        if exchange is not None:
-            from .tree import NodeData, Tree
-            adopted = []
-            while True:
+        adopted = []
+        try:
+            for ks in claim_roots(len(roots), batch=batch, key=claim_key):
+                st = grow([roots[k] for k in ks])
+                mine += ks
+                tally(st)
+                given += st.get('given', [])
+            while exchange is not None:
+                from .tree import NodeData, Tree
                 parcel = exchange.wait_for_work()
                 if parcel is None:
                     break
@@ -667,6 +675,13 @@ def grow_roots_sharded(oracle, roots, action='ecc', device=None, deal='static', 
                 st = grow(trees, cells=parcel)
                 tally(st)
                 adopted.append(dict(id=parcel['id'], trees=trees, given=st['given']))
+        except BaseException:
+            # the ranks that wait for cells (now or later) leave with an error of their own
+            # instead of waiting for this rank to become idle
+            if exchange is not None:
+                exchange.fail()
+            raise
+        if exchange is not None:
             stats['cells_adopted'] = sum(len(a['trees']) for a in adopted)
             stats['parcels_given'] = exchange.given
             everybody = [None] * world

@@ -699,3 +699,37 @@ def test_cell_exchange_protocol_over_a_store():
     assert sorted(u for _, u in done) == list(range(40))
     assert {r for r, _ in done} == {0, 1, 2}              # everybody got some
     assert int(store.add('t/cells/idle', 0)) == world
+
+
+def test_cell_exchange_a_failing_rank_releases_the_waiting_ones():
+    """A rank whose driver raises calls CellExchange.fail(): the ranks that wait for cells raise too
+    instead of waiting for it to become idle."""
+    import threading
+    import time
+    import torch.distributed as dist
+    from explicit_hybrid_mpc_amd import distributed
+    store = dist.HashStore()
+    world = 3
+    outcome = {}
+
+    def rank_main(rank):
+        ex = distributed.CellExchange(store, rank, world, key='f/cells', poll=0.0005)
+        try:
+            if rank == 0:
+                for _ in range(5):
+                    time.sleep(0.01)
+                    ex.serve(lambda: None)          # busy, nothing to give yet
+                ex.fail()
+                outcome[rank] = 'failed'
+                return
+            outcome[rank] = ex.wait_for_work()
+        except RuntimeError as e:
+            outcome[rank] = str(e)
+    threads = [threading.Thread(target=rank_main, args=(r,)) for r in range(world)]
+    for t in threads:
+        t.start()
+    for t in threads:
+        t.join(timeout=30)
+    assert not any(t.is_alive() for t in threads)
+    assert outcome[0] == 'failed'
+    assert 'another rank failed' in outcome[1] and 'another rank failed' in outcome[2]
