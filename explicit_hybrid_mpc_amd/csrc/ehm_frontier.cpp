@@ -20,6 +20,7 @@
 #include <cmath>
 #include <cstdarg>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <limits>
 #include <memory>
@@ -731,6 +732,9 @@ struct __attribute__((visibility("hidden"))) ehm_frontier {
     std::vector<double> opt_J, opt_u;
     ehm_frontier_stats st{};
     int32_t max_depth = 0;                      // of the run in progress (0 = none)
+    // EHM_FR_TALLY=1: slack problems asked by caller, printed at the end of a run (diagnostics)
+    int64_t tally_seed = 0, tally_bar_e = 0, tally_bar_d = 0, tally_cells_e = 0, tally_cells_d = 0,
+            tally_closed = 0;
     int64_t base_ctr[5] = {0, 0, 0, 0, 0};      // the device solver's counters at the last reset
 
     int64_t n_nodes() const { return (int64_t)left.size(); }
@@ -1352,6 +1356,7 @@ void ehm_frontier::bar_d(const std::vector<int32_t>& O, std::vector<Learned>& le
     const size_t n = O.size();
     if (!n) return;
     st.calls_bar_d += (int64_t)n;
+    tally_cells_d += (int64_t)n;
     struct Search {
         int phase = 1;
         PrefixHeap heap;
@@ -1458,6 +1463,7 @@ void ehm_frontier::bar_d(const std::vector<int32_t>& O, std::vector<Learned>& le
         }
         if (!ask_code.empty()) {
             std::vector<double> t, al;
+            tally_bar_d += (int64_t)ask_code.size();
             slack_pairs(ask_code, ask_node, t, &al);
             for (size_t a = 0; a < ask_code.size(); ++a) {
                 Search& q = sr[ask_at[a].first];
@@ -1657,6 +1663,7 @@ void ehm_frontier::lcss_round(const std::vector<int32_t>& Lc, int launch_target,
     if (!n) return;
     st.calls_bar_e += (int64_t)n;
     st.lcss_visits += (int64_t)n;
+    tally_cells_e += (int64_t)n;
     alpha_pool.clear();
     std::vector<double> guard(n);
     for (size_t j = 0; j < n; ++j) {
@@ -1697,6 +1704,7 @@ void ehm_frontier::lcss_round(const std::vector<int32_t>& Lc, int launch_target,
             }
         if (!ic.empty()) {
             std::vector<double> t, al;
+            tally_seed += (int64_t)ic.size();
             slack_pairs(ic, in, t, &al);
             for (size_t q = 0; q < ic.size(); ++q) {
                 const int64_t at = (int64_t)(alpha_pool.size() / nv);
@@ -1720,6 +1728,7 @@ void ehm_frontier::lcss_round(const std::vector<int32_t>& Lc, int launch_target,
         codes.resize((size_t)n_ask); owner.resize((size_t)n_ask); node_of.resize((size_t)n_ask);
         chk_search(ehm_search_bare_asks(Bq, codes.data(), owner.data()), "ehm_search_bare_asks");
         for (int64_t a = 0; a < n_ask; ++a) node_of[(size_t)a] = Lc[owner[(size_t)a]];
+        tally_bar_e += (int64_t)codes.size();
         slack_pairs(codes, node_of, t, nullptr);
         chk_search(ehm_search_bare_answer(Bq, t.data(), &left_n), "ehm_search_bare_answer");
     }
@@ -1797,6 +1806,12 @@ void ehm_frontier::run(const ehm_frontier_opts& o) {
     }
     st.n_nodes = n_nodes();
     st.seconds_total += now() - t0;
+    if (const char* e = std::getenv("EHM_FR_TALLY"))
+        if (e[0] == '1')
+            std::fprintf(stderr, "ehm_frontier tally: lcss cells %lld (slack problems: incumbent seeds %lld, "
+                         "bar_E search %lld), bar_D cells %lld (slack problems %lld), regions %lld\n",
+                         (long long)tally_cells_e, (long long)tally_seed, (long long)tally_bar_e,
+                         (long long)tally_cells_d, (long long)tally_bar_d, (long long)st.regions);
     if (dev) {                                  // since the last reset
         st.lp_solves = dev->total_lp() - base_ctr[0];
         st.launches = dev->launches - base_ctr[1];

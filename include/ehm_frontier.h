@@ -156,7 +156,10 @@ typedef struct ehm_frontier_stats {
  * A call that FAILS inside a round (a solver error, EHM_E_NUMERIC, out of memory) leaves the handle
  * poisoned: the cells of that round are in no work list any more, so run / p_theta / add_root /
  * export answer EHM_E_INVALID ("reset first") until ehm_frontier_reset -- never a silently
- * incomplete tree. */
+ * incomplete tree.
+ * Environment EHM_FR_TALLY=1: the slack problems asked so far by caller (incumbent seeds, the
+ * suboptimality test's search, bar_D's search) go to stderr at the end of every call -- diagnostics
+ * (tools/c5_tally.py). */
 int ehm_frontier_run(ehm_frontier* f, const ehm_frontier_opts* opts, ehm_frontier_stats* stats);
 
 /* Oracle.P_theta (lib/oracle.py:104-139) at n parameters ([n][p]) in lockstep: J [n] (+inf: no mode
