@@ -10,7 +10,7 @@ law, oracle/milp_check.py):
   indicators) is infeasible;
 * closed leaves: vertex costs = the uncondensed fixed-sequence LP; where the commutation was
   adopted at the cell it is the lexicographic minimum of V_R's MILP; bar_E's MILP has max t < 0;
-* an lcss split (round 6): bar_E's MILP has max t >= 0 (the largest over big-M 50 / 10 / 200 -- any
+* three lcss splits (round 6): bar_E's MILP has max t >= 0 (the largest over big-M 50 / 10 / 200 -- any
   run's point is feasible for the reference's problem, so that is a certified lower bound), the
   children are the longest-edge bisection and hold the node's commutation or bar_D's optimum --
   compared tie-aware: a child's sequence is also accepted where it is feasible at every vertex
@@ -52,12 +52,13 @@ def test_nodes_of_a_native_tree_against_one_milp_per_oracle_call():
     own_leaves = [i for i, (nd, loc) in enumerate(nodes) if nd.is_leaf() and
                   (loc == '' or not has[loc[:-1]])]
     lcss_splits = [i for i, (nd, loc) in enumerate(nodes) if not nd.is_leaf() and has[loc]]
-    assert len(lcss_splits) >= 2
+    assert len(lcss_splits) >= 3
     picks = list(rng.choice(ecc_splits, 3, replace=False)) + \
         list(rng.choice(own_leaves, 2, replace=False)) + \
-        list(rng.choice(lcss_splits, 1, replace=False))     # (~3 min of HiGHS per lcss split)
+        list(rng.choice(lcss_splits, 3, replace=False))     # (~3 min of HiGHS per lcss split)
     seq_of = lambda d: tuple(int(i) for i in np.asarray(d).reshape(mpc.N, mpc.delta_size).argmax(1))
     nv, p = roots.shape[1], roots.shape[2]
+    jobs, meta = [], []
     for k, i in enumerate(picks):
         nd, loc = nodes[i]
         d = nd.data
@@ -73,7 +74,16 @@ def test_nodes_of_a_native_tree_against_one_milp_per_oracle_call():
                np.full((2, nv, p), np.nan) if leaf else
                np.array([np.asarray(c.data.vertices) for c in (nd.left, nd.right)]),
                kids_seq, eps_a, c5.EPS_R)
-        res = c5._check_one(job)
+        jobs.append(job)
+        meta.append((loc, kind, leaf))
+    # the checks are independent CPU work (HiGHS; the device handle is closed): one process each,
+    # the lcss splits -- minutes of branch and bound each -- first
+    import multiprocessing as mp
+    order = sorted(range(len(jobs)), key=lambda k: -jobs[k][1])
+    with mp.get_context('fork').Pool(min(len(jobs), os.cpu_count() or 1)) as pool:
+        results = pool.map(c5._check_one, [jobs[k] for k in order], chunksize=1)
+    for k, res in zip(order, results):
+        loc, kind, leaf = meta[k]
         assert res['ok'] and not res['routed'], (loc, kind, res['notes'])
         if leaf:
             assert res['t_max'] < 0. and res['max_cost_diff'] <= 1e-7
